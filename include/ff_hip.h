@@ -1,0 +1,305 @@
+/* ff_hip.h -- C-ABI of the MI355X-native DLRM operator kernels.
+ *
+ * This is the drop-in boundary for the DLRM training hot path of
+ * facebookresearch/DLRM-FlexFlow.  Every entry point replaces one of the
+ * reference's static `X::forward_kernel / backward_kernel` members (the tier
+ * that its Legion task wrappers, FusedOp and the simulator all call with raw
+ * device pointers, integer dims and a stream -- SURVEY.md section 8b).  The
+ * reference interface each function replaces is cited as
+ * `[ref: file:line]` (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - POD arguments only: raw device pointers, sizes, enum values as int
+ *    (values identical to the reference's include/ffconst.h:4-57), a stream
+ *    as `void*` (a hipStream_t).  No C++/torch types cross this boundary.
+ *  - Every tensor is a flat row-major buffer with the batch outermost
+ *    (Legion dims reversed, [ref: src/runtime/model.cc:865-868]).  Where a
+ *    function takes a leading dimension (`ld*`, in elements) the operand may
+ *    be a column slice of a wider buffer (e.g. an embedding output living
+ *    inside the concat buffer); `ld == row width` gives the reference's dense
+ *    layout.
+ *  - All compute entry points are asynchronous on the caller's stream, never
+ *    synchronise, never allocate; scratch comes from the workspace the caller
+ *    attached to the ctx (the reference's FFHandler.workSpace,
+ *    [ref: include/config.h:75-84]).
+ *  - Return value: 0 (FFH_OK) or a negative FFH_ERR_*; the text of the last
+ *    error on a ctx is available from ffh_last_error_string().  The library
+ *    never exits or asserts across the ABI (the reference's
+ *    checkCUDA/assert abort behaviour, [ref: include/cuda_helper.h:6-47], is
+ *    re-created by the C++ FFModel shim on a non-zero return).
+ *  - A ctx is bound to one device and is not thread-safe; different ctxs are
+ *    independent.
+ *
+ * Two libraries export this ABI:
+ *   dlrm_flexflow_amd/csrc  -> libffhip.so     the product (hand-written gfx950 HIP)
+ *   oracle/                 -> libffh_oracle.so test-only CPU restatement of the
+ *                                               reference arithmetic ("device"
+ *                                               pointers are host pointers)
+ * Only tests, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * the second one.
+ */
+#ifndef FF_HIP_H_
+#define FF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFH_ABI_VERSION 1
+
+/* status codes */
+#define FFH_OK               0
+#define FFH_ERR_BAD_ARG     (-1)
+#define FFH_ERR_HIP         (-2)
+#define FFH_ERR_UNSUPPORTED (-3)
+#define FFH_ERR_WORKSPACE   (-4)
+#define FFH_ERR_NOMEM       (-5)
+
+/* enum values, identical to [ref: include/ffconst.h:4-57] */
+#define FFH_AC_MODE_NONE     10
+#define FFH_AC_MODE_RELU     11
+#define FFH_AC_MODE_SIGMOID  12
+#define FFH_AC_MODE_TANH     13
+#define FFH_AC_MODE_GELU     14
+#define FFH_AGGR_MODE_NONE   20
+#define FFH_AGGR_MODE_SUM    21
+#define FFH_AGGR_MODE_AVG    22
+
+/* limits */
+#define FFH_MAX_TABLES        64   /* tables per batched embedding launch        */
+#define FFH_MAX_CONCAT_INPUTS 256  /* [ref: include/config.h:30-37 MAX_NUM_INPUTS] */
+/* chunk length of the canonical summation order of the fused
+ * embedding backward + SGD (see ffh_embedding_bwd_sgd_fused) */
+#define FFH_EMB_CHUNK         128
+
+typedef struct ffh_ctx ffh_ctx;   /* opaque; mirrors FFHandler [ref: include/config.h:75-84] */
+typedef void* ffh_stream;         /* hipStream_t */
+typedef void* ffh_event;          /* hipEvent_t  */
+typedef void* ffh_graph;          /* hipGraphExec_t */
+
+/* PerfMetrics subset kept on the device [ref: include/metrics_functions.h, src/metrics_functions/metrics_functions.cu:108-173] */
+typedef struct ffh_perf_metrics {
+  int32_t train_all;
+  int32_t train_correct;
+  float   cce_loss;
+  float   sparse_cce_loss;
+  float   mse_loss;
+  float   rmse_loss;
+  float   mae_loss;
+  int32_t pad_;
+} ffh_perf_metrics;
+
+typedef struct ffh_device_info {
+  char     name[128];
+  char     arch[64];
+  int32_t  compute_units;
+  int32_t  wavefront_size;
+  int64_t  total_mem_bytes;
+  int32_t  lds_bytes_per_cu;
+  int32_t  clock_khz;
+} ffh_device_info;
+
+/* One table of a batched (multi-table) embedding launch. */
+typedef struct ffh_emb_table {
+  const int64_t* idx;     /* [batch][in_dim] int64 row ids                            */
+  float*         weight;  /* [num_entries][out_dim] fp32 table                        */
+  float*         io;      /* fwd: out [batch][ld]; bwd: out_grad [batch][ld] (read)   */
+  int64_t        num_entries;
+  int64_t        ld;      /* leading dimension of `io` in floats (>= out_dim)         */
+} ffh_emb_table;
+
+/* ------------------------------------------------------------------ */
+/* library / context                                                  */
+/* ------------------------------------------------------------------ */
+int         ffh_abi_version(void);
+const char* ffh_backend_name(void);                 /* "hip-gfx950" | "oracle-cpu" */
+int         ffh_ctx_create(ffh_ctx** out, int device);
+int         ffh_ctx_destroy(ffh_ctx* ctx);
+const char* ffh_last_error_string(const ffh_ctx* ctx);
+int         ffh_device_query(ffh_ctx* ctx, ffh_device_info* info);
+/* attach caller-owned scratch; replaces FFHandler.workSpace/workSpaceSize */
+int         ffh_ctx_set_workspace(ffh_ctx* ctx, void* ws, size_t bytes);
+
+/* memory / streams / events / graphs: what Legion+Realm provide to the
+ * reference ops (regions, get_legion_stream [ref: src/runtime/cuda_helper.cu:5-31],
+ * begin_trace/end_trace [ref: examples/cpp/DLRM/dlrm.cc:174-181]). */
+int ffh_malloc(ffh_ctx* ctx, void** ptr, size_t bytes);
+int ffh_free(ffh_ctx* ctx, void* ptr);
+int ffh_memcpy_h2d(ffh_ctx* ctx, void* dst, const void* src, size_t bytes, ffh_stream s);
+int ffh_memcpy_d2h(ffh_ctx* ctx, void* dst, const void* src, size_t bytes, ffh_stream s);
+int ffh_memcpy_d2d(ffh_ctx* ctx, void* dst, const void* src, size_t bytes, ffh_stream s);
+int ffh_stream_create(ffh_ctx* ctx, ffh_stream* s);
+int ffh_stream_destroy(ffh_ctx* ctx, ffh_stream s);
+int ffh_stream_sync(ffh_ctx* ctx, ffh_stream s);
+int ffh_device_sync(ffh_ctx* ctx);
+int ffh_event_create(ffh_ctx* ctx, ffh_event* e);
+int ffh_event_destroy(ffh_ctx* ctx, ffh_event e);
+int ffh_event_record(ffh_ctx* ctx, ffh_event e, ffh_stream s);
+int ffh_event_sync(ffh_ctx* ctx, ffh_event e);
+int ffh_stream_wait_event(ffh_ctx* ctx, ffh_stream s, ffh_event e);
+int ffh_event_elapsed_ms(ffh_ctx* ctx, ffh_event start, ffh_event stop, float* ms);
+int ffh_graph_begin_capture(ffh_ctx* ctx, ffh_stream s);
+int ffh_graph_end_capture(ffh_ctx* ctx, ffh_stream s, ffh_graph* g);
+int ffh_graph_launch(ffh_ctx* ctx, ffh_graph g, ffh_stream s);
+int ffh_graph_destroy(ffh_ctx* ctx, ffh_graph g);
+
+/* ------------------------------------------------------------------ */
+/* initialisers and synthetic data (counter-based, seeded, bit-exact    */
+/* between the two backends; see DESIGN.md "RNG")                       */
+/* ------------------------------------------------------------------ */
+/* assign_kernel [ref: src/runtime/cuda_helper.cu:52-60]; ZeroInitializer
+ * [ref: src/runtime/initializer_kernel.cu:209-241] is value = 0 */
+int ffh_fill_f32(ffh_ctx* ctx, float* ptr, int64_t count, float value, ffh_stream s);
+int ffh_zero(ffh_ctx* ctx, void* ptr, size_t bytes, ffh_stream s);
+/* UniformInitializer [ref: src/runtime/initializer_kernel.cu:24-98] (own stream, not cuRAND's):
+ * ptr[i] = lo + (hi-lo) * u24(seed, i) */
+int ffh_init_uniform(ffh_ctx* ctx, float* ptr, int64_t count, uint64_t seed, float lo, float hi, ffh_stream s);
+/* synthetic DLRM inputs, distributions of [ref: examples/cpp/DLRM/dlrm.cc:413-420]:
+ * idx[i] = hash(seed, first + i) mod num_entries; dense = u24 in [0,1); label in {0,1} */
+int ffh_gen_indices(ffh_ctx* ctx, int64_t* idx, int64_t count, uint64_t seed, int64_t first, int64_t num_entries, ffh_stream s);
+int ffh_gen_uniform01(ffh_ctx* ctx, float* ptr, int64_t count, uint64_t seed, int64_t first, ffh_stream s);
+int ffh_gen_bernoulli(ffh_ctx* ctx, float* ptr, int64_t count, uint64_t seed, int64_t first, ffh_stream s);
+
+/* ------------------------------------------------------------------ */
+/* Embedding                                                          */
+/* ------------------------------------------------------------------ */
+/* Embedding::forward_kernel [ref: include/model.h:1169-1177, src/ops/embedding.cu:219-231,166-190]
+ * out[b][d] = sum_{j<in_dim} weight[idx[b][j]][d], j ascending, fp32, starting from +0.
+ * aggr: FFH_AGGR_MODE_SUM, or FFH_AGGR_MODE_AVG (true mean: sum * (1/in_dim); the
+ * reference's AVG divides inside the j loop, a bug not reproduced -- SURVEY 8a-1).
+ * Row ids must satisfy 0 <= idx < num_entries (CPU reference asserts it,
+ * [ref: src/ops/embedding.cc:71-73]); out-of-range ids are not checked on the device. */
+int ffh_embedding_fwd(ffh_ctx* ctx, const int64_t* idx, float* out, const float* weight,
+                      int in_dim, int out_dim, int64_t batch, int64_t num_entries,
+                      int64_t out_ld, int aggr, ffh_stream s);
+/* the same for n tables in one launch (tables[i].io = out) */
+int ffh_embedding_fwd_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int ntables,
+                            int in_dim, int out_dim, int64_t batch, int aggr, ffh_stream s);
+
+/* Embedding::backward_kernel [ref: include/model.h:1178-1186, src/ops/embedding.cu:308-320,192-217]
+ * weight_grad[idx[b][j]][d] += out_grad[b][d] (AVG: / in_dim) with fp32 atomics into the
+ * dense, pre-zeroed full-table gradient -- the reference's own backward. */
+int ffh_embedding_bwd_dense(ffh_ctx* ctx, const int64_t* idx, const float* out_grad, float* weight_grad,
+                            int in_dim, int out_dim, int64_t batch, int64_t num_entries,
+                            int64_t grad_ld, int aggr, ffh_stream s);
+
+/* Fused embedding backward + SGD: the net effect of
+ *   Op::zero_grad            [ref: src/runtime/model.cc:466-490]
+ *   Embedding::backward_kernel [ref: src/ops/embedding.cu:192-217]
+ *   sgd_update (momentum 0, weight_decay 0) [ref: src/runtime/optimizer_kernel.cu:23-41]
+ * on one table, without the dense gradient:
+ *   weight[r][:] -= lr * sum_{(b,j): idx[b][j]==r} out_grad[b][:]      (rows not hit: untouched)
+ * Canonical (deterministic) summation order: contributions of a row sorted by position
+ * p = b*in_dim+j ascending; the table's sorted (row,p) list is cut at multiples of
+ * FFH_EMB_CHUNK; inside a chunk the row's contributions are added left to right in fp32;
+ * a row whose run crosses chunk boundaries adds its per-chunk partial sums left to right;
+ * then one `w = w - lr*sum` (fp32 multiply, fp32 subtract).
+ * Needs ffh_embedding_bwd_workspace_bytes() of workspace attached to the ctx. */
+int ffh_embedding_bwd_sgd_fused(ffh_ctx* ctx, const int64_t* idx, const float* out_grad, float* weight,
+                                int in_dim, int out_dim, int64_t batch, int64_t num_entries,
+                                int64_t grad_ld, int aggr, float lr, ffh_stream s);
+int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int ntables,
+                                      int in_dim, int out_dim, int64_t batch, int aggr, float lr, ffh_stream s);
+size_t ffh_embedding_bwd_workspace_bytes(int ntables, int in_dim, int out_dim, int64_t batch);
+
+/* ------------------------------------------------------------------ */
+/* Linear                                                             */
+/* ------------------------------------------------------------------ */
+/* Linear::forward_kernel [ref: include/model.h:1011-1017, src/ops/linear.cu:425-465]
+ * y[b][o] = act( sum_i x[b][i]*w[o][i] + bias[o] ); bias may be NULL; fp32 throughout
+ * (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32). activation: NONE, RELU, SIGMOID (GELU/TANH: unsupported). */
+int ffh_linear_fwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy,
+                   const float* w, const float* bias,
+                   int in_dim, int out_dim, int64_t batch, int activation, ffh_stream s);
+/* Linear::backward_kernel [ref: include/model.h:1018-1027, src/ops/linear.cu:610-660]
+ * in place: dy = dy * act'(y)   (relu: y>0 ? dy : 0 [ref: src/runtime/cuda_helper.cu:71-78];
+ *                                sigmoid: dy*y*(1-y) [ref: src/ops/linear.cu:600-607])
+ * dw[o][i] += sum_b dy[b][o]*x[b][i];  db[o] += sum_b dy[b][o] (db may be NULL);
+ * dx[b][i] += sum_o dy[b][o]*w[o][i]   (dx may be NULL: first layer, gradient discarded).
+ * All three accumulate (beta = 1) into buffers the caller zeroed, exactly as the reference. */
+int ffh_linear_bwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                   const float* y, int64_t ldy, float* dy, int64_t lddy,
+                   const float* w, float* dw, float* db,
+                   int in_dim, int out_dim, int64_t batch, int activation, ffh_stream s);
+
+/* ------------------------------------------------------------------ */
+/* Concat                                                             */
+/* ------------------------------------------------------------------ */
+/* Concat::forward_kernel [ref: include/model.h:1771-1777, src/ops/concat.cu:211-249] with the
+ * Domain arguments flattened the way calc_blk_size does [ref: src/ops/concat.cu:194-208]:
+ * for every block blk < num_blocks: out[blk*out_blk + off_i + e] = in_i[blk*in_ld[i] + e],
+ * e < in_blk[i], off_i = sum_{i'<i} in_blk[i'].  in_ld may be NULL (= in_blk).  One launch
+ * for all inputs (the reference launches copy_with_stride once per input,
+ * [ref: src/runtime/cuda_helper.cu:128-144]).  An input whose pointer already is
+ * out + off_i with in_ld[i] == out_blk is skipped (aliased producer). */
+int ffh_concat_fwd(ffh_ctx* ctx, float* out, int64_t out_blk, const float* const* ins,
+                   const int64_t* in_blk, const int64_t* in_ld, int num_inputs,
+                   int64_t num_blocks, ffh_stream s);
+/* Concat::backward_kernel [ref: include/model.h:1778-1784, src/ops/concat.cu:325-360],
+ * add_with_stride [ref: src/runtime/cuda_helper.cu:110-126]:
+ * in_grad_i[blk*in_ld[i] + e] += out_grad[blk*out_blk + off_i + e]  (accumulate) */
+int ffh_concat_bwd(ffh_ctx* ctx, const float* out_grad, int64_t out_blk, float* const* in_grads,
+                   const int64_t* in_blk, const int64_t* in_ld, int num_inputs,
+                   int64_t num_blocks, ffh_stream s);
+
+/* ------------------------------------------------------------------ */
+/* BatchMatmul                                                        */
+/* ------------------------------------------------------------------ */
+/* BatchMatmul::forward_kernel [ref: include/model.h:1098-1108, src/ops/batch_matmul.cu:194-244]
+ * A [batch][n][k], B [batch][k][m], O [batch][n][m]; O = A*B.  a_seq_length_dim /
+ * b_seq_length_dim / seq_length shrink k, n or m as the reference does (-1: unused). */
+int ffh_bmm_fwd(ffh_ctx* ctx, float* o, const float* a, const float* b,
+                int m, int n, int k, int64_t batch,
+                int a_seq_length_dim, int b_seq_length_dim, int seq_length, ffh_stream s);
+/* BatchMatmul::backward_kernel [ref: include/model.h:1109-1118, src/ops/batch_matmul.cu:375-400]
+ * a_grad += o_grad * B^T ; b_grad += A^T * o_grad  (both accumulate) */
+int ffh_bmm_bwd(ffh_ctx* ctx, const float* o_grad, const float* a, float* a_grad,
+                const float* b, float* b_grad, int m, int n, int k, int64_t batch, ffh_stream s);
+
+/* ------------------------------------------------------------------ */
+/* Loss, metrics, optimizer                                           */
+/* ------------------------------------------------------------------ */
+/* mean_squared_error_avg_loss_backward + scale_kernel(0, scale)
+ * [ref: src/loss_functions/loss_functions.cu:65-76,160-166; src/runtime/cuda_helper.cu:33-40]
+ * logit_grad[i] = (logit[i] - label[i]) * scale, scale = 1/global_batch [ref: loss_functions.cu:202] */
+int ffh_mse_bwd(ffh_ctx* ctx, float* logit_grad, const float* logit, const float* label,
+                int64_t count, float scale, ffh_stream s);
+/* update_metrics_label_kernel [ref: src/metrics_functions/metrics_functions.cu:108-173], label
+ * (dense) form, restricted to accuracy + MSE/RMSE/MAE.  flags: bit0 accuracy, bit1 mse, bit2 rmse,
+ * bit3 mae.  Accumulates into *perf (device memory).  With num_classes == 1 and accuracy on,
+ * train_all is counted twice per sample, as the reference does (:119-125). */
+int ffh_metrics_update(ffh_ctx* ctx, const float* logits, const float* labels, ffh_perf_metrics* perf,
+                       int64_t num_samples, int num_classes, int flags, ffh_stream s);
+/* sgd_update [ref: src/runtime/optimizer_kernel.cu:23-41]; v may be NULL when momentum == 0 */
+int ffh_sgd_update(ffh_ctx* ctx, float* w, const float* w_grad, float* v, int64_t count,
+                   float lr, float weight_decay, float momentum, int nesterov, ffh_stream s);
+/* apply_add_with_scale [ref: src/runtime/cuda_helper.cu:99-108] : dst += src*scale */
+int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, float scale, ffh_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+
+/* X-macro list of every exported symbol (used by the dlopen loader of the C++
+ * FFModel shim and by tests/test_abi_symbols.py). */
+#define FFH_API_LIST(X) \
+  X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) \
+  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) \
+  X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
+  X(ffh_stream_create) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
+  X(ffh_event_create) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \
+  X(ffh_stream_wait_event) X(ffh_event_elapsed_ms) \
+  X(ffh_graph_begin_capture) X(ffh_graph_end_capture) X(ffh_graph_launch) X(ffh_graph_destroy) \
+  X(ffh_fill_f32) X(ffh_zero) X(ffh_init_uniform) \
+  X(ffh_gen_indices) X(ffh_gen_uniform01) X(ffh_gen_bernoulli) \
+  X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
+  X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
+  X(ffh_embedding_bwd_workspace_bytes) \
+  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_concat_fwd) X(ffh_concat_bwd) \
+  X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_mse_bwd) X(ffh_metrics_update) \
+  X(ffh_sgd_update) X(ffh_add_scaled)
+
+#endif /* FF_HIP_H_ */

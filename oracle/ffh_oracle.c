@@ -1,0 +1,578 @@
+/* ffh_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C CPU restatement of the arithmetic of the reference's DLRM hot path
+ * (facebookresearch/DLRM-FlexFlow), exporting the same C-ABI as the HIP library
+ * (include/ff_hip.h) with "device" pointers being host pointers.  It exists so
+ * that tests can check the HIP kernels against it, so that
+ * __graft_entry__.smoke() can check one invocation, and so that bench.py can
+ * time a CPU baseline ("cpu_baseline.kind" = "port").  Nothing in the product
+ * path (dlrm_flexflow_amd/, the C++ FFModel shim's default backend) loads it.
+ *
+ * Pinning: the embedding forward is checked against the reference's own AVX2
+ * lookup compiled from /root/reference (oracle/Makefile -> oracle/_ref/), and
+ * the Linear / Concat / BatchMatmul / SGD / MSE functions against PyTorch-CPU
+ * + numpy, the oracle the reference's op tests use (tests/ops/test_harness.py);
+ * vectors are committed under tests/golden/ (tests/golden/make_golden.py).
+ * The fused embedding backward + SGD, the metrics kernel and the multi-GPU
+ * exchange have no reference test or golden vector: PARITY UNPINNED by the
+ * reference for those three -- they are pinned only against the float64
+ * mathematical result (tests/test_oracle_golden.py).
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * the reference checkout).  Summation orders are fixed and documented so the
+ * results do not depend on the OpenMP thread count: threads only ever split
+ * independent output elements.
+ */
+#include "../include/ff_hip.h"
+#include "../include/ffh_rng.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+struct ffh_ctx {
+  void*  ws;
+  size_t ws_bytes;
+  char   err[256];
+};
+
+static int fail(ffh_ctx* c, int code, const char* msg) {
+  if (c) snprintf(c->err, sizeof c->err, "%s", msg);
+  return code;
+}
+
+/* ------------------------------------------------------------------ */
+/* library / context / memory: host stand-ins                          */
+/* ------------------------------------------------------------------ */
+int         ffh_abi_version(void) { return FFH_ABI_VERSION; }
+const char* ffh_backend_name(void) { return "oracle-cpu"; }
+
+int ffh_ctx_create(ffh_ctx** out, int device) {
+  (void)device;
+  if (!out) return FFH_ERR_BAD_ARG;
+  ffh_ctx* c = (ffh_ctx*)calloc(1, sizeof *c);
+  if (!c) return FFH_ERR_NOMEM;
+  *out = c;
+  return FFH_OK;
+}
+int ffh_ctx_destroy(ffh_ctx* c) { free(c); return FFH_OK; }
+const char* ffh_last_error_string(const ffh_ctx* c) { return c ? c->err : "null ctx"; }
+int ffh_device_query(ffh_ctx* c, ffh_device_info* info) {
+  if (!c || !info) return FFH_ERR_BAD_ARG;
+  memset(info, 0, sizeof *info);
+  snprintf(info->name, sizeof info->name, "host CPU (oracle)");
+  snprintf(info->arch, sizeof info->arch, "cpu");
+  info->wavefront_size = 1;
+  return FFH_OK;
+}
+int ffh_ctx_set_workspace(ffh_ctx* c, void* ws, size_t bytes) {
+  if (!c) return FFH_ERR_BAD_ARG;
+  c->ws = ws; c->ws_bytes = bytes;
+  return FFH_OK;
+}
+int ffh_malloc(ffh_ctx* c, void** p, size_t bytes) {
+  if (!c || !p) return FFH_ERR_BAD_ARG;
+  *p = NULL;
+  if (posix_memalign(p, 256, bytes ? bytes : 256)) return fail(c, FFH_ERR_NOMEM, "host alloc failed");
+  return FFH_OK;
+}
+int ffh_free(ffh_ctx* c, void* p) { (void)c; free(p); return FFH_OK; }
+int ffh_memcpy_h2d(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) { (void)c; (void)st; memcpy(d, s, n); return FFH_OK; }
+int ffh_memcpy_d2h(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) { (void)c; (void)st; memcpy(d, s, n); return FFH_OK; }
+int ffh_memcpy_d2d(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) { (void)c; (void)st; memmove(d, s, n); return FFH_OK; }
+int ffh_stream_create(ffh_ctx* c, ffh_stream* s) { (void)c; if (s) *s = NULL; return FFH_OK; }
+int ffh_stream_destroy(ffh_ctx* c, ffh_stream s) { (void)c; (void)s; return FFH_OK; }
+int ffh_stream_sync(ffh_ctx* c, ffh_stream s) { (void)c; (void)s; return FFH_OK; }
+int ffh_device_sync(ffh_ctx* c) { (void)c; return FFH_OK; }
+/* events carry a host timestamp so that ffh_event_elapsed_ms works */
+int ffh_event_create(ffh_ctx* c, ffh_event* e) {
+  (void)c; if (!e) return FFH_ERR_BAD_ARG;
+  *e = calloc(1, sizeof(double));
+  return *e ? FFH_OK : FFH_ERR_NOMEM;
+}
+int ffh_event_destroy(ffh_ctx* c, ffh_event e) { (void)c; free(e); return FFH_OK; }
+int ffh_event_record(ffh_ctx* c, ffh_event e, ffh_stream s) {
+  (void)c; (void)s; if (!e) return FFH_ERR_BAD_ARG;
+  struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  *(double*)e = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+  return FFH_OK;
+}
+int ffh_event_sync(ffh_ctx* c, ffh_event e) { (void)c; (void)e; return FFH_OK; }
+int ffh_stream_wait_event(ffh_ctx* c, ffh_stream s, ffh_event e) { (void)c; (void)s; (void)e; return FFH_OK; }
+int ffh_event_elapsed_ms(ffh_ctx* c, ffh_event a, ffh_event b, float* ms) {
+  (void)c; if (!a || !b || !ms) return FFH_ERR_BAD_ARG;
+  *ms = (float)(*(double*)b - *(double*)a);
+  return FFH_OK;
+}
+/* no graphs on the host: capture is refused so callers run eagerly */
+int ffh_graph_begin_capture(ffh_ctx* c, ffh_stream s) { (void)s; return fail(c, FFH_ERR_UNSUPPORTED, "oracle: no graph capture"); }
+int ffh_graph_end_capture(ffh_ctx* c, ffh_stream s, ffh_graph* g) { (void)s; (void)g; return fail(c, FFH_ERR_UNSUPPORTED, "oracle: no graph capture"); }
+int ffh_graph_launch(ffh_ctx* c, ffh_graph g, ffh_stream s) { (void)g; (void)s; return fail(c, FFH_ERR_UNSUPPORTED, "oracle: no graph capture"); }
+int ffh_graph_destroy(ffh_ctx* c, ffh_graph g) { (void)c; (void)g; return FFH_OK; }
+
+/* ------------------------------------------------------------------ */
+/* initialisers / synthetic data                                       */
+/* ------------------------------------------------------------------ */
+/* assign_kernel [ref: src/runtime/cuda_helper.cu:52-60] */
+int ffh_fill_f32(ffh_ctx* c, float* p, int64_t n, float v, ffh_stream s) {
+  (void)c; (void)s;
+  for (int64_t i = 0; i < n; i++) p[i] = v;
+  return FFH_OK;
+}
+int ffh_zero(ffh_ctx* c, void* p, size_t bytes, ffh_stream s) { (void)c; (void)s; memset(p, 0, bytes); return FFH_OK; }
+/* UniformInitializer::init_task [ref: src/runtime/initializer_kernel.cu:24-98]: curandGenerateUniform
+ * then scale_kernel(min,max); here the uniform comes from include/ffh_rng.h */
+int ffh_init_uniform(ffh_ctx* c, float* p, int64_t n, uint64_t seed, float lo, float hi, ffh_stream s) {
+  (void)c; (void)s;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) p[i] = ffh_uniform(ffh_hash(seed, (uint64_t)i), lo, hi);
+  return FFH_OK;
+}
+/* DataLoader::load_entire_dataset synthetic branch [ref: examples/cpp/DLRM/dlrm.cc:413-420] */
+int ffh_gen_indices(ffh_ctx* c, int64_t* idx, int64_t n, uint64_t seed, int64_t first, int64_t R, ffh_stream s) {
+  (void)s;
+  if (R <= 0) return fail(c, FFH_ERR_BAD_ARG, "gen_indices: num_entries <= 0");
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) idx[i] = ffh_index(ffh_hash(seed, (uint64_t)(first + i)), R);
+  return FFH_OK;
+}
+int ffh_gen_uniform01(ffh_ctx* c, float* p, int64_t n, uint64_t seed, int64_t first, ffh_stream s) {
+  (void)c; (void)s;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) p[i] = ffh_u24(ffh_hash(seed, (uint64_t)(first + i)));
+  return FFH_OK;
+}
+int ffh_gen_bernoulli(ffh_ctx* c, float* p, int64_t n, uint64_t seed, int64_t first, ffh_stream s) {
+  (void)c; (void)s;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) p[i] = ffh_bernoulli(ffh_hash(seed, (uint64_t)(first + i)));
+  return FFH_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* Embedding                                                          */
+/* ------------------------------------------------------------------ */
+/* embed_forward [ref: src/ops/embedding.cu:166-190]: output[i] = 0; for j ascending
+ * output[i] += embed[idx*out_dim + off].  The CPU twin
+ * [ref: src/ops/embedding.cc:262-314] does op[j] = fma(1.0f, ip[j], op[j]) from a zeroed
+ * op, which is the same value.  AVG: the reference divides inside the j loop (a bug,
+ * SURVEY 8a-1); the restated AVG is the true mean sum * (1.0f/in_dim), as the CPU
+ * twin's normalize_by_lengths branch computes it [ref: src/ops/embedding.cc:300-311]. */
+int ffh_embedding_fwd(ffh_ctx* c, const int64_t* idx, float* out, const float* w,
+                      int L, int D, int64_t B, int64_t R, int64_t out_ld, int aggr, ffh_stream s) {
+  (void)s;
+  if (L <= 0 || D <= 0 || B < 0 || out_ld < D) return fail(c, FFH_ERR_BAD_ARG, "embedding_fwd: bad dims");
+  if (aggr != FFH_AGGR_MODE_SUM && aggr != FFH_AGGR_MODE_AVG) return fail(c, FFH_ERR_BAD_ARG, "embedding_fwd: aggr");
+  for (int64_t i = 0; i < B * L; i++)
+    if (idx[i] < 0 || idx[i] >= R) return fail(c, FFH_ERR_BAD_ARG, "embedding_fwd: index out of range");
+  const float inv = 1.0f / (float)L;
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < B; b++) {
+    float* o = out + b * out_ld;
+    for (int d = 0; d < D; d++) o[d] = 0.0f;
+    for (int j = 0; j < L; j++) {
+      const float* row = w + idx[b * L + j] * (int64_t)D;
+      for (int d = 0; d < D; d++) o[d] = o[d] + row[d];
+    }
+    if (aggr == FFH_AGGR_MODE_AVG)
+      for (int d = 0; d < D; d++) o[d] = o[d] * inv;
+  }
+  return FFH_OK;
+}
+
+int ffh_embedding_fwd_multi(ffh_ctx* c, const ffh_emb_table* t, int nt, int L, int D, int64_t B, int aggr, ffh_stream s) {
+  if (nt < 0 || nt > FFH_MAX_TABLES) return fail(c, FFH_ERR_BAD_ARG, "embedding_fwd_multi: ntables");
+  for (int i = 0; i < nt; i++) {
+    int rc = ffh_embedding_fwd(c, t[i].idx, t[i].io, t[i].weight, L, D, B, t[i].num_entries, t[i].ld, aggr, s);
+    if (rc) return rc;
+  }
+  return FFH_OK;
+}
+
+/* embed_backward [ref: src/ops/embedding.cu:192-217]: atomicAdd(embed + idx*D + off, g) for
+ * every (b, j).  Atomic arrival order is undefined in the reference; restated in the order
+ * (b ascending, j ascending), which is what a single-threaded run of the kernel gives. */
+int ffh_embedding_bwd_dense(ffh_ctx* c, const int64_t* idx, const float* g, float* wg,
+                            int L, int D, int64_t B, int64_t R, int64_t gld, int aggr, ffh_stream s) {
+  (void)s;
+  if (L <= 0 || D <= 0 || B < 0 || gld < D) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_dense: bad dims");
+  if (aggr != FFH_AGGR_MODE_SUM && aggr != FFH_AGGR_MODE_AVG) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_dense: aggr");
+  for (int64_t i = 0; i < B * L; i++)
+    if (idx[i] < 0 || idx[i] >= R) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_dense: index out of range");
+  for (int64_t b = 0; b < B; b++)
+    for (int j = 0; j < L; j++) {
+      float* row = wg + idx[b * L + j] * (int64_t)D;
+      for (int d = 0; d < D; d++) {
+        float gr = g[b * gld + d];
+        if (aggr == FFH_AGGR_MODE_AVG) gr = gr / (float)L;   /* [ref: embedding.cu:206-209] */
+        row[d] += gr;
+      }
+    }
+  return FFH_OK;
+}
+
+typedef struct { int64_t row; int64_t pos; } rp_t;
+static int rp_cmp(const void* a, const void* b) {
+  const rp_t* x = (const rp_t*)a; const rp_t* y = (const rp_t*)b;
+  if (x->row != y->row) return x->row < y->row ? -1 : 1;
+  if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+  return 0;
+}
+
+/* Net effect on an embedding table of one reference training step
+ *   zero_grad   [ref: src/runtime/model.cc:466-490]  (dense gradient := 0)
+ *   embed_backward [ref: src/ops/embedding.cu:192-217] (scatter-add)
+ *   sgd_update  [ref: src/runtime/optimizer_kernel.cu:23-41] with momentum = 0, wd = 0
+ *               (the driver's SGDOptimizer(&ff, 0.01f), [ref: examples/cpp/DLRM/dlrm.cc:130])
+ * i.e. W[r] -= lr * sum of the gradients that hit r; rows not hit keep their bits
+ * (W -= lr*0).  `W[i] -= lr*gt` is contracted to one FMA by nvcc's default -fmad=true, so
+ * the update is restated as fmaf(-lr, sum, w).  The summation order is the canonical one
+ * documented at ffh_embedding_bwd_sgd_fused in include/ff_hip.h. */
+int ffh_embedding_bwd_sgd_fused(ffh_ctx* c, const int64_t* idx, const float* g, float* w,
+                                int L, int D, int64_t B, int64_t R, int64_t gld, int aggr, float lr, ffh_stream s) {
+  (void)s;
+  if (L <= 0 || D <= 0 || B < 0 || gld < D) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_sgd_fused: bad dims");
+  if (aggr != FFH_AGGR_MODE_SUM && aggr != FFH_AGGR_MODE_AVG) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_sgd_fused: aggr");
+  const int64_t N = B * L;
+  if (N == 0) return FFH_OK;
+  rp_t* v = (rp_t*)malloc(sizeof(rp_t) * (size_t)N);
+  float* part = (float*)malloc(sizeof(float) * (size_t)D);
+  float* tot = (float*)malloc(sizeof(float) * (size_t)D);
+  if (!v || !part || !tot) { free(v); free(part); free(tot); return fail(c, FFH_ERR_NOMEM, "oom"); }
+  for (int64_t p = 0; p < N; p++) {
+    if (idx[p] < 0 || idx[p] >= R) { free(v); free(part); free(tot); return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_sgd_fused: index out of range"); }
+    v[p].row = idx[p]; v[p].pos = p;
+  }
+  qsort(v, (size_t)N, sizeof(rp_t), rp_cmp);
+  const float invL = 1.0f / (float)L; (void)invL;
+  int64_t i = 0;
+  while (i < N) {
+    const int64_t row = v[i].row;
+    int64_t e = i;
+    while (e < N && v[e].row == row) e++;
+    /* sub-runs: [i,e) cut at multiples of FFH_EMB_CHUNK */
+    int first_part = 1;
+    int64_t a = i;
+    while (a < e) {
+      int64_t z = (a / FFH_EMB_CHUNK + 1) * FFH_EMB_CHUNK;
+      if (z > e) z = e;
+      for (int64_t q = a; q < z; q++) {
+        const float* gr = g + (v[q].pos / L) * gld;
+        for (int d = 0; d < D; d++) {
+          float x = gr[d];
+          if (aggr == FFH_AGGR_MODE_AVG) x = x / (float)L;
+          part[d] = (q == a) ? x : part[d] + x;
+        }
+      }
+      for (int d = 0; d < D; d++) tot[d] = first_part ? part[d] : tot[d] + part[d];
+      first_part = 0;
+      a = z;
+    }
+    float* wr = w + row * (int64_t)D;
+    for (int d = 0; d < D; d++) wr[d] = fmaf(-lr, tot[d], wr[d]);
+    i = e;
+  }
+  free(v); free(part); free(tot);
+  return FFH_OK;
+}
+
+int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* t, int nt, int L, int D, int64_t B, int aggr, float lr, ffh_stream s) {
+  if (nt < 0 || nt > FFH_MAX_TABLES) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_sgd_fused_multi: ntables");
+  for (int i = 0; i < nt; i++) {
+    int rc = ffh_embedding_bwd_sgd_fused(c, t[i].idx, t[i].io, t[i].weight, L, D, B, t[i].num_entries, t[i].ld, aggr, lr, s);
+    if (rc) return rc;
+  }
+  return FFH_OK;
+}
+size_t ffh_embedding_bwd_workspace_bytes(int nt, int L, int D, int64_t B) { (void)nt; (void)L; (void)D; (void)B; return 0; }
+
+/* ------------------------------------------------------------------ */
+/* Linear                                                             */
+/* ------------------------------------------------------------------ */
+static float act_fwd(float v, int act) {
+  if (act == FFH_AC_MODE_RELU) return v > 0.0f ? v : 0.0f;        /* CUDNN_ACTIVATION_RELU */
+  if (act == FFH_AC_MODE_SIGMOID) return 1.0f / (1.0f + expf(-v)); /* CUDNN_ACTIVATION_SIGMOID */
+  return v;
+}
+
+/* Linear::forward_kernel [ref: src/ops/linear.cu:436-453]:
+ *   cublasSgemm(T,N, out,B,in): Y = W^T-view * X, beta 0      -> y[b][o] = sum_i x[b][i] w[o][i]
+ *   cublasSgemm(T,N, out,B,1) with the ones vector, beta 1    -> y[b][o] += bias[o]
+ *   cudnnActivationForward in place                           -> y = act(y)
+ * cuBLAS's internal summation order is not published; restated as an i-ascending fp32
+ * FMA chain from 0 (what v_mfma_f32_32x32x2_f32 also computes). */
+int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ldy,
+                   const float* w, const float* bias, int in, int out, int64_t B, int act, ffh_stream s) {
+  (void)s;
+  if (in <= 0 || out <= 0 || B < 0 || ldx < in || ldy < out) return fail(c, FFH_ERR_BAD_ARG, "linear_fwd: bad dims");
+  if (act != FFH_AC_MODE_NONE && act != FFH_AC_MODE_RELU && act != FFH_AC_MODE_SIGMOID)
+    return fail(c, FFH_ERR_UNSUPPORTED, "linear_fwd: activation");
+  float* wt = (float*)malloc(sizeof(float) * (size_t)in * (size_t)out);   /* [in][out] */
+  if (!wt) return fail(c, FFH_ERR_NOMEM, "oom");
+  for (int o = 0; o < out; o++) for (int i = 0; i < in; i++) wt[(size_t)i * out + o] = w[(size_t)o * in + i];
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < B; b++) {
+    float* yr = y + b * ldy;
+    const float* xr = x + b * ldx;
+    for (int o = 0; o < out; o++) yr[o] = 0.0f;
+    for (int i = 0; i < in; i++) {
+      const float xi = xr[i];
+      const float* wr = wt + (size_t)i * out;
+      for (int o = 0; o < out; o++) yr[o] = fmaf(xi, wr[o], yr[o]);
+    }
+    if (bias) for (int o = 0; o < out; o++) yr[o] = yr[o] + bias[o];
+    if (act != FFH_AC_MODE_NONE) for (int o = 0; o < out; o++) yr[o] = act_fwd(yr[o], act);
+  }
+  free(wt);
+  return FFH_OK;
+}
+
+/* Linear::backward_kernel [ref: src/ops/linear.cu:610-660]:
+ *   reluBackward [ref: src/runtime/cuda_helper.cu:71-78] / sigmoid_backward [ref: src/ops/linear.cu:600-607] in place on dy
+ *   cublasSgemm(N,T, in,out,B) alpha=beta=1 : dw[o][i] += sum_b x[b][i] dy[b][o]
+ *   cublasSgemv(N, out,B)      alpha=beta=1 : db[o]    += sum_b dy[b][o]
+ *   cublasSgemm(N,N, in,B,out) alpha=beta=1 : dx[b][i] += sum_o w[o][i] dy[b][o]
+ * Each product is an ascending FMA chain from 0 over the reduced index, then one add into
+ * the accumulated buffer (C = 1*AB + 1*C). */
+int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                   const float* y, int64_t ldy, float* dy, int64_t lddy,
+                   const float* w, float* dw, float* db,
+                   int in, int out, int64_t B, int act, ffh_stream s) {
+  (void)s;
+  if (in <= 0 || out <= 0 || B < 0 || ldx < in || ldy < out || lddy < out || (dx && lddx < in))
+    return fail(c, FFH_ERR_BAD_ARG, "linear_bwd: bad dims");
+  if (act != FFH_AC_MODE_NONE && act != FFH_AC_MODE_RELU && act != FFH_AC_MODE_SIGMOID)
+    return fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd: activation");
+  if (act == FFH_AC_MODE_RELU) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; b++)
+      for (int o = 0; o < out; o++)
+        dy[b * lddy + o] = (y[b * ldy + o] > 0.0f) ? dy[b * lddy + o] : 0.0f;
+  } else if (act == FFH_AC_MODE_SIGMOID) {
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < B; b++)
+      for (int o = 0; o < out; o++) {
+        const float yo = y[b * ldy + o];
+        dy[b * lddy + o] = dy[b * lddy + o] * yo * (1 - yo);
+      }
+  }
+  /* dw */
+#pragma omp parallel
+  {
+    float* tmp = (float*)malloc(sizeof(float) * (size_t)in);
+#pragma omp for schedule(static)
+    for (int o = 0; o < out; o++) {
+      for (int i = 0; i < in; i++) tmp[i] = 0.0f;
+      for (int64_t b = 0; b < B; b++) {
+        const float d = dy[b * lddy + o];
+        const float* xr = x + b * ldx;
+        for (int i = 0; i < in; i++) tmp[i] = fmaf(d, xr[i], tmp[i]);
+      }
+      for (int i = 0; i < in; i++) dw[(size_t)o * in + i] += tmp[i];
+    }
+    free(tmp);
+  }
+  /* db */
+  if (db) {
+    for (int o = 0; o < out; o++) {
+      float acc = 0.0f;
+      for (int64_t b = 0; b < B; b++) acc = fmaf(dy[b * lddy + o], 1.0f, acc);
+      db[o] += acc;
+    }
+  }
+  /* dx */
+  if (dx) {
+#pragma omp parallel
+    {
+      float* tmp = (float*)malloc(sizeof(float) * (size_t)in);
+#pragma omp for schedule(static)
+      for (int64_t b = 0; b < B; b++) {
+        for (int i = 0; i < in; i++) tmp[i] = 0.0f;
+        for (int o = 0; o < out; o++) {
+          const float d = dy[b * lddy + o];
+          const float* wr = w + (size_t)o * in;
+          for (int i = 0; i < in; i++) tmp[i] = fmaf(d, wr[i], tmp[i]);
+        }
+        for (int i = 0; i < in; i++) dx[b * lddx + i] += tmp[i];
+      }
+      free(tmp);
+    }
+  }
+  return FFH_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* Concat                                                             */
+/* ------------------------------------------------------------------ */
+/* Concat::forward_kernel [ref: src/ops/concat.cu:211-249] + copy_with_stride
+ * [ref: src/runtime/cuda_helper.cu:128-144] */
+int ffh_concat_fwd(ffh_ctx* c, float* out, int64_t out_blk, const float* const* ins,
+                   const int64_t* in_blk, const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
+  (void)s;
+  if (n < 0 || n > FFH_MAX_CONCAT_INPUTS || nblk < 0) return fail(c, FFH_ERR_BAD_ARG, "concat_fwd: bad dims");
+  int64_t off = 0;
+  for (int i = 0; i < n; i++) {
+    const int64_t ld = in_ld ? in_ld[i] : in_blk[i];
+    if (in_blk[i] < 0 || ld < in_blk[i] || off + in_blk[i] > out_blk) return fail(c, FFH_ERR_BAD_ARG, "concat_fwd: widths");
+    if (!(ins[i] == out + off && ld == out_blk))
+      for (int64_t b = 0; b < nblk; b++)
+        for (int64_t e = 0; e < in_blk[i]; e++)
+          out[b * out_blk + off + e] = ins[i][b * ld + e];
+    off += in_blk[i];
+  }
+  return FFH_OK;
+}
+/* Concat::backward_kernel [ref: src/ops/concat.cu:325-360] + add_with_stride
+ * [ref: src/runtime/cuda_helper.cu:110-126] */
+int ffh_concat_bwd(ffh_ctx* c, const float* og, int64_t out_blk, float* const* igs,
+                   const int64_t* in_blk, const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
+  (void)s;
+  if (n < 0 || n > FFH_MAX_CONCAT_INPUTS || nblk < 0) return fail(c, FFH_ERR_BAD_ARG, "concat_bwd: bad dims");
+  int64_t off = 0;
+  for (int i = 0; i < n; i++) {
+    const int64_t ld = in_ld ? in_ld[i] : in_blk[i];
+    if (in_blk[i] < 0 || ld < in_blk[i] || off + in_blk[i] > out_blk) return fail(c, FFH_ERR_BAD_ARG, "concat_bwd: widths");
+    if (igs[i] && !(igs[i] == og + off && ld == out_blk))
+      for (int64_t b = 0; b < nblk; b++)
+        for (int64_t e = 0; e < in_blk[i]; e++)
+          igs[i][b * ld + e] += og[b * out_blk + off + e];
+    off += in_blk[i];
+  }
+  return FFH_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* BatchMatmul                                                        */
+/* ------------------------------------------------------------------ */
+/* BatchMatmul::forward_kernel [ref: src/ops/batch_matmul.cu:194-244]: strides are taken
+ * from the FULL n,k,m (:212-215) before seq_length shrinks k / n / m (:216-236); then
+ * cublasSgemmStridedBatched(N,N, m,n,k), beta 0: o[b][r][c] = sum_q a[b][r][q] b[b][q][c]. */
+int ffh_bmm_fwd(ffh_ctx* c, float* o, const float* a, const float* b,
+                int m, int n, int k, int64_t batch, int asd, int bsd, int seq, ffh_stream s) {
+  (void)s;
+  if (m <= 0 || n <= 0 || k <= 0 || batch < 0) return fail(c, FFH_ERR_BAD_ARG, "bmm_fwd: bad dims");
+  const int lda = k, ldb = m, ldo = m;
+  const int64_t sa = (int64_t)n * k, sb = (int64_t)k * m, so = (int64_t)n * m;
+  if (asd == 0 && seq >= 0) { if (seq > k || bsd != 1) return fail(c, FFH_ERR_BAD_ARG, "bmm_fwd: seq_length"); k = seq; }
+  else if (asd == 1 && seq >= 0) { if (seq > n) return fail(c, FFH_ERR_BAD_ARG, "bmm_fwd: seq_length"); n = seq; }
+  else if (!(asd < 0 || seq < 0)) return fail(c, FFH_ERR_BAD_ARG, "bmm_fwd: a_seq_length_dim");
+  if (bsd == 0 && seq >= 0) { if (seq > m) return fail(c, FFH_ERR_BAD_ARG, "bmm_fwd: seq_length"); m = seq; }
+  else if (bsd == 1 && seq >= 0) { if (asd != 0 || k != seq) return fail(c, FFH_ERR_BAD_ARG, "bmm_fwd: seq_length"); }
+  else if (!(bsd < 0 || seq < 0)) return fail(c, FFH_ERR_BAD_ARG, "bmm_fwd: b_seq_length_dim");
+#pragma omp parallel for schedule(static)
+  for (int64_t bi = 0; bi < batch; bi++) {
+    const float* A = a + bi * sa; const float* Bm = b + bi * sb; float* O = o + bi * so;
+    for (int r = 0; r < n; r++) {
+      for (int cc = 0; cc < m; cc++) O[(size_t)r * ldo + cc] = 0.0f;
+      for (int q = 0; q < k; q++) {
+        const float av = A[(size_t)r * lda + q];
+        for (int cc = 0; cc < m; cc++) O[(size_t)r * ldo + cc] = fmaf(av, Bm[(size_t)q * ldb + cc], O[(size_t)r * ldo + cc]);
+      }
+    }
+  }
+  return FFH_OK;
+}
+/* BatchMatmul::backward_kernel [ref: src/ops/batch_matmul.cu:375-400]:
+ *   a_grad[b][r][q] += sum_c o_grad[b][r][c] * B[b][q][c]
+ *   b_grad[b][q][c] += sum_r A[b][r][q] * o_grad[b][r][c] */
+int ffh_bmm_bwd(ffh_ctx* c, const float* og, const float* a, float* ag, const float* b, float* bg,
+                int m, int n, int k, int64_t batch, ffh_stream s) {
+  (void)s;
+  if (m <= 0 || n <= 0 || k <= 0 || batch < 0) return fail(c, FFH_ERR_BAD_ARG, "bmm_bwd: bad dims");
+  const int64_t sa = (int64_t)n * k, sb = (int64_t)k * m, so = (int64_t)n * m;
+#pragma omp parallel for schedule(static)
+  for (int64_t bi = 0; bi < batch; bi++) {
+    const float* A = a + bi * sa; const float* Bm = b + bi * sb; const float* G = og + bi * so;
+    float* AG = ag + bi * sa; float* BG = bg + bi * sb;
+    for (int r = 0; r < n; r++)
+      for (int q = 0; q < k; q++) {
+        float acc = 0.0f;
+        for (int cc = 0; cc < m; cc++) acc = fmaf(G[(size_t)r * m + cc], Bm[(size_t)q * m + cc], acc);
+        AG[(size_t)r * k + q] += acc;
+      }
+    for (int q = 0; q < k; q++)
+      for (int cc = 0; cc < m; cc++) {
+        float acc = 0.0f;
+        for (int r = 0; r < n; r++) acc = fmaf(A[(size_t)r * k + q], G[(size_t)r * m + cc], acc);
+        BG[(size_t)q * m + cc] += acc;
+      }
+  }
+  return FFH_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* Loss / metrics / optimizer                                         */
+/* ------------------------------------------------------------------ */
+/* mean_squared_error_avg_loss_backward [ref: src/loss_functions/loss_functions.cu:65-76]
+ * then scale_kernel(ptr, n, 0, scale) [ref: :160-166; src/runtime/cuda_helper.cu:33-40]:
+ * ptr = (scale - 0)*ptr + 0  == fl(scale * fl(logit - label)) */
+int ffh_mse_bwd(ffh_ctx* c, float* lg, const float* logit, const float* label, int64_t n, float scale, ffh_stream s) {
+  (void)c; (void)s;
+  for (int64_t i = 0; i < n; i++) {
+    const float d = logit[i] - label[i];
+    lg[i] = fmaf(scale - 0.0f, d, 0.0f);
+  }
+  return FFH_OK;
+}
+
+/* update_metrics_label_kernel [ref: src/metrics_functions/metrics_functions.cu:108-173];
+ * atomics arrive in undefined order in the reference, here b ascending. */
+int ffh_metrics_update(ffh_ctx* c, const float* logits, const float* labels, ffh_perf_metrics* perf,
+                       int64_t ns, int nc, int flags, ffh_stream s) {
+  (void)s;
+  if (nc <= 0 || ns < 0 || !perf) return fail(c, FFH_ERR_BAD_ARG, "metrics_update: bad dims");
+  for (int64_t b = 0; b < ns; b++) {
+    perf->train_all += 1;
+    if (flags & 1) {
+      if (nc == 1) { perf->train_all += 1; perf->train_correct += 1; }
+      else {
+        float max_val = 0.0f; int my = -1, tr = -1;
+        for (int i = 0; i < nc; i++) {
+          if (my == -1 || logits[b * nc + i] > max_val) { max_val = logits[b * nc + i]; my = i; }
+          if (labels[b * nc + i] > 0.9f) tr = i;
+        }
+        if (tr == my) perf->train_correct += 1;
+      }
+    }
+    if (flags & (2 | 4 | 8)) {
+      float mse = 0.0f, mae = 0.0f;
+      for (int i = 0; i < nc; i++) {
+        const float diff = logits[b * nc + i] - labels[b * nc + i];
+        mse = fmaf(diff, diff, mse);
+        mae += fabsf(diff);
+      }
+      if (flags & 2) perf->mse_loss += mse;
+      if (flags & 4) perf->rmse_loss += sqrtf(mse);
+      if (flags & 8) perf->mae_loss += mae;
+    }
+  }
+  return FFH_OK;
+}
+
+/* sgd_update [ref: src/runtime/optimizer_kernel.cu:23-41], with the multiply-adds
+ * contracted the way nvcc's default -fmad=true contracts them. */
+int ffh_sgd_update(ffh_ctx* c, float* w, const float* g, float* v, int64_t n,
+                   float lr, float wd, float mom, int nesterov, ffh_stream s) {
+  (void)s;
+  if (mom > 0.0f && !v) return fail(c, FFH_ERR_BAD_ARG, "sgd_update: momentum without V");
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    float gt = fmaf(wd, w[i], g[i]);
+    if (mom > 0.0f) {
+      v[i] = fmaf(v[i], mom, gt);
+      if (nesterov) gt = fmaf(mom, v[i], gt); else gt = v[i];
+    }
+    w[i] = fmaf(-lr, gt, w[i]);
+  }
+  return FFH_OK;
+}
+
+/* apply_add_with_scale [ref: src/runtime/cuda_helper.cu:99-108] */
+int ffh_add_scaled(ffh_ctx* c, float* d, const float* src, int64_t n, float scale, ffh_stream s) {
+  (void)c; (void)s;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) d[i] = fmaf(src[i], scale, d[i]);
+  return FFH_OK;
+}
