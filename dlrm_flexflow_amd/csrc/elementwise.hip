@@ -1,0 +1,247 @@
+// elementwise.hip -- Concat, MSE-loss backward, metrics, dense SGD, add-scaled for gfx950.
+// All HBM-bound streaming kernels: 16-B accesses where alignment allows, one launch per
+// op (the reference launches copy_with_stride / add_with_stride once per concat input,
+// [ref: src/ops/concat.cu:243-248,353-357]).
+#include "ffh_common.h"
+
+namespace {
+
+constexpr int kConcatMaxPerLaunch = 64;
+
+struct ConcatArgs {
+  float*  part[kConcatMaxPerLaunch];      // input (fwd) / input-grad (bwd) pointers
+  int64_t blk[kConcatMaxPerLaunch];       // width of each part
+  int64_t ld[kConcatMaxPerLaunch];        // leading dimension of each part
+  int64_t off[kConcatMaxPerLaunch];       // column offset inside the concatenated row
+  float*  big;                            // out (fwd) / out_grad (bwd)
+  int64_t out_blk;
+  int64_t num_blocks;
+  int     n;
+};
+
+// grid.y = part; each workgroup streams rows of its part.  BWD adds (accumulates) into the part.
+template <bool BWD, int VEC>
+__global__ __launch_bounds__(256) void concat_kernel(const ConcatArgs a) {
+  const int p = blockIdx.y;
+  float* part = a.part[p];
+  const int64_t w = a.blk[p], ld = a.ld[p], off = a.off[p];
+  const int64_t wv = w / VEC;
+  const int64_t total = a.num_blocks * wv;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / wv;
+    const int64_t e = (i - b * wv) * VEC;
+    float* bp = a.big + b * a.out_blk + off + e;
+    float* pp = part + b * ld + e;
+    if (VEC == 4) {
+      if (BWD) {
+        float4 x = *reinterpret_cast<float4*>(pp);
+        const float4 g = *reinterpret_cast<const float4*>(bp);
+        x.x += g.x; x.y += g.y; x.z += g.z; x.w += g.w;
+        *reinterpret_cast<float4*>(pp) = x;
+      } else {
+        *reinterpret_cast<float4*>(bp) = *reinterpret_cast<const float4*>(pp);
+      }
+    } else {
+      if (BWD) *pp += *bp; else *bp = *pp;
+    }
+  }
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <bool BWD>
+int concat_impl(ffh_ctx* c, float* big, int64_t out_blk, float* const* parts, const int64_t* in_blk,
+                const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
+  if (n < 0 || n > FFH_MAX_CONCAT_INPUTS || nblk < 0 || out_blk < 0) return ffh_fail(c, FFH_ERR_BAD_ARG, "concat: bad dims");
+  if (n && (!big || !parts || !in_blk)) return ffh_fail(c, FFH_ERR_BAD_ARG, "concat: null pointer");
+  int64_t off = 0;
+  ConcatArgs a;
+  a.big = big; a.out_blk = out_blk; a.num_blocks = nblk; a.n = 0;
+  bool vec = al16(big) && (out_blk % 4 == 0);
+  int64_t maxw = 0;
+  auto flush = [&]() -> int {
+    if (a.n == 0) return FFH_OK;
+    dim3 grid(ffh_grid(nblk * ((maxw + 3) / 4), 256, 1024), a.n);
+    if (vec) hipLaunchKernelGGL((concat_kernel<BWD, 4>), grid, dim3(256), 0, as_stream(s), a);
+    else hipLaunchKernelGGL((concat_kernel<BWD, 1>), grid, dim3(256), 0, as_stream(s), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ffh_fail_hip(c, e, "concat_kernel");
+    a.n = 0; maxw = 0; vec = al16(big) && (out_blk % 4 == 0);
+    return FFH_OK;
+  };
+  for (int i = 0; i < n; i++) {
+    const int64_t ld = in_ld ? in_ld[i] : in_blk[i];
+    if (in_blk[i] < 0 || ld < in_blk[i] || off + in_blk[i] > out_blk) return ffh_fail(c, FFH_ERR_BAD_ARG, "concat: widths do not fit");
+    float* p = parts[i];
+    const bool aliased = (p == big + off) && (ld == out_blk);   // producer already wrote in place
+    if (p && !aliased && in_blk[i] > 0 && nblk > 0) {
+      const bool v = al16(big) && (out_blk % 4 == 0) && al16(p) && (ld % 4 == 0) && (in_blk[i] % 4 == 0) && (off % 4 == 0);
+      if (a.n && v != vec) { int rc = flush(); if (rc) return rc; }
+      vec = v;
+      a.part[a.n] = p; a.blk[a.n] = in_blk[i]; a.ld[a.n] = ld; a.off[a.n] = off;
+      a.n++;
+      maxw = in_blk[i] > maxw ? in_blk[i] : maxw;
+      if (a.n == kConcatMaxPerLaunch) { int rc = flush(); if (rc) return rc; }
+    } else if (!p && !BWD) {
+      return ffh_fail(c, FFH_ERR_BAD_ARG, "concat_fwd: null input");
+    }
+    off += in_blk[i];
+  }
+  return flush();
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_bwd_kernel(float* __restrict__ lg, const float* __restrict__ logit,
+                                                      const float* __restrict__ label, int64_t n, float scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = logit[i] - label[i];
+    lg[i] = __fmaf_rn(scale - 0.0f, d, 0.0f);       // scale_kernel: (b-a)*x + a with a = 0
+  }
+}
+
+// per-workgroup reduction in registers/LDS, then one atomic per workgroup per counter
+__global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                                      ffh_perf_metrics* __restrict__ perf, int64_t ns, int nc, int flags) {
+  __shared__ float s_f[3][4];
+  __shared__ int   s_i[2][4];
+  float mse_s = 0.f, rmse_s = 0.f, mae_s = 0.f;
+  int all = 0, correct = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < ns; b += stride) {
+    all += 1;
+    if (flags & 1) {
+      if (nc == 1) { all += 1; correct += 1; }
+      else {
+        float max_val = 0.0f; int my = -1, tr = -1;
+        for (int i = 0; i < nc; i++) {
+          const float lv = logits[b * nc + i];
+          if (my == -1 || lv > max_val) { max_val = lv; my = i; }
+          if (labels[b * nc + i] > 0.9f) tr = i;
+        }
+        if (tr == my) correct += 1;
+      }
+    }
+    if (flags & (2 | 4 | 8)) {
+      float mse = 0.f, mae = 0.f;
+      for (int i = 0; i < nc; i++) {
+        const float diff = logits[b * nc + i] - labels[b * nc + i];
+        mse = __fmaf_rn(diff, diff, mse);
+        mae += fabsf(diff);
+      }
+      mse_s += mse; rmse_s += sqrtf(mse); mae_s += mae;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mse_s += __shfl_down(mse_s, o); rmse_s += __shfl_down(rmse_s, o); mae_s += __shfl_down(mae_s, o);
+    all += __shfl_down(all, o); correct += __shfl_down(correct, o);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s_f[0][wave] = mse_s; s_f[1][wave] = rmse_s; s_f[2][wave] = mae_s; s_i[0][wave] = all; s_i[1][wave] = correct; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m = (s_f[0][0] + s_f[0][1]) + (s_f[0][2] + s_f[0][3]);
+    const float r = (s_f[1][0] + s_f[1][1]) + (s_f[1][2] + s_f[1][3]);
+    const float ab = (s_f[2][0] + s_f[2][1]) + (s_f[2][2] + s_f[2][3]);
+    const int al = s_i[0][0] + s_i[0][1] + s_i[0][2] + s_i[0][3];
+    const int co = s_i[1][0] + s_i[1][1] + s_i[1][2] + s_i[1][3];
+    if (al) atomicAdd(&perf->train_all, al);
+    if (co) atomicAdd(&perf->train_correct, co);
+    if (flags & 2) atomicAdd(&perf->mse_loss, m);
+    if (flags & 4) atomicAdd(&perf->rmse_loss, r);
+    if (flags & 8) atomicAdd(&perf->mae_loss, ab);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
+                                                  int64_t n, float lr, float wd, float mom, int nesterov) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nv = n / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    float wv[VEC], gv[VEC], vv[VEC];
+    if (VEC == 4) {
+      const float4 a = reinterpret_cast<const float4*>(w)[i], b = reinterpret_cast<const float4*>(g)[i];
+      wv[0] = a.x; wv[1] = a.y; wv[2] = a.z; wv[3] = a.w;
+      gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+      if (mom > 0.f) { const float4 q = reinterpret_cast<const float4*>(v)[i]; vv[0] = q.x; vv[1] = q.y; vv[2] = q.z; vv[3] = q.w; }
+    } else {
+      wv[0] = w[i]; gv[0] = g[i];
+      if (mom > 0.f) vv[0] = v[i];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      float gt = __fmaf_rn(wd, wv[k], gv[k]);
+      if (mom > 0.f) {
+        vv[k] = __fmaf_rn(vv[k], mom, gt);
+        gt = nesterov ? __fmaf_rn(mom, vv[k], gt) : vv[k];
+      }
+      wv[k] = __fmaf_rn(-lr, gt, wv[k]);
+    }
+    if (VEC == 4) {
+      reinterpret_cast<float4*>(w)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      if (mom > 0.f) reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    } else {
+      w[i] = wv[0];
+      if (mom > 0.f) v[i] = vv[0];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ d, const float* __restrict__ src, int64_t n, float scale) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = __fmaf_rn(src[i], scale, d[i]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ffh_concat_fwd(ffh_ctx* c, float* out, int64_t out_blk, const float* const* ins, const int64_t* in_blk,
+                   const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
+  return concat_impl<false>(c, out, out_blk, const_cast<float* const*>(reinterpret_cast<const float* const*>(ins)), in_blk, in_ld, n, nblk, s);
+}
+int ffh_concat_bwd(ffh_ctx* c, const float* og, int64_t out_blk, float* const* igs, const int64_t* in_blk,
+                   const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
+  return concat_impl<true>(c, const_cast<float*>(og), out_blk, igs, in_blk, in_ld, n, nblk, s);
+}
+
+int ffh_mse_bwd(ffh_ctx* c, float* lg, const float* logit, const float* label, int64_t n, float scale, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && ((lg && logit && label) || n == 0), "mse_bwd: bad args");
+  if (n == 0) return FFH_OK;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), lg, logit, label, n, scale);
+  FFH_LAUNCH_CHECK(c, "mse_bwd_kernel");
+  return FFH_OK;
+}
+
+int ffh_metrics_update(ffh_ctx* c, const float* logits, const float* labels, ffh_perf_metrics* perf,
+                       int64_t ns, int nc, int flags, ffh_stream s) {
+  FFH_REQUIRE(c, ns >= 0 && nc > 0 && perf && ((logits && labels) || ns == 0), "metrics_update: bad args");
+  if (ns == 0) return FFH_OK;
+  hipLaunchKernelGGL(metrics_kernel, dim3(ffh_grid(ns, 256, 256)), dim3(256), 0, as_stream(s), logits, labels, perf, ns, nc, flags);
+  FFH_LAUNCH_CHECK(c, "metrics_kernel");
+  return FFH_OK;
+}
+
+int ffh_sgd_update(ffh_ctx* c, float* w, const float* g, float* v, int64_t n, float lr, float wd, float mom, int nesterov, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && ((w && g) || n == 0), "sgd_update: bad args");
+  FFH_REQUIRE(c, !(mom > 0.f) || v, "sgd_update: momentum needs V");
+  if (n == 0) return FFH_OK;
+  const bool vec = al16(w) && al16(g) && (!(mom > 0.f) || al16(v)) && (n % 4 == 0);
+  if (vec) hipLaunchKernelGGL((sgd_kernel<4>), dim3(ffh_grid(n / 4, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov);
+  else hipLaunchKernelGGL((sgd_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov);
+  FFH_LAUNCH_CHECK(c, "sgd_kernel");
+  return FFH_OK;
+}
+
+int ffh_add_scaled(ffh_ctx* c, float* d, const float* src, int64_t n, float scale, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && ((d && src) || n == 0), "add_scaled: bad args");
+  if (n == 0) return FFH_OK;
+  hipLaunchKernelGGL(add_scaled_kernel, dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), d, src, n, scale);
+  FFH_LAUNCH_CHECK(c, "add_scaled_kernel");
+  return FFH_OK;
+}
+
+}  // extern "C"

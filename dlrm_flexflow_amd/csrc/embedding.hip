@@ -1,0 +1,660 @@
+// embedding.hip -- Embedding forward (gather + bag-sum), the reference's dense atomic
+// backward, and the fused backward + sparse SGD, hand-written for gfx950.
+//
+// HBM-bound integer/byte work.  Design rules applied:
+//   * a table row is read by `D/4` adjacent lanes with one 16-B load each, so a
+//     wave-instruction covers 64/(D/4) whole rows (512-B rows: two per instruction,
+//     64-B rows: sixteen) -- full-line coalesced reads and writes;
+//   * every lane-group keeps several independent row loads in flight (UNROLL);
+//   * all tables of a model go in ONE launch (grid.y = table) instead of the
+//     reference's one task per table;
+//   * 64-bit addressing everywhere (a 200M x 256 table is 204.8 GB; the reference's
+//     `int outputSize` [ref: src/ops/embedding.cu:226,229] would overflow);
+//   * the backward never materialises the dense [R][D] gradient: row ids are radix-sorted
+//     per table with LDS histograms and wave-ballot ranking, duplicate rows are reduced
+//     in registers by the lane-group that owns the run, and each touched row is
+//     read-modified-written exactly once.
+#include "ffh_common.h"
+
+#include <type_traits>
+
+namespace {
+
+constexpr int kMaxChunks = 4;   // row chunks per lane: D <= 4*64*4 = 1024 (vector) / 256 (scalar)
+
+struct EmbArgs {
+  ffh_emb_table t[FFH_MAX_TABLES];
+  int64_t batch;
+  int     ntables;
+  int     L;
+  int     D;
+  int     aggr;
+};
+
+// ---------------------------------------------------------------------------
+// forward: out[b][:] = sum_j W[idx[b][j]][:]
+// ---------------------------------------------------------------------------
+// VEC = floats per lane per access (4: 16-B accesses; 1: any D / alignment)
+template <int VEC, int UNROLL>
+__global__ __launch_bounds__(256) void emb_fwd_kernel(const EmbArgs a) {
+  using vec_t = typename std::conditional<VEC == 4, float4, float>::type;
+  const ffh_emb_table tb = a.t[blockIdx.y];
+  const int D = a.D, L = a.L;
+  const int nvec = D / VEC;                       // vectors per row
+  const int lpr = nvec < 64 ? nvec : 64;          // lanes per row
+  const int rpw = 64 / lpr;                       // rows per wave-instruction
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int rsub = lane / lpr;                    // which of the wave's rows
+  const int c0 = lane - rsub * lpr;               // first vector of the row for this lane
+  const bool active = rsub < rpw;
+  const int64_t rows_per_block = (int64_t)(blockDim.x >> 6) * rpw * UNROLL;
+  const float inv = 1.0f / (float)L;
+  const bool avg = a.aggr == FFH_AGGR_MODE_AVG;
+
+  for (int64_t base = (int64_t)blockIdx.x * rows_per_block; base < a.batch; base += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t b0 = base + (int64_t)wave * rpw * UNROLL + rsub;
+    for (int c = c0; c < nvec; c += lpr) {
+      float acc[UNROLL][VEC];
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++)
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[u][v] = 0.0f;
+      for (int j = 0; j < L; j++) {
+        int64_t row[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+          const int64_t b = b0 + (int64_t)u * rpw;
+          row[u] = (active && b < a.batch) ? tb.idx[b * L + j] : -1;
+        }
+        vec_t val[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+          if (row[u] >= 0) val[u] = reinterpret_cast<const vec_t*>(tb.weight + row[u] * (int64_t)D)[c];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+          if (row[u] >= 0) {
+            const float* f = reinterpret_cast<const float*>(&val[u]);
+#pragma unroll
+            for (int v = 0; v < VEC; v++) acc[u][v] = acc[u][v] + f[v];   // 0 + w first: (+0)+(-0) = +0 as the reference
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; u++) {
+        const int64_t b = b0 + (int64_t)u * rpw;
+        if (active && b < a.batch) {
+          vec_t o;
+          float* f = reinterpret_cast<float*>(&o);
+#pragma unroll
+          for (int v = 0; v < VEC; v++) f[v] = avg ? acc[u][v] * inv : acc[u][v];
+          reinterpret_cast<vec_t*>(tb.io + b * tb.ld)[c] = o;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// reference-parity dense backward: fp32 atomics into the full-table gradient.
+// One dword per lane, lanes contiguous along the row: each atomic wave-instruction is
+// 256 contiguous bytes, the shape the memory-side atomic units run at full rate.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emb_bwd_dense_kernel(const int64_t* __restrict__ idx, const float* __restrict__ g,
+                                                            float* __restrict__ wg, int L, int D, int64_t batch,
+                                                            int64_t gld, int avg) {
+  const int64_t total = batch * D;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / D;
+    const int off = (int)(i - b * D);
+    float gr = g[b * gld + off];
+    if (avg) gr = gr / (float)L;
+    for (int j = 0; j < L; j++) {
+      const int64_t row = idx[b * L + j];
+      atomicAdd(wg + row * (int64_t)D + off, gr);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fused backward + SGD, step 1: per-table stable LSD radix sort of (row id, position)
+// ---------------------------------------------------------------------------
+constexpr int kSortThreads = 256;
+constexpr int kSortPerThread = 8;
+constexpr int kSortTile = kSortThreads * kSortPerThread;   // 2048 entries per workgroup
+constexpr int kMaxRadixBits = 9;
+constexpr int kMaxRadix = 1 << kMaxRadixBits;
+
+struct SortArgs {
+  const int64_t* idx[FFH_MAX_TABLES];   // pass 0 source
+  uint32_t* keys_src;                   // [nt][N]
+  uint32_t* pos_src;
+  uint32_t* keys_dst;
+  uint32_t* pos_dst;
+  uint32_t* hist;                       // [nt][nblk][radix]
+  int64_t   N;                          // entries per table (batch * L)
+  int       nblk;
+  int       shift;
+  int       bits;
+};
+
+template <bool FIRST>
+__device__ __forceinline__ uint32_t sort_load_key(const SortArgs& a, int t, int64_t i) {
+  if (FIRST) return (uint32_t)a.idx[t][i];
+  return a.keys_src[(int64_t)t * a.N + i];
+}
+
+// histogram of the current digit per 2048-entry tile (LDS-staged bucketing)
+template <bool FIRST>
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const SortArgs a) {
+  __shared__ uint32_t s_hist[kMaxRadix];
+  const int t = blockIdx.y, blk = blockIdx.x;
+  const int radix = 1 << a.bits;
+  const uint32_t mask = radix - 1;
+  for (int d = threadIdx.x; d < radix; d += kSortThreads) s_hist[d] = 0;
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blk * kSortTile;
+#pragma unroll
+  for (int e = 0; e < kSortPerThread; e++) {
+    const int64_t i = tile0 + e * kSortThreads + threadIdx.x;
+    if (i < a.N) atomicAdd(&s_hist[(sort_load_key<FIRST>(a, t, i) >> a.shift) & mask], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = a.hist + ((int64_t)t * a.nblk + blk) * radix;
+  for (int d = threadIdx.x; d < radix; d += kSortThreads) out[d] = s_hist[d];
+}
+
+// stable scatter.  Each wave owns 512 consecutive entries of the tile and ranks them 64 at a
+// time: the lanes holding the same digit find each other with `bits` ballots (a match-any),
+// the rank inside the group is a popcount of the lower lanes, and the group's lowest lane
+// advances the wave's running offset in LDS.
+template <bool FIRST>
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortArgs a) {
+  __shared__ uint32_t s_off[4][kMaxRadix];
+  __shared__ uint32_t s_scan[kMaxRadix];
+  __shared__ uint32_t s_wsum[4];
+  const int t = blockIdx.y, blk = blockIdx.x;
+  const int radix = 1 << a.bits;
+  const uint32_t mask = radix - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile0 = (int64_t)blk * kSortTile;
+
+  for (int d = threadIdx.x; d < 4 * kMaxRadix; d += kSortThreads) (&s_off[0][0])[d] = 0;
+  __syncthreads();
+
+  uint32_t key[kSortPerThread], pos[kSortPerThread];
+  bool valid[kSortPerThread];
+#pragma unroll
+  for (int e = 0; e < kSortPerThread; e++) {
+    const int64_t i = tile0 + wave * (kSortTile / 4) + e * 64 + lane;
+    valid[e] = i < a.N;
+    key[e] = valid[e] ? sort_load_key<FIRST>(a, t, i) : 0u;
+    pos[e] = valid[e] ? (FIRST ? (uint32_t)i : a.pos_src[(int64_t)t * a.N + i]) : 0u;
+    if (valid[e]) atomicAdd(&s_off[wave][(key[e] >> a.shift) & mask], 1u);
+  }
+  __syncthreads();
+
+  // global base of every digit for this tile: digits below (all tiles) + same digit, earlier tiles
+  const uint32_t* hist_t = a.hist + (int64_t)t * a.nblk * radix;
+  uint32_t all_d[2] = {0, 0}, before_d[2] = {0, 0};
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int d = threadIdx.x + q * kSortThreads;
+    if (d < radix) {
+      uint32_t all = 0, before = 0;
+      for (int b2 = 0; b2 < a.nblk; b2++) {
+        const uint32_t h = hist_t[(int64_t)b2 * radix + d];
+        all += h;
+        if (b2 < blk) before += h;
+      }
+      all_d[q] = all; before_d[q] = before;
+    }
+  }
+  // exclusive scan of all_d over digits (digit d = threadIdx.x + q*256): scan q=0 half, then q=1 half
+  uint32_t carry = 0;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (q * kSortThreads >= radix) break;
+    uint32_t v = all_d[q];
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t n = __shfl_up(incl, o);
+      if (lane >= o) incl += n;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w2 = 0; w2 < wave; w2++) woff += s_wsum[w2];
+    const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    const int d = threadIdx.x + q * kSortThreads;
+    if (d < radix) s_scan[d] = carry + woff + incl - v + before_d[q];
+    carry += total;
+    __syncthreads();
+  }
+  // per-wave starting offsets: base + counts of the earlier waves
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int d = threadIdx.x + q * kSortThreads;
+    if (d < radix) {
+      uint32_t run = s_scan[d];
+#pragma unroll
+      for (int w2 = 0; w2 < 4; w2++) {
+        const uint32_t cnt = s_off[w2][d];
+        s_off[w2][d] = run;
+        run += cnt;
+      }
+    }
+  }
+  __syncthreads();
+
+  volatile uint32_t* my_off = s_off[wave];
+  uint32_t* kd = a.keys_dst + (int64_t)t * a.N;
+  uint32_t* pd = a.pos_dst + (int64_t)t * a.N;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int e = 0; e < kSortPerThread; e++) {
+    const uint32_t d = (key[e] >> a.shift) & mask;
+    unsigned long long peers = __ballot(valid[e]);
+    for (int bit = 0; bit < a.bits; bit++) {
+      const bool one = (d >> bit) & 1u;
+      const unsigned long long bal = __ballot(one);
+      peers &= one ? bal : ~bal;
+    }
+    if (valid[e]) {
+      const uint32_t base = my_off[d];
+      const uint32_t rank = __popcll(peers & lt_mask);
+      const uint32_t dest = base + rank;
+      kd[dest] = key[e];
+      pd[dest] = pos[e];
+      if (rank == 0) my_off[d] = base + __popcll(peers);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fused backward + SGD, step 2: segmented reduce of the sorted list + row update
+// ---------------------------------------------------------------------------
+constexpr int kRedThreads = 256;
+constexpr int kRedTile = 1024;                        // sorted entries per workgroup (multiple of FFH_EMB_CHUNK)
+constexpr int kRedChunksPerTile = kRedTile / FFH_EMB_CHUNK;
+static_assert(kRedTile % FFH_EMB_CHUNK == 0, "tile must hold whole chunks");
+
+enum : uint32_t { kMetaNone = 0, kMetaFirst = 1, kMetaCont = 2 };
+
+struct RedArgs {
+  ffh_emb_table t[FFH_MAX_TABLES];
+  const uint32_t* keys;     // sorted [nt][N]
+  const uint32_t* pos;
+  float*    partial;        // [nt][2*nchunks][D]
+  uint2*    meta;           // [nt][2*nchunks] {kind, key}
+  int64_t   N;
+  int       nchunks;
+  int       L;
+  int       D;
+  int       avg;
+  float     lr;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_grad(float (&dst)[VEC], const float* rowp, int c, float invdiv, bool avg) {
+  if (VEC == 4) {
+    const float4 v = reinterpret_cast<const float4*>(rowp)[c];
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  } else {
+    dst[0] = rowp[c];
+  }
+  if (avg) {
+#pragma unroll
+    for (int v = 0; v < VEC; v++) dst[v] = dst[v] / invdiv;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedArgs a) {
+  __shared__ uint32_t s_key[kRedTile + 2];     // [0] = key before the tile, [1+i], [1+n] = key after
+  __shared__ uint32_t s_pos[kRedTile];
+  __shared__ uint16_t s_start[kRedTile + 1];
+  __shared__ uint32_t s_cnt[(kRedTile / 64) + 1];
+  __shared__ uint2    s_meta[2 * kRedChunksPerTile];
+
+  const int tix = blockIdx.y;
+  const ffh_emb_table tb = a.t[tix];
+  const int64_t N = a.N;
+  const int64_t tile0 = (int64_t)blockIdx.x * kRedTile;
+  const int n = (int)((N - tile0) < kRedTile ? (N - tile0) : kRedTile);
+  const uint32_t* keys = a.keys + (int64_t)tix * N;
+  const uint32_t* posg = a.pos + (int64_t)tix * N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  for (int i = threadIdx.x; i < n; i += kRedThreads) {
+    s_key[1 + i] = keys[tile0 + i];
+    s_pos[i] = posg[tile0 + i];
+  }
+  if (threadIdx.x == 0) {
+    s_key[0] = tile0 > 0 ? keys[tile0 - 1] : 0xFFFFFFFFu;            // no valid key equals it when tile0 == 0 (checked below)
+    s_key[1 + n] = (tile0 + n < N) ? keys[tile0 + n] : 0xFFFFFFFFu;
+  }
+  if (threadIdx.x < 2 * kRedChunksPerTile) s_meta[threadIdx.x] = make_uint2(kMetaNone, 0);
+  __syncthreads();
+
+  // sub-run starts: chunk boundaries and changes of row id; compacted in order
+  // entry handled by (wave, e, lane) = wave*256 + e*64 + lane keeps the list sorted
+  const bool at_table_start = tile0 == 0;
+  bool st[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int i = wave * 256 + e * 64 + lane;
+    bool s = false;
+    if (i < n) s = (i % FFH_EMB_CHUNK == 0) || (s_key[1 + i] != s_key[i]) || (i == 0 && at_table_start);
+    st[e] = s;
+    const unsigned long long bal = __ballot(s);
+    if (lane == 0) s_cnt[wave * 4 + e] = __popcll(bal);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int q = 0; q < kRedTile / 64; q++) { const uint32_t c = s_cnt[q]; s_cnt[q] = run; run += c; }
+    s_cnt[kRedTile / 64] = run;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const int i = wave * 256 + e * 64 + lane;
+    const unsigned long long bal = __ballot(st[e]);
+    if (st[e]) s_start[s_cnt[wave * 4 + e] + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+  }
+  const int S = (int)s_cnt[kRedTile / 64];
+  if (threadIdx.x == 0) s_start[S] = (uint16_t)n;
+  __syncthreads();
+
+  // lane-groups walk the sub-runs
+  const int D = a.D;
+  const int nvec = D / VEC;
+  const int lpr = nvec < 64 ? nvec : 64;
+  const int rpw = 64 / lpr;
+  const int rsub = lane / lpr;
+  const int c0 = lane - rsub * lpr;
+  const int groups = (kRedThreads / 64) * rpw;
+  const int gid = wave * rpw + rsub;
+  const float Lf = (float)a.L;
+  const bool avg = a.avg != 0;
+
+  if (rsub < rpw) {
+    for (int k = gid; k < S; k += groups) {
+      const int s = s_start[k], e = s_start[k + 1];
+      const uint32_t key = s_key[1 + s];
+      const bool head = (s_key[s] != key) || (s == 0 && at_table_start);
+      const bool tail = (s_key[1 + e] != key) || (tile0 + e >= N);
+      const int64_t chunk = (tile0 + s) / FFH_EMB_CHUNK;
+      const int slot_local = (int)(chunk - tile0 / FFH_EMB_CHUNK) * 2 + ((s % FFH_EMB_CHUNK) ? 1 : 0);
+      const bool single = head && tail;
+      if (!single && c0 == 0) s_meta[slot_local] = make_uint2(head ? kMetaFirst : kMetaCont, key);
+      float* wrow = tb.weight + (int64_t)key * D;
+      float* prow = a.partial + (((int64_t)tix * a.nchunks + chunk) * 2 + ((s % FFH_EMB_CHUNK) ? 1 : 0)) * D;
+      for (int c = c0; c < nvec; c += lpr) {
+        float acc[VEC];
+        load_grad<VEC>(acc, tb.io + (int64_t)(s_pos[s] / a.L) * tb.ld, c, Lf, avg);
+        int q = s + 1;
+        // four independent row loads in flight, summed in order
+        for (; q + 4 <= e; q += 4) {
+          float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+          load_grad<VEC>(v0, tb.io + (int64_t)(s_pos[q] / a.L) * tb.ld, c, Lf, avg);
+          load_grad<VEC>(v1, tb.io + (int64_t)(s_pos[q + 1] / a.L) * tb.ld, c, Lf, avg);
+          load_grad<VEC>(v2, tb.io + (int64_t)(s_pos[q + 2] / a.L) * tb.ld, c, Lf, avg);
+          load_grad<VEC>(v3, tb.io + (int64_t)(s_pos[q + 3] / a.L) * tb.ld, c, Lf, avg);
+#pragma unroll
+          for (int v = 0; v < VEC; v++) acc[v] = (((acc[v] + v0[v]) + v1[v]) + v2[v]) + v3[v];
+        }
+        for (; q < e; q++) {
+          float v0[VEC];
+          load_grad<VEC>(v0, tb.io + (int64_t)(s_pos[q] / a.L) * tb.ld, c, Lf, avg);
+#pragma unroll
+          for (int v = 0; v < VEC; v++) acc[v] = acc[v] + v0[v];
+        }
+        if (single) {
+          if (VEC == 4) {
+            float4 w = reinterpret_cast<float4*>(wrow)[c];
+            w.x = __fmaf_rn(-a.lr, acc[0], w.x); w.y = __fmaf_rn(-a.lr, acc[1], w.y);
+            w.z = __fmaf_rn(-a.lr, acc[2], w.z); w.w = __fmaf_rn(-a.lr, acc[3], w.w);
+            reinterpret_cast<float4*>(wrow)[c] = w;
+          } else {
+            wrow[c] = __fmaf_rn(-a.lr, acc[0], wrow[c]);
+          }
+        } else {
+          if (VEC == 4) reinterpret_cast<float4*>(prow)[c] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+          else prow[c] = acc[0];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * kRedChunksPerTile) {
+    const int64_t slot = (tile0 / FFH_EMB_CHUNK) * 2 + threadIdx.x;
+    if (slot < 2 * (int64_t)a.nchunks) a.meta[(int64_t)tix * 2 * a.nchunks + slot] = s_meta[threadIdx.x];
+  }
+}
+
+// step 3: rows whose run crosses chunk boundaries: add the per-chunk partials left to right
+template <int VEC>
+__global__ __launch_bounds__(256) void emb_sgd_combine_kernel(const RedArgs a) {
+  const int tix = blockIdx.y;
+  const ffh_emb_table tb = a.t[tix];
+  const int D = a.D;
+  const int nvec = D / VEC;
+  const int lpr = nvec < 64 ? nvec : 64;
+  const int rpw = 64 / lpr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rsub = lane / lpr;
+  const int c0 = lane - rsub * lpr;
+  if (rsub >= rpw) return;
+  const int64_t nslots = 2 * (int64_t)a.nchunks;
+  const uint2* meta = a.meta + (int64_t)tix * nslots;
+  const float* part = a.partial + (int64_t)tix * nslots * D;
+  const int64_t groups = (int64_t)gridDim.x * (blockDim.x >> 6) * rpw;
+  for (int64_t slot = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * rpw + rsub; slot < nslots; slot += groups) {
+    const uint2 m = meta[slot];
+    if (m.x != kMetaFirst) continue;
+    float* wrow = tb.weight + (int64_t)m.y * D;
+    for (int c = c0; c < nvec; c += lpr) {
+      float acc[VEC];
+      load_grad<VEC>(acc, part + slot * D, c, 1.0f, false);
+      for (int64_t s2 = (slot / 2 + 1) * 2; s2 < nslots; s2 += 2) {
+        const uint2 m2 = meta[s2];
+        if (m2.x != kMetaCont || m2.y != m.y) break;
+        float v0[VEC];
+        load_grad<VEC>(v0, part + s2 * D, c, 1.0f, false);
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[v] = acc[v] + v0[v];
+      }
+      if (VEC == 4) {
+        float4 w = reinterpret_cast<float4*>(wrow)[c];
+        w.x = __fmaf_rn(-a.lr, acc[0], w.x); w.y = __fmaf_rn(-a.lr, acc[1], w.y);
+        w.z = __fmaf_rn(-a.lr, acc[2], w.z); w.w = __fmaf_rn(-a.lr, acc[3], w.w);
+        reinterpret_cast<float4*>(wrow)[c] = w;
+      } else {
+        wrow[c] = __fmaf_rn(-a.lr, acc[0], wrow[c]);
+      }
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct BwdLayout {
+  size_t keys_a, pos_a, keys_b, pos_b, hist, partial, meta, total;
+  int nblk, nchunks;
+};
+
+inline BwdLayout bwd_layout(int nt, int L, int D, int64_t batch) {
+  BwdLayout l;
+  const int64_t N = batch * L;
+  l.nblk = (int)((N + kSortTile - 1) / kSortTile);
+  l.nchunks = (int)((N + FFH_EMB_CHUNK - 1) / FFH_EMB_CHUNK);
+  const size_t arr = align_up((size_t)nt * (size_t)N * sizeof(uint32_t), 256);
+  size_t o = 0;
+  l.keys_a = o; o += arr;
+  l.pos_a = o; o += arr;
+  l.keys_b = o; o += arr;
+  l.pos_b = o; o += arr;
+  l.hist = o; o += align_up((size_t)nt * (size_t)l.nblk * kMaxRadix * sizeof(uint32_t), 256);
+  l.partial = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks * (size_t)D * sizeof(float), 256);
+  l.meta = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks * sizeof(uint2), 256);
+  l.total = o;
+  return l;
+}
+
+int validate_tables(ffh_ctx* c, const ffh_emb_table* t, int nt, int L, int D, int64_t batch, int aggr, const char* who) {
+  if (nt < 0 || nt > FFH_MAX_TABLES) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: ntables out of range");
+  if (L <= 0 || D <= 0 || batch < 0) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: bad dims");
+  if (aggr != FFH_AGGR_MODE_SUM && aggr != FFH_AGGR_MODE_AVG) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: aggr must be SUM or AVG");
+  for (int i = 0; i < nt; i++) {
+    if (!t[i].idx || !t[i].weight || !t[i].io) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: null pointer");
+    if (t[i].ld < D || t[i].num_entries <= 0) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: ld < out_dim or num_entries <= 0");
+  }
+  (void)who;
+  return FFH_OK;
+}
+
+bool can_vec4(const ffh_emb_table* t, int nt, int D) {
+  if (D % 4) return false;
+  for (int i = 0; i < nt; i++)
+    if (!aligned16(t[i].weight) || !aligned16(t[i].io) || (t[i].ld % 4)) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ffh_embedding_fwd_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch, int aggr, ffh_stream s) {
+  int rc = validate_tables(c, tables, nt, L, D, batch, aggr, "embedding_fwd");
+  if (rc) return rc;
+  if (nt == 0 || batch == 0) return FFH_OK;
+  const bool v4 = can_vec4(tables, nt, D);
+  const int nvec = v4 ? D / 4 : D;
+  if ((nvec + 63) / 64 > kMaxChunks * 64) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "embedding_fwd: out_dim too large");
+  EmbArgs a;
+  memset(&a, 0, sizeof a);
+  for (int i = 0; i < nt; i++) a.t[i] = tables[i];
+  a.batch = batch; a.ntables = nt; a.L = L; a.D = D; a.aggr = aggr;
+  const int lpr = nvec < 64 ? nvec : 64;
+  const int rpw = 64 / lpr;
+  constexpr int U = 4;
+  const int64_t rows_per_block = 4LL * rpw * U;
+  // fill 256 CUs x 8 workgroups across all tables, grid-stride the rest
+  int64_t gx = (batch + rows_per_block - 1) / rows_per_block;
+  const int64_t cap = 4096 / nt > 0 ? 4096 / nt : 1;
+  if (gx > cap) gx = cap;
+  dim3 grid((unsigned)gx, (unsigned)nt);
+  if (v4) hipLaunchKernelGGL((emb_fwd_kernel<4, U>), grid, dim3(256), 0, as_stream(s), a);
+  else hipLaunchKernelGGL((emb_fwd_kernel<1, U>), grid, dim3(256), 0, as_stream(s), a);
+  FFH_LAUNCH_CHECK(c, "emb_fwd_kernel");
+  return FFH_OK;
+}
+
+int ffh_embedding_fwd(ffh_ctx* c, const int64_t* idx, float* out, const float* weight, int L, int D, int64_t batch,
+                      int64_t num_entries, int64_t out_ld, int aggr, ffh_stream s) {
+  ffh_emb_table t{idx, const_cast<float*>(weight), out, num_entries, out_ld};
+  return ffh_embedding_fwd_multi(c, &t, 1, L, D, batch, aggr, s);
+}
+
+int ffh_embedding_bwd_dense(ffh_ctx* c, const int64_t* idx, const float* g, float* wg, int L, int D, int64_t batch,
+                            int64_t num_entries, int64_t gld, int aggr, ffh_stream s) {
+  ffh_emb_table t{idx, wg, const_cast<float*>(g), num_entries, gld};
+  int rc = validate_tables(c, &t, 1, L, D, batch, aggr, "embedding_bwd_dense");
+  if (rc) return rc;
+  if (batch == 0) return FFH_OK;
+  hipLaunchKernelGGL(emb_bwd_dense_kernel, dim3(ffh_grid(batch * D, 256, 4096)), dim3(256), 0, as_stream(s),
+                     idx, g, wg, L, D, batch, gld, aggr == FFH_AGGR_MODE_AVG ? 1 : 0);
+  FFH_LAUNCH_CHECK(c, "emb_bwd_dense_kernel");
+  return FFH_OK;
+}
+
+size_t ffh_embedding_bwd_workspace_bytes(int nt, int L, int D, int64_t batch) {
+  if (nt <= 0 || L <= 0 || D <= 0 || batch <= 0) return 0;
+  return bwd_layout(nt, L, D, batch).total;
+}
+
+int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch,
+                                      int aggr, float lr, ffh_stream s) {
+  int rc = validate_tables(c, tables, nt, L, D, batch, aggr, "embedding_bwd_sgd_fused");
+  if (rc) return rc;
+  if (nt == 0 || batch == 0) return FFH_OK;
+  const int64_t N = batch * L;
+  if (N >= (1LL << 31)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "embedding_bwd_sgd_fused: batch*in_dim >= 2^31");
+  int64_t maxR = 1;
+  for (int i = 0; i < nt; i++) maxR = tables[i].num_entries > maxR ? tables[i].num_entries : maxR;
+  if (maxR > (1LL << 32)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "embedding_bwd_sgd_fused: num_entries > 2^32");
+  const bool v4 = can_vec4(tables, nt, D);
+  const int nvec = v4 ? D / 4 : D;
+  if ((nvec + 63) / 64 > kMaxChunks * 64) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "embedding_bwd_sgd_fused: out_dim too large");
+  const BwdLayout lay = bwd_layout(nt, L, D, batch);
+  if (!c->ws || c->ws_bytes < lay.total) return ffh_fail(c, FFH_ERR_WORKSPACE, "embedding_bwd_sgd_fused: workspace too small (ffh_embedding_bwd_workspace_bytes)");
+  char* ws = (char*)c->ws;
+  if (!aligned16(ws)) return ffh_fail(c, FFH_ERR_WORKSPACE, "embedding_bwd_sgd_fused: workspace must be 16-byte aligned");
+
+  // radix plan: digits of <= 9 bits covering bit_length(maxR-1)
+  int bits = 1;
+  while (bits < 32 && ((maxR - 1) >> bits) != 0) bits++;
+  const int passes = (bits + kMaxRadixBits - 1) / kMaxRadixBits;
+  const int rb = (bits + passes - 1) / passes;
+
+  SortArgs sa;
+  memset(&sa, 0, sizeof sa);
+  for (int i = 0; i < nt; i++) sa.idx[i] = tables[i].idx;
+  sa.hist = (uint32_t*)(ws + lay.hist);
+  sa.N = N; sa.nblk = lay.nblk; sa.bits = rb;
+  uint32_t* kbuf[2] = {(uint32_t*)(ws + lay.keys_a), (uint32_t*)(ws + lay.keys_b)};
+  uint32_t* pbuf[2] = {(uint32_t*)(ws + lay.pos_a), (uint32_t*)(ws + lay.pos_b)};
+  dim3 sgrid((unsigned)lay.nblk, (unsigned)nt);
+  int cur = 0;   // buffer holding the output of the previous pass
+  for (int p = 0; p < passes; p++) {
+    sa.shift = p * rb;
+    sa.keys_src = kbuf[cur]; sa.pos_src = pbuf[cur];
+    sa.keys_dst = kbuf[cur ^ 1]; sa.pos_dst = pbuf[cur ^ 1];
+    if (p == 0) {
+      hipLaunchKernelGGL((radix_hist_kernel<true>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
+      hipLaunchKernelGGL((radix_scatter_kernel<true>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
+    } else {
+      hipLaunchKernelGGL((radix_hist_kernel<false>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
+      hipLaunchKernelGGL((radix_scatter_kernel<false>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
+    }
+    cur ^= 1;
+  }
+  FFH_LAUNCH_CHECK(c, "radix sort");
+
+  RedArgs ra;
+  memset(&ra, 0, sizeof ra);
+  for (int i = 0; i < nt; i++) ra.t[i] = tables[i];
+  ra.keys = kbuf[cur]; ra.pos = pbuf[cur];
+  ra.partial = (float*)(ws + lay.partial);
+  ra.meta = (uint2*)(ws + lay.meta);
+  ra.N = N; ra.nchunks = lay.nchunks; ra.L = L; ra.D = D;
+  ra.avg = aggr == FFH_AGGR_MODE_AVG ? 1 : 0;
+  ra.lr = lr;
+  dim3 rgrid((unsigned)((N + kRedTile - 1) / kRedTile), (unsigned)nt);
+  const int lpr = nvec < 64 ? nvec : 64;
+  const int64_t cgroups = 2LL * lay.nchunks;
+  dim3 cgrid((unsigned)ffh_grid(cgroups, 4 * (64 / lpr), 1024), (unsigned)nt);
+  if (v4) {
+    hipLaunchKernelGGL((emb_sgd_reduce_kernel<4>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
+    hipLaunchKernelGGL((emb_sgd_combine_kernel<4>), cgrid, dim3(256), 0, as_stream(s), ra);
+  } else {
+    hipLaunchKernelGGL((emb_sgd_reduce_kernel<1>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
+    hipLaunchKernelGGL((emb_sgd_combine_kernel<1>), cgrid, dim3(256), 0, as_stream(s), ra);
+  }
+  FFH_LAUNCH_CHECK(c, "emb_sgd_reduce/combine");
+  return FFH_OK;
+}
+
+int ffh_embedding_bwd_sgd_fused(ffh_ctx* c, const int64_t* idx, const float* g, float* weight, int L, int D, int64_t batch,
+                                int64_t num_entries, int64_t gld, int aggr, float lr, ffh_stream s) {
+  ffh_emb_table t{idx, weight, const_cast<float*>(g), num_entries, gld};
+  return ffh_embedding_bwd_sgd_fused_multi(c, &t, 1, L, D, batch, aggr, lr, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// ffh_common.h -- internals shared by the HIP translation units of libffhip.so
+// (gfx950 / MI355X only; wave = 64 lanes, 256 CUs in 8 XCDs, 160 KiB LDS per CU).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ff_hip.h"
+#include "../../include/ffh_rng.h"
+
+struct ffh_ctx {
+  int         device;
+  void*       ws;        // caller-attached scratch (FFHandler.workSpace analogue)
+  size_t      ws_bytes;
+  int         num_cus;
+  char        err[512];
+};
+
+static inline int ffh_fail(ffh_ctx* c, int code, const char* msg) {
+  if (c) snprintf(c->err, sizeof c->err, "%s", msg);
+  return code;
+}
+
+static inline int ffh_fail_hip(ffh_ctx* c, hipError_t e, const char* what) {
+  if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
+  return FFH_ERR_HIP;
+}
+
+#define FFH_HIP_TRY(ctx, expr)                                  \
+  do {                                                          \
+    hipError_t e__ = (expr);                                    \
+    if (e__ != hipSuccess) return ffh_fail_hip((ctx), e__, #expr); \
+  } while (0)
+
+// after a kernel launch: surface launch-configuration errors without synchronising
+#define FFH_LAUNCH_CHECK(ctx, name)                             \
+  do {                                                          \
+    hipError_t e__ = hipGetLastError();                         \
+    if (e__ != hipSuccess) return ffh_fail_hip((ctx), e__, name); \
+  } while (0)
+
+#define FFH_REQUIRE(ctx, cond, msg)                             \
+  do {                                                          \
+    if (!(cond)) return ffh_fail((ctx), FFH_ERR_BAD_ARG, msg);  \
+  } while (0)
+
+static inline hipStream_t as_stream(ffh_stream s) { return (hipStream_t)s; }
+
+// grid sizing for memory-bound grid-stride kernels: enough workgroups to fill
+// 256 CUs x 8 blocks, capped (cdna guide, Guideline 11)
+static inline unsigned ffh_grid(int64_t work_items, int per_block, unsigned cap = 2048) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > (int64_t)cap) g = cap;
+  return (unsigned)g;
+}
+
+constexpr int kWave = 64;

@@ -1,0 +1,212 @@
+// runtime.hip -- context, memory, streams/events/graphs and the fill / RNG kernels of
+// libffhip.so.  What Legion/Realm give the reference's operator tasks (device memory
+// in regions, a per-task stream [ref: src/runtime/cuda_helper.cu:5-31], trace replay
+// [ref: examples/cpp/DLRM/dlrm.cc:174-181]) is exposed here as plain HIP objects.
+#include "ffh_common.h"
+
+#include <new>
+
+extern "C" {
+
+int         ffh_abi_version(void) { return FFH_ABI_VERSION; }
+const char* ffh_backend_name(void) { return "hip-gfx950"; }
+
+int ffh_ctx_create(ffh_ctx** out, int device) {
+  if (!out) return FFH_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return FFH_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return FFH_ERR_HIP;
+  ffh_ctx* c = new (std::nothrow) ffh_ctx();
+  if (!c) return FFH_ERR_NOMEM;
+  memset(c, 0, sizeof *c);
+  c->device = device;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) == hipSuccess) c->num_cus = p.multiProcessorCount;
+  if (c->num_cus <= 0) c->num_cus = 256;
+  *out = c;
+  return FFH_OK;
+}
+
+int ffh_ctx_destroy(ffh_ctx* c) { delete c; return FFH_OK; }
+
+const char* ffh_last_error_string(const ffh_ctx* c) { return c ? c->err : "null ctx"; }
+
+int ffh_device_query(ffh_ctx* c, ffh_device_info* info) {
+  if (!c || !info) return FFH_ERR_BAD_ARG;
+  memset(info, 0, sizeof *info);
+  hipDeviceProp_t p;
+  FFH_HIP_TRY(c, hipGetDeviceProperties(&p, c->device));
+  snprintf(info->name, sizeof info->name, "%s", p.name);
+  snprintf(info->arch, sizeof info->arch, "%s", p.gcnArchName);
+  info->compute_units = p.multiProcessorCount;
+  info->wavefront_size = p.warpSize;
+  info->total_mem_bytes = (int64_t)p.totalGlobalMem;
+  info->lds_bytes_per_cu = (int32_t)p.maxSharedMemoryPerMultiProcessor;
+  info->clock_khz = p.clockRate;
+  return FFH_OK;
+}
+
+int ffh_ctx_set_workspace(ffh_ctx* c, void* ws, size_t bytes) {
+  if (!c) return FFH_ERR_BAD_ARG;
+  c->ws = ws;
+  c->ws_bytes = bytes;
+  return FFH_OK;
+}
+
+int ffh_malloc(ffh_ctx* c, void** p, size_t bytes) {
+  if (!c || !p) return FFH_ERR_BAD_ARG;
+  *p = nullptr;
+  hipError_t e = hipMalloc(p, bytes ? bytes : 256);
+  if (e != hipSuccess) { ffh_fail_hip(c, e, "hipMalloc"); return FFH_ERR_NOMEM; }
+  return FFH_OK;
+}
+int ffh_free(ffh_ctx* c, void* p) { if (p) FFH_HIP_TRY(c, hipFree(p)); return FFH_OK; }
+int ffh_memcpy_h2d(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) {
+  FFH_HIP_TRY(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, as_stream(st))); return FFH_OK; }
+int ffh_memcpy_d2h(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) {
+  FFH_HIP_TRY(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, as_stream(st))); return FFH_OK; }
+int ffh_memcpy_d2d(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) {
+  FFH_HIP_TRY(c, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, as_stream(st))); return FFH_OK; }
+
+int ffh_stream_create(ffh_ctx* c, ffh_stream* s) {
+  if (!s) return FFH_ERR_BAD_ARG;
+  hipStream_t st;
+  FFH_HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *s = (ffh_stream)st;
+  return FFH_OK;
+}
+int ffh_stream_destroy(ffh_ctx* c, ffh_stream s) { if (s) FFH_HIP_TRY(c, hipStreamDestroy(as_stream(s))); return FFH_OK; }
+int ffh_stream_sync(ffh_ctx* c, ffh_stream s) { FFH_HIP_TRY(c, hipStreamSynchronize(as_stream(s))); return FFH_OK; }
+int ffh_device_sync(ffh_ctx* c) { FFH_HIP_TRY(c, hipDeviceSynchronize()); return FFH_OK; }
+
+int ffh_event_create(ffh_ctx* c, ffh_event* e) {
+  if (!e) return FFH_ERR_BAD_ARG;
+  hipEvent_t ev;
+  FFH_HIP_TRY(c, hipEventCreate(&ev));
+  *e = (ffh_event)ev;
+  return FFH_OK;
+}
+int ffh_event_destroy(ffh_ctx* c, ffh_event e) { if (e) FFH_HIP_TRY(c, hipEventDestroy((hipEvent_t)e)); return FFH_OK; }
+int ffh_event_record(ffh_ctx* c, ffh_event e, ffh_stream s) { FFH_HIP_TRY(c, hipEventRecord((hipEvent_t)e, as_stream(s))); return FFH_OK; }
+int ffh_event_sync(ffh_ctx* c, ffh_event e) { FFH_HIP_TRY(c, hipEventSynchronize((hipEvent_t)e)); return FFH_OK; }
+int ffh_stream_wait_event(ffh_ctx* c, ffh_stream s, ffh_event e) { FFH_HIP_TRY(c, hipStreamWaitEvent(as_stream(s), (hipEvent_t)e, 0)); return FFH_OK; }
+int ffh_event_elapsed_ms(ffh_ctx* c, ffh_event a, ffh_event b, float* ms) {
+  if (!ms) return FFH_ERR_BAD_ARG;
+  FFH_HIP_TRY(c, hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return FFH_OK;
+}
+
+// The reference memoises its task graph with Legion traces (begin_trace/end_trace(111),
+// [ref: examples/cpp/DLRM/dlrm.cc:174-181]); the MI355X counterpart is a captured hipGraph.
+int ffh_graph_begin_capture(ffh_ctx* c, ffh_stream s) {
+  FFH_HIP_TRY(c, hipStreamBeginCapture(as_stream(s), hipStreamCaptureModeThreadLocal));
+  return FFH_OK;
+}
+int ffh_graph_end_capture(ffh_ctx* c, ffh_stream s, ffh_graph* g) {
+  if (!g) return FFH_ERR_BAD_ARG;
+  hipGraph_t graph = nullptr;
+  FFH_HIP_TRY(c, hipStreamEndCapture(as_stream(s), &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) return ffh_fail_hip(c, e, "hipGraphInstantiate");
+  *g = (ffh_graph)exec;
+  return FFH_OK;
+}
+int ffh_graph_launch(ffh_ctx* c, ffh_graph g, ffh_stream s) {
+  FFH_HIP_TRY(c, hipGraphLaunch((hipGraphExec_t)g, as_stream(s)));
+  return FFH_OK;
+}
+int ffh_graph_destroy(ffh_ctx* c, ffh_graph g) { if (g) FFH_HIP_TRY(c, hipGraphExecDestroy((hipGraphExec_t)g)); return FFH_OK; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// fill / RNG kernels: pure streaming stores, 16 B per lane
+// ---------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, int64_t n, float v) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const float4 v4 = make_float4(v, v, v, v);
+  for (int64_t k = i; k < n4; k += stride) p4[k] = v4;
+  for (int64_t k = (n4 << 2) + i; k < n; k += stride) p[k] = v;
+}
+
+template <int MODE>  // 0 uniform(lo,hi), 1 u24 in [0,1), 2 bernoulli
+__global__ __launch_bounds__(256) void gen_f32_kernel(float* __restrict__ p, int64_t n, uint64_t seed, int64_t first, float lo, float hi) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t h = ffh_hash(seed, (uint64_t)(first + i));
+    float v;
+    if (MODE == 0) v = ffh_uniform(h, lo, hi);
+    else if (MODE == 1) v = ffh_u24(h);
+    else v = ffh_bernoulli(h);
+    p[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void gen_idx_kernel(int64_t* __restrict__ p, int64_t n, uint64_t seed, int64_t first, int64_t R) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    p[i] = ffh_index(ffh_hash(seed, (uint64_t)(first + i)), R);
+}
+
+}  // namespace
+
+extern "C" {
+
+// assign_kernel [ref: src/runtime/cuda_helper.cu:52-60]
+int ffh_fill_f32(ffh_ctx* c, float* p, int64_t n, float v, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && (p || n == 0), "fill_f32: bad args");
+  if (n == 0) return FFH_OK;
+  if (((uintptr_t)p & 15) != 0) {  // unaligned base: plain memset pattern through the scalar tail path
+    hipLaunchKernelGGL((gen_f32_kernel<0>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), p, n, 0, 0, v, v);
+  } else {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(ffh_grid((n + 3) / 4, 256)), dim3(256), 0, as_stream(s), p, n, v);
+  }
+  FFH_LAUNCH_CHECK(c, "fill_f32");
+  return FFH_OK;
+}
+
+// ZeroInitializer::init_task / Op::zero_grad [ref: src/runtime/initializer_kernel.cu:209-241, src/runtime/model.cc:466-490]
+int ffh_zero(ffh_ctx* c, void* p, size_t bytes, ffh_stream s) {
+  if (bytes == 0) return FFH_OK;
+  FFH_HIP_TRY(c, hipMemsetAsync(p, 0, bytes, as_stream(s)));
+  return FFH_OK;
+}
+
+int ffh_init_uniform(ffh_ctx* c, float* p, int64_t n, uint64_t seed, float lo, float hi, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && (p || n == 0), "init_uniform: bad args");
+  if (n == 0) return FFH_OK;
+  hipLaunchKernelGGL((gen_f32_kernel<0>), dim3(ffh_grid(n, 256, 8192)), dim3(256), 0, as_stream(s), p, n, seed, (int64_t)0, lo, hi);
+  FFH_LAUNCH_CHECK(c, "init_uniform");
+  return FFH_OK;
+}
+int ffh_gen_indices(ffh_ctx* c, int64_t* p, int64_t n, uint64_t seed, int64_t first, int64_t R, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && R > 0 && (p || n == 0), "gen_indices: bad args");
+  if (n == 0) return FFH_OK;
+  hipLaunchKernelGGL(gen_idx_kernel, dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), p, n, seed, first, R);
+  FFH_LAUNCH_CHECK(c, "gen_indices");
+  return FFH_OK;
+}
+int ffh_gen_uniform01(ffh_ctx* c, float* p, int64_t n, uint64_t seed, int64_t first, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && (p || n == 0), "gen_uniform01: bad args");
+  if (n == 0) return FFH_OK;
+  hipLaunchKernelGGL((gen_f32_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), p, n, seed, first, 0.f, 1.f);
+  FFH_LAUNCH_CHECK(c, "gen_uniform01");
+  return FFH_OK;
+}
+int ffh_gen_bernoulli(ffh_ctx* c, float* p, int64_t n, uint64_t seed, int64_t first, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && (p || n == 0), "gen_bernoulli: bad args");
+  if (n == 0) return FFH_OK;
+  hipLaunchKernelGGL((gen_f32_kernel<2>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), p, n, seed, first, 0.f, 1.f);
+  FFH_LAUNCH_CHECK(c, "gen_bernoulli");
+  return FFH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,529 @@
+"""GPU parity tests (-m gpu): the hand-written HIP kernels, called through the C-ABI
+(dlrm_flexflow_amd/csrc/libffhip.so), against
+  * the committed golden vectors (reference's compiled AVX2 lookup / torch / numpy),
+  * the CPU oracle on the same seeded inputs, and
+  * size-independent properties at BASELINE.json's full sizes.
+Bar: bit-exact for index / gather / copy / canonical-order work; 1e-5 relative for fp32
+reductions whose order differs (GEMMs, atomics), tolerance written at each check.
+torch is used only to own device memory and, in the full-size property tests, as an
+independent checker of pure gathers.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from dlrm_flexflow_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+@pytest.fixture(scope="module")
+def ws(hip):
+    """128 MiB of scratch attached to the ctx (FFHandler.workSpace analogue)."""
+    buf = torch.empty(128 << 20, dtype=torch.uint8, device=DEV)
+    hip.set_workspace(buf, buf.numel())
+    return buf
+
+
+def bits_equal(a, b):
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+# ---------------------------------------------------------------------------
+# RNG / init kernels: bit-exact with the oracle
+# ---------------------------------------------------------------------------
+def test_rng_kernels_bit_exact(hip, oracle):
+    n = 100003
+    t = torch.empty(n, dtype=torch.float32, device=DEV)
+    hip.call("ffh_init_uniform", t, n, 7, -0.125, 0.25, None)
+    assert bits_equal(host(t), oracle.init_uniform(n, 7, -0.125, 0.25))
+    hip.call("ffh_gen_uniform01", t, n, 9, 555, None)
+    assert bits_equal(host(t), oracle.gen_uniform01(n, 9, 555))
+    hip.call("ffh_gen_bernoulli", t, n, 9, 555, None)
+    assert bits_equal(host(t), oracle.gen_bernoulli(n, 9, 555))
+    i = torch.empty(n, dtype=torch.int64, device=DEV)
+    for R in (3, 10131227, 200_000_000):
+        hip.call("ffh_gen_indices", i, n, 11, 1 << 33, R, None)
+        assert bits_equal(host(i), oracle.gen_indices(n, 11, 1 << 33, R))
+    hip.call("ffh_fill_f32", t, n, 1.5, None)
+    assert (host(t) == 1.5).all()
+    hip.call("ffh_fill_f32", t[1:], n - 1, -2.0, None)       # unaligned base
+    h = host(t)
+    assert h[0] == 1.5 and (h[1:] == -2.0).all()
+
+
+# ---------------------------------------------------------------------------
+# Embedding forward
+# ---------------------------------------------------------------------------
+def gpu_emb_fwd(hip, idx, w, aggr=capi.AGGR_MODE_SUM, out_ld=None, col_off=0):
+    B, L = idx.shape
+    R, D = w.shape
+    out_ld = out_ld or D
+    out = torch.full((B, out_ld), 777.0, dtype=torch.float32, device=DEV)
+    hip.call("ffh_embedding_fwd", dev(idx), out[:, col_off:], dev(w), L, D, B, R, out_ld, aggr, None)
+    return host(out)
+
+
+def test_embedding_fwd_reference_golden_bit_exact(hip):
+    """Golden vectors produced by the reference's own compiled AVX2 lookup."""
+    g = golden("embedding_fwd_ref")
+    for k in range(int(g["n_cases"])):
+        out = gpu_emb_fwd(hip, g[f"c{k}_idx"], g[f"c{k}_w"])
+        assert bits_equal(out, g[f"c{k}_out"]), f"case {k}"
+    # ragged bags of the fixture, evaluated bag by bag (fixed bag size in this ABI), SUM and mean
+    w, flat, lens = g["ragged_w"], g["ragged_idx"], g["ragged_len"]
+    pos = 0
+    for b, ln in enumerate(lens):
+        if ln:
+            idx = flat[pos:pos + ln].reshape(1, ln)
+            assert bits_equal(gpu_emb_fwd(hip, idx, w), g["ragged_out"][b:b + 1])
+            assert bits_equal(gpu_emb_fwd(hip, idx, w, capi.AGGR_MODE_AVG), g["ragged_out_mean"][b:b + 1])
+            pos += ln
+
+
+@pytest.mark.parametrize("B,L,D,R", [(4096, 1, 128, 100000), (2048, 1, 16, 10131227 // 50), (1000, 3, 64, 5000),
+                                     (777, 2, 13, 300), (513, 1, 512, 2000), (64, 4, 20, 9), (1, 1, 128, 5), (100, 1, 48, 77)])
+def test_embedding_fwd_vs_oracle_bit_exact(hip, oracle, B, L, D, R):
+    rng = np.random.default_rng(B + D)
+    w = rng.uniform(-1, 1, (R, D)).astype(np.float32)
+    idx = rng.integers(0, R, (B, L))
+    assert bits_equal(gpu_emb_fwd(hip, idx, w), oracle.embedding_fwd(idx, w))
+    if L > 1:
+        assert bits_equal(gpu_emb_fwd(hip, idx, w, capi.AGGR_MODE_AVG), oracle.embedding_fwd(idx, w, capi.AGGR_MODE_AVG))
+
+
+def test_embedding_fwd_empty_batch_and_bad_args(hip):
+    w = torch.zeros(4, 8, device=DEV)
+    idx = torch.zeros(0, 1, dtype=torch.int64, device=DEV)
+    out = torch.zeros(1, 8, device=DEV)
+    hip.call("ffh_embedding_fwd", idx, out, w, 1, 8, 0, 4, 8, capi.AGGR_MODE_SUM, None)     # empty: no-op
+    with pytest.raises(capi.FFHError):
+        hip.call("ffh_embedding_fwd", idx, out, w, 1, 8, 1, 4, 4, capi.AGGR_MODE_SUM, None)  # ld < D
+    with pytest.raises(capi.FFHError):
+        hip.call("ffh_embedding_fwd", idx, out, w, 1, 8, 1, 4, 8, capi.AGGR_MODE_NONE, None)
+
+
+def test_embedding_fwd_multi_table_into_concat_buffer(hip, oracle):
+    """26 Criteo-Kaggle-shaped tables in one launch, writing straight into the [B][16+26*16]
+    concat buffer (out_ld = 432): gathers bit-exact, other columns untouched."""
+    rows = [1460, 583, 10131227 // 100, 2202608 // 100, 305, 24, 12517, 633, 3, 93145, 5683, 8351593 // 100, 3194, 27,
+            14992, 5461306 // 100, 10, 5652, 2173, 4, 7046547 // 100, 18, 15, 286181, 105, 142572]
+    B, D = 2048, 16
+    rng = np.random.default_rng(0)
+    ws_, idxs = [], []
+    Z = torch.full((B, 16 + 26 * D), -5.0, dtype=torch.float32, device=DEV)
+    entries = []
+    for t, R in enumerate(rows):
+        w = rng.uniform(-1, 1, (R, D)).astype(np.float32)
+        idx = rng.integers(0, R, (B, 1))
+        ws_.append(w); idxs.append(idx)
+        entries.append((dev(idx), dev(w), Z[:, 16 + t * D:], R, Z.shape[1]))
+    keep = entries
+    arr = hip.emb_tables(keep)
+    hip.check(hip.lib.ffh_embedding_fwd_multi(hip.ctx, arr, len(rows), 1, D, B, capi.AGGR_MODE_SUM, None), "fwd_multi")
+    z = host(Z)
+    assert (z[:, :16] == -5.0).all()
+    for t in range(26):
+        assert bits_equal(z[:, 16 + t * D:16 + (t + 1) * D].copy(), oracle.embedding_fwd(idxs[t], ws_[t]))
+
+
+# ---------------------------------------------------------------------------
+# Embedding backward: dense atomics (reference's own form) and the fused sparse SGD
+# ---------------------------------------------------------------------------
+def test_embedding_bwd_dense(hip, oracle):
+    rng = np.random.default_rng(2)
+    B, L, D, R = 3000, 2, 16, 50
+    idx = rng.integers(0, R, (B, L))
+    g = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+    wg = torch.zeros(R, D, device=DEV)
+    hip.call("ffh_embedding_bwd_dense", dev(idx), dev(g), wg, L, D, B, R, D, capi.AGGR_MODE_SUM, None)
+    exp = oracle.embedding_bwd_dense(idx, g, R)
+    mass = np.zeros((R, D))
+    np.add.at(mass, idx.reshape(-1), np.repeat(np.abs(g.astype(np.float64)), L, axis=0))
+    # atomics arrive in any order: 1e-5 of the L1 mass of each sum (north_star tolerance)
+    assert np.all(np.abs(host(wg) - exp) <= 1e-5 * mass)
+    # unique rows: a single add each -> bit-exact
+    idx_u = rng.permutation(4000)[:B].reshape(B, 1)
+    wg = torch.zeros(4000, D, device=DEV)
+    hip.call("ffh_embedding_bwd_dense", dev(idx_u), dev(g), wg, 1, D, B, 4000, D, capi.AGGR_MODE_SUM, None)
+    assert np.array_equal(host(wg), oracle.embedding_bwd_dense(idx_u, g, 4000))
+
+
+def gpu_fused(hip, idx, g, w, lr, aggr=capi.AGGR_MODE_SUM, gld=None):
+    B, L = idx.shape
+    R, D = w.shape
+    gt = dev(g)
+    wt = dev(w)
+    hip.call("ffh_embedding_bwd_sgd_fused", dev(idx), gt, wt, L, D, B, R, gld or g.shape[1], aggr, float(lr), None)
+    return host(wt)
+
+
+@pytest.mark.parametrize("B,L,D,R", [
+    (32768, 1, 16, 3), (32768, 1, 128, 36), (8192, 1, 16, 1460), (4096, 1, 128, 100000), (2048, 1, 16, 10131227),
+    (3000, 2, 64, 500), (1000, 3, 13, 40), (5000, 1, 20, 7), (1, 1, 16, 10), (129, 1, 8, 1), (2047, 1, 256, 2000),
+    (4096, 1, 512, 50)])
+def test_embedding_fused_bwd_sgd_bit_exact_vs_oracle(hip, oracle, ws, B, L, D, R):
+    """Canonical-order reduction: the GPU result equals the oracle bit for bit, for heavy
+    duplicates (R=3), rare duplicates, bags, odd D (scalar path) and rows untouched."""
+    rng = np.random.default_rng(R + B)
+    idx = rng.integers(0, R, (B, L))
+    g = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+    if R <= 200000:
+        w = rng.uniform(-1, 1, (R, D)).astype(np.float32)
+        got = gpu_fused(hip, idx, g, w, 0.01)
+        assert bits_equal(got, oracle.embedding_bwd_sgd_fused(idx, g, w, 0.01))
+        if L > 1:
+            got = gpu_fused(hip, idx, g, w, 0.01, capi.AGGR_MODE_AVG)
+            assert bits_equal(got, oracle.embedding_bwd_sgd_fused(idx, g, w, 0.01, capi.AGGR_MODE_AVG))
+    else:
+        # big table: compare only the touched rows (the oracle copy of the table would be 650 MB)
+        wt = torch.empty(R, D, device=DEV)
+        hip.call("ffh_init_uniform", wt, R * D, 3, -0.1, 0.1, None)
+        before = wt.clone()
+        hip.call("ffh_embedding_bwd_sgd_fused", dev(idx), dev(g), wt, L, D, B, R, D, capi.AGGR_MODE_SUM, 0.01, None)
+        rows = np.unique(idx)
+        sub = host(before[torch.from_numpy(rows).to(DEV)])
+        remap = np.searchsorted(rows, idx)
+        exp = oracle.embedding_bwd_sgd_fused(remap, g, sub, 0.01)
+        assert bits_equal(host(wt[torch.from_numpy(rows).to(DEV)]), exp)
+        mask = torch.ones(R, dtype=torch.bool, device=DEV)
+        mask[torch.from_numpy(rows).to(DEV)] = False
+        assert torch.equal(wt[mask], before[mask])           # untouched rows keep their bits
+
+
+def test_embedding_fused_multi_table_strided_grad(hip, oracle, ws):
+    """Several tables in one call, gradients read as column slices of one [B][ld] buffer
+    (the concat gradient), exactly how the FFModel shim calls it."""
+    rng = np.random.default_rng(5)
+    B, D = 4096, 16
+    rows = [3, 100, 5000, 250000, 17]
+    ld = 16 + len(rows) * D
+    G = rng.uniform(-1, 1, (B, ld)).astype(np.float32)
+    Gt = dev(G)
+    ents, wt, ws_, idxs = [], [], [], []
+    for t, R in enumerate(rows):
+        w = rng.uniform(-1, 1, (R, D)).astype(np.float32)
+        idx = rng.integers(0, R, (B, 1))
+        ws_.append(w); idxs.append(idx)
+        wt.append(dev(w))
+        ents.append((dev(idx), wt[-1], Gt[:, 16 + t * D:], R, ld))
+    arr = hip.emb_tables(ents)
+    hip.check(hip.lib.ffh_embedding_bwd_sgd_fused_multi(hip.ctx, arr, len(rows), 1, D, B, capi.AGGR_MODE_SUM, 0.05, None), "fused_multi")
+    for t, R in enumerate(rows):
+        gs = np.ascontiguousarray(G[:, 16 + t * D:16 + (t + 1) * D])
+        assert bits_equal(host(wt[t]), oracle.embedding_bwd_sgd_fused(idxs[t], gs, ws_[t], 0.05)), f"table {t}"
+
+
+def test_embedding_fused_equals_reference_three_step_path(hip, oracle, ws):
+    """zero_grad -> embed_backward (atomics) -> sgd_update, all three on the GPU, against the
+    fused kernel: same table within 1e-5 (the dense path's atomics have no fixed order)."""
+    rng = np.random.default_rng(9)
+    B, D, R, lr = 8192, 32, 1000, 0.01
+    idx = rng.integers(0, R, (B, 1))
+    g = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+    w = rng.uniform(-1, 1, (R, D)).astype(np.float32)
+    fused = gpu_fused(hip, idx, g, w, lr)
+    wt, wg = dev(w), torch.empty(R, D, device=DEV)
+    hip.call("ffh_zero", wg, R * D * 4, None)
+    hip.call("ffh_embedding_bwd_dense", dev(idx), dev(g), wg, 1, D, B, R, D, capi.AGGR_MODE_SUM, None)
+    hip.call("ffh_sgd_update", wt, wg, None, R * D, lr, 0.0, 0.0, 0, None)
+    mass = np.zeros((R, D))
+    np.add.at(mass, idx.reshape(-1), np.abs(g.astype(np.float64)))
+    assert np.all(np.abs(host(wt) - fused) <= 1e-5 * (lr * mass + np.abs(w)))
+
+
+def test_embedding_fused_needs_workspace(hip):
+    hip.set_workspace(None, 0)
+    w = torch.zeros(4, 8, device=DEV)
+    idx = torch.zeros(16, 1, dtype=torch.int64, device=DEV)
+    g = torch.zeros(16, 8, device=DEV)
+    with pytest.raises(capi.FFHError, match="workspace"):
+        hip.call("ffh_embedding_bwd_sgd_fused", idx, g, w, 1, 8, 16, 4, 8, capi.AGGR_MODE_SUM, 0.1, None)
+
+
+# ---------------------------------------------------------------------------
+# Linear (exact-fp32 MFMA GEMM)
+# ---------------------------------------------------------------------------
+def gpu_linear_fwd(hip, x, w, b, act, ldx=None, ldy=None):
+    B, IN = x.shape
+    OUT = w.shape[0]
+    ldx, ldy = ldx or IN, ldy or OUT
+    xt = torch.zeros(B, ldx, device=DEV); xt[:, :IN] = dev(x)
+    yt = torch.full((B, ldy), 3.0, device=DEV)
+    hip.call("ffh_linear_fwd", xt, ldx, yt, ldy, dev(w), None if b is None else dev(b), IN, OUT, B, act, None)
+    return host(yt)[:, :OUT].copy()
+
+
+def gpu_linear_bwd(hip, x, y, gy, w, act, want_dx=True, use_bias=True):
+    B, IN = x.shape
+    OUT = w.shape[0]
+    dx = torch.zeros(B, IN, device=DEV) if want_dx else None
+    dw = torch.zeros(OUT, IN, device=DEV)
+    db = torch.zeros(OUT, device=DEV) if use_bias else None
+    dy = dev(gy)
+    hip.call("ffh_linear_bwd", dev(x), IN, dx, IN, dev(y), OUT, dy, OUT, dev(w), dw, db, IN, OUT, B, act, None)
+    return (host(dx) if want_dx else None), host(dw), (host(db) if use_bias else None), host(dy)
+
+
+def assert_gemm_close(got, exp, absmass, what):
+    """|got-exp| <= 1e-5 * sum_k |a_k b_k|  (1e-5 relative, north_star) + 1e-6 absolute"""
+    err = np.abs(got.astype(np.float64) - exp.astype(np.float64))
+    assert np.all(err <= 1e-5 * absmass + 1e-6), f"{what}: max err {err.max()} vs mass {absmass.max()}"
+
+
+def test_linear_torch_golden(hip):
+    g = golden("linear_torch")
+    for k in range(int(g["n_cases"])):
+        x, w, b, gy = g[f"c{k}_x"], g[f"c{k}_w"], g[f"c{k}_b"], g[f"c{k}_gy"]
+        act = int(g[f"c{k}_act"])
+        y = gpu_linear_fwd(hip, x, w, b, act)
+        np.testing.assert_allclose(y, g[f"c{k}_y"], rtol=1e-5, atol=1e-5)
+        dx, dw, db, _ = gpu_linear_bwd(hip, x, g[f"c{k}_y"], gy, w, act)
+        np.testing.assert_allclose(dw, g[f"c{k}_dw"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(db, g[f"c{k}_db"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(dx, g[f"c{k}_dx"], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,IN,OUT,act", [
+    (2048, 13, 512, capi.AC_MODE_RELU), (2048, 512, 256, capi.AC_MODE_RELU), (2048, 256, 64, capi.AC_MODE_RELU),
+    (2048, 64, 16, capi.AC_MODE_RELU), (2048, 432, 512, capi.AC_MODE_RELU), (2048, 256, 1, capi.AC_MODE_SIGMOID),
+    (128, 144, 64, capi.AC_MODE_NONE), (4096, 1024, 1024, capi.AC_MODE_RELU), (333, 77, 45, capi.AC_MODE_SIGMOID),
+    (10, 2000, 1000, capi.AC_MODE_NONE)])
+def test_linear_vs_oracle(hip, oracle, B, IN, OUT, act):
+    """DLRM layer shapes of C1/C2/C4 plus ragged sizes and the reference harness shape
+    (10,2000,1000) [ref: tests/ops/test_harness.py:201-283]."""
+    rng = np.random.default_rng(IN * OUT)
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    y = gpu_linear_fwd(hip, x, w, b, act)
+    y_exp = oracle.linear_fwd(x, w, b, act)
+    mass = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+    assert_gemm_close(y, y_exp, mass, "y")
+    dx, dw, db, dy_after = gpu_linear_bwd(hip, x, y_exp, gy, w, act)
+    dx_e, dw_e, db_e, dy_e = oracle.linear_bwd(x, y_exp, gy, w, act)
+    np.testing.assert_allclose(dy_after, dy_e, rtol=1e-6, atol=1e-7)       # elementwise activation gradient
+    a = np.abs(dy_e).astype(np.float64)
+    assert_gemm_close(dw, dw_e, a.T @ np.abs(x).astype(np.float64), "dw")
+    assert_gemm_close(db, db_e, a.sum(0), "db")
+    assert_gemm_close(dx, dx_e, a @ np.abs(w).astype(np.float64), "dx")
+
+
+def test_linear_strided_operands_and_accumulate(hip, oracle):
+    """x and y as column slices of wider buffers (the concat buffer), dx accumulated on top of
+    existing values (beta = 1, the reference's semantics), no bias, dx = NULL."""
+    rng = np.random.default_rng(3)
+    B, IN, OUT = 300, 24, 40
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = rng.uniform(-1, 1, (OUT, IN)).astype(np.float32)
+    y = gpu_linear_fwd(hip, x, w, None, capi.AC_MODE_NONE, ldx=IN + 8, ldy=OUT + 4)
+    assert_gemm_close(y, oracle.linear_fwd(x, w, None), np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T, "y")
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    dx0 = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    dxt, dwt = dev(dx0), torch.zeros(OUT, IN, device=DEV)
+    hip.call("ffh_linear_bwd", dev(x), IN, dxt, IN, dev(y), OUT, dev(gy), OUT, dev(w), dwt, None, IN, OUT, B, capi.AC_MODE_NONE, None)
+    dx_e, dw_e, _, _ = oracle.linear_bwd(x, y, gy, w, capi.AC_MODE_NONE, use_bias=False)
+    np.testing.assert_allclose(host(dxt), dx0 + dx_e, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(host(dwt), dw_e, rtol=1e-5, atol=1e-4)
+    dwt.zero_()
+    hip.call("ffh_linear_bwd", dev(x), IN, None, IN, dev(y), OUT, dev(gy), OUT, dev(w), dwt, None, IN, OUT, B, capi.AC_MODE_NONE, None)
+    np.testing.assert_allclose(host(dwt), dw_e, rtol=1e-5, atol=1e-4)
+
+
+def test_linear_unsupported_activation_is_an_error(hip):
+    t = torch.zeros(4, 4, device=DEV)
+    with pytest.raises(capi.FFHError):
+        hip.call("ffh_linear_fwd", t, 4, t, 4, t, None, 4, 4, 4, capi.AC_MODE_GELU, None)
+
+
+# ---------------------------------------------------------------------------
+# Concat / BatchMatmul / loss / metrics / SGD
+# ---------------------------------------------------------------------------
+def test_concat_golden_and_alias(hip):
+    g = golden("concat_numpy")
+    for k in range(int(g["n_cases"])):
+        parts = [g[f"c{k}_in{i}"] for i in range(int(g[f"c{k}_n"]))]
+        widths = [p.shape[1] for p in parts]
+        nb = parts[0].shape[0]
+        pt = [dev(p) for p in parts]
+        out = torch.empty(nb, sum(widths), device=DEV)
+        hip.concat("ffh_concat_fwd", out, sum(widths), pt, widths, None, nb)
+        assert bits_equal(host(out), g[f"c{k}_out"])               # pure copy: bit-exact
+        grads = [torch.zeros(nb, w_, device=DEV) for w_ in widths]
+        hip.concat("ffh_concat_bwd", out, sum(widths), grads, widths, None, nb)
+        for p, q in zip(parts, grads):
+            assert np.array_equal(p, host(q))
+    # aliased producers: inputs that already live in the output are skipped, others copied
+    nb, widths = 64, [16, 16, 16]
+    Z = torch.zeros(nb, 48, device=DEV)
+    Z[:, 16:32] = 7.0
+    a, c = torch.ones(nb, 16, device=DEV), torch.full((nb, 16), 2.0, device=DEV)
+    hip.concat("ffh_concat_fwd", Z, 48, [a, Z[:, 16:], c], widths, [16, 48, 16], nb)
+    z = host(Z)
+    assert (z[:, :16] == 1).all() and (z[:, 16:32] == 7).all() and (z[:, 32:] == 2).all()
+
+
+def test_bmm_golden_and_harness_shape(hip, oracle):
+    g = golden("bmm_torch")
+    for k in range(int(g["n_cases"])):
+        a, b, go = g[f"c{k}_a"], g[f"c{k}_b"], g[f"c{k}_go"]
+        d, n, kk = a.shape
+        m = b.shape[2]
+        o = torch.empty(d, n, m, device=DEV)
+        hip.call("ffh_bmm_fwd", o, dev(a), dev(b), m, n, kk, d, -1, -1, -1, None)
+        np.testing.assert_allclose(host(o), g[f"c{k}_o"], rtol=1e-5, atol=1e-5)     # harness: 1e-5
+        ga, gb = torch.zeros(d, n, kk, device=DEV), torch.zeros(d, kk, m, device=DEV)
+        hip.call("ffh_bmm_bwd", dev(go), dev(a), ga, dev(b), gb, m, n, kk, d, None)
+        np.testing.assert_allclose(host(ga), g[f"c{k}_ga"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(host(gb), g[f"c{k}_gb"], rtol=1e-5, atol=1e-5)
+    np.random.seed(0)
+    d, m, n, kk = 145, 265, 15, 64                                                  # harness: 1e-4 here
+    a = np.random.uniform(0, 1, (d, n, kk)).astype(np.float32)
+    b = np.random.uniform(0, 1, (d, kk, m)).astype(np.float32)
+    o = torch.empty(d, n, m, device=DEV)
+    hip.call("ffh_bmm_fwd", o, dev(a), dev(b), m, n, kk, d, -1, -1, -1, None)
+    np.testing.assert_allclose(host(o), np.matmul(a, b), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(o), oracle.bmm_fwd(a, b), rtol=1e-5, atol=1e-4)
+    # seq_length truncation keeps full-size strides
+    o.zero_()
+    hip.call("ffh_bmm_fwd", o, dev(a), dev(b), m, n, kk, d, 0, 1, 40, None)
+    np.testing.assert_allclose(host(o), oracle.bmm_fwd(a, b, 0, 1, 40), rtol=1e-5, atol=1e-4)
+    # DLRM dot-interaction shape: Z [B][27][128] x Z^T
+    rng = np.random.default_rng(0)
+    z = rng.uniform(-1, 1, (64, 27, 128)).astype(np.float32)
+    zt = np.ascontiguousarray(z.transpose(0, 2, 1))
+    o = torch.empty(64, 27, 27, device=DEV)
+    hip.call("ffh_bmm_fwd", o, dev(z), dev(zt), 27, 27, 128, 64, -1, -1, -1, None)
+    np.testing.assert_allclose(host(o), oracle.bmm_fwd(z, zt), rtol=1e-5, atol=1e-4)
+
+
+def test_sgd_mse_metrics(hip, oracle):
+    g = golden("sgd_mse_torch")
+    for k in range(int(g["n_cases"])):
+        lr, wd, mom, nest = g[f"c{k}_hp"]
+        w = dev(g[f"c{k}_w0"])
+        v = torch.zeros_like(w) if mom > 0 else None
+        w_o = g[f"c{k}_w0"].copy()
+        v_o = np.zeros_like(w_o) if mom > 0 else None
+        for step in range(3):
+            hip.call("ffh_sgd_update", w, dev(g[f"c{k}_g"][step]), v, w.numel(), float(lr), float(wd), float(mom), int(nest), None)
+            w_o = oracle.sgd_update(w_o, g[f"c{k}_g"][step], lr, wd, mom, bool(nest), v_o)
+        assert bits_equal(host(w), w_o)                               # same FMA sequence: bit-exact
+        np.testing.assert_allclose(host(w), g[f"c{k}_w3"], rtol=1e-5, atol=1e-6)
+    n = 1 << 20                                                       # vector path, large
+    rng = np.random.default_rng(1)
+    w0, gr = rng.uniform(-1, 1, n).astype(np.float32), rng.uniform(-1, 1, n).astype(np.float32)
+    w = dev(w0)
+    hip.call("ffh_sgd_update", w, dev(gr), None, n, 0.01, 0.0, 0.0, 0, None)
+    assert bits_equal(host(w), oracle.sgd_update(w0, gr, 0.01))
+    p, y = dev(g["mse_p"]), dev(g["mse_y"])
+    lg = torch.empty_like(p)
+    hip.call("ffh_mse_bwd", lg, p, y, p.numel(), 1.0 / 37, None)
+    assert bits_equal(host(lg), oracle.mse_bwd(g["mse_p"], g["mse_y"], 1.0 / 37))
+    np.testing.assert_allclose(host(lg), g["mse_grad"], rtol=1e-6, atol=1e-8)
+    perf = torch.zeros(8, dtype=torch.int32, device=DEV)
+    hip.call("ffh_metrics_update", p, y, perf, 37, 1, capi.METRIC_ACCURACY | capi.METRIC_MSE, None)
+    hp = host(perf)
+    assert hp[0] == 74 and hp[1] == 37                                # train_all double count (1 class + accuracy)
+    mse = hp[4:5].view(np.float32)[0]
+    assert abs(mse - float(g["mse_sum"])) <= 1e-5 * float(g["mse_sum"])
+    d, s = dev(w0), dev(gr)
+    hip.call("ffh_add_scaled", d, s, n, 0.5, None)
+    np.testing.assert_array_equal(host(d), (w0.astype(np.float64) + gr.astype(np.float64) * 0.5).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json full sizes: size-independent properties
+# ---------------------------------------------------------------------------
+def test_full_size_terabyte_shape_properties(hip, ws):
+    """Criteo-Terabyte per-table shape (B = 32768, D = 128, R = 39,884,406 rows = 20.4 GB):
+    gather == pure row copy (checked with torch indexing), fused update touches exactly the
+    indexed rows, is linear in the gradient, and leaves every other row's bits alone."""
+    B, D, R, lr = 32768, 128, 39884406, 0.01
+    W = torch.empty(R, D, device=DEV)
+    hip.call("ffh_init_uniform", W, R * D, 1, -(1.0 / R) ** 0.5, (1.0 / R) ** 0.5, None)
+    idx = torch.empty(B, 1, dtype=torch.int64, device=DEV)
+    hip.call("ffh_gen_indices", idx, B, 2, 0, R, None)
+    sync()
+    assert int(idx.min()) >= 0 and int(idx.max()) < R
+    out = torch.empty(B, D, device=DEV)
+    hip.call("ffh_embedding_fwd", idx, out, W, 1, D, B, R, D, capi.AGGR_MODE_SUM, None)
+    sync()
+    assert torch.equal(out, W[idx[:, 0]])                              # bit-exact gather at full size
+    g = torch.empty(B, D, device=DEV)
+    hip.call("ffh_gen_uniform01", g, B * D, 3, 0, None)
+    rows = torch.unique(idx)
+    before = W[rows].clone()
+    csum_before = W.sum(dtype=torch.float64)
+    hip.call("ffh_embedding_bwd_sgd_fused", idx, g, W, 1, D, B, R, D, capi.AGGR_MODE_SUM, lr, None)
+    sync()
+    # linearity / checksum: sum(W_after) - sum(W_before) == -lr * sum(g)
+    delta = float(W.sum(dtype=torch.float64) - csum_before)
+    expect = -lr * float(g.sum(dtype=torch.float64))
+    assert abs(delta - expect) <= 1e-5 * lr * float(g.abs().sum(dtype=torch.float64)) + 1e-3
+    # per-row: W_after[row] = W_before[row] - lr * sum of its gradients (float64 check, 1e-5 rel)
+    acc = torch.zeros(rows.numel(), D, dtype=torch.float64, device=DEV)
+    inv = torch.searchsorted(rows, idx[:, 0])
+    acc.index_add_(0, inv, g.double())
+    exp = before.double() - lr * acc
+    assert torch.all((W[rows].double() - exp).abs() <= 1e-5 * (before.abs().double() + lr * acc.abs()) + 1e-12)
+    # untouched rows keep their bits: regenerate the first 4096 rows of the same counter-based stream
+    lo, hi = -(1.0 / R) ** 0.5, (1.0 / R) ** 0.5
+    full = torch.empty(4096, D, device=DEV)
+    hip.call("ffh_init_uniform", full, 4096 * D, 1, lo, hi, None)     # first 4096 rows of the same stream
+    sync()
+    small = torch.arange(0, 4096, device=DEV)
+    small = small[~torch.isin(small, rows)]
+    assert torch.equal(W[small], full[small])                          # untouched rows keep their bits
+
+
+def test_full_size_kaggle_step_shapes(hip, oracle, ws):
+    """Criteo-Kaggle shape (C2): all 26 tables with their true row counts, B = 2048, D = 16.
+    Forward into the concat buffer and fused update, each against the oracle bit for bit."""
+    rows = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306,
+            10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+    B, D = 2048, 16
+    Wt, It = [], []
+    Z = torch.zeros(B, 16 + 26 * D, device=DEV)
+    G = torch.empty(B, 16 + 26 * D, device=DEV)
+    hip.call("ffh_gen_uniform01", G, G.numel(), 77, 0, None)
+    for t, R in enumerate(rows):
+        w = torch.empty(R, D, device=DEV)
+        hip.call("ffh_init_uniform", w, R * D, 100 + t, -(1.0 / R) ** 0.5, (1.0 / R) ** 0.5, None)
+        i = torch.empty(B, 1, dtype=torch.int64, device=DEV)
+        hip.call("ffh_gen_indices", i, B, 200 + t, 0, R, None)
+        Wt.append(w); It.append(i)
+    arr = hip.emb_tables([(It[t], Wt[t], Z[:, 16 + t * D:], rows[t], Z.shape[1]) for t in range(26)])
+    hip.check(hip.lib.ffh_embedding_fwd_multi(hip.ctx, arr, 26, 1, D, B, capi.AGGR_MODE_SUM, None), "fwd")
+    sync()
+    for t in range(26):
+        assert torch.equal(Z[:, 16 + t * D:16 + (t + 1) * D], Wt[t][It[t][:, 0]])
+    before = [Wt[t][torch.unique(It[t])].clone() for t in range(26)]
+    arr = hip.emb_tables([(It[t], Wt[t], G[:, 16 + t * D:], rows[t], G.shape[1]) for t in range(26)])
+    hip.check(hip.lib.ffh_embedding_bwd_sgd_fused_multi(hip.ctx, arr, 26, 1, D, B, capi.AGGR_MODE_SUM, 0.01, None), "bwd")
+    sync()
+    Gh = host(G)
+    for t in range(26):
+        rws = torch.unique(It[t])
+        idx_h = host(It[t])
+        remap = np.searchsorted(host(rws), idx_h)
+        gs = np.ascontiguousarray(Gh[:, 16 + t * D:16 + (t + 1) * D])
+        exp = oracle.embedding_bwd_sgd_fused(remap, gs, host(before[t]), 0.01)
+        assert bits_equal(host(Wt[t][rws]), exp), f"table {t} R={rows[t]}"
