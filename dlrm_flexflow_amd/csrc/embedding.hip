@@ -512,7 +512,7 @@ int validate_tables(ffh_ctx* c, const ffh_emb_table* t, int nt, int L, int D, in
   if (L <= 0 || D <= 0 || batch < 0) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: bad dims");
   if (aggr != FFH_AGGR_MODE_SUM && aggr != FFH_AGGR_MODE_AVG) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: aggr must be SUM or AVG");
   for (int i = 0; i < nt; i++) {
-    if (!t[i].idx || !t[i].weight || !t[i].io) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: null pointer");
+    if (batch > 0 && (!t[i].idx || !t[i].weight || !t[i].io)) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: null pointer");
     if (t[i].ld < D || t[i].num_entries <= 0) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding: ld < out_dim or num_entries <= 0");
   }
   (void)who;

@@ -248,13 +248,16 @@ def test_embedding_fused_equals_reference_three_step_path(hip, oracle, ws):
     assert np.all(np.abs(host(wt) - fused) <= 1e-5 * (lr * mass + np.abs(w)))
 
 
-def test_embedding_fused_needs_workspace(hip):
+def test_embedding_fused_needs_workspace(hip, ws):
     hip.set_workspace(None, 0)
     w = torch.zeros(4, 8, device=DEV)
     idx = torch.zeros(16, 1, dtype=torch.int64, device=DEV)
     g = torch.zeros(16, 8, device=DEV)
-    with pytest.raises(capi.FFHError, match="workspace"):
-        hip.call("ffh_embedding_bwd_sgd_fused", idx, g, w, 1, 8, 16, 4, 8, capi.AGGR_MODE_SUM, 0.1, None)
+    try:
+        with pytest.raises(capi.FFHError, match="workspace"):
+            hip.call("ffh_embedding_bwd_sgd_fused", idx, g, w, 1, 8, 16, 4, 8, capi.AGGR_MODE_SUM, 0.1, None)
+    finally:
+        hip.set_workspace(ws, ws.numel())
 
 
 # ---------------------------------------------------------------------------
