@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- DLRM training throughput (samples/s) of the MI355X-native path, one JSON line.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kaggle|terabyte|tiny]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+              --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one training iteration of the reference driver's loop -- forward, zero_gradients,
+backward, update [ref: examples/cpp/DLRM/dlrm.cc:166-182] -- on one resident synthetic batch (the
+reference reuses the warm-up batch for random input, :167-173), replayed from a captured hipGraph
+on one GPU (the reference's begin_trace/end_trace).  Workload at N = 1: BASELINE.json configs[1],
+the Criteo-Kaggle shape (26 tables with run_criteo_kaggle.sh's row counts, emb_dim 16, batch 2048,
+bot 13-512-256-64-16, top 432-512-256-1).  N > 1 is weak scaling: 2048 samples per GPU, tables
+sharded table-wise (table t on rank t % N), all-to-all each way + one all-reduce of MLP gradients
+over RCCL (torch.distributed "nccl").  fp32 throughout (the reference's arithmetic type).
+
+Besides the contract fields the line carries
+  roofline      the embedding gather kernel (BASELINE's second metric): algorithmic bytes
+                (B*(L*(8+4D)+4D) per table = 3,536 B/sample here) / HIP-event time
+  kernels       the same for the fused embedding backward+SGD, plus a Terabyte-shaped probe of
+                the gather (D = 128, B = 32768, 40M-row tables) where the kernel is HBM-bound
+  cpu_baseline  the same application on the host cores with the CPU oracle as kernel library
+                (kind "port": the reference has no CPU path for this step), bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+KAGGLE_ROWS = "1396-550-1761917-507795-290-21-11948-608-3-58176-5237-1497287-3127-26-12153-1068715-10-4836-2085-4-1312273-17-15-110946-91-72655"
+TERABYTE_ROWS = "39884406-39043-17289-7420-20263-3-7120-1543-63-38532951-2953546-403346-10-2208-11938-155-4-976-14-39979771-25641295-39664984-585935-12972-108-36"
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
+F32_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def workload(name: str, per_gpu_batch: int | None, world: int):
+    if name == "kaggle":       # BASELINE configs[1]
+        b = per_gpu_batch or 2048
+        return dict(name="criteo-kaggle-shape", rows=KAGGLE_ROWS, D=16, bot="13-512-256-64-16", top="432-512-256-1", B=b * world)
+    if name == "terabyte":     # BASELINE configs[2] (all 26 tables: 96 GB fp32, fits one MI355X; sharded for N > 1)
+        b = per_gpu_batch or 4096
+        return dict(name="criteo-terabyte-shape", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="3456-1024-1024-512-256-1", B=b * world)
+    if name == "tiny":         # BASELINE configs[0]
+        b = per_gpu_batch or 128
+        return dict(name="tiny", rows="-".join(["1000"] * 8), D=16, bot="13-64-16", top="144-64-1", B=b * world)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def flags_of(w, extra=()):
+    return ["-b", str(w["B"]), "--arch-sparse-feature-size", str(w["D"]), "--arch-embedding-size", w["rows"],
+            "--arch-mlp-bot", w["bot"], "--arch-mlp-top", w["top"], "--data-size", str(w["B"]), *extra]
+
+
+def mlp_flops_per_sample(w):
+    bot = [int(x) for x in w["bot"].split("-")]
+    top = [int(x) for x in w["top"].split("-")]
+    top[0] = bot[-1] + len(w["rows"].split("-")) * w["D"]     # input width comes from the tensor, not the flag
+    f = sum(2 * a * b for a, b in zip(bot[:-1], bot[1:])) + sum(2 * a * b for a, b in zip(top[:-1], top[1:]))
+    return 3 * f   # forward + dX + dW
+
+
+def cpu_baseline(w, budget_s=15.0):
+    """The same DLRM application with the CPU oracle as its kernel library, timed on the host."""
+    from oracle import oracle
+    from dlrm_flexflow_amd import ffmodel
+    oracle.build()
+    import ctypes
+    try:
+        cores = int(ctypes.CDLL("libgomp.so.1").omp_get_max_threads())   # threads the oracle's OpenMP loops will use
+    except OSError:
+        cores = os.cpu_count() or 1
+    app = ffmodel.DLRM(flags_of(w, ["--backend", oracle.ORACLE_LIB, "--no-trace"]))
+    app.warmup()
+    t0 = time.perf_counter()
+    app.train_steps(1, trace=False)
+    app.model.sync()
+    t1 = time.perf_counter() - t0
+    n = max(1, min(50, int(budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    app.train_steps(n, trace=False)
+    app.model.sync()
+    dt = time.perf_counter() - t0
+    app.close()
+    return {"value": round(n * w["B"] / dt, 2), "unit": "samples/s", "cores": cores,
+            "kind": "port", "sample": f"{n} training steps of the same {w['name']} config (batch {w['B']}) in {dt:.1f} s, "
+                                      f"oracle/ffh_oracle.c (OpenMP over the batch) behind the same C++ FFModel host code"}
+
+
+def terabyte_gather_probe(hip):
+    """Embedding gather where it is HBM-bound: 4 tables of the Terabyte shape, B = 32768, D = 128."""
+    import torch
+    from dlrm_flexflow_amd import capi
+    rows = [39884406, 38532951, 39979771, 25641295]
+    B, D, T = 32768, 128, len(rows)
+    W, I = [], []
+    for t, R in enumerate(rows):
+        w = torch.empty(R, D, device="cuda")
+        hip.call("ffh_init_uniform", w, R * D, t, -0.01, 0.01, None)
+        i = torch.empty(B, 1, dtype=torch.int64, device="cuda")
+        hip.call("ffh_gen_indices", i, B, 100 + t, 0, R, None)
+        W.append(w); I.append(i)
+    Z = torch.empty(B, T * D, device="cuda")
+    arr = hip.emb_tables([(I[t], W[t], Z[:, t * D:], rows[t], T * D) for t in range(T)])
+    launch = lambda: hip.check(hip.lib.ffh_embedding_fwd_multi(hip.ctx, arr, T, 1, D, B, capi.AGGR_MODE_SUM, None), "fwd")
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # launches go to the null stream = torch's current stream
+    torch.cuda.synchronize()
+    iters = 50
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    nbytes = T * B * (8 + 4 * D + 4 * D)
+    del W, I, Z
+    torch.cuda.empty_cache()
+    return {"kernel": "emb_fwd_kernel<4,4>", "shape": f"{T} tables x ~40M rows x {D} fp32, batch {B}", "bound": "hbm",
+            "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "us_per_launch": round(sec * 1e6, 2), "algorithmic_bytes": nbytes}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="kaggle")
+    ap.add_argument("--per-gpu-batch", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--no-trace", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with\n"
+                         f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                         f"--master-port 29511 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
+    import torch
+    import torch.distributed as dist
+    from dlrm_flexflow_amd import capi, ffmodel
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from dlrm_flexflow_amd.comm import TorchComm
+        comm = TorchComm(on_gpu=True)
+
+    w = workload(args.workload, args.per_gpu_batch, world)
+    extra = ["--device", str(local_rank)] + (["--no-trace"] if args.no_trace else [])
+    app = ffmodel.DLRM(flags_of(w, extra), comm=comm.struct if comm else None)
+    trace = not args.no_trace
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    app.warmup()                                   # the reference's own warm-up iteration (loads the batch)
+    app.train_steps(args.warmup, trace=trace)      # W untimed steps (the first traced one captures the graph)
+    app.model.sync()
+    barrier()
+    t0 = time.perf_counter()
+    app.train_steps(args.steps, trace=trace)       # EXACTLY K timed steps
+    app.model.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel device time, HIP events on the stream the kernels are launched on (the model's stream)
+    T = len(w["rows"].split("-"))
+    owned = len([t for t in range(T) if t % world == rank])
+    B, D = w["B"], w["D"]
+    t_fwd = app.time_kernel(0, 200) * 1e-3 if world == 1 else None
+    t_bwd = app.time_kernel(1, 100) * 1e-3 if world == 1 else None
+    t_step_dev = app.time_kernel(2, 100) * 1e-3 if world == 1 else None
+    pm = app.model.perf_metrics()
+    uses_graph = app.model.uses_graph
+    app.close()
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    samples = w["B"] * args.steps
+    out = {
+        "metric": "dlrm_training_samples_per_sec", "value": round(samples / elapsed, 1), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{w['name']}: {T} tables (rows {w['rows']}), emb_dim {D}, bag 1, bot {w['bot']}, top {w['top']}, "
+                               f"cat interaction, SGD lr 0.01, MSE loss",
+                   "global_batch": w["B"], "per_gpu_batch": w["B"] // world,
+                   "parallelism": "single GPU, hipGraph-replayed step" if world == 1 else
+                                  f"tables table-wise over {world} ranks (RCCL all-to-all fwd+bwd), MLPs data-parallel (1 all-reduce)",
+                   "step_graph": bool(uses_graph)},
+        "mse_after_run": round(pm.mse_loss / max(pm.train_all, 1), 6),
+    }
+    if world == 1:
+        fwd_bytes = owned * B * (8 + 4 * D + 4 * D)            # 3,536 B/sample at the Kaggle shape
+        bwd_bytes = owned * B * (8 + 4 * D + 2 * 4 * D)
+        out["roofline"] = {"kernel": "emb_fwd_kernel (embedding gather + bag-sum, all tables in one launch)", "bound": "hbm",
+                           "achieved": round(fwd_bytes / t_fwd / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(fwd_bytes / t_fwd / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                           "us_per_launch": round(t_fwd * 1e6, 2), "algorithmic_bytes_per_launch": fwd_bytes,
+                           "bytes_per_sample": fwd_bytes // B}
+        flops = mlp_flops_per_sample(w) * B
+        out["kernels"] = {
+            "embedding_bwd_sgd_fused": {"bound": "hbm", "achieved": round(bwd_bytes / t_bwd / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(bwd_bytes / t_bwd / 1e9 / HBM_PEAK_GBS, 4), "us_per_call": round(t_bwd * 1e6, 2),
+                                        "note": "radix sort (hist+scatter per digit) + segmented reduce + combine, all tables batched"},
+            "whole_step_device": {"us": round(t_step_dev * 1e6, 2), "mlp_gflop_per_step": round(flops / 1e9, 3),
+                                  "mlp_tflops_over_whole_step": round(flops / t_step_dev / 1e12, 2), "f32_mfma_peak_tflops": F32_PEAK_TFLOPS},
+        }
+        if not args.no_probe:
+            try:
+                out["kernels"]["embedding_gather_terabyte_shape"] = terabyte_gather_probe(capi.load_hip(local_rank))
+            except Exception as e:  # noqa: BLE001
+                out["kernels"]["embedding_gather_terabyte_shape"] = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

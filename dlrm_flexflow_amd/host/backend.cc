@@ -1,0 +1,51 @@
+#include "backend.h"
+
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
+std::string default_backend_path() {
+  if (const char* e = getenv("FFH_BACKEND_LIB")) return std::string(e);
+  Dl_info info;
+  std::string dir = ".";
+  if (dladdr((void*)&default_backend_path, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    size_t k = p.rfind('/');
+    if (k != std::string::npos) dir = p.substr(0, k);
+  }
+  return dir + "/../csrc/libffhip.so";
+}
+
+const KernelApi* load_kernel_api(const std::string& path_in) {
+  static std::map<std::string, KernelApi*> cache;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  const std::string path = path_in.empty() ? default_backend_path() : path_in;
+  auto it = cache.find(path);
+  if (it != cache.end()) return it->second;
+  void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!h) {
+    fprintf(stderr, "FATAL: cannot load kernel library %s: %s\n"
+                    "       build it with: python -c 'import __graft_entry__ as g; g.build()'\n", path.c_str(), dlerror());
+    abort();
+  }
+  KernelApi* api = new KernelApi();
+  api->handle = h;
+  api->path = path;
+#define FFH_LOAD(name)                                                        \
+  api->name = reinterpret_cast<decltype(api->name)>(dlsym(h, #name));         \
+  if (!api->name) {                                                           \
+    fprintf(stderr, "FATAL: %s does not export %s\n", path.c_str(), #name);   \
+    abort();                                                                  \
+  }
+  FFH_API_LIST(FFH_LOAD)
+#undef FFH_LOAD
+  if (api->ffh_abi_version() != FFH_ABI_VERSION) {
+    fprintf(stderr, "FATAL: %s has ABI version %d, expected %d\n", path.c_str(), api->ffh_abi_version(), FFH_ABI_VERSION);
+    abort();
+  }
+  cache[path] = api;
+  return api;
+}

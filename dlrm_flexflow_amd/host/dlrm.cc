@@ -1,0 +1,267 @@
+// dlrm.cc -- DLRM application on the FFModel shim [ref: examples/cpp/DLRM/dlrm.cc].
+#include "dlrm.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+
+#include "backend.h"
+
+namespace {
+double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+void print_vector(const std::string& name, const std::vector<int>& v) {
+  std::ostringstream out;
+  for (size_t i = 0; i < v.size(); i++) out << v[i] << (i + 1 < v.size() ? " " : "");
+  printf("[DLRM] %s: %s\n", name.c_str(), out.str().c_str());
+}
+}  // namespace
+
+DLRMConfig::DLRMConfig(void)
+    : sparse_feature_size(2), sigmoid_bot(-1), sigmoid_top(-1), embedding_bag_size(1), loss_threshold(0.0f),
+      arch_interaction_op("cat"), dataset_path(""), data_size(-1) {
+  embedding_size.push_back(4);
+  mlp_bot.push_back(4); mlp_bot.push_back(2);
+  mlp_top.push_back(8); mlp_top.push_back(2);
+}
+
+// [ref: examples/cpp/DLRM/dlrm.cc:197-260] -- identical flags
+void parse_input_args(char** argv, int argc, DLRMConfig& config) {
+  auto split = [](const char* s) {
+    std::vector<int> v;
+    std::stringstream ss((std::string(s)));
+    std::string word;
+    while (std::getline(ss, word, '-')) v.push_back(std::stoi(word));
+    return v;
+  };
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "--arch-sparse-feature-size")) { config.sparse_feature_size = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--arch-embedding-size")) { config.embedding_size = split(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--embedding-bag-size")) { config.embedding_bag_size = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--arch-mlp-bot")) { config.mlp_bot = split(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--arch-mlp-top")) { config.mlp_top = split(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--loss-threshold")) { config.loss_threshold = (float)atof(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--sigmoid-top")) { config.sigmoid_top = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--sigmoid-bot")) { config.sigmoid_bot = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--arch-interaction-op")) { config.arch_interaction_op = std::string(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--dataset")) { config.dataset_path = std::string(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--data-size")) { config.data_size = atoi(argv[++i]); continue; }
+  }
+}
+
+// [ref: examples/cpp/DLRM/dlrm.cc:26-39]: N(0, sqrt(2/(in+out))) weights, N(0, sqrt(2/out)) bias,
+// ReLU everywhere except `sigmoid_layer`
+Tensor create_mlp(FFModel* model, const Tensor& input, std::vector<int> ln, int sigmoid_layer) {
+  Tensor t = input;
+  for (int i = 0; i < (int)(ln.size() - 1); i++) {
+    float std_dev = std::sqrt(2.0f / (ln[i + 1] + ln[i]));
+    Initializer* weight_init = new NormInitializer(std::rand(), 0, std_dev);
+    std_dev = std::sqrt(2.0f / ln[i + 1]);
+    Initializer* bias_init = new NormInitializer(std::rand(), 0, std_dev);
+    ActiMode activation = i == sigmoid_layer ? AC_MODE_SIGMOID : AC_MODE_RELU;
+    t = model->dense(t, ln[i + 1], activation, true /*bias*/, NULL /*weight_sharing*/, weight_init, bias_init);
+  }
+  return t;
+}
+
+// [ref: examples/cpp/DLRM/dlrm.cc:41-47]: U(-sqrt(1/R), sqrt(1/R)), AGGR_MODE_SUM
+Tensor create_emb(FFModel* model, const Tensor& input, int input_dim, int output_dim, int idx) {
+  (void)idx;
+  float range = std::sqrt(1.0f / input_dim);
+  Initializer* embed_init = new UniformInitializer(std::rand(), -range, range);
+  return model->embedding(input, input_dim, output_dim, AGGR_MODE_SUM, NULL /*weight_sharing*/, embed_init);
+}
+
+// [ref: examples/cpp/DLRM/dlrm.cc:49-65]: only "cat" exists in the reference (dot is a TODO that asserts)
+Tensor interact_features(FFModel* model, const Tensor& x, const std::vector<Tensor>& ly, std::string interaction) {
+  if (interaction == "cat") {
+    std::vector<Tensor> inputs;
+    inputs.push_back(x);
+    for (size_t i = 0; i < ly.size(); i++) inputs.push_back(ly[i]);
+    return model->concat((int)inputs.size(), inputs.data(), 1 /*axis*/);
+  }
+  fprintf(stderr, "FATAL: --arch-interaction-op %s: only 'cat' is implemented by the DLRM driver "
+                  "(the reference asserts here too, examples/cpp/DLRM/dlrm.cc:53-64)\n", interaction.c_str());
+  abort();
+}
+
+// =============================================================================================
+DataLoader::DataLoader(FFModel& ff, const DLRMConfig& dlrm, const std::vector<Tensor>& sparse_inputs, Tensor dense_input, Tensor label)
+    : num_samples(0), next_index(0), batch_sparse_inputs(sparse_inputs), batch_dense_input(dense_input), batch_label(label),
+      full_dense(nullptr), full_label(nullptr), model(&ff) {
+  if (dlrm.dataset_path != "") {
+    fprintf(stderr, "FATAL: --dataset %s: the HDF5 Criteo loader is not part of this build (no HDF5 in the image); "
+                    "run without --dataset for the synthetic generator\n", dlrm.dataset_path.c_str());
+    abort();
+  }
+  printf("[DLRM] Use random dataset...\n");
+  if (dlrm.data_size > 0) num_samples = dlrm.data_size;
+  else num_samples = 256 * 4 * std::max(1, ff.world_size) * ff.config.numNodes;   // [ref: dlrm.cc:272-276]
+  const int B = ff.config.batchSize;
+  if (num_samples < B) num_samples = B;
+  num_samples = num_samples / B * B;
+  printf("[DLRM] Number of random samples = %d\n", num_samples);
+  bag = dlrm.embedding_bag_size;
+  dense_dim = dense_input.adim[0];
+  const uint64_t s0 = ff.config.seed * 1000003ULL;
+  const int nb = num_samples / B;
+  const int64_t Bl = ff.local_batch;
+  // sparse ids: owner of table t keeps ids of every sample (it gathers for the global batch)
+  full_sparse.assign(sparse_inputs.size(), nullptr);
+  for (size_t t = 0; t < sparse_inputs.size(); t++) {
+    if ((int)(t % ff.world_size) != ff.rank) continue;
+    const int64_t n = (int64_t)num_samples * bag;
+    full_sparse[t] = (int64_t*)ff.dmalloc((size_t)n * sizeof(int64_t));
+    ff.check(ff.api->ffh_gen_indices(ff.ctx, full_sparse[t], n, s0 + 17 + t, 0, dlrm.embedding_size[t], ff.stream), "gen_indices");
+  }
+  // dense features and labels: this rank's slice [rank*Bl, (rank+1)*Bl) of every batch
+  full_dense = (float*)ff.dmalloc((size_t)nb * Bl * dense_dim * sizeof(float));
+  full_label = (float*)ff.dmalloc((size_t)nb * Bl * sizeof(float));
+  for (int k = 0; k < nb; k++) {
+    const int64_t n0 = (int64_t)k * B + (int64_t)ff.rank * Bl;
+    ff.check(ff.api->ffh_gen_uniform01(ff.ctx, full_dense + (int64_t)k * Bl * dense_dim, Bl * dense_dim, s0 + 5, n0 * dense_dim, ff.stream), "gen dense");
+    ff.check(ff.api->ffh_gen_bernoulli(ff.ctx, full_label + (int64_t)k * Bl, Bl, s0 + 7, n0, ff.stream), "gen label");
+  }
+  ff.check(ff.api->ffh_stream_sync(ff.ctx, ff.stream), "dataset sync");
+}
+
+DataLoader::~DataLoader() {
+  for (int64_t* p : full_sparse) if (p) model->api->ffh_free(model->ctx, p);
+  if (full_dense) model->api->ffh_free(model->ctx, full_dense);
+  if (full_label) model->api->ffh_free(model->ctx, full_label);
+}
+
+// [ref: examples/cpp/DLRM/dlrm.cc:482-585, dlrm.cu:19-122]: device-to-device copies on the compute stream
+void DataLoader::next_batch(FFModel& ff) {
+  const int B = ff.config.batchSize;
+  if (next_index + B > num_samples) next_index = 0;
+  const int64_t Bl = ff.local_batch;
+  const int k = next_index / B;
+  for (size_t t = 0; t < batch_sparse_inputs.size(); t++) {
+    if (!full_sparse[t]) continue;
+    ff.check(ff.api->ffh_memcpy_d2d(ff.ctx, batch_sparse_inputs[t].impl->ptr, full_sparse[t] + (int64_t)next_index * bag,
+                                    (size_t)B * bag * sizeof(int64_t), ff.stream), "load sparse");
+  }
+  ff.check(ff.api->ffh_memcpy_d2d(ff.ctx, batch_dense_input.impl->ptr, full_dense + (int64_t)k * Bl * dense_dim,
+                                  (size_t)Bl * dense_dim * sizeof(float), ff.stream), "load dense");
+  ff.check(ff.api->ffh_memcpy_d2d(ff.ctx, batch_label.impl->ptr, full_label + (int64_t)k * Bl, (size_t)Bl * sizeof(float), ff.stream),
+           "load label");
+  next_index += B;
+}
+
+// =============================================================================================
+DLRMApp::DLRMApp(int argc, char** argv, const ffcomm* comm) : ff(nullptr), loader(nullptr), warmed_up(false) {
+  ffconfig.parse_args(argv, argc);
+  if (comm) ffconfig.comm = *comm;
+  parse_input_args(argv, argc, dlrm);
+  const bool chatty = ffconfig.comm.world_size <= 1 || ffconfig.comm.rank == 0;
+  if (chatty) {
+    printf("[DLRM] batchSize(%d) workersPerNodes(%d) numNodes(%d)\n", ffconfig.batchSize, ffconfig.workersPerNode, ffconfig.numNodes);
+    printf("[DLRM] EmbeddingBagSize(%d)\n", dlrm.embedding_bag_size);
+    print_vector("Embedding Vocab Sizes", dlrm.embedding_size);
+    print_vector("MLP Top", dlrm.mlp_top);
+    print_vector("MLP Bot", dlrm.mlp_bot);
+  }
+  if (dlrm.embedding_size.size() > MAX_NUM_EMB) { fprintf(stderr, "FATAL: more than %d tables\n", MAX_NUM_EMB); abort(); }
+  std::srand(1 + (unsigned)ffconfig.seed);   // initializer seeds come from std::rand() as in the reference, but seeded
+  ff = new FFModel(ffconfig);
+
+  for (size_t i = 0; i < dlrm.embedding_size.size(); i++) {
+    const int dims[] = {ffconfig.batchSize, dlrm.embedding_bag_size};
+    sparse_inputs.push_back(ff->create_tensor<2>(dims, DT_INT64));
+  }
+  {
+    const int dims[] = {ffconfig.batchSize, dlrm.mlp_bot[0]};
+    dense_input = ff->create_tensor<2>(dims, DT_FLOAT);
+  }
+  // Step 1 create dense_mlp
+  Tensor x = create_mlp(ff, dense_input, dlrm.mlp_bot, dlrm.sigmoid_bot);
+  std::vector<Tensor> ly;
+  for (size_t i = 0; i < dlrm.embedding_size.size(); i++)
+    ly.push_back(create_emb(ff, sparse_inputs[i], dlrm.embedding_size[i], dlrm.sparse_feature_size, (int)i));
+  Tensor z = interact_features(ff, x, ly, dlrm.arch_interaction_op);
+  create_mlp(ff, z, dlrm.mlp_top, (int)dlrm.mlp_top.size() - 2);
+  if (dlrm.loss_threshold > 0.0f && dlrm.loss_threshold < 1.0f) {
+    fprintf(stderr, "FATAL: --loss-threshold clamp is not implemented (the reference asserts here, dlrm.cc:125-128)\n");
+    abort();
+  }
+  // Use SGD Optimizer
+  Optimizer* optimizer = new SGDOptimizer(ff, 0.01f);
+  std::vector<MetricsType> metrics;
+  metrics.push_back(METRICS_ACCURACY);
+  metrics.push_back(METRICS_MEAN_SQUARED_ERROR);
+  ff->compile(optimizer, LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE, metrics);
+  loader = new DataLoader(*ff, dlrm, sparse_inputs, dense_input, ff->label_tensor);
+  ff->init_layers();
+}
+
+DLRMApp::~DLRMApp() {
+  if (ff) ff->sync();
+  delete loader;
+  delete ff;
+}
+
+void DLRMApp::warmup() {
+  // [ref: examples/cpp/DLRM/dlrm.cc:139-149]
+  loader->reset();
+  ff->reset_metrics();
+  loader->next_batch(*ff);
+  ff->forward();
+  ff->zero_gradients();
+  ff->backward();
+  ff->update();
+  ff->sync();
+  warmed_up = true;
+}
+
+void DLRMApp::train_steps(int n, bool trace) {
+  for (int it = 0; it < n; it++) {
+    // random input: the batch loaded in the warm-up is reused [ref: examples/cpp/DLRM/dlrm.cc:167-173]
+    if (trace) ff->begin_trace(111 /*trace_id*/);
+    ff->forward();
+    ff->zero_gradients();
+    ff->backward();
+    ff->update();
+    if (trace) ff->end_trace(111 /*trace_id*/);
+  }
+}
+
+double DLRMApp::run_epochs() {
+  if (!warmed_up) warmup();
+  const bool chatty = ff->rank == 0;
+  ff->sync();   // issue_execution_fence + timing measurement
+  if (ffconfig.comm.world_size > 1 && ffconfig.comm.barrier) ffconfig.comm.barrier(ffconfig.comm.user);
+  if (chatty) {
+    printf("[DLRM] Warmup finished...Start timer...\n");
+    printf("[DLRM] Num. epochs = %d\n", ffconfig.epochs);
+    printf("[DLRM] Num. iterations/epoch = %d\n", loader->num_samples / ffconfig.batchSize);
+    printf("parameters.size() = %lu\n", ff->parameters.size());
+  }
+  const double ts_start = now_us();
+  for (int epoch = 0; epoch < ffconfig.epochs; epoch++) {
+    loader->reset();
+    ff->reset_metrics();
+    const int iterations = loader->num_samples / ffconfig.batchSize;
+    train_steps(iterations, epoch > 0 /* the reference traces from the second epoch on */);
+  }
+  ff->sync();
+  if (ffconfig.comm.world_size > 1 && ffconfig.comm.barrier) ffconfig.comm.barrier(ffconfig.comm.user);
+  const double ts_end = now_us();
+  const double run_time = 1e-6 * (ts_end - ts_start);
+  if (chatty) {
+    PerfMetrics pm = ff->get_perf_metrics();
+    pm.print(ff->metrics_flags);
+    printf("ELAPSED TIME = %.4fs, THROUGHPUT = %.2f samples/s\n", run_time, loader->num_samples * (double)ffconfig.epochs / run_time);
+  }
+  return run_time;
+}
+
+int dlrm_main(int argc, char** argv, const ffcomm* comm) {
+  DLRMApp app(argc, argv, comm);
+  app.run_epochs();
+  return 0;
+}

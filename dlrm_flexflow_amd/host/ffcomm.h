@@ -1,0 +1,35 @@
+/* ffcomm.h -- the collectives the data-parallel / table-wise-sharded DLRM step needs, as a POD
+ * table of callbacks supplied by the launcher.
+ *
+ * The reference has no explicit exchange: embedding outputs are mapped to zero-copy host memory
+ * and moved by Legion DMA [ref: src/ops/embedding.cu:295-299,376-381], and weight gradients are
+ * summed by ncclAllReduce, one call per tensor [ref: src/runtime/optimizer_kernel.cu:170-171].
+ * Here each process owns one GPU (one rank) and the launcher (bench.py / run_dlrm.py: torch.distributed
+ * with the "nccl" backend = RCCL over xGMI; "gloo" in the CPU tests) provides:
+ *   alltoall   uneven all-to-all of fp32 blocks  (embedding rows forward, their gradients backward)
+ *   allreduce  in-place fp32 sum                 (one bucket = all MLP gradients)
+ * All calls are asynchronous on `stream` (a hipStream_t): they must be ordered after work already
+ * enqueued on it and work enqueued later must see their result.  world_size == 1 needs no callbacks.
+ */
+#ifndef FFCOMM_H_
+#define FFCOMM_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ffcomm {
+  int   rank;
+  int   world_size;
+  void* user;
+  /* counts are in floats, one entry per peer; blocks are contiguous in rank order */
+  int (*alltoall_f32)(void* user, const float* send, const int64_t* send_counts,
+                      float* recv, const int64_t* recv_counts, void* stream);
+  int (*allreduce_sum_f32)(void* user, float* buf, int64_t count, void* stream);
+  int (*barrier)(void* user);
+} ffcomm;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,345 @@
+// ffmodel.h -- the reference's FFModel operator API for the DLRM path, re-built as a thin C++
+// host layer over the kernel C-ABI (include/ff_hip.h).  One process drives one GPU; there is no
+// Legion, no mapper and no strategy search: placement is the fixed sharding of DESIGN.md
+// (tables table-wise over ranks, everything else data-parallel).
+//
+// Mirrors, with the same names, argument meaning and error behaviour (print + abort):
+//   FFConfig                      [ref: include/config.h:98-154, src/runtime/model.cc:2211-2403]
+//   Tensor / Parameter            [ref: include/tensor.h:27-73, src/runtime/model.cu:337-467]
+//   Initializer family            [ref: include/initializer.h:25-110]
+//   Optimizer / SGDOptimizer      [ref: include/optimizer.h:30-60, src/runtime/optimizer.cc:43-189]
+//   Op, Linear, Embedding, Concat, BatchMatmul [ref: include/model.h:205-271,968-1202,1739-1791]
+//   FFModel                       [ref: include/model.h:283-588, src/runtime/model.cc:1410-1819]
+//   PerfMetrics                   [ref: src/metrics_functions/metrics_functions.cc:20-80]
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ff_hip.h"
+#include "ffcomm.h"
+
+// ---- enums: identical values to [ref: include/ffconst.h:4-57] -------------------------------
+enum ActiMode { AC_MODE_NONE = 10, AC_MODE_RELU = 11, AC_MODE_SIGMOID = 12, AC_MODE_TANH = 13, AC_MODE_GELU = 14 };
+enum AggrMode { AGGR_MODE_NONE = 20, AGGR_MODE_SUM = 21, AGGR_MODE_AVG = 22 };
+enum DataType { DT_FLOAT = 40, DT_DOUBLE = 41, DT_INT32 = 42, DT_INT64 = 43, DT_BOOLEAN = 44, DT_NONE = 49 };
+enum LossType {
+  LOSS_CATEGORICAL_CROSSENTROPY = 50,
+  LOSS_SPARSE_CATEGORICAL_CROSSENTROPY = 51,
+  LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE = 52,
+  LOSS_MEAN_SQUARED_ERROR_SUM_REDUCE = 53,
+};
+enum CompMode { COMP_MODE_TRAINING = 70, COMP_MODE_INFERENCE = 71 };
+enum ParameterSyncType { NONE = 80, PS = 81, NCCL = 82 };
+enum MetricsType {
+  METRICS_ACCURACY = 1001,
+  METRICS_CATEGORICAL_CROSSENTROPY = 1002,
+  METRICS_SPARSE_CATEGORICAL_CROSSENTROPY = 1004,
+  METRICS_MEAN_SQUARED_ERROR = 1008,
+  METRICS_ROOT_MEAN_SQUARED_ERROR = 1016,
+  METRICS_MEAN_ABSOLUTE_ERROR = 1032,
+};
+enum OperatorType { OP_INPUT, OP_LINEAR, OP_EMBEDDING, OP_CONCAT, OP_BATCHMATMUL };
+
+#define MAX_TENSOR_DIM 4
+#define MAX_NUM_INPUTS 256
+#define MAX_OPNAME 64
+
+class FFModel;
+class Op;
+struct KernelApi;   // dlopen'ed table of the ffh_* entry points (backend.h)
+
+// ---------------------------------------------------------------------------------------------
+class FFConfig {
+ public:
+  FFConfig();
+  void parse_args(char** argv, int argc);
+  // reference fields
+  int epochs, batchSize, printFreq;
+  int numNodes, cpusPerNode, workersPerNode;
+  float learningRate, weightDecay;
+  size_t workSpaceSize;
+  bool syntheticInput, profiling, perform_fusion;
+  CompMode computationMode;
+  std::string dataset_path;
+  std::string import_strategy_file, export_strategy_file;   // parsed, rejected at compile()
+  // this build
+  std::string backend_lib;     // library exporting include/ff_hip.h; default: libffhip.so next to libffmodel.so
+  int device;                  // HIP device ordinal of this process
+  uint64_t seed;               // counter-based RNG seed (reference: unseeded std::rand)
+  bool enable_graph;           // begin_trace/end_trace capture + replay as a hipGraph
+  bool overlap_embedding;      // embedding gather (+exchange) on a side stream beside the bottom MLP
+  bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
+  bool force_exchange;         // run the all-to-all / all-reduce path even with one rank (tests the collectives on 1 GPU)
+  ffcomm comm;                 // rank / world_size / collectives supplied by the launcher (ffcomm.h)
+};
+
+// ---------------------------------------------------------------------------------------------
+struct TensorImpl {
+  void*   ptr = nullptr;        // device address of element (0, 0)
+  int64_t ld = 0;               // elements between consecutive rows (rows = product of outer dims)
+  float*  grad = nullptr;
+  int64_t grad_ld = 0;
+  bool    alias = false;        // lives inside another tensor's buffer (e.g. the concat output)
+  bool    grad_alias = false;
+  bool    is_input = false;
+  size_t  bytes = 0;
+  int64_t rows_local = 0;      // rows held by this rank (batch-sharded tensors: rows / world_size)
+  int     guid = -1;
+};
+
+struct Tensor {
+  Tensor(void);
+  size_t get_volume() const;
+  int64_t rows() const;         // product of all dims but the innermost
+  int64_t cols() const { return adim[0]; }
+  // host <-> device copies of the whole tensor, row-major with the batch outermost
+  // [ref: src/runtime/model.cu:337-467 set_tensor/get_tensor]
+  template <typename T> bool set_tensor(const FFModel* model, const std::vector<int>& dims, const T* data);
+  template <typename T> bool get_tensor(const FFModel* model, T* data) const;
+  template <typename T> bool get_grad(const FFModel* model, T* data) const;
+  int numDim, adim[MAX_TENSOR_DIM];   // Legion order: adim[0] is the innermost dimension
+  DataType data_type;
+  ParameterSyncType sync_type;
+  Op* owner_op;
+  int owner_idx;
+  TensorImpl* impl;                   // filled by FFModel::compile
+};
+
+struct Parameter : Tensor {
+  template <typename T> bool set_weights(const FFModel* model, const std::vector<int>& dims, const T* data);
+  template <typename T> bool get_weights(const FFModel* model, T* data) const;
+};
+
+// ---------------------------------------------------------------------------------------------
+class Initializer {
+ public:
+  virtual ~Initializer() {}
+  virtual void init(const FFModel* ff, const Parameter* p) = 0;
+};
+class ZeroInitializer : public Initializer {
+ public:
+  void init(const FFModel* ff, const Parameter* p) override;
+};
+class ConstantInitializer : public Initializer {
+ public:
+  explicit ConstantInitializer(float v) : value(v) {}
+  void init(const FFModel* ff, const Parameter* p) override;
+  float value;
+};
+class UniformInitializer : public Initializer {
+ public:
+  UniformInitializer(int _seed, float _min, float _max) : seed(_seed), min_val(_min), max_val(_max) {}
+  void init(const FFModel* ff, const Parameter* p) override;   // device kernel, counter-based
+  int seed;
+  float min_val, max_val;
+};
+class NormInitializer : public Initializer {
+ public:
+  NormInitializer(int _seed, float _mean, float _stddev) : seed(_seed), mean(_mean), stddev(_stddev) {}
+  void init(const FFModel* ff, const Parameter* p) override;   // host Box-Muller from the counter RNG, then upload
+  int seed;
+  float mean, stddev;
+};
+class GlorotUniform : public Initializer {
+ public:
+  explicit GlorotUniform(int _seed) : seed(_seed) {}
+  void init(const FFModel* ff, const Parameter* p) override;
+  int seed;
+};
+
+// ---------------------------------------------------------------------------------------------
+class Optimizer {
+ public:
+  explicit Optimizer(const FFModel* _model) : model(_model) {}
+  virtual ~Optimizer() {}
+  virtual void init(void) = 0;
+  virtual void next(void) = 0;
+  virtual void update(const Parameter* p) = 0;
+  const FFModel* model;
+};
+class SGDOptimizer : public Optimizer {
+ public:
+  SGDOptimizer(const FFModel* _model, double lr = 0.01f, double momentum = 0.0f, bool nesterov = false,
+               double weight_decay = 0.0f);
+  void init(void) override;
+  void next(void) override;
+  void update(const Parameter* p) override;
+  void set_weight_decay(double wd) { weight_decay = wd; }
+  double lr, momentum;
+  bool nesterov;
+  double weight_decay;
+  std::map<const void*, float*> v_values;   // momentum buffers, keyed by weight pointer
+};
+
+// ---------------------------------------------------------------------------------------------
+struct PerfMetrics {
+  PerfMetrics();
+  void update(const PerfMetrics& one);
+  void print(int flags) const;       // the reference's "[Metrics] ..." line on stderr
+  int train_all, train_correct;
+  float cce_loss, sparse_cce_loss, mse_loss, rmse_loss, mae_loss;
+  double start_time;
+};
+
+// ---------------------------------------------------------------------------------------------
+class Op {
+ public:
+  Op(FFModel& model, OperatorType type, const char* name, int num_inputs, const Tensor* inputs);
+  virtual ~Op() {}
+  virtual void init(const FFModel&) {}
+  virtual void forward(const FFModel&) = 0;
+  virtual void backward(const FFModel&) = 0;
+  virtual void create_weights(FFModel&) {}
+  virtual void create_output_and_partition(FFModel&) = 0;
+  virtual void print_layer(const FFModel&) const;
+  OperatorType op_type;
+  char name[MAX_OPNAME];
+  Tensor inputs[MAX_NUM_INPUTS];
+  Tensor outputs[1];
+  Parameter weights[2];
+  int numInputs, numWeights, numOutputs;
+  bool profiling;
+};
+
+class Linear : public Op {
+ public:
+  Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode activation, bool use_bias, const Op* shared_op,
+         Initializer* kernel_initializer, Initializer* bias_initializer, const char* name);
+  void create_weights(FFModel& model) override;
+  void create_output_and_partition(FFModel& model) override;
+  void forward(const FFModel&) override;
+  void backward(const FFModel&) override;
+  int in_channels, out_channels;
+  ActiMode activation;
+  bool use_bias;
+  bool discard_input_grad;      // first layer on a model input: dX is never consumed
+  Initializer *kernel_initializer, *bias_initializer;
+};
+
+class Embedding : public Op {
+ public:
+  Embedding(FFModel& model, const Tensor& input, int num_entries, int outDim, AggrMode aggr, const Op* shared_op,
+            Initializer* kernel_initializer, const char* name);
+  void create_weights(FFModel& model) override;
+  void create_output_and_partition(FFModel& model) override;
+  void forward(const FFModel&) override;     // first table of a group launches the whole group
+  void backward(const FFModel&) override;
+  int num_entries, out_channels;
+  AggrMode aggr;
+  Initializer* kernel_initializer;
+  int table_index;              // position among the model's embedding ops
+  int owner_rank;               // table-wise sharding: table_index % world_size
+};
+
+class Concat : public Op {
+ public:
+  Concat(FFModel& model, int n, const Tensor* inputs, int axis, const char* name);
+  void create_output_and_partition(FFModel& model) override;
+  void forward(const FFModel&) override;
+  void backward(const FFModel&) override;
+  int axis;                     // Legion axis (user axis flipped, [ref: src/ops/concat.cu:29-49,109-112])
+};
+
+class BatchMatmul : public Op {
+ public:
+  BatchMatmul(FFModel& model, const Tensor& A, const Tensor& B, int a_seq_length_dim, int b_seq_length_dim);
+  void create_output_and_partition(FFModel& model) override;
+  void forward(const FFModel&) override;
+  void backward(const FFModel&) override;
+  int a_seq_length_dim, b_seq_length_dim;
+};
+
+// ---------------------------------------------------------------------------------------------
+class FFModel {
+ public:
+  explicit FFModel(FFConfig& config);
+  ~FFModel();
+
+  Tensor embedding(const Tensor& input, int num_entires, int outDim, AggrMode aggr, const Op* shared_op = NULL,
+                   Initializer* kernel_initializer = NULL, const char* name = NULL);
+  Tensor batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_dim = -1, int b_seq_length_dim = -1);
+  Tensor dense(const Tensor& input, int outDim, ActiMode activation = AC_MODE_NONE, bool use_bias = true,
+               const Op* shared_op = NULL, Initializer* kernel_initializer = NULL,
+               Initializer* bias_initializer = NULL, const char* name = NULL);
+  Tensor concat(int n, const Tensor* tensors, int axis, const char* name = NULL);
+  template <int NDIM>
+  Tensor create_tensor(const int dims[], DataType data_type, const Op* owner_op = NULL, bool create_grad = true);
+  template <int NDIM>
+  Parameter create_weight(const int dims[], const Op* op, DataType data_type, Initializer* initializer,
+                          bool create_grad = true);
+
+  void compile(LossType loss_type, const std::vector<MetricsType>& metrics, CompMode comp_mode = COMP_MODE_TRAINING);
+  void compile(Optimizer* optimizer, LossType loss_type, const std::vector<MetricsType>& metrics,
+               CompMode comp_mode = COMP_MODE_TRAINING);
+  void init_layers();
+  void reset_metrics();
+  void forward(int seq_length = -1);
+  void zero_gradients();
+  void compute_metrics();
+  void backward(int seq_length = -1);
+  void update();
+  // Legion trace memoisation [ref: examples/cpp/DLRM/dlrm.cc:174-181] == hipGraph capture + replay
+  void begin_trace(int trace_id);
+  void end_trace(int trace_id);
+  void sync();                                   // issue_execution_fence + wait
+  PerfMetrics get_perf_metrics();                // device -> host (synchronises)
+  void print_layers(int id);
+  std::string get_operator_type_name(OperatorType type) const;
+
+  // ---- state ---------------------------------------------------------------------------------
+  int op_global_guid;
+  FFConfig config;
+  Optimizer* optimizer;
+  LossType loss_type;
+  int metrics_flags;
+  Tensor label_tensor;
+  std::vector<Op*> layers;
+  std::vector<Parameter> parameters;
+  int seq_length;
+
+  // ---- runtime (what FFHandler + Legion regions are in the reference) ------------------------
+  const KernelApi* api;
+  ffh_ctx* ctx;
+  ffh_stream stream;           // main compute stream
+  ffh_stream side_stream;      // embedding gather / exchange / sparse update
+  ffh_event ev_fork, ev_join, ev_grad_ready, ev_update_done;
+  int rank, world_size;
+  bool exchange;               // table-wise exchange + gradient all-reduce active (world_size > 1)
+  int64_t local_batch;         // config.batchSize / world_size
+  bool compiled;
+
+  void* dmalloc(size_t bytes) const;
+  void check(int rc, const char* what) const;   // non-zero rc -> print ffh_last_error_string + abort (reference behaviour)
+
+  // embedding group (all Embedding ops share L, D, aggr in DLRM): batched launches + exchange
+  std::vector<Embedding*> embeddings;
+  void embedding_group_forward(ffh_stream s) const;
+  void embedding_group_update(ffh_stream s) const;
+  bool fused_embedding_update() const;
+  mutable bool emb_forward_issued, emb_forward_joined;
+
+  // slabs
+  float *mlp_weights, *mlp_grads;  size_t mlp_count;          // all Linear params, contiguous (one all-reduce, one SGD launch)
+  char* act_grad_slab;  size_t act_grad_bytes;                // every activation gradient (one memset per step)
+  void* workspace;  size_t workspace_bytes;
+  ffh_perf_metrics* d_perf;
+  // table-wise exchange buffers (world_size > 1)
+  float *xsend, *xrecv, *gsend, *grecv;
+  std::vector<int64_t> fwd_send_counts, fwd_recv_counts;      // floats per peer
+  std::vector<int> owned_tables;                              // table indices this rank owns
+  int tables_of_rank(int r) const;
+
+  // trace / graph
+  std::map<int, ffh_graph> graphs;
+  int capturing_trace, replaying_trace;
+
+  std::vector<TensorImpl*> tensor_impls;
+  std::vector<Tensor*> input_tensors;
+ private:
+  void allocate();
+};

@@ -1,0 +1,1123 @@
+// model.cc -- FFModel / Op / Optimizer / Initializer of the reference API over the kernel C-ABI.
+// See ffmodel.h for the reference declarations each class mirrors.
+#include "ffmodel.h"
+
+#include <algorithm>
+#include <cassert>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/ffh_rng.h"
+#include "backend.h"
+
+namespace {
+
+[[noreturn]] void die(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  fprintf(stderr, "FATAL: ");
+  vfprintf(stderr, fmt, ap);
+  fprintf(stderr, "\n");
+  va_end(ap);
+  abort();   // the reference asserts/exits on every such condition [ref: include/cuda_helper.h:6-47]
+}
+
+double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+size_t dtype_size(DataType t) {
+  switch (t) {
+    case DT_FLOAT: return 4;
+    case DT_DOUBLE: return 8;
+    case DT_INT32: return 4;
+    case DT_INT64: return 8;
+    case DT_BOOLEAN: return 1;
+    default: return 0;
+  }
+}
+
+size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+// =============================================================================================
+// FFConfig  [ref: src/runtime/model.cc:2211-2403]
+// =============================================================================================
+FFConfig::FFConfig() {
+  epochs = 1;
+  batchSize = 64;
+  printFreq = 10;
+  numNodes = 1;
+  cpusPerNode = 0;
+  workersPerNode = 0;
+  learningRate = 0.01f;
+  weightDecay = 0.0001f;
+  workSpaceSize = (size_t)1 << 30;
+  syntheticInput = false;
+  profiling = false;
+  perform_fusion = false;
+  computationMode = COMP_MODE_TRAINING;
+  device = 0;
+  seed = 0;
+  enable_graph = true;
+  overlap_embedding = true;
+  dense_embedding_update = false;
+  force_exchange = false;
+  memset(&comm, 0, sizeof comm);
+  comm.rank = 0;
+  comm.world_size = 1;
+}
+
+void FFConfig::parse_args(char** argv, int argc) {
+  for (int i = 1; i < argc; i++) {
+    auto is = [&](const char* a) { return !strcmp(argv[i], a); };
+    auto next = [&]() -> const char* {
+      if (i + 1 >= argc) die("flag %s needs a value", argv[i]);
+      return argv[++i];
+    };
+    if (is("-e") || is("--epochs")) { epochs = atoi(next()); continue; }
+    if (is("-b") || is("--batch-size")) { batchSize = atoi(next()); continue; }
+    if (is("--lr") || is("--learning-rate")) { learningRate = (float)atof(next()); continue; }
+    if (is("--wd") || is("--weight-decay")) { weightDecay = (float)atof(next()); continue; }
+    if (is("-p") || is("--print-freq")) { printFreq = atoi(next()); continue; }
+    if (is("-d") || is("--dataset")) { dataset_path = next(); continue; }
+    if (is("--import") || is("--import-strategy")) { import_strategy_file = next(); continue; }
+    if (is("--export") || is("--export-strategy")) { export_strategy_file = next(); continue; }
+    if (is("-ll:gpu")) { workersPerNode = atoi(next()); continue; }
+    if (is("--nodes")) { numNodes = atoi(next()); continue; }
+    if (is("-ll:cpu")) { cpusPerNode = atoi(next()); continue; }
+    if (is("--profiling")) { profiling = true; continue; }
+    if (is("--fusion")) { perform_fusion = true; continue; }
+    // Legion/Realm pass-through flags of the reference scripts: accepted, meaningless here
+    if (is("-ll:fsize") || is("-ll:zsize") || is("-ll:util") || is("-ll:csize") || is("--budget") || is("--search-budget") ||
+        is("--alpha") || is("--search-alpha") || is("--simulator-workspace-size") || is("--strategy") ||
+        is("--machine-model-version") || is("--machine-model-file") || is("--simulator-segment-size") ||
+        is("--simulator-max-num-segments") || is("--taskgraph")) { next(); continue; }
+    if (is("-dm:memoize") || is("-dm:memorize") || is("--overlap") || is("--enable-parameter-parallel") ||
+        is("--enable-attribute-parallel") || is("--allow-tensor-op-math-conversion") || is("--enable-propagation")) continue;
+    // this build
+    if (is("--seed")) { seed = strtoull(next(), nullptr, 10); continue; }
+    if (is("--backend")) { backend_lib = next(); continue; }
+    if (is("--device")) { device = atoi(next()); continue; }
+    if (is("--no-trace")) { enable_graph = false; continue; }
+    if (is("--no-overlap")) { overlap_embedding = false; continue; }
+    if (is("--dense-embedding-update")) { dense_embedding_update = true; continue; }
+    if (is("--force-exchange")) { force_exchange = true; continue; }
+  }
+}
+
+// =============================================================================================
+// Tensor / Parameter
+// =============================================================================================
+Tensor::Tensor() : numDim(0), data_type(DT_FLOAT), sync_type(NONE), owner_op(nullptr), owner_idx(0), impl(nullptr) {
+  for (int i = 0; i < MAX_TENSOR_DIM; i++) adim[i] = 0;
+}
+
+size_t Tensor::get_volume() const {
+  size_t v = 1;
+  for (int i = 0; i < numDim; i++) v *= (size_t)adim[i];
+  return v;
+}
+
+int64_t Tensor::rows() const {
+  int64_t r = 1;
+  for (int i = 1; i < numDim; i++) r *= adim[i];
+  return r;
+}
+
+namespace {
+int64_t local_rows(const Tensor& t, const FFModel*) { return t.impl ? t.impl->rows_local : 0; }
+}  // namespace
+
+template <typename T>
+bool Tensor::set_tensor(const FFModel* model, const std::vector<int>& dims, const T* data) {
+  if (!impl || !impl->ptr) die("set_tensor before compile()");
+  if (sizeof(T) != dtype_size(data_type)) die("set_tensor: element type does not match the tensor's data type");
+  size_t vol = 1;
+  for (int d : dims) vol *= (size_t)d;
+  const int64_t cols_ = adim[0];
+  const int64_t nrows = (int64_t)(vol / (size_t)cols_);
+  if (vol % (size_t)cols_ != 0 || nrows != impl->rows_local)
+    die("set_tensor: %zu elements given, this rank holds %lld x %lld", vol, (long long)impl->rows_local, (long long)cols_);
+  if (impl->ld == cols_) {
+    model->check(model->api->ffh_memcpy_h2d(model->ctx, impl->ptr, data, vol * sizeof(T), model->stream), "set_tensor");
+  } else {
+    for (int64_t r = 0; r < nrows; r++)
+      model->check(model->api->ffh_memcpy_h2d(model->ctx, (char*)impl->ptr + r * impl->ld * sizeof(T), data + r * cols_,
+                                               cols_ * sizeof(T), model->stream), "set_tensor");
+  }
+  model->check(model->api->ffh_stream_sync(model->ctx, model->stream), "set_tensor sync");
+  return true;
+}
+
+namespace {
+template <typename T>
+bool copy_out(const FFModel* model, const Tensor& t, const void* base, int64_t ld, T* data) {
+  if (!base) die("get_tensor before compile() (or tensor has no gradient)");
+  const int64_t cols_ = t.adim[0];
+  const int64_t nrows = local_rows(t, model);
+  model->check(model->api->ffh_stream_sync(model->ctx, model->stream), "get_tensor sync");
+  model->check(model->api->ffh_stream_sync(model->ctx, model->side_stream), "get_tensor sync");
+  if (ld == cols_) {
+    model->check(model->api->ffh_memcpy_d2h(model->ctx, data, base, (size_t)nrows * cols_ * sizeof(T), model->stream), "get_tensor");
+  } else {
+    for (int64_t r = 0; r < nrows; r++)
+      model->check(model->api->ffh_memcpy_d2h(model->ctx, data + r * cols_, (const char*)base + r * ld * sizeof(T),
+                                               cols_ * sizeof(T), model->stream), "get_tensor");
+  }
+  model->check(model->api->ffh_stream_sync(model->ctx, model->stream), "get_tensor sync");
+  return true;
+}
+}  // namespace
+
+template <typename T>
+bool Tensor::get_tensor(const FFModel* model, T* data) const {
+  if (sizeof(T) != dtype_size(data_type)) die("get_tensor: element type does not match the tensor's data type");
+  return copy_out<T>(model, *this, impl ? impl->ptr : nullptr, impl ? impl->ld : 0, data);
+}
+template <typename T>
+bool Tensor::get_grad(const FFModel* model, T* data) const {
+  return copy_out<T>(model, *this, impl ? impl->grad : nullptr, impl ? impl->grad_ld : 0, data);
+}
+template <typename T>
+bool Parameter::set_weights(const FFModel* model, const std::vector<int>& dims, const T* data) {
+  return set_tensor<T>(model, dims, data);
+}
+template <typename T>
+bool Parameter::get_weights(const FFModel* model, T* data) const {
+  return get_tensor<T>(model, data);
+}
+template bool Tensor::set_tensor<float>(const FFModel*, const std::vector<int>&, const float*);
+template bool Tensor::set_tensor<int64_t>(const FFModel*, const std::vector<int>&, const int64_t*);
+template bool Tensor::get_tensor<float>(const FFModel*, float*) const;
+template bool Tensor::get_tensor<int64_t>(const FFModel*, int64_t*) const;
+template bool Tensor::get_grad<float>(const FFModel*, float*) const;
+template bool Parameter::set_weights<float>(const FFModel*, const std::vector<int>&, const float*);
+template bool Parameter::get_weights<float>(const FFModel*, float*) const;
+
+// =============================================================================================
+// Initializers [ref: src/runtime/initializer.cc, initializer_kernel.cu:24-276]
+// The reference draws from cuRAND; streams here come from include/ffh_rng.h.
+// =============================================================================================
+void ZeroInitializer::init(const FFModel* ff, const Parameter* p) {
+  ff->check(ff->api->ffh_zero(ff->ctx, p->impl->ptr, p->get_volume() * sizeof(float), ff->stream), "ZeroInitializer");
+}
+void ConstantInitializer::init(const FFModel* ff, const Parameter* p) {
+  ff->check(ff->api->ffh_fill_f32(ff->ctx, (float*)p->impl->ptr, (int64_t)p->get_volume(), value, ff->stream), "ConstantInitializer");
+}
+void UniformInitializer::init(const FFModel* ff, const Parameter* p) {
+  ff->check(ff->api->ffh_init_uniform(ff->ctx, (float*)p->impl->ptr, (int64_t)p->get_volume(),
+                                      ff->config.seed * 0x9E3779B1ULL + (uint64_t)(uint32_t)seed, min_val, max_val, ff->stream),
+            "UniformInitializer");
+}
+void NormInitializer::init(const FFModel* ff, const Parameter* p) {
+  // Box-Muller on the host from the counter-based stream, then one upload (MLP tensors are small)
+  const size_t n = p->get_volume();
+  std::vector<float> h(n);
+  const uint64_t s = ff->config.seed * 0x9E3779B1ULL + (uint64_t)(uint32_t)seed;
+  for (size_t i = 0; i < n; i++) {
+    const uint64_t h1 = ffh_hash(s, 2 * i), h2 = ffh_hash(s, 2 * i + 1);
+    const double u1 = ((double)(h1 >> 40) + 1.0) / 16777216.0;   // (0, 1]
+    const double u2 = (double)(h2 >> 40) / 16777216.0;           // [0, 1)
+    const double z = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586476925 * u2);
+    h[i] = (float)((double)mean + (double)stddev * z);
+  }
+  ff->check(ff->api->ffh_memcpy_h2d(ff->ctx, p->impl->ptr, h.data(), n * sizeof(float), ff->stream), "NormInitializer");
+  ff->check(ff->api->ffh_stream_sync(ff->ctx, ff->stream), "NormInitializer sync");
+}
+void GlorotUniform::init(const FFModel* ff, const Parameter* p) {
+  // scale = sqrt(6 / (fan_in + fan_out)) [ref: src/runtime/initializer_kernel.cu:24-60]
+  const float fan = (float)(p->adim[0] + (p->numDim > 1 ? p->adim[1] : 0));
+  const float scale = std::sqrt(6.0f / fan);
+  ff->check(ff->api->ffh_init_uniform(ff->ctx, (float*)p->impl->ptr, (int64_t)p->get_volume(),
+                                      ff->config.seed * 0x9E3779B1ULL + (uint64_t)(uint32_t)seed, -scale, scale, ff->stream),
+            "GlorotUniform");
+}
+
+// =============================================================================================
+// PerfMetrics [ref: src/metrics_functions/metrics_functions.cc:20-80]
+// =============================================================================================
+PerfMetrics::PerfMetrics()
+    : train_all(0), train_correct(0), cce_loss(0), sparse_cce_loss(0), mse_loss(0), rmse_loss(0), mae_loss(0) {
+  start_time = now_us();
+}
+void PerfMetrics::update(const PerfMetrics& o) {
+  train_all += o.train_all; train_correct += o.train_correct; cce_loss += o.cce_loss;
+  sparse_cce_loss += o.sparse_cce_loss; mse_loss += o.mse_loss; rmse_loss += o.rmse_loss; mae_loss += o.mae_loss;
+}
+void PerfMetrics::print(int flags) const {
+  std::string out = "[Metrics]";
+  if (flags & 1) {
+    const float acc = train_all ? train_correct * 100.0f / train_all : 0.0f;
+    out += " accuracy: " + std::to_string(acc) + "% (" + std::to_string(train_correct) + " / " + std::to_string(train_all) + ")";
+  }
+  if (flags & 2) out += " mean_squared_error: " + std::to_string(train_all ? mse_loss / train_all : 0.0f);
+  if (flags & 4) out += " root_mean_squared_error: " + std::to_string(train_all ? rmse_loss / train_all : 0.0f);
+  if (flags & 8) out += " mean_absolute_error: " + std::to_string(train_all ? mae_loss / train_all : 0.0f);
+  fprintf(stderr, "%s\n", out.c_str());
+}
+
+// =============================================================================================
+// Op base
+// =============================================================================================
+std::string FFModel::get_operator_type_name(OperatorType type) const {
+  switch (type) {
+    case OP_LINEAR: return "Dense";
+    case OP_EMBEDDING: return "Embedding";
+    case OP_CONCAT: return "Concat";
+    case OP_BATCHMATMUL: return "BatchMatmul";
+    default: return "Unknown";
+  }
+}
+
+Op::Op(FFModel& model, OperatorType type, const char* _name, int num_inputs, const Tensor* _inputs)
+    : op_type(type), numInputs(num_inputs), numWeights(0), numOutputs(1), profiling(model.config.profiling) {
+  // "<Type>_<guid>" from guid 100 [ref: src/runtime/model.cc:253-268]
+  std::string pc = (_name == nullptr ? model.get_operator_type_name(type) : std::string(_name)) + "_" +
+                   std::to_string(model.op_global_guid++);
+  if (pc.length() >= MAX_OPNAME) die("operator name too long: %s", pc.c_str());
+  strcpy(name, pc.c_str());
+  if (num_inputs > MAX_NUM_INPUTS) die("%s: more than %d inputs", name, MAX_NUM_INPUTS);
+  for (int i = 0; i < num_inputs; i++) inputs[i] = _inputs[i];
+  outputs[0].owner_op = this;
+  outputs[0].owner_idx = 0;
+  outputs[0].data_type = DT_FLOAT;
+  outputs[0].impl = new TensorImpl();
+  model.tensor_impls.push_back(outputs[0].impl);
+  outputs[0].impl->guid = (int)model.tensor_impls.size() - 1;
+}
+
+void Op::print_layer(const FFModel&) const {
+  printf("%s: inputs %d ->", name, numInputs);
+  for (int d = outputs[0].numDim - 1; d >= 0; d--) printf(" %d", outputs[0].adim[d]);
+  printf("\n");
+}
+
+// =============================================================================================
+// FFModel: construction, graph building
+// =============================================================================================
+FFModel::FFModel(FFConfig& _config)
+    : op_global_guid(100), config(_config), optimizer(nullptr), loss_type(LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE),
+      metrics_flags(0), seq_length(-1), api(nullptr), ctx(nullptr), stream(nullptr), side_stream(nullptr),
+      ev_fork(nullptr), ev_join(nullptr), ev_grad_ready(nullptr), ev_update_done(nullptr), compiled(false),
+      emb_forward_issued(false), emb_forward_joined(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
+      act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
+      xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1) {
+  rank = config.comm.world_size > 1 ? config.comm.rank : 0;
+  world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
+  if (world_size == 1 && config.workersPerNode > 1)
+    die("-ll:gpu %d: this build runs one process per GPU; launch %d ranks with\n"
+        "       python -m torch.distributed.run --nproc-per-node %d dlrm_flexflow_amd/run_dlrm.py <flags>",
+        config.workersPerNode, config.workersPerNode, config.workersPerNode);
+  if (world_size > 1 && (!config.comm.alltoall_f32 || !config.comm.allreduce_sum_f32))
+    die("world_size %d needs the ffcomm callbacks", world_size);
+  if (config.batchSize % world_size != 0) die("batch size %d is not divisible by %d ranks", config.batchSize, world_size);
+  local_batch = config.batchSize / world_size;
+  exchange = world_size > 1 || (config.force_exchange && config.comm.alltoall_f32 && config.comm.allreduce_sum_f32);
+  api = load_kernel_api(config.backend_lib);
+  int rc = api->ffh_ctx_create(&ctx, config.device);
+  if (rc != FFH_OK || !ctx) die("ffh_ctx_create(device %d) failed with %d on %s -- no usable GPU?", config.device, rc, api->path.c_str());
+  check(api->ffh_stream_create(ctx, &stream), "stream create");
+  check(api->ffh_stream_create(ctx, &side_stream), "stream create");
+  check(api->ffh_event_create(ctx, &ev_fork), "event create");
+  check(api->ffh_event_create(ctx, &ev_join), "event create");
+  check(api->ffh_event_create(ctx, &ev_grad_ready), "event create");
+  check(api->ffh_event_create(ctx, &ev_update_done), "event create");
+}
+
+FFModel::~FFModel() {
+  if (!ctx) return;
+  api->ffh_device_sync(ctx);
+  for (auto& kv : graphs) api->ffh_graph_destroy(ctx, kv.second);
+  // device memory is released with the context's process; explicit frees keep long-lived hosts clean
+  for (TensorImpl* t : tensor_impls) {
+    if (t->ptr && !t->alias && t->bytes) api->ffh_free(ctx, t->ptr);
+    delete t;
+  }
+  for (void* p : {(void*)mlp_weights, (void*)mlp_grads, (void*)act_grad_slab, workspace, (void*)d_perf, (void*)xsend,
+                  (void*)xrecv, (void*)gsend, (void*)grecv})
+    if (p) api->ffh_free(ctx, p);
+  api->ffh_event_destroy(ctx, ev_fork); api->ffh_event_destroy(ctx, ev_join);
+  api->ffh_event_destroy(ctx, ev_grad_ready); api->ffh_event_destroy(ctx, ev_update_done);
+  api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream);
+  api->ffh_ctx_destroy(ctx);
+}
+
+void FFModel::check(int rc, const char* what) const {
+  if (rc != FFH_OK) die("%s failed (%d): %s", what, rc, api->ffh_last_error_string(ctx));
+}
+
+void* FFModel::dmalloc(size_t bytes) const {
+  void* p = nullptr;
+  int rc = api->ffh_malloc(ctx, &p, bytes);
+  if (rc != FFH_OK || !p) die("device allocation of %zu bytes failed: %s", bytes, api->ffh_last_error_string(ctx));
+  return p;
+}
+
+template <int NDIM>
+Tensor FFModel::create_tensor(const int dims[], DataType data_type, const Op* owner_op, bool create_grad) {
+  (void)create_grad;
+  Tensor t;
+  t.numDim = NDIM;
+  t.data_type = data_type;
+  t.owner_op = const_cast<Op*>(owner_op);
+  for (int i = 0; i < NDIM; i++) t.adim[i] = dims[NDIM - 1 - i];   // Legion order [ref: src/runtime/model.cc:865-868]
+  t.impl = new TensorImpl();
+  tensor_impls.push_back(t.impl);
+  t.impl->guid = (int)tensor_impls.size() - 1;
+  t.impl->is_input = owner_op == nullptr;
+  if (owner_op == nullptr) {
+    Tensor* keep = new Tensor(t);
+    input_tensors.push_back(keep);
+  }
+  return t;
+}
+template Tensor FFModel::create_tensor<1>(const int[], DataType, const Op*, bool);
+template Tensor FFModel::create_tensor<2>(const int[], DataType, const Op*, bool);
+template Tensor FFModel::create_tensor<3>(const int[], DataType, const Op*, bool);
+template Tensor FFModel::create_tensor<4>(const int[], DataType, const Op*, bool);
+
+template <int NDIM>
+Parameter FFModel::create_weight(const int dims[], const Op* op, DataType data_type, Initializer* initializer, bool) {
+  Parameter p;
+  p.numDim = NDIM;
+  p.data_type = data_type;
+  p.owner_op = const_cast<Op*>(op);
+  p.sync_type = world_size > 1 ? NCCL : PS;
+  for (int i = 0; i < NDIM; i++) p.adim[i] = dims[NDIM - 1 - i];
+  p.impl = new TensorImpl();
+  tensor_impls.push_back(p.impl);
+  p.impl->guid = (int)tensor_impls.size() - 1;
+  (void)initializer;
+  return p;
+}
+template Parameter FFModel::create_weight<1>(const int[], const Op*, DataType, Initializer*, bool);
+template Parameter FFModel::create_weight<2>(const int[], const Op*, DataType, Initializer*, bool);
+
+Tensor FFModel::dense(const Tensor& input, int outDim, ActiMode activation, bool use_bias, const Op* shared_op,
+                      Initializer* kernel_initializer, Initializer* bias_initializer, const char* name) {
+  // default initialisers [ref: src/ops/linear.cu:19-39]
+  if (kernel_initializer == nullptr) kernel_initializer = new GlorotUniform(std::rand());
+  if (bias_initializer == nullptr) bias_initializer = new ZeroInitializer();
+  Linear* li = new Linear(*this, input, outDim, activation, use_bias, shared_op, kernel_initializer, bias_initializer, name);
+  layers.push_back(li);
+  return li->outputs[0];
+}
+
+Tensor FFModel::embedding(const Tensor& input, int num_entries, int outDim, AggrMode aggr, const Op* shared_op,
+                          Initializer* kernel_initializer, const char* name) {
+  if (kernel_initializer == nullptr) kernel_initializer = new GlorotUniform(std::rand());   // [ref: src/ops/embedding.cu:19-34]
+  Embedding* e = new Embedding(*this, input, num_entries, outDim, aggr, shared_op, kernel_initializer, name);
+  layers.push_back(e);
+  return e->outputs[0];
+}
+
+Tensor FFModel::concat(int n, const Tensor* tensors, int axis, const char* name) {
+  Concat* c = new Concat(*this, n, tensors, axis, name);
+  layers.push_back(c);
+  return c->outputs[0];
+}
+
+Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_dim, int b_seq_length_dim) {
+  BatchMatmul* b = new BatchMatmul(*this, A, B, a_seq_length_dim, b_seq_length_dim);
+  layers.push_back(b);
+  return b->outputs[0];
+}
+
+// =============================================================================================
+// Linear [ref: src/ops/linear.cu]
+// =============================================================================================
+Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activation, bool _use_bias, const Op* shared_op,
+               Initializer* ki, Initializer* bi, const char* name)
+    : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), activation(_activation),
+      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), kernel_initializer(ki), bias_initializer(bi) {
+  if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
+  if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
+  if (activation != AC_MODE_NONE && activation != AC_MODE_RELU && activation != AC_MODE_SIGMOID)
+    die("%s: activation %d not supported (NONE, RELU, SIGMOID)", this->name, (int)activation);
+  outputs[0].numDim = input.numDim;
+  for (int i = 1; i < input.numDim; i++) outputs[0].adim[i] = input.adim[i];
+  outputs[0].adim[0] = out_dim;   // [ref: src/ops/linear.cu:41-71]
+  numWeights = use_bias ? 2 : 1;
+}
+void Linear::create_output_and_partition(FFModel&) {}
+void Linear::create_weights(FFModel& model) {
+  const int kdims[2] = {out_channels, in_channels};
+  weights[0] = model.create_weight<2>(kdims, this, DT_FLOAT, kernel_initializer);
+  if (use_bias) {
+    const int bdims[1] = {out_channels};
+    weights[1] = model.create_weight<1>(bdims, this, DT_FLOAT, bias_initializer);
+  }
+}
+void Linear::forward(const FFModel& ff) {
+  const Tensor& x = inputs[0];
+  const Tensor& y = outputs[0];
+  const int64_t b = local_rows(y, &ff);
+  ff.check(ff.api->ffh_linear_fwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, (float*)y.impl->ptr, y.impl->ld,
+                                  (const float*)weights[0].impl->ptr, use_bias ? (const float*)weights[1].impl->ptr : nullptr,
+                                  in_channels, out_channels, b, (int)activation, ff.stream), name);
+}
+void Linear::backward(const FFModel& ff) {
+  const Tensor& x = inputs[0];
+  const Tensor& y = outputs[0];
+  const int64_t b = local_rows(y, &ff);
+  float* dx = discard_input_grad ? nullptr : x.impl->grad;
+  ff.check(ff.api->ffh_linear_bwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, dx, x.impl->grad_ld,
+                                  (const float*)y.impl->ptr, y.impl->ld, y.impl->grad, y.impl->grad_ld,
+                                  (const float*)weights[0].impl->ptr, weights[0].impl->grad,
+                                  use_bias ? weights[1].impl->grad : nullptr, in_channels, out_channels, b, (int)activation,
+                                  ff.stream), name);
+}
+
+// =============================================================================================
+// Embedding [ref: src/ops/embedding.cu]
+// =============================================================================================
+Embedding::Embedding(FFModel& model, const Tensor& input, int _num_entries, int outDim, AggrMode _aggr, const Op* shared_op,
+                     Initializer* ki, const char* name)
+    : Op(model, OP_EMBEDDING, name, 1, &input), num_entries(_num_entries), out_channels(outDim), aggr(_aggr),
+      kernel_initializer(ki) {
+  if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
+  if (input.data_type != DT_INT64) die("%s: input must be DT_INT64", this->name);
+  if (input.numDim != 2) die("%s: input must be [batch][bag]", this->name);
+  if (input.owner_op != nullptr) die("%s: input must be a model input tensor", this->name);
+  if (aggr != AGGR_MODE_SUM && aggr != AGGR_MODE_AVG) die("%s: aggr must be SUM or AVG", this->name);
+  outputs[0].numDim = 2;
+  outputs[0].adim[0] = outDim;
+  outputs[0].adim[1] = input.adim[1];
+  numWeights = 1;
+  table_index = (int)model.embeddings.size();
+  owner_rank = table_index % model.world_size;   // table i -> GPU i % n [ref: examples/cpp/DLRM/strategies/dlrm_strategy.cc:252-256]
+  model.embeddings.push_back(this);
+}
+void Embedding::create_output_and_partition(FFModel&) {}
+void Embedding::create_weights(FFModel& model) {
+  const int dims[2] = {num_entries, out_channels};
+  weights[0] = model.create_weight<2>(dims, this, DT_FLOAT, kernel_initializer);
+}
+void Embedding::forward(const FFModel& ff) {
+  // the whole group was launched at the top of forward() (side stream) or is launched by its first table
+  if (!ff.emb_forward_issued) {
+    ff.embedding_group_forward(ff.stream);
+    ff.emb_forward_issued = true;
+    ff.emb_forward_joined = true;
+  }
+}
+void Embedding::backward(const FFModel& ff) {
+  // reverse layer order: the LAST table is visited first; every table's output gradient is
+  // complete by then (their only consumer ran already), so the group update can start.
+  if (table_index != (int)ff.embeddings.size() - 1) return;
+  if (ff.fused_embedding_update()) {
+    if (ff.config.overlap_embedding) {
+      ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
+      ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.side_stream, ff.ev_grad_ready), "event");
+      ff.embedding_group_update(ff.side_stream);
+      ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_update_done, ff.side_stream), "event");
+    }
+    return;
+  }
+  // reference path: dense scatter-add into the full-table gradient [ref: src/ops/embedding.cu:308-320]
+  for (Embedding* e : ff.embeddings) {
+    if (e->owner_rank != ff.rank) continue;
+    const Tensor& in = e->inputs[0];
+    const Tensor& out = e->outputs[0];
+    const float* g = out.impl->grad;
+    int64_t gld = out.impl->grad_ld, batch = ff.local_batch;
+    if (ff.exchange) die("dense embedding update is single-rank only");
+    ff.check(ff.api->ffh_embedding_bwd_dense(ff.ctx, (const int64_t*)in.impl->ptr, g, e->weights[0].impl->grad, in.adim[0],
+                                             e->out_channels, batch, e->num_entries, gld, (int)e->aggr, ff.stream), e->name);
+  }
+}
+
+// =============================================================================================
+// Concat [ref: src/ops/concat.cu]
+// =============================================================================================
+Concat::Concat(FFModel& model, int n, const Tensor* _inputs, int _axis, const char* name)
+    : Op(model, OP_CONCAT, name, n, _inputs) {
+  if (n < 1) die("%s: needs at least one input", this->name);
+  const int nd = _inputs[0].numDim;
+  axis = nd - 1 - _axis;   // user axis -> Legion axis [ref: src/ops/concat.cu:29-49]
+  if (axis < 0 || axis >= nd) die("%s: axis out of range", this->name);
+  outputs[0].numDim = nd;
+  for (int d = 0; d < nd; d++) outputs[0].adim[d] = _inputs[0].adim[d];
+  for (int i = 1; i < n; i++) {
+    if (_inputs[i].numDim != nd) die("%s: rank mismatch", this->name);
+    for (int d = 0; d < nd; d++) {
+      if (d == axis) outputs[0].adim[d] += _inputs[i].adim[d];
+      else if (_inputs[i].adim[d] != outputs[0].adim[d]) die("%s: shape mismatch on dim %d", this->name, d);
+    }
+  }
+  for (int i = 0; i < n; i++)
+    if (_inputs[i].data_type != DT_FLOAT) die("%s: inputs must be DT_FLOAT", this->name);
+}
+void Concat::create_output_and_partition(FFModel&) {}
+
+namespace {
+// calc_blk_size [ref: src/ops/concat.cu:194-208]: block = dims <= axis, num_blocks = dims > axis
+void concat_geometry(const Concat* c, const FFModel& ff, int64_t& num_blocks, int64_t& out_blk, std::vector<int64_t>& in_blk) {
+  const Tensor& o = c->outputs[0];
+  num_blocks = 1; out_blk = 1;
+  for (int d = 0; d < o.numDim; d++) {
+    if (d <= c->axis) out_blk *= o.adim[d];
+    else num_blocks *= (d == o.numDim - 1) ? o.adim[d] / ff.world_size : o.adim[d];   // batch is sharded over ranks
+  }
+  in_blk.resize(c->numInputs);
+  for (int i = 0; i < c->numInputs; i++) {
+    int64_t b = 1;
+    for (int d = 0; d <= c->axis; d++) b *= c->inputs[i].adim[d];
+    in_blk[i] = b;
+  }
+}
+}  // namespace
+
+void Concat::forward(const FFModel& ff) {
+  if (ff.emb_forward_issued && !ff.emb_forward_joined) {   // join the side stream before the first consumer
+    ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.stream, ff.ev_join), "join");
+    ff.emb_forward_joined = true;
+  }
+  int64_t nb, ob;
+  std::vector<int64_t> ib;
+  concat_geometry(this, ff, nb, ob, ib);
+  std::vector<const float*> ptrs(numInputs);
+  std::vector<int64_t> lds(numInputs);
+  for (int i = 0; i < numInputs; i++) {
+    ptrs[i] = (const float*)inputs[i].impl->ptr;
+    lds[i] = axis == 0 ? inputs[i].impl->ld : ib[i];
+  }
+  ff.check(ff.api->ffh_concat_fwd(ff.ctx, (float*)outputs[0].impl->ptr, ob, ptrs.data(), ib.data(), lds.data(), numInputs, nb,
+                                  ff.stream), name);
+}
+void Concat::backward(const FFModel& ff) {
+  int64_t nb, ob;
+  std::vector<int64_t> ib;
+  concat_geometry(this, ff, nb, ob, ib);
+  std::vector<float*> ptrs(numInputs);
+  std::vector<int64_t> lds(numInputs);
+  for (int i = 0; i < numInputs; i++) {
+    ptrs[i] = inputs[i].impl->grad;   // NULL for model inputs: skipped
+    lds[i] = axis == 0 ? inputs[i].impl->grad_ld : ib[i];
+  }
+  ff.check(ff.api->ffh_concat_bwd(ff.ctx, outputs[0].impl->grad, ob, ptrs.data(), ib.data(), lds.data(), numInputs, nb,
+                                  ff.stream), name);
+}
+
+// =============================================================================================
+// BatchMatmul [ref: src/ops/batch_matmul.cu]
+// =============================================================================================
+BatchMatmul::BatchMatmul(FFModel& model, const Tensor& A, const Tensor& B, int asd, int bsd)
+    : Op(model, OP_BATCHMATMUL, nullptr, 2, std::vector<Tensor>{A, B}.data()), a_seq_length_dim(asd), b_seq_length_dim(bsd) {
+  // A (batch, n, k)  B (batch, k, m)  O (batch, n, m) [ref: src/ops/batch_matmul.cu:31-60]
+  if (A.numDim != B.numDim || A.numDim < 3) die("%s: operands must both be [batch..][rows][cols]", name);
+  if (A.adim[0] != B.adim[1]) die("%s: inner dimensions differ (%d vs %d)", name, A.adim[0], B.adim[1]);
+  for (int d = 2; d < A.numDim; d++)
+    if (A.adim[d] != B.adim[d]) die("%s: batch dimensions differ", name);
+  outputs[0].numDim = A.numDim;
+  for (int d = 0; d < A.numDim; d++) outputs[0].adim[d] = A.adim[d];
+  outputs[0].adim[0] = B.adim[0];
+}
+void BatchMatmul::create_output_and_partition(FFModel&) {}
+void BatchMatmul::forward(const FFModel& ff) {
+  const Tensor &a = inputs[0], &b = inputs[1], &o = outputs[0];
+  const int m = b.adim[0], n = a.adim[1], k = a.adim[0];
+  const int64_t batch = local_rows(o, &ff) / n;
+  ff.check(ff.api->ffh_bmm_fwd(ff.ctx, (float*)o.impl->ptr, (const float*)a.impl->ptr, (const float*)b.impl->ptr, m, n, k, batch,
+                               a_seq_length_dim, b_seq_length_dim, ff.seq_length, ff.stream), name);
+}
+void BatchMatmul::backward(const FFModel& ff) {
+  const Tensor &a = inputs[0], &b = inputs[1], &o = outputs[0];
+  const int m = b.adim[0], n = a.adim[1], k = a.adim[0];
+  const int64_t batch = local_rows(o, &ff) / n;
+  if (ff.seq_length >= 0) die("%s: backward does not support seq_length [ref: src/ops/batch_matmul.cu:483-484]", name);
+  if (!a.impl->grad || !b.impl->grad) die("%s: backward needs gradients for both operands", name);
+  ff.check(ff.api->ffh_bmm_bwd(ff.ctx, o.impl->grad, (const float*)a.impl->ptr, a.impl->grad, (const float*)b.impl->ptr,
+                               b.impl->grad, m, n, k, batch, ff.stream), name);
+}
+
+// =============================================================================================
+// SGDOptimizer [ref: src/runtime/optimizer.cc:43-189]
+// =============================================================================================
+SGDOptimizer::SGDOptimizer(const FFModel* _model, double _lr, double _momentum, bool _nesterov, double _wd)
+    : Optimizer(_model), lr(_lr), momentum(_momentum), nesterov(_nesterov), weight_decay(_wd) {}
+void SGDOptimizer::init(void) {
+  if (momentum > 0.0) {
+    for (const Parameter& p : model->parameters) {
+      if (!p.impl->grad) continue;
+      const size_t bytes = p.get_volume() * sizeof(float);
+      float* v = (float*)model->dmalloc(bytes);
+      model->check(model->api->ffh_zero(model->ctx, v, bytes, model->stream), "momentum init");
+      v_values[p.impl->ptr] = v;
+    }
+  }
+}
+void SGDOptimizer::next(void) {}
+void SGDOptimizer::update(const Parameter* p) {
+  if (!p->impl->grad) return;   // embedding tables on the fused path have no dense gradient
+  float* v = momentum > 0.0 ? v_values[p->impl->ptr] : nullptr;
+  model->check(model->api->ffh_sgd_update(model->ctx, (float*)p->impl->ptr, p->impl->grad, v, (int64_t)p->get_volume(), (float)lr,
+                                          (float)weight_decay, (float)momentum, nesterov ? 1 : 0, model->stream), "sgd_update");
+}
+
+// =============================================================================================
+// compile / allocate
+// =============================================================================================
+int FFModel::tables_of_rank(int r) const {
+  int n = 0;
+  for (const Embedding* e : embeddings) n += e->owner_rank == r;
+  return n;
+}
+
+bool FFModel::fused_embedding_update() const {
+  if (config.dense_embedding_update) return false;
+  const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(optimizer);
+  // the fused sparse update equals the reference's dense sweep only for plain SGD
+  return sgd && sgd->momentum == 0.0 && sgd->weight_decay == 0.0;
+}
+
+void FFModel::compile(LossType lt, const std::vector<MetricsType>& metrics, CompMode cm) {
+  if (!optimizer) die("compile(): no optimizer set");
+  compile(optimizer, lt, metrics, cm);
+}
+
+void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vector<MetricsType>& metrics, CompMode comp_mode) {
+  if (compiled) die("compile() called twice");
+  if (layers.empty()) die("compile(): the model has no layers");
+  if (!config.import_strategy_file.empty() || !config.export_strategy_file.empty())
+    fprintf(stderr, "note: strategy files are ignored; placement is the fixed sharding (tables: rank = index %% %d; the rest data-parallel)\n", world_size);
+  optimizer = _optimizer;
+  loss_type = _loss_type;
+  config.computationMode = comp_mode;
+  if (loss_type != LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE && loss_type != LOSS_MEAN_SQUARED_ERROR_SUM_REDUCE)
+    die("loss type %d is not on the DLRM path (only the two MSE losses)", (int)loss_type);
+  metrics_flags = 0;
+  for (MetricsType m : metrics) {
+    switch (m) {
+      case METRICS_ACCURACY: metrics_flags |= 1; break;
+      case METRICS_MEAN_SQUARED_ERROR: metrics_flags |= 2; break;
+      case METRICS_ROOT_MEAN_SQUARED_ERROR: metrics_flags |= 4; break;
+      case METRICS_MEAN_ABSOLUTE_ERROR: metrics_flags |= 8; break;
+      default: die("metrics type %d is not on the DLRM path", (int)m);
+    }
+  }
+  for (Op* op : layers) {
+    op->create_output_and_partition(*this);
+    op->create_weights(*this);
+    for (int i = 0; i < op->numWeights; i++) parameters.push_back(op->weights[i]);
+  }
+  // label tensor: same shape as the final output [ref: src/runtime/model.cc:1740-1769]
+  {
+    const Tensor& fin = layers.back()->outputs[0];
+    label_tensor = fin;
+    label_tensor.owner_op = nullptr;
+    label_tensor.impl = new TensorImpl();
+    tensor_impls.push_back(label_tensor.impl);
+    label_tensor.impl->is_input = true;
+  }
+  if (exchange && config.enable_graph) config.enable_graph = false;   // collectives are host callbacks: not capturable
+  if (exchange && !fused_embedding_update()) die("multi-rank runs need the fused embedding update (plain SGD)");
+  allocate();
+  for (Op* op : layers) {
+    if (Linear* li = dynamic_cast<Linear*>(op)) {
+      li->kernel_initializer->init(this, &li->weights[0]);
+      if (li->use_bias) li->bias_initializer->init(this, &li->weights[1]);
+    } else if (Embedding* e = dynamic_cast<Embedding*>(op)) {
+      if (e->owner_rank == rank) e->kernel_initializer->init(this, &e->weights[0]);
+    }
+  }
+  compiled = true;
+  optimizer->init();
+  check(api->ffh_stream_sync(ctx, stream), "compile sync");
+}
+
+void FFModel::allocate() {
+  // ---- 1. who consumes what -------------------------------------------------------------------
+  std::map<TensorImpl*, int> consumers;
+  for (Op* op : layers)
+    for (int i = 0; i < op->numInputs; i++) consumers[op->inputs[i].impl]++;
+
+  // ---- 2. inputs and label ----------------------------------------------------------------------
+  std::map<TensorImpl*, Embedding*> sparse_of;
+  for (Embedding* e : embeddings) sparse_of[e->inputs[0].impl] = e;
+  auto alloc_rows = [&](const Tensor& t, int64_t nrows) {
+    TensorImpl* im = t.impl;
+    im->ld = t.adim[0];
+    im->rows_local = nrows;
+    im->bytes = (size_t)nrows * (size_t)t.adim[0] * dtype_size(t.data_type);
+    im->ptr = dmalloc(im->bytes);
+    check(api->ffh_zero(ctx, im->ptr, im->bytes, stream), "zero input");
+  };
+  for (Tensor* t : input_tensors) {
+    if (t->adim[t->numDim - 1] != config.batchSize)
+      die("input tensor %d: outermost dimension %d is not the batch size %d", t->impl->guid, t->adim[t->numDim - 1], config.batchSize);
+    auto it = sparse_of.find(t->impl);
+    if (it != sparse_of.end()) {
+      // sparse ids of a table: the owner gathers for the GLOBAL batch; other ranks hold nothing
+      if (it->second->owner_rank == rank) alloc_rows(*t, t->rows());
+    } else {
+      alloc_rows(*t, t->rows() / world_size);
+    }
+  }
+  alloc_rows(label_tensor, label_tensor.rows() / world_size);
+
+  // ---- 3. exchange buffers (table-wise sharding) ----------------------------------------------
+  const int T = (int)embeddings.size();
+  int D = 0, L = 0;
+  if (T) {
+    D = embeddings[0]->out_channels;
+    L = embeddings[0]->inputs[0].adim[0];
+    for (Embedding* e : embeddings)
+      if (e->out_channels != D || e->inputs[0].adim[0] != L || e->aggr != embeddings[0]->aggr)
+        die("all embedding tables must share out_dim, bag size and aggregation (DLRM)");
+    if (T > FFH_MAX_TABLES * 8) die("too many embedding tables");
+  }
+  owned_tables.clear();
+  for (Embedding* e : embeddings)
+    if (e->owner_rank == rank) owned_tables.push_back(e->table_index);
+  const int Tr = (int)owned_tables.size();
+  if (exchange && T) {
+    const size_t send_floats = (size_t)config.batchSize * Tr * D;     // [B_global][Tr*D]
+    size_t recv_floats = 0;
+    fwd_send_counts.assign(world_size, local_batch * Tr * D);
+    fwd_recv_counts.resize(world_size);
+    for (int s = 0; s < world_size; s++) { fwd_recv_counts[s] = local_batch * tables_of_rank(s) * D; recv_floats += fwd_recv_counts[s]; }
+    xsend = (float*)dmalloc(std::max<size_t>(send_floats, 1) * 4);
+    grecv = (float*)dmalloc(std::max<size_t>(send_floats, 1) * 4);
+    xrecv = (float*)dmalloc(std::max<size_t>(recv_floats, 1) * 4);
+    gsend = (float*)dmalloc(std::max<size_t>(recv_floats, 1) * 4);
+  }
+
+  // ---- 4. activations: aliasing into the concat buffer, then one slab per kind -----------------
+  // A producer (Linear / Embedding) whose only consumer is a feature-axis Concat writes straight
+  // into the Concat output; its gradient is the matching slice of the Concat output gradient.
+  std::map<TensorImpl*, std::pair<Concat*, int64_t>> alias_of;   // impl -> (concat, column offset)
+  for (Op* op : layers) {
+    Concat* c = dynamic_cast<Concat*>(op);
+    if (!c || c->axis != 0) continue;
+    int64_t off = 0;
+    for (int i = 0; i < c->numInputs; i++) {
+      const Tensor& in = c->inputs[i];
+      const bool producer_ok = in.owner_op && (in.owner_op->op_type == OP_LINEAR || in.owner_op->op_type == OP_EMBEDDING);
+      const bool via_exchange = exchange && in.owner_op && in.owner_op->op_type == OP_EMBEDDING;
+      if (producer_ok && !via_exchange && consumers[in.impl] == 1 && !alias_of.count(in.impl)) alias_of[in.impl] = {c, off};
+      off += in.adim[0];
+    }
+  }
+  // sizes
+  size_t act_bytes = 0;
+  act_grad_bytes = 0;
+  std::vector<Op*> need;   // ops whose output gets its own storage
+  for (Op* op : layers) {
+    TensorImpl* im = op->outputs[0].impl;
+    if (alias_of.count(im)) continue;
+    if (exchange && op->op_type == OP_EMBEDDING) continue;   // lives in xrecv / gsend
+    const Tensor& o = op->outputs[0];
+    const size_t b = align_up((size_t)(o.rows() / world_size) * o.adim[0] * 4);
+    act_bytes += b;
+    act_grad_bytes += b;
+    need.push_back(op);
+  }
+  char* act_slab = (char*)dmalloc(std::max<size_t>(act_bytes, 256));
+  act_grad_slab = (char*)dmalloc(std::max<size_t>(act_grad_bytes, 256));
+  size_t off_a = 0;
+  for (Op* op : need) {
+    const Tensor& o = op->outputs[0];
+    TensorImpl* im = o.impl;
+    const size_t raw = (size_t)(o.rows() / world_size) * o.adim[0] * 4;
+    im->ptr = act_slab + off_a;
+    im->ld = o.adim[0];
+    im->grad = (float*)(act_grad_slab + off_a);
+    im->grad_ld = o.adim[0];
+    im->bytes = raw;
+    im->rows_local = o.rows() / world_size;
+    im->alias = true;        // slab-owned: not freed individually
+    off_a += align_up(raw);
+  }
+  for (auto& kv : alias_of) {
+    TensorImpl* im = kv.first;
+    Concat* c = kv.second.first;
+    TensorImpl* zo = c->outputs[0].impl;
+    im->ptr = (float*)zo->ptr + kv.second.second;
+    im->ld = zo->ld;
+    im->grad = zo->grad + kv.second.second;
+    im->grad_ld = zo->grad_ld;
+    im->alias = im->grad_alias = true;
+    im->rows_local = c->outputs[0].rows() / world_size;
+    im->bytes = (size_t)(c->outputs[0].rows() / world_size) * zo->ld * 4;
+  }
+  if (exchange) {
+    // embedding outputs are views into the receive buffer: block of source s is [Bl][T_s*D]
+    std::vector<int64_t> base(world_size, 0);
+    for (int s = 1; s < world_size; s++) base[s] = base[s - 1] + fwd_recv_counts[s - 1];
+    std::vector<int> seen(world_size, 0);
+    for (Embedding* e : embeddings) {
+      const int s = e->owner_rank, k = seen[s]++;
+      TensorImpl* im = e->outputs[0].impl;
+      im->ptr = xrecv + base[s] + (int64_t)k * D;
+      im->ld = (int64_t)tables_of_rank(s) * D;
+      im->grad = gsend + base[s] + (int64_t)k * D;
+      im->grad_ld = im->ld;
+      im->alias = im->grad_alias = true;
+      im->rows_local = local_batch;
+      im->bytes = (size_t)local_batch * im->ld * 4;
+    }
+  }
+
+  // ---- 5. parameters: one slab for every Linear tensor, tables on their own ---------------------
+  mlp_count = 0;
+  for (Parameter& p : parameters)
+    if (p.owner_op->op_type == OP_LINEAR) mlp_count += (p.get_volume() + 3) / 4 * 4;
+  mlp_weights = (float*)dmalloc(std::max<size_t>(mlp_count, 64) * 4);
+  mlp_grads = (float*)dmalloc(std::max<size_t>(mlp_count, 64) * 4);
+  check(api->ffh_zero(ctx, mlp_weights, std::max<size_t>(mlp_count, 64) * 4, stream), "zero");
+  check(api->ffh_zero(ctx, mlp_grads, std::max<size_t>(mlp_count, 64) * 4, stream), "zero");
+  size_t off_p = 0;
+  const bool fused = fused_embedding_update();
+  for (Parameter& p : parameters) {
+    TensorImpl* im = p.impl;
+    im->ld = p.adim[0];
+    im->rows_local = (int64_t)(p.get_volume() / (size_t)p.adim[0]);
+    if (p.owner_op->op_type == OP_LINEAR) {
+      im->ptr = mlp_weights + off_p;
+      im->grad = mlp_grads + off_p;
+      im->grad_ld = im->ld;
+      im->alias = true;
+      im->bytes = p.get_volume() * 4;
+      off_p += (p.get_volume() + 3) / 4 * 4;
+    } else {
+      Embedding* e = static_cast<Embedding*>(p.owner_op);
+      if (e->owner_rank != rank) continue;       // sole owner: never replicated, never all-reduced
+      im->bytes = p.get_volume() * 4;
+      im->ptr = dmalloc(im->bytes);
+      if (!fused) {
+        im->grad = (float*)dmalloc(im->bytes);
+        im->grad_ld = im->ld;
+      }
+    }
+  }
+  // Op::weights[] are copies of the Parameters: same impl pointers, nothing to patch.
+
+  // ---- 6. workspace + metrics -------------------------------------------------------------------
+  workspace_bytes = 256;
+  if (Tr && fused) {
+    const int chunk = std::min(Tr, FFH_MAX_TABLES);
+    workspace_bytes = api->ffh_embedding_bwd_workspace_bytes(chunk, L, D, config.batchSize) + 256;
+  }
+  workspace = dmalloc(workspace_bytes);
+  check(api->ffh_ctx_set_workspace(ctx, workspace, workspace_bytes), "set workspace");
+  d_perf = (ffh_perf_metrics*)dmalloc(sizeof(ffh_perf_metrics));
+  check(api->ffh_zero(ctx, d_perf, sizeof(ffh_perf_metrics), stream), "zero");
+  check(api->ffh_zero(ctx, act_slab, std::max<size_t>(act_bytes, 256), stream), "zero");
+  check(api->ffh_zero(ctx, act_grad_slab, std::max<size_t>(act_grad_bytes, 256), stream), "zero");
+  check(api->ffh_stream_sync(ctx, stream), "allocate sync");
+}
+
+void FFModel::init_layers() {
+  if (!compiled) die("init_layers() before compile()");
+  for (Op* op : layers) op->init(*this);
+}
+
+void FFModel::print_layers(int id) {
+  if (id == -1) for (Op* op : layers) op->print_layer(*this);
+  else layers.at(id)->print_layer(*this);
+}
+
+// =============================================================================================
+// embedding group: batched gather (+ exchange) and batched fused update
+// =============================================================================================
+void FFModel::embedding_group_forward(ffh_stream s) const {
+  if (embeddings.empty()) return;
+  const int D = embeddings[0]->out_channels, L = embeddings[0]->inputs[0].adim[0];
+  const int aggr = (int)embeddings[0]->aggr;
+  std::vector<ffh_emb_table> tabs;
+  const int Tr = (int)owned_tables.size();
+  int k = 0;
+  for (int ti : owned_tables) {
+    const Embedding* e = embeddings[ti];
+    ffh_emb_table t;
+    t.idx = (const int64_t*)e->inputs[0].impl->ptr;
+    t.weight = (float*)e->weights[0].impl->ptr;
+    t.num_entries = e->num_entries;
+    if (!exchange) { t.io = (float*)e->outputs[0].impl->ptr; t.ld = e->outputs[0].impl->ld; }
+    else { t.io = xsend + (int64_t)k * D; t.ld = (int64_t)Tr * D; }
+    tabs.push_back(t);
+    k++;
+  }
+  for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
+    const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
+    check(api->ffh_embedding_fwd_multi(ctx, tabs.data() + b, n, L, D, config.batchSize, aggr, s), "embedding_fwd_multi");
+  }
+  if (exchange) {
+    // each owner gathered its tables for the global batch; rows go to the rank that owns the sample
+    if (config.comm.alltoall_f32(config.comm.user, xsend, fwd_send_counts.data(), xrecv, fwd_recv_counts.data(), s) != 0)
+      die("alltoall (embedding forward) failed");
+  }
+}
+
+void FFModel::embedding_group_update(ffh_stream s) const {
+  if (embeddings.empty()) return;
+  const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(optimizer);
+  const int D = embeddings[0]->out_channels, L = embeddings[0]->inputs[0].adim[0];
+  const int aggr = (int)embeddings[0]->aggr;
+  const int Tr = (int)owned_tables.size();
+  if (exchange) {
+    // gradients of the rows go back to the table owners (transposed exchange)
+    if (config.comm.alltoall_f32(config.comm.user, gsend, fwd_recv_counts.data(), grecv, fwd_send_counts.data(), s) != 0)
+      die("alltoall (embedding backward) failed");
+  }
+  std::vector<ffh_emb_table> tabs;
+  int k = 0;
+  for (int ti : owned_tables) {
+    const Embedding* e = embeddings[ti];
+    ffh_emb_table t;
+    t.idx = (const int64_t*)e->inputs[0].impl->ptr;
+    t.weight = (float*)e->weights[0].impl->ptr;
+    t.num_entries = e->num_entries;
+    if (!exchange) { t.io = e->outputs[0].impl->grad; t.ld = e->outputs[0].impl->grad_ld; }
+    else { t.io = grecv + (int64_t)k * D; t.ld = (int64_t)Tr * D; }
+    tabs.push_back(t);
+    k++;
+  }
+  for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
+    const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
+    check(api->ffh_embedding_bwd_sgd_fused_multi(ctx, tabs.data() + b, n, L, D, config.batchSize, aggr, (float)sgd->lr, s),
+          "embedding_bwd_sgd_fused_multi");
+  }
+}
+
+// =============================================================================================
+// the training step [ref: src/runtime/model.cc:1410-1477, examples/cpp/DLRM/dlrm.cc:166-182]
+// =============================================================================================
+void FFModel::reset_metrics() {
+  if (replaying_trace >= 0) return;
+  check(api->ffh_zero(ctx, d_perf, sizeof(ffh_perf_metrics), stream), "reset_metrics");
+}
+
+void FFModel::forward(int _seq_length) {
+  if (replaying_trace >= 0) return;
+  seq_length = _seq_length;
+  emb_forward_issued = emb_forward_joined = false;
+  if (config.overlap_embedding && !embeddings.empty()) {
+    // gather (+ all-to-all) on the side stream while the main stream runs the bottom MLP
+    check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
+    check(api->ffh_stream_wait_event(ctx, side_stream, ev_fork), "fork");
+    embedding_group_forward(side_stream);
+    check(api->ffh_event_record(ctx, ev_join, side_stream), "join");
+    emb_forward_issued = true;
+  }
+  for (Op* op : layers) op->forward(*this);
+  if (emb_forward_issued && !emb_forward_joined) {
+    check(api->ffh_stream_wait_event(ctx, stream, ev_join), "join");
+    emb_forward_joined = true;
+  }
+}
+
+void FFModel::zero_gradients() {
+  if (replaying_trace >= 0) return;
+  // Op::zero_grad for every layer [ref: src/runtime/model.cc:466-490]: two slabs instead of ~34 tasks.
+  // Embedding tables have no dense gradient on the fused path (nothing to zero: SURVEY fact 1).
+  check(api->ffh_zero(ctx, act_grad_slab, act_grad_bytes, stream), "zero_gradients");
+  check(api->ffh_zero(ctx, mlp_grads, mlp_count * 4, stream), "zero_gradients");
+  if (exchange && gsend) {
+    size_t n = 0;
+    for (int64_t c : fwd_recv_counts) n += (size_t)c;
+    check(api->ffh_zero(ctx, gsend, n * 4, stream), "zero_gradients");
+  }
+  if (!fused_embedding_update())
+    for (Embedding* e : embeddings)
+      if (e->owner_rank == rank) check(api->ffh_zero(ctx, e->weights[0].impl->grad, e->weights[0].impl->bytes, stream), "zero_gradients");
+}
+
+void FFModel::compute_metrics() {
+  if (replaying_trace >= 0) return;
+  const Tensor& fin = layers.back()->outputs[0];
+  check(api->ffh_metrics_update(ctx, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, d_perf,
+                                local_rows(fin, this), fin.adim[0], metrics_flags, stream), "compute_metrics");
+}
+
+void FFModel::backward(int _seq_length) {
+  if (replaying_trace >= 0) return;
+  seq_length = _seq_length;
+  if (config.computationMode != COMP_MODE_TRAINING) die("backward() in inference mode");
+  compute_metrics();
+  // loss [ref: src/loss_functions/loss_functions.cu:141-170,196-237]: scale_factor = 1 / global batch
+  const Tensor& fin = layers.back()->outputs[0];
+  const int64_t count = local_rows(fin, this) * fin.adim[0];
+  const float scale = loss_type == LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE ? 1.0f / (float)fin.adim[fin.numDim - 1] : 1.0f;
+  if (fin.impl->grad_ld != fin.adim[0]) die("final layer output must be contiguous");
+  check(api->ffh_mse_bwd(ctx, fin.impl->grad, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, count, scale, stream),
+        "loss backward");
+  for (int l = (int)layers.size() - 1; l >= 0; l--) layers[l]->backward(*this);
+}
+
+void FFModel::update() {
+  if (replaying_trace >= 0) return;
+  optimizer->next();
+  SGDOptimizer* sgd = dynamic_cast<SGDOptimizer*>(optimizer);
+  if (!sgd) die("only SGDOptimizer is on the DLRM path");
+  // data-parallel MLP gradients: ONE bucket [ref: one ncclAllReduce per tensor, src/runtime/optimizer_kernel.cu:170-171].
+  // No 1/world_size: the loss already divides by the global batch.
+  if (exchange && mlp_count)
+    if (config.comm.allreduce_sum_f32(config.comm.user, mlp_grads, (int64_t)mlp_count, stream) != 0) die("allreduce failed");
+  if (sgd->momentum > 0.0) {
+    for (const Parameter& p : parameters)
+      if (p.owner_op->op_type == OP_LINEAR) sgd->update(&p);
+  } else if (mlp_count) {
+    check(api->ffh_sgd_update(ctx, mlp_weights, mlp_grads, nullptr, (int64_t)mlp_count, (float)sgd->lr, (float)sgd->weight_decay, 0.0f,
+                              0, stream), "sgd_update (MLP slab)");
+  }
+  if (fused_embedding_update()) {
+    if (config.overlap_embedding) {
+      if (!embeddings.empty()) check(api->ffh_stream_wait_event(ctx, stream, ev_update_done), "join update");   // launched in backward()
+    } else {
+      embedding_group_update(stream);
+    }
+  } else {
+    for (Embedding* e : embeddings)
+      if (e->owner_rank == rank) sgd->update(&e->weights[0]);
+  }
+}
+
+void FFModel::begin_trace(int trace_id) {
+  if (!config.enable_graph) return;
+  auto it = graphs.find(trace_id);
+  if (it != graphs.end()) { replaying_trace = trace_id; return; }
+  int rc = api->ffh_graph_begin_capture(ctx, stream);
+  if (rc == FFH_ERR_UNSUPPORTED) { config.enable_graph = false; return; }   // backend without graphs: run eagerly
+  check(rc, "begin_trace");
+  capturing_trace = trace_id;
+}
+
+void FFModel::end_trace(int trace_id) {
+  if (!config.enable_graph) return;
+  if (capturing_trace == trace_id) {
+    ffh_graph g = nullptr;
+    check(api->ffh_graph_end_capture(ctx, stream, &g), "end_trace");
+    graphs[trace_id] = g;
+    capturing_trace = -1;
+    check(api->ffh_graph_launch(ctx, g, stream), "graph launch");   // the captured iteration has not run yet
+    return;
+  }
+  if (replaying_trace == trace_id) {
+    check(api->ffh_graph_launch(ctx, graphs[trace_id], stream), "graph launch");
+    replaying_trace = -1;
+  }
+}
+
+void FFModel::sync() {
+  check(api->ffh_stream_sync(ctx, stream), "sync");
+  check(api->ffh_stream_sync(ctx, side_stream), "sync");
+}
+
+PerfMetrics FFModel::get_perf_metrics() {
+  sync();
+  ffh_perf_metrics h;
+  check(api->ffh_memcpy_d2h(ctx, &h, d_perf, sizeof h, stream), "metrics d2h");
+  check(api->ffh_stream_sync(ctx, stream), "sync");
+  PerfMetrics p;
+  p.train_all = h.train_all; p.train_correct = h.train_correct; p.cce_loss = h.cce_loss;
+  p.sparse_cce_loss = h.sparse_cce_loss; p.mse_loss = h.mse_loss; p.rmse_loss = h.rmse_loss; p.mae_loss = h.mae_loss;
+  return p;
+}

@@ -1,0 +1,55 @@
+"""One rank of the world_size-2 gloo tests (launched by tests/test_ffmodel_host.py).
+Kernels come from the CPU oracle (test infrastructure); the collectives are the product's
+TorchComm callbacks over the gloo backend."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from dlrm_flexflow_amd import ffmodel  # noqa: E402
+from dlrm_flexflow_amd.comm import TorchComm  # noqa: E402
+import dlrm_helpers as H  # noqa: E402
+
+
+def main():
+    mode, outdir = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo", init_method=f"tcp://{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}",
+                            rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank = dist.get_rank()
+    comm = TorchComm(on_gpu=False)
+    out = {}
+    if mode == "golden":
+        m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True)
+        recs = H.run_steps(m, h, 2)
+        for step, rec in enumerate(recs):
+            for k, v in rec.items():
+                out[f"s{step}/{k}"] = v
+        m.close()
+    else:
+        args = ["--backend", H.oracle_backend(), "-b", "64", "--arch-sparse-feature-size", "8", "--arch-embedding-size",
+                "50-7-300-3-1000-20-11", "--arch-mlp-bot", "13-32-8", "--arch-mlp-top", "64-32-1", "--data-size", "128", "--epochs", "6"]
+        app = ffmodel.DLRM(args, comm=comm.struct)
+        app.warmup()
+        pm0 = app.model.perf_metrics()
+        out["mse_first"] = np.array(pm0.mse_loss / max(pm0.train_all, 1))
+        app.run_epochs()
+        pm1 = app.model.perf_metrics()
+        out["mse_last"] = np.array(pm1.mse_loss / max(pm1.train_all, 1))
+        out["w_bot"] = app.model.parameter(0, 0).get_weights()
+        out["w_top"] = app.model.parameter(app.model.num_layers - 1, 0).get_weights()
+        app.close()
+    out["alltoall_calls"] = np.array(comm.calls["alltoall"])
+    out["allreduce_calls"] = np.array(comm.calls["allreduce"])
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+"""Shared by the host-layer tests: builds the small DLRM of tests/golden/dlrm_step_torch.npz through
+the Python FFModel API (the reference's ffmodel.dense / embedding / concat surface), injects the
+golden weights and inputs, runs training steps and collects predictions + parameters.
+
+`backend` is the path of a library exporting include/ff_hip.h: the HIP library for the GPU
+tests, the CPU oracle (test infrastructure) for the host-logic tests that run without a GPU.
+"""
+import os
+
+import numpy as np
+
+from conftest import golden
+from dlrm_flexflow_amd import capi, ffmodel
+
+
+def oracle_backend():
+    from oracle import oracle
+    oracle.build()
+    return oracle.ORACLE_LIB
+
+
+def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dense_update=False, g=None, force_exchange=False):
+    """Returns (model, handles) with weights and inputs of the golden fixture loaded.
+    With `comm` (world_size > 1) each rank loads its batch slice / its tables."""
+    g = g or golden("dlrm_step_torch")
+    B, D, L = int(g["B"]), int(g["D"]), int(g["L"])
+    rows, bot, top = list(g["rows"]), list(g["bot"]), list(g["top"])
+    world = comm.world_size if comm is not None else 1
+    rank = comm.rank if comm is not None else 0
+    cfg = ffmodel.FFConfig(argv=["-b", str(B)] + (["--force-exchange"] if force_exchange else []), backend=backend, comm=comm)
+    cfg.set(enable_graph=enable_graph, overlap_embedding=overlap, dense_embedding_update=dense_update)
+    m = ffmodel.FFModel(cfg)
+    sparse = [m.create_tensor([B, L], ffmodel.DT_INT64) for _ in rows]
+    dense = m.create_tensor([B, bot[0]], ffmodel.DT_FLOAT)
+    x = dense
+    for i in range(len(bot) - 1):
+        x = m.dense(x, bot[i + 1], capi.AC_MODE_RELU)
+    ly = [m.embedding(s, r, D, capi.AGGR_MODE_SUM) for s, r in zip(sparse, rows)]
+    z = m.concat([x] + ly, 1)
+    for i in range(len(top) - 1):
+        z = m.dense(z, top[i + 1], capi.AC_MODE_SIGMOID if i == len(top) - 2 else capi.AC_MODE_RELU)
+    m.set_sgd_optimizer(lr=0.01)
+    m.compile()
+    m.init_layers()
+    # layer order: bottom dense..., embeddings..., concat, top dense...
+    nb, nt = len(bot) - 1, len(top) - 1
+    layer = 0
+    names = {}
+    for i in range(nb):
+        names[f"bot.{i}"] = layer; layer += 1
+    for t in range(len(rows)):
+        names[f"emb.{t}"] = layer; layer += 1
+    layer += 1
+    for i in range(nt):
+        names[f"top.{i}"] = layer; layer += 1
+    assert layer == m.num_layers
+    assert m.layer_name(0) == "Dense_100" and m.layer_name(nb) == f"Embedding_{100 + nb}"   # reference naming
+    for k, li in names.items():
+        if k.startswith("emb"):
+            p = m.parameter(li, 0)
+            if p.is_local:
+                p.set_weights(g[f"init/{k}.weight"])
+        else:
+            m.parameter(li, 0).set_weights(g[f"init/{k}.weight"])
+            m.parameter(li, 1).set_weights(g[f"init/{k}.bias"])
+    Bl = B // world
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    dense.set(g["dense"][sl])
+    m.label_tensor.set(g["label"][sl])
+    for t, s in enumerate(sparse):
+        if s.is_local:
+            s.set(g[f"sparse{t}"])
+    return m, {"names": names, "final": m.num_layers - 1, "slice": sl, "g": g}
+
+
+def run_steps(m, h, steps=2, trace=False):
+    """Returns per-step predictions (this rank's rows) and the parameters after each step."""
+    out = []
+    for _ in range(steps):
+        if trace:
+            m.begin_trace(7)
+        m.forward(); m.zero_gradients(); m.backward(); m.update()
+        if trace:
+            m.end_trace(7)
+        m.sync()
+        rec = {"pred": m.layer_output(h["final"]).get()}
+        for k, li in h["names"].items():
+            p = m.parameter(li, 0)
+            if p.is_local:
+                rec[f"{k}.weight"] = p.get_weights()
+            if not k.startswith("emb"):
+                rec[f"{k}.bias"] = m.parameter(li, 1).get_weights()
+        out.append(rec)
+    return out
+
+
+def check_against_golden(recs, h, rtol=1e-5, atol=1e-6):
+    g = h["g"]
+    for step, rec in enumerate(recs):
+        # the forward of step k sees the parameters after step k-1: predictions of the golden step k
+        np.testing.assert_allclose(rec["pred"], g[f"step{step}/pred"][h["slice"]], rtol=rtol, atol=atol, err_msg=f"pred step {step}")
+        for k, v in rec.items():
+            if k == "pred":
+                continue
+            np.testing.assert_allclose(v, g[f"step{step}/{k}"], rtol=rtol, atol=atol, err_msg=f"{k} step {step}")

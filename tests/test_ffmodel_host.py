@@ -1,0 +1,190 @@
+"""CPU tests of the host layer (C++ FFModel shim + DLRM driver + Python binding + ffcomm).
+
+The operator kernels are supplied by the CPU oracle here -- test infrastructure standing in for
+the GPU so that graph construction, aliasing into the concat buffer, the training-step order,
+the table-wise sharding and the collectives can be checked without a GPU.  The same host code
+runs the HIP library in tests/test_gpu_model.py.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+from dlrm_flexflow_amd import build, capi, ffmodel
+import dlrm_helpers as H
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    build.build_host()
+
+
+@pytest.mark.parametrize("overlap,dense_update", [(True, False), (False, False), (False, True)])
+def test_dlrm_two_steps_match_torch_golden(overlap, dense_update):
+    """Whole-model parity: forward / zero_gradients / backward / update x2 against the torch
+    model of the reference topology (tests/golden/make_golden.py), 1e-5 relative."""
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=overlap, dense_update=dense_update)
+    recs = H.run_steps(m, h, 2)
+    H.check_against_golden(recs, h)
+    pm = m.perf_metrics()
+    B = int(h["g"]["B"])
+    assert pm.train_all == 2 * 2 * B          # two steps, the reference's double count for 1 class + accuracy
+    mse = float(h["g"]["step0/mse_sum"]) + float(h["g"]["step1/mse_sum"])
+    assert abs(pm.mse_loss - mse) <= 1e-5 * mse
+    m.close()
+
+
+def test_fused_and_dense_embedding_paths_agree():
+    """The fused sparse update and the reference's dense zero/scatter/sweep path give the same
+    tables (1e-6: only the summation order inside duplicate rows differs)."""
+    a, ha = H.build_golden_dlrm(H.oracle_backend(), overlap=False, dense_update=False)
+    b, hb = H.build_golden_dlrm(H.oracle_backend(), overlap=False, dense_update=True)
+    ra, rb = H.run_steps(a, ha, 2), H.run_steps(b, hb, 2)
+    for k in ra[1]:
+        np.testing.assert_allclose(ra[1][k], rb[1][k], rtol=1e-6, atol=1e-7, err_msg=k)
+    a.close(); b.close()
+
+
+def test_gradients_are_exposed_like_the_reference():
+    """Tensor::get_grad after backward(): concat slices alias the concat gradient (bit-equal)."""
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False)
+    m.forward(); m.zero_gradients(); m.backward(); m.sync()
+    n_bot = len(h["g"]["bot"]) - 1
+    concat_layer = n_bot + len(h["g"]["rows"])
+    dz = m.layer_output(concat_layer).get_grad()
+    D = int(h["g"]["D"])
+    off = D
+    for t in range(len(h["g"]["rows"])):
+        ge = m.layer_output(n_bot + t).get_grad()
+        assert np.array_equal(ge, dz[:, off:off + D])
+        off += D
+    m.close()
+
+
+def test_dlrm_driver_binary_runs_the_tiny_config():
+    """BASELINE config 1 (8 tables x 1000 rows, emb_dim 16, batch 128) through the `dlrm`
+    executable with the reference's own flags; prints the reference's THROUGHPUT line."""
+    exe = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
+    args = [exe, "--backend", H.oracle_backend(), "-ll:gpu", "1", "-b", "128", "--arch-sparse-feature-size", "16",
+            "--arch-embedding-size", "-".join(["1000"] * 8), "--arch-mlp-bot", "13-64-16", "--arch-mlp-top", "144-64-1",
+            "--epochs", "2", "--data-size", "512"]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "THROUGHPUT = " in r.stdout and "samples/s" in r.stdout
+    assert "parameters.size() = 16" in r.stdout        # 5 Linear x (kernel, bias) + ... as the reference prints
+    assert "[Metrics]" in r.stderr and "mean_squared_error" in r.stderr
+
+
+def test_driver_rejects_what_the_reference_rejects():
+    exe = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
+    base = [exe, "--backend", H.oracle_backend(), "-b", "8", "--arch-embedding-size", "10-10", "--arch-sparse-feature-size", "4",
+            "--arch-mlp-bot", "3-4", "--arch-mlp-top", "12-1"]
+    r = subprocess.run(base + ["--arch-interaction-op", "dot"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "only 'cat'" in r.stderr
+    r = subprocess.run(base + ["--dataset", "x.h5"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "HDF5" in r.stderr
+    r = subprocess.run(base + ["-ll:gpu", "4"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "one process per GPU" in r.stderr
+    r = subprocess.run([exe, "--backend", "/nonexistent/libffhip.so", "-b", "8"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "cannot load kernel library" in r.stderr     # no silent fallback
+
+
+def test_dlrm_app_object_and_data_loader_are_deterministic():
+    """Same seed -> same synthetic batch and same trajectory; different seed -> different."""
+    args = ["--backend", H.oracle_backend(), "-b", "32", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "50-7-300",
+            "--arch-mlp-bot", "13-16-8", "--arch-mlp-top", "32-16-1", "--data-size", "64"]
+    outs = []
+    for seed in (0, 0, 1):
+        app = ffmodel.DLRM(args + ["--seed", str(seed)])
+        app.warmup()
+        app.train_steps(3, trace=False)
+        app.model.sync()
+        outs.append((app.sparse_input(1).get(np.int64), app.model.parameter(0, 0).get_weights(), app.model.parameter(3, 0).get_weights()))
+        assert app.num_samples == 64 and app.num_tables == 3
+        app.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert not np.array_equal(outs[0][0], outs[2][0])
+    assert outs[0][0].min() >= 0 and outs[0][0].max() < 7
+
+
+# ---------------------------------------------------------------------------------------------
+# two ranks over gloo: table-wise sharding + all-to-all + bucketed all-reduce
+# ---------------------------------------------------------------------------------------------
+WORKER = os.path.join(ROOT, "tests", "_dist_worker.py")
+
+
+def _run_ranks(world, tmp_path, mode):
+    port = 29500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, WORKER, mode, str(tmp_path)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    return outs
+
+
+def test_two_rank_gloo_run_equals_single_rank(tmp_path):
+    """world_size 2 (gloo, CPU): rank r owns tables r, r+2; each rank runs half the batch through the
+    MLPs; the exchange is an all-to-all each way, MLP gradients one all-reduce.  Result must equal
+    the single-rank run: embedding tables bit-exact (same canonical order), MLP within 1e-5."""
+    _run_ranks(2, tmp_path, "golden")
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    B = int(h["g"]["B"])
+    seen_tables = set()
+    for r in range(2):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        for step in range(2):
+            sl = slice(r * B // 2, (r + 1) * B // 2)
+            np.testing.assert_allclose(z[f"s{step}/pred"], ref[step]["pred"][sl], rtol=1e-5, atol=1e-6)
+            for k, v in ref[step].items():
+                key = f"s{step}/{k}"
+                if k == "pred":
+                    continue
+                if k.startswith("emb"):
+                    t = int(k.split(".")[1])
+                    if t % 2 == r:
+                        assert key in z.files
+                        np.testing.assert_allclose(z[key], v, rtol=1e-6, atol=1e-7, err_msg=key)
+                        seen_tables.add(t)
+                    else:
+                        assert key not in z.files              # sole owner: never replicated
+                else:
+                    np.testing.assert_allclose(z[key], v, rtol=1e-5, atol=1e-6, err_msg=key)
+        assert int(z["alltoall_calls"]) == 2 * 2 and int(z["allreduce_calls"]) == 2   # 2 steps x (fwd + bwd), 2 x 1 bucket
+    assert seen_tables == set(range(len(h["g"]["rows"])))
+    # and against the torch golden itself
+    z0 = np.load(os.path.join(tmp_path, "rank0.npz"))
+    np.testing.assert_allclose(z0["s1/top.0.weight"], h["g"]["step1/top.0.weight"], rtol=1e-5, atol=1e-6)
+
+
+def test_single_rank_forced_exchange_equals_plain_run(tmp_path):
+    """--force-exchange: one rank still goes through the all-to-all / all-reduce callbacks (how the
+    collectives are exercised on a 1-GPU box); results equal the plain single-rank run."""
+    _run_ranks(1, tmp_path, "golden")
+    z = np.load(os.path.join(tmp_path, "rank0.npz"))
+    assert int(z["alltoall_calls"]) == 4 and int(z["allreduce_calls"]) == 2
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    for k, v in ref[1].items():
+        np.testing.assert_allclose(z[f"s1/{k}"], v, rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+def test_two_rank_driver_flags(tmp_path):
+    """The DLRM application object under 2 ranks with the driver's flags (7 tables over 2 ranks:
+    4 + 3, uneven all-to-all splits); loss decreases and both ranks hold identical MLPs."""
+    outs = _run_ranks(2, tmp_path, "driver")
+    z0 = np.load(os.path.join(tmp_path, "rank0.npz"))
+    z1 = np.load(os.path.join(tmp_path, "rank1.npz"))
+    assert np.array_equal(z0["w_top"], z1["w_top"]) and np.array_equal(z0["w_bot"], z1["w_bot"])
+    assert float(z0["mse_last"]) < float(z0["mse_first"])
+    assert "THROUGHPUT" in outs[0]
