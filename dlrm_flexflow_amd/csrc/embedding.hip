@@ -120,8 +120,7 @@ __global__ __launch_bounds__(256) void emb_bwd_dense_kernel(const int64_t* __res
 // fused backward + SGD, step 1: per-table stable LSD radix sort of (row id, position)
 // ---------------------------------------------------------------------------
 constexpr int kSortThreads = 256;
-constexpr int kSortPerThread = 8;
-constexpr int kSortTile = kSortThreads * kSortPerThread;   // 2048 entries per workgroup
+constexpr int kSortMaxPerThread = 8;                        // tile = 256 * E entries, E in {1,2,4,8} chosen per call
 constexpr int kMaxRadixBits = 9;
 constexpr int kMaxRadix = 1 << kMaxRadixBits;
 
@@ -136,6 +135,8 @@ struct SortArgs {
   int       nblk;
   int       shift;
   int       bits;
+  int       pass;
+  uint8_t   npass[FFH_MAX_TABLES];      // digits table t really has; later passes would be the identity and are skipped
 };
 
 template <bool FIRST>
@@ -145,10 +146,13 @@ __device__ __forceinline__ uint32_t sort_load_key(const SortArgs& a, int t, int6
 }
 
 // histogram of the current digit per 2048-entry tile (LDS-staged bucketing)
-template <bool FIRST>
+template <bool FIRST, int E>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const SortArgs a) {
+  constexpr int kSortTile = kSortThreads * E;
+  constexpr int kSortPerThread = E;
   __shared__ uint32_t s_hist[kMaxRadix];
   const int t = blockIdx.y, blk = blockIdx.x;
+  if (a.pass >= a.npass[t]) return;
   const int radix = 1 << a.bits;
   const uint32_t mask = radix - 1;
   for (int d = threadIdx.x; d < radix; d += kSortThreads) s_hist[d] = 0;
@@ -168,8 +172,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const SortArgs
 // time: the lanes holding the same digit find each other with `bits` ballots (a match-any),
 // the rank inside the group is a popcount of the lower lanes, and the group's lowest lane
 // advances the wave's running offset in LDS.
-template <bool FIRST>
+template <bool FIRST, int E>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortArgs a) {
+  constexpr int kSortTile = kSortThreads * E;
+  constexpr int kSortPerThread = E;
+  if (a.pass >= a.npass[blockIdx.y]) return;
   __shared__ uint32_t s_off[4][kMaxRadix];
   __shared__ uint32_t s_scan[kMaxRadix];
   __shared__ uint32_t s_wsum[4];
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
 // fused backward + SGD, step 2: segmented reduce of the sorted list + row update
 // ---------------------------------------------------------------------------
 constexpr int kRedThreads = 256;
-constexpr int kRedTile = 1024;                        // sorted entries per workgroup (multiple of FFH_EMB_CHUNK)
+constexpr int kRedTile = 1024;                        // max sorted entries per workgroup; the call picks 128..1024
 constexpr int kRedChunksPerTile = kRedTile / FFH_EMB_CHUNK;
 static_assert(kRedTile % FFH_EMB_CHUNK == 0, "tile must hold whole chunks");
 
@@ -285,8 +292,10 @@ enum : uint32_t { kMetaNone = 0, kMetaFirst = 1, kMetaCont = 2 };
 
 struct RedArgs {
   ffh_emb_table t[FFH_MAX_TABLES];
-  const uint32_t* keys;     // sorted [nt][N]
-  const uint32_t* pos;
+  const uint32_t* keys[2];  // sorted [nt][N]: table t ends in buffer parity[t]
+  const uint32_t* pos[2];
+  uint8_t   parity[FFH_MAX_TABLES];
+  int       tile;           // sorted entries per workgroup: multiple of FFH_EMB_CHUNK, <= kRedTile
   float*    partial;        // [nt][2*nchunks][D]
   uint2*    meta;           // [nt][2*nchunks] {kind, key}
   int64_t   N;
@@ -322,10 +331,11 @@ __global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedAr
   const int tix = blockIdx.y;
   const ffh_emb_table tb = a.t[tix];
   const int64_t N = a.N;
-  const int64_t tile0 = (int64_t)blockIdx.x * kRedTile;
-  const int n = (int)((N - tile0) < kRedTile ? (N - tile0) : kRedTile);
-  const uint32_t* keys = a.keys + (int64_t)tix * N;
-  const uint32_t* posg = a.pos + (int64_t)tix * N;
+  const int tile = a.tile;
+  const int64_t tile0 = (int64_t)blockIdx.x * tile;
+  const int n = (int)((N - tile0) < tile ? (N - tile0) : tile);
+  const uint32_t* keys = a.keys[a.parity[tix]] + (int64_t)tix * N;
+  const uint32_t* posg = a.pos[a.parity[tix]] + (int64_t)tix * N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   for (int i = threadIdx.x; i < n; i += kRedThreads) {
@@ -336,7 +346,8 @@ __global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedAr
     s_key[0] = tile0 > 0 ? keys[tile0 - 1] : 0xFFFFFFFFu;            // no valid key equals it when tile0 == 0 (checked below)
     s_key[1 + n] = (tile0 + n < N) ? keys[tile0 + n] : 0xFFFFFFFFu;
   }
-  if (threadIdx.x < 2 * kRedChunksPerTile) s_meta[threadIdx.x] = make_uint2(kMetaNone, 0);
+  const int metas = 2 * (tile / FFH_EMB_CHUNK);
+  if (threadIdx.x < metas) s_meta[threadIdx.x] = make_uint2(kMetaNone, 0);
   __syncthreads();
 
   // sub-run starts: chunk boundaries and changes of row id; compacted in order
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedAr
     }
   }
   __syncthreads();
-  if (threadIdx.x < 2 * kRedChunksPerTile) {
+  if (threadIdx.x < metas) {
     const int64_t slot = (tile0 / FFH_EMB_CHUNK) * 2 + threadIdx.x;
     if (slot < 2 * (int64_t)a.nchunks) a.meta[(int64_t)tix * 2 * a.nchunks + slot] = s_meta[threadIdx.x];
   }
@@ -489,10 +500,25 @@ struct BwdLayout {
   int nblk, nchunks;
 };
 
+// entries per thread of the sort kernels: enough workgroups to cover the chip, tiles as large as that allows
+inline int sort_per_thread(int nt, int64_t N) {
+  const int64_t want = N * nt / (512LL * kSortThreads);
+  int e = 1;
+  while (e * 2 <= want && e < kSortMaxPerThread) e *= 2;
+  return e;
+}
+inline int reduce_tile(int nt, int64_t N) {
+  const int64_t want = N * nt / 1024;
+  int t = FFH_EMB_CHUNK;
+  while (t * 2 <= want && t < kRedTile) t *= 2;
+  return t;
+}
+
 inline BwdLayout bwd_layout(int nt, int L, int D, int64_t batch) {
   BwdLayout l;
   const int64_t N = batch * L;
-  l.nblk = (int)((N + kSortTile - 1) / kSortTile);
+  const int sort_tile = kSortThreads * sort_per_thread(nt, N);
+  l.nblk = (int)((N + sort_tile - 1) / sort_tile);
   l.nchunks = (int)((N + FFH_EMB_CHUNK - 1) / FFH_EMB_CHUNK);
   const size_t arr = align_up((size_t)nt * (size_t)N * sizeof(uint32_t), 256);
   size_t o = 0;
@@ -597,7 +623,7 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
   char* ws = (char*)c->ws;
   if (!aligned16(ws)) return ffh_fail(c, FFH_ERR_WORKSPACE, "embedding_bwd_sgd_fused: workspace must be 16-byte aligned");
 
-  // radix plan: digits of <= 9 bits covering bit_length(maxR-1)
+  // radix plan: digits of <= 9 bits covering bit_length(maxR-1); a table only runs the passes its own ids need
   int bits = 1;
   while (bits < 32 && ((maxR - 1) >> bits) != 0) bits++;
   const int passes = (bits + kMaxRadixBits - 1) / kMaxRadixBits;
@@ -605,38 +631,50 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
 
   SortArgs sa;
   memset(&sa, 0, sizeof sa);
-  for (int i = 0; i < nt; i++) sa.idx[i] = tables[i].idx;
+  RedArgs ra;
+  memset(&ra, 0, sizeof ra);
+  for (int i = 0; i < nt; i++) {
+    sa.idx[i] = tables[i].idx;
+    int tb = 1;
+    while (tb < 32 && ((tables[i].num_entries - 1) >> tb) != 0) tb++;
+    const int np = (tb + rb - 1) / rb;
+    sa.npass[i] = (uint8_t)np;
+    ra.parity[i] = (uint8_t)(np & 1);
+  }
   sa.hist = (uint32_t*)(ws + lay.hist);
   sa.N = N; sa.nblk = lay.nblk; sa.bits = rb;
   uint32_t* kbuf[2] = {(uint32_t*)(ws + lay.keys_a), (uint32_t*)(ws + lay.keys_b)};
   uint32_t* pbuf[2] = {(uint32_t*)(ws + lay.pos_a), (uint32_t*)(ws + lay.pos_b)};
   dim3 sgrid((unsigned)lay.nblk, (unsigned)nt);
-  int cur = 0;   // buffer holding the output of the previous pass
+  const int E = sort_per_thread(nt, N);
   for (int p = 0; p < passes; p++) {
     sa.shift = p * rb;
-    sa.keys_src = kbuf[cur]; sa.pos_src = pbuf[cur];
-    sa.keys_dst = kbuf[cur ^ 1]; sa.pos_dst = pbuf[cur ^ 1];
+    sa.pass = p;
+    // pass p reads buffer p%2 (pass 0: the int64 ids) and writes buffer (p+1)%2
+    sa.keys_src = kbuf[p & 1]; sa.pos_src = pbuf[p & 1];
+    sa.keys_dst = kbuf[(p + 1) & 1]; sa.pos_dst = pbuf[(p + 1) & 1];
+#define FFH_SORT_PASS(FIRSTV, EV)                                                                              \
+    hipLaunchKernelGGL((radix_hist_kernel<FIRSTV, EV>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);      \
+    hipLaunchKernelGGL((radix_scatter_kernel<FIRSTV, EV>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
     if (p == 0) {
-      hipLaunchKernelGGL((radix_hist_kernel<true>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
-      hipLaunchKernelGGL((radix_scatter_kernel<true>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
+      switch (E) { case 1: FFH_SORT_PASS(true, 1) break; case 2: FFH_SORT_PASS(true, 2) break; case 4: FFH_SORT_PASS(true, 4) break; default: FFH_SORT_PASS(true, 8) break; }
     } else {
-      hipLaunchKernelGGL((radix_hist_kernel<false>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
-      hipLaunchKernelGGL((radix_scatter_kernel<false>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
+      switch (E) { case 1: FFH_SORT_PASS(false, 1) break; case 2: FFH_SORT_PASS(false, 2) break; case 4: FFH_SORT_PASS(false, 4) break; default: FFH_SORT_PASS(false, 8) break; }
     }
-    cur ^= 1;
+#undef FFH_SORT_PASS
   }
   FFH_LAUNCH_CHECK(c, "radix sort");
 
-  RedArgs ra;
-  memset(&ra, 0, sizeof ra);
   for (int i = 0; i < nt; i++) ra.t[i] = tables[i];
-  ra.keys = kbuf[cur]; ra.pos = pbuf[cur];
+  ra.keys[0] = kbuf[0]; ra.keys[1] = kbuf[1];
+  ra.pos[0] = pbuf[0]; ra.pos[1] = pbuf[1];
+  ra.tile = reduce_tile(nt, N);
   ra.partial = (float*)(ws + lay.partial);
   ra.meta = (uint2*)(ws + lay.meta);
   ra.N = N; ra.nchunks = lay.nchunks; ra.L = L; ra.D = D;
   ra.avg = aggr == FFH_AGGR_MODE_AVG ? 1 : 0;
   ra.lr = lr;
-  dim3 rgrid((unsigned)((N + kRedTile - 1) / kRedTile), (unsigned)nt);
+  dim3 rgrid((unsigned)((N + ra.tile - 1) / ra.tile), (unsigned)nt);
   const int lpr = nvec < 64 ? nvec : 64;
   const int64_t cgroups = 2LL * lay.nchunks;
   dim3 cgrid((unsigned)ffh_grid(cgroups, 4 * (64 / lpr), 1024), (unsigned)nt);

@@ -19,6 +19,8 @@
 // cublasSgemmStridedBatched [ref: src/ops/batch_matmul.cu:238-241,393-398].
 #include "ffh_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -37,9 +39,15 @@ struct GemmArgs {
   int splitk;
   int epi;
   int act;
+  // dW form only (FUSE_DY): relu'(y) applied to the dy operand as it is loaded (and written back in
+  // place by the first column of workgroups), bias gradient = column sums of the same tiles
+  const float* act_y;
+  int64_t      ld_act_y;
+  float*       db;
+  int          fuse;         // bit0: relu mask from act_y, bit1: db += column sums
 };
 
-constexpr int kSplitGran = 32;   // split-K granularity: a multiple of every BK
+constexpr int kSplitGran = 32;   // split-K granularity; splits are multiples of 2*kSplitGran = 64 = the largest BK
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == FFH_AC_MODE_RELU) return v > 0.0f ? v : 0.0f;
@@ -60,28 +68,51 @@ __device__ __forceinline__ float4 load4_guard(const float* p, bool row_ok, int c
   return v;
 }
 
-template <int BM, int BN, int BK, bool AKC, bool BKC>
+// SPLITW = false: 2x2 waves tile the BM x BN block, each wave owns (BM/2) x (BN/2) and the whole K.
+// SPLITW = true : BM = BN = 32; the four waves share ONE 32x32 tile and split every k-tile four
+//                 ways (intra-workgroup split-K), partial accumulators meet in LDS in a fixed order.
+//                 For the skinny DLRM layers (2048 x 256, 2048 x 64 ...) this gives 4x the waves of
+//                 a 64x64 tiling: a 32x32x2 MFMA chain over K = 512 alone is 16k cycles.
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool SPLITW = false, bool FUSE_DY = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+  static_assert(!FUSE_DY || !AKC, "the fused dy form is the m-contiguous A operand");
   constexpr int PA = AKC ? 1 : 4, PB = BKC ? 1 : 4;
   constexpr int LA = BM + PA, LB = BN + PB;
   constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 staging slots per thread
   constexpr int KQ = BK / 4;                                // float4 per k-contiguous row
   constexpr int RPP = 256 / KQ;                             // rows per staging pass
-  constexpr int WM = BM / 64, WN = BN / 64;          // 32x32 MFMA tiles per wave (2x2 waves)
+  constexpr int WM = SPLITW ? 1 : BM / 64, WN = SPLITW ? 1 : BN / 64;   // 32x32 MFMA tiles per wave
+  static_assert(!SPLITW || (BM == 32 && BN == 32 && BK % 8 == 0), "split-wave form is 32x32");
   __shared__ float As[2][BK * LA];
   __shared__ float Bs[2][BK * LB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs in
+  // dispatch order, so XCD x sees linear ids x, x+8, ...  Give each XCD one CONTIGUOUS range of
+  // the (z, y, x) tile space instead: its A rows / its K-split are then private to its L2 and only
+  // the small shared operand is fetched by all eight.
+  int bx, by, bz;
+  {
+    const unsigned nbx = gridDim.x, nby = gridDim.y, nbz = gridDim.z;
+    const unsigned total = nbx * nby * nbz;
+    const unsigned lin = (blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x;
+    const unsigned xcd = lin & 7u, loc = lin >> 3;
+    const unsigned q = total >> 3, rem = total & 7u;
+    const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
+    bx = (int)(nlin % nbx);
+    by = (int)((nlin / nbx) % nby);
+    bz = (int)(nlin / (nbx * nby));
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const float* A = g.A;
   const float* B = g.B;
   float* C = g.C;
   int kb = 0, ke = g.K;
   if (g.splitk > 1) {
-    kb = blockIdx.z * g.k_per_split;
+    kb = bz * g.k_per_split;
     ke = kb + g.k_per_split < g.K ? kb + g.k_per_split : g.K;
   } else {
-    A += (int64_t)blockIdx.z * g.bsA; B += (int64_t)blockIdx.z * g.bsB; C += (int64_t)blockIdx.z * g.bsC;
+    A += (int64_t)bz * g.bsA; B += (int64_t)bz * g.bsB; C += (int64_t)bz * g.bsC;
   }
   if (kb >= ke) return;
   const int nk = (ke - kb + BK - 1) / BK;
@@ -90,20 +121,55 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   const bool b_vec = (BKC ? (g.sBn % 4 == 0) : (g.sBk % 4 == 0)) && (((uintptr_t)B & 15) == 0);
 
   float4 ra[NA], rb[NB];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool y_vec = FUSE_DY && (g.ld_act_y % 4 == 0) && (((uintptr_t)g.act_y & 15) == 0);
 
-  auto load_tile = [&](int kt) {
+  // interior tiles (the common case) take unguarded 16-B loads: the branch is workgroup-uniform
+  const bool a_in = a_vec && (m0 + BM <= g.M);
+  const bool b_in = b_vec && (n0 + BN <= g.N);
+
+  // k-tiles that lie completely inside the matrices take the unguarded body (FAST): no per-element
+  // predicates, plain global_load_dwordx4.  The choice is workgroup-uniform.
+  const int nfull = (a_in && b_in && (!FUSE_DY || y_vec)) ? (ke - kb) / BK : 0;
+
+  auto load_tile_t = [&](int kt, auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     const int k0 = kb + kt * BK;
 #pragma unroll
     for (int i = 0; i < NA; i++) {
-      if (AKC) {   // rows of A are k-contiguous: 8 float4 per row
+      if (AKC) {   // rows of A are k-contiguous: BK/4 float4 per row
         const int k4 = tid % KQ, row = tid / KQ + i * RPP;
         const int m = m0 + row, k = k0 + k4 * 4;
-        ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, a_vec);
+        if (FAST) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)m * g.sAm + k);
+        else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, a_vec);
       } else {     // rows of the tile are k, contiguous along m
         constexpr int PER = BM / 4;
         const int m4 = tid % PER, kr = tid / PER + i * (256 / PER);
         const int m = m0 + m4 * 4, k = k0 + kr;
-        ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, a_vec);
+        if (FAST) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)k * g.sAk + m);
+        else ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, a_vec);
+        if (FUSE_DY) {
+          if (g.fuse & 1) {
+            // reluBackward [ref: src/runtime/cuda_helper.cu:71-78] on the fly; idempotent, so the
+            // in-place write-back by column 0 may race with the other columns' reads harmlessly
+            float4 yv;
+            if (FAST) yv = *reinterpret_cast<const float4*>(g.act_y + (int64_t)k * g.ld_act_y + m);
+            else yv = load4_guard(g.act_y + (int64_t)k * g.ld_act_y + m, k < ke, m, g.M, y_vec);
+            ra[i].x = yv.x > 0.0f ? ra[i].x : 0.0f; ra[i].y = yv.y > 0.0f ? ra[i].y : 0.0f;
+            ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
+            if (bx == 0 && (FAST || k < ke)) {
+              float* wp = const_cast<float*>(A) + (int64_t)k * g.sAk + m;
+              if (FAST || (a_vec && m + 3 < g.M)) *reinterpret_cast<float4*>(wp) = ra[i];
+              else {
+                if (m + 0 < g.M) wp[0] = ra[i].x;
+                if (m + 1 < g.M) wp[1] = ra[i].y;
+                if (m + 2 < g.M) wp[2] = ra[i].z;
+                if (m + 3 < g.M) wp[3] = ra[i].w;
+              }
+            }
+          }
+          if ((g.fuse & 2) && bx == 0) { bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w; }
+        }
       }
     }
 #pragma unroll
@@ -111,12 +177,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
       if (BKC) {
         const int k4 = tid % KQ, row = tid / KQ + i * RPP;
         const int n = n0 + row, k = k0 + k4 * 4;
-        rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, b_vec);
+        if (FAST) rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)n * g.sBn + k);
+        else rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, b_vec);
       } else {
         constexpr int PER = BN / 4;
         const int n4 = tid % PER, kr = tid / PER + i * (256 / PER);
         const int n = n0 + n4 * 4, k = k0 + kr;
-        rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, b_vec);
+        if (FAST) rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)k * g.sBk + n);
+        else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, b_vec);
       }
     }
   };
@@ -162,35 +230,103 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+  const int wm0 = SPLITW ? 0 : (wave >> 1) * (BM / 2), wn0 = SPLITW ? 0 : (wave & 1) * (BN / 2);
+  constexpr int KPAIRS = SPLITW ? BK / 8 : BK / 2;     // k-pairs (MFMA steps) per wave per k-tile
+  const int kk0 = SPLITW ? wave * KPAIRS : 0;
   const int lr = lane & 31, lh = lane >> 5;
 
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+  auto compute_tile = [&](int buf) {
     const float* as = As[buf];
     const float* bs = Bs[buf];
+    // all operand fetches of the k-tile first (counted lgkmcnt waits), then the MFMA chain
+    constexpr int KH = KPAIRS > 8 ? 8 : KPAIRS;     // fetch in groups of <= 8 k-pairs to bound registers
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; kk++) {
-      float a[WM], b[WN];
+    for (int kg = 0; kg < KPAIRS; kg += KH) {
+      float a[KH][WM], b[KH][WN];
 #pragma unroll
-      for (int i = 0; i < WM; i++) a[i] = as[(2 * kk + lh) * LA + wm0 + i * 32 + lr];
+      for (int kq = 0; kq < KH; kq++) {
+        const int kk = kk0 + kg + kq;
 #pragma unroll
-      for (int j = 0; j < WN; j++) b[j] = bs[(2 * kk + lh) * LB + wn0 + j * 32 + lr];
+        for (int i = 0; i < WM; i++) a[kq][i] = as[(2 * kk + lh) * LA + wm0 + i * 32 + lr];
 #pragma unroll
-      for (int i = 0; i < WM; i++)
+        for (int j = 0; j < WN; j++) b[kq][j] = bs[(2 * kk + lh) * LB + wn0 + j * 32 + lr];
+      }
 #pragma unroll
-        for (int j = 0; j < WN; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int kq = 0; kq < KH; kq++)
+#pragma unroll
+        for (int i = 0; i < WM; i++)
+#pragma unroll
+          for (int j = 0; j < WN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kq][i], b[kq][j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+  };
+
+  // phase 1: interior k-tiles, software-pipelined (tile t+1 in flight in registers while tile t
+  // feeds the MFMAs), one barrier per tile, unguarded loads only -- a separate loop so that no
+  // control-flow merge forces the compiler to drain vmcnt early
+  if (nfull > 0) {
+    load_tile_t(0, std::true_type{});
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nfull; kt++) {
+      const int buf = kt & 1;
+      if (kt + 1 < nfull) load_tile_t(kt + 1, std::true_type{});
+      compute_tile(buf);
+      if (kt + 1 < nfull) store_tile(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // phase 2: edge tiles (K tail, ragged M/N, unaligned operands): guarded loads, not pipelined
+  for (int kt = nfull; kt < nk; kt++) {
+    load_tile_t(kt, std::false_type{});
+    store_tile(0);
+    __syncthreads();
+    compute_tile(0);
     __syncthreads();
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+  if (FUSE_DY) {
+    if ((g.fuse & 2) && bx == 0) {
+      // bias gradient: the threads that staged the same 4 columns (different k rows) meet in LDS
+      constexpr int PER = BM / 4;
+      float4* sb = reinterpret_cast<float4*>(As[0]);
+      sb[tid] = bsum;
+      __syncthreads();
+      if (tid < PER) {
+        float4 t = sb[tid];
+        for (int q = 1; q < 256 / PER; q++) { const float4 u = sb[q * PER + tid]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        const int m = m0 + tid * 4;
+        if (m + 0 < g.M) atomicAdd(&g.db[m + 0], t.x);
+        if (m + 1 < g.M) atomicAdd(&g.db[m + 1], t.y);
+        if (m + 2 < g.M) atomicAdd(&g.db[m + 2], t.z);
+        if (m + 3 < g.M) atomicAdd(&g.db[m + 3], t.w);
+      }
+    }
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+  if (SPLITW) {
+    // the four k-slices of the tile: ((w0 + w1) + w2) + w3, each wave finishes 4 of the 16 registers
+    __shared__ float red[4 * 16 * 64];
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
+    __syncthreads();
+    const int n = n0 + lr;
+    if (n < g.N) {
+      const float bv = (g.epi == EPI_STORE && g.bias) ? g.bias[n] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = wave * 4 + q;
+        const float v = ((red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane]) + red[(3 * 16 + r) * 64 + lane];
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.M) continue;
+        float* cp = C + (int64_t)m * g.ldc + n;
+        if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
+        else if (g.epi == EPI_ADD) *cp = *cp + v;
+        else atomicAdd(cp, v);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < WM; i++)
 #pragma unroll
@@ -212,66 +348,100 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 }
 
 // dy <- dy * act'(y) in place, and db[o] += sum_b dy[b][o]; one pass over dy.
-// Column sums are reduced in LDS per workgroup, then one global atomic per column.
+// 256 threads = TX column-threads x TY row-threads; a thread owns VEC adjacent columns (16-B
+// accesses when the layout allows), walks its rows with the partial column sums in registers,
+// the TY partials of a column meet in LDS and one global atomic per column per workgroup is left.
+template <int VEC>
 __global__ __launch_bounds__(256) void act_bwd_bias_kernel(float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
-                                                           float* __restrict__ db, int out, int64_t batch, int rows_per_block, int act) {
-  extern __shared__ float s_col[];
-  const bool want_db = db != nullptr;
-  if (want_db) {
-    for (int c = threadIdx.x; c < out; c += blockDim.x) s_col[c] = 0.0f;
-    __syncthreads();
-  }
+                                                           float* __restrict__ db, int out, int64_t batch, int rows_per_block, int act,
+                                                           int tx_count) {
+  __shared__ float s_red[256 * VEC];
+  const int TX = tx_count, TY = 256 / tx_count;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cols_v = (out + VEC - 1) / VEC;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < batch ? r0 + rows_per_block : batch;
-  const int64_t total = (r1 - r0) * out;
-  if (out >= 256 || (256 % out) != 0) {
-    // general: LDS float atomics per element
-    for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
-      const int64_t r = r0 + e / out;
-      const int c = (int)(e % out);
-      float d = dy[r * lddy + c];
-      if (act == FFH_AC_MODE_RELU) { d = (y[r * ldy + c] > 0.0f) ? d : 0.0f; dy[r * lddy + c] = d; }
-      else if (act == FFH_AC_MODE_SIGMOID) { const float yo = y[r * ldy + c]; d = d * yo * (1 - yo); dy[r * lddy + c] = d; }
-      if (want_db) atomicAdd(&s_col[c], d);
+  for (int c0 = 0; c0 < cols_v; c0 += TX) {      // uniform trip count: the LDS reduction below has barriers
+    const int c = c0 + tx;
+    const bool live = c < cols_v;
+    float part[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; v++) part[v] = 0.0f;
+    for (int64_t r = r0 + ty; live && r < r1; r += TY) {
+      float d[VEC], yo[VEC];
+      float* dp = dy + r * lddy + (int64_t)c * VEC;
+      const float* yp = y + r * ldy + (int64_t)c * VEC;
+      if (VEC == 4) {
+        const float4 dv = *reinterpret_cast<const float4*>(dp);
+        d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+        if (act != FFH_AC_MODE_NONE) { const float4 yv = *reinterpret_cast<const float4*>(yp); yo[0] = yv.x; yo[1] = yv.y; yo[2] = yv.z; yo[3] = yv.w; }
+      } else {
+        d[0] = dp[0];
+        if (act != FFH_AC_MODE_NONE) yo[0] = yp[0];
+      }
+      if (act == FFH_AC_MODE_RELU) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) d[v] = (yo[v] > 0.0f) ? d[v] : 0.0f;
+      } else if (act == FFH_AC_MODE_SIGMOID) {
+#pragma unroll
+        for (int v = 0; v < VEC; v++) d[v] = d[v] * yo[v] * (1 - yo[v]);
+      }
+      if (act != FFH_AC_MODE_NONE) {
+        if (VEC == 4) *reinterpret_cast<float4*>(dp) = make_float4(d[0], d[1], d[2], d[3]);
+        else dp[0] = d[0];
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; v++) part[v] += d[v];
     }
-  } else {
-    // out divides 256: a thread stays on one column; sum in a register first
-    const int c = threadIdx.x % out;
-    float part = 0.0f;
-    for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
-      const int64_t r = r0 + e / out;
-      float d = dy[r * lddy + c];
-      if (act == FFH_AC_MODE_RELU) { d = (y[r * ldy + c] > 0.0f) ? d : 0.0f; dy[r * lddy + c] = d; }
-      else if (act == FFH_AC_MODE_SIGMOID) { const float yo = y[r * ldy + c]; d = d * yo * (1 - yo); dy[r * lddy + c] = d; }
-      part += d;
+    if (db) {
+      if (TY == 1) {
+        if (live) {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) atomicAdd(&db[c * VEC + v], part[v]);
+        }
+      } else {
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VEC; v++) s_red[(ty * TX + tx) * VEC + v] = part[v];
+        __syncthreads();
+        if (ty == 0 && live) {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            float sum = 0.0f;
+            for (int q = 0; q < TY; q++) sum += s_red[(q * TX + tx) * VEC + v];
+            atomicAdd(&db[c * VEC + v], sum);
+          }
+        }
+      }
     }
-    if (want_db) atomicAdd(&s_col[c], part);
-  }
-  if (want_db) {
-    __syncthreads();
-    for (int c = threadIdx.x; c < out; c += blockDim.x) atomicAdd(&db[c], s_col[c]);
   }
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool FUSE_DY = false>
 int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char* name) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || batch <= 0) return FFH_OK;
+  // tile choice: 128x128 when that alone fills the chip twice; 64x64 when it yields >= 2 workgroups
+  // per CU; else one 32x32 tile per workgroup with the four waves splitting K
   const int64_t tiles128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
-  const bool big = tiles128 >= 2 * c->num_cus && g.M >= 128 && g.N >= 128;
-  const int BMv = big ? 128 : 64;
+  const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64) * batch;
+  int cfg;   // 0: 128x128, 1: 64x64, 2: 32x32 split-wave
+  if (tiles128 >= 2 * c->num_cus && g.M >= 128 && g.N >= 128) cfg = 0;
+  else if (tiles64 >= 2 * c->num_cus || g.K < 64) cfg = 1;
+  else cfg = 2;
+  const int BMv = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32);
   const int gx = (g.N + BMv - 1) / BMv, gy = (g.M + BMv - 1) / BMv;
   int gz = (int)batch;
   g.splitk = 1;
   g.k_per_split = g.K;
   if (g.epi == EPI_ATOMIC) {
-    // split K so that about two workgroups per CU are in flight; each split is a multiple of BK
+    // split K over workgroups so that about two of them per CU are in flight; each split is a multiple of kSplitGran
     const int64_t tiles = (int64_t)gx * gy;
     int want = (int)((2LL * c->num_cus + tiles - 1) / tiles);
     const int max_split = (g.K + 4 * kSplitGran - 1) / (4 * kSplitGran);
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
     int kps = (g.K + want - 1) / want;
-    kps = (kps + kSplitGran - 1) / kSplitGran * kSplitGran;
+    kps = (kps + 2 * kSplitGran - 1) / (2 * kSplitGran) * (2 * kSplitGran);
     g.k_per_split = kps;
     g.splitk = (g.K + kps - 1) / kps;
     if (g.splitk <= 1) { g.splitk = 2; }       // keeps blockIdx.z meaning "split" (second split is empty)
@@ -280,8 +450,9 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   }
   if (gy > 65535 || gz > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm: grid too large");
   dim3 grid(gx, gy, gz);
-  if (big) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AKC, BKC>), grid, dim3(256), 0, as_stream(s), g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, AKC, BKC>), grid, dim3(256), 0, as_stream(s), g);
+  if (cfg == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
+  else if (cfg == 1) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
+  else hipLaunchKernelGGL((gemm_f32_kernel<32, 32, 64, AKC, BKC, true, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, name);
   return FFH_OK;
@@ -317,13 +488,20 @@ int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t l
   FFH_REQUIRE(c, batch < (1LL << 31), "linear_bwd: batch too large");
   if (!act_ok(act)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd: activation not supported (NONE, RELU, SIGMOID)");
   if (batch == 0) return FFH_OK;
-  // 1. activation gradient in place + bias gradient (one pass over dy)
-  if (act != FFH_AC_MODE_NONE || db) {
-    int rows = (int)((batch + 2 * c->num_cus - 1) / (2 * c->num_cus));
-    if (rows < 4) rows = 4;
+  // 1. sigmoid: its gradient is not idempotent, so it gets its own in-place pass (with the bias sums).
+  //    relu / none: folded into the dw GEMM's operand loads below (no separate pass over dy).
+  const bool separate = act == FFH_AC_MODE_SIGMOID;
+  if (separate) {
+    const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
+    const int cols_v = v4 ? out / 4 : out;
+    int tx = 1;
+    while (tx < cols_v && tx < 256) tx <<= 1;       // power of two: TY = 256 / TX rows in flight per workgroup
+    const int ty = 256 / tx;
+    int64_t rows = (batch + 2 * c->num_cus - 1) / (2 * c->num_cus);
+    if (rows < 4 * ty) rows = 4 * ty;
     const unsigned grid = (unsigned)((batch + rows - 1) / rows);
-    hipLaunchKernelGGL(act_bwd_bias_kernel, dim3(grid), dim3(256), (size_t)out * sizeof(float), as_stream(s),
-                       dy, lddy, y, ldy, db, out, batch, rows, act);
+    if (v4) hipLaunchKernelGGL((act_bwd_bias_kernel<4>), dim3(grid), dim3(256), 0, as_stream(s), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
+    else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(grid), dim3(256), 0, as_stream(s), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
     FFH_LAUNCH_CHECK(c, "act_bwd_bias_kernel");
   }
   // 2. dw[o][i] += sum_b dy[b][o] x[b][i]   (split-K over the batch, fp32 atomics)
@@ -334,7 +512,9 @@ int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t l
     g.C = dw; g.ldc = in;
     g.M = out; g.N = in; g.K = (int)batch;
     g.epi = EPI_ATOMIC; g.act = FFH_AC_MODE_NONE;
-    int rc = launch_gemm<false, false>(c, g, 1, s, "linear_bwd dw gemm");
+    g.act_y = y; g.ld_act_y = ldy; g.db = db;
+    g.fuse = separate ? 0 : ((act == FFH_AC_MODE_RELU ? 1 : 0) | (db ? 2 : 0));
+    int rc = launch_gemm<false, false, true>(c, g, 1, s, "linear_bwd dw gemm");
     if (rc) return rc;
   }
   // 3. dx[b][i] += sum_o dy[b][o] w[o][i]
