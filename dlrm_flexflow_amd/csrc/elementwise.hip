@@ -102,8 +102,10 @@ __global__ __launch_bounds__(256) void mse_bwd_kernel(float* __restrict__ lg, co
 }
 
 // per-workgroup reduction in registers/LDS, then one atomic per workgroup per counter
+// lg != NULL: also writes the MSE gradient lg[b][i] = (logit - label) * scale (FFModel::backward's loss step)
 __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
-                                                      ffh_perf_metrics* __restrict__ perf, int64_t ns, int nc, int flags) {
+                                                      ffh_perf_metrics* __restrict__ perf, int64_t ns, int nc, int flags,
+                                                      float* __restrict__ lg, float scale) {
   __shared__ float s_f[3][4];
   __shared__ int   s_i[2][4];
   float mse_s = 0.f, rmse_s = 0.f, mae_s = 0.f;
@@ -111,6 +113,12 @@ __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ 
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < ns; b += stride) {
     all += 1;
+    if (lg) {
+      for (int i = 0; i < nc; i++) {
+        const float d = logits[b * nc + i] - labels[b * nc + i];
+        lg[b * nc + i] = __fmaf_rn(scale - 0.0f, d, 0.0f);
+      }
+    }
     if (flags & 1) {
       if (nc == 1) { all += 1; correct += 1; }
       else {
@@ -220,8 +228,18 @@ int ffh_metrics_update(ffh_ctx* c, const float* logits, const float* labels, ffh
                        int64_t ns, int nc, int flags, ffh_stream s) {
   FFH_REQUIRE(c, ns >= 0 && nc > 0 && perf && ((logits && labels) || ns == 0), "metrics_update: bad args");
   if (ns == 0) return FFH_OK;
-  hipLaunchKernelGGL(metrics_kernel, dim3(ffh_grid(ns, 256, 256)), dim3(256), 0, as_stream(s), logits, labels, perf, ns, nc, flags);
+  hipLaunchKernelGGL(metrics_kernel, dim3(ffh_grid(ns, 256, 256)), dim3(256), 0, as_stream(s), logits, labels, perf, ns, nc, flags,
+                     (float*)nullptr, 0.0f);
   FFH_LAUNCH_CHECK(c, "metrics_kernel");
+  return FFH_OK;
+}
+
+int ffh_mse_bwd_metrics(ffh_ctx* c, float* lg, const float* logit, const float* label, ffh_perf_metrics* perf,
+                        int64_t ns, int nc, float scale, int flags, ffh_stream s) {
+  FFH_REQUIRE(c, ns >= 0 && nc > 0 && perf && ((lg && logit && label) || ns == 0), "mse_bwd_metrics: bad args");
+  if (ns == 0) return FFH_OK;
+  hipLaunchKernelGGL(metrics_kernel, dim3(ffh_grid(ns, 256, 256)), dim3(256), 0, as_stream(s), logit, label, perf, ns, nc, flags, lg, scale);
+  FFH_LAUNCH_CHECK(c, "metrics_kernel (with loss)");
   return FFH_OK;
 }
 

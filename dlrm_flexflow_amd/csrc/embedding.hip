@@ -201,7 +201,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
   }
   __syncthreads();
 
-  // global base of every digit for this tile: digits below (all tiles) + same digit, earlier tiles
+  // global base of every digit for this tile: digits below (all tiles) + same digit, earlier tiles.
+  // The column walk over the [tiles][radix] matrix is unrolled so that 8 L2 loads are in flight.
   const uint32_t* hist_t = a.hist + (int64_t)t * a.nblk * radix;
   uint32_t all_d[2] = {0, 0}, before_d[2] = {0, 0};
 #pragma unroll
@@ -209,10 +210,18 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
     const int d = threadIdx.x + q * kSortThreads;
     if (d < radix) {
       uint32_t all = 0, before = 0;
-      for (int b2 = 0; b2 < a.nblk; b2++) {
+      int b2 = 0;
+      for (; b2 + 8 <= a.nblk; b2 += 8) {
+        uint32_t h[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) h[u] = hist_t[(int64_t)(b2 + u) * radix + d];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { all += h[u]; before += (b2 + u < blk) ? h[u] : 0u; }
+      }
+      for (; b2 < a.nblk; b2++) {
         const uint32_t h = hist_t[(int64_t)b2 * radix + d];
         all += h;
-        if (b2 < blk) before += h;
+        before += (b2 < blk) ? h : 0u;
       }
       all_d[q] = all; before_d[q] = before;
     }
@@ -505,6 +514,8 @@ inline int sort_per_thread(int nt, int64_t N) {
   const int64_t want = N * nt / (512LL * kSortThreads);
   int e = 1;
   while (e * 2 <= want && e < kSortMaxPerThread) e *= 2;
+  // every scatter workgroup walks the table's [tiles][radix] histogram matrix: keep <= 32 tiles per table
+  while ((N + (int64_t)kSortThreads * e - 1) / ((int64_t)kSortThreads * e) > 32 && e < kSortMaxPerThread) e *= 2;
   return e;
 }
 inline int reduce_tile(int nt, int64_t N) {

@@ -15,6 +15,7 @@ struct ffh_ctx {
   void*       ws;        // caller-attached scratch (FFHandler.workSpace analogue)
   size_t      ws_bytes;
   int         num_cus;
+  hipEvent_t  ev_fork;   // ffh_linear_bwd_ex: orders the weight-gradient stream behind the caller's stream
   char        err[512];
 };
 

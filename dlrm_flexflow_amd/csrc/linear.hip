@@ -19,6 +19,7 @@
 // cublasSgemmStridedBatched [ref: src/ops/batch_matmul.cu:238-241,393-398].
 #include "ffh_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -75,7 +76,6 @@ __device__ __forceinline__ float4 load4_guard(const float* p, bool row_ok, int c
 //                 a 64x64 tiling: a 32x32x2 MFMA chain over K = 512 alone is 16k cycles.
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool SPLITW = false, bool FUSE_DY = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-  static_assert(!FUSE_DY || !AKC, "the fused dy form is the m-contiguous A operand");
   constexpr int PA = AKC ? 1 : 4, PB = BKC ? 1 : 4;
   constexpr int LA = BM + PA, LB = BN + PB;
   constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 staging slots per thread
@@ -142,13 +142,22 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         const int m = m0 + row, k = k0 + k4 * 4;
         if (FAST) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)m * g.sAm + k);
         else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, a_vec);
+        if (FUSE_DY && (g.fuse & 1)) {
+          // dx form: relu' applied to dy as it is loaded (the in-place result belongs to the dw GEMM,
+          // which may run concurrently on another stream)
+          float4 yv;
+          if (FAST) yv = *reinterpret_cast<const float4*>(g.act_y + (int64_t)m * g.ld_act_y + k);
+          else yv = load4_guard(g.act_y + (int64_t)m * g.ld_act_y + k, m < g.M, k, ke, y_vec);
+          ra[i].x = yv.x > 0.0f ? ra[i].x : 0.0f; ra[i].y = yv.y > 0.0f ? ra[i].y : 0.0f;
+          ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
+        }
       } else {     // rows of the tile are k, contiguous along m
         constexpr int PER = BM / 4;
         const int m4 = tid % PER, kr = tid / PER + i * (256 / PER);
         const int m = m0 + m4 * 4, k = k0 + kr;
         if (FAST) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)k * g.sAk + m);
         else ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, a_vec);
-        if (FUSE_DY) {
+        if (FUSE_DY && !AKC) {
           if (g.fuse & 1) {
             // reluBackward [ref: src/runtime/cuda_helper.cu:71-78] on the fly; idempotent, so the
             // in-place write-back by column 0 may race with the other columns' reads harmlessly
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     __syncthreads();
   }
 
-  if (FUSE_DY) {
+  if (FUSE_DY && !AKC) {
     if ((g.fuse & 2) && bx == 0) {
       // bias gradient: the threads that staged the same 4 columns (different k rows) meet in LDS
       constexpr int PER = BM / 4;
@@ -425,9 +434,16 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   const int64_t tiles128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
   const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64) * batch;
   int cfg;   // 0: 128x128, 1: 64x64, 2: 32x32 split-wave
-  if (tiles128 >= 2 * c->num_cus && g.M >= 128 && g.N >= 128) cfg = 0;
+  if (g.epi == EPI_ATOMIC) {
+    // split-K supplies the parallelism here, so the tile follows the amount of work (measured on MI355X):
+    // big tiles for deep/wide products (arithmetic intensity), the split-wave form for the skinny DLRM layers
+    const double work = (double)g.M * g.N * g.K;
+    cfg = work >= 3e9 && g.M >= 128 && g.N >= 128 ? 0 : (work >= 8e8 ? 1 : 2);
+  } else if (tiles128 >= 2 * c->num_cus && g.M >= 128 && g.N >= 128) cfg = 0;
   else if (tiles64 >= 2 * c->num_cus || g.K < 64) cfg = 1;
   else cfg = 2;
+  static const int forced = getenv("FFH_GEMM_CFG") ? atoi(getenv("FFH_GEMM_CFG")) : -1;   // tuning aid
+  if (forced >= 0 && forced <= 2) cfg = forced;
   const int BMv = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32);
   const int gx = (g.N + BMv - 1) / BMv, gy = (g.M + BMv - 1) / BMv;
   int gz = (int)batch;
@@ -480,16 +496,16 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   return launch_gemm<true, true>(c, g, 1, s, "linear_fwd gemm");
 }
 
-int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
-                   float* dy, int64_t lddy, const float* w, float* dw, float* db,
-                   int in, int out, int64_t batch, int act, ffh_stream s) {
+int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
+                      float* dy, int64_t lddy, const float* w, float* dw, float* db,
+                      int in, int out, int64_t batch, int act, int flags, ffh_stream s, ffh_stream s_dw) {
   FFH_REQUIRE(c, in > 0 && out > 0 && batch >= 0 && ldx >= in && ldy >= out && lddy >= out && (!dx || lddx >= in), "linear_bwd: bad dims");
   FFH_REQUIRE(c, batch == 0 || (x && y && dy && w && dw), "linear_bwd: null pointer");
   FFH_REQUIRE(c, batch < (1LL << 31), "linear_bwd: batch too large");
   if (!act_ok(act)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd: activation not supported (NONE, RELU, SIGMOID)");
   if (batch == 0) return FFH_OK;
   // 1. sigmoid: its gradient is not idempotent, so it gets its own in-place pass (with the bias sums).
-  //    relu / none: folded into the dw GEMM's operand loads below (no separate pass over dy).
+  //    relu / none: folded into the GEMMs' operand loads below (no separate pass over dy).
   const bool separate = act == FFH_AC_MODE_SIGMOID;
   if (separate) {
     const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
@@ -504,7 +520,17 @@ int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t l
     else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(grid), dim3(256), 0, as_stream(s), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
     FFH_LAUNCH_CHECK(c, "act_bwd_bias_kernel");
   }
-  // 2. dw[o][i] += sum_b dy[b][o] x[b][i]   (split-K over the batch, fp32 atomics)
+  // the weight-gradient GEMM may go to its own stream: it only needs dy (and y, x), which are ready on s now
+  const bool forked = s_dw != nullptr && s_dw != s;
+  ffh_stream sw = forked ? s_dw : s;
+  if (forked) {
+    if (!c->ev_fork) FFH_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    FFH_HIP_TRY(c, hipEventRecord(c->ev_fork, as_stream(s)));
+    FFH_HIP_TRY(c, hipStreamWaitEvent(as_stream(sw), c->ev_fork, 0));
+  }
+  const bool relu = act == FFH_AC_MODE_RELU;
+  // 2. dw[o][i] += sum_b dy[b][o] x[b][i]   (split-K over the batch, fp32 atomics); relu' mask applied on load and
+  //    written back to dy in place, db = column sums of the same tiles
   {
     GemmArgs g{};
     g.A = dy; g.sAm = 1; g.sAk = lddy;
@@ -513,22 +539,36 @@ int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t l
     g.M = out; g.N = in; g.K = (int)batch;
     g.epi = EPI_ATOMIC; g.act = FFH_AC_MODE_NONE;
     g.act_y = y; g.ld_act_y = ldy; g.db = db;
-    g.fuse = separate ? 0 : ((act == FFH_AC_MODE_RELU ? 1 : 0) | (db ? 2 : 0));
-    int rc = launch_gemm<false, false, true>(c, g, 1, s, "linear_bwd dw gemm");
+    g.fuse = separate ? 0 : ((relu ? 1 : 0) | (db ? 2 : 0));
+    int rc = launch_gemm<false, false, true>(c, g, 1, sw, "linear_bwd dw gemm");
     if (rc) return rc;
   }
-  // 3. dx[b][i] += sum_o dy[b][o] w[o][i]
+  // 3. dx[b][i] (+)= sum_o dy[b][o] w[o][i].  Unforked it runs behind the dw GEMM and reads the masked dy;
+  //    forked it masks dy itself while loading (idempotent, so the concurrent in-place write-back is harmless)
   if (dx) {
     GemmArgs g{};
     g.A = dy; g.sAm = lddy; g.sAk = 1;
     g.B = w; g.sBn = 1; g.sBk = in;
     g.C = dx; g.ldc = lddx;
     g.M = (int)batch; g.N = in; g.K = out;
-    g.epi = EPI_ADD; g.act = FFH_AC_MODE_NONE;
-    int rc = launch_gemm<true, false>(c, g, 1, s, "linear_bwd dx gemm");
+    g.epi = (flags & FFH_LINEAR_DX_OVERWRITE) ? EPI_STORE : EPI_ADD;
+    g.act = FFH_AC_MODE_NONE;
+    int rc;
+    if (forked && relu) {
+      g.act_y = y; g.ld_act_y = ldy; g.fuse = 1;
+      rc = launch_gemm<true, false, true>(c, g, 1, s, "linear_bwd dx gemm (masking)");
+    } else {
+      rc = launch_gemm<true, false>(c, g, 1, s, "linear_bwd dx gemm");
+    }
     if (rc) return rc;
   }
   return FFH_OK;
+}
+
+int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
+                   float* dy, int64_t lddy, const float* w, float* dw, float* db,
+                   int in, int out, int64_t batch, int act, ffh_stream s) {
+  return ffh_linear_bwd_ex(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, 0, s, nullptr);
 }
 
 int ffh_bmm_fwd(ffh_ctx* c, float* o, const float* a, const float* b, int m, int n, int k, int64_t batch,

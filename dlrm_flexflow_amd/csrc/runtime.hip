@@ -28,7 +28,11 @@ int ffh_ctx_create(ffh_ctx** out, int device) {
   return FFH_OK;
 }
 
-int ffh_ctx_destroy(ffh_ctx* c) { delete c; return FFH_OK; }
+int ffh_ctx_destroy(ffh_ctx* c) {
+  if (c && c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  delete c;
+  return FFH_OK;
+}
 
 const char* ffh_last_error_string(const ffh_ctx* c) { return c ? c->err : "null ctx"; }
 
@@ -109,7 +113,7 @@ int ffh_graph_end_capture(ffh_ctx* c, ffh_stream s, ffh_graph* g) {
   FFH_HIP_TRY(c, hipStreamEndCapture(as_stream(s), &graph));
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (e != hipSuccess) return ffh_fail_hip(c, e, "hipGraphInstantiate");
   *g = (ffh_graph)exec;
   return FFH_OK;

@@ -74,6 +74,7 @@ class FFConfig {
   bool enable_graph;           // begin_trace/end_trace capture + replay as a hipGraph
   bool overlap_embedding;      // embedding gather (+exchange) on a side stream beside the bottom MLP
   bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
+  bool parallel_dw;            // weight-gradient GEMMs on their own stream beside the data-gradient chain
   bool force_exchange;         // run the all-to-all / all-reduce path even with one rank (tests the collectives on 1 GPU)
   ffcomm comm;                 // rank / world_size / collectives supplied by the launcher (ffcomm.h)
 };
@@ -218,6 +219,7 @@ class Linear : public Op {
   ActiMode activation;
   bool use_bias;
   bool discard_input_grad;      // first layer on a model input: dX is never consumed
+  bool dx_overwrite;            // input has no other consumer: dX may be stored instead of accumulated
   Initializer *kernel_initializer, *bias_initializer;
 };
 
@@ -307,6 +309,10 @@ class FFModel {
   ffh_ctx* ctx;
   ffh_stream stream;           // main compute stream
   ffh_stream side_stream;      // embedding gather / exchange / sparse update
+  ffh_stream dw_stream;        // weight-gradient GEMMs (parallel_dw)
+  ffh_event ev_dw_done;
+  bool need_zero_act_grads;    // some activation gradient is accumulated by more than one producer
+  mutable bool dw_forked;
   ffh_event ev_fork, ev_join, ev_grad_ready, ev_update_done;
   int rank, world_size;
   bool exchange;               // table-wise exchange + gradient all-reduce active (world_size > 1)

@@ -68,6 +68,7 @@ FFConfig::FFConfig() {
   overlap_embedding = true;
   dense_embedding_update = false;
   force_exchange = false;
+  parallel_dw = true;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
   comm.world_size = 1;
@@ -108,6 +109,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-overlap")) { overlap_embedding = false; continue; }
     if (is("--dense-embedding-update")) { dense_embedding_update = true; continue; }
     if (is("--force-exchange")) { force_exchange = true; continue; }
+    if (is("--serial-dw")) { parallel_dw = false; continue; }
   }
 }
 
@@ -163,6 +165,7 @@ bool copy_out(const FFModel* model, const Tensor& t, const void* base, int64_t l
   const int64_t nrows = local_rows(t, model);
   model->check(model->api->ffh_stream_sync(model->ctx, model->stream), "get_tensor sync");
   model->check(model->api->ffh_stream_sync(model->ctx, model->side_stream), "get_tensor sync");
+  model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream), "get_tensor sync");
   if (ld == cols_) {
     model->check(model->api->ffh_memcpy_d2h(model->ctx, data, base, (size_t)nrows * cols_ * sizeof(T), model->stream), "get_tensor");
   } else {
@@ -308,6 +311,7 @@ FFModel::FFModel(FFConfig& _config)
       emb_forward_issued(false), emb_forward_joined(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
       act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1) {
+  dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; dw_forked = false;
   rank = config.comm.world_size > 1 ? config.comm.rank : 0;
   world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
   if (world_size == 1 && config.workersPerNode > 1)
@@ -324,6 +328,8 @@ FFModel::FFModel(FFConfig& _config)
   if (rc != FFH_OK || !ctx) die("ffh_ctx_create(device %d) failed with %d on %s -- no usable GPU?", config.device, rc, api->path.c_str());
   check(api->ffh_stream_create(ctx, &stream), "stream create");
   check(api->ffh_stream_create(ctx, &side_stream), "stream create");
+  check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
+  check(api->ffh_event_create(ctx, &ev_dw_done), "event create");
   check(api->ffh_event_create(ctx, &ev_fork), "event create");
   check(api->ffh_event_create(ctx, &ev_join), "event create");
   check(api->ffh_event_create(ctx, &ev_grad_ready), "event create");
@@ -344,7 +350,8 @@ FFModel::~FFModel() {
     if (p) api->ffh_free(ctx, p);
   api->ffh_event_destroy(ctx, ev_fork); api->ffh_event_destroy(ctx, ev_join);
   api->ffh_event_destroy(ctx, ev_grad_ready); api->ffh_event_destroy(ctx, ev_update_done);
-  api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream);
+  api->ffh_event_destroy(ctx, ev_dw_done);
+  api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream);
   api->ffh_ctx_destroy(ctx);
 }
 
@@ -435,7 +442,7 @@ Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_
 Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activation, bool _use_bias, const Op* shared_op,
                Initializer* ki, Initializer* bi, const char* name)
     : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), activation(_activation),
-      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), kernel_initializer(ki), bias_initializer(bi) {
+      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), kernel_initializer(ki), bias_initializer(bi) {
   if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
   if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
   if (activation != AC_MODE_NONE && activation != AC_MODE_RELU && activation != AC_MODE_SIGMOID)
@@ -467,11 +474,13 @@ void Linear::backward(const FFModel& ff) {
   const Tensor& y = outputs[0];
   const int64_t b = local_rows(y, &ff);
   float* dx = discard_input_grad ? nullptr : x.impl->grad;
-  ff.check(ff.api->ffh_linear_bwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, dx, x.impl->grad_ld,
-                                  (const float*)y.impl->ptr, y.impl->ld, y.impl->grad, y.impl->grad_ld,
-                                  (const float*)weights[0].impl->ptr, weights[0].impl->grad,
-                                  use_bias ? weights[1].impl->grad : nullptr, in_channels, out_channels, b, (int)activation,
-                                  ff.stream), name);
+  const bool fork = ff.config.parallel_dw;
+  ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, dx, x.impl->grad_ld,
+                                     (const float*)y.impl->ptr, y.impl->ld, y.impl->grad, y.impl->grad_ld,
+                                     (const float*)weights[0].impl->ptr, weights[0].impl->grad,
+                                     use_bias ? weights[1].impl->grad : nullptr, in_channels, out_channels, b, (int)activation,
+                                     dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0, ff.stream, fork ? ff.dw_stream : nullptr), name);
+  if (fork) ff.dw_forked = true;
 }
 
 // =============================================================================================
@@ -865,6 +874,20 @@ void FFModel::allocate() {
     }
   }
 
+  // ---- 4b. which activation gradients have exactly one producer (then nothing needs zeroing) ----
+  need_zero_act_grads = false;
+  for (Op* op : layers) {
+    if (consumers[op->outputs[0].impl] > 1) need_zero_act_grads = true;           // several ops add into its gradient
+    if (op->op_type == OP_BATCHMATMUL) need_zero_act_grads = true;                // accumulates into both operands
+    if (Linear* li = dynamic_cast<Linear*>(op)) li->dx_overwrite = consumers[li->inputs[0].impl] == 1;
+    if (Concat* c = dynamic_cast<Concat*>(op))
+      for (int i = 0; i < c->numInputs; i++) {
+        TensorImpl* im = c->inputs[i].impl;
+        const bool via_exchange = exchange && c->inputs[i].owner_op && c->inputs[i].owner_op->op_type == OP_EMBEDDING;
+        if (im->grad && !im->grad_alias && !via_exchange) need_zero_act_grads = true;   // add_with_stride accumulates
+      }
+  }
+
   // ---- 5. parameters: one slab for every Linear tensor, tables on their own ---------------------
   mlp_count = 0;
   for (Parameter& p : parameters)
@@ -1018,7 +1041,8 @@ void FFModel::zero_gradients() {
   if (replaying_trace >= 0) return;
   // Op::zero_grad for every layer [ref: src/runtime/model.cc:466-490]: two slabs instead of ~34 tasks.
   // Embedding tables have no dense gradient on the fused path (nothing to zero: SURVEY fact 1).
-  check(api->ffh_zero(ctx, act_grad_slab, act_grad_bytes, stream), "zero_gradients");
+  // activation gradients with a single producer are stored, not accumulated: nothing to clear (0 + x == x)
+  if (need_zero_act_grads) check(api->ffh_zero(ctx, act_grad_slab, act_grad_bytes, stream), "zero_gradients");
   check(api->ffh_zero(ctx, mlp_grads, mlp_count * 4, stream), "zero_gradients");
   if (exchange && gsend) {
     size_t n = 0;
@@ -1041,14 +1065,14 @@ void FFModel::backward(int _seq_length) {
   if (replaying_trace >= 0) return;
   seq_length = _seq_length;
   if (config.computationMode != COMP_MODE_TRAINING) die("backward() in inference mode");
-  compute_metrics();
-  // loss [ref: src/loss_functions/loss_functions.cu:141-170,196-237]: scale_factor = 1 / global batch
+  // compute_metrics() + loss backward [ref: src/runtime/model.cc:1443-1452; src/loss_functions/loss_functions.cu:141-170,196-237]
+  // in one launch; scale_factor = 1 / global batch
   const Tensor& fin = layers.back()->outputs[0];
-  const int64_t count = local_rows(fin, this) * fin.adim[0];
   const float scale = loss_type == LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE ? 1.0f / (float)fin.adim[fin.numDim - 1] : 1.0f;
-  if (fin.impl->grad_ld != fin.adim[0]) die("final layer output must be contiguous");
-  check(api->ffh_mse_bwd(ctx, fin.impl->grad, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, count, scale, stream),
-        "loss backward");
+  if (fin.impl->grad_ld != fin.adim[0] || fin.impl->ld != fin.adim[0]) die("final layer output must be contiguous");
+  dw_forked = false;
+  check(api->ffh_mse_bwd_metrics(ctx, fin.impl->grad, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, d_perf,
+                                 local_rows(fin, this), fin.adim[0], scale, metrics_flags, stream), "metrics + loss backward");
   for (int l = (int)layers.size() - 1; l >= 0; l--) layers[l]->backward(*this);
 }
 
@@ -1057,6 +1081,11 @@ void FFModel::update() {
   optimizer->next();
   SGDOptimizer* sgd = dynamic_cast<SGDOptimizer*>(optimizer);
   if (!sgd) die("only SGDOptimizer is on the DLRM path");
+  if (dw_forked) {   // the weight-gradient GEMMs ran on their own stream: join before the gradients are consumed
+    check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");
+    check(api->ffh_stream_wait_event(ctx, stream, ev_dw_done), "join dw");
+    dw_forked = false;
+  }
   // data-parallel MLP gradients: ONE bucket [ref: one ncclAllReduce per tensor, src/runtime/optimizer_kernel.cu:170-171].
   // No 1/world_size: the loss already divides by the global batch.
   if (exchange && mlp_count)
@@ -1109,6 +1138,7 @@ void FFModel::end_trace(int trace_id) {
 void FFModel::sync() {
   check(api->ffh_stream_sync(ctx, stream), "sync");
   check(api->ffh_stream_sync(ctx, side_stream), "sync");
+  check(api->ffh_stream_sync(ctx, dw_stream), "sync");
 }
 
 PerfMetrics FFModel::get_perf_metrics() {

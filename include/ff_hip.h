@@ -225,6 +225,22 @@ int ffh_linear_bwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t
                    const float* w, float* dw, float* db,
                    int in_dim, int out_dim, int64_t batch, int activation, ffh_stream s);
 
+/* Linear::backward_kernel with the scheduling freedoms the Legion task graph gives the reference
+ * (independent tasks run concurrently) made explicit.  Same arithmetic as ffh_linear_bwd; flags:
+ *   FFH_LINEAR_DX_OVERWRITE  dx = dy*w instead of dx += dy*w (caller knows dx has no other producer,
+ *                            so it need not be zeroed first: 0 + x == x)
+ *   s_dw != NULL, != s       the weight/bias-gradient GEMM is issued on stream s_dw behind an event
+ *                            recorded on s; the data-gradient GEMM on s does not wait for it (it applies
+ *                            relu' to dy as it loads it instead of reading the in-place result).  The
+ *                            caller joins s_dw before it consumes dw/db.  dy still ends up overwritten
+ *                            by the activation gradient, as in the reference. */
+#define FFH_LINEAR_DX_OVERWRITE 1
+int ffh_linear_bwd_ex(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                      const float* y, int64_t ldy, float* dy, int64_t lddy,
+                      const float* w, float* dw, float* db,
+                      int in_dim, int out_dim, int64_t batch, int activation,
+                      int flags, ffh_stream s, ffh_stream s_dw);
+
 /* ------------------------------------------------------------------ */
 /* Concat                                                             */
 /* ------------------------------------------------------------------ */
@@ -267,6 +283,11 @@ int ffh_bmm_bwd(ffh_ctx* ctx, const float* o_grad, const float* a, float* a_grad
  * logit_grad[i] = (logit[i] - label[i]) * scale, scale = 1/global_batch [ref: loss_functions.cu:202] */
 int ffh_mse_bwd(ffh_ctx* ctx, float* logit_grad, const float* logit, const float* label,
                 int64_t count, float scale, ffh_stream s);
+/* compute_metrics + loss backward of FFModel::backward [ref: src/runtime/model.cc:1443-1452] in one
+ * launch: exactly ffh_metrics_update followed by ffh_mse_bwd on the same logits/labels. */
+int ffh_mse_bwd_metrics(ffh_ctx* ctx, float* logit_grad, const float* logit, const float* label,
+                        ffh_perf_metrics* perf, int64_t num_samples, int num_classes, float scale,
+                        int flags, ffh_stream s);
 /* update_metrics_label_kernel [ref: src/metrics_functions/metrics_functions.cu:108-173], label
  * (dense) form, restricted to accuracy + MSE/RMSE/MAE.  flags: bit0 accuracy, bit1 mse, bit2 rmse,
  * bit3 mae.  Accumulates into *perf (device memory).  With num_classes == 1 and accuracy on,
@@ -298,8 +319,8 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) \
-  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_concat_fwd) X(ffh_concat_bwd) \
-  X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_mse_bwd) X(ffh_metrics_update) \
+  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_concat_fwd) X(ffh_concat_bwd) \
+  X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_add_scaled)
 
 #endif /* FF_HIP_H_ */

@@ -403,6 +403,17 @@ int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t l
   return FFH_OK;
 }
 
+/* same arithmetic; streams mean nothing on the host.  DX_OVERWRITE: dx is zeroed here, then accumulated */
+int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                      const float* y, int64_t ldy, float* dy, int64_t lddy,
+                      const float* w, float* dw, float* db, int in, int out, int64_t B, int act,
+                      int flags, ffh_stream s, ffh_stream s_dw) {
+  (void)s_dw;
+  if ((flags & FFH_LINEAR_DX_OVERWRITE) && dx && in > 0 && lddx >= in)
+    for (int64_t b = 0; b < B; b++) memset(dx + b * lddx, 0, sizeof(float) * (size_t)in);
+  return ffh_linear_bwd(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, s);
+}
+
 /* ------------------------------------------------------------------ */
 /* Concat                                                             */
 /* ------------------------------------------------------------------ */
@@ -515,6 +526,16 @@ int ffh_mse_bwd(ffh_ctx* c, float* lg, const float* logit, const float* label, i
     lg[i] = fmaf(scale - 0.0f, d, 0.0f);
   }
   return FFH_OK;
+}
+
+int ffh_metrics_update(ffh_ctx* c, const float* logits, const float* labels, ffh_perf_metrics* perf,
+                       int64_t ns, int nc, int flags, ffh_stream s);
+/* FFModel::backward's compute_metrics + loss backward [ref: src/runtime/model.cc:1443-1452] */
+int ffh_mse_bwd_metrics(ffh_ctx* c, float* lg, const float* logit, const float* label, ffh_perf_metrics* perf,
+                        int64_t ns, int nc, float scale, int flags, ffh_stream s) {
+  int rc = ffh_metrics_update(c, logit, label, perf, ns, nc, flags, s);
+  if (rc) return rc;
+  return ffh_mse_bwd(c, lg, logit, label, ns * nc, scale, s);
 }
 
 /* update_metrics_label_kernel [ref: src/metrics_functions/metrics_functions.cu:108-173];

@@ -39,7 +39,10 @@ def emb(hip):
              ("kaggle-26", 26, 2048, 16, [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194,
                                           27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]),
              ("giant-colshard", 1, 32768, 32, [200_000_000])]
+    only = [a for a in sys.argv[2:]]
     for name, T, B, D, rows in cases:
+        if only and name not in only:
+            continue
         W, I = [], []
         for t, R in enumerate(rows):
             w = torch.empty(R, D, device=DEV)
@@ -89,7 +92,7 @@ def gemm(hip):
 if __name__ == "__main__":
     hip = capi.load_hip(0)
     print(hip.device_info().name.decode(), hip.device_info().compute_units, "CUs")
-    what = sys.argv[1:] or ["emb", "gemm"]
+    what = sys.argv[1:2] or ["emb", "gemm"]
     if "emb" in what:
         emb(hip)
     if "gemm" in what:
