@@ -49,12 +49,26 @@ def workload(name: str, per_gpu_batch: int | None, world: int):
     if name == "tiny":         # BASELINE configs[0]
         b = per_gpu_batch or 128
         return dict(name="tiny", rows="-".join(["1000"] * 8), D=16, bot="13-64-16", top="144-64-1", B=b * world)
+    if name == "giant":        # BASELINE configs[4]: one 200M-row x 256 table (204.8 GB), column-wise over the ranks
+        b = per_gpu_batch or 4096
+        return dict(name="giant-table-column-wise", rows="200000000", D=256, bot="13-512-256", top="512-512-256-1", B=b * world,
+                    extra=["--column-shard-rows", "100000000"])
     raise SystemExit(f"unknown workload {name}")
 
 
 def flags_of(w, extra=()):
     return ["-b", str(w["B"]), "--arch-sparse-feature-size", str(w["D"]), "--arch-embedding-size", w["rows"],
-            "--arch-mlp-bot", w["bot"], "--arch-mlp-top", w["top"], "--data-size", str(w["B"]), *extra]
+            "--arch-mlp-bot", w["bot"], "--arch-mlp-top", w["top"], "--data-size", str(w["B"]), *w.get("extra", []), *extra]
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch of the gather from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1])).get(key)
+    return (d["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if d else (None, None)
 
 
 def mlp_flops_per_sample(w):
@@ -226,7 +240,9 @@ def main():
         bwd_bytes = owned * B * (8 + 4 * D + 2 * 4 * D)
         out["roofline"] = {"kernel": "emb_fwd_kernel (embedding gather + bag-sum, all tables in one launch)", "bound": "hbm",
                            "achieved": round(fwd_bytes / t_fwd / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(fwd_bytes / t_fwd / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(fwd_bytes / t_fwd / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": pmc_traffic("kaggle")[0] if args.workload == "kaggle" and not args.per_gpu_batch else None,
+                           "traffic_source": pmc_traffic("kaggle")[1],
                            "us_per_launch": round(t_fwd * 1e6, 2), "algorithmic_bytes_per_launch": fwd_bytes,
                            "bytes_per_sample": fwd_bytes // B}
         flops = mlp_flops_per_sample(w) * B

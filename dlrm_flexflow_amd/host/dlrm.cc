@@ -113,7 +113,7 @@ DataLoader::DataLoader(FFModel& ff, const DLRMConfig& dlrm, const std::vector<Te
   // sparse ids: owner of table t keeps ids of every sample (it gathers for the global batch)
   full_sparse.assign(sparse_inputs.size(), nullptr);
   for (size_t t = 0; t < sparse_inputs.size(); t++) {
-    if ((int)(t % ff.world_size) != ff.rank) continue;
+    if (!sparse_inputs[t].impl->ptr) continue;          // this rank neither owns the table nor holds a column block of it
     const int64_t n = (int64_t)num_samples * bag;
     full_sparse[t] = (int64_t*)ff.dmalloc((size_t)n * sizeof(int64_t));
     ff.check(ff.api->ffh_gen_indices(ff.ctx, full_sparse[t], n, s0 + 17 + t, 0, dlrm.embedding_size[t], ff.stream), "gen_indices");

@@ -74,12 +74,20 @@ class FFConfig {
   bool enable_graph;           // begin_trace/end_trace capture + replay as a hipGraph
   bool overlap_embedding;      // embedding gather (+exchange) on a side stream beside the bottom MLP
   bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
+  int64_t column_shard_rows;   // tables with at least this many rows are sharded column-wise over the ranks (0: never)
   bool parallel_dw;            // weight-gradient GEMMs on their own stream beside the data-gradient chain
   bool force_exchange;         // run the all-to-all / all-reduce path even with one rank (tests the collectives on 1 GPU)
   ffcomm comm;                 // rank / world_size / collectives supplied by the launcher (ffcomm.h)
 };
 
 // ---------------------------------------------------------------------------------------------
+struct TensorPiece {            // one column block of a tensor that is scattered over several buffers
+  float*  ptr;
+  float*  grad;
+  int64_t ld;
+  int     cols;
+};
+
 struct TensorImpl {
   void*   ptr = nullptr;        // device address of element (0, 0)
   int64_t ld = 0;               // elements between consecutive rows (rows = product of outer dims)
@@ -91,6 +99,9 @@ struct TensorImpl {
   size_t  bytes = 0;
   int64_t rows_local = 0;      // rows held by this rank (batch-sharded tensors: rows / world_size)
   int     guid = -1;
+  // non-empty: the tensor has no single buffer; its columns are these pieces in order (the output of a
+  // column-sharded embedding table inside the all-to-all receive buffer)
+  std::vector<TensorPiece> pieces;
 };
 
 struct Tensor {
@@ -236,6 +247,8 @@ class Embedding : public Op {
   Initializer* kernel_initializer;
   int table_index;              // position among the model's embedding ops
   int owner_rank;               // table-wise sharding: table_index % world_size
+  bool column_sharded;          // every rank holds out_channels / world_size columns of all rows
+  int local_cols;               // columns of the table held by this rank
 };
 
 class Concat : public Op {
@@ -334,6 +347,10 @@ class FFModel {
   char* act_grad_slab;  size_t act_grad_bytes;                // every activation gradient (one memset per step)
   void* workspace;  size_t workspace_bytes;
   ffh_perf_metrics* d_perf;
+  // one unit of the exchange: a whole table (table-wise) or a column block of a giant table (column-wise)
+  struct EmbShard { Embedding* e; int owner; int col0; int cols; int64_t off; };
+  std::vector<EmbShard> shards;
+  std::vector<int64_t> rank_width;                            // columns each rank contributes to one sample's row
   // table-wise exchange buffers (world_size > 1)
   float *xsend, *xrecv, *gsend, *grecv;
   std::vector<int64_t> fwd_send_counts, fwd_recv_counts;      // floats per peer

@@ -69,6 +69,7 @@ FFConfig::FFConfig() {
   dense_embedding_update = false;
   force_exchange = false;
   parallel_dw = true;
+  column_shard_rows = 0;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
   comm.world_size = 1;
@@ -110,6 +111,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--dense-embedding-update")) { dense_embedding_update = true; continue; }
     if (is("--force-exchange")) { force_exchange = true; continue; }
     if (is("--serial-dw")) { parallel_dw = false; continue; }
+    if (is("--column-shard-rows")) { column_shard_rows = atoll(next()); continue; }
   }
 }
 
@@ -501,11 +503,16 @@ Embedding::Embedding(FFModel& model, const Tensor& input, int _num_entries, int 
   numWeights = 1;
   table_index = (int)model.embeddings.size();
   owner_rank = table_index % model.world_size;   // table i -> GPU i % n [ref: examples/cpp/DLRM/strategies/dlrm_strategy.cc:252-256]
+  // giant tables: column-wise instead (the reference cannot split an embedding except on the sample
+  // dim, [ref: src/ops/embedding.cu:84-85]); every rank then holds all rows x out_dim/G columns
+  column_sharded = model.world_size > 1 && model.config.column_shard_rows > 0 && num_entries >= model.config.column_shard_rows;
+  if (column_sharded && outDim % model.world_size != 0) die("%s: out_dim %d is not divisible by %d ranks", this->name, outDim, model.world_size);
+  local_cols = column_sharded ? outDim / model.world_size : outDim;
   model.embeddings.push_back(this);
 }
 void Embedding::create_output_and_partition(FFModel&) {}
 void Embedding::create_weights(FFModel& model) {
-  const int dims[2] = {num_entries, out_channels};
+  const int dims[2] = {num_entries, local_cols};   // column-sharded: this rank's slice only
   weights[0] = model.create_weight<2>(dims, this, DT_FLOAT, kernel_initializer);
 }
 void Embedding::forward(const FFModel& ff) {
@@ -583,34 +590,44 @@ void concat_geometry(const Concat* c, const FFModel& ff, int64_t& num_blocks, in
 }
 }  // namespace
 
+namespace {
+// flat part list of a concat: an input scattered over several buffers (column-sharded table) contributes its pieces
+void concat_parts(const Concat* c, const std::vector<int64_t>& ib, bool grads, std::vector<float*>& ptrs,
+                  std::vector<int64_t>& blks, std::vector<int64_t>& lds) {
+  for (int i = 0; i < c->numInputs; i++) {
+    const TensorImpl* im = c->inputs[i].impl;
+    if (!im->pieces.empty()) {
+      if (c->axis != 0) die("%s: a column-sharded input needs a feature-axis concat", c->name);
+      for (const TensorPiece& p : im->pieces) { ptrs.push_back(grads ? p.grad : p.ptr); blks.push_back(p.cols); lds.push_back(p.ld); }
+    } else {
+      ptrs.push_back(grads ? im->grad : (float*)im->ptr);       // NULL gradient (model input): skipped by the kernel
+      blks.push_back(ib[i]);
+      lds.push_back(c->axis == 0 ? (grads ? im->grad_ld : im->ld) : ib[i]);
+    }
+  }
+}
+}  // namespace
+
 void Concat::forward(const FFModel& ff) {
   if (ff.emb_forward_issued && !ff.emb_forward_joined) {   // join the side stream before the first consumer
     ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.stream, ff.ev_join), "join");
     ff.emb_forward_joined = true;
   }
   int64_t nb, ob;
-  std::vector<int64_t> ib;
+  std::vector<int64_t> ib, blks, lds;
+  std::vector<float*> ptrs;
   concat_geometry(this, ff, nb, ob, ib);
-  std::vector<const float*> ptrs(numInputs);
-  std::vector<int64_t> lds(numInputs);
-  for (int i = 0; i < numInputs; i++) {
-    ptrs[i] = (const float*)inputs[i].impl->ptr;
-    lds[i] = axis == 0 ? inputs[i].impl->ld : ib[i];
-  }
-  ff.check(ff.api->ffh_concat_fwd(ff.ctx, (float*)outputs[0].impl->ptr, ob, ptrs.data(), ib.data(), lds.data(), numInputs, nb,
-                                  ff.stream), name);
+  concat_parts(this, ib, false, ptrs, blks, lds);
+  ff.check(ff.api->ffh_concat_fwd(ff.ctx, (float*)outputs[0].impl->ptr, ob, (const float* const*)ptrs.data(), blks.data(), lds.data(),
+                                  (int)ptrs.size(), nb, ff.stream), name);
 }
 void Concat::backward(const FFModel& ff) {
   int64_t nb, ob;
-  std::vector<int64_t> ib;
+  std::vector<int64_t> ib, blks, lds;
+  std::vector<float*> ptrs;
   concat_geometry(this, ff, nb, ob, ib);
-  std::vector<float*> ptrs(numInputs);
-  std::vector<int64_t> lds(numInputs);
-  for (int i = 0; i < numInputs; i++) {
-    ptrs[i] = inputs[i].impl->grad;   // NULL for model inputs: skipped
-    lds[i] = axis == 0 ? inputs[i].impl->grad_ld : ib[i];
-  }
-  ff.check(ff.api->ffh_concat_bwd(ff.ctx, outputs[0].impl->grad, ob, ptrs.data(), ib.data(), lds.data(), numInputs, nb,
+  concat_parts(this, ib, true, ptrs, blks, lds);
+  ff.check(ff.api->ffh_concat_bwd(ff.ctx, outputs[0].impl->grad, ob, ptrs.data(), blks.data(), lds.data(), (int)ptrs.size(), nb,
                                   ff.stream), name);
 }
 
@@ -733,7 +750,7 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
       li->kernel_initializer->init(this, &li->weights[0]);
       if (li->use_bias) li->bias_initializer->init(this, &li->weights[1]);
     } else if (Embedding* e = dynamic_cast<Embedding*>(op)) {
-      if (e->owner_rank == rank) e->kernel_initializer->init(this, &e->weights[0]);
+      if (e->owner_rank == rank || e->column_sharded) e->kernel_initializer->init(this, &e->weights[0]);
     }
   }
   compiled = true;
@@ -764,7 +781,7 @@ void FFModel::allocate() {
     auto it = sparse_of.find(t->impl);
     if (it != sparse_of.end()) {
       // sparse ids of a table: the owner gathers for the GLOBAL batch; other ranks hold nothing
-      if (it->second->owner_rank == rank) alloc_rows(*t, t->rows());
+      if (it->second->owner_rank == rank || it->second->column_sharded) alloc_rows(*t, t->rows());
     } else {
       alloc_rows(*t, t->rows() / world_size);
     }
@@ -785,13 +802,25 @@ void FFModel::allocate() {
   owned_tables.clear();
   for (Embedding* e : embeddings)
     if (e->owner_rank == rank) owned_tables.push_back(e->table_index);
-  const int Tr = (int)owned_tables.size();
+  // exchange units: a table lives whole on one rank (table-wise) or as G column blocks (column-wise)
+  shards.clear();
+  rank_width.assign(world_size, 0);
+  for (Embedding* e : embeddings) {
+    if (e->column_sharded) {
+      for (int g = 0; g < world_size; g++) shards.push_back({e, g, g * e->local_cols, e->local_cols, 0});
+    } else {
+      shards.push_back({e, e->owner_rank, 0, e->out_channels, 0});
+    }
+  }
+  for (EmbShard& sh : shards) { sh.off = rank_width[sh.owner]; rank_width[sh.owner] += sh.cols; }
+  int owned_shards = 0;
+  for (const EmbShard& sh : shards) owned_shards += sh.owner == rank;
   if (exchange && T) {
-    const size_t send_floats = (size_t)config.batchSize * Tr * D;     // [B_global][Tr*D]
+    const size_t send_floats = (size_t)config.batchSize * rank_width[rank];     // [B_global][width of this rank]
     size_t recv_floats = 0;
-    fwd_send_counts.assign(world_size, local_batch * Tr * D);
+    fwd_send_counts.assign(world_size, local_batch * rank_width[rank]);
     fwd_recv_counts.resize(world_size);
-    for (int s = 0; s < world_size; s++) { fwd_recv_counts[s] = local_batch * tables_of_rank(s) * D; recv_floats += fwd_recv_counts[s]; }
+    for (int s = 0; s < world_size; s++) { fwd_recv_counts[s] = local_batch * rank_width[s]; recv_floats += fwd_recv_counts[s]; }
     xsend = (float*)dmalloc(std::max<size_t>(send_floats, 1) * 4);
     grecv = (float*)dmalloc(std::max<size_t>(send_floats, 1) * 4);
     xrecv = (float*)dmalloc(std::max<size_t>(recv_floats, 1) * 4);
@@ -857,20 +886,23 @@ void FFModel::allocate() {
     im->bytes = (size_t)(c->outputs[0].rows() / world_size) * zo->ld * 4;
   }
   if (exchange) {
-    // embedding outputs are views into the receive buffer: block of source s is [Bl][T_s*D]
+    // embedding outputs are views into the receive buffer: the block of source s is [Bl][rank_width[s]]
     std::vector<int64_t> base(world_size, 0);
     for (int s = 1; s < world_size; s++) base[s] = base[s - 1] + fwd_recv_counts[s - 1];
-    std::vector<int> seen(world_size, 0);
-    for (Embedding* e : embeddings) {
-      const int s = e->owner_rank, k = seen[s]++;
-      TensorImpl* im = e->outputs[0].impl;
-      im->ptr = xrecv + base[s] + (int64_t)k * D;
-      im->ld = (int64_t)tables_of_rank(s) * D;
-      im->grad = gsend + base[s] + (int64_t)k * D;
-      im->grad_ld = im->ld;
-      im->alias = im->grad_alias = true;
+    for (const EmbShard& sh : shards) {
+      TensorImpl* im = sh.e->outputs[0].impl;
+      float* p = xrecv + base[sh.owner] + sh.off;
+      float* gp = gsend + base[sh.owner] + sh.off;
       im->rows_local = local_batch;
-      im->bytes = (size_t)local_batch * im->ld * 4;
+      im->alias = im->grad_alias = true;
+      if (sh.e->column_sharded) {
+        im->pieces.push_back({p, gp, rank_width[sh.owner], sh.cols});   // pushed in column order (owner ascending)
+        im->bytes = 0;
+      } else {
+        im->ptr = p; im->ld = rank_width[sh.owner];
+        im->grad = gp; im->grad_ld = im->ld;
+        im->bytes = (size_t)local_batch * im->ld * 4;
+      }
     }
   }
 
@@ -884,7 +916,7 @@ void FFModel::allocate() {
       for (int i = 0; i < c->numInputs; i++) {
         TensorImpl* im = c->inputs[i].impl;
         const bool via_exchange = exchange && c->inputs[i].owner_op && c->inputs[i].owner_op->op_type == OP_EMBEDDING;
-        if (im->grad && !im->grad_alias && !via_exchange) need_zero_act_grads = true;   // add_with_stride accumulates
+        if (im->grad && !im->grad_alias && !via_exchange && im->pieces.empty()) need_zero_act_grads = true;   // add_with_stride accumulates
       }
   }
 
@@ -911,7 +943,7 @@ void FFModel::allocate() {
       off_p += (p.get_volume() + 3) / 4 * 4;
     } else {
       Embedding* e = static_cast<Embedding*>(p.owner_op);
-      if (e->owner_rank != rank) continue;       // sole owner: never replicated, never all-reduced
+      if (e->owner_rank != rank && !e->column_sharded) continue;   // sole owner (or one column block per rank): never replicated, never all-reduced
       im->bytes = p.get_volume() * 4;
       im->ptr = dmalloc(im->bytes);
       if (!fused) {
@@ -924,8 +956,8 @@ void FFModel::allocate() {
 
   // ---- 6. workspace + metrics -------------------------------------------------------------------
   workspace_bytes = 256;
-  if (Tr && fused) {
-    const int chunk = std::min(Tr, FFH_MAX_TABLES);
+  if (owned_shards && fused) {
+    const int chunk = std::min(owned_shards, FFH_MAX_TABLES);
     workspace_bytes = api->ffh_embedding_bwd_workspace_bytes(chunk, L, D, config.batchSize) + 256;
   }
   workspace = dmalloc(workspace_bytes);
@@ -950,30 +982,45 @@ void FFModel::print_layers(int id) {
 // =============================================================================================
 // embedding group: batched gather (+ exchange) and batched fused update
 // =============================================================================================
-void FFModel::embedding_group_forward(ffh_stream s) const {
-  if (embeddings.empty()) return;
-  const int D = embeddings[0]->out_channels, L = embeddings[0]->inputs[0].adim[0];
-  const int aggr = (int)embeddings[0]->aggr;
-  std::vector<ffh_emb_table> tabs;
-  const int Tr = (int)owned_tables.size();
-  int k = 0;
-  for (int ti : owned_tables) {
-    const Embedding* e = embeddings[ti];
+// launches one batched kernel per distinct shard width (all table-wise tables share one; column blocks of
+// giant tables another); FWD: gather, else fused backward + SGD
+static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s) {
+  const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(ff->optimizer);
+  const int L = ff->embeddings[0]->inputs[0].adim[0];
+  const int aggr = (int)ff->embeddings[0]->aggr;
+  std::map<int, std::vector<ffh_emb_table>> by_cols;
+  for (const FFModel::EmbShard& sh : ff->shards) {
+    if (sh.owner != ff->rank) continue;
+    const Embedding* e = sh.e;
     ffh_emb_table t;
     t.idx = (const int64_t*)e->inputs[0].impl->ptr;
-    t.weight = (float*)e->weights[0].impl->ptr;
+    t.weight = (float*)e->weights[0].impl->ptr;      // column-sharded: the local [R][cols] slice
     t.num_entries = e->num_entries;
-    if (!exchange) { t.io = (float*)e->outputs[0].impl->ptr; t.ld = e->outputs[0].impl->ld; }
-    else { t.io = xsend + (int64_t)k * D; t.ld = (int64_t)Tr * D; }
-    tabs.push_back(t);
-    k++;
+    if (!ff->exchange) {
+      t.io = fwd ? (float*)e->outputs[0].impl->ptr : e->outputs[0].impl->grad;
+      t.ld = fwd ? e->outputs[0].impl->ld : e->outputs[0].impl->grad_ld;
+    } else {
+      t.io = (fwd ? ff->xsend : ff->grecv) + sh.off;
+      t.ld = ff->rank_width[ff->rank];
+    }
+    by_cols[sh.cols].push_back(t);
   }
-  for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
-    const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
-    check(api->ffh_embedding_fwd_multi(ctx, tabs.data() + b, n, L, D, config.batchSize, aggr, s), "embedding_fwd_multi");
+  for (auto& kv : by_cols) {
+    std::vector<ffh_emb_table>& tabs = kv.second;
+    for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
+      const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
+      if (fwd) ff->check(ff->api->ffh_embedding_fwd_multi(ff->ctx, tabs.data() + b, n, L, kv.first, ff->config.batchSize, aggr, s), "embedding_fwd_multi");
+      else ff->check(ff->api->ffh_embedding_bwd_sgd_fused_multi(ff->ctx, tabs.data() + b, n, L, kv.first, ff->config.batchSize, aggr, (float)sgd->lr, s),
+                     "embedding_bwd_sgd_fused_multi");
+    }
   }
+}
+
+void FFModel::embedding_group_forward(ffh_stream s) const {
+  if (embeddings.empty()) return;
+  launch_shard_groups(this, true, s);
   if (exchange) {
-    // each owner gathered its tables for the global batch; rows go to the rank that owns the sample
+    // each owner gathered its tables / column blocks for the global batch; rows go to the rank that owns the sample
     if (config.comm.alltoall_f32(config.comm.user, xsend, fwd_send_counts.data(), xrecv, fwd_recv_counts.data(), s) != 0)
       die("alltoall (embedding forward) failed");
   }
@@ -981,33 +1028,12 @@ void FFModel::embedding_group_forward(ffh_stream s) const {
 
 void FFModel::embedding_group_update(ffh_stream s) const {
   if (embeddings.empty()) return;
-  const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(optimizer);
-  const int D = embeddings[0]->out_channels, L = embeddings[0]->inputs[0].adim[0];
-  const int aggr = (int)embeddings[0]->aggr;
-  const int Tr = (int)owned_tables.size();
   if (exchange) {
-    // gradients of the rows go back to the table owners (transposed exchange)
+    // gradients of the rows go back to the owners (transposed exchange)
     if (config.comm.alltoall_f32(config.comm.user, gsend, fwd_recv_counts.data(), grecv, fwd_send_counts.data(), s) != 0)
       die("alltoall (embedding backward) failed");
   }
-  std::vector<ffh_emb_table> tabs;
-  int k = 0;
-  for (int ti : owned_tables) {
-    const Embedding* e = embeddings[ti];
-    ffh_emb_table t;
-    t.idx = (const int64_t*)e->inputs[0].impl->ptr;
-    t.weight = (float*)e->weights[0].impl->ptr;
-    t.num_entries = e->num_entries;
-    if (!exchange) { t.io = e->outputs[0].impl->grad; t.ld = e->outputs[0].impl->grad_ld; }
-    else { t.io = grecv + (int64_t)k * D; t.ld = (int64_t)Tr * D; }
-    tabs.push_back(t);
-    k++;
-  }
-  for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
-    const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
-    check(api->ffh_embedding_bwd_sgd_fused_multi(ctx, tabs.data() + b, n, L, D, config.batchSize, aggr, (float)sgd->lr, s),
-          "embedding_bwd_sgd_fused_multi");
-  }
+  launch_shard_groups(this, false, s);
 }
 
 // =============================================================================================

@@ -24,8 +24,9 @@ def main():
     rank = dist.get_rank()
     comm = TorchComm(on_gpu=False)
     out = {}
-    if mode == "golden":
-        m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True)
+    if mode in ("golden", "column"):
+        m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True,
+                                   column_shard_rows=40 if mode == "column" else 0)
         recs = H.run_steps(m, h, 2)
         for step, rec in enumerate(recs):
             for k, v in rec.items():

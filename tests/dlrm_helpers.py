@@ -19,7 +19,8 @@ def oracle_backend():
     return oracle.ORACLE_LIB
 
 
-def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dense_update=False, g=None, force_exchange=False):
+def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dense_update=False, g=None, force_exchange=False,
+                      column_shard_rows=0):
     """Returns (model, handles) with weights and inputs of the golden fixture loaded.
     With `comm` (world_size > 1) each rank loads its batch slice / its tables."""
     g = g or golden("dlrm_step_torch")
@@ -27,7 +28,10 @@ def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dens
     rows, bot, top = list(g["rows"]), list(g["bot"]), list(g["top"])
     world = comm.world_size if comm is not None else 1
     rank = comm.rank if comm is not None else 0
-    cfg = ffmodel.FFConfig(argv=["-b", str(B)] + (["--force-exchange"] if force_exchange else []), backend=backend, comm=comm)
+    argv = ["-b", str(B)] + (["--force-exchange"] if force_exchange else [])
+    if column_shard_rows:
+        argv += ["--column-shard-rows", str(column_shard_rows)]
+    cfg = ffmodel.FFConfig(argv=argv, backend=backend, comm=comm)
     cfg.set(enable_graph=enable_graph, overlap_embedding=overlap, dense_embedding_update=dense_update)
     m = ffmodel.FFModel(cfg)
     sparse = [m.create_tensor([B, L], ffmodel.DT_INT64) for _ in rows]
@@ -59,7 +63,9 @@ def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dens
         if k.startswith("emb"):
             p = m.parameter(li, 0)
             if p.is_local:
-                p.set_weights(g[f"init/{k}.weight"])
+                w0 = g[f"init/{k}.weight"]
+                cols = p.dims[1]                      # column-sharded giant table: this rank holds D/G columns of every row
+                p.set_weights(w0 if cols == w0.shape[1] else np.ascontiguousarray(w0[:, rank * cols:(rank + 1) * cols]))
         else:
             m.parameter(li, 0).set_weights(g[f"init/{k}.weight"])
             m.parameter(li, 1).set_weights(g[f"init/{k}.bias"])

@@ -166,6 +166,35 @@ def test_two_rank_gloo_run_equals_single_rank(tmp_path):
     np.testing.assert_allclose(z0["s1/top.0.weight"], h["g"]["step1/top.0.weight"], rtol=1e-5, atol=1e-6)
 
 
+def test_two_rank_column_sharded_giant_table(tmp_path):
+    """--column-shard-rows 40: the 50-row table is split column-wise (every rank holds all rows x D/2
+    columns and gathers its slice for the global batch), the others stay table-wise; one all-to-all
+    carries both kinds.  Every rank's slice must equal the same columns of the single-rank table."""
+    _run_ranks(2, tmp_path, "column")
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    B, D = int(h["g"]["B"]), int(h["g"]["D"])
+    rows = list(h["g"]["rows"])
+    big = [t for t, r in enumerate(rows) if r >= 40]
+    assert big == [1]
+    owner_of_small = {}
+    k = 0
+    for r in range(2):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        sl = slice(r * B // 2, (r + 1) * B // 2)
+        np.testing.assert_allclose(z["s1/pred"], ref[1]["pred"][sl], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(z["s1/top.0.weight"], ref[1]["top.0.weight"], rtol=1e-5, atol=1e-6)
+        got = z["s1/emb.1.weight"]
+        assert got.shape == (rows[1], D // 2)
+        np.testing.assert_allclose(got, ref[1]["emb.1.weight"][:, r * D // 2:(r + 1) * D // 2], rtol=1e-6, atol=1e-7)
+        for t in range(len(rows)):
+            if t not in big and f"s1/emb.{t}.weight" in z.files:
+                np.testing.assert_allclose(z[f"s1/emb.{t}.weight"], ref[1][f"emb.{t}.weight"], rtol=1e-6, atol=1e-7)
+                owner_of_small[t] = r
+    assert sorted(owner_of_small) == [0, 2, 3]
+
+
 def test_single_rank_forced_exchange_equals_plain_run(tmp_path):
     """--force-exchange: one rank still goes through the all-to-all / all-reduce callbacks (how the
     collectives are exercised on a 1-GPU box); results equal the plain single-rank run."""
