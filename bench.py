@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-trace", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true", help="1 GPU: still run the all-to-all / all-reduce path (1-rank RCCL group)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,14 +169,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     comm = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from dlrm_flexflow_amd.comm import TorchComm
         comm = TorchComm(on_gpu=True)
 
     w = workload(args.workload, args.per_gpu_batch, world)
-    extra = ["--device", str(local_rank)] + (["--no-trace"] if args.no_trace else [])
+    extra = ["--device", str(local_rank)] + (["--no-trace"] if args.no_trace else []) + (["--force-exchange"] if args.force_exchange else [])
     app = ffmodel.DLRM(flags_of(w, extra), comm=comm.struct if comm else None)
     trace = not args.no_trace
 
@@ -187,6 +191,8 @@ def main():
     app.warmup()                                   # the reference's own warm-up iteration (loads the batch)
     # hipGraph replay (the reference's Legion trace) vs eager launches: keep whichever is faster on this box
     step_us = {}
+    if args.force_exchange:
+        trace = False
     if trace and world == 1:
         step_us["graph"] = app.time_kernel(2, 30) * 1e3
         step_us["eager"] = app.time_kernel(4, 30) * 1e3
@@ -210,14 +216,15 @@ def main():
     T = len(w["rows"].split("-"))
     owned = len([t for t in range(T) if t % world == rank])
     B, D = w["B"], w["D"]
-    t_fwd = app.time_kernel(0, 200) * 1e-3 if world == 1 else None
-    t_bwd = app.time_kernel(1, 100) * 1e-3 if world == 1 else None
-    t_step_dev = app.time_kernel(2 if trace else 4, 100) * 1e-3 if world == 1 else None
+    solo = world == 1 and not args.force_exchange
+    t_fwd = app.time_kernel(0, 200) * 1e-3 if solo else None
+    t_bwd = app.time_kernel(1, 100) * 1e-3 if solo else None
+    t_step_dev = app.time_kernel(2 if trace else 4, 100) * 1e-3 if solo else None
     uses_graph = app.model.uses_graph and trace
     app.close()
 
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -235,7 +242,9 @@ def main():
                    "step_graph": bool(uses_graph), "step_us_graph_vs_eager": {k: round(v, 1) for k, v in step_us.items()}},
         "mse_over_timed_steps": round(2.0 * pm.mse_loss / max(pm.train_all, 1), 6),   # train_all is double-counted (1 class + accuracy), as in the reference
     }
-    if world == 1:
+    if args.force_exchange:
+        out["config"]["parallelism"] = "1 rank, exchange path forced (all-to-all fwd+bwd + all-reduce through the RCCL callbacks)"
+    if solo:
         fwd_bytes = owned * B * (8 + 4 * D + 4 * D)            # 3,536 B/sample at the Kaggle shape
         bwd_bytes = owned * B * (8 + 4 * D + 2 * 4 * D)
         out["roofline"] = {"kernel": "emb_fwd_kernel (embedding gather + bag-sum, all tables in one launch)", "bound": "hbm",
@@ -261,7 +270,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -43,6 +43,9 @@ class TorchComm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.calls = {"alltoall": 0, "allreduce": 0}
+        self._tensors = {}     # (ptr, count) -> zero-copy tensor view; the model's buffers are fixed after compile()
+        self._streams = {}     # hipStream_t -> torch.cuda.ExternalStream
+        self._splits = {}
         self._a2a = ALLTOALL_FN(self._alltoall)
         self._ar = ALLREDUCE_FN(self._allreduce)
         self._bar = BARRIER_FN(self._barrier)
@@ -50,18 +53,30 @@ class TorchComm:
 
     def _stream_ctx(self, stream):
         if self.on_gpu and stream:
-            return torch.cuda.stream(torch.cuda.ExternalStream(stream))
+            ext = self._streams.get(stream)
+            if ext is None:
+                ext = self._streams[stream] = torch.cuda.ExternalStream(stream)
+            return torch.cuda.stream(ext)
         import contextlib
         return contextlib.nullcontext()
 
+    def _view(self, ptr, count):
+        key = (ptr, count)
+        t = self._tensors.get(key)
+        if t is None:
+            t = self._tensors[key] = _as_tensor(ptr, count, self.on_gpu)
+        return t
+
     def _alltoall(self, user, send, send_counts, recv, recv_counts, stream):
         try:
-            sc = [int(send_counts[i]) for i in range(self.world)]
-            rc = [int(recv_counts[i]) for i in range(self.world)]
+            key = (C.addressof(send_counts.contents), C.addressof(recv_counts.contents))
+            sp = self._splits.get(key)
+            if sp is None:
+                sp = self._splits[key] = ([int(send_counts[i]) for i in range(self.world)], [int(recv_counts[i]) for i in range(self.world)])
+            sc, rc = sp
             with self._stream_ctx(stream):
-                inp = _as_tensor(send, sum(sc), self.on_gpu)
-                out = _as_tensor(recv, sum(rc), self.on_gpu)
-                dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
+                dist.all_to_all_single(self._view(recv, sum(rc)), self._view(send, sum(sc)), output_split_sizes=rc, input_split_sizes=sc,
+                                       group=self.group)
             self.calls["alltoall"] += 1
             return 0
         except Exception as e:  # noqa: BLE001  (must not unwind into C++)
@@ -71,8 +86,7 @@ class TorchComm:
     def _allreduce(self, user, buf, count, stream):
         try:
             with self._stream_ctx(stream):
-                t = _as_tensor(buf, int(count), self.on_gpu)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self._view(buf, int(count)), op=dist.ReduceOp.SUM, group=self.group)
             self.calls["allreduce"] += 1
             return 0
         except Exception as e:  # noqa: BLE001

@@ -340,7 +340,7 @@ class FFModel {
   void embedding_group_forward(ffh_stream s) const;
   void embedding_group_update(ffh_stream s) const;
   bool fused_embedding_update() const;
-  mutable bool emb_forward_issued, emb_forward_joined;
+  mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
 
   // slabs
   float *mlp_weights, *mlp_grads;  size_t mlp_count;          // all Linear params, contiguous (one all-reduce, one SGD launch)

@@ -310,7 +310,7 @@ FFModel::FFModel(FFConfig& _config)
     : op_global_guid(100), config(_config), optimizer(nullptr), loss_type(LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE),
       metrics_flags(0), seq_length(-1), api(nullptr), ctx(nullptr), stream(nullptr), side_stream(nullptr),
       ev_fork(nullptr), ev_join(nullptr), ev_grad_ready(nullptr), ev_update_done(nullptr), compiled(false),
-      emb_forward_issued(false), emb_forward_joined(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
+      emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
       act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1) {
   dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; dw_forked = false;
@@ -516,8 +516,17 @@ void Embedding::create_weights(FFModel& model) {
   weights[0] = model.create_weight<2>(dims, this, DT_FLOAT, kernel_initializer);
 }
 void Embedding::forward(const FFModel& ff) {
-  // the whole group was launched at the top of forward() (side stream) or is launched by its first table
-  if (!ff.emb_forward_issued) {
+  // The first table launches the whole group.  With overlap it goes to the side stream, ordered behind the
+  // fork event recorded at the top of forward() (inputs ready): the host has ALREADY enqueued the layers
+  // in front of the tables (the bottom MLP), so the GPU runs those while the host walks the exchange callback.
+  if (ff.emb_forward_issued) return;
+  if (ff.config.overlap_embedding) {
+    ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.side_stream, ff.ev_fork), "fork");
+    ff.embedding_group_forward(ff.side_stream);
+    ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_join, ff.side_stream), "join");
+    ff.emb_forward_issued = true;
+    ff.emb_forward_joined = false;
+  } else {
     ff.embedding_group_forward(ff.stream);
     ff.emb_forward_issued = true;
     ff.emb_forward_joined = true;
@@ -529,10 +538,10 @@ void Embedding::backward(const FFModel& ff) {
   if (table_index != (int)ff.embeddings.size() - 1) return;
   if (ff.fused_embedding_update()) {
     if (ff.config.overlap_embedding) {
+      // gradients of every table are complete here; the side-stream update itself is issued at the END of
+      // backward(), after the host has enqueued the bottom-MLP backward it overlaps with
       ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
-      ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.side_stream, ff.ev_grad_ready), "event");
-      ff.embedding_group_update(ff.side_stream);
-      ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_update_done, ff.side_stream), "event");
+      ff.emb_update_pending = true;
     }
     return;
   }
@@ -1048,14 +1057,8 @@ void FFModel::forward(int _seq_length) {
   if (replaying_trace >= 0) return;
   seq_length = _seq_length;
   emb_forward_issued = emb_forward_joined = false;
-  if (config.overlap_embedding && !embeddings.empty()) {
-    // gather (+ all-to-all) on the side stream while the main stream runs the bottom MLP
-    check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
-    check(api->ffh_stream_wait_event(ctx, side_stream, ev_fork), "fork");
-    embedding_group_forward(side_stream);
-    check(api->ffh_event_record(ctx, ev_join, side_stream), "join");
-    emb_forward_issued = true;
-  }
+  // gather (+ all-to-all) go to the side stream beside the bottom MLP: the fork point is here (inputs ready)
+  if (config.overlap_embedding && !embeddings.empty()) check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
   for (Op* op : layers) op->forward(*this);
   if (emb_forward_issued && !emb_forward_joined) {
     check(api->ffh_stream_wait_event(ctx, stream, ev_join), "join");
@@ -1099,7 +1102,15 @@ void FFModel::backward(int _seq_length) {
   dw_forked = false;
   check(api->ffh_mse_bwd_metrics(ctx, fin.impl->grad, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, d_perf,
                                  local_rows(fin, this), fin.adim[0], scale, metrics_flags, stream), "metrics + loss backward");
+  emb_update_pending = false;
   for (int l = (int)layers.size() - 1; l >= 0; l--) layers[l]->backward(*this);
+  if (emb_update_pending) {
+    // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
+    check(api->ffh_stream_wait_event(ctx, side_stream, ev_grad_ready), "event");
+    embedding_group_update(side_stream);
+    check(api->ffh_event_record(ctx, ev_update_done, side_stream), "event");
+    emb_update_pending = false;
+  }
 }
 
 void FFModel::update() {
