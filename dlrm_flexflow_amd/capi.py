@@ -25,7 +25,7 @@ FFH_OK = 0
 AC_MODE_NONE, AC_MODE_RELU, AC_MODE_SIGMOID, AC_MODE_TANH, AC_MODE_GELU = 10, 11, 12, 13, 14
 AGGR_MODE_NONE, AGGR_MODE_SUM, AGGR_MODE_AVG = 20, 21, 22
 MAX_TABLES = 64
-EMB_CHUNK = 128
+EMB_CHUNK, EMB_CHUNK1 = 32, 1024
 METRIC_ACCURACY, METRIC_MSE, METRIC_RMSE, METRIC_MAE = 1, 2, 4, 8
 
 P = C.c_void_p

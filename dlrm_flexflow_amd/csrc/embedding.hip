@@ -305,7 +305,7 @@ struct RedArgs {
   const uint32_t* pos[2];
   uint8_t   parity[FFH_MAX_TABLES];
   int       tile;           // sorted entries per workgroup: multiple of FFH_EMB_CHUNK, <= kRedTile
-  float*    partial;        // [nt][2*nchunks][D]
+  float*    partial;        // level-0 partial rows [nt][2*nchunks][D] (2 slots per FFH_EMB_CHUNK block)
   uint2*    meta;           // [nt][2*nchunks] {kind, key}
   int64_t   N;
   int       nchunks;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedAr
   __shared__ uint32_t s_pos[kRedTile];
   __shared__ uint16_t s_start[kRedTile + 1];
   __shared__ uint32_t s_cnt[(kRedTile / 64) + 1];
-  __shared__ uint2    s_meta[2 * kRedChunksPerTile];
+  __shared__ uint2    s_meta[2 * kRedChunksPerTile];   // 64 at FFH_EMB_CHUNK = 32
 
   const int tix = blockIdx.y;
   const ffh_emb_table tb = a.t[tix];
@@ -456,9 +456,24 @@ __global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedAr
   }
 }
 
-// step 3: rows whose run crosses chunk boundaries: add the per-chunk partials left to right
+// step 3: fold.  A row whose run crosses block boundaries left one partial per block at level k (slot 2b:
+// the run enters block b from the left; slot 2b+1: the run starts inside block b and leaves it to the
+// right).  One lane-group per starting slot adds the row's consecutive level-k partials left to right,
+// stopping at the boundary of the enclosing level-(k+1) block (`ratio` level-k blocks; 0 = no boundary,
+// last level).  A run that is now complete is applied to the table; otherwise its level-(k+1) partial
+// is written with the same two-slots-per-block convention.  Chains are <= ratio steps long.
+struct FoldArgs {
+  ffh_emb_table t[FFH_MAX_TABLES];
+  const float* pin;   // [nt][2*nin][D]
+  const uint2* min;   // [nt][2*nin]
+  float*       pout;  // [nt][2*nout][D]
+  uint2*       mout;  // [nt][2*nout]   (pre-zeroed = kMetaNone)
+  int nin, nout, ratio, D;
+  float lr;
+};
+
 template <int VEC>
-__global__ __launch_bounds__(256) void emb_sgd_combine_kernel(const RedArgs a) {
+__global__ __launch_bounds__(256) void emb_sgd_fold_kernel(const FoldArgs a) {
   const int tix = blockIdx.y;
   const ffh_emb_table tb = a.t[tix];
   const int D = a.D;
@@ -469,32 +484,65 @@ __global__ __launch_bounds__(256) void emb_sgd_combine_kernel(const RedArgs a) {
   const int rsub = lane / lpr;
   const int c0 = lane - rsub * lpr;
   if (rsub >= rpw) return;
-  const int64_t nslots = 2 * (int64_t)a.nchunks;
-  const uint2* meta = a.meta + (int64_t)tix * nslots;
-  const float* part = a.partial + (int64_t)tix * nslots * D;
+  const int64_t nslots = 2 * (int64_t)a.nin;
+  const uint2* meta = a.min + (int64_t)tix * nslots;
+  const float* part = a.pin + (int64_t)tix * nslots * D;
   const int64_t groups = (int64_t)gridDim.x * (blockDim.x >> 6) * rpw;
   for (int64_t slot = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * rpw + rsub; slot < nslots; slot += groups) {
     const uint2 m = meta[slot];
-    if (m.x != kMetaFirst) continue;
+    if (m.x == kMetaNone) continue;
+    const int64_t b = slot >> 1;
+    const bool at_block_start = a.ratio > 0 && (b % a.ratio == 0) && ((slot & 1) == 0);
+    if (!(m.x == kMetaFirst || (m.x == kMetaCont && at_block_start))) continue;   // consumed by the walk that starts left of it
+    const int64_t B = a.ratio > 0 ? b / a.ratio : 0;
+    int64_t bend = a.ratio > 0 ? (B + 1) * (int64_t)a.ratio : (int64_t)a.nin;
+    if (bend > a.nin) bend = a.nin;
+    // length of the walk (same for every column chunk)
+    int64_t b2 = b + 1;
+    while (b2 < bend) {
+      const uint2 m2 = meta[2 * b2];
+      if (m2.x != kMetaCont || m2.y != m.y) break;
+      b2++;
+    }
+    bool cont_after = false;
+    if (b2 == bend && bend < a.nin) { const uint2 m3 = meta[2 * bend]; cont_after = (m3.x == kMetaCont && m3.y == m.y); }
+    const bool head = m.x == kMetaFirst;
+    const bool complete = head && !cont_after;
+    const int64_t oslot = 2 * B + (at_block_start ? 0 : 1);
+    if (!complete && c0 == 0) a.mout[(int64_t)tix * 2 * a.nout + oslot] = make_uint2(head ? kMetaFirst : kMetaCont, m.y);
     float* wrow = tb.weight + (int64_t)m.y * D;
+    float* orow = a.pout + ((int64_t)tix * 2 * a.nout + oslot) * D;
     for (int c = c0; c < nvec; c += lpr) {
       float acc[VEC];
       load_grad<VEC>(acc, part + slot * D, c, 1.0f, false);
-      for (int64_t s2 = (slot / 2 + 1) * 2; s2 < nslots; s2 += 2) {
-        const uint2 m2 = meta[s2];
-        if (m2.x != kMetaCont || m2.y != m.y) break;
+      int64_t q = b + 1;
+      for (; q + 4 <= b2; q += 4) {   // four partial rows in flight, added in order
+        float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+        load_grad<VEC>(v0, part + 2 * q * D, c, 1.0f, false);
+        load_grad<VEC>(v1, part + 2 * (q + 1) * D, c, 1.0f, false);
+        load_grad<VEC>(v2, part + 2 * (q + 2) * D, c, 1.0f, false);
+        load_grad<VEC>(v3, part + 2 * (q + 3) * D, c, 1.0f, false);
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[v] = (((acc[v] + v0[v]) + v1[v]) + v2[v]) + v3[v];
+      }
+      for (; q < b2; q++) {
         float v0[VEC];
-        load_grad<VEC>(v0, part + s2 * D, c, 1.0f, false);
+        load_grad<VEC>(v0, part + 2 * q * D, c, 1.0f, false);
 #pragma unroll
         for (int v = 0; v < VEC; v++) acc[v] = acc[v] + v0[v];
       }
-      if (VEC == 4) {
-        float4 w = reinterpret_cast<float4*>(wrow)[c];
-        w.x = __fmaf_rn(-a.lr, acc[0], w.x); w.y = __fmaf_rn(-a.lr, acc[1], w.y);
-        w.z = __fmaf_rn(-a.lr, acc[2], w.z); w.w = __fmaf_rn(-a.lr, acc[3], w.w);
-        reinterpret_cast<float4*>(wrow)[c] = w;
+      if (complete) {
+        if (VEC == 4) {
+          float4 w = reinterpret_cast<float4*>(wrow)[c];
+          w.x = __fmaf_rn(-a.lr, acc[0], w.x); w.y = __fmaf_rn(-a.lr, acc[1], w.y);
+          w.z = __fmaf_rn(-a.lr, acc[2], w.z); w.w = __fmaf_rn(-a.lr, acc[3], w.w);
+          reinterpret_cast<float4*>(wrow)[c] = w;
+        } else {
+          wrow[c] = __fmaf_rn(-a.lr, acc[0], wrow[c]);
+        }
       } else {
-        wrow[c] = __fmaf_rn(-a.lr, acc[0], wrow[c]);
+        if (VEC == 4) reinterpret_cast<float4*>(orow)[c] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else orow[c] = acc[0];
       }
     }
   }
@@ -505,8 +553,8 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct BwdLayout {
-  size_t keys_a, pos_a, keys_b, pos_b, hist, partial, meta, total;
-  int nblk, nchunks;
+  size_t keys_a, pos_a, keys_b, pos_b, hist, partial, meta, partial1, meta1, total;
+  int nblk, nchunks, nchunks1;
 };
 
 // entries per thread of the sort kernels: enough workgroups to cover the chip, tiles as large as that allows
@@ -520,7 +568,7 @@ inline int sort_per_thread(int nt, int64_t N) {
 }
 inline int reduce_tile(int nt, int64_t N) {
   const int64_t want = N * nt / 1024;
-  int t = FFH_EMB_CHUNK;
+  int t = 128;
   while (t * 2 <= want && t < kRedTile) t *= 2;
   return t;
 }
@@ -540,6 +588,9 @@ inline BwdLayout bwd_layout(int nt, int L, int D, int64_t batch) {
   l.hist = o; o += align_up((size_t)nt * (size_t)l.nblk * kMaxRadix * sizeof(uint32_t), 256);
   l.partial = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks * (size_t)D * sizeof(float), 256);
   l.meta = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks * sizeof(uint2), 256);
+  l.nchunks1 = (int)((N + FFH_EMB_CHUNK1 - 1) / FFH_EMB_CHUNK1);
+  l.partial1 = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks1 * (size_t)D * sizeof(float), 256);
+  l.meta1 = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks1 * sizeof(uint2), 256);
   l.total = o;
   return l;
 }
@@ -687,14 +738,28 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
   ra.lr = lr;
   dim3 rgrid((unsigned)((N + ra.tile - 1) / ra.tile), (unsigned)nt);
   const int lpr = nvec < 64 ? nvec : 64;
-  const int64_t cgroups = 2LL * lay.nchunks;
-  dim3 cgrid((unsigned)ffh_grid(cgroups, 4 * (64 / lpr), 1024), (unsigned)nt);
-  if (v4) {
-    hipLaunchKernelGGL((emb_sgd_reduce_kernel<4>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
-    hipLaunchKernelGGL((emb_sgd_combine_kernel<4>), cgrid, dim3(256), 0, as_stream(s), ra);
+  if (v4) hipLaunchKernelGGL((emb_sgd_reduce_kernel<4>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
+  else hipLaunchKernelGGL((emb_sgd_reduce_kernel<1>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
+  // folds: 32-block partials -> 1024-block partials -> row totals (the second level only exists for N > 1024)
+  FoldArgs fa;
+  memset(&fa, 0, sizeof fa);
+  for (int i = 0; i < nt; i++) fa.t[i] = tables[i];
+  fa.D = D; fa.lr = lr;
+  const int groups_per_block = 4 * (64 / lpr);
+  auto launch_fold = [&](const float* pin, const uint2* min, int nin, float* pout, uint2* mout, int nout, int ratio) {
+    fa.pin = pin; fa.min = min; fa.nin = nin; fa.pout = pout; fa.mout = mout; fa.nout = nout; fa.ratio = ratio;
+    dim3 fgrid((unsigned)ffh_grid(2LL * nin, groups_per_block, 1024), (unsigned)nt);
+    if (v4) hipLaunchKernelGGL((emb_sgd_fold_kernel<4>), fgrid, dim3(256), 0, as_stream(s), fa);
+    else hipLaunchKernelGGL((emb_sgd_fold_kernel<1>), fgrid, dim3(256), 0, as_stream(s), fa);
+  };
+  float* p1 = (float*)(ws + lay.partial1);
+  uint2* m1 = (uint2*)(ws + lay.meta1);
+  if (lay.nchunks1 > 1) {
+    FFH_HIP_TRY(c, hipMemsetAsync(m1, 0, (size_t)nt * 2 * lay.nchunks1 * sizeof(uint2), as_stream(s)));
+    launch_fold(ra.partial, ra.meta, lay.nchunks, p1, m1, lay.nchunks1, FFH_EMB_CHUNK1 / FFH_EMB_CHUNK);
+    launch_fold(p1, m1, lay.nchunks1, p1, m1, 1, 0);
   } else {
-    hipLaunchKernelGGL((emb_sgd_reduce_kernel<1>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
-    hipLaunchKernelGGL((emb_sgd_combine_kernel<1>), cgrid, dim3(256), 0, as_stream(s), ra);
+    launch_fold(ra.partial, ra.meta, lay.nchunks, p1, m1, 1, 0);
   }
   FFH_LAUNCH_CHECK(c, "emb_sgd_reduce/combine");
   return FFH_OK;

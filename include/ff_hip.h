@@ -71,9 +71,10 @@ extern "C" {
 /* limits */
 #define FFH_MAX_TABLES        64   /* tables per batched embedding launch        */
 #define FFH_MAX_CONCAT_INPUTS 256  /* [ref: include/config.h:30-37 MAX_NUM_INPUTS] */
-/* chunk length of the canonical summation order of the fused
+/* block lengths of the canonical (two-level) summation order of the fused
  * embedding backward + SGD (see ffh_embedding_bwd_sgd_fused) */
-#define FFH_EMB_CHUNK         128
+#define FFH_EMB_CHUNK         32
+#define FFH_EMB_CHUNK1        1024
 
 typedef struct ffh_ctx ffh_ctx;   /* opaque; mirrors FFHandler [ref: include/config.h:75-84] */
 typedef void* ffh_stream;         /* hipStream_t */
@@ -192,11 +193,12 @@ int ffh_embedding_bwd_dense(ffh_ctx* ctx, const int64_t* idx, const float* out_g
  *   sgd_update (momentum 0, weight_decay 0) [ref: src/runtime/optimizer_kernel.cu:23-41]
  * on one table, without the dense gradient:
  *   weight[r][:] -= lr * sum_{(b,j): idx[b][j]==r} out_grad[b][:]      (rows not hit: untouched)
- * Canonical (deterministic) summation order: contributions of a row sorted by position
- * p = b*in_dim+j ascending; the table's sorted (row,p) list is cut at multiples of
- * FFH_EMB_CHUNK; inside a chunk the row's contributions are added left to right in fp32;
- * a row whose run crosses chunk boundaries adds its per-chunk partial sums left to right;
- * then one `w = w - lr*sum` (fp32 multiply, fp32 subtract).
+ * Canonical (deterministic) summation order, chosen so that a hot row is summed by many lane-groups
+ * at once yet the result never depends on the launch geometry: the table's contributions are sorted
+ * by (row, position p = b*in_dim+j); the sorted list is cut at multiples of FFH_EMB_CHUNK (32) and of
+ * FFH_EMB_CHUNK1 (1024).  Inside a 32-block the row's contributions are added left to right in fp32;
+ * the 32-block partials of a row inside one 1024-block are added left to right; the 1024-block
+ * partials of the row are added left to right; then one `w = fmaf(-lr, sum, w)`.
  * Needs ffh_embedding_bwd_workspace_bytes() of workspace attached to the ctx. */
 int ffh_embedding_bwd_sgd_fused(ffh_ctx* ctx, const int64_t* idx, const float* out_grad, float* weight,
                                 int in_dim, int out_dim, int64_t batch, int64_t num_entries,

@@ -239,10 +239,11 @@ int ffh_embedding_bwd_sgd_fused(ffh_ctx* c, const int64_t* idx, const float* g, 
   if (N == 0) return FFH_OK;
   rp_t* v = (rp_t*)malloc(sizeof(rp_t) * (size_t)N);
   float* part = (float*)malloc(sizeof(float) * (size_t)D);
+  float* mid = (float*)malloc(sizeof(float) * (size_t)D);
   float* tot = (float*)malloc(sizeof(float) * (size_t)D);
-  if (!v || !part || !tot) { free(v); free(part); free(tot); return fail(c, FFH_ERR_NOMEM, "oom"); }
+  if (!v || !part || !mid || !tot) { free(v); free(part); free(mid); free(tot); return fail(c, FFH_ERR_NOMEM, "oom"); }
   for (int64_t p = 0; p < N; p++) {
-    if (idx[p] < 0 || idx[p] >= R) { free(v); free(part); free(tot); return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_sgd_fused: index out of range"); }
+    if (idx[p] < 0 || idx[p] >= R) { free(v); free(part); free(mid); free(tot); return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_sgd_fused: index out of range"); }
     v[p].row = idx[p]; v[p].pos = p;
   }
   qsort(v, (size_t)N, sizeof(rp_t), rp_cmp);
@@ -252,29 +253,38 @@ int ffh_embedding_bwd_sgd_fused(ffh_ctx* c, const int64_t* idx, const float* g, 
     const int64_t row = v[i].row;
     int64_t e = i;
     while (e < N && v[e].row == row) e++;
-    /* sub-runs: [i,e) cut at multiples of FFH_EMB_CHUNK */
-    int first_part = 1;
-    int64_t a = i;
-    while (a < e) {
-      int64_t z = (a / FFH_EMB_CHUNK + 1) * FFH_EMB_CHUNK;
-      if (z > e) z = e;
-      for (int64_t q = a; q < z; q++) {
-        const float* gr = g + (v[q].pos / L) * gld;
-        for (int d = 0; d < D; d++) {
-          float x = gr[d];
-          if (aggr == FFH_AGGR_MODE_AVG) x = x / (float)L;
-          part[d] = (q == a) ? x : part[d] + x;
+    /* two-level canonical order: 32-blocks inside 1024-blocks, left-to-right folds at every level */
+    int first_big = 1;
+    int64_t a1 = i;
+    while (a1 < e) {
+      int64_t z1 = (a1 / FFH_EMB_CHUNK1 + 1) * FFH_EMB_CHUNK1;
+      if (z1 > e) z1 = e;
+      int first_small = 1;
+      int64_t a = a1;
+      while (a < z1) {
+        int64_t z = (a / FFH_EMB_CHUNK + 1) * FFH_EMB_CHUNK;
+        if (z > z1) z = z1;
+        for (int64_t q = a; q < z; q++) {
+          const float* gr = g + (v[q].pos / L) * gld;
+          for (int d = 0; d < D; d++) {
+            float x = gr[d];
+            if (aggr == FFH_AGGR_MODE_AVG) x = x / (float)L;
+            part[d] = (q == a) ? x : part[d] + x;
+          }
         }
+        for (int d = 0; d < D; d++) mid[d] = first_small ? part[d] : mid[d] + part[d];
+        first_small = 0;
+        a = z;
       }
-      for (int d = 0; d < D; d++) tot[d] = first_part ? part[d] : tot[d] + part[d];
-      first_part = 0;
-      a = z;
+      for (int d = 0; d < D; d++) tot[d] = first_big ? mid[d] : tot[d] + mid[d];
+      first_big = 0;
+      a1 = z1;
     }
     float* wr = w + row * (int64_t)D;
     for (int d = 0; d < D; d++) wr[d] = fmaf(-lr, tot[d], wr[d]);
     i = e;
   }
-  free(v); free(part); free(tot);
+  free(v); free(part); free(mid); free(tot);
   return FFH_OK;
 }
 

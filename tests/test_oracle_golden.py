@@ -111,23 +111,44 @@ def test_embedding_fused_vs_float64_and_dense_path(oracle, R, B, L):
     assert fused[once].tobytes() == three_step[once].tobytes()
 
 
-def test_embedding_fused_canonical_order_is_chunked(oracle):
-    """The documented canonical order: per-chunk left-to-right partial sums, partials added
-    left to right.  Re-derive it in numpy for a single hot row spanning several chunks."""
+def test_embedding_fused_canonical_order_is_two_level(oracle):
+    """The documented canonical order: left-to-right sums inside 32-blocks, 32-block partials added
+    left to right inside 1024-blocks, 1024-block partials added left to right.  Re-derived in numpy
+    for one hot row spanning several 1024-blocks, with a second row shifting the block alignment."""
     rng = np.random.default_rng(7)
-    B, D, lr = 5 * capi.EMB_CHUNK + 17, 4, 0.5
-    idx = np.zeros((B, 1), np.int64)
+    n_hot, n_other = 2 * capi.EMB_CHUNK1 + 5 * capi.EMB_CHUNK + 17, 11
+    D, lr = 4, 0.5
+    idx = np.concatenate([np.zeros(n_other, np.int64), np.ones(n_hot, np.int64)]).reshape(-1, 1)   # row 0 first: row 1's run starts at sorted position 11
+    B = idx.shape[0]
     g = rng.uniform(-1, 1, (B, D)).astype(np.float32)
-    w = rng.uniform(-1, 1, (1, D)).astype(np.float32)
+    w = rng.uniform(-1, 1, (2, D)).astype(np.float32)
     got = oracle.embedding_bwd_sgd_fused(idx, g, w, lr)
-    tot = None
-    for a in range(0, B, capi.EMB_CHUNK):
-        part = g[a].copy()
-        for q in range(a + 1, min(a + capi.EMB_CHUNK, B)):
-            part = (part + g[q]).astype(np.float32)
-        tot = part if tot is None else (tot + part).astype(np.float32)
-    exp = np.array([np.float32(np.float64(w[0, d]) + np.float64(np.float32(-lr)) * np.float64(tot[d])) for d in range(D)], np.float32)
-    assert got[0].tobytes() == exp.tobytes()
+
+    def fold(parts):
+        acc = parts[0]
+        for p in parts[1:]:
+            acc = (acc + p).astype(np.float32)
+        return acc
+
+    def canonical(lo, hi):          # sorted positions [lo, hi) of one row; sorted order == batch order here
+        bigs = []
+        a1 = lo
+        while a1 < hi:
+            z1 = min((a1 // capi.EMB_CHUNK1 + 1) * capi.EMB_CHUNK1, hi)
+            smalls = []
+            a = a1
+            while a < z1:
+                z = min((a // capi.EMB_CHUNK + 1) * capi.EMB_CHUNK, z1)
+                smalls.append(fold([g[q] for q in range(a, z)]))
+                a = z
+            bigs.append(fold(smalls))
+            a1 = z1
+        return fold(bigs)
+
+    for row, (lo, hi) in enumerate(((0, n_other), (n_other, B))):
+        tot = canonical(lo, hi)
+        exp = np.array([np.float32(np.float64(w[row, d]) + np.float64(np.float32(-lr)) * np.float64(tot[d])) for d in range(D)], np.float32)
+        assert got[row].tobytes() == exp.tobytes()
 
 
 # ---------------------------------------------------------------------------
