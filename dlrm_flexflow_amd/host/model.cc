@@ -541,7 +541,13 @@ void Embedding::backward(const FFModel& ff) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
       // backward(), after the host has enqueued the bottom-MLP backward it overlaps with
       ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
-      ff.emb_update_pending = true;
+      if (ff.exchange) {
+        ff.emb_update_pending = true;      // host-side collectives: issue after the bottom-MLP backward is enqueued
+      } else {
+        ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.side_stream, ff.ev_grad_ready), "event");
+        ff.embedding_group_update(ff.side_stream);
+        ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_update_done, ff.side_stream), "event");
+      }
     }
     return;
   }
@@ -1058,7 +1064,15 @@ void FFModel::forward(int _seq_length) {
   seq_length = _seq_length;
   emb_forward_issued = emb_forward_joined = false;
   // gather (+ all-to-all) go to the side stream beside the bottom MLP: the fork point is here (inputs ready)
-  if (config.overlap_embedding && !embeddings.empty()) check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
+  if (config.overlap_embedding && !embeddings.empty()) {
+    check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
+    if (!exchange) {   // no host-side collective in the way: start the gather right now
+      check(api->ffh_stream_wait_event(ctx, side_stream, ev_fork), "fork");
+      embedding_group_forward(side_stream);
+      check(api->ffh_event_record(ctx, ev_join, side_stream), "join");
+      emb_forward_issued = true;
+    }
+  }
   for (Op* op : layers) op->forward(*this);
   if (emb_forward_issued && !emb_forward_joined) {
     check(api->ffh_stream_wait_event(ctx, stream, ev_join), "join");
