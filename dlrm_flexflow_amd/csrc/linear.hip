@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   const bool a_vec = (AKC ? (g.sAm % 4 == 0) : (g.sAk % 4 == 0)) && (((uintptr_t)A & 15) == 0);
   const bool b_vec = (BKC ? (g.sBn % 4 == 0) : (g.sBk % 4 == 0)) && (((uintptr_t)B & 15) == 0);
 
-  float4 ra[NA], rb[NB];
+  float4 ra2[2][NA], rb2[2][NB];     // two tiles in flight in registers (set = stage parity)
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool y_vec = FUSE_DY && (g.ld_act_y % 4 == 0) && (((uintptr_t)g.act_y & 15) == 0);
 
@@ -132,8 +132,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   // predicates, plain global_load_dwordx4.  The choice is workgroup-uniform.
   const int nfull = (a_in && b_in && (!FUSE_DY || y_vec)) ? (ke - kb) / BK : 0;
 
-  auto load_tile_t = [&](int kt, auto fast_tag) {
+  auto load_tile_t = [&](int kt, auto fast_tag, auto set_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
+    float4 (&ra)[NA] = ra2[decltype(set_tag)::value];
+    float4 (&rb)[NB] = rb2[decltype(set_tag)::value];
     const int k0 = kb + kt * BK;
 #pragma unroll
     for (int i = 0; i < NA; i++) {
@@ -198,7 +200,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
   };
 
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, auto set_tag) {
+    float4 (&ra)[NA] = ra2[decltype(set_tag)::value];
+    float4 (&rb)[NB] = rb2[decltype(set_tag)::value];
     float* as = As[buf];
     float* bs = Bs[buf];
 #pragma unroll
@@ -270,25 +274,53 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     }
   };
 
-  // phase 1: interior k-tiles, software-pipelined (tile t+1 in flight in registers while tile t
-  // feeds the MFMAs), one barrier per tile, unguarded loads only -- a separate loop so that no
-  // control-flow merge forces the compiler to drain vmcnt early
-  if (nfull > 0) {
-    load_tile_t(0, std::true_type{});
-    store_tile(0);
+  // phase 1: software pipeline over "stages": the interior k-tiles, preceded by the single K-tail tile when
+  // there is exactly one (K = 432: 6 full tiles + 48).  TWO stages are in flight in registers while the
+  // MFMAs run on a third in LDS: one k-tile of MFMA work (0.2-0.4 us) is far shorter than an L2/HBM round
+  // trip under load, so a single prefetched tile leaves the matrix pipe waiting.  Only stage 0 may take the
+  // guarded loader; the loop body has unguarded loads only, so no control-flow merge drains vmcnt early.
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  const int tail_first = (nfull > 0 && nk == nfull + 1) ? 1 : 0;
+  const int nstages = nfull > 0 ? nfull + tail_first : 0;
+  if (nstages > 0) {
+    if (tail_first) load_tile_t(nk - 1, std::false_type{}, S0{});
+    else load_tile_t(0, std::true_type{}, S0{});
+    if (nstages > 1) load_tile_t(1 - tail_first, std::true_type{}, S1{});
+    store_tile(0, S0{});
     __syncthreads();
-    for (int kt = 0; kt < nfull; kt++) {
-      const int buf = kt & 1;
-      if (kt + 1 < nfull) load_tile_t(kt + 1, std::true_type{});
-      compute_tile(buf);
-      if (kt + 1 < nfull) store_tile(buf ^ 1);
+    int i = 0;
+    // steady state, branch-free: both prefetches exist (straight-line code keeps the accumulators in AGPRs and
+    // lets the scheduler place the LDS stores of stage i+1 behind the MFMAs of stage i)
+    for (; i + 3 < nstages; i += 2) {
+      load_tile_t(i + 2 - tail_first, std::true_type{}, S0{});
+      compute_tile(0);
+      store_tile(1, S1{});
+      __syncthreads();
+      load_tile_t(i + 3 - tail_first, std::true_type{}, S1{});
+      compute_tile(1);
+      store_tile(0, S0{});
+      __syncthreads();
+    }
+    // drain: the last (up to three) stages
+    for (; i < nstages; i += 2) {
+      // even stage: LDS buffer 0 holds stage i, register set 1 holds stage i+1
+      if (i + 2 < nstages) load_tile_t(i + 2 - tail_first, std::true_type{}, S0{});
+      compute_tile(0);
+      if (i + 1 < nstages) store_tile(1, S1{});
+      __syncthreads();
+      if (i + 1 >= nstages) break;
+      // odd stage: LDS buffer 1 holds stage i+1, register set 0 holds stage i+2
+      if (i + 3 < nstages) load_tile_t(i + 3 - tail_first, std::true_type{}, S1{});
+      compute_tile(1);
+      if (i + 2 < nstages) store_tile(0, S0{});
       __syncthreads();
     }
   }
-  // phase 2: edge tiles (K tail, ragged M/N, unaligned operands): guarded loads, not pipelined
-  for (int kt = nfull; kt < nk; kt++) {
-    load_tile_t(kt, std::false_type{});
-    store_tile(0);
+  // phase 2: the remaining edge tiles (ragged M/N, unaligned operands, more than one partial k-tile): guarded, not pipelined
+  for (int kt = nfull; kt < nk - tail_first; kt++) {
+    load_tile_t(kt, std::false_type{}, S0{});
+    store_tile(0, S0{});
     __syncthreads();
     compute_tile(0);
     __syncthreads();
@@ -507,7 +539,10 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   // 1. sigmoid: its gradient is not idempotent, so it gets its own in-place pass (with the bias sums).
   //    relu / none: folded into the GEMMs' operand loads below (no separate pass over dy).
   const bool separate = act == FFH_AC_MODE_SIGMOID;
-  if (separate) {
+  const bool do_dw = !(flags & FFH_LINEAR_ONLY_DX);
+  const bool do_dx = !(flags & FFH_LINEAR_ONLY_DW);
+  FFH_REQUIRE(c, do_dw || do_dx, "linear_bwd_ex: ONLY_DX and ONLY_DW are exclusive");
+  if (separate && do_dx) {
     const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
     const int cols_v = v4 ? out / 4 : out;
     int tx = 1;
@@ -521,7 +556,7 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     FFH_LAUNCH_CHECK(c, "act_bwd_bias_kernel");
   }
   // the weight-gradient GEMM may go to its own stream: it only needs dy (and y, x), which are ready on s now
-  const bool forked = s_dw != nullptr && s_dw != s;
+  const bool forked = do_dw && do_dx && s_dw != nullptr && s_dw != s;
   ffh_stream sw = forked ? s_dw : s;
   if (forked) {
     if (!c->ev_fork) FFH_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -531,7 +566,7 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   const bool relu = act == FFH_AC_MODE_RELU;
   // 2. dw[o][i] += sum_b dy[b][o] x[b][i]   (split-K over the batch, fp32 atomics); relu' mask applied on load and
   //    written back to dy in place, db = column sums of the same tiles
-  {
+  if (do_dw) {
     GemmArgs g{};
     g.A = dy; g.sAm = 1; g.sAk = lddy;
     g.B = x; g.sBn = 1; g.sBk = ldx;
@@ -545,7 +580,7 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   }
   // 3. dx[b][i] (+)= sum_o dy[b][o] w[o][i].  Unforked it runs behind the dw GEMM and reads the masked dy;
   //    forked it masks dy itself while loading (idempotent, so the concurrent in-place write-back is harmless)
-  if (dx) {
+  if (dx && do_dx) {
     GemmArgs g{};
     g.A = dy; g.sAm = lddy; g.sAk = 1;
     g.B = w; g.sBn = 1; g.sBk = in;
@@ -554,7 +589,7 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     g.epi = (flags & FFH_LINEAR_DX_OVERWRITE) ? EPI_STORE : EPI_ADD;
     g.act = FFH_AC_MODE_NONE;
     int rc;
-    if (forked && relu) {
+    if ((forked || !do_dw) && relu) {
       g.act_y = y; g.ld_act_y = ldy; g.fuse = 1;
       rc = launch_gemm<true, false, true>(c, g, 1, s, "linear_bwd dx gemm (masking)");
     } else {

@@ -15,8 +15,12 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <condition_variable>
+#include <deque>
 #include <functional>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -75,6 +79,7 @@ class FFConfig {
   bool overlap_embedding;      // embedding gather (+exchange) on a side stream beside the bottom MLP
   bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
   int64_t column_shard_rows;   // tables with at least this many rows are sharded column-wise over the ranks (0: never)
+  bool async_launch;           // auxiliary streams are fed by their own host threads (HIP backend only)
   bool parallel_dw;            // weight-gradient GEMMs on their own stream beside the data-gradient chain
   bool force_exchange;         // run the all-to-all / all-reduce path even with one rank (tests the collectives on 1 GPU)
   ffcomm comm;                 // rank / world_size / collectives supplied by the launcher (ffcomm.h)
@@ -215,6 +220,7 @@ class Op {
   Tensor outputs[1];
   Parameter weights[2];
   int numInputs, numWeights, numOutputs;
+  int layer_index;              // position in FFModel::layers
   bool profiling;
 };
 
@@ -267,6 +273,32 @@ class BatchMatmul : public Op {
   void forward(const FFModel&) override;
   void backward(const FFModel&) override;
   int a_seq_length_dim, b_seq_length_dim;
+};
+
+// ---------------------------------------------------------------------------------------------
+// A host thread that issues the launches of one auxiliary HIP stream.  The training step is bound by
+// the host's launch rate (~7 us per launch, ~35 launches per Kaggle step); the weight-gradient GEMMs
+// and the embedding side stream are therefore enqueued by their own threads while the main thread
+// walks the critical path.  Ordering between streams is by HIP events; the only host-side rule is
+// that a thread may wait on an event only after the recording thread has issued the record, which
+// `drain()` provides at the few join points.  (What Legion's utility processors do for the reference.)
+class LaunchWorker {
+ public:
+  LaunchWorker(const KernelApi* api, int device);
+  ~LaunchWorker();
+  void post(std::function<void(ffh_ctx*)> fn);
+  void drain();
+  ffh_ctx* ctx() const { return wctx; }
+ private:
+  void run();
+  const KernelApi* api;
+  int device;
+  ffh_ctx* wctx;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv, cv_idle;
+  std::deque<std::function<void(ffh_ctx*)>> q;
+  bool stop, busy;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -326,6 +358,9 @@ class FFModel {
   ffh_event ev_dw_done;
   bool need_zero_act_grads;    // some activation gradient is accumulated by more than one producer
   mutable bool dw_forked;
+  LaunchWorker *dw_worker, *side_worker;   // NULL: launches are issued inline by the calling thread
+  std::vector<ffh_event> layer_events;     // one per layer: "dY of this layer is ready"
+  bool use_workers() const { return dw_worker != nullptr && capturing_trace < 0; }
   ffh_event ev_fork, ev_join, ev_grad_ready, ev_update_done;
   int rank, world_size;
   bool exchange;               // table-wise exchange + gradient all-reduce active (world_size > 1)
@@ -337,9 +372,12 @@ class FFModel {
 
   // embedding group (all Embedding ops share L, D, aggr in DLRM): batched launches + exchange
   std::vector<Embedding*> embeddings;
-  void embedding_group_forward(ffh_stream s) const;
-  void embedding_group_update(ffh_stream s) const;
+  void embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx = nullptr) const;   // on_ctx: the issuing thread's ctx
+  void embedding_group_update(ffh_stream s, ffh_ctx* on_ctx = nullptr) const;
   bool fused_embedding_update() const;
+  void issue_embedding_forward_on_side_stream() const;
+  void join_embedding_forward() const;
+  void issue_embedding_update_on_side_stream() const;
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
 
   // slabs

@@ -46,6 +46,60 @@ size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 }  // namespace
 
 // =============================================================================================
+// LaunchWorker
+// =============================================================================================
+LaunchWorker::LaunchWorker(const KernelApi* _api, int _device) : api(_api), device(_device), wctx(nullptr), stop(false), busy(false) {
+  th = std::thread([this] { run(); });
+  drain();   // the ctx exists once the first (empty) round trip is over
+}
+LaunchWorker::~LaunchWorker() {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    stop = true;
+  }
+  cv.notify_all();
+  if (th.joinable()) th.join();
+  if (wctx) api->ffh_ctx_destroy(wctx);
+}
+void LaunchWorker::run() {
+  {
+    ffh_ctx* c = nullptr;
+    if (api->ffh_ctx_create(&c, device) != FFH_OK) die("launch worker: ffh_ctx_create(device %d) failed", device);   // also binds the thread to the device
+    std::lock_guard<std::mutex> lk(mu);
+    wctx = c;
+  }
+  cv_idle.notify_all();
+  for (;;) {
+    std::function<void(ffh_ctx*)> fn;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [this] { return stop || !q.empty(); });
+      if (q.empty()) { if (stop) return; continue; }
+      fn = std::move(q.front());
+      q.pop_front();
+      busy = true;
+    }
+    fn(wctx);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      busy = false;
+    }
+    cv_idle.notify_all();
+  }
+}
+void LaunchWorker::post(std::function<void(ffh_ctx*)> fn) {
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    q.push_back(std::move(fn));
+  }
+  cv.notify_one();
+}
+void LaunchWorker::drain() {
+  std::unique_lock<std::mutex> lk(mu);
+  cv_idle.wait(lk, [this] { return q.empty() && !busy && wctx != nullptr; });
+}
+
+// =============================================================================================
 // FFConfig  [ref: src/runtime/model.cc:2211-2403]
 // =============================================================================================
 FFConfig::FFConfig() {
@@ -69,6 +123,7 @@ FFConfig::FFConfig() {
   dense_embedding_update = false;
   force_exchange = false;
   parallel_dw = true;
+  async_launch = false;   // measured on MI355X / ROCm 7.2: no gain over one issuing thread (280 vs 272 us per Kaggle step)
   column_shard_rows = 0;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
@@ -111,6 +166,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--dense-embedding-update")) { dense_embedding_update = true; continue; }
     if (is("--force-exchange")) { force_exchange = true; continue; }
     if (is("--serial-dw")) { parallel_dw = false; continue; }
+    if (is("--inline-launch")) { async_launch = false; continue; }
+    if (is("--async-launch")) { async_launch = true; continue; }
     if (is("--column-shard-rows")) { column_shard_rows = atoll(next()); continue; }
   }
 }
@@ -165,6 +222,8 @@ bool copy_out(const FFModel* model, const Tensor& t, const void* base, int64_t l
   if (!base) die("get_tensor before compile() (or tensor has no gradient)");
   const int64_t cols_ = t.adim[0];
   const int64_t nrows = local_rows(t, model);
+  if (model->dw_worker) model->dw_worker->drain();
+  if (model->side_worker) model->side_worker->drain();
   model->check(model->api->ffh_stream_sync(model->ctx, model->stream), "get_tensor sync");
   model->check(model->api->ffh_stream_sync(model->ctx, model->side_stream), "get_tensor sync");
   model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream), "get_tensor sync");
@@ -281,7 +340,7 @@ std::string FFModel::get_operator_type_name(OperatorType type) const {
 }
 
 Op::Op(FFModel& model, OperatorType type, const char* _name, int num_inputs, const Tensor* _inputs)
-    : op_type(type), numInputs(num_inputs), numWeights(0), numOutputs(1), profiling(model.config.profiling) {
+    : op_type(type), numInputs(num_inputs), numWeights(0), numOutputs(1), layer_index(-1), profiling(model.config.profiling) {
   // "<Type>_<guid>" from guid 100 [ref: src/runtime/model.cc:253-268]
   std::string pc = (_name == nullptr ? model.get_operator_type_name(type) : std::string(_name)) + "_" +
                    std::to_string(model.op_global_guid++);
@@ -313,7 +372,7 @@ FFModel::FFModel(FFConfig& _config)
       emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
       act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1) {
-  dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; dw_forked = false;
+  dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; dw_forked = false; dw_worker = side_worker = nullptr;
   rank = config.comm.world_size > 1 ? config.comm.rank : 0;
   world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
   if (world_size == 1 && config.workersPerNode > 1)
@@ -332,6 +391,12 @@ FFModel::FFModel(FFConfig& _config)
   check(api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
   check(api->ffh_event_create(ctx, &ev_dw_done), "event create");
+  dw_worker = side_worker = nullptr;
+  if (config.async_launch && (std::string(api->ffh_backend_name()).rfind("hip", 0) == 0 || getenv("FFM_FORCE_ASYNC_LAUNCH"))) {
+    // asynchronous devices only: on the CPU oracle a "launch" is the computation itself
+    dw_worker = new LaunchWorker(api, config.device);
+    side_worker = new LaunchWorker(api, config.device);
+  }
   check(api->ffh_event_create(ctx, &ev_fork), "event create");
   check(api->ffh_event_create(ctx, &ev_join), "event create");
   check(api->ffh_event_create(ctx, &ev_grad_ready), "event create");
@@ -340,7 +405,9 @@ FFModel::FFModel(FFConfig& _config)
 
 FFModel::~FFModel() {
   if (!ctx) return;
+  delete dw_worker; delete side_worker;
   api->ffh_device_sync(ctx);
+  for (ffh_event e : layer_events) api->ffh_event_destroy(ctx, e);
   for (auto& kv : graphs) api->ffh_graph_destroy(ctx, kv.second);
   // device memory is released with the context's process; explicit frees keep long-lived hosts clean
   for (TensorImpl* t : tensor_impls) {
@@ -414,6 +481,7 @@ Tensor FFModel::dense(const Tensor& input, int outDim, ActiMode activation, bool
   if (kernel_initializer == nullptr) kernel_initializer = new GlorotUniform(std::rand());
   if (bias_initializer == nullptr) bias_initializer = new ZeroInitializer();
   Linear* li = new Linear(*this, input, outDim, activation, use_bias, shared_op, kernel_initializer, bias_initializer, name);
+  li->layer_index = (int)layers.size();
   layers.push_back(li);
   return li->outputs[0];
 }
@@ -422,18 +490,21 @@ Tensor FFModel::embedding(const Tensor& input, int num_entries, int outDim, Aggr
                           Initializer* kernel_initializer, const char* name) {
   if (kernel_initializer == nullptr) kernel_initializer = new GlorotUniform(std::rand());   // [ref: src/ops/embedding.cu:19-34]
   Embedding* e = new Embedding(*this, input, num_entries, outDim, aggr, shared_op, kernel_initializer, name);
+  e->layer_index = (int)layers.size();
   layers.push_back(e);
   return e->outputs[0];
 }
 
 Tensor FFModel::concat(int n, const Tensor* tensors, int axis, const char* name) {
   Concat* c = new Concat(*this, n, tensors, axis, name);
+  c->layer_index = (int)layers.size();
   layers.push_back(c);
   return c->outputs[0];
 }
 
 Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_dim, int b_seq_length_dim) {
   BatchMatmul* b = new BatchMatmul(*this, A, B, a_seq_length_dim, b_seq_length_dim);
+  b->layer_index = (int)layers.size();
   layers.push_back(b);
   return b->outputs[0];
 }
@@ -477,11 +548,31 @@ void Linear::backward(const FFModel& ff) {
   const int64_t b = local_rows(y, &ff);
   float* dx = discard_input_grad ? nullptr : x.impl->grad;
   const bool fork = ff.config.parallel_dw;
-  ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, dx, x.impl->grad_ld,
-                                     (const float*)y.impl->ptr, y.impl->ld, y.impl->grad, y.impl->grad_ld,
-                                     (const float*)weights[0].impl->ptr, weights[0].impl->grad,
-                                     use_bias ? weights[1].impl->grad : nullptr, in_channels, out_channels, b, (int)activation,
-                                     dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0, ff.stream, fork ? ff.dw_stream : nullptr), name);
+  const int flags = dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0;
+  const float *xp = (const float*)x.impl->ptr, *yp = (const float*)y.impl->ptr, *wp = (const float*)weights[0].impl->ptr;
+  float *dyp = y.impl->grad, *dwp = weights[0].impl->grad, *dbp = use_bias ? weights[1].impl->grad : nullptr;
+  const int64_t ldx = x.impl->ld, lddx = x.impl->grad_ld, ldy = y.impl->ld, lddy = y.impl->grad_ld;
+  if (fork && ff.use_workers()) {
+    // two host threads: this one keeps walking the dX chain, the dW GEMM is issued by the dw worker on its stream
+    const KernelApi* api = ff.api;
+    ffh_stream dws = ff.dw_stream;
+    ffh_event ev = ff.layer_events[layer_index];
+    const int in = in_channels, out = out_channels, act = (int)activation;
+    const char* nm = name;
+    auto dw_call = [=](ffh_ctx* wc) {
+      int rc = api->ffh_stream_wait_event(wc, dws, ev);
+      if (rc == FFH_OK) rc = api->ffh_linear_bwd_ex(wc, xp, ldx, nullptr, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in, out, b, act, flags | FFH_LINEAR_ONLY_DW, dws, nullptr);
+      if (rc != FFH_OK) die("%s (weight gradient) failed (%d): %s", nm, rc, api->ffh_last_error_string(wc));
+    };
+    const bool sig = activation == AC_MODE_SIGMOID;   // its in-place activation pass (in the ONLY_DX call) must precede the dW GEMM
+    if (!sig) { ff.check(api->ffh_event_record(ff.ctx, ev, ff.stream), "event"); ff.dw_worker->post(dw_call); }
+    ff.check(api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in, out, b, act, flags | FFH_LINEAR_ONLY_DX, ff.stream, nullptr), name);
+    if (sig) { ff.check(api->ffh_event_record(ff.ctx, ev, ff.stream), "event"); ff.dw_worker->post(dw_call); }
+    ff.dw_forked = true;
+    return;
+  }
+  ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_channels, out_channels, b, (int)activation,
+                                     flags, ff.stream, fork ? ff.dw_stream : nullptr), name);
   if (fork) ff.dw_forked = true;
 }
 
@@ -521,11 +612,7 @@ void Embedding::forward(const FFModel& ff) {
   // in front of the tables (the bottom MLP), so the GPU runs those while the host walks the exchange callback.
   if (ff.emb_forward_issued) return;
   if (ff.config.overlap_embedding) {
-    ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.side_stream, ff.ev_fork), "fork");
-    ff.embedding_group_forward(ff.side_stream);
-    ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_join, ff.side_stream), "join");
-    ff.emb_forward_issued = true;
-    ff.emb_forward_joined = false;
+    ff.issue_embedding_forward_on_side_stream();
   } else {
     ff.embedding_group_forward(ff.stream);
     ff.emb_forward_issued = true;
@@ -541,12 +628,10 @@ void Embedding::backward(const FFModel& ff) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
       // backward(), after the host has enqueued the bottom-MLP backward it overlaps with
       ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
-      if (ff.exchange) {
-        ff.emb_update_pending = true;      // host-side collectives: issue after the bottom-MLP backward is enqueued
+      if (ff.exchange && !ff.use_workers()) {
+        ff.emb_update_pending = true;      // host-side collectives on this thread: issue after the bottom-MLP backward is enqueued
       } else {
-        ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.side_stream, ff.ev_grad_ready), "event");
-        ff.embedding_group_update(ff.side_stream);
-        ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_update_done, ff.side_stream), "event");
+        ff.issue_embedding_update_on_side_stream();
       }
     }
     return;
@@ -624,10 +709,7 @@ void concat_parts(const Concat* c, const std::vector<int64_t>& ib, bool grads, s
 }  // namespace
 
 void Concat::forward(const FFModel& ff) {
-  if (ff.emb_forward_issued && !ff.emb_forward_joined) {   // join the side stream before the first consumer
-    ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.stream, ff.ev_join), "join");
-    ff.emb_forward_joined = true;
-  }
+  if (ff.emb_forward_issued && !ff.emb_forward_joined) ff.join_embedding_forward();   // before the first consumer
   int64_t nb, ob;
   std::vector<int64_t> ib, blks, lds;
   std::vector<float*> ptrs;
@@ -977,6 +1059,9 @@ void FFModel::allocate() {
   }
   workspace = dmalloc(workspace_bytes);
   check(api->ffh_ctx_set_workspace(ctx, workspace, workspace_bytes), "set workspace");
+  if (side_worker) check(api->ffh_ctx_set_workspace(side_worker->ctx(), workspace, workspace_bytes), "set workspace");   // the only other user
+  layer_events.resize(layers.size(), nullptr);
+  for (ffh_event& e : layer_events) check(api->ffh_event_create(ctx, &e), "event create");
   d_perf = (ffh_perf_metrics*)dmalloc(sizeof(ffh_perf_metrics));
   check(api->ffh_zero(ctx, d_perf, sizeof(ffh_perf_metrics), stream), "zero");
   check(api->ffh_zero(ctx, act_slab, std::max<size_t>(act_bytes, 256), stream), "zero");
@@ -999,7 +1084,7 @@ void FFModel::print_layers(int id) {
 // =============================================================================================
 // launches one batched kernel per distinct shard width (all table-wise tables share one; column blocks of
 // giant tables another); FWD: gather, else fused backward + SGD
-static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s) {
+static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s, ffh_ctx* cx) {
   const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(ff->optimizer);
   const int L = ff->embeddings[0]->inputs[0].adim[0];
   const int aggr = (int)ff->embeddings[0]->aggr;
@@ -1024,16 +1109,16 @@ static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s) {
     std::vector<ffh_emb_table>& tabs = kv.second;
     for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
       const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
-      if (fwd) ff->check(ff->api->ffh_embedding_fwd_multi(ff->ctx, tabs.data() + b, n, L, kv.first, ff->config.batchSize, aggr, s), "embedding_fwd_multi");
-      else ff->check(ff->api->ffh_embedding_bwd_sgd_fused_multi(ff->ctx, tabs.data() + b, n, L, kv.first, ff->config.batchSize, aggr, (float)sgd->lr, s),
+      if (fwd) ff->check(ff->api->ffh_embedding_fwd_multi(cx, tabs.data() + b, n, L, kv.first, ff->config.batchSize, aggr, s), "embedding_fwd_multi");
+      else ff->check(ff->api->ffh_embedding_bwd_sgd_fused_multi(cx, tabs.data() + b, n, L, kv.first, ff->config.batchSize, aggr, (float)sgd->lr, s),
                      "embedding_bwd_sgd_fused_multi");
     }
   }
 }
 
-void FFModel::embedding_group_forward(ffh_stream s) const {
+void FFModel::embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx) const {
   if (embeddings.empty()) return;
-  launch_shard_groups(this, true, s);
+  launch_shard_groups(this, true, s, on_ctx ? on_ctx : ctx);
   if (exchange) {
     // each owner gathered its tables / column blocks for the global batch; rows go to the rank that owns the sample
     if (config.comm.alltoall_f32(config.comm.user, xsend, fwd_send_counts.data(), xrecv, fwd_recv_counts.data(), s) != 0)
@@ -1041,14 +1126,14 @@ void FFModel::embedding_group_forward(ffh_stream s) const {
   }
 }
 
-void FFModel::embedding_group_update(ffh_stream s) const {
+void FFModel::embedding_group_update(ffh_stream s, ffh_ctx* on_ctx) const {
   if (embeddings.empty()) return;
   if (exchange) {
     // gradients of the rows go back to the owners (transposed exchange)
     if (config.comm.alltoall_f32(config.comm.user, gsend, fwd_recv_counts.data(), grecv, fwd_send_counts.data(), s) != 0)
       die("alltoall (embedding backward) failed");
   }
-  launch_shard_groups(this, false, s);
+  launch_shard_groups(this, false, s, on_ctx ? on_ctx : ctx);
 }
 
 // =============================================================================================
@@ -1066,17 +1151,48 @@ void FFModel::forward(int _seq_length) {
   // gather (+ all-to-all) go to the side stream beside the bottom MLP: the fork point is here (inputs ready)
   if (config.overlap_embedding && !embeddings.empty()) {
     check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
-    if (!exchange) {   // no host-side collective in the way: start the gather right now
-      check(api->ffh_stream_wait_event(ctx, side_stream, ev_fork), "fork");
-      embedding_group_forward(side_stream);
-      check(api->ffh_event_record(ctx, ev_join, side_stream), "join");
-      emb_forward_issued = true;
-    }
+    // start the gather right now unless a host-side collective would stall THIS thread's launches
+    if (!exchange || use_workers()) issue_embedding_forward_on_side_stream();
   }
   for (Op* op : layers) op->forward(*this);
-  if (emb_forward_issued && !emb_forward_joined) {
-    check(api->ffh_stream_wait_event(ctx, stream, ev_join), "join");
-    emb_forward_joined = true;
+  if (emb_forward_issued && !emb_forward_joined) join_embedding_forward();
+}
+
+void FFModel::issue_embedding_forward_on_side_stream() const {
+  if (use_workers()) {
+    const FFModel* self = this;
+    side_worker->post([self](ffh_ctx* wc) {
+      self->check(self->api->ffh_stream_wait_event(wc, self->side_stream, self->ev_fork), "fork");
+      self->embedding_group_forward(self->side_stream, wc);
+      self->check(self->api->ffh_event_record(wc, self->ev_join, self->side_stream), "join");
+    });
+  } else {
+    check(api->ffh_stream_wait_event(ctx, side_stream, ev_fork), "fork");
+    embedding_group_forward(side_stream);
+    check(api->ffh_event_record(ctx, ev_join, side_stream), "join");
+  }
+  emb_forward_issued = true;
+  emb_forward_joined = false;
+}
+
+void FFModel::join_embedding_forward() const {
+  if (side_worker) side_worker->drain();   // the record of ev_join must have been issued before we wait on it
+  check(api->ffh_stream_wait_event(ctx, stream, ev_join), "join");
+  emb_forward_joined = true;
+}
+
+void FFModel::issue_embedding_update_on_side_stream() const {
+  if (use_workers()) {
+    const FFModel* self = this;
+    side_worker->post([self](ffh_ctx* wc) {
+      self->check(self->api->ffh_stream_wait_event(wc, self->side_stream, self->ev_grad_ready), "event");
+      self->embedding_group_update(self->side_stream, wc);
+      self->check(self->api->ffh_event_record(wc, self->ev_update_done, self->side_stream), "event");
+    });
+  } else {
+    check(api->ffh_stream_wait_event(ctx, side_stream, ev_grad_ready), "event");
+    embedding_group_update(side_stream);
+    check(api->ffh_event_record(ctx, ev_update_done, side_stream), "event");
   }
 }
 
@@ -1120,9 +1236,7 @@ void FFModel::backward(int _seq_length) {
   for (int l = (int)layers.size() - 1; l >= 0; l--) layers[l]->backward(*this);
   if (emb_update_pending) {
     // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
-    check(api->ffh_stream_wait_event(ctx, side_stream, ev_grad_ready), "event");
-    embedding_group_update(side_stream);
-    check(api->ffh_event_record(ctx, ev_update_done, side_stream), "event");
+    issue_embedding_update_on_side_stream();
     emb_update_pending = false;
   }
 }
@@ -1132,7 +1246,10 @@ void FFModel::update() {
   optimizer->next();
   SGDOptimizer* sgd = dynamic_cast<SGDOptimizer*>(optimizer);
   if (!sgd) die("only SGDOptimizer is on the DLRM path");
+  // every rank must issue its collectives in the same order: the side thread's all-to-all (backward) first
+  if (side_worker) side_worker->drain();
   if (dw_forked) {   // the weight-gradient GEMMs ran on their own stream: join before the gradients are consumed
+    if (dw_worker) dw_worker->drain();
     check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");
     check(api->ffh_stream_wait_event(ctx, stream, ev_dw_done), "join dw");
     dw_forked = false;
@@ -1164,6 +1281,8 @@ void FFModel::begin_trace(int trace_id) {
   if (!config.enable_graph) return;
   auto it = graphs.find(trace_id);
   if (it != graphs.end()) { replaying_trace = trace_id; return; }
+  if (dw_worker) dw_worker->drain();      // stream capture is thread-local: everything is issued inline while capturing
+  if (side_worker) side_worker->drain();
   int rc = api->ffh_graph_begin_capture(ctx, stream);
   if (rc == FFH_ERR_UNSUPPORTED) { config.enable_graph = false; return; }   // backend without graphs: run eagerly
   check(rc, "begin_trace");
@@ -1187,6 +1306,8 @@ void FFModel::end_trace(int trace_id) {
 }
 
 void FFModel::sync() {
+  if (dw_worker) dw_worker->drain();
+  if (side_worker) side_worker->drain();
   check(api->ffh_stream_sync(ctx, stream), "sync");
   check(api->ffh_stream_sync(ctx, side_stream), "sync");
   check(api->ffh_stream_sync(ctx, dw_stream), "sync");

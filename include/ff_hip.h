@@ -237,6 +237,14 @@ int ffh_linear_bwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t
  *                            caller joins s_dw before it consumes dw/db.  dy still ends up overwritten
  *                            by the activation gradient, as in the reference. */
 #define FFH_LINEAR_DX_OVERWRITE 1
+/* split form, for callers that issue the two GEMMs themselves (e.g. from two host threads on two streams):
+ *   FFH_LINEAR_ONLY_DX  [sigmoid: in-place activation gradient + db first] then dx only; relu' is applied to dy
+ *                       while it is loaded, dy itself is not written
+ *   FFH_LINEAR_ONLY_DW  dw (+ db for relu / none) only; relu' is applied on load and written back to dy in place.
+ *                       For sigmoid the ONLY_DX call must have completed on the device first.
+ * Issued once each (any order for relu / none) they equal one ffh_linear_bwd call. */
+#define FFH_LINEAR_ONLY_DX 4
+#define FFH_LINEAR_ONLY_DW 2
 int ffh_linear_bwd_ex(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,
                       const float* w, float* dw, float* db,

@@ -346,54 +346,53 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
  *   cublasSgemm(N,N, in,B,out) alpha=beta=1 : dx[b][i] += sum_o w[o][i] dy[b][o]
  * Each product is an ascending FMA chain from 0 over the reduced index, then one add into
  * the accumulated buffer (C = 1*AB + 1*C). */
-int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
-                   const float* y, int64_t ldy, float* dy, int64_t lddy,
-                   const float* w, float* dw, float* db,
-                   int in, int out, int64_t B, int act, ffh_stream s) {
-  (void)s;
+static float act_grad(float d, float yo, int act) {
+  if (act == FFH_AC_MODE_RELU) return (yo > 0.0f) ? d : 0.0f;                 /* reluBackward [ref: src/runtime/cuda_helper.cu:71-78] */
+  if (act == FFH_AC_MODE_SIGMOID) return d * yo * (1 - yo);                   /* sigmoid_backward [ref: src/ops/linear.cu:600-607] */
+  return d;
+}
+
+/* parts of Linear::backward_kernel; mask_on_load: dy is read through act'(y) without being modified */
+static int linear_bwd_parts(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                            const float* y, int64_t ldy, float* dy, int64_t lddy,
+                            const float* w, float* dw, float* db, int in, int out, int64_t B, int act,
+                            int act_inplace, int do_dw, int do_db, int do_dx, int mask_on_load) {
   if (in <= 0 || out <= 0 || B < 0 || ldx < in || ldy < out || lddy < out || (dx && lddx < in))
     return fail(c, FFH_ERR_BAD_ARG, "linear_bwd: bad dims");
   if (act != FFH_AC_MODE_NONE && act != FFH_AC_MODE_RELU && act != FFH_AC_MODE_SIGMOID)
     return fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd: activation");
-  if (act == FFH_AC_MODE_RELU) {
+  if (act_inplace && act != FFH_AC_MODE_NONE) {
 #pragma omp parallel for schedule(static)
     for (int64_t b = 0; b < B; b++)
       for (int o = 0; o < out; o++)
-        dy[b * lddy + o] = (y[b * ldy + o] > 0.0f) ? dy[b * lddy + o] : 0.0f;
-  } else if (act == FFH_AC_MODE_SIGMOID) {
-#pragma omp parallel for schedule(static)
-    for (int64_t b = 0; b < B; b++)
-      for (int o = 0; o < out; o++) {
-        const float yo = y[b * ldy + o];
-        dy[b * lddy + o] = dy[b * lddy + o] * yo * (1 - yo);
-      }
+        dy[b * lddy + o] = act_grad(dy[b * lddy + o], y[b * ldy + o], act);
   }
-  /* dw */
+  const int m = mask_on_load ? act : FFH_AC_MODE_NONE;
+  if (do_dw) {
 #pragma omp parallel
-  {
-    float* tmp = (float*)malloc(sizeof(float) * (size_t)in);
+    {
+      float* tmp = (float*)malloc(sizeof(float) * (size_t)in);
 #pragma omp for schedule(static)
-    for (int o = 0; o < out; o++) {
-      for (int i = 0; i < in; i++) tmp[i] = 0.0f;
-      for (int64_t b = 0; b < B; b++) {
-        const float d = dy[b * lddy + o];
-        const float* xr = x + b * ldx;
-        for (int i = 0; i < in; i++) tmp[i] = fmaf(d, xr[i], tmp[i]);
+      for (int o = 0; o < out; o++) {
+        for (int i = 0; i < in; i++) tmp[i] = 0.0f;
+        for (int64_t b = 0; b < B; b++) {
+          const float d = act_grad(dy[b * lddy + o], y[b * ldy + o], m);
+          const float* xr = x + b * ldx;
+          for (int i = 0; i < in; i++) tmp[i] = fmaf(d, xr[i], tmp[i]);
+        }
+        for (int i = 0; i < in; i++) dw[(size_t)o * in + i] += tmp[i];
       }
-      for (int i = 0; i < in; i++) dw[(size_t)o * in + i] += tmp[i];
+      free(tmp);
     }
-    free(tmp);
   }
-  /* db */
-  if (db) {
+  if (do_db && db) {
     for (int o = 0; o < out; o++) {
       float acc = 0.0f;
-      for (int64_t b = 0; b < B; b++) acc = fmaf(dy[b * lddy + o], 1.0f, acc);
+      for (int64_t b = 0; b < B; b++) acc = fmaf(act_grad(dy[b * lddy + o], y[b * ldy + o], m), 1.0f, acc);
       db[o] += acc;
     }
   }
-  /* dx */
-  if (dx) {
+  if (do_dx && dx) {
 #pragma omp parallel
     {
       float* tmp = (float*)malloc(sizeof(float) * (size_t)in);
@@ -401,7 +400,7 @@ int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t l
       for (int64_t b = 0; b < B; b++) {
         for (int i = 0; i < in; i++) tmp[i] = 0.0f;
         for (int o = 0; o < out; o++) {
-          const float d = dy[b * lddy + o];
+          const float d = act_grad(dy[b * lddy + o], y[b * ldy + o], m);
           const float* wr = w + (size_t)o * in;
           for (int i = 0; i < in; i++) tmp[i] = fmaf(d, wr[i], tmp[i]);
         }
@@ -413,15 +412,30 @@ int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t l
   return FFH_OK;
 }
 
+int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                   const float* y, int64_t ldy, float* dy, int64_t lddy,
+                   const float* w, float* dw, float* db,
+                   int in, int out, int64_t B, int act, ffh_stream s) {
+  (void)s;
+  return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, 1, 1, 1, 1, 0);
+}
+
 /* same arithmetic; streams mean nothing on the host.  DX_OVERWRITE: dx is zeroed here, then accumulated */
 int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,
                       const float* w, float* dw, float* db, int in, int out, int64_t B, int act,
                       int flags, ffh_stream s, ffh_stream s_dw) {
-  (void)s_dw;
-  if ((flags & FFH_LINEAR_DX_OVERWRITE) && dx && in > 0 && lddx >= in)
+  (void)s; (void)s_dw;
+  const int only_dx = flags & FFH_LINEAR_ONLY_DX, only_dw = flags & FFH_LINEAR_ONLY_DW;
+  if (only_dx && only_dw) return fail(c, FFH_ERR_BAD_ARG, "linear_bwd_ex: ONLY_DX and ONLY_DW are exclusive");
+  if ((flags & FFH_LINEAR_DX_OVERWRITE) && !only_dw && dx && in > 0 && lddx >= in)
     for (int64_t b = 0; b < B; b++) memset(dx + b * lddx, 0, sizeof(float) * (size_t)in);
-  return ffh_linear_bwd(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, s);
+  const int sig = act == FFH_AC_MODE_SIGMOID;
+  if (only_dx)   /* sigmoid: in-place pass + db here; relu: dy untouched, masked while read */
+    return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, sig, 0, sig, 1, !sig);
+  if (only_dw)   /* relu: mask written back in place; sigmoid: dy already transformed, db already done */
+    return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, sig ? FFH_AC_MODE_NONE : act, !sig, 1, !sig, 0, 0);
+  return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, 1, 1, 1, 1, 0);
 }
 
 /* ------------------------------------------------------------------ */

@@ -20,7 +20,7 @@ def oracle_backend():
 
 
 def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dense_update=False, g=None, force_exchange=False,
-                      column_shard_rows=0):
+                      column_shard_rows=0, extra_argv=()):
     """Returns (model, handles) with weights and inputs of the golden fixture loaded.
     With `comm` (world_size > 1) each rank loads its batch slice / its tables."""
     g = g or golden("dlrm_step_torch")
@@ -31,7 +31,7 @@ def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dens
     argv = ["-b", str(B)] + (["--force-exchange"] if force_exchange else [])
     if column_shard_rows:
         argv += ["--column-shard-rows", str(column_shard_rows)]
-    cfg = ffmodel.FFConfig(argv=argv, backend=backend, comm=comm)
+    cfg = ffmodel.FFConfig(argv=argv + list(extra_argv), backend=backend, comm=comm)
     cfg.set(enable_graph=enable_graph, overlap_embedding=overlap, dense_embedding_update=dense_update)
     m = ffmodel.FFModel(cfg)
     sparse = [m.create_tensor([B, L], ffmodel.DT_INT64) for _ in rows]

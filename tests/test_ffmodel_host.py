@@ -37,6 +37,18 @@ def test_dlrm_two_steps_match_torch_golden(overlap, dense_update):
     m.close()
 
 
+@pytest.mark.timeout(180)
+def test_launch_worker_threads_on_cpu(monkeypatch):
+    """The multi-threaded launch path (dW GEMMs and the embedding side stream issued by their own host
+    threads, joined through drain() + events) with the CPU oracle as the device: same results as the
+    inline path, and no deadlock (hard timeout)."""
+    monkeypatch.setenv("FFM_FORCE_ASYNC_LAUNCH", "1")
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=True, extra_argv=["--async-launch"])
+    recs = H.run_steps(m, h, 2)
+    H.check_against_golden(recs, h)
+    m.close()
+
+
 def test_fused_and_dense_embedding_paths_agree():
     """The fused sparse update and the reference's dense zero/scatter/sweep path give the same
     tables (1e-6: only the summation order inside duplicate rows differs)."""

@@ -31,6 +31,15 @@ def test_dlrm_two_steps_match_torch_golden_on_gpu(hip, overlap, graph, dense_upd
     m.close()
 
 
+@pytest.mark.timeout(300)
+def test_async_launch_threads_on_gpu(hip):
+    """--async-launch: weight-gradient GEMMs and the embedding side stream issued by their own host threads."""
+    m, h = H.build_golden_dlrm(HIP, overlap=True, extra_argv=["--async-launch"])
+    recs = H.run_steps(m, h, 3)[:2]
+    H.check_against_golden(recs, h)
+    m.close()
+
+
 def test_trace_replay_equals_eager(hip):
     """begin_trace/end_trace (hipGraph capture + replay) over 4 steps == 4 eager steps, bit for bit
     on the embedding tables and within 1e-6 on the MLP (atomics in the dW split-K)."""
