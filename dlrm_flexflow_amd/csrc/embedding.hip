@@ -761,7 +761,7 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
   } else {
     launch_fold(ra.partial, ra.meta, lay.nchunks, p1, m1, 1, 0);
   }
-  FFH_LAUNCH_CHECK(c, "emb_sgd_reduce/combine");
+  FFH_LAUNCH_CHECK(c, "emb_sgd_reduce/fold");
   return FFH_OK;
 }
 

@@ -350,6 +350,43 @@ def test_linear_strided_operands_and_accumulate(hip, oracle):
     np.testing.assert_allclose(host(dwt), dw_e, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("act", [capi.AC_MODE_RELU, capi.AC_MODE_SIGMOID, capi.AC_MODE_NONE])
+def test_linear_bwd_ex_forms_equal_reference_form(hip, oracle, act):
+    """ffh_linear_bwd_ex: overwrite-mode dx, the forked weight-gradient stream, and the split
+    ONLY_DX / ONLY_DW calls all give what one ffh_linear_bwd call gives (and what the oracle gives)."""
+    rng = np.random.default_rng(act)
+    B, IN, OUT = 777, 96, 80
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / 8).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    y = oracle.linear_fwd(x, w, b, act)
+    dx_e, dw_e, db_e, dy_e = oracle.linear_bwd(x, y, gy, w, act)
+    s2 = torch.cuda.Stream()
+
+    def run(mode):
+        dx = torch.full((B, IN), 5.0, device=DEV) if mode != "plain" else torch.zeros(B, IN, device=DEV)
+        dw, db, dy = torch.zeros(OUT, IN, device=DEV), torch.zeros(OUT, device=DEV), dev(gy)
+        args = (dev(x), IN, dx, IN, dev(y), OUT, dy, OUT, dev(w), dw, db, IN, OUT, B, act)
+        if mode == "plain":
+            hip.call("ffh_linear_bwd", *args, None)
+        elif mode == "overwrite+fork":
+            hip.call("ffh_linear_bwd_ex", *args, 1, None, s2.cuda_stream)
+        else:   # split calls; sigmoid needs ONLY_DX first
+            hip.call("ffh_linear_bwd_ex", *args, 1 | 4, None, None)
+            hip.call("ffh_linear_bwd_ex", *args, 2, None, None)
+        torch.cuda.synchronize()
+        return host(dx), host(dw), host(db), host(dy)
+
+    for mode in ("plain", "overwrite+fork", "split"):
+        dx, dw, db, dy = run(mode)
+        a = np.abs(dy_e).astype(np.float64)
+        np.testing.assert_allclose(dy, dy_e, rtol=1e-6, atol=1e-7, err_msg=mode)
+        assert_gemm_close(dx, dx_e, a @ np.abs(w).astype(np.float64), f"dx {mode}")
+        assert_gemm_close(dw, dw_e, a.T @ np.abs(x).astype(np.float64), f"dw {mode}")
+        assert_gemm_close(db, db_e, a.sum(0), f"db {mode}")
+
+
 def test_linear_unsupported_activation_is_an_error(hip):
     t = torch.zeros(4, 4, device=DEV)
     with pytest.raises(capi.FFHError):
@@ -441,8 +478,13 @@ def test_sgd_mse_metrics(hip, oracle):
     hip.call("ffh_mse_bwd", lg, p, y, p.numel(), 1.0 / 37, None)
     assert bits_equal(host(lg), oracle.mse_bwd(g["mse_p"], g["mse_y"], 1.0 / 37))
     np.testing.assert_allclose(host(lg), g["mse_grad"], rtol=1e-6, atol=1e-8)
+    # compute_metrics + loss backward in one launch == the two separate entry points
+    perf2, lg2 = torch.zeros(8, dtype=torch.int32, device=DEV), torch.empty_like(p)
+    hip.call("ffh_mse_bwd_metrics", lg2, p, y, perf2, 37, 1, 1.0 / 37, capi.METRIC_ACCURACY | capi.METRIC_MSE, None)
+    assert bits_equal(host(lg2), host(lg))
     perf = torch.zeros(8, dtype=torch.int32, device=DEV)
     hip.call("ffh_metrics_update", p, y, perf, 37, 1, capi.METRIC_ACCURACY | capi.METRIC_MSE, None)
+    assert host(perf2)[:2].tolist() == [74, 37] and abs(host(perf2)[4:5].view(np.float32)[0] - float(g["mse_sum"])) <= 1e-5 * float(g["mse_sum"])
     hp = host(perf)
     assert hp[0] == 74 and hp[1] == 37                                # train_all double count (1 class + accuracy)
     mse = hp[4:5].view(np.float32)[0]
