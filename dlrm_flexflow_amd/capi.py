@@ -103,6 +103,8 @@ _SIGS = {
     "ffh_concat_bwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),
     "ffh_bmm_fwd": (I, [P, P, P, P, I, I, I, L, I, I, I, P]),
     "ffh_bmm_bwd": (I, [P, P, P, P, P, P, I, I, I, L, P]),
+    "ffh_transpose_fwd": (I, [P, P, P, I, C.POINTER(L), C.POINTER(I), P]),
+    "ffh_transpose_bwd": (I, [P, P, P, I, C.POINTER(L), C.POINTER(I), P]),
     "ffh_mse_bwd": (I, [P, P, P, P, L, F, P]),
     "ffh_metrics_update": (I, [P, P, P, P, L, I, I, P]),
     "ffh_sgd_update": (I, [P, P, P, P, L, F, F, F, I, P]),
@@ -197,6 +199,12 @@ class FFHLib:
         for k, (idx, w, io, r, ld) in enumerate(entries):
             arr[k] = EmbTable(ptr(idx), ptr(w), ptr(io), int(r), int(ld))
         return arr
+
+    def transpose(self, name: str, dst, src, in_dims, perm, stream=None):
+        n = len(in_dims)
+        da = (L * n)(*[int(v) for v in in_dims])
+        pa = (I * n)(*[int(v) for v in perm])
+        self.check(getattr(self.lib, name)(self.ctx, ptr(dst), ptr(src), n, da, pa, ptr(stream)), name)
 
     def concat(self, name: str, big, out_blk: int, parts, in_blk, in_ld, num_blocks: int, stream=None):
         n = len(parts)

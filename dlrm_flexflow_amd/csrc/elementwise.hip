@@ -163,6 +163,95 @@ __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Transpose: general <= 4-D permutation (one thread per output element, coalesced stores), and the
+// case the dot interaction needs -- swap of the two innermost dims of [batch][r][c] -- through a
+// padded 32x33 LDS tile so that loads AND stores are coalesced.
+struct TransposeArgs {
+  int64_t od[4], is_perm[4];   // output dims; input stride of the input dim that feeds output dim i
+  int64_t vol;
+  int nd;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void transpose_generic_kernel(float* __restrict__ dst, const float* __restrict__ src, const TransposeArgs a) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < a.vol; o += stride) {
+    int64_t t = o, ii = 0;
+#pragma unroll
+    for (int i = 3; i >= 0; i--)
+      if (i < a.nd) { const int64_t q = t % a.od[i]; t /= a.od[i]; ii += q * a.is_perm[i]; }
+    if (BWD) dst[ii] += src[o];      // the map o -> ii is a bijection: no two threads meet
+    else dst[o] = src[ii];
+  }
+}
+
+// src [batch][R][C] -> dst [batch][C][R];  BWD: dst [batch][R][C] += src [batch][C][R]^T (same tile walk, roles swapped)
+template <bool ACC>
+__global__ __launch_bounds__(256) void transpose_last2_kernel(float* __restrict__ dst, const float* __restrict__ src, int R, int C) {
+  __shared__ float tile[32][33];
+  const int64_t b = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const float* sp = src + b * (int64_t)R * C;
+  float* dp = dst + b * (int64_t)R * C;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int r = r0 + ty + k * 8, cc = c0 + tx;
+    if (r < R && cc < C) tile[ty + k * 8][tx] = sp[(int64_t)r * C + cc];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int cc = c0 + ty + k * 8, r = r0 + tx;
+    if (r < R && cc < C) {
+      float* p = dp + (int64_t)cc * R + r;
+      if (ACC) *p += tile[tx][ty + k * 8]; else *p = tile[tx][ty + k * 8];
+    }
+  }
+}
+
+int transpose_launch(ffh_ctx* c, float* dst, const float* src, int nd, const int64_t* in_dims, const int* perm, bool bwd, ffh_stream s) {
+  if (nd < 1 || nd > 4 || !in_dims || !perm) return ffh_fail(c, FFH_ERR_BAD_ARG, "transpose: ndim must be 1..4");
+  bool seen[4] = {false, false, false, false};
+  for (int i = 0; i < nd; i++) {
+    if (perm[i] < 0 || perm[i] >= nd || seen[perm[i]] || in_dims[i] <= 0) return ffh_fail(c, FFH_ERR_BAD_ARG, "transpose: bad perm/dims");
+    seen[perm[i]] = true;
+  }
+  int64_t is[4], vol = 1;
+  for (int i = nd - 1; i >= 0; i--) { is[i] = (i == nd - 1) ? 1 : is[i + 1] * in_dims[i + 1]; vol *= in_dims[i]; }
+  if (!dst || !src) return ffh_fail(c, FFH_ERR_BAD_ARG, "transpose: null pointer");
+  // fast path: identity on the leading dims, swap of the two innermost
+  bool last2 = nd >= 2 && perm[nd - 1] == nd - 2 && perm[nd - 2] == nd - 1;
+  for (int i = 0; i < nd - 2; i++) last2 = last2 && perm[i] == i;
+  if (last2) {
+    int64_t batch = 1;
+    for (int i = 0; i < nd - 2; i++) batch *= in_dims[i];
+    const int R = (int)in_dims[nd - 2], C = (int)in_dims[nd - 1];
+    if (batch <= 65535) {
+      if (!bwd) {
+        dim3 grid((C + 31) / 32, (R + 31) / 32, (unsigned)batch);
+        hipLaunchKernelGGL((transpose_last2_kernel<false>), grid, dim3(256), 0, as_stream(s), dst, src, R, C);
+      } else {   // src = out_grad [batch][C][R]; dst = in_grad [batch][R][C] += src^T
+        dim3 grid((R + 31) / 32, (C + 31) / 32, (unsigned)batch);
+        hipLaunchKernelGGL((transpose_last2_kernel<true>), grid, dim3(256), 0, as_stream(s), dst, src, C, R);
+      }
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return ffh_fail_hip(c, e, "transpose_last2_kernel");
+      return FFH_OK;
+    }
+  }
+  TransposeArgs a;
+  a.nd = nd; a.vol = vol;
+  for (int i = 0; i < 4; i++) { a.od[i] = 1; a.is_perm[i] = 0; }
+  for (int i = 0; i < nd; i++) { a.od[i] = in_dims[perm[i]]; a.is_perm[i] = is[perm[i]]; }
+  if (bwd) hipLaunchKernelGGL((transpose_generic_kernel<true>), dim3(ffh_grid(vol, 256)), dim3(256), 0, as_stream(s), dst, src, a);
+  else hipLaunchKernelGGL((transpose_generic_kernel<false>), dim3(ffh_grid(vol, 256)), dim3(256), 0, as_stream(s), dst, src, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ffh_fail_hip(c, e, "transpose_generic_kernel");
+  return FFH_OK;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
                                                   int64_t n, float lr, float wd, float mom, int nesterov) {
@@ -214,6 +303,13 @@ int ffh_concat_fwd(ffh_ctx* c, float* out, int64_t out_blk, const float* const* 
 int ffh_concat_bwd(ffh_ctx* c, const float* og, int64_t out_blk, float* const* igs, const int64_t* in_blk,
                    const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
   return concat_impl<true>(c, const_cast<float*>(og), out_blk, igs, in_blk, in_ld, n, nblk, s);
+}
+
+int ffh_transpose_fwd(ffh_ctx* c, float* out, const float* in, int nd, const int64_t* in_dims, const int* perm, ffh_stream s) {
+  return transpose_launch(c, out, in, nd, in_dims, perm, false, s);
+}
+int ffh_transpose_bwd(ffh_ctx* c, float* in_grad, const float* out_grad, int nd, const int64_t* in_dims, const int* perm, ffh_stream s) {
+  return transpose_launch(c, in_grad, out_grad, nd, in_dims, perm, true, s);
 }
 
 int ffh_mse_bwd(ffh_ctx* c, float* lg, const float* logit, const float* label, int64_t n, float scale, ffh_stream s) {

@@ -73,6 +73,9 @@ def lib() -> C.CDLL:
         "flexflow_model_add_embedding": (H, [H, H, I, I, I, H, C.c_char_p]),
         "flexflow_model_add_concat": (H, [H, I, C.POINTER(H), I, C.c_char_p]),
         "flexflow_model_add_batch_matmul": (H, [H, H, H, I, I]),
+        "flexflow_model_add_flat": (H, [H, H, C.c_char_p]),
+        "flexflow_model_add_transpose": (H, [H, H, I, IP, C.c_char_p]),
+        "flexflow_model_add_reshape": (H, [H, H, I, IP, C.c_char_p]),
         "flexflow_zero_initializer_create": (H, []), "flexflow_uniform_initializer_create": (H, [I, F, F]),
         "flexflow_norm_initializer_create": (H, [I, F, F]), "flexflow_glorot_uniform_initializer_create": (H, [I]),
         "flexflow_sgd_optimizer_create": (H, [H, D, D, B, D]), "flexflow_model_set_sgd_optimizer": (None, [H, H]),
@@ -220,6 +223,17 @@ class FFModel:
 
     def batch_matmul(self, a: Tensor, b: Tensor, a_seq_length_dim=-1, b_seq_length_dim=-1) -> Tensor:
         return Tensor(lib().flexflow_model_add_batch_matmul(self.h, a.h, b.h, a_seq_length_dim, b_seq_length_dim), self)
+
+    def flat(self, input: Tensor, name=None) -> Tensor:
+        return Tensor(lib().flexflow_model_add_flat(self.h, input.h, name.encode() if name else None), self)
+
+    def transpose(self, input: Tensor, perm, name=None) -> Tensor:
+        p = (C.c_int * len(perm))(*perm)
+        return Tensor(lib().flexflow_model_add_transpose(self.h, input.h, len(perm), p, name.encode() if name else None), self)
+
+    def reshape(self, input: Tensor, shape, name=None) -> Tensor:
+        p = (C.c_int * len(shape))(*shape)
+        return Tensor(lib().flexflow_model_add_reshape(self.h, input.h, len(shape), p, name.encode() if name else None), self)
 
     @staticmethod
     def uniform_initializer(seed, lo, hi): return lib().flexflow_uniform_initializer_create(seed, lo, hi)

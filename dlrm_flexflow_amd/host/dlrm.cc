@@ -76,16 +76,32 @@ Tensor create_emb(FFModel* model, const Tensor& input, int input_dim, int output
   return model->embedding(input, input_dim, output_dim, AGGR_MODE_SUM, NULL /*weight_sharing*/, embed_init);
 }
 
-// [ref: examples/cpp/DLRM/dlrm.cc:49-65]: only "cat" exists in the reference (dot is a TODO that asserts)
+// [ref: examples/cpp/DLRM/dlrm.cc:49-65]: the reference implements "cat" and asserts on "dot" (a TODO).
+// "dot" here is the composition the reference's own op tests spell out for the pairwise interaction
+// [ref: tests/ops/test_harness.py:125-177]: cat -> reshape [B][C][D] -> transpose -> batch_matmul -> flat,
+// concatenated with the bottom-MLP output: [x | vec(Z Z^T)], width D + C*C with C = 1 + #tables.
+// (MLPerf's variant keeps only the strict lower triangle; the reference has no op for that extraction.)
 Tensor interact_features(FFModel* model, const Tensor& x, const std::vector<Tensor>& ly, std::string interaction) {
-  if (interaction == "cat") {
-    std::vector<Tensor> inputs;
-    inputs.push_back(x);
-    for (size_t i = 0; i < ly.size(); i++) inputs.push_back(ly[i]);
-    return model->concat((int)inputs.size(), inputs.data(), 1 /*axis*/);
+  std::vector<Tensor> inputs;
+  inputs.push_back(x);
+  for (size_t i = 0; i < ly.size(); i++) inputs.push_back(ly[i]);
+  if (interaction == "cat") return model->concat((int)inputs.size(), inputs.data(), 1 /*axis*/);
+  if (interaction == "dot") {
+    const int batch = x.adim[1], d = x.adim[0], c = (int)inputs.size();
+    for (const Tensor& t : inputs)
+      if (t.adim[0] != d) {
+        fprintf(stderr, "FATAL: --arch-interaction-op dot needs the bottom MLP output width (%d) to equal --arch-sparse-feature-size (%d)\n", d, t.adim[0]);
+        abort();
+      }
+    Tensor cat = model->concat(c, inputs.data(), 1 /*axis*/);
+    Tensor z = model->reshape(cat, {batch, c, d});
+    Tensor zt = model->transpose(z, {0, 2, 1});
+    Tensor p = model->batch_matmul(z, zt);            // [batch][c][c]
+    Tensor pf = model->flat(p);
+    Tensor both[2] = {x, pf};
+    return model->concat(2, both, 1 /*axis*/);
   }
-  fprintf(stderr, "FATAL: --arch-interaction-op %s: only 'cat' is implemented by the DLRM driver "
-                  "(the reference asserts here too, examples/cpp/DLRM/dlrm.cc:53-64)\n", interaction.c_str());
+  fprintf(stderr, "FATAL: --arch-interaction-op %s: 'cat' or 'dot'\n", interaction.c_str());
   abort();
 }
 

@@ -47,7 +47,7 @@ enum MetricsType {
   METRICS_ROOT_MEAN_SQUARED_ERROR = 1016,
   METRICS_MEAN_ABSOLUTE_ERROR = 1032,
 };
-enum OperatorType { OP_INPUT, OP_LINEAR, OP_EMBEDDING, OP_CONCAT, OP_BATCHMATMUL };
+enum OperatorType { OP_INPUT, OP_LINEAR, OP_EMBEDDING, OP_CONCAT, OP_BATCHMATMUL, OP_TRANSPOSE, OP_RESHAPE, OP_FLAT };
 
 #define MAX_TENSOR_DIM 4
 #define MAX_NUM_INPUTS 256
@@ -275,6 +275,24 @@ class BatchMatmul : public Op {
   int a_seq_length_dim, b_seq_length_dim;
 };
 
+// The three shape ops the reference composes the dot interaction from
+// [ref: src/ops/transpose.cu, src/ops/reshape.cu:203-210, src/ops/flat.cu:117-124]
+class Transpose : public Op {
+ public:
+  Transpose(FFModel& model, const Tensor& input, const std::vector<int>& perm, const char* name);
+  void create_output_and_partition(FFModel&) override {}
+  void forward(const FFModel&) override;
+  void backward(const FFModel&) override;
+  int perm[MAX_TENSOR_DIM];     // natural order: output dim i = input dim perm[i]
+};
+class Reshape : public Op {     // also serves Flat: a copy forward, an accumulate backward
+ public:
+  Reshape(FFModel& model, OperatorType type, const Tensor& input, const std::vector<int>& shape, const char* name);
+  void create_output_and_partition(FFModel&) override {}
+  void forward(const FFModel&) override;
+  void backward(const FFModel&) override;
+};
+
 // ---------------------------------------------------------------------------------------------
 // A host thread that issues the launches of one auxiliary HIP stream.  The training step is bound by
 // the host's launch rate (~7 us per launch, ~35 launches per Kaggle step); the weight-gradient GEMMs
@@ -314,6 +332,9 @@ class FFModel {
                const Op* shared_op = NULL, Initializer* kernel_initializer = NULL,
                Initializer* bias_initializer = NULL, const char* name = NULL);
   Tensor concat(int n, const Tensor* tensors, int axis, const char* name = NULL);
+  Tensor flat(const Tensor& input, const char* name = NULL);
+  Tensor transpose(const Tensor& input, const std::vector<int>& perm, const char* name = NULL);
+  Tensor reshape(const Tensor& input, const std::vector<int>& shape, const char* name = NULL);
   template <int NDIM>
   Tensor create_tensor(const int dims[], DataType data_type, const Op* owner_op = NULL, bool create_grad = true);
   template <int NDIM>

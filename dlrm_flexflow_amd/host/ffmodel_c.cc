@@ -59,6 +59,13 @@ flexflow_tensor_t flexflow_model_add_concat(flexflow_model_t m, int n, const fle
   for (int i = 0; i < n; i++) v.push_back(*T(ins[i]));
   return wrap(M(m)->concat(n, v.data(), axis, name));
 }
+flexflow_tensor_t flexflow_model_add_flat(flexflow_model_t m, flexflow_tensor_t in, const char* name) { return wrap(M(m)->flat(*T(in), name)); }
+flexflow_tensor_t flexflow_model_add_transpose(flexflow_model_t m, flexflow_tensor_t in, int n, const int* perm, const char* name) {
+  return wrap(M(m)->transpose(*T(in), dims_vec(perm, n), name));
+}
+flexflow_tensor_t flexflow_model_add_reshape(flexflow_model_t m, flexflow_tensor_t in, int n, const int* shape, const char* name) {
+  return wrap(M(m)->reshape(*T(in), dims_vec(shape, n), name));
+}
 flexflow_tensor_t flexflow_model_add_batch_matmul(flexflow_model_t m, flexflow_tensor_t a, flexflow_tensor_t b, int asd, int bsd) {
   return wrap(M(m)->batch_matmul(*T(a), *T(b), asd, bsd));
 }

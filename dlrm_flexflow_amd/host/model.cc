@@ -335,6 +335,9 @@ std::string FFModel::get_operator_type_name(OperatorType type) const {
     case OP_EMBEDDING: return "Embedding";
     case OP_CONCAT: return "Concat";
     case OP_BATCHMATMUL: return "BatchMatmul";
+    case OP_TRANSPOSE: return "Transpose";
+    case OP_RESHAPE: return "Reshape";
+    case OP_FLAT: return "Flat";
     default: return "Unknown";
   }
 }
@@ -761,6 +764,104 @@ void BatchMatmul::backward(const FFModel& ff) {
 }
 
 // =============================================================================================
+// Transpose / Reshape / Flat [ref: src/ops/transpose.cu, reshape.cu, flat.cu]
+// =============================================================================================
+Transpose::Transpose(FFModel& model, const Tensor& input, const std::vector<int>& _perm, const char* name)
+    : Op(model, OP_TRANSPOSE, name, 1, &input) {
+  const int nd = input.numDim;
+  if ((int)_perm.size() != nd) die("%s: perm has %zu entries for a %d-D tensor", this->name, _perm.size(), nd);
+  if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
+  if (_perm[0] != 0) die("%s: the batch dimension must stay outermost (it is sharded over ranks)", this->name);
+  outputs[0].numDim = nd;
+  for (int i = 0; i < nd; i++) {
+    perm[i] = _perm[i];
+    if (perm[i] < 0 || perm[i] >= nd) die("%s: bad perm", this->name);
+    outputs[0].adim[nd - 1 - i] = input.adim[nd - 1 - perm[i]];   // natural dim i of the output = natural dim perm[i] of the input
+  }
+}
+namespace {
+void natural_local_dims(const Tensor& t, const FFModel& ff, int64_t* d) {
+  for (int i = 0; i < t.numDim; i++) d[i] = t.adim[t.numDim - 1 - i];
+  d[0] = d[0] / ff.world_size;   // batch-sharded
+}
+bool contiguous(const TensorImpl* im, const Tensor& t) { return im->pieces.empty() && im->ld == t.adim[0]; }
+}  // namespace
+void Transpose::forward(const FFModel& ff) {
+  const Tensor &x = inputs[0], &y = outputs[0];
+  if (!contiguous(x.impl, x) || !contiguous(y.impl, y)) die("%s: operands must be contiguous", name);
+  int64_t d[MAX_TENSOR_DIM];
+  natural_local_dims(x, ff, d);
+  ff.check(ff.api->ffh_transpose_fwd(ff.ctx, (float*)y.impl->ptr, (const float*)x.impl->ptr, x.numDim, d, perm, ff.stream), name);
+}
+void Transpose::backward(const FFModel& ff) {
+  const Tensor &x = inputs[0], &y = outputs[0];
+  if (!x.impl->grad) return;
+  if (x.impl->grad_ld != x.adim[0] || y.impl->grad_ld != y.adim[0]) die("%s: gradients must be contiguous", name);
+  int64_t d[MAX_TENSOR_DIM];
+  natural_local_dims(x, ff, d);
+  ff.check(ff.api->ffh_transpose_bwd(ff.ctx, x.impl->grad, y.impl->grad, x.numDim, d, perm, ff.stream), name);
+}
+
+Reshape::Reshape(FFModel& model, OperatorType type, const Tensor& input, const std::vector<int>& shape, const char* name)
+    : Op(model, type, name, 1, &input) {
+  if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
+  size_t vol = 1;
+  for (int v : shape) vol *= (size_t)v;
+  if (vol != input.get_volume()) die("%s: %zu elements cannot be viewed as %zu", this->name, input.get_volume(), vol);
+  if (shape.empty() || (int)shape.size() > MAX_TENSOR_DIM) die("%s: 1..%d dimensions", this->name, MAX_TENSOR_DIM);
+  if (shape[0] != input.adim[input.numDim - 1]) die("%s: the batch dimension must be preserved (it is sharded over ranks)", this->name);
+  outputs[0].numDim = (int)shape.size();
+  for (size_t i = 0; i < shape.size(); i++) outputs[0].adim[shape.size() - 1 - i] = shape[i];
+}
+void Reshape::forward(const FFModel& ff) {
+  const Tensor &x = inputs[0], &y = outputs[0];
+  if (!contiguous(y.impl, y)) die("%s: output must be contiguous", name);
+  const int64_t rows = x.impl->rows_local, cols = x.adim[0];
+  if (contiguous(x.impl, x)) {   // copy_kernel [ref: src/ops/reshape.cu:203-210, src/ops/flat.cu:117-124]
+    ff.check(ff.api->ffh_memcpy_d2d(ff.ctx, y.impl->ptr, x.impl->ptr, (size_t)rows * cols * sizeof(float), ff.stream), name);
+  } else {                       // input lives as a column slice / pieces of other buffers: gather it with the concat kernel
+    std::vector<const float*> ptrs; std::vector<int64_t> blks, lds;
+    if (!x.impl->pieces.empty()) for (const TensorPiece& p : x.impl->pieces) { ptrs.push_back(p.ptr); blks.push_back(p.cols); lds.push_back(p.ld); }
+    else { ptrs.push_back((const float*)x.impl->ptr); blks.push_back(cols); lds.push_back(x.impl->ld); }
+    ff.check(ff.api->ffh_concat_fwd(ff.ctx, (float*)y.impl->ptr, cols, ptrs.data(), blks.data(), lds.data(), (int)ptrs.size(), rows, ff.stream), name);
+  }
+}
+void Reshape::backward(const FFModel& ff) {
+  const Tensor &x = inputs[0], &y = outputs[0];
+  if (!x.impl->grad && x.impl->pieces.empty()) return;
+  const int64_t rows = x.impl->rows_local, cols = x.adim[0];
+  if (x.impl->pieces.empty() && x.impl->grad_ld == cols) {   // in_grad += out_grad
+    ff.check(ff.api->ffh_add_scaled(ff.ctx, x.impl->grad, y.impl->grad, rows * cols, 1.0f, ff.stream), name);
+  } else {
+    std::vector<float*> ptrs; std::vector<int64_t> blks, lds;
+    if (!x.impl->pieces.empty()) for (const TensorPiece& p : x.impl->pieces) { ptrs.push_back(p.grad); blks.push_back(p.cols); lds.push_back(p.ld); }
+    else { ptrs.push_back(x.impl->grad); blks.push_back(cols); lds.push_back(x.impl->grad_ld); }
+    ff.check(ff.api->ffh_concat_bwd(ff.ctx, y.impl->grad, cols, ptrs.data(), blks.data(), lds.data(), (int)ptrs.size(), rows, ff.stream), name);
+  }
+}
+
+Tensor FFModel::transpose(const Tensor& input, const std::vector<int>& perm, const char* name) {
+  Transpose* t = new Transpose(*this, input, perm, name);
+  t->layer_index = (int)layers.size();
+  layers.push_back(t);
+  return t->outputs[0];
+}
+Tensor FFModel::reshape(const Tensor& input, const std::vector<int>& shape, const char* name) {
+  Reshape* r = new Reshape(*this, OP_RESHAPE, input, shape, name);
+  r->layer_index = (int)layers.size();
+  layers.push_back(r);
+  return r->outputs[0];
+}
+Tensor FFModel::flat(const Tensor& input, const char* name) {
+  // [batch][rest...] -> [batch][prod(rest)] [ref: src/ops/flat.cu:31-60]
+  const int batch = input.adim[input.numDim - 1];
+  Reshape* r = new Reshape(*this, OP_FLAT, input, {batch, (int)(input.get_volume() / (size_t)batch)}, name);
+  r->layer_index = (int)layers.size();
+  layers.push_back(r);
+  return r->outputs[0];
+}
+
+// =============================================================================================
 // SGDOptimizer [ref: src/runtime/optimizer.cc:43-189]
 // =============================================================================================
 SGDOptimizer::SGDOptimizer(const FFModel* _model, double _lr, double _momentum, bool _nesterov, double _wd)
@@ -1007,7 +1108,8 @@ void FFModel::allocate() {
   need_zero_act_grads = false;
   for (Op* op : layers) {
     if (consumers[op->outputs[0].impl] > 1) need_zero_act_grads = true;           // several ops add into its gradient
-    if (op->op_type == OP_BATCHMATMUL) need_zero_act_grads = true;                // accumulates into both operands
+    if (op->op_type == OP_BATCHMATMUL || op->op_type == OP_TRANSPOSE || op->op_type == OP_RESHAPE || op->op_type == OP_FLAT)
+      need_zero_act_grads = true;                                                // these accumulate into their operands' gradients
     if (Linear* li = dynamic_cast<Linear*>(op)) li->dx_overwrite = consumers[li->inputs[0].impl] == 1;
     if (Concat* c = dynamic_cast<Concat*>(op))
       for (int i = 0; i < c->numInputs; i++) {

@@ -286,6 +286,16 @@ int ffh_bmm_bwd(ffh_ctx* ctx, const float* o_grad, const float* a, float* a_grad
                 const float* b, float* b_grad, int m, int n, int k, int64_t batch, ffh_stream s);
 
 /* ------------------------------------------------------------------ */
+/* Transpose (the reference-op composition of the dot interaction) */
+/* ------------------------------------------------------------------ */
+/* Transpose::forward_kernel [ref: src/ops/transpose.cu:195-251]: out = permute(in): out.dims[i] = in.dims[perm[i]]
+ * (dims and perm in natural order, batch first; ndim <= 4).  The reference kernel adds into the output
+ * (`out += out*beta + in` with beta = 0, a slip); the restated semantics is the plain permutation. */
+int ffh_transpose_fwd(ffh_ctx* ctx, float* out, const float* in, int ndim, const int64_t* in_dims, const int* perm, ffh_stream s);
+/* Transpose::backward_kernel [ref: src/ops/transpose.cu:262-330]: in_grad += inverse-permute(out_grad) */
+int ffh_transpose_bwd(ffh_ctx* ctx, float* in_grad, const float* out_grad, int ndim, const int64_t* in_dims, const int* perm, ffh_stream s);
+
+/* ------------------------------------------------------------------ */
 /* Loss, metrics, optimizer                                           */
 /* ------------------------------------------------------------------ */
 /* mean_squared_error_avg_loss_backward + scale_kernel(0, scale)
@@ -330,7 +340,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) \
   X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_concat_fwd) X(ffh_concat_bwd) \
-  X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
+  X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_add_scaled)
 
 #endif /* FF_HIP_H_ */

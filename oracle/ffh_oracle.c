@@ -538,6 +538,36 @@ int ffh_bmm_bwd(ffh_ctx* c, const float* og, const float* a, float* ag, const fl
 }
 
 /* ------------------------------------------------------------------ */
+/* Transpose                                                          */
+/* ------------------------------------------------------------------ */
+/* transpose_simple_kernel [ref: src/ops/transpose.cu:195-251]: every output index is decomposed by the output
+ * strides and re-assembled with the permuted input strides.  dims/perm here are in natural order. */
+static int transpose_impl(ffh_ctx* c, float* dst, const float* src, int nd, const int64_t* in_dims, const int* perm, int backward) {
+  if (nd < 1 || nd > 4) return fail(c, FFH_ERR_BAD_ARG, "transpose: ndim must be 1..4");
+  int seen[4] = {0, 0, 0, 0};
+  int64_t od[4], is[4], vol = 1;
+  for (int i = 0; i < nd; i++) {
+    if (perm[i] < 0 || perm[i] >= nd || seen[perm[i]] || in_dims[i] <= 0) return fail(c, FFH_ERR_BAD_ARG, "transpose: bad perm/dims");
+    seen[perm[i]] = 1;
+  }
+  for (int i = nd - 1; i >= 0; i--) { is[i] = (i == nd - 1) ? 1 : is[i + 1] * in_dims[i + 1]; vol *= in_dims[i]; }
+  for (int i = 0; i < nd; i++) od[i] = in_dims[perm[i]];
+  for (int64_t o = 0; o < vol; o++) {
+    int64_t t = o, ii = 0;
+    for (int i = nd - 1; i >= 0; i--) { const int64_t q = t % od[i]; t /= od[i]; ii += q * is[perm[i]]; }
+    if (backward) dst[ii] += src[o];      /* in_grad[ii] += out_grad[o] */
+    else dst[o] = src[ii];
+  }
+  return FFH_OK;
+}
+int ffh_transpose_fwd(ffh_ctx* c, float* out, const float* in, int nd, const int64_t* in_dims, const int* perm, ffh_stream s) {
+  (void)s; return transpose_impl(c, out, in, nd, in_dims, perm, 0);
+}
+int ffh_transpose_bwd(ffh_ctx* c, float* in_grad, const float* out_grad, int nd, const int64_t* in_dims, const int* perm, ffh_stream s) {
+  (void)s; return transpose_impl(c, in_grad, out_grad, nd, in_dims, perm, 1);
+}
+
+/* ------------------------------------------------------------------ */
 /* Loss / metrics / optimizer                                         */
 /* ------------------------------------------------------------------ */
 /* mean_squared_error_avg_loss_backward [ref: src/loss_functions/loss_functions.cu:65-76]

@@ -49,6 +49,19 @@ def test_launch_worker_threads_on_cpu(monkeypatch):
     m.close()
 
 
+def test_dot_interaction_matches_torch():
+    """--arch-interaction-op dot (Reshape / Transpose / BatchMatmul / Flat composition):
+    predictions and every parameter after warm-up + 2 steps against a torch model, 1e-5."""
+    import dot_helpers
+    out, got, exp = dot_helpers.run_dot_dlrm(H.oracle_backend(), steps=2)
+    for g, e in out:
+        for k in g:
+            np.testing.assert_allclose(g[k], e[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    assert set(got) == set(exp)
+    for k in got:
+        np.testing.assert_allclose(got[k], exp[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
 def test_fused_and_dense_embedding_paths_agree():
     """The fused sparse update and the reference's dense zero/scatter/sweep path give the same
     tables (1e-6: only the summation order inside duplicate rows differs)."""
@@ -94,8 +107,8 @@ def test_driver_rejects_what_the_reference_rejects():
     exe = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
     base = [exe, "--backend", H.oracle_backend(), "-b", "8", "--arch-embedding-size", "10-10", "--arch-sparse-feature-size", "4",
             "--arch-mlp-bot", "3-4", "--arch-mlp-top", "12-1"]
-    r = subprocess.run(base + ["--arch-interaction-op", "dot"], capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "only 'cat'" in r.stderr
+    r = subprocess.run(base + ["--arch-interaction-op", "sum"], capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "'cat' or 'dot'" in r.stderr
     r = subprocess.run(base + ["--dataset", "x.h5"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "HDF5" in r.stderr
     r = subprocess.run(base + ["-ll:gpu", "4"], capture_output=True, text=True, timeout=60)

@@ -95,6 +95,18 @@ def test_driver_kaggle_shape_hip_equals_oracle_backend(hip, trace):
         np.testing.assert_allclose(g[k], c[k], rtol=2e-5, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("trace", [False, True])
+def test_dot_interaction_matches_torch_on_gpu(hip, trace):
+    """--arch-interaction-op dot on the MI355X: Reshape / Transpose / BatchMatmul / Flat composition vs torch."""
+    import dot_helpers
+    out, got, exp = dot_helpers.run_dot_dlrm(HIP, steps=3, trace=trace)
+    for g, e in out:
+        for k in g:
+            np.testing.assert_allclose(g[k], e[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    for k in got:
+        np.testing.assert_allclose(got[k], exp[k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
 def test_dlrm_executable_on_gpu(hip):
     exe = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
     r = subprocess.run([exe] + DRIVER_C1 + ["--epochs", "3"], capture_output=True, text=True, timeout=300)

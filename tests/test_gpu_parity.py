@@ -454,6 +454,22 @@ def test_bmm_golden_and_harness_shape(hip, oracle):
     np.testing.assert_allclose(host(o), oracle.bmm_fwd(z, zt), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("dims,perm", [((64, 27, 128), (0, 2, 1)), ((5, 33, 70), (0, 2, 1)), ((3, 4, 5, 6), (0, 3, 1, 2)),
+                                       ((17, 9), (1, 0)), ((2, 3, 4), (2, 0, 1)), ((2048, 27, 16), (0, 2, 1))])
+def test_transpose_bit_exact(hip, dims, perm):
+    """Transpose forward is a pure permutation (bit-exact vs numpy); backward accumulates the inverse permutation."""
+    rng = np.random.default_rng(len(dims))
+    a = rng.uniform(-1, 1, dims).astype(np.float32)
+    out = torch.empty([dims[p] for p in perm], device=DEV)
+    hip.transpose("ffh_transpose_fwd", out, dev(a), dims, perm)
+    assert bits_equal(host(out), np.ascontiguousarray(np.transpose(a, perm)))
+    g = rng.uniform(-1, 1, out.shape).astype(np.float32)
+    ig0 = rng.uniform(-1, 1, dims).astype(np.float32)
+    ig = dev(ig0)
+    hip.transpose("ffh_transpose_bwd", ig, dev(g), dims, perm)
+    np.testing.assert_array_equal(host(ig), ig0 + np.transpose(g, np.argsort(perm)))
+
+
 def test_sgd_mse_metrics(hip, oracle):
     g = golden("sgd_mse_torch")
     for k in range(int(g["n_cases"])):
@@ -497,11 +513,12 @@ def test_sgd_mse_metrics(hip, oracle):
 # ---------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties
 # ---------------------------------------------------------------------------
-def test_full_size_terabyte_shape_properties(hip, ws):
-    """Criteo-Terabyte per-table shape (B = 32768, D = 128, R = 39,884,406 rows = 20.4 GB):
+@pytest.mark.parametrize("B", [32768, 65536])
+def test_full_size_terabyte_shape_properties(hip, ws, B):
+    """Criteo-Terabyte / MLPerf per-table shape (B = 32768 and 65536, D = 128, R = 39,884,406 rows = 20.4 GB):
     gather == pure row copy (checked with torch indexing), fused update touches exactly the
     indexed rows, is linear in the gradient, and leaves every other row's bits alone."""
-    B, D, R, lr = 32768, 128, 39884406, 0.01
+    D, R, lr = 128, 39884406, 0.01
     W = torch.empty(R, D, device=DEV)
     hip.call("ffh_init_uniform", W, R * D, 1, -(1.0 / R) ** 0.5, (1.0 / R) ** 0.5, None)
     idx = torch.empty(B, 1, dtype=torch.int64, device=DEV)
