@@ -168,6 +168,79 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const SortArgs
   for (int d = threadIdx.x; d < radix; d += kSortThreads) out[d] = s_hist[d];
 }
 
+// exclusive scan of the per-digit totals over digits (digit d = threadIdx.x + q*256) plus `before_d`, then the
+// per-wave starting offsets: s_off[w][d] (in: count of digit d in wave w's entries) becomes the first
+// destination of wave w's entries with digit d.
+__device__ __forceinline__ void sort_scan_offsets(const uint32_t (&all_d)[2], const uint32_t (&before_d)[2], int radix,
+                                                  uint32_t (*s_off)[kMaxRadix], uint32_t* s_scan, uint32_t* s_wsum) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t carry = 0;
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (q * kSortThreads >= radix) break;
+    uint32_t v = all_d[q];
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t n = __shfl_up(incl, o);
+      if (lane >= o) incl += n;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w2 = 0; w2 < wave; w2++) woff += s_wsum[w2];
+    const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    const int d = threadIdx.x + q * kSortThreads;
+    if (d < radix) s_scan[d] = carry + woff + incl - v + before_d[q];
+    carry += total;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    const int d = threadIdx.x + q * kSortThreads;
+    if (d < radix) {
+      uint32_t run = s_scan[d];
+#pragma unroll
+      for (int w2 = 0; w2 < 4; w2++) {
+        const uint32_t cnt = s_off[w2][d];
+        s_off[w2][d] = run;
+        run += cnt;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// stable ranking of a wave's E x 64 entries, 64 at a time: the lanes holding the same digit find each other with
+// `bits` ballots (a match-any), the rank inside the group is a popcount of the lower lanes, and the group's
+// lowest lane advances the wave's running offset in LDS.  kd / pd may point to LDS or to global memory.
+template <int E>
+__device__ __forceinline__ void sort_rank_and_scatter(const uint32_t (&key)[E], const uint32_t (&pos)[E], const bool (&valid)[E],
+                                                      int shift, int bits, uint32_t mask, uint32_t* wave_off, uint32_t* kd, uint32_t* pd) {
+  const int lane = threadIdx.x & 63;
+  volatile uint32_t* my_off = wave_off;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const uint32_t d = (key[e] >> shift) & mask;
+    unsigned long long peers = __ballot(valid[e]);
+    for (int bit = 0; bit < bits; bit++) {
+      const bool one = (d >> bit) & 1u;
+      const unsigned long long bal = __ballot(one);
+      peers &= one ? bal : ~bal;
+    }
+    if (valid[e]) {
+      const uint32_t base = my_off[d];
+      const uint32_t rank = __popcll(peers & lt_mask);
+      const uint32_t dest = base + rank;
+      kd[dest] = key[e];
+      pd[dest] = pos[e];
+      if (rank == 0) my_off[d] = base + __popcll(peers);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // stable scatter.  Each wave owns 512 consecutive entries of the tile and ranks them 64 at a
 // time: the lanes holding the same digit find each other with `bits` ballots (a match-any),
 // the rank inside the group is a popcount of the lower lanes, and the group's lowest lane
@@ -226,67 +299,9 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
       all_d[q] = all; before_d[q] = before;
     }
   }
-  // exclusive scan of all_d over digits (digit d = threadIdx.x + q*256): scan q=0 half, then q=1 half
-  uint32_t carry = 0;
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    if (q * kSortThreads >= radix) break;
-    uint32_t v = all_d[q];
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t n = __shfl_up(incl, o);
-      if (lane >= o) incl += n;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w2 = 0; w2 < wave; w2++) woff += s_wsum[w2];
-    const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    const int d = threadIdx.x + q * kSortThreads;
-    if (d < radix) s_scan[d] = carry + woff + incl - v + before_d[q];
-    carry += total;
-    __syncthreads();
-  }
-  // per-wave starting offsets: base + counts of the earlier waves
-#pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int d = threadIdx.x + q * kSortThreads;
-    if (d < radix) {
-      uint32_t run = s_scan[d];
-#pragma unroll
-      for (int w2 = 0; w2 < 4; w2++) {
-        const uint32_t cnt = s_off[w2][d];
-        s_off[w2][d] = run;
-        run += cnt;
-      }
-    }
-  }
-  __syncthreads();
-
-  volatile uint32_t* my_off = s_off[wave];
-  uint32_t* kd = a.keys_dst + (int64_t)t * a.N;
-  uint32_t* pd = a.pos_dst + (int64_t)t * a.N;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int e = 0; e < kSortPerThread; e++) {
-    const uint32_t d = (key[e] >> a.shift) & mask;
-    unsigned long long peers = __ballot(valid[e]);
-    for (int bit = 0; bit < a.bits; bit++) {
-      const bool one = (d >> bit) & 1u;
-      const unsigned long long bal = __ballot(one);
-      peers &= one ? bal : ~bal;
-    }
-    if (valid[e]) {
-      const uint32_t base = my_off[d];
-      const uint32_t rank = __popcll(peers & lt_mask);
-      const uint32_t dest = base + rank;
-      kd[dest] = key[e];
-      pd[dest] = pos[e];
-      if (rank == 0) my_off[d] = base + __popcll(peers);
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+  sort_scan_offsets(all_d, before_d, radix, s_off, s_scan, s_wsum);
+  sort_rank_and_scatter<kSortPerThread>(key, pos, valid, a.shift, a.bits, mask, s_off[wave], a.keys_dst + (int64_t)t * a.N,
+                                        a.pos_dst + (int64_t)t * a.N);
 }
 
 // ---------------------------------------------------------------------------
@@ -329,22 +344,27 @@ __device__ __forceinline__ void load_grad(float (&dst)[VEC], const float* rowp, 
   }
 }
 
-template <int VEC>
-__global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedArgs a) {
-  __shared__ uint32_t s_key[kRedTile + 2];     // [0] = key before the tile, [1+i], [1+n] = key after
-  __shared__ uint32_t s_pos[kRedTile];
-  __shared__ uint16_t s_start[kRedTile + 1];
-  __shared__ uint32_t s_cnt[(kRedTile / 64) + 1];
-  __shared__ uint2    s_meta[2 * kRedChunksPerTile];   // 64 at FFH_EMB_CHUNK = 32
+struct RedShared {
+  uint32_t key[kRedTile + 2];     // [0] = key before the tile, [1+i], [1+n] = key after
+  uint32_t pos[kRedTile];
+  uint16_t start[kRedTile + 1];
+  uint32_t cnt[(kRedTile / 64) + 1];
+  uint2    meta[2 * kRedChunksPerTile];   // 64 at FFH_EMB_CHUNK = 32
+};
 
-  const int tix = blockIdx.y;
-  const ffh_emb_table tb = a.t[tix];
-  const int64_t N = a.N;
-  const int tile = a.tile;
-  const int64_t tile0 = (int64_t)blockIdx.x * tile;
+// one tile of one table; `partial_t` / `meta_t` are the table's level-0 slot arrays
+template <int VEC>
+__device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const uint32_t* keys, const uint32_t* posg,
+                                                 float* partial_t, uint2* meta_t, int64_t N, int nchunks, int tile, int tile_index,
+                                                 int L, int D_, bool avg_, float lr_, RedShared& sh) {
+  uint32_t* s_key = sh.key;
+  uint32_t* s_pos = sh.pos;
+  uint16_t* s_start = sh.start;
+  uint32_t* s_cnt = sh.cnt;
+  uint2* s_meta = sh.meta;
+  struct { int64_t N; int nchunks, L, D, avg; float lr; } a = {N, nchunks, L, D_, avg_ ? 1 : 0, lr_};
+  const int64_t tile0 = (int64_t)tile_index * tile;
   const int n = (int)((N - tile0) < tile ? (N - tile0) : tile);
-  const uint32_t* keys = a.keys[a.parity[tix]] + (int64_t)tix * N;
-  const uint32_t* posg = a.pos[a.parity[tix]] + (int64_t)tix * N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   for (int i = threadIdx.x; i < n; i += kRedThreads) {
@@ -412,7 +432,7 @@ __global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedAr
       const bool single = head && tail;
       if (!single && c0 == 0) s_meta[slot_local] = make_uint2(head ? kMetaFirst : kMetaCont, key);
       float* wrow = tb.weight + (int64_t)key * D;
-      float* prow = a.partial + (((int64_t)tix * a.nchunks + chunk) * 2 + ((s % FFH_EMB_CHUNK) ? 1 : 0)) * D;
+      float* prow = partial_t + (chunk * 2 + ((s % FFH_EMB_CHUNK) ? 1 : 0)) * D;
       for (int c = c0; c < nvec; c += lpr) {
         float acc[VEC];
         load_grad<VEC>(acc, tb.io + (int64_t)(s_pos[s] / a.L) * tb.ld, c, Lf, avg);
@@ -452,8 +472,17 @@ __global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedAr
   __syncthreads();
   if (threadIdx.x < metas) {
     const int64_t slot = (tile0 / FFH_EMB_CHUNK) * 2 + threadIdx.x;
-    if (slot < 2 * (int64_t)a.nchunks) a.meta[(int64_t)tix * 2 * a.nchunks + slot] = s_meta[threadIdx.x];
+    if (slot < 2 * (int64_t)a.nchunks) meta_t[slot] = s_meta[threadIdx.x];
   }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedArgs a) {
+  __shared__ RedShared sh;
+  const int tix = blockIdx.y;
+  reduce_tile_body<VEC>(a.t[tix], a.keys[a.parity[tix]] + (int64_t)tix * a.N, a.pos[a.parity[tix]] + (int64_t)tix * a.N,
+                        a.partial + (int64_t)tix * 2 * a.nchunks * a.D, a.meta + (int64_t)tix * 2 * a.nchunks, a.N, a.nchunks, a.tile,
+                        (int)blockIdx.x, a.L, a.D, a.avg != 0, a.lr, sh);
 }
 
 // step 3: fold.  A row whose run crosses block boundaries left one partial per block at level k (slot 2b:
@@ -472,31 +501,27 @@ struct FoldArgs {
   float lr;
 };
 
+// one table; the lane-groups numbered group0, group0+ngroups, ... share the slots
 template <int VEC>
-__global__ __launch_bounds__(256) void emb_sgd_fold_kernel(const FoldArgs a) {
-  const int tix = blockIdx.y;
-  const ffh_emb_table tb = a.t[tix];
-  const int D = a.D;
+__device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const float* part, const uint2* meta, float* pout_t, uint2* mout_t,
+                                                int nin, int ratio, int D, float lr, int64_t group0, int64_t ngroups) {
   const int nvec = D / VEC;
   const int lpr = nvec < 64 ? nvec : 64;
   const int rpw = 64 / lpr;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   const int rsub = lane / lpr;
   const int c0 = lane - rsub * lpr;
   if (rsub >= rpw) return;
-  const int64_t nslots = 2 * (int64_t)a.nin;
-  const uint2* meta = a.min + (int64_t)tix * nslots;
-  const float* part = a.pin + (int64_t)tix * nslots * D;
-  const int64_t groups = (int64_t)gridDim.x * (blockDim.x >> 6) * rpw;
-  for (int64_t slot = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * rpw + rsub; slot < nslots; slot += groups) {
+  const int64_t nslots = 2 * (int64_t)nin;
+  for (int64_t slot = group0; slot < nslots; slot += ngroups) {
     const uint2 m = meta[slot];
     if (m.x == kMetaNone) continue;
     const int64_t b = slot >> 1;
-    const bool at_block_start = a.ratio > 0 && (b % a.ratio == 0) && ((slot & 1) == 0);
+    const bool at_block_start = ratio > 0 && (b % ratio == 0) && ((slot & 1) == 0);
     if (!(m.x == kMetaFirst || (m.x == kMetaCont && at_block_start))) continue;   // consumed by the walk that starts left of it
-    const int64_t B = a.ratio > 0 ? b / a.ratio : 0;
-    int64_t bend = a.ratio > 0 ? (B + 1) * (int64_t)a.ratio : (int64_t)a.nin;
-    if (bend > a.nin) bend = a.nin;
+    const int64_t B = ratio > 0 ? b / ratio : 0;
+    int64_t bend = ratio > 0 ? (B + 1) * (int64_t)ratio : (int64_t)nin;
+    if (bend > nin) bend = nin;
     // length of the walk (same for every column chunk)
     int64_t b2 = b + 1;
     while (b2 < bend) {
@@ -505,13 +530,13 @@ __global__ __launch_bounds__(256) void emb_sgd_fold_kernel(const FoldArgs a) {
       b2++;
     }
     bool cont_after = false;
-    if (b2 == bend && bend < a.nin) { const uint2 m3 = meta[2 * bend]; cont_after = (m3.x == kMetaCont && m3.y == m.y); }
+    if (b2 == bend && bend < nin) { const uint2 m3 = meta[2 * bend]; cont_after = (m3.x == kMetaCont && m3.y == m.y); }
     const bool head = m.x == kMetaFirst;
     const bool complete = head && !cont_after;
     const int64_t oslot = 2 * B + (at_block_start ? 0 : 1);
-    if (!complete && c0 == 0) a.mout[(int64_t)tix * 2 * a.nout + oslot] = make_uint2(head ? kMetaFirst : kMetaCont, m.y);
+    if (!complete && c0 == 0) mout_t[oslot] = make_uint2(head ? kMetaFirst : kMetaCont, m.y);
     float* wrow = tb.weight + (int64_t)m.y * D;
-    float* orow = a.pout + ((int64_t)tix * 2 * a.nout + oslot) * D;
+    float* orow = pout_t + oslot * D;
     for (int c = c0; c < nvec; c += lpr) {
       float acc[VEC];
       load_grad<VEC>(acc, part + slot * D, c, 1.0f, false);
@@ -534,17 +559,140 @@ __global__ __launch_bounds__(256) void emb_sgd_fold_kernel(const FoldArgs a) {
       if (complete) {
         if (VEC == 4) {
           float4 w = reinterpret_cast<float4*>(wrow)[c];
-          w.x = __fmaf_rn(-a.lr, acc[0], w.x); w.y = __fmaf_rn(-a.lr, acc[1], w.y);
-          w.z = __fmaf_rn(-a.lr, acc[2], w.z); w.w = __fmaf_rn(-a.lr, acc[3], w.w);
+          w.x = __fmaf_rn(-lr, acc[0], w.x); w.y = __fmaf_rn(-lr, acc[1], w.y);
+          w.z = __fmaf_rn(-lr, acc[2], w.z); w.w = __fmaf_rn(-lr, acc[3], w.w);
           reinterpret_cast<float4*>(wrow)[c] = w;
         } else {
-          wrow[c] = __fmaf_rn(-a.lr, acc[0], wrow[c]);
+          wrow[c] = __fmaf_rn(-lr, acc[0], wrow[c]);
         }
       } else {
         if (VEC == 4) reinterpret_cast<float4*>(orow)[c] = make_float4(acc[0], acc[1], acc[2], acc[3]);
         else orow[c] = acc[0];
       }
     }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void emb_sgd_fold_kernel(const FoldArgs a) {
+  const int tix = blockIdx.y;
+  const int nvec = a.D / VEC;
+  const int lpr = nvec < 64 ? nvec : 64;
+  const int rpw = 64 / lpr;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t group0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * rpw + lane / lpr;
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x >> 6) * rpw;
+  fold_table_body<VEC>(a.t[tix], a.pin + (int64_t)tix * 2 * a.nin * a.D, a.min + (int64_t)tix * 2 * a.nin,
+                       a.pout + (int64_t)tix * 2 * a.nout * a.D, a.mout + (int64_t)tix * 2 * a.nout, a.nin, a.ratio, a.D, a.lr, group0, ngroups);
+}
+
+// ---------------------------------------------------------------------------
+// small batches (N = batch*bag <= 2048 per table, e.g. the 2048-sample Criteo-Kaggle step): the whole
+// chain -- LDS-resident radix sort, segmented reduce, both folds -- in ONE launch, one workgroup per
+// table.  At this size the ten-launch pipeline is pure launch latency (and host issue time); the
+// arithmetic and its order are identical (same device bodies), so the result is bit-identical too.
+// ---------------------------------------------------------------------------
+constexpr int kSmallMax = 2048;
+struct SmallArgs {
+  ffh_emb_table t[FFH_MAX_TABLES];
+  uint8_t   npass[FFH_MAX_TABLES];
+  uint32_t* keys;      // [nt][N] sorted row ids   (workspace)
+  uint32_t* pos;       // [nt][N] their positions
+  float*    partial0;  uint2* meta0;   // level-0 slots [nt][2*nch0]
+  float*    partial1;  uint2* meta1;   // level-1 slots [nt][2*nch1]
+  int64_t   N;
+  int nch0, nch1, rb, L, D, avg;
+  float lr;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kSortThreads) void emb_sgd_small_kernel(const SmallArgs a) {
+  constexpr int E = kSmallMax / kSortThreads;   // 8 entries per thread, wave w owns [512w, 512w+512)
+  __shared__ uint32_t s_k[kSmallMax], s_p[kSmallMax];
+  __shared__ uint32_t s_off[4][kMaxRadix];
+  __shared__ uint32_t s_scan[kMaxRadix];
+  __shared__ uint32_t s_wsum[4];
+  __shared__ RedShared sh;
+  const int tix = blockIdx.x;
+  const ffh_emb_table tb = a.t[tix];
+  const int64_t N = a.N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int radix = 1 << a.rb;
+  const uint32_t mask = radix - 1;
+
+  uint32_t key[E], pos[E];
+  bool valid[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int i = wave * (kSmallMax / 4) + e * 64 + lane;
+    valid[e] = i < N;
+    key[e] = valid[e] ? (uint32_t)tb.idx[i] : 0u;
+    pos[e] = (uint32_t)i;
+  }
+  const int npass = a.npass[tix];
+  for (int p = 0; p < npass; p++) {
+    const int shift = p * a.rb;
+    for (int d = threadIdx.x; d < 4 * kMaxRadix; d += kSortThreads) (&s_off[0][0])[d] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; e++)
+      if (valid[e]) atomicAdd(&s_off[wave][(key[e] >> shift) & mask], 1u);
+    __syncthreads();
+    uint32_t all_d[2] = {0, 0};
+    const uint32_t before_d[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int d = threadIdx.x + q * kSortThreads;
+      if (d < radix) all_d[q] = s_off[0][d] + s_off[1][d] + s_off[2][d] + s_off[3][d];
+    }
+    sort_scan_offsets(all_d, before_d, radix, s_off, s_scan, s_wsum);
+    sort_rank_and_scatter<E>(key, pos, valid, shift, a.rb, mask, s_off[wave], s_k, s_p);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      const int i = wave * (kSmallMax / 4) + e * 64 + lane;
+      if (valid[e]) { key[e] = s_k[i]; pos[e] = s_p[i]; }
+    }
+    __syncthreads();
+  }
+  uint32_t* keys = a.keys + (int64_t)tix * N;
+  uint32_t* posg = a.pos + (int64_t)tix * N;
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int i = wave * (kSmallMax / 4) + e * 64 + lane;
+    if (valid[e]) { keys[i] = key[e]; posg[i] = pos[e]; }
+  }
+  uint2* m1 = a.meta1 + (int64_t)tix * 2 * a.nch1;
+  for (int i = threadIdx.x; i < 2 * a.nch1; i += kSortThreads) m1[i] = make_uint2(kMetaNone, 0);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  float* p0 = a.partial0 + (int64_t)tix * 2 * a.nch0 * a.D;
+  uint2* m0 = a.meta0 + (int64_t)tix * 2 * a.nch0;
+  const int ntiles = (int)((N + kRedTile - 1) / kRedTile);
+  for (int ti = 0; ti < ntiles; ti++) {
+    reduce_tile_body<VEC>(tb, keys, posg, p0, m0, N, a.nch0, kRedTile, ti, a.L, a.D, a.avg != 0, a.lr, sh);
+    __syncthreads();
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  const int nvec = a.D / VEC;
+  const int lpr = nvec < 64 ? nvec : 64;
+  const int rpw = 64 / lpr;
+  const int64_t group0 = (int64_t)wave * rpw + lane / lpr;
+  const int64_t ngroups = (int64_t)(kSortThreads >> 6) * rpw;
+  float* p1 = a.partial1 + (int64_t)tix * 2 * a.nch1 * a.D;
+  if (a.nch1 > 1) {
+    fold_table_body<VEC>(tb, p0, m0, p1, m1, a.nch0, FFH_EMB_CHUNK1 / FFH_EMB_CHUNK, a.D, a.lr, group0, ngroups);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    fold_table_body<VEC>(tb, p1, m1, p1, m1, a.nch1, 0, a.D, a.lr, group0, ngroups);
+  } else {
+    fold_table_body<VEC>(tb, p0, m0, p1, m1, a.nch0, 0, a.D, a.lr, group0, ngroups);
   }
 }
 
@@ -685,6 +833,30 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
   char* ws = (char*)c->ws;
   if (!aligned16(ws)) return ffh_fail(c, FFH_ERR_WORKSPACE, "embedding_bwd_sgd_fused: workspace must be 16-byte aligned");
 
+  if (N <= kSmallMax) {
+    // small-batch path: one launch, one workgroup per table (see emb_sgd_small_kernel)
+    int bits_s = 1;
+    while (bits_s < 32 && ((maxR - 1) >> bits_s) != 0) bits_s++;
+    const int passes_s = (bits_s + kMaxRadixBits - 1) / kMaxRadixBits;
+    const int rb_s = (bits_s + passes_s - 1) / passes_s;
+    SmallArgs sm;
+    memset(&sm, 0, sizeof sm);
+    for (int i = 0; i < nt; i++) {
+      sm.t[i] = tables[i];
+      int tb = 1;
+      while (tb < 32 && ((tables[i].num_entries - 1) >> tb) != 0) tb++;
+      sm.npass[i] = (uint8_t)((tb + rb_s - 1) / rb_s);
+    }
+    sm.keys = (uint32_t*)(ws + lay.keys_a); sm.pos = (uint32_t*)(ws + lay.pos_a);
+    sm.partial0 = (float*)(ws + lay.partial); sm.meta0 = (uint2*)(ws + lay.meta);
+    sm.partial1 = (float*)(ws + lay.partial1); sm.meta1 = (uint2*)(ws + lay.meta1);
+    sm.N = N; sm.nch0 = lay.nchunks; sm.nch1 = lay.nchunks1; sm.rb = rb_s; sm.L = L; sm.D = D;
+    sm.avg = aggr == FFH_AGGR_MODE_AVG ? 1 : 0; sm.lr = lr;
+    if (v4) hipLaunchKernelGGL((emb_sgd_small_kernel<4>), dim3(nt), dim3(kSortThreads), 0, as_stream(s), sm);
+    else hipLaunchKernelGGL((emb_sgd_small_kernel<1>), dim3(nt), dim3(kSortThreads), 0, as_stream(s), sm);
+    FFH_LAUNCH_CHECK(c, "emb_sgd_small_kernel");
+    return FFH_OK;
+  }
   // radix plan: digits of <= 9 bits covering bit_length(maxR-1); a table only runs the passes its own ids need
   int bits = 1;
   while (bits < 32 && ((maxR - 1) >> bits) != 0) bits++;

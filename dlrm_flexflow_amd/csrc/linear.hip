@@ -346,8 +346,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   }
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
   if (SPLITW) {
-    // the four k-slices of the tile: ((w0 + w1) + w2) + w3, each wave finishes 4 of the 16 registers
-    __shared__ float red[4 * 16 * 64];
+    // the four k-slices of the tile: ((w0 + w1) + w2) + w3, each wave finishes 4 of the 16 registers.
+    // The staging buffers are dead by now (the k loop ended on a barrier): reuse A's as the exchange area, so
+    // the kernel stays at 34 KB of LDS = four workgroups per CU (1024 tiles of a 2048 x 512 layer in ONE round).
+    static_assert(2 * BK * LA >= 4 * 16 * 64, "A staging area too small for the split-wave reduction");
+    float* red = &As[0][0];
 #pragma unroll
     for (int r = 0; r < 16; r++) red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
     __syncthreads();
