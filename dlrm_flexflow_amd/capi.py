@@ -26,6 +26,7 @@ AC_MODE_NONE, AC_MODE_RELU, AC_MODE_SIGMOID, AC_MODE_TANH, AC_MODE_GELU = 10, 11
 AGGR_MODE_NONE, AGGR_MODE_SUM, AGGR_MODE_AVG = 20, 21, 22
 MAX_TABLES = 64
 EMB_CHUNK, EMB_CHUNK1 = 32, 1024
+OPT_ZERO_GRAD = 1
 METRIC_ACCURACY, METRIC_MSE, METRIC_RMSE, METRIC_MAE = 1, 2, 4, 8
 
 P = C.c_void_p
@@ -108,6 +109,8 @@ _SIGS = {
     "ffh_mse_bwd": (I, [P, P, P, P, L, F, P]),
     "ffh_metrics_update": (I, [P, P, P, P, L, I, I, P]),
     "ffh_sgd_update": (I, [P, P, P, P, L, F, F, F, I, P]),
+    "ffh_sgd_update_ex": (I, [P, P, P, P, L, F, F, F, I, I, P]),
+    "ffh_adam_update": (I, [P, P, P, P, P, L, F, F, F, F, F, I, P]),
     "ffh_add_scaled": (I, [P, P, P, L, F, P]),
 }
 

@@ -253,8 +253,8 @@ int transpose_launch(ffh_ctx* c, float* dst, const float* src, int nd, const int
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ v,
-                                                  int64_t n, float lr, float wd, float mom, int nesterov) {
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ v,
+                                                  int64_t n, float lr, float wd, float mom, int nesterov, int zero_grad) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t nv = n / VEC;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
@@ -280,9 +280,58 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const f
     if (VEC == 4) {
       reinterpret_cast<float4*>(w)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
       if (mom > 0.f) reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       w[i] = wv[0];
       if (mom > 0.f) v[i] = vv[0];
+      if (zero_grad) g[i] = 0.f;
+    }
+  }
+}
+
+// adam_update [ref: src/runtime/optimizer_kernel.cu:206-226]; canonical rounding as stated in ff_hip.h
+template <int VEC>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n, float alpha_t, float b1, float b2, float wd, float eps, int zero_grad) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t nv = n / VEC;
+  const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    float wv[VEC], gv[VEC], mv[VEC], vv[VEC];
+    if (VEC == 4) {
+      const float4 a = reinterpret_cast<const float4*>(w)[i], b = reinterpret_cast<const float4*>(g)[i];
+      const float4 c = reinterpret_cast<const float4*>(m)[i], d = reinterpret_cast<const float4*>(v)[i];
+      wv[0] = a.x; wv[1] = a.y; wv[2] = a.z; wv[3] = a.w;
+      gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+      mv[0] = c.x; mv[1] = c.y; mv[2] = c.z; mv[3] = c.w;
+      vv[0] = d.x; vv[1] = d.y; vv[2] = d.z; vv[3] = d.w;
+    } else {
+      wv[0] = w[i]; gv[0] = g[i]; mv[0] = m[i]; vv[0] = v[i];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; k++) {
+      // plain IEEE operations (sqrtf and / are correctly rounded under hipcc's default
+      // -fhip-fp32-correctly-rounded-divide-sqrt); no contraction beyond the fmaf written out
+#pragma clang fp contract(off)
+      const float gt = fmaf(wd, wv[k], gv[k]);
+      const float t1 = omb1 * gt;
+      mv[k] = fmaf(b1, mv[k], t1);
+      const float t2 = omb2 * gt;
+      const float t3 = t2 * gt;
+      vv[k] = fmaf(b2, vv[k], t3);
+      const float num = alpha_t * mv[k];
+      const float den = sqrtf(vv[k]) + eps;
+      const float step = num / den;
+      wv[k] = wv[k] - step;
+    }
+    if (VEC == 4) {
+      reinterpret_cast<float4*>(w)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      reinterpret_cast<float4*>(m)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+      reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      w[i] = wv[0]; m[i] = mv[0]; v[i] = vv[0];
+      if (zero_grad) g[i] = 0.f;
     }
   }
 }
@@ -339,14 +388,34 @@ int ffh_mse_bwd_metrics(ffh_ctx* c, float* lg, const float* logit, const float* 
   return FFH_OK;
 }
 
-int ffh_sgd_update(ffh_ctx* c, float* w, const float* g, float* v, int64_t n, float lr, float wd, float mom, int nesterov, ffh_stream s) {
+int ffh_sgd_update_ex(ffh_ctx* c, float* w, float* g, float* v, int64_t n, float lr, float wd, float mom, int nesterov, int flags,
+                      ffh_stream s) {
   FFH_REQUIRE(c, n >= 0 && ((w && g) || n == 0), "sgd_update: bad args");
   FFH_REQUIRE(c, !(mom > 0.f) || v, "sgd_update: momentum needs V");
+  FFH_REQUIRE(c, (flags & ~FFH_OPT_ZERO_GRAD) == 0, "sgd_update: unknown flags");
   if (n == 0) return FFH_OK;
+  const int zg = (flags & FFH_OPT_ZERO_GRAD) ? 1 : 0;
   const bool vec = al16(w) && al16(g) && (!(mom > 0.f) || al16(v)) && (n % 4 == 0);
-  if (vec) hipLaunchKernelGGL((sgd_kernel<4>), dim3(ffh_grid(n / 4, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov);
-  else hipLaunchKernelGGL((sgd_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov);
+  if (vec) hipLaunchKernelGGL((sgd_kernel<4>), dim3(ffh_grid(n / 4, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov, zg);
+  else hipLaunchKernelGGL((sgd_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov, zg);
   FFH_LAUNCH_CHECK(c, "sgd_kernel");
+  return FFH_OK;
+}
+
+int ffh_sgd_update(ffh_ctx* c, float* w, const float* g, float* v, int64_t n, float lr, float wd, float mom, int nesterov, ffh_stream s) {
+  return ffh_sgd_update_ex(c, w, const_cast<float*>(g), v, n, lr, wd, mom, nesterov, 0, s);
+}
+
+int ffh_adam_update(ffh_ctx* c, float* w, float* g, float* m, float* v, int64_t n, float alpha_t, float b1, float b2, float wd, float eps,
+                    int flags, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && ((w && g && m && v) || n == 0), "adam_update: bad args");
+  FFH_REQUIRE(c, (flags & ~FFH_OPT_ZERO_GRAD) == 0, "adam_update: unknown flags");
+  if (n == 0) return FFH_OK;
+  const int zg = (flags & FFH_OPT_ZERO_GRAD) ? 1 : 0;
+  const bool vec = al16(w) && al16(g) && al16(m) && al16(v) && (n % 4 == 0);
+  if (vec) hipLaunchKernelGGL((adam_kernel<4>), dim3(ffh_grid(n / 4, 256)), dim3(256), 0, as_stream(s), w, g, m, v, n, alpha_t, b1, b2, wd, eps, zg);
+  else hipLaunchKernelGGL((adam_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, m, v, n, alpha_t, b1, b2, wd, eps, zg);
+  FFH_LAUNCH_CHECK(c, "adam_kernel");
   return FFH_OK;
 }
 

@@ -473,7 +473,7 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
     // split-K supplies the parallelism here, so the tile follows the amount of work (measured on MI355X):
     // big tiles for deep/wide products (arithmetic intensity), the split-wave form for the skinny DLRM layers
     const double work = (double)g.M * g.N * g.K;
-    cfg = work >= 3e9 && g.M >= 128 && g.N >= 128 ? 0 : (work >= 8e8 ? 1 : 2);
+    cfg = work >= 3e9 && g.M >= 128 && g.N >= 128 ? 0 : (work >= 4e8 ? 1 : 2);
   } else if (tiles128 >= 2 * c->num_cus && g.M >= 128 && g.N >= 128) cfg = 0;
   else if (tiles64 >= 2 * c->num_cus || g.K < 64) cfg = 1;
   else cfg = 2;
@@ -488,6 +488,8 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
     // split K over workgroups so that about two of them per CU are in flight; each split is a multiple of kSplitGran
     const int64_t tiles = (int64_t)gx * gy;
     int want = (int)((2LL * c->num_cus + tiles - 1) / tiles);
+    static const int forced_split = getenv("FFH_GEMM_SPLIT") ? atoi(getenv("FFH_GEMM_SPLIT")) : 0;   // tuning aid
+    if (forced_split > 0) want = forced_split;
     const int max_split = (g.K + 4 * kSplitGran - 1) / (4 * kSplitGran);
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;

@@ -79,6 +79,8 @@ def lib() -> C.CDLL:
         "flexflow_zero_initializer_create": (H, []), "flexflow_uniform_initializer_create": (H, [I, F, F]),
         "flexflow_norm_initializer_create": (H, [I, F, F]), "flexflow_glorot_uniform_initializer_create": (H, [I]),
         "flexflow_sgd_optimizer_create": (H, [H, D, D, B, D]), "flexflow_model_set_sgd_optimizer": (None, [H, H]),
+        "flexflow_adam_optimizer_create": (H, [H, D, D, D, D, D]), "flexflow_model_set_adam_optimizer": (None, [H, H]),
+        "flexflow_adam_optimizer_set_lr": (None, [H, D]),
         "flexflow_model_compile": (None, [H, I, IP, I, I]),
         "flexflow_model_init_layers": (None, [H]), "flexflow_model_reset_metrics": (None, [H]),
         "flexflow_model_forward": (None, [H, I]), "flexflow_model_zero_gradients": (None, [H]),
@@ -247,6 +249,11 @@ class FFModel:
     def set_sgd_optimizer(self, lr=0.01, momentum=0.0, nesterov=False, weight_decay=0.0):
         self._opt = lib().flexflow_sgd_optimizer_create(self.h, lr, momentum, nesterov, weight_decay)
         lib().flexflow_model_set_sgd_optimizer(self.h, self._opt)
+
+    def set_adam_optimizer(self, alpha=0.001, beta1=0.9, beta2=0.999, weight_decay=0.0, epsilon=1e-8):
+        """AdamOptimizer [ref: python/flexflow/core/flexflow_cffi.py AdamOptimizer; include/optimizer.h:62-85]"""
+        self._opt = lib().flexflow_adam_optimizer_create(self.h, alpha, beta1, beta2, weight_decay, epsilon)
+        lib().flexflow_model_set_adam_optimizer(self.h, self._opt)
 
     def compile(self, loss_type=LOSS_MSE_AVG, metrics=(METRICS_ACCURACY, METRICS_MSE), comp_mode=COMP_MODE_TRAINING):
         m = (C.c_int * len(metrics))(*metrics)

@@ -193,6 +193,22 @@ class SGDOptimizer : public Optimizer {
   std::map<const void*, float*> v_values;   // momentum buffers, keyed by weight pointer
 };
 
+// AdamOptimizer [ref: include/optimizer.h:62-85, src/runtime/optimizer.cc:190-330].  m and v live in two slabs laid
+// out like the MLP parameter slab (one launch for every Linear parameter) plus one pair per dense embedding table.
+class AdamOptimizer : public Optimizer {
+ public:
+  AdamOptimizer(const FFModel* _model, double _alpha = 0.001f, double _beta1 = 0.9f, double _beta2 = 0.999f,
+                double _weight_decay = 0.0f, double _epsilon = 1e-8);
+  void init(void) override;
+  void next(void) override;
+  void update(const Parameter* p) override;
+  void set_weight_decay(double wd) { weight_decay = wd; }
+  double alpha, beta1, beta2, weight_decay, epsilon;
+  double alpha_t, beta1_t, beta2_t;
+  float *mlp_m, *mlp_v;                                        // moments of the MLP slab
+  std::map<const void*, std::pair<float*, float*>> mv_values;  // (m, v) of every other parameter, keyed by weight pointer
+};
+
 // ---------------------------------------------------------------------------------------------
 struct PerfMetrics {
   PerfMetrics();
@@ -379,6 +395,7 @@ class FFModel {
   ffh_event ev_dw_done;
   bool need_zero_act_grads;    // some activation gradient is accumulated by more than one producer
   mutable bool dw_forked;
+  mutable bool mlp_grads_clean;   // the optimizer kernel cleared the MLP gradient slab (FFH_OPT_ZERO_GRAD): zero_gradients() skips it
   LaunchWorker *dw_worker, *side_worker;   // NULL: launches are issued inline by the calling thread
   std::vector<ffh_event> layer_events;     // one per layer: "dY of this layer is ready"
   bool use_workers() const { return dw_worker != nullptr && capturing_trace < 0; }

@@ -77,6 +77,11 @@ flexflow_sgd_optimizer_t flexflow_sgd_optimizer_create(flexflow_model_t m, doubl
   flexflow_sgd_optimizer_t h; h.impl = new SGDOptimizer(M(m), lr, mom, nest, wd); return h;
 }
 void flexflow_model_set_sgd_optimizer(flexflow_model_t m, flexflow_sgd_optimizer_t o) { M(m)->optimizer = (SGDOptimizer*)o.impl; }
+flexflow_adam_optimizer_t flexflow_adam_optimizer_create(flexflow_model_t m, double alpha, double b1, double b2, double wd, double eps) {
+  flexflow_adam_optimizer_t h; h.impl = new AdamOptimizer(M(m), alpha, b1, b2, wd, eps); return h;
+}
+void flexflow_adam_optimizer_set_lr(flexflow_adam_optimizer_t o, double lr) { ((AdamOptimizer*)o.impl)->alpha = lr; }
+void flexflow_model_set_adam_optimizer(flexflow_model_t m, flexflow_adam_optimizer_t o) { M(m)->optimizer = (AdamOptimizer*)o.impl; }
 void flexflow_model_compile(flexflow_model_t m, int loss, const int* metrics, int nb, int comp_mode) {
   std::vector<MetricsType> v;
   for (int i = 0; i < nb; i++) v.push_back((MetricsType)metrics[i]);

@@ -17,6 +17,7 @@ FF_NEW_OPAQUE_TYPE(flexflow_model_t);
 FF_NEW_OPAQUE_TYPE(flexflow_tensor_t);
 FF_NEW_OPAQUE_TYPE(flexflow_initializer_t);
 FF_NEW_OPAQUE_TYPE(flexflow_sgd_optimizer_t);
+FF_NEW_OPAQUE_TYPE(flexflow_adam_optimizer_t);
 FF_NEW_OPAQUE_TYPE(flexflow_dlrm_t);
 #undef FF_NEW_OPAQUE_TYPE
 
@@ -58,6 +59,10 @@ flexflow_initializer_t flexflow_norm_initializer_create(int seed, float mean, fl
 flexflow_initializer_t flexflow_glorot_uniform_initializer_create(int seed);
 flexflow_sgd_optimizer_t flexflow_sgd_optimizer_create(flexflow_model_t, double lr, double momentum, bool nesterov, double weight_decay);
 void flexflow_model_set_sgd_optimizer(flexflow_model_t, flexflow_sgd_optimizer_t);
+/* [ref: python/flexflow_c.h:398-400,572-588] */
+flexflow_adam_optimizer_t flexflow_adam_optimizer_create(flexflow_model_t, double alpha, double beta1, double beta2, double weight_decay, double epsilon);
+void flexflow_adam_optimizer_set_lr(flexflow_adam_optimizer_t, double lr);
+void flexflow_model_set_adam_optimizer(flexflow_model_t, flexflow_adam_optimizer_t);
 void flexflow_model_compile(flexflow_model_t, int loss_type, const int* metrics, int nb_metrics, int comp_mode);
 void flexflow_model_init_layers(flexflow_model_t);
 void flexflow_model_reset_metrics(flexflow_model_t);

@@ -375,7 +375,7 @@ FFModel::FFModel(FFConfig& _config)
       emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
       act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1) {
-  dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; dw_forked = false; dw_worker = side_worker = nullptr;
+  dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
   rank = config.comm.world_size > 1 ? config.comm.rank : 0;
   world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
   if (world_size == 1 && config.workersPerNode > 1)
@@ -886,6 +886,46 @@ void SGDOptimizer::update(const Parameter* p) {
 }
 
 // =============================================================================================
+// AdamOptimizer [ref: src/runtime/optimizer.cc:190-330, src/runtime/optimizer_kernel.cu:206-226]
+// =============================================================================================
+AdamOptimizer::AdamOptimizer(const FFModel* _model, double _alpha, double _beta1, double _beta2, double _wd, double _eps)
+    : Optimizer(_model), alpha(_alpha), beta1(_beta1), beta2(_beta2), weight_decay(_wd), epsilon(_eps), alpha_t(_alpha),
+      beta1_t(1.0f), beta2_t(1.0f), mlp_m(nullptr), mlp_v(nullptr) {}
+void AdamOptimizer::init(void) {
+  // ZeroInitializer on both moments of every parameter [ref: optimizer.cc:204-236]
+  auto zeros = [&](size_t count) {
+    float* p = (float*)model->dmalloc(count * sizeof(float));
+    model->check(model->api->ffh_zero(model->ctx, p, count * sizeof(float), model->stream), "adam moments");
+    return p;
+  };
+  if (model->mlp_count) { mlp_m = zeros(model->mlp_count); mlp_v = zeros(model->mlp_count); }
+  for (const Parameter& p : model->parameters) {
+    if (p.owner_op->op_type == OP_LINEAR || !p.impl->grad) continue;
+    mv_values[p.impl->ptr] = std::make_pair(zeros(p.get_volume()), zeros(p.get_volume()));
+  }
+}
+void AdamOptimizer::next(void) {
+  // [ref: optimizer.cc:248-254]
+  beta1_t *= beta1;
+  beta2_t *= beta2;
+  alpha_t = alpha * sqrt(1 - beta2_t) / (1 - beta1_t);
+}
+void AdamOptimizer::update(const Parameter* p) {
+  if (!p->impl->grad) return;
+  float *m, *v;
+  if (p->owner_op->op_type == OP_LINEAR) {
+    const size_t off = (size_t)((float*)p->impl->ptr - model->mlp_weights);
+    m = mlp_m + off; v = mlp_v + off;
+  } else {
+    auto it = mv_values.find(p->impl->ptr);
+    if (it == mv_values.end()) die("AdamOptimizer::update: parameter without moments");
+    m = it->second.first; v = it->second.second;
+  }
+  model->check(model->api->ffh_adam_update(model->ctx, (float*)p->impl->ptr, p->impl->grad, m, v, (int64_t)p->get_volume(), (float)alpha_t,
+                                           (float)beta1, (float)beta2, (float)weight_decay, (float)epsilon, 0, model->stream), "adam_update");
+}
+
+// =============================================================================================
 // compile / allocate
 // =============================================================================================
 int FFModel::tables_of_rank(int r) const {
@@ -941,6 +981,7 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
     label_tensor.impl->is_input = true;
   }
   if (exchange && config.enable_graph) config.enable_graph = false;   // collectives are host callbacks: not capturable
+  if (dynamic_cast<AdamOptimizer*>(optimizer) && config.enable_graph) config.enable_graph = false;   // alpha_t is a new launch argument every step
   if (exchange && !fused_embedding_update()) die("multi-rank runs need the fused embedding update (plain SGD)");
   allocate();
   for (Op* op : layers) {
@@ -1304,7 +1345,7 @@ void FFModel::zero_gradients() {
   // Embedding tables have no dense gradient on the fused path (nothing to zero: SURVEY fact 1).
   // activation gradients with a single producer are stored, not accumulated: nothing to clear (0 + x == x)
   if (need_zero_act_grads) check(api->ffh_zero(ctx, act_grad_slab, act_grad_bytes, stream), "zero_gradients");
-  check(api->ffh_zero(ctx, mlp_grads, mlp_count * 4, stream), "zero_gradients");
+  if (!mlp_grads_clean) check(api->ffh_zero(ctx, mlp_grads, mlp_count * 4, stream), "zero_gradients");
   if (exchange && gsend) {
     size_t n = 0;
     for (int64_t c : fwd_recv_counts) n += (size_t)c;
@@ -1335,6 +1376,7 @@ void FFModel::backward(int _seq_length) {
   check(api->ffh_mse_bwd_metrics(ctx, fin.impl->grad, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, d_perf,
                                  local_rows(fin, this), fin.adim[0], scale, metrics_flags, stream), "metrics + loss backward");
   emb_update_pending = false;
+  mlp_grads_clean = false;
   for (int l = (int)layers.size() - 1; l >= 0; l--) layers[l]->backward(*this);
   if (emb_update_pending) {
     // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
@@ -1347,7 +1389,8 @@ void FFModel::update() {
   if (replaying_trace >= 0) return;
   optimizer->next();
   SGDOptimizer* sgd = dynamic_cast<SGDOptimizer*>(optimizer);
-  if (!sgd) die("only SGDOptimizer is on the DLRM path");
+  AdamOptimizer* adam = dynamic_cast<AdamOptimizer*>(optimizer);
+  if (!sgd && !adam) die("update(): unknown optimizer");
   // every rank must issue its collectives in the same order: the side thread's all-to-all (backward) first
   if (side_worker) side_worker->drain();
   if (dw_forked) {   // the weight-gradient GEMMs ran on their own stream: join before the gradients are consumed
@@ -1360,12 +1403,22 @@ void FFModel::update() {
   // No 1/world_size: the loss already divides by the global batch.
   if (exchange && mlp_count)
     if (config.comm.allreduce_sum_f32(config.comm.user, mlp_grads, (int64_t)mlp_count, stream) != 0) die("allreduce failed");
-  if (sgd->momentum > 0.0) {
+  // one launch over the whole MLP slab; it also clears the gradients it consumed, so the next zero_gradients()
+  // has nothing to sweep [ref: one update task per parameter, src/runtime/optimizer.cc:93-189,256-330]
+  if (adam) {
+    if (mlp_count) {
+      check(api->ffh_adam_update(ctx, mlp_weights, mlp_grads, adam->mlp_m, adam->mlp_v, (int64_t)mlp_count, (float)adam->alpha_t,
+                                 (float)adam->beta1, (float)adam->beta2, (float)adam->weight_decay, (float)adam->epsilon,
+                                 FFH_OPT_ZERO_GRAD, stream), "adam_update (MLP slab)");
+      mlp_grads_clean = true;
+    }
+  } else if (sgd->momentum > 0.0) {
     for (const Parameter& p : parameters)
       if (p.owner_op->op_type == OP_LINEAR) sgd->update(&p);
   } else if (mlp_count) {
-    check(api->ffh_sgd_update(ctx, mlp_weights, mlp_grads, nullptr, (int64_t)mlp_count, (float)sgd->lr, (float)sgd->weight_decay, 0.0f,
-                              0, stream), "sgd_update (MLP slab)");
+    check(api->ffh_sgd_update_ex(ctx, mlp_weights, mlp_grads, nullptr, (int64_t)mlp_count, (float)sgd->lr, (float)sgd->weight_decay, 0.0f,
+                                 0, FFH_OPT_ZERO_GRAD, stream), "sgd_update (MLP slab)");
+    mlp_grads_clean = true;
   }
   if (fused_embedding_update()) {
     if (config.overlap_embedding) {
@@ -1375,7 +1428,7 @@ void FFModel::update() {
     }
   } else {
     for (Embedding* e : embeddings)
-      if (e->owner_rank == rank) sgd->update(&e->weights[0]);
+      if (e->owner_rank == rank) optimizer->update(&e->weights[0]);
   }
 }
 

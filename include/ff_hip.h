@@ -317,6 +317,20 @@ int ffh_metrics_update(ffh_ctx* ctx, const float* logits, const float* labels, f
 /* sgd_update [ref: src/runtime/optimizer_kernel.cu:23-41]; v may be NULL when momentum == 0 */
 int ffh_sgd_update(ffh_ctx* ctx, float* w, const float* w_grad, float* v, int64_t count,
                    float lr, float weight_decay, float momentum, int nesterov, ffh_stream s);
+/* The same update with flags.  FFH_OPT_ZERO_GRAD: w_grad is cleared by the kernel that consumed it, which
+ * replaces the next step's Op::zero_grad sweep over it [ref: src/runtime/model.cc:466-490] (the shim keeps
+ * track of which gradient buffers are already clean). */
+#define FFH_OPT_ZERO_GRAD 1
+int ffh_sgd_update_ex(ffh_ctx* ctx, float* w, float* w_grad, float* v, int64_t count,
+                      float lr, float weight_decay, float momentum, int nesterov, int flags, ffh_stream s);
+/* adam_update [ref: src/runtime/optimizer_kernel.cu:206-226]:
+ *   gt = g + weight_decay*w;  m = beta1*m + (1-beta1)*gt;  v = beta2*v + (1-beta2)*gt*gt;
+ *   w -= alpha_t * m / (sqrt(v) + epsilon)
+ * alpha_t carries the bias correction and is advanced by the caller (AdamOptimizer::next,
+ * [ref: src/runtime/optimizer.cc:248-254]).  Canonical rounding (so that the HIP kernel and the oracle agree
+ * bit for bit): every a*b+c above is one fused multiply-add, sqrt and the division are correctly rounded. */
+int ffh_adam_update(ffh_ctx* ctx, float* w, float* w_grad, float* m, float* v, int64_t count,
+                    float alpha_t, float beta1, float beta2, float weight_decay, float epsilon, int flags, ffh_stream s);
 /* apply_add_with_scale [ref: src/runtime/cuda_helper.cu:99-108] : dst += src*scale */
 int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, float scale, ffh_stream s);
 
@@ -341,6 +355,6 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_bwd_workspace_bytes) \
   X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_concat_fwd) X(ffh_concat_bwd) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
-  X(ffh_sgd_update) X(ffh_add_scaled)
+  X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 
 #endif /* FF_HIP_H_ */

@@ -627,11 +627,13 @@ int ffh_metrics_update(ffh_ctx* c, const float* logits, const float* labels, ffh
 }
 
 /* sgd_update [ref: src/runtime/optimizer_kernel.cu:23-41], with the multiply-adds
- * contracted the way nvcc's default -fmad=true contracts them. */
-int ffh_sgd_update(ffh_ctx* c, float* w, const float* g, float* v, int64_t n,
-                   float lr, float wd, float mom, int nesterov, ffh_stream s) {
+ * contracted the way nvcc's default -fmad=true contracts them.  FFH_OPT_ZERO_GRAD clears the
+ * consumed gradient (what the next step's zero_grad [ref: src/runtime/model.cc:466-490] would do). */
+int ffh_sgd_update_ex(ffh_ctx* c, float* w, float* g, float* v, int64_t n,
+                      float lr, float wd, float mom, int nesterov, int flags, ffh_stream s) {
   (void)s;
   if (mom > 0.0f && !v) return fail(c, FFH_ERR_BAD_ARG, "sgd_update: momentum without V");
+  if (flags & ~FFH_OPT_ZERO_GRAD) return fail(c, FFH_ERR_BAD_ARG, "sgd_update: unknown flags");
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < n; i++) {
     float gt = fmaf(wd, w[i], g[i]);
@@ -640,6 +642,34 @@ int ffh_sgd_update(ffh_ctx* c, float* w, const float* g, float* v, int64_t n,
       if (nesterov) gt = fmaf(mom, v[i], gt); else gt = v[i];
     }
     w[i] = fmaf(-lr, gt, w[i]);
+    if (flags & FFH_OPT_ZERO_GRAD) g[i] = 0.0f;
+  }
+  return FFH_OK;
+}
+
+int ffh_sgd_update(ffh_ctx* c, float* w, const float* g, float* v, int64_t n,
+                   float lr, float wd, float mom, int nesterov, ffh_stream s) {
+  return ffh_sgd_update_ex(c, w, (float*)g, v, n, lr, wd, mom, nesterov, 0, s);
+}
+
+/* adam_update [ref: src/runtime/optimizer_kernel.cu:206-226], one statement of the reference per line;
+ * the a*b+c forms are single fused multiply-adds (the canonical rounding of include/ff_hip.h), sqrtf and
+ * the division are IEEE correctly rounded. */
+int ffh_adam_update(ffh_ctx* c, float* w, float* g, float* m, float* v, int64_t n, float alpha_t, float beta1,
+                    float beta2, float wd, float eps, int flags, ffh_stream s) {
+  (void)s;
+  if (n > 0 && (!w || !g || !m || !v)) return fail(c, FFH_ERR_BAD_ARG, "adam_update: bad args");
+  if (flags & ~FFH_OPT_ZERO_GRAD) return fail(c, FFH_ERR_BAD_ARG, "adam_update: unknown flags");
+  const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    const float gt = fmaf(wd, w[i], g[i]);                 /* gt = WGrad[i] + weight_decay * W[i]            :218 */
+    const float mt = fmaf(beta1, m[i], omb1 * gt);         /* mt = beta1 * M[i] + (1 - beta1) * gt           :219 */
+    const float vt = fmaf(beta2, v[i], (omb2 * gt) * gt);  /* vt = beta2 * V[i] + (1 - beta2) * gt * gt      :220 */
+    m[i] = mt;
+    v[i] = vt;
+    w[i] = w[i] - (alpha_t * mt) / (sqrtf(vt) + eps);      /* W[i] -= alpha_t * mt / (sqrt(vt) + epsilon)    :223 */
+    if (flags & FFH_OPT_ZERO_GRAD) g[i] = 0.0f;
   }
   return FFH_OK;
 }

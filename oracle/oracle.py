@@ -162,6 +162,34 @@ def sgd_update(w, g, lr, wd=0.0, momentum=0.0, nesterov=False, v=None):
     return w
 
 
+def sgd_update_zero_grad(w, g, lr, wd=0.0, momentum=0.0, nesterov=False, v=None):
+    """ffh_sgd_update_ex with FFH_OPT_ZERO_GRAD; returns (w, g_after)."""
+    w, g = _f32(w).copy(), _f32(g).copy()
+    lib().call("ffh_sgd_update_ex", w, g, v, w.size, float(lr), float(wd), float(momentum), int(nesterov), capi.OPT_ZERO_GRAD, None)
+    return w, g
+
+
+class AdamState:
+    """AdamOptimizer's host-side scalars [ref: src/runtime/optimizer.cc:194-201,248-254] (doubles, as there)."""
+
+    def __init__(self, alpha=0.001, beta1=0.9, beta2=0.999, weight_decay=0.0, epsilon=1e-8):
+        self.alpha, self.beta1, self.beta2, self.weight_decay, self.epsilon = alpha, beta1, beta2, weight_decay, epsilon
+        self.alpha_t, self.beta1_t, self.beta2_t = alpha, 1.0, 1.0
+
+    def next(self):
+        self.beta1_t *= self.beta1
+        self.beta2_t *= self.beta2
+        self.alpha_t = self.alpha * np.sqrt(1 - self.beta2_t) / (1 - self.beta1_t)
+
+
+def adam_update(w, g, m, v, st: AdamState, zero_grad=False):
+    """One adam_update over (w, m, v) in place of copies; returns (w, m, v[, g_after])."""
+    w, g, m, v = _f32(w).copy(), _f32(g).copy(), _f32(m).copy(), _f32(v).copy()
+    lib().call("ffh_adam_update", w, g, m, v, w.size, float(st.alpha_t), float(st.beta1), float(st.beta2), float(st.weight_decay),
+               float(st.epsilon), capi.OPT_ZERO_GRAD if zero_grad else 0, None)
+    return (w, m, v, g) if zero_grad else (w, m, v)
+
+
 def init_uniform(count, seed, lo, hi):
     p = np.empty(count, np.float32)
     lib().call("ffh_init_uniform", p, count, seed, float(lo), float(hi), None)

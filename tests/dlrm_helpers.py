@@ -20,7 +20,7 @@ def oracle_backend():
 
 
 def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dense_update=False, g=None, force_exchange=False,
-                      column_shard_rows=0, extra_argv=()):
+                      column_shard_rows=0, extra_argv=(), adam=None):
     """Returns (model, handles) with weights and inputs of the golden fixture loaded.
     With `comm` (world_size > 1) each rank loads its batch slice / its tables."""
     g = g or golden("dlrm_step_torch")
@@ -43,7 +43,10 @@ def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dens
     z = m.concat([x] + ly, 1)
     for i in range(len(top) - 1):
         z = m.dense(z, top[i + 1], capi.AC_MODE_SIGMOID if i == len(top) - 2 else capi.AC_MODE_RELU)
-    m.set_sgd_optimizer(lr=0.01)
+    if adam is not None:
+        m.set_adam_optimizer(**adam)
+    else:
+        m.set_sgd_optimizer(lr=0.01)
     m.compile()
     m.init_layers()
     # layer order: bottom dense..., embeddings..., concat, top dense...
@@ -109,3 +112,52 @@ def check_against_golden(recs, h, rtol=1e-5, atol=1e-6):
             if k == "pred":
                 continue
             np.testing.assert_allclose(v, g[f"step{step}/{k}"], rtol=rtol, atol=atol, err_msg=f"{k} step {step}")
+
+
+def torch_adam_reference(g, steps, alpha=0.001, beta1=0.9, beta2=0.999, weight_decay=0.0, epsilon=1e-8):
+    """The golden DLRM in torch (autograd for the gradients) with the reference's Adam applied by hand, statement by
+    statement in fp32 [ref: src/runtime/optimizer_kernel.cu:206-226; alpha_t: src/runtime/optimizer.cc:248-254] --
+    torch.optim.Adam places epsilon differently, which matters for the small gradients of this model.
+    Returns per-step {"pred", "<name>.weight", "<name>.bias"} like run_steps()."""
+    import torch
+    rows, bot, top = list(g["rows"]), list(g["bot"]), list(g["top"])
+    B = int(g["B"])
+    P = {}
+    for i in range(len(bot) - 1):
+        P[f"bot.{i}.weight"] = g[f"init/bot.{i}.weight"]; P[f"bot.{i}.bias"] = g[f"init/bot.{i}.bias"]
+    for i in range(len(top) - 1):
+        P[f"top.{i}.weight"] = g[f"init/top.{i}.weight"]; P[f"top.{i}.bias"] = g[f"init/top.{i}.bias"]
+    for t in range(len(rows)):
+        P[f"emb.{t}.weight"] = g[f"init/emb.{t}.weight"]
+    P = {k: torch.tensor(np.array(v, np.float32), requires_grad=True) for k, v in P.items()}
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    dense, label = torch.from_numpy(g["dense"]), torch.from_numpy(g["label"])
+    sparse = [torch.from_numpy(g[f"sparse{t}"]) for t in range(len(rows))]
+    b1t = b2t = 1.0
+    out = []
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32)
+    for _ in range(steps):
+        x = dense
+        for i in range(len(bot) - 1):
+            x = torch.relu(x @ P[f"bot.{i}.weight"].T + P[f"bot.{i}.bias"])
+        ly = [P[f"emb.{t}.weight"][s].sum(1) for t, s in enumerate(sparse)]
+        z = torch.cat([x] + ly, 1)
+        for i in range(len(top) - 1):
+            z = z @ P[f"top.{i}.weight"].T + P[f"top.{i}.bias"]
+            z = torch.sigmoid(z) if i == len(top) - 2 else torch.relu(z)
+        for v in P.values():
+            v.grad = None
+        (0.5 * ((z - label) ** 2).sum() / B).backward()
+        b1t *= beta1; b2t *= beta2
+        alpha_t = alpha * np.sqrt(1 - b2t) / (1 - b1t)
+        with torch.no_grad():
+            for k, w in P.items():
+                gt = w.grad + f32(weight_decay) * w
+                M[k] = f32(beta1) * M[k] + (1 - f32(beta1)) * gt
+                V[k] = f32(beta2) * V[k] + (1 - f32(beta2)) * gt * gt
+                w -= f32(alpha_t) * M[k] / (torch.sqrt(V[k]) + f32(epsilon))
+        rec = {"pred": z.detach().numpy().copy()}
+        rec.update({k: v.detach().numpy().copy() for k, v in P.items()})
+        out.append(rec)
+    return out

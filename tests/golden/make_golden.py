@@ -181,6 +181,30 @@ def sgd_mse_from_torch():
     save("sgd_mse_torch", **cases)
 
 
+def adam_from_torch():
+    """torch.optim.Adam (L2 weight decay folded into the gradient, like the reference's adam_update
+    [ref: src/runtime/optimizer_kernel.cu:206-226]).  torch places epsilon after the bias correction of sqrt(v), the
+    reference before it: with |g| ~ 0.1..1 the two differ by ~1e-8 relative, far below the 1e-5 of the comparison."""
+    np.random.seed(3)
+    cases = {}
+    k = 0
+    for (alpha, b1, b2, wd, eps) in ((0.001, 0.9, 0.999, 0.0, 1e-8), (0.01, 0.9, 0.999, 1e-4, 1e-8), (0.003, 0.8, 0.99, 0.0, 1e-8)):
+        w0 = np.random.uniform(-1, 1, (515,)).astype(np.float32)
+        p = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+        opt = torch.optim.Adam([p], lr=alpha, betas=(b1, b2), eps=eps, weight_decay=wd)
+        grads = []
+        for step in range(5):
+            g = (np.random.uniform(0.1, 1, (515,)) * np.random.choice([-1.0, 1.0], (515,))).astype(np.float32)
+            grads.append(g)
+            p.grad = torch.from_numpy(g.copy())
+            opt.step()
+        cases.update({f"c{k}_w0": w0, f"c{k}_g": np.stack(grads), f"c{k}_w5": p.detach().numpy().copy(),
+                      f"c{k}_hp": np.array([alpha, b1, b2, wd, eps], np.float64)})
+        k += 1
+    cases["n_cases"] = np.array(k)
+    save("adam_torch", **cases)
+
+
 class TorchDLRM(torch.nn.Module):
     """The topology the reference driver builds [ref: examples/cpp/DLRM/dlrm.cc:26-65,97-128]:
     bottom MLP (all ReLU), T EmbeddingBag(sum), concat [x, e_0..e_{T-1}], top MLP (ReLU, last sigmoid)."""
@@ -243,4 +267,5 @@ if __name__ == "__main__":
     concat_from_numpy()
     bmm_from_torch()
     sgd_mse_from_torch()
+    adam_from_torch()
     dlrm_step_from_torch()

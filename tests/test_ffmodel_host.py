@@ -62,6 +62,27 @@ def test_dot_interaction_matches_torch():
         np.testing.assert_allclose(got[k], exp[k], rtol=1e-5, atol=1e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("wd", [0.0, 1e-3])
+def test_adam_optimizer_matches_torch(wd):
+    """AdamOptimizer through the FFModel API (dense embedding gradients, as the reference: every row's
+    moments decay every step) against a torch model updated with the reference's formula."""
+    hp = dict(alpha=0.01, beta1=0.9, beta2=0.999, weight_decay=wd, epsilon=1e-8)
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False, adam=hp)
+    recs = H.run_steps(m, h, 3)
+    exp = H.torch_adam_reference(h["g"], 3, **hp)
+    for step in range(3):
+        assert set(recs[step]) == set(exp[step])
+        for k in recs[step]:
+            np.testing.assert_allclose(recs[step][k], exp[step][k], rtol=2e-5, atol=2e-6, err_msg=f"step {step} {k}")
+    # weights really moved by about alpha per step (Adam's signature), also in rows of tables the batch never touched
+    # once they had a gradient -- and untouched-forever rows stay put
+    g = h["g"]
+    t0 = recs[2]["emb.0.weight"] - g["init/emb.0.weight"]
+    touched = np.zeros(t0.shape[0], bool); touched[np.unique(g["sparse0"])] = True
+    assert np.abs(t0[touched]).max() > 0.01 and (wd > 0 or not t0[~touched].any())
+    m.close()
+
+
 def test_fused_and_dense_embedding_paths_agree():
     """The fused sparse update and the reference's dense zero/scatter/sweep path give the same
     tables (1e-6: only the summation order inside duplicate rows differs)."""

@@ -31,6 +31,20 @@ def test_dlrm_two_steps_match_torch_golden_on_gpu(hip, overlap, graph, dense_upd
     m.close()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_adam_optimizer_matches_torch_on_gpu(hip, graph):
+    """AdamOptimizer (ffh_adam_update over the MLP slab + dense embedding tables) on the GPU against the
+    torch model updated with the reference's formula; eager and hipGraph replay."""
+    hp = dict(alpha=0.01, beta1=0.9, beta2=0.999, weight_decay=1e-3, epsilon=1e-8)
+    m, h = H.build_golden_dlrm(HIP, enable_graph=graph, overlap=False, adam=hp)
+    recs = H.run_steps(m, h, 3, trace=graph)
+    exp = H.torch_adam_reference(h["g"], 3, **hp)
+    for step in range(3):
+        for k in recs[step]:
+            np.testing.assert_allclose(recs[step][k], exp[step][k], rtol=2e-5, atol=2e-6, err_msg=f"step {step} {k}")
+    m.close()
+
+
 @pytest.mark.timeout(300)
 def test_async_launch_threads_on_gpu(hip):
     """--async-launch: weight-gradient GEMMs and the embedding side stream issued by their own host threads."""

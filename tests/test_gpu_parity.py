@@ -470,6 +470,40 @@ def test_transpose_bit_exact(hip, dims, perm):
     np.testing.assert_array_equal(host(ig), ig0 + np.transpose(g, np.argsort(perm)))
 
 
+def test_adam_and_zero_grad(hip, oracle):
+    """ffh_adam_update / ffh_sgd_update_ex: bit-exact with the oracle, within 1e-5 of torch.optim.Adam (fixture)."""
+    g = golden("adam_torch")
+    for k in range(int(g["n_cases"])):
+        alpha, b1, b2, wd, eps = g[f"c{k}_hp"]
+        st = oracle.AdamState(alpha, b1, b2, wd, eps)
+        w = dev(g[f"c{k}_w0"]); m = torch.zeros_like(w); v = torch.zeros_like(w)
+        w_o = g[f"c{k}_w0"].copy(); m_o = np.zeros_like(w_o); v_o = np.zeros_like(w_o)
+        for step in range(5):
+            st.next()
+            gd = dev(g[f"c{k}_g"][step])
+            hip.call("ffh_adam_update", w, gd, m, v, w.numel(), float(st.alpha_t), float(b1), float(b2), float(wd), float(eps),
+                     capi.OPT_ZERO_GRAD if step % 2 else 0, None)
+            assert (host(gd) == 0).all() if step % 2 else bits_equal(host(gd), g[f"c{k}_g"][step])
+            w_o, m_o, v_o = oracle.adam_update(w_o, g[f"c{k}_g"][step], m_o, v_o, st)
+        assert bits_equal(host(w), w_o) and bits_equal(host(m), m_o) and bits_equal(host(v), v_o)
+        np.testing.assert_allclose(host(w), g[f"c{k}_w5"], rtol=1e-5, atol=1e-6)
+    n = (1 << 20) + 4                                                 # vector path, large; and an odd count (scalar path)
+    rng = np.random.default_rng(1)
+    for cnt in (n, 1001):
+        w0, gr = rng.uniform(-1, 1, cnt).astype(np.float32), rng.uniform(-1, 1, cnt).astype(np.float32)
+        m0, v0 = rng.uniform(-0.1, 0.1, cnt).astype(np.float32), rng.uniform(0, 0.1, cnt).astype(np.float32)
+        st = oracle.AdamState(0.01, 0.9, 0.999, 1e-3, 1e-8); st.next(); st.next()
+        w, gd, m, v = dev(w0), dev(gr), dev(m0), dev(v0)
+        hip.call("ffh_adam_update", w, gd, m, v, cnt, float(st.alpha_t), 0.9, 0.999, 1e-3, 1e-8, capi.OPT_ZERO_GRAD, None)
+        w_o, m_o, v_o = oracle.adam_update(w0, gr, m0, v0, st)
+        assert bits_equal(host(w), w_o) and bits_equal(host(m), m_o) and bits_equal(host(v), v_o) and not host(gd).any()
+        w, gd = dev(w0), dev(gr)
+        hip.call("ffh_sgd_update_ex", w, gd, None, cnt, 0.01, 0.0, 0.0, 0, capi.OPT_ZERO_GRAD, None)
+        assert bits_equal(host(w), oracle.sgd_update(w0, gr, 0.01)) and not host(gd).any()
+    with pytest.raises(capi.FFHError):
+        hip.call("ffh_adam_update", w, gd, None, None, 4, 0.01, 0.9, 0.999, 0.0, 1e-8, 0, None)
+
+
 def test_sgd_mse_metrics(hip, oracle):
     g = golden("sgd_mse_torch")
     for k in range(int(g["n_cases"])):

@@ -246,6 +246,40 @@ def test_sgd_and_mse_match_torch_golden(oracle):
     assert abs(perf.mse_loss - float(g["mse_sum"])) <= 1e-5 * float(g["mse_sum"])
 
 
+def test_adam_matches_torch_golden(oracle):
+    """adam_update [ref: src/runtime/optimizer_kernel.cu:206-226] + AdamOptimizer::next [ref: optimizer.cc:248-254]
+    against torch.optim.Adam over 5 steps (fixture: tests/golden/make_golden.py:adam_from_torch)."""
+    g = golden("adam_torch")
+    for k in range(int(g["n_cases"])):
+        alpha, b1, b2, wd, eps = g[f"c{k}_hp"]
+        st = oracle.AdamState(alpha, b1, b2, wd, eps)
+        w = g[f"c{k}_w0"].copy()
+        m, v = np.zeros_like(w), np.zeros_like(w)
+        for step in range(5):
+            st.next()
+            w, m, v = oracle.adam_update(w, g[f"c{k}_g"][step], m, v, st)
+        np.testing.assert_allclose(w, g[f"c{k}_w5"], rtol=1e-5, atol=1e-6)
+    # the statement-by-statement float32 evaluation in numpy, one step (independent of the C code)
+    rng = np.random.default_rng(0)
+    w0, g0 = rng.uniform(-1, 1, 1000).astype(np.float32), rng.uniform(-1, 1, 1000).astype(np.float32)
+    m0, v0 = rng.uniform(-0.1, 0.1, 1000).astype(np.float32), rng.uniform(0, 0.1, 1000).astype(np.float32)
+    st = oracle.AdamState(0.01, 0.9, 0.999, 1e-3, 1e-8)
+    st.next()
+    f = np.float32
+    gt = (g0.astype(np.float64) + np.float64(f(1e-3)) * w0).astype(f)                          # single rounding = fma
+    mt = (np.float64(f(0.9)) * m0 + ((f(1) - f(0.9)) * gt).astype(np.float64)).astype(f)
+    vt = (np.float64(f(0.999)) * v0 + (((f(1) - f(0.999)) * gt) * gt).astype(np.float64)).astype(f)
+    wn = w0 - (f(st.alpha_t) * mt) / (np.sqrt(vt) + f(1e-8))
+    w1, m1, v1, g1 = oracle.adam_update(w0, g0, m0, v0, st, zero_grad=True)
+    np.testing.assert_array_equal(m1, mt)
+    np.testing.assert_array_equal(v1, vt)
+    np.testing.assert_array_equal(w1, wn.astype(f))
+    assert not g1.any()
+    w2, g2 = oracle.sgd_update_zero_grad(w0, g0, 0.01)
+    np.testing.assert_array_equal(w2, oracle.sgd_update(w0, g0, 0.01))
+    assert not g2.any()
+
+
 # ---------------------------------------------------------------------------
 # RNG contract (include/ffh_rng.h)
 # ---------------------------------------------------------------------------
