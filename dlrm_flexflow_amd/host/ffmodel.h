@@ -58,6 +58,26 @@ class Op;
 struct KernelApi;   // dlopen'ed table of the ffh_* entry points (backend.h)
 
 // ---------------------------------------------------------------------------------------------
+// ParallelConfig + strategy files [ref: include/config.h:47-73, src/runtime/strategy.cc:95-189].
+// Text format: "<n_ops>" then per op "<name> <device_type> <nDims> <dim[0..nDims)> <n_ids> <ids...>", dims in
+// Legion order (dim[nDims-1] = sample dim).  What this build can place: an Embedding on ONE device
+// (all dims 1, device_ids[0] = owning rank -- the shape examples/cpp/DLRM/strategies/dlrm_strategy.cc:92-110 emits);
+// every other op data-parallel over all ranks (only the sample dim split, ids 0..world_size-1).
+struct ParallelConfig {
+  enum DeviceType { GPU = 0, CPU = 1 };
+  ParallelConfig() : device_type(GPU), nDims(0) { for (int& d : dim) d = 1; }
+  int num_parts() const { int n = 1; for (int i = 0; i < nDims; i++) n *= dim[i]; return n; }
+  bool is_data_parallel() const;      // only the sample dim is split
+  bool operator==(const ParallelConfig& rhs) const;
+  DeviceType device_type;
+  int nDims, dim[MAX_TENSOR_DIM];
+  std::vector<int> device_ids;
+};
+typedef size_t MappingTagID;
+bool load_strategies_from_file(const std::string& filename, std::map<MappingTagID, ParallelConfig>& strategies);
+bool save_strategies_to_file(const std::string& filename, const std::map<std::string, ParallelConfig>& strategies);
+
+// ---------------------------------------------------------------------------------------------
 class FFConfig {
  public:
   FFConfig();
@@ -70,7 +90,10 @@ class FFConfig {
   bool syntheticInput, profiling, perform_fusion;
   CompMode computationMode;
   std::string dataset_path;
-  std::string import_strategy_file, export_strategy_file;   // parsed, rejected at compile()
+  std::string import_strategy_file, export_strategy_file;   // --import / --export [ref: src/runtime/model.cc:2327-2334]
+  std::map<MappingTagID, ParallelConfig> strategies;        // keyed by get_hash_id(op name), as the reference
+  static MappingTagID get_hash_id(const std::string& pcname);
+  bool find_parallel_config(int ndims, const std::string& pcname, ParallelConfig& config) const;   // false: not in the file
   // this build
   std::string backend_lib;     // library exporting include/ff_hip.h; default: libffhip.so next to libffmodel.so
   int device;                  // HIP device ordinal of this process
@@ -441,4 +464,5 @@ class FFModel {
   std::vector<Tensor*> input_tensors;
  private:
   void allocate();
+  void apply_strategies();      // --import / --export [ref: src/runtime/model.cc:1575-1577, src/runtime/simulator.cu:131-143]
 };

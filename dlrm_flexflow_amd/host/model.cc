@@ -941,6 +941,64 @@ bool FFModel::fused_embedding_update() const {
   return sgd && sgd->momentum == 0.0 && sgd->weight_decay == 0.0;
 }
 
+// Placement from a strategy file [ref: FFModel::compile -> load_strategies_from_file, src/runtime/model.cc:1575-1577;
+// Op::create_output_and_partition looks its config up by op name, e.g. src/ops/embedding.cu:75-79].  Ops the file
+// does not name keep the default: tables round-robin over the ranks, everything else data-parallel.
+void FFModel::apply_strategies() {
+  if (!config.import_strategy_file.empty() && !load_strategies_from_file(config.import_strategy_file, config.strategies))
+    die("cannot read strategy file %s", config.import_strategy_file.c_str());
+  for (Op* op : layers) {
+    ParallelConfig pc;
+    if (!config.find_parallel_config(op->outputs[0].numDim, op->name, pc)) continue;
+    if (pc.device_type != ParallelConfig::GPU) die("%s: strategy places it on the CPU; this build runs every op on the GPUs", op->name);
+    for (int id : pc.device_ids)
+      if (id < 0 || id >= world_size) die("%s: strategy names device %d, the job has %d rank(s)", op->name, id, world_size);
+    if (Embedding* e = dynamic_cast<Embedding*>(op)) {
+      // one table on one device (what dlrm_strategy.cc emits); a table split over the sample dim would be a
+      // replicated table with an all-reduced dense gradient -- the reference's default, not built here
+      if (pc.num_parts() == world_size && world_size > 1 && pc.dim[0] == world_size) {
+        // this build's own extension, as --export writes it: the table split column-wise over all ranks
+        if (e->out_channels % world_size) die("%s: out_dim %d is not divisible by %d ranks", op->name, e->out_channels, world_size);
+        for (size_t j = 0; j < pc.device_ids.size(); j++)
+          if (pc.device_ids[j] != (int)j) die("%s: column blocks must sit on devices 0..%d in order", op->name, world_size - 1);
+        e->column_sharded = true;
+        e->local_cols = e->out_channels / world_size;
+        continue;
+      }
+      if (pc.num_parts() != 1) die("%s: an embedding can only be placed whole on one device (dims all 1), the strategy splits it %d ways", op->name, pc.num_parts());
+      e->owner_rank = pc.device_ids.empty() ? 0 : pc.device_ids[0];
+      e->column_sharded = false;
+      e->local_cols = e->out_channels;
+    } else {
+      if (!pc.is_data_parallel() || pc.num_parts() != world_size)
+        die("%s: only data parallelism over all %d rank(s) is built for this op (strategy: %d parts%s)", op->name, world_size, pc.num_parts(),
+            pc.is_data_parallel() ? "" : ", not on the sample dim");
+      for (size_t j = 0; j < pc.device_ids.size(); j++)
+        if (pc.device_ids[j] != (int)j) die("%s: data-parallel parts must sit on devices 0..%d in order", op->name, world_size - 1);
+    }
+  }
+  if (!config.export_strategy_file.empty() && rank == 0) {
+    // the placement in force, in the reference's format (it writes the result of its search here)
+    std::map<std::string, ParallelConfig> out;
+    for (Op* op : layers) {
+      ParallelConfig pc;
+      pc.nDims = op->outputs[0].numDim;
+      Embedding* e = dynamic_cast<Embedding*>(op);
+      if (e && !e->column_sharded) {
+        pc.device_ids.push_back(e->owner_rank);
+      } else if (e) {
+        pc.dim[0] = world_size;                       // column-wise giant table: split on the channel dim (this build's extension)
+        for (int j = 0; j < world_size; j++) pc.device_ids.push_back(j);
+      } else {
+        pc.dim[pc.nDims - 1] = world_size;
+        for (int j = 0; j < world_size; j++) pc.device_ids.push_back(j);
+      }
+      out[op->name] = pc;
+    }
+    if (!save_strategies_to_file(config.export_strategy_file, out)) die("cannot write strategy file %s", config.export_strategy_file.c_str());
+  }
+}
+
 void FFModel::compile(LossType lt, const std::vector<MetricsType>& metrics, CompMode cm) {
   if (!optimizer) die("compile(): no optimizer set");
   compile(optimizer, lt, metrics, cm);
@@ -949,8 +1007,7 @@ void FFModel::compile(LossType lt, const std::vector<MetricsType>& metrics, Comp
 void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vector<MetricsType>& metrics, CompMode comp_mode) {
   if (compiled) die("compile() called twice");
   if (layers.empty()) die("compile(): the model has no layers");
-  if (!config.import_strategy_file.empty() || !config.export_strategy_file.empty())
-    fprintf(stderr, "note: strategy files are ignored; placement is the fixed sharding (tables: rank = index %% %d; the rest data-parallel)\n", world_size);
+  apply_strategies();
   optimizer = _optimizer;
   loss_type = _loss_type;
   config.computationMode = comp_mode;

@@ -24,9 +24,10 @@ def main():
     rank = dist.get_rank()
     comm = TorchComm(on_gpu=False)
     out = {}
-    if mode in ("golden", "column"):
+    if mode in ("golden", "column", "strategy"):
+        extra = ["--import", os.path.join(outdir, "strategy.txt"), "--export", os.path.join(outdir, "export.txt")] if mode == "strategy" else []
         m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True,
-                                   column_shard_rows=40 if mode == "column" else 0)
+                                   column_shard_rows=40 if mode == "column" else 0, extra_argv=extra)
         recs = H.run_steps(m, h, 2)
         for step, rec in enumerate(recs):
             for k, v in rec.items():

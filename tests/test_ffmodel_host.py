@@ -241,6 +241,93 @@ def test_two_rank_column_sharded_giant_table(tmp_path):
     assert sorted(owner_of_small) == [0, 2, 3]
 
 
+def _strategy_text(entries):
+    """The reference's text format [ref: src/runtime/strategy.cc:147-189]: count, then per op name / device type /
+    nDims / dims / number of ids / ids, one per line, lists tab-separated."""
+    lines = [str(len(entries))]
+    for name, dims, ids in entries:
+        lines += [name, "0", str(len(dims)), "\t".join(map(str, dims)) + "\t", str(len(ids)), "\t".join(map(str, ids)) + "\t"]
+    return "\n".join(lines) + "\n"
+
+
+def _parse_strategy(path):
+    tok = open(path).read().split()
+    n, i, out = int(tok[0]), 1, {}
+    for _ in range(n):
+        name, dev, nd = tok[i], int(tok[i + 1]), int(tok[i + 2]); i += 3
+        dims = [int(x) for x in tok[i:i + nd]]; i += nd
+        k = int(tok[i]); i += 1
+        out[name] = (dev, dims, [int(x) for x in tok[i:i + k]]); i += k
+    assert i == len(tok)
+    return out
+
+
+@pytest.mark.parametrize("owners", [(1, 0, 1, 0), (1, 1, 1, 1)])
+def test_two_rank_strategy_file_places_the_tables(tmp_path, owners):
+    """SURVEY 8f-3: --import a strategy file in the reference's text format that moves the tables (swapped round-robin;
+    all four on rank 1, so rank 0 owns none), leaves one op to the default and names the MLP ops data-parallel.
+    Results equal the single-rank run; --export writes the placement in force, which loads back."""
+    g = golden("dlrm_step_torch")
+    nb = len(g["bot"]) - 1
+    entries = [(f"Embedding_{100 + nb + t}", [1, 1], [owners[t]]) for t in range(4)]
+    entries += [("Dense_100", [1, 2], [0, 1]), (f"Concat_{100 + nb + 4}", [1, 2], [0, 1]), ("NotInThisModel_7", [1, 1, 1, 4], [0, 1, 2, 3])]
+    (tmp_path / "strategy.txt").write_text(_strategy_text(entries))
+    _run_ranks(2, tmp_path, "strategy")
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False)
+    ref = H.run_steps(m, h, 2)
+    n_layers = m.num_layers
+    m.close()
+    B = int(g["B"])
+    for r in range(2):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        sl = slice(r * B // 2, (r + 1) * B // 2)
+        for step in range(2):
+            np.testing.assert_allclose(z[f"s{step}/pred"], ref[step]["pred"][sl], rtol=1e-5, atol=1e-6)
+            for t in range(4):
+                key = f"s{step}/emb.{t}.weight"
+                assert (key in z.files) == (owners[t] == r)
+                if owners[t] == r:
+                    np.testing.assert_allclose(z[key], ref[step][f"emb.{t}.weight"], rtol=1e-6, atol=1e-7, err_msg=key)
+            np.testing.assert_allclose(z[f"s{step}/top.0.weight"], ref[step]["top.0.weight"], rtol=1e-5, atol=1e-6)
+    exp = _parse_strategy(tmp_path / "export.txt")
+    assert len(exp) == n_layers
+    for t in range(4):
+        assert exp[f"Embedding_{100 + nb + t}"] == (0, [1, 1], [owners[t]])
+    assert exp["Dense_100"] == (0, [1, 2], [0, 1]) and exp[f"Concat_{100 + nb + 4}"] == (0, [1, 2], [0, 1])
+
+
+def test_strategy_file_round_trip_and_rejections(tmp_path):
+    """Single rank: export -> import round trip; a strategy this build cannot honour aborts with a message naming the op
+    (the reference asserts, include/cuda_helper.h / strategy.cc:91)."""
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False, extra_argv=["--export", str(tmp_path / "a.txt")])
+    n_layers = m.num_layers
+    a = H.run_steps(m, h, 1)
+    m.close()
+    exp = _parse_strategy(tmp_path / "a.txt")
+    assert len(exp) == n_layers and all(v == (0, [1, 1], [0]) for v in exp.values())
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False, extra_argv=["--import", str(tmp_path / "a.txt"), "--export", str(tmp_path / "b.txt")])
+    b = H.run_steps(m, h, 1)
+    m.close()
+    assert (tmp_path / "a.txt").read_text() == (tmp_path / "b.txt").read_text()
+    for k in a[0]:
+        assert np.array_equal(a[0][k], b[0][k])
+    bad = {
+        "split.txt": _strategy_text([("Embedding_102", [1, 2], [0, 1])]),          # table split over the sample dim
+        "device.txt": _strategy_text([("Embedding_102", [1, 1], [3])]),            # device the job does not have
+        "model.txt": _strategy_text([("Dense_100", [2, 1], [0, 1])]),              # channel-parallel Linear
+        "dims.txt": _strategy_text([("Dense_100", [1, 1, 1], [0])]),               # wrong dimensionality (reference: assert)
+        "dup.txt": _strategy_text([("Dense_100", [1, 1], [0]), ("Dense_100", [1, 1], [0])]),
+    }
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import dlrm_helpers as H; "
+            "H.build_golden_dlrm(H.oracle_backend(), overlap=False, extra_argv=['--import', sys.argv[1]])") % (ROOT, os.path.join(ROOT, "tests"))
+    for name, text in bad.items():
+        (tmp_path / name).write_text(text)
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / name)], capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "FATAL" in r.stderr, (name, r.stderr[-400:])
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "missing.txt")], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "strategy file" in r.stderr
+
+
 def test_single_rank_forced_exchange_equals_plain_run(tmp_path):
     """--force-exchange: one rank still goes through the all-to-all / all-reduce callbacks (how the
     collectives are exercised on a 1-GPU box); results equal the plain single-rank run."""
