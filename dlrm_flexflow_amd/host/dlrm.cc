@@ -1,5 +1,6 @@
 // dlrm.cc -- DLRM application on the FFModel shim [ref: examples/cpp/DLRM/dlrm.cc].
 #include "dlrm.h"
+#include "hdf5_io.h"
 
 #include <chrono>
 #include <cmath>
@@ -109,27 +110,29 @@ Tensor interact_features(FFModel* model, const Tensor& x, const std::vector<Tens
 DataLoader::DataLoader(FFModel& ff, const DLRMConfig& dlrm, const std::vector<Tensor>& sparse_inputs, Tensor dense_input, Tensor label)
     : num_samples(0), next_index(0), batch_sparse_inputs(sparse_inputs), batch_dense_input(dense_input), batch_label(label),
       full_dense(nullptr), full_label(nullptr), model(&ff) {
-  if (dlrm.dataset_path != "") {
-    fprintf(stderr, "FATAL: --dataset %s: the HDF5 Criteo loader is not part of this build (no HDF5 in the image); "
-                    "run without --dataset for the synthetic generator\n", dlrm.dataset_path.c_str());
-    abort();
-  }
-  printf("[DLRM] Use random dataset...\n");
+  bag = dlrm.embedding_bag_size;
+  dense_dim = dense_input.adim[0];
+  full_sparse.assign(sparse_inputs.size(), nullptr);
+  if (dlrm.dataset_path != "") load_hdf5(ff, dlrm);
+  else generate_random(ff, dlrm);
+  ff.check(ff.api->ffh_stream_sync(ff.ctx, ff.stream), "dataset sync");
+}
+
+void DataLoader::generate_random(FFModel& ff, const DLRMConfig& dlrm) {
+  const bool chatty = ff.world_size <= 1 || ff.rank == 0;
+  if (chatty) printf("[DLRM] Use random dataset...\n");
   if (dlrm.data_size > 0) num_samples = dlrm.data_size;
   else num_samples = 256 * 4 * std::max(1, ff.world_size) * ff.config.numNodes;   // [ref: dlrm.cc:272-276]
   const int B = ff.config.batchSize;
   if (num_samples < B) num_samples = B;
   num_samples = num_samples / B * B;
-  printf("[DLRM] Number of random samples = %d\n", num_samples);
-  bag = dlrm.embedding_bag_size;
-  dense_dim = dense_input.adim[0];
+  if (chatty) printf("[DLRM] Number of random samples = %d\n", num_samples);
   const uint64_t s0 = ff.config.seed * 1000003ULL;
   const int nb = num_samples / B;
   const int64_t Bl = ff.local_batch;
   // sparse ids: owner of table t keeps ids of every sample (it gathers for the global batch)
-  full_sparse.assign(sparse_inputs.size(), nullptr);
-  for (size_t t = 0; t < sparse_inputs.size(); t++) {
-    if (!sparse_inputs[t].impl->ptr) continue;          // this rank neither owns the table nor holds a column block of it
+  for (size_t t = 0; t < batch_sparse_inputs.size(); t++) {
+    if (!batch_sparse_inputs[t].impl->ptr) continue;          // this rank neither owns the table nor holds a column block of it
     const int64_t n = (int64_t)num_samples * bag;
     full_sparse[t] = (int64_t*)ff.dmalloc((size_t)n * sizeof(int64_t));
     ff.check(ff.api->ffh_gen_indices(ff.ctx, full_sparse[t], n, s0 + 17 + t, 0, dlrm.embedding_size[t], ff.stream), "gen_indices");
@@ -142,7 +145,80 @@ DataLoader::DataLoader(FFModel& ff, const DLRMConfig& dlrm, const std::vector<Te
     ff.check(ff.api->ffh_gen_uniform01(ff.ctx, full_dense + (int64_t)k * Bl * dense_dim, Bl * dense_dim, s0 + 5, n0 * dense_dim, ff.stream), "gen dense");
     ff.check(ff.api->ffh_gen_bernoulli(ff.ctx, full_label + (int64_t)k * Bl, Bl, s0 + 7, n0, ff.stream), "gen label");
   }
-  ff.check(ff.api->ffh_stream_sync(ff.ctx, ff.stream), "dataset sync");
+}
+
+// The Criteo file of the reference [ref: examples/cpp/DLRM/dlrm.cc:279-326 (shape checks), :421-479 (H5Dread of X_cat as
+// LLONG, X_int and y as FLOAT); written by preprocess_hdf.py:14-24]: X_int [N][dense] float (already log(x+1)),
+// X_cat [N][tables*bag] integer, y [N] or [N][1] float.  The whole set becomes device-resident in the same layout the
+// synthetic generator produces; the file is read in row chunks so that host memory stays bounded.
+void DataLoader::load_hdf5(FFModel& ff, const DLRMConfig& dlrm) {
+  const bool chatty = ff.world_size <= 1 || ff.rank == 0;
+  if (chatty) printf("[DLRM] Start loading dataset from %s\n", dlrm.dataset_path.c_str());
+  Hdf5File file(dlrm.dataset_path);
+  auto bad = [&](const char* what) {
+    fprintf(stderr, "FATAL: --dataset %s: %s\n", dlrm.dataset_path.c_str(), what);
+    abort();
+  };
+  const Hdf5Dataset xi = file.describe("X_int"), xc = file.describe("X_cat"), yy = file.describe("y");
+  const size_t T = batch_sparse_inputs.size();
+  if (xi.dims.size() != 2 || xi.type_class != 1) bad("X_int must be a 2-D float dataset");
+  if ((int)xi.dims[1] != dense_dim) bad("X_int's second dimension must equal --arch-mlp-bot[0]");                 // [ref: dlrm.cc:292]
+  if (xc.dims.size() != 2 || xc.type_class != 0) bad("X_cat must be a 2-D integer dataset");
+  if (xc.dims[0] != xi.dims[0] || yy.dims[0] != xi.dims[0]) bad("X_int, X_cat and y must have the same number of samples");
+  if (xc.dims[1] != T * (size_t)bag) bad("X_cat's second dimension must equal (number of tables) x (bag size)");  // [ref: dlrm.cc:307]
+  if (yy.dims.size() == 2 && yy.dims[1] != 1) bad("y must be [N] or [N][1]");
+  const int B = ff.config.batchSize;
+  uint64_t n_file = xi.dims[0];
+  if (dlrm.data_size > 0 && (uint64_t)dlrm.data_size < n_file) n_file = (uint64_t)dlrm.data_size;   // --data-size caps what is loaded
+  if (n_file / B == 0) bad("fewer samples than one batch");
+  if (n_file / B * B > 0x7fffffffULL) bad("more than 2^31 samples");
+  num_samples = (int)(n_file / B * B);       // the reference iterates num_samples / batchSize whole batches (dlrm.cc:157)
+  const int nb = num_samples / B;
+  const int64_t Bl = ff.local_batch;
+  for (size_t t = 0; t < T; t++)
+    if (batch_sparse_inputs[t].impl->ptr) full_sparse[t] = (int64_t*)ff.dmalloc((size_t)num_samples * bag * sizeof(int64_t));
+  full_dense = (float*)ff.dmalloc((size_t)nb * Bl * dense_dim * sizeof(float));
+  full_label = (float*)ff.dmalloc((size_t)nb * Bl * sizeof(float));
+
+  const int batches_per_chunk = std::max(1, (1 << 18) / B);       // about 256k samples per pass over the file
+  const size_t C = T * (size_t)bag;
+  std::vector<int64_t> cat((size_t)batches_per_chunk * B * C), col((size_t)batches_per_chunk * B * bag);
+  std::vector<float> xint((size_t)batches_per_chunk * B * dense_dim), lab((size_t)batches_per_chunk * B);
+  for (int k0 = 0; k0 < nb; k0 += batches_per_chunk) {
+    const int kb = std::min(batches_per_chunk, nb - k0);
+    const uint64_t row0 = (uint64_t)k0 * B, rows = (uint64_t)kb * B;
+    file.read_rows_i64("X_cat", row0, rows, cat.data());
+    file.read_rows_f32("X_int", row0, rows, xint.data());
+    file.read_rows_f32("y", row0, rows, lab.data());
+    for (size_t t = 0; t < T; t++) {
+      if (!full_sparse[t]) continue;
+      const int64_t R = dlrm.embedding_size[t];
+      for (uint64_t i = 0; i < rows; i++)
+        for (int j = 0; j < bag; j++) {
+          const int64_t id = cat[i * C + t * bag + j];
+          // the reference gathers without a bounds check on the GPU and asserts on the CPU path (src/ops/embedding.cc:71-73)
+          if (id < 0 || id >= R) {
+            fprintf(stderr, "FATAL: --dataset %s: X_cat[%llu][%zu] = %lld is outside table %zu (%lld rows)\n", dlrm.dataset_path.c_str(),
+                    (unsigned long long)(row0 + i), t * bag + j, (long long)id, t, (long long)R);
+            abort();
+          }
+          col[i * bag + j] = id;
+        }
+      ff.check(ff.api->ffh_memcpy_h2d(ff.ctx, full_sparse[t] + row0 * bag, col.data(), rows * bag * sizeof(int64_t), ff.stream), "dataset H2D");
+      ff.check(ff.api->ffh_stream_sync(ff.ctx, ff.stream), "dataset sync");     // col is reused for the next table
+    }
+    for (int k = 0; k < kb; k++) {
+      const size_t src = (size_t)k * B + (size_t)ff.rank * Bl;                   // this rank's slice of batch k0 + k
+      ff.check(ff.api->ffh_memcpy_h2d(ff.ctx, full_dense + (int64_t)(k0 + k) * Bl * dense_dim, xint.data() + src * dense_dim,
+                                      (size_t)Bl * dense_dim * sizeof(float), ff.stream), "dataset H2D");
+      ff.check(ff.api->ffh_memcpy_h2d(ff.ctx, full_label + (int64_t)(k0 + k) * Bl, lab.data() + src, (size_t)Bl * sizeof(float), ff.stream), "dataset H2D");
+    }
+    ff.check(ff.api->ffh_stream_sync(ff.ctx, ff.stream), "dataset sync");
+  }
+  if (chatty) {
+    printf("[DLRM] Finish loading dataset from %s\n", dlrm.dataset_path.c_str());
+    printf("[DLRM] Loaded %d samples\n", num_samples);
+  }
 }
 
 DataLoader::~DataLoader() {
@@ -236,7 +312,9 @@ void DLRMApp::warmup() {
 
 void DLRMApp::train_steps(int n, bool trace) {
   for (int it = 0; it < n; it++) {
-    // random input: the batch loaded in the warm-up is reused [ref: examples/cpp/DLRM/dlrm.cc:167-173]
+    // random input: the batch loaded in the warm-up is reused; a dataset advances every iteration, outside the trace
+    // [ref: examples/cpp/DLRM/dlrm.cc:167-175]
+    if (!dlrm.dataset_path.empty()) loader->next_batch(*ff);
     if (trace) ff->begin_trace(111 /*trace_id*/);
     ff->forward();
     ff->zero_gradients();

@@ -25,7 +25,7 @@ Tensor create_mlp(FFModel* model, const Tensor& input, std::vector<int> ln, int 
 Tensor create_emb(FFModel* model, const Tensor& input, int input_dim, int output_dim, int idx);
 Tensor interact_features(FFModel* model, const Tensor& x, const std::vector<Tensor>& ly, std::string interaction);
 
-// Synthetic dataset resident on the device (the reference keeps it in zero-copy host memory and
+// Dataset (synthetic, or the reference's HDF5 Criteo file with --dataset) resident on the device (the reference keeps it in zero-copy host memory and
 // gathers + copies H2D every batch, [ref: examples/cpp/DLRM/dlrm.cc:357-377, dlrm.cu:19-122]).
 // Distributions of [ref: examples/cpp/DLRM/dlrm.cc:413-420] from the seeded counter RNG, with a
 // per-table row count (the reference asserts all tables equal, :349-354 -- lifted).
@@ -39,6 +39,8 @@ class DataLoader {
   int num_samples, next_index;
 
  private:
+  void generate_random(FFModel& ff, const DLRMConfig& dlrm);
+  void load_hdf5(FFModel& ff, const DLRMConfig& dlrm);      // --dataset: X_int / X_cat / y of the reference's Criteo file
   std::vector<Tensor> batch_sparse_inputs;
   Tensor batch_dense_input, batch_label;
   std::vector<int64_t*> full_sparse;   // per owned table: [num_samples][bag]

@@ -33,6 +33,21 @@ def main():
             for k, v in rec.items():
                 out[f"s{step}/{k}"] = v
         m.close()
+    elif mode == "hdf5":
+        app = ffmodel.DLRM(["--backend", H.oracle_backend()] + H.HDF5_ARGS + ["--dataset", os.path.join(outdir, "day.h5")], comm=comm.struct)
+        app.warmup()
+        app.train_steps(7, trace=False)          # 1 + 7 steps over 6 batches: wraps around once
+        app.model.sync()
+        out["dense"] = app.dense_input().get()
+        out["label"] = app.model.label_tensor.get()
+        out["num_samples"] = np.array(app.num_samples)
+        for t in range(3):
+            if app.sparse_input(t).is_local:
+                out[f"sparse{t}"] = app.sparse_input(t).get(np.int64)
+                out[f"emb{t}"] = app.model.parameter(2 + t, 0).get_weights()
+        out["w_bot"] = app.model.parameter(0, 0).get_weights()
+        out["w_top"] = app.model.parameter(app.model.num_layers - 1, 0).get_weights()
+        app.close()
     else:
         args = ["--backend", H.oracle_backend(), "-b", "64", "--arch-sparse-feature-size", "8", "--arch-embedding-size",
                 "50-7-300-3-1000-20-11", "--arch-mlp-bot", "13-32-8", "--arch-mlp-top", "64-32-1", "--data-size", "128", "--epochs", "6"]

@@ -161,3 +161,27 @@ def torch_adam_reference(g, steps, alpha=0.001, beta1=0.9, beta2=0.999, weight_d
         rec.update({k: v.detach().numpy().copy() for k, v in P.items()})
         out.append(rec)
     return out
+
+
+def make_criteo_like_hdf5(tmp_path, n=100, rows=(50, 7, 300), dense=13, seed=5, bad_id=False):
+    """A Criteo-shaped npz (raw integer counts, categorical ids, 0/1 labels) converted by tools/preprocess_hdf.py --
+    the counterpart of the reference's examples/cpp/DLRM/preprocess_hdf.py.  Returns (hdf5 path, the arrays the loader
+    must deliver: X_int after log(x+1), X_cat as int64, y as float32)."""
+    import importlib.util
+    rng = np.random.default_rng(seed)
+    raw = {"X_int": rng.integers(0, 1000, (n, dense)).astype(np.int32),
+           "X_cat": np.stack([rng.integers(0, r, n) for r in rows], 1).astype(np.int32),
+           "y": rng.integers(0, 2, n).astype(np.int32)}
+    if bad_id:
+        raw["X_cat"][n // 2, 1] = rows[1]
+    npz, h5 = os.path.join(tmp_path, "day.npz"), os.path.join(tmp_path, "day.h5")
+    np.savez(npz, **raw)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("preprocess_hdf", os.path.join(root, "tools", "preprocess_hdf.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    mod.convert(npz, h5)
+    return h5, {"X_int": np.log(raw["X_int"].astype(np.float32) + 1), "X_cat": raw["X_cat"].astype(np.int64), "y": raw["y"].astype(np.float32)}
+
+
+HDF5_ARGS = ["-b", "16", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "50-7-300", "--arch-mlp-bot", "13-16-8",
+             "--arch-mlp-top", "32-16-1"]

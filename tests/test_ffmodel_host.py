@@ -328,6 +328,78 @@ def test_strategy_file_round_trip_and_rejections(tmp_path):
     assert r.returncode != 0 and "strategy file" in r.stderr
 
 
+def test_hdf5_criteo_loader(tmp_path):
+    """--dataset reads X_int / X_cat / y of the reference's HDF5 layout (written here by the
+    preprocess_hdf.py counterpart); batches arrive in file order, whole batches only, wrapping around."""
+    h5, exp = H.make_criteo_like_hdf5(str(tmp_path))
+    from dlrm_flexflow_amd import hdf5_lite
+    for k in exp:                                                   # the file itself holds what the reference script writes
+        got = hdf5_lite.read(h5, k)
+        assert got.dtype == exp[k].dtype and np.array_equal(got, exp[k])
+    app = ffmodel.DLRM(["--backend", H.oracle_backend()] + H.HDF5_ARGS + ["--dataset", h5])
+    assert app.num_samples == 96 and app.num_tables == 3            # 100 samples = 6 whole batches of 16
+    B = 16
+    app.warmup()
+    for step in range(8):                                           # batches 0..5, then 0, 1 again
+        app.model.sync()
+        k = step % 6
+        assert np.array_equal(app.dense_input().get(), exp["X_int"][k * B:(k + 1) * B])
+        assert np.array_equal(app.model.label_tensor.get().reshape(-1), exp["y"][k * B:(k + 1) * B])
+        for t in range(3):
+            assert np.array_equal(app.sparse_input(t).get(np.int64).reshape(-1), exp["X_cat"][k * B:(k + 1) * B, t])
+        app.train_steps(1, trace=False)
+    pm = app.model.perf_metrics()
+    assert pm.train_all > 0 and np.isfinite(pm.mse_loss)
+    app.close()
+    # --data-size caps what is loaded
+    app = ffmodel.DLRM(["--backend", H.oracle_backend()] + H.HDF5_ARGS + ["--dataset", h5, "--data-size", "40"])
+    assert app.num_samples == 32
+    app.close()
+
+
+def test_hdf5_loader_rejections(tmp_path):
+    """Ids outside a table, a dataset of the wrong shape and a missing libhdf5 stop the run with a message
+    (the reference asserts on the shapes, examples/cpp/DLRM/dlrm.cc:288-310)."""
+    exe = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
+    base = [exe, "--backend", H.oracle_backend()] + H.HDF5_ARGS
+    h5, _ = H.make_criteo_like_hdf5(str(tmp_path), bad_id=True)
+    r = subprocess.run(base + ["--dataset", h5], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "is outside table 1 (7 rows)" in r.stderr
+    r = subprocess.run(base[:-4] + ["--arch-mlp-bot", "12-16-8", "--arch-mlp-top", "32-16-1", "--dataset", h5], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "X_int's second dimension" in r.stderr
+    r = subprocess.run(base + ["--dataset", h5, "--embedding-bag-size", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "X_cat's second dimension" in r.stderr
+    r = subprocess.run(base + ["--dataset", h5], capture_output=True, text=True, timeout=120, env=dict(os.environ, FFH_HDF5_LIB="/nonexistent/libhdf5.so"))
+    assert r.returncode != 0 and "needs libhdf5" in r.stderr
+
+
+def test_two_rank_hdf5_dataset(tmp_path):
+    """Two ranks read the same file: each keeps its half of every batch (dense, labels) and all ids of the tables it
+    owns; the trajectory equals the single-rank run on the same file."""
+    h5, exp = H.make_criteo_like_hdf5(str(tmp_path))
+    _run_ranks(2, tmp_path, "hdf5")
+    app = ffmodel.DLRM(["--backend", H.oracle_backend()] + H.HDF5_ARGS + ["--dataset", h5])
+    app.warmup(); app.train_steps(7, trace=False); app.model.sync()
+    ref = {"w_bot": app.model.parameter(0, 0).get_weights(), "w_top": app.model.parameter(app.model.num_layers - 1, 0).get_weights()}
+    for t in range(3):
+        ref[f"emb{t}"] = app.model.parameter(2 + t, 0).get_weights()
+    app.close()
+    owned = set()
+    for r in range(2):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        assert int(z["num_samples"]) == 96
+        assert np.array_equal(z["dense"], exp["X_int"][16 + 8 * r:16 + 8 * (r + 1)])      # 8th step = batch 1, this rank's half
+        assert np.array_equal(z["label"].reshape(-1), exp["y"][16 + 8 * r:16 + 8 * (r + 1)])
+        for t in range(3):
+            if f"sparse{t}" in z.files:
+                owned.add(t)
+                assert np.array_equal(z[f"sparse{t}"].reshape(-1), exp["X_cat"][16:32, t])   # the owner gathers for the global batch
+                np.testing.assert_allclose(z[f"emb{t}"], ref[f"emb{t}"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(z["w_bot"], ref["w_bot"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(z["w_top"], ref["w_top"], rtol=1e-5, atol=1e-6)
+    assert owned == {0, 1, 2}
+
+
 def test_single_rank_forced_exchange_equals_plain_run(tmp_path):
     """--force-exchange: one rank still goes through the all-to-all / all-reduce callbacks (how the
     collectives are exercised on a 1-GPU box); results equal the plain single-rank run."""

@@ -121,6 +121,28 @@ def test_dot_interaction_matches_torch_on_gpu(hip, trace):
         np.testing.assert_allclose(got[k], exp[k], rtol=2e-5, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("trace", [False, True])
+def test_hdf5_dataset_on_gpu(hip, tmp_path, trace):
+    """--dataset (HDF5 Criteo layout) feeding the GPU run: the batches on the device are the file's rows, and
+    8 steps (one wrap-around; with trace the batch copies stay outside the replayed graph) follow the oracle backend."""
+    h5, exp = H.make_criteo_like_hdf5(str(tmp_path))
+    res = {}
+    for name, backend in (("hip", HIP), ("cpu", H.oracle_backend())):
+        app = ffmodel.DLRM(["--backend", backend] + H.HDF5_ARGS + ["--dataset", h5])
+        assert app.num_samples == 96
+        app.warmup()
+        app.train_steps(7, trace=trace and name == "hip")
+        app.model.sync()
+        if name == "hip":
+            assert np.array_equal(app.dense_input().get(), exp["X_int"][16:32])
+            assert np.array_equal(app.sparse_input(2).get(np.int64).reshape(-1), exp["X_cat"][16:32, 2])
+        res[name] = {f"p{l}": app.model.parameter(l, 0).get_weights() for l in range(app.model.num_layers) if app.model.layer_num_weights(l)}
+        res[name]["pred"] = app.model.layer_output(app.model.num_layers - 1).get()
+        app.close()
+    for k in res["hip"]:
+        np.testing.assert_allclose(res["hip"][k], res["cpu"][k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
 def test_dlrm_executable_on_gpu(hip):
     exe = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
     r = subprocess.run([exe] + DRIVER_C1 + ["--epochs", "3"], capture_output=True, text=True, timeout=300)
