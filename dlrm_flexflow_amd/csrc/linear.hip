@@ -46,6 +46,9 @@ struct GemmArgs {
   int64_t      ld_act_y;
   float*       db;
   int          fuse;         // bit0: relu mask from act_y, bit1: db += column sums
+  // FFH_LINEAR_DX_MASK_BY_X: C = mask[m][n] > 0 ? v : 0 in the epilogue
+  const float* mask;
+  int64_t      ldmask;
 };
 
 constexpr int kSplitGran = 32;   // split-K granularity; splits are multiples of 2*kSplitGran = 64 = the largest BK
@@ -364,9 +367,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= g.M) continue;
         float* cp = C + (int64_t)m * g.ldc + n;
-        if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
-        else if (g.epi == EPI_ADD) *cp = *cp + v;
-        else atomicAdd(cp, v);
+        const float vm = (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) ? 0.0f : v;
+        if (g.epi == EPI_STORE) *cp = act_apply(vm + bv, g.act);
+        else if (g.epi == EPI_ADD) *cp = *cp + vm;
+        else atomicAdd(cp, vm);
       }
     }
     return;
@@ -383,12 +387,288 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= g.M) continue;
         float* cp = C + (int64_t)m * g.ldc + n;
-        const float v = acc[i][j][r];
+        float v = acc[i][j][r];
+        if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) v = 0.0f;
         if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
         else if (g.epi == EPI_ADD) *cp = *cp + v;
         else atomicAdd(cp, v);
       }
     }
+}
+
+// =============================================================================================
+// LDS-DMA GEMM for the mid-size layers of the 2048-sample step (432x512, 512x256 ...): outputs of only
+// ~1 M elements, i.e. ONE 64x64 tile per CU.  What bounds such a launch is not the matrix pipe but how the
+// operand bytes get on chip next to it, so:
+//   * operands go global -> LDS by global_load_lds_dwordx4 (no staging registers, no ds_write pass), three
+//     k-tiles of 64 in flight, counted s_waitcnt vmcnt + one raw s_barrier per k-tile;
+//   * a workgroup is 16 waves on one tile: 4 (or 2) sub-tiles of 32x32 x 4 (or 8) k-slices of every k-tile.
+//     Issuing one 1-KiB DMA piece costs its wave ~60-180 cycles; with four waves per SIMD that time sits
+//     under the other waves' MFMAs (measured: 4 waves 16.0 us, 8 waves 14.1, 16 waves 12.9 on 2048x512x432);
+//   * the DMA pieces of a k-tile are issued between the MFMAs of the previous one, not in a burst;
+//   * LDS images are lane-linear (a DMA writes base + 16*lane); any layout freedom is taken on the SOURCE
+//     address.  A k-contiguous operand (rows = m) is XOR-swizzled by 16-B chunk so that the MFMA operand fetch
+//     is one conflict-free ds_read_b128 per FOUR k-steps -- legal because a sum over k may visit k in any
+//     order as long as both operands agree: lane (row, half h) of the 32x32x2 MFMA takes k = 8j + 4h + e.
+//     An m/n-contiguous operand (rows = k) is read with one ds_read_b32 per k-step in that same k order;
+//   * rows / k beyond the matrix come from a 256-byte zero page (per-lane source address), so edges need no
+//     predicated code; the k-slices meet in LDS in a fixed order; bias, activation, relu'(x) mask or atomics
+//     in the epilogue; db (column sums of dy) is summed from the LDS image by the first column of workgroups.
+// Results differ from the register-staged kernel above only in the order of the k sum (both are exact-fp32
+// fmaf chains); parity tests compare both against the oracle at 1e-5.
+// =============================================================================================
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct GldsArgs {
+  const float* A;  const float* B;  float* C;
+  const float* bias;
+  const float* zeros;        // >= 16 readable zero bytes
+  const float* mask;         // epilogue: C = mask[m][n] > 0 ? v : 0 (relu' of the layer below), or null
+  float*       db;           // dW form: db[m] += sum_k A(m,k), or null
+  int64_t lda, ldb, ldc, ldmask;
+  int M, N, K;
+  int k_per_split, splitk;   // grid.z = splitk; k_per_split is a multiple of 64
+  int epi, act;
+};
+
+template <int N_> __device__ __forceinline__ void glds_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+constexpr int kGldsWaves = 16;
+constexpr int kGldsStages = 3;
+
+// AKR / BKR: false = rows of the operand are m (n), k contiguous (x, w in fwd; dy in dx); true = rows are k, m (n) contiguous.
+template <bool AKR, bool BKR, int BM>
+__global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_kernel(const GldsArgs g) {
+  constexpr int NW = kGldsWaves, NSTAGE = kGldsStages, BN = 64;
+  constexpr int NSUB = (BM / 32) * 2;                   // 32x32 sub-tiles of the block tile
+  constexpr int KS = NW / NSUB;                         // k-slices of every k-tile
+  constexpr int JW = 8 / KS;                            // k-octets per wave per k-tile
+  constexpr int A_CH = BM * 16, B_CH = BN * 16, STAGE_CH = A_CH + B_CH;   // 16-byte chunks
+  constexpr int NPIECE = STAGE_CH / 64;
+  constexpr int NIW = (NPIECE + NW - 1) / NW;           // DMA pieces per k-tile per wave (the last may be absent)
+  static_assert(JW >= 1 && 8 % KS == 0, "k-slices");
+  extern __shared__ float4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  int bx, by, bz;
+  {
+    const unsigned nbx = gridDim.x, nby = gridDim.y, nbz = gridDim.z;
+    const unsigned total = nbx * nby * nbz;
+    const unsigned lin = (blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x;
+    const unsigned xcd = lin & 7u, loc = lin >> 3, q = total >> 3, rem = total & 7u;
+    const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
+    bx = (int)(nlin % nbx); by = (int)((nlin / nbx) % nby); bz = (int)(nlin / (nbx * nby));
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kb = bz * g.k_per_split;
+  const int ke = kb + g.k_per_split < g.K ? kb + g.k_per_split : g.K;
+  if (kb >= ke) return;
+  const int nk = (ke - kb + 63) / 64;
+  const int sub = wave % NSUB, ks = wave / NSUB;
+  const int wm = sub >> 1, wn = sub & 1;
+
+  // per-lane source of this wave's DMA pieces.  Piece q holds chunks 64q .. 64q+63 of the stage image:
+  //   rows-are-m image: chunk = row * 16 + slot, slot = kchunk ^ (row & 15)  (k-tile = 16 chunks of 4 k)
+  //   rows-are-k image: chunk = krow * (cols/4) + mchunk                      (no swizzle: read by ds_read_b32 along m)
+  const float* src[NIW];
+  int src_k[NIW];          // k offset of the lane's chunk inside the k-tile
+  bool src_on[NIW];
+#pragma unroll
+  for (int i = 0; i < NIW; i++) {
+    const int q = wave + NW * i;
+    src_on[i] = q < NPIECE;
+    const int ch = q * 64 + lane;
+    const bool isA = ch < A_CH;
+    const int cb = isA ? ch : ch - A_CH;
+    const float* base = isA ? g.A : g.B;
+    const int64_t ld = isA ? g.lda : g.ldb;
+    const int o0 = isA ? m0 : n0, olim = isA ? g.M : g.N;
+    const bool kr = isA ? AKR : BKR;
+    const int cols4 = (isA ? BM : BN) / 4;
+    if (!kr) {
+      const int r = cb >> 4, c = (cb & 15) ^ (r & 15);
+      src[i] = (o0 + r < olim) ? base + (int64_t)(o0 + r) * ld + 4 * c : nullptr;
+      src_k[i] = 4 * c;
+    } else {
+      const int kr_ = cb / cols4, c = cb - kr_ * cols4;
+      src[i] = (o0 + 4 * c < olim) ? base + (int64_t)kr_ * ld + o0 + 4 * c : nullptr;
+      src_k[i] = kr_ | (1 << 30);       // flag: the k offset moves the row, not the column
+    }
+  }
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
+  auto issue = [&](int kt, int buf, int i0, int i1) {
+    const int k0 = kb + kt * 64;
+#pragma unroll
+    for (int i = i0; i < i1; i++) {
+      const int q = wave + NW * i;
+      const bool rows_k = (src_k[i] >> 30) & 1;
+      const int kk = k0 + (src_k[i] & 0xFFFF);
+      const int64_t ld = (q * 64 < A_CH) ? g.lda : g.ldb;
+      const float* p = (src_on[i] && src[i] != nullptr && kk < ke) ? (rows_k ? src[i] + (int64_t)k0 * ld : src[i] + k0) : g.zeros;
+      // a wave without an i-th piece (24 pieces on 16 waves) still issues one, into a spare KiB behind the stages: every
+      // wave then has the same number of DMAs per k-tile and one counted vmcnt wait serves all of them
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(src_on[i] ? buf * STAGE_CH + q * 64 : NSTAGE * STAGE_CH) * 16u);
+      unsigned keep;
+      // inline asm on purpose: hipcc's waitcnt pass must not see the LDS-DMA, or it drains vmcnt(0) before every ds_read
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(p), "s"(dst) : "memory");
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+  float dbsum = 0.0f;
+  const bool do_db = AKR && g.db != nullptr && bx == 0;
+  constexpr int DB_GROUPS = NW * 64 / BM, DB_ROWS = 64 / DB_GROUPS;
+
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; s++) issue(s, s, 0, NIW);
+  const int ra = wm * 32 + lr, rb = wn * 32 + lr;
+  int buf = 0, nbuf = NSTAGE - 1;
+  for (int t = 0; t < nk; t++) {
+    glds_wait_vmcnt<(NSTAGE - 2) * NIW>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float4* as4 = lds + buf * STAGE_CH;
+    const float4* bs4 = as4 + A_CH;
+    const float* as1 = reinterpret_cast<const float*>(as4);
+    const float* bs1 = reinterpret_cast<const float*>(bs4);
+    auto rd = [&](int j, float4& a, float4& b) {
+      const int oct = ks * JW + j;
+      if (!AKR) a = as4[ra * 16 + ((2 * oct + lh) ^ (ra & 15))];
+      else {
+        const float* q = as1 + (8 * oct + 4 * lh) * BM + ra;
+        a = make_float4(q[0], q[BM], q[2 * BM], q[3 * BM]);
+      }
+      if (!BKR) b = bs4[rb * 16 + ((2 * oct + lh) ^ (rb & 15))];
+      else {
+        const float* q = bs1 + (8 * oct + 4 * lh) * BN + rb;
+        b = make_float4(q[0], q[BN], q[2 * BN], q[3 * BN]);
+      }
+    };
+    float4 a_cur, b_cur, a_nxt, b_nxt;
+    rd(0, a_cur, b_cur);
+#pragma unroll
+    for (int j = 0; j < JW; j++) {
+      if (j + 1 < JW) rd(j + 1, a_nxt, b_nxt);
+      issue(t + NSTAGE - 1, nbuf, j * NIW / JW, (j + 1) * NIW / JW);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur.w, acc, 0, 0, 0);
+      a_cur = a_nxt; b_cur = b_nxt;
+    }
+    if (do_db) {
+      // bias gradient: column sums of the dy image (rows = k): thread -> column tid % BM, rows (tid / BM) * DB_ROWS ...
+      const int col = tid % BM, r0 = (tid / BM) * DB_ROWS;
+#pragma unroll
+      for (int r = 0; r < DB_ROWS; r++) dbsum += as1[(r0 + r) * BM + col];
+    }
+    buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+    nbuf = nbuf + 1 == NSTAGE ? 0 : nbuf + 1;
+  }
+  glds_wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // the k-slices of a sub-tile meet in LDS, ((s0 + s1) + s2) + ..., each wave finishes 16 / KS accumulator registers
+  constexpr int RPW = 16 / KS;
+  float* red = reinterpret_cast<float*>(lds);        // [ks][sub][16][64] floats = NW * 4 KB
+  float out[RPW];
+  if (KS > 1) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[((ks * NSUB + sub) * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RPW; q++) {
+      const int r = ks * RPW + q;
+      float v = red[((0 * NSUB + sub) * 16 + r) * 64 + lane];
+#pragma unroll
+      for (int s2 = 1; s2 < KS; s2++) v += red[((s2 * NSUB + sub) * 16 + r) * 64 + lane];
+      out[q] = v;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < RPW; q++) out[q] = acc[q];
+  }
+  if (do_db) {
+    __syncthreads();
+    red[tid] = dbsum;                                  // [DB_GROUPS][BM]
+    __syncthreads();
+    if (tid < BM) {
+      float v = red[tid];
+      for (int q = 1; q < DB_GROUPS; q++) v += red[q * BM + tid];
+      if (m0 + tid < g.M) atomicAdd(&g.db[m0 + tid], v);
+    }
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+  const int n = n0 + wn * 32 + lr;
+  if (n < g.N) {
+    const float bv = (g.epi == EPI_STORE && g.bias) ? g.bias[n] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < RPW; q++) {
+      const int r = KS > 1 ? ks * RPW + q : q;
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= g.M) continue;
+      float v = out[q];
+      if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) v = 0.0f;
+      float* cp = g.C + (int64_t)m * g.ldc + n;
+      if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
+      else if (g.epi == EPI_ADD) *cp = *cp + v;
+      else atomicAdd(cp, v);
+    }
+  }
+}
+
+inline bool glds_aligned(const float* p, int64_t ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
+
+// Returns 1 if the LDS-DMA kernel took the GEMM, 0 if the shape is not its business, < 0 on error.
+template <bool AKR, bool BKR>
+int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const char* name) {
+  static const int off = getenv("FFH_GEMM_NO_GLDS") ? atoi(getenv("FFH_GEMM_NO_GLDS")) : 0;   // tuning aid
+  if (off || !c->zeros) return 0;
+  if (!glds_aligned(g.A, g.lda) || !glds_aligned(g.B, g.ldb)) return 0;
+  // whole 16-byte chunks only: the contiguous extent of each operand must be a multiple of 4 floats
+  if ((AKR ? g.M : g.K) % 4 || (BKR ? g.N : g.K) % 4) return 0;
+  const double work = (double)g.M * g.N * g.K;
+  if (work < 1.5e8 || g.M < 64 || g.N < 64 || g.K < 128) return 0;     // the small layers are launch-bound either way
+  const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64);
+  int bm = 64;
+  int64_t tiles = tiles64;
+  if (!atomic_splitk && tiles64 < (3 * c->num_cus) / 4) { bm = 32; tiles = (int64_t)((g.M + 31) / 32) * ((g.N + 63) / 64); }
+  if (!atomic_splitk && tiles > (3 * c->num_cus) / 2) return 0;        // bigger GEMMs: the register-staged kernels with their larger tiles
+  g.zeros = c->zeros;
+  g.splitk = 1; g.k_per_split = (g.K + 63) / 64 * 64;
+  if (atomic_splitk) {
+    int want = (int)((c->num_cus + tiles - 1) / tiles);
+    const int max_split = (g.K + 255) / 256;            // at least four k-tiles per workgroup
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    int kps = (g.K + want - 1) / want;
+    kps = (kps + 63) / 64 * 64;
+    g.k_per_split = kps;
+    g.splitk = (g.K + kps - 1) / kps;
+  }
+  const int gy = (g.M + bm - 1) / bm, gx = (g.N + 63) / 64;
+  if (gy > 65535 || g.splitk > 65535) return 0;
+  dim3 grid(gx, gy, g.splitk);
+  const int lds_bytes = kGldsStages * (bm + 64) * 256 + 1024;
+#define FFH_GLDS_LAUNCH(BMV)                                                                                               \
+  {                                                                                                                        \
+    auto kern = gemm_glds_kernel<AKR, BKR, BMV>;                                                                           \
+    static bool attr_set = false;                                                                                          \
+    if (!attr_set) {                                                                                                       \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kGldsStages * (BMV + 64) * 256 + 1024) != hipSuccess) { (void)hipGetLastError(); return 0; } \
+      attr_set = true;                                                                                                     \
+    }                                                                                                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(kGldsWaves * 64), lds_bytes, as_stream(s), g);                                     \
+  }
+  if (bm == 64) FFH_GLDS_LAUNCH(64) else FFH_GLDS_LAUNCH(32)
+#undef FFH_GLDS_LAUNCH
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+  return 1;
 }
 
 // dy <- dy * act'(y) in place, and db[o] += sum_b dy[b][o]; one pass over dy.
@@ -530,6 +810,13 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   g.C = y; g.ldc = ldy; g.bias = bias;
   g.M = (int)batch; g.N = out; g.K = in;
   g.epi = EPI_STORE; g.act = act;
+  {
+    GldsArgs d{};
+    d.A = x; d.lda = ldx; d.B = w; d.ldb = in; d.C = y; d.ldc = ldy; d.bias = bias;
+    d.M = (int)batch; d.N = out; d.K = in; d.epi = EPI_STORE; d.act = act;
+    const int rc = launch_glds<false, false>(c, d, false, s, "linear_fwd gemm (lds-dma)");
+    if (rc != 0) return rc < 0 ? rc : FFH_OK;
+  }
   return launch_gemm<true, true>(c, g, 1, s, "linear_fwd gemm");
 }
 
@@ -543,6 +830,9 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   if (batch == 0) return FFH_OK;
   // 1. sigmoid: its gradient is not idempotent, so it gets its own in-place pass (with the bias sums).
   //    relu / none: folded into the GEMMs' operand loads below (no separate pass over dy).
+  const bool premasked = (flags & FFH_LINEAR_DY_PREMASKED) != 0;
+  if (premasked) act = FFH_AC_MODE_NONE;           // the producer of dy applied the activation derivative already
+  const bool mask_by_x = (flags & FFH_LINEAR_DX_MASK_BY_X) != 0;
   const bool separate = act == FFH_AC_MODE_SIGMOID;
   const bool do_dw = !(flags & FFH_LINEAR_ONLY_DX);
   const bool do_dx = !(flags & FFH_LINEAR_ONLY_DW);
@@ -580,7 +870,18 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     g.epi = EPI_ATOMIC; g.act = FFH_AC_MODE_NONE;
     g.act_y = y; g.ld_act_y = ldy; g.db = db;
     g.fuse = separate ? 0 : ((relu ? 1 : 0) | (db ? 2 : 0));
-    int rc = launch_gemm<false, false, true>(c, g, 1, sw, "linear_bwd dw gemm");
+    int rc = 0;
+    if (!relu) {
+      // no mask to apply while loading: eligible for the LDS-DMA kernel (db from its LDS image)
+      GldsArgs d{};
+      d.A = dy; d.lda = lddy; d.B = x; d.ldb = ldx; d.C = dw; d.ldc = in;
+      d.M = out; d.N = in; d.K = (int)batch; d.epi = EPI_ATOMIC; d.act = FFH_AC_MODE_NONE;
+      d.db = separate ? nullptr : db;
+      rc = launch_glds<true, true>(c, d, true, sw, "linear_bwd dw gemm (lds-dma)");
+      if (rc < 0) return rc;
+    }
+    if (rc == 0) rc = launch_gemm<false, false, true>(c, g, 1, sw, "linear_bwd dw gemm");
+    else rc = 0;
     if (rc) return rc;
   }
   // 3. dx[b][i] (+)= sum_o dy[b][o] w[o][i].  Unforked it runs behind the dw GEMM and reads the masked dy;
@@ -593,7 +894,17 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     g.M = (int)batch; g.N = in; g.K = out;
     g.epi = (flags & FFH_LINEAR_DX_OVERWRITE) ? EPI_STORE : EPI_ADD;
     g.act = FFH_AC_MODE_NONE;
+    if (mask_by_x) { g.mask = x; g.ldmask = ldx; }
     int rc;
+    if (!relu) {
+      GldsArgs d{};
+      d.A = dy; d.lda = lddy; d.B = w; d.ldb = in; d.C = dx; d.ldc = lddx;
+      d.M = (int)batch; d.N = in; d.K = out; d.epi = g.epi; d.act = FFH_AC_MODE_NONE;
+      if (mask_by_x) { d.mask = x; d.ldmask = ldx; }
+      rc = launch_glds<false, true>(c, d, false, s, "linear_bwd dx gemm (lds-dma)");
+      if (rc < 0) return rc;
+      if (rc == 1) return FFH_OK;
+    }
     if ((forked || !do_dw) && relu) {
       g.act_y = y; g.ld_act_y = ldy; g.fuse = 1;
       rc = launch_gemm<true, false, true>(c, g, 1, s, "linear_bwd dx gemm (masking)");

@@ -24,12 +24,14 @@ int ffh_ctx_create(ffh_ctx** out, int device) {
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, device) == hipSuccess) c->num_cus = p.multiProcessorCount;
   if (c->num_cus <= 0) c->num_cus = 256;
+  if (hipMalloc((void**)&c->zeros, 256) != hipSuccess || hipMemset(c->zeros, 0, 256) != hipSuccess) { (void)hipGetLastError(); c->zeros = nullptr; }
   *out = c;
   return FFH_OK;
 }
 
 int ffh_ctx_destroy(ffh_ctx* c) {
   if (c && c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c && c->zeros) (void)hipFree(c->zeros);
   delete c;
   return FFH_OK;
 }

@@ -276,6 +276,7 @@ class Linear : public Op {
   bool use_bias;
   bool discard_input_grad;      // first layer on a model input: dX is never consumed
   bool dx_overwrite;            // input has no other consumer: dX may be stored instead of accumulated
+  bool dx_mask_by_x, dy_premasked;   // relu' of the layer below applied by this layer's dX epilogue / already applied by the layer above
   Initializer *kernel_initializer, *bias_initializer;
 };
 

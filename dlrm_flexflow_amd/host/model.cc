@@ -518,7 +518,8 @@ Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_
 Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activation, bool _use_bias, const Op* shared_op,
                Initializer* ki, Initializer* bi, const char* name)
     : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), activation(_activation),
-      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), kernel_initializer(ki), bias_initializer(bi) {
+      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), dx_mask_by_x(false), dy_premasked(false),
+      kernel_initializer(ki), bias_initializer(bi) {
   if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
   if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
   if (activation != AC_MODE_NONE && activation != AC_MODE_RELU && activation != AC_MODE_SIGMOID)
@@ -551,7 +552,7 @@ void Linear::backward(const FFModel& ff) {
   const int64_t b = local_rows(y, &ff);
   float* dx = discard_input_grad ? nullptr : x.impl->grad;
   const bool fork = ff.config.parallel_dw;
-  const int flags = dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0;
+  const int flags = (dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0) | (dx_mask_by_x ? FFH_LINEAR_DX_MASK_BY_X : 0) | (dy_premasked ? FFH_LINEAR_DY_PREMASKED : 0);
   const float *xp = (const float*)x.impl->ptr, *yp = (const float*)y.impl->ptr, *wp = (const float*)weights[0].impl->ptr;
   float *dyp = y.impl->grad, *dwp = weights[0].impl->grad, *dbp = use_bias ? weights[1].impl->grad : nullptr;
   const int64_t ldx = x.impl->ld, lddx = x.impl->grad_ld, ldy = y.impl->ld, lddy = y.impl->grad_ld;
@@ -1208,7 +1209,18 @@ void FFModel::allocate() {
     if (consumers[op->outputs[0].impl] > 1) need_zero_act_grads = true;           // several ops add into its gradient
     if (op->op_type == OP_BATCHMATMUL || op->op_type == OP_TRANSPOSE || op->op_type == OP_RESHAPE || op->op_type == OP_FLAT)
       need_zero_act_grads = true;                                                // these accumulate into their operands' gradients
-    if (Linear* li = dynamic_cast<Linear*>(op)) li->dx_overwrite = consumers[li->inputs[0].impl] == 1;
+    if (Linear* li = dynamic_cast<Linear*>(op)) {
+      li->dx_overwrite = consumers[li->inputs[0].impl] == 1;
+      // Linear(ReLU) -> Linear with nothing else reading the tensor in between: the upper layer applies the lower layer's
+      // relu' to the gradient it hands down (FFH_LINEAR_DX_MASK_BY_X), the lower one takes it as is (DY_PREMASKED) --
+      // reluBackward [ref: src/runtime/cuda_helper.cu:71-78] moved to where its operand is produced, so that no backward
+      // kernel has to re-read y next to dy
+      Linear* below = li->inputs[0].owner_op ? dynamic_cast<Linear*>(const_cast<Op*>(li->inputs[0].owner_op)) : nullptr;
+      if (below && below->activation == AC_MODE_RELU && li->dx_overwrite && !li->discard_input_grad) {
+        li->dx_mask_by_x = true;
+        below->dy_premasked = true;
+      }
+    }
     if (Concat* c = dynamic_cast<Concat*>(op))
       for (int i = 0; i < c->numInputs; i++) {
         TensorImpl* im = c->inputs[i].impl;

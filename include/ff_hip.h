@@ -245,6 +245,16 @@ int ffh_linear_bwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t
  * Issued once each (any order for relu / none) they equal one ffh_linear_bwd call. */
 #define FFH_LINEAR_ONLY_DX 4
 #define FFH_LINEAR_ONLY_DW 2
+/* moving relu' to the producer of a gradient (what a fused Linear->Linear chain does): the layer ABOVE hands down a
+ * gradient that already carries this layer's activation derivative, so no kernel has to read y and dy again:
+ *   FFH_LINEAR_DX_MASK_BY_X  x is the output of a ReLU (the layer below): the data gradient this call produces is
+ *                            (x > 0) ? dy*w : 0, i.e. reluBackward [ref: src/runtime/cuda_helper.cu:71-78] of the layer
+ *                            below applied where its operand is produced (x > 0 <=> that layer's y > 0)
+ *   FFH_LINEAR_DY_PREMASKED  dy already carries this layer's activation derivative (its consumer ran with
+ *                            DX_MASK_BY_X): that step is skipped, dy is not modified, db = column sums of dy
+ * A layer run with DY_PREMASKED below a layer run with DX_MASK_BY_X computes exactly what two plain calls compute. */
+#define FFH_LINEAR_DY_PREMASKED 8
+#define FFH_LINEAR_DX_MASK_BY_X 16
 int ffh_linear_bwd_ex(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,
                       const float* w, float* dw, float* db,

@@ -356,7 +356,7 @@ static float act_grad(float d, float yo, int act) {
 static int linear_bwd_parts(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
                             const float* y, int64_t ldy, float* dy, int64_t lddy,
                             const float* w, float* dw, float* db, int in, int out, int64_t B, int act,
-                            int act_inplace, int do_dw, int do_db, int do_dx, int mask_on_load) {
+                            int act_inplace, int do_dw, int do_db, int do_dx, int mask_on_load, int mask_by_x) {
   if (in <= 0 || out <= 0 || B < 0 || ldx < in || ldy < out || lddy < out || (dx && lddx < in))
     return fail(c, FFH_ERR_BAD_ARG, "linear_bwd: bad dims");
   if (act != FFH_AC_MODE_NONE && act != FFH_AC_MODE_RELU && act != FFH_AC_MODE_SIGMOID)
@@ -404,7 +404,8 @@ static int linear_bwd_parts(ffh_ctx* c, const float* x, int64_t ldx, float* dx, 
           const float* wr = w + (size_t)o * in;
           for (int i = 0; i < in; i++) tmp[i] = fmaf(d, wr[i], tmp[i]);
         }
-        for (int i = 0; i < in; i++) dx[b * lddx + i] += tmp[i];
+        /* DX_MASK_BY_X: reluBackward of the layer below, applied to what this layer hands down */
+        for (int i = 0; i < in; i++) dx[b * lddx + i] += (mask_by_x && !(x[b * ldx + i] > 0.0f)) ? 0.0f : tmp[i];
       }
       free(tmp);
     }
@@ -417,7 +418,7 @@ int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t l
                    const float* w, float* dw, float* db,
                    int in, int out, int64_t B, int act, ffh_stream s) {
   (void)s;
-  return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, 1, 1, 1, 1, 0);
+  return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, 1, 1, 1, 1, 0, 0);
 }
 
 /* same arithmetic; streams mean nothing on the host.  DX_OVERWRITE: dx is zeroed here, then accumulated */
@@ -430,12 +431,19 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   if (only_dx && only_dw) return fail(c, FFH_ERR_BAD_ARG, "linear_bwd_ex: ONLY_DX and ONLY_DW are exclusive");
   if ((flags & FFH_LINEAR_DX_OVERWRITE) && !only_dw && dx && in > 0 && lddx >= in)
     for (int64_t b = 0; b < B; b++) memset(dx + b * lddx, 0, sizeof(float) * (size_t)in);
+  const int mbx = (flags & FFH_LINEAR_DX_MASK_BY_X) ? 1 : 0;
+  if (flags & FFH_LINEAR_DY_PREMASKED) {
+    /* the activation derivative was applied by the producer of dy: this layer is linear in dy */
+    if (only_dx) return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, FFH_AC_MODE_NONE, 0, 0, 0, 1, 0, mbx);
+    if (only_dw) return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, FFH_AC_MODE_NONE, 0, 1, 1, 0, 0, 0);
+    return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, FFH_AC_MODE_NONE, 0, 1, 1, 1, 0, mbx);
+  }
   const int sig = act == FFH_AC_MODE_SIGMOID;
   if (only_dx)   /* sigmoid: in-place pass + db here; relu: dy untouched, masked while read */
-    return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, sig, 0, sig, 1, !sig);
+    return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, sig, 0, sig, 1, !sig, mbx);
   if (only_dw)   /* relu: mask written back in place; sigmoid: dy already transformed, db already done */
-    return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, sig ? FFH_AC_MODE_NONE : act, !sig, 1, !sig, 0, 0);
-  return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, 1, 1, 1, 1, 0);
+    return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, sig ? FFH_AC_MODE_NONE : act, !sig, 1, !sig, 0, 0, 0);
+  return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, 1, 1, 1, 1, 0, mbx);
 }
 
 /* ------------------------------------------------------------------ */
