@@ -27,6 +27,7 @@ AGGR_MODE_NONE, AGGR_MODE_SUM, AGGR_MODE_AVG = 20, 21, 22
 MAX_TABLES = 64
 EMB_CHUNK, EMB_CHUNK1 = 32, 1024
 OPT_ZERO_GRAD = 1
+LINEAR_DX_OVERWRITE, LINEAR_ONLY_DW, LINEAR_ONLY_DX, LINEAR_DY_PREMASKED, LINEAR_DX_MASK_BY_X = 1, 2, 4, 8, 16
 METRIC_ACCURACY, METRIC_MSE, METRIC_RMSE, METRIC_MAE = 1, 2, 4, 8
 
 P = C.c_void_p

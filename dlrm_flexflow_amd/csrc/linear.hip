@@ -791,6 +791,110 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   return FFH_OK;
 }
 
+// =============================================================================================
+// Linear with a handful of outputs (the click-probability layer of the DLRM top MLP: out = 1).  GEMV-shaped and
+// HBM-bound: a 32x32 MFMA tile would be 97 % padding and the layer would cost three or four launches; here the
+// forward is one wave per sample row and the whole backward (activation gradient in place, db, dW, dX) ONE launch.
+// =============================================================================================
+constexpr int kSkinnyMaxOut = 4;
+constexpr int kSkinnyMaxIn = 1024;      // backward: a thread keeps <= 4 columns x kSkinnyMaxOut partial dW sums
+
+__global__ __launch_bounds__(256) void linear_skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+                                                                const float* __restrict__ w, const float* __restrict__ bias, int in, int out,
+                                                                int64_t batch, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < batch; b += (int64_t)gridDim.x * 4) {
+    float acc[kSkinnyMaxOut] = {0.f, 0.f, 0.f, 0.f};
+    const float* xr = x + b * ldx;
+    for (int i = lane; i < in; i += 64) {
+      const float xv = xr[i];
+#pragma unroll
+      for (int o = 0; o < kSkinnyMaxOut; o++)
+        if (o < out) acc[o] = __fmaf_rn(xv, w[(int64_t)o * in + i], acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < kSkinnyMaxOut; o++)
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) acc[o] += __shfl_down(acc[o], d);
+    if (lane == 0)
+      for (int o = 0; o < out; o++) y[b * ldy + o] = act_apply(acc[o] + (bias ? bias[o] : 0.0f), act);
+  }
+}
+
+struct SkinnyBwdArgs {
+  const float* x;  float* dx;  const float* y;  float* dy;  const float* w;  float* dw;  float* db;
+  int64_t ldx, lddx, ldy, lddy, batch;
+  int in, out, rows_per_block;
+  int act;          // activation whose derivative is applied to dy here (NONE: dy is taken as it is)
+  int write_back;   // store the activation gradient into dy (the reference mutates dy in place)
+  int do_db, do_dw, do_dx, dx_overwrite, mask_by_x;
+};
+
+__global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdArgs a) {
+  extern __shared__ float s_dz[];                       // [rows_per_block][out]
+  const int tid = threadIdx.x;
+  const int64_t b0 = (int64_t)blockIdx.x * a.rows_per_block;
+  const int rows = (int)((a.batch - b0) < a.rows_per_block ? (a.batch - b0) : a.rows_per_block);
+  if (rows <= 0) return;
+  // 1. activation gradient of this block's rows: reluBackward [ref: src/runtime/cuda_helper.cu:71-78] /
+  //    sigmoid_backward [ref: src/ops/linear.cu:600-607], once per element, then shared through LDS
+  for (int e = tid; e < rows * a.out; e += 256) {
+    const int r = e / a.out, o = e - r * a.out;
+    float d = a.dy[(b0 + r) * a.lddy + o];
+    if (a.act == FFH_AC_MODE_RELU) d = a.y[(b0 + r) * a.ldy + o] > 0.0f ? d : 0.0f;
+    else if (a.act == FFH_AC_MODE_SIGMOID) { const float yo = a.y[(b0 + r) * a.ldy + o]; d = d * yo * (1 - yo); }
+    if (a.write_back) a.dy[(b0 + r) * a.lddy + o] = d;
+    s_dz[e] = d;
+  }
+  __syncthreads();
+  if (a.do_db && a.db && tid < a.out) {
+    float sum = 0.f;
+    for (int r = 0; r < rows; r++) sum += s_dz[r * a.out + tid];
+    atomicAdd(&a.db[tid], sum);
+  }
+  // 2. a thread owns columns tid, tid + 256, ...: dX row by row, dW partial sums over the block's rows in registers
+  float wv[4][kSkinnyMaxOut], dwacc[4][kSkinnyMaxOut];
+#pragma unroll
+  for (int c = 0; c < 4; c++)
+#pragma unroll
+    for (int o = 0; o < kSkinnyMaxOut; o++) {
+      const int i = tid + 256 * c;
+      wv[c][o] = (i < a.in && o < a.out) ? a.w[(int64_t)o * a.in + i] : 0.0f;
+      dwacc[c][o] = 0.0f;
+    }
+  for (int r = 0; r < rows; r++) {
+    float dz[kSkinnyMaxOut];
+#pragma unroll
+    for (int o = 0; o < kSkinnyMaxOut; o++) dz[o] = o < a.out ? s_dz[r * a.out + o] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = tid + 256 * c;
+      if (i >= a.in) continue;
+      const float xv = a.x[(b0 + r) * a.ldx + i];
+      if (a.do_dw) {
+#pragma unroll
+        for (int o = 0; o < kSkinnyMaxOut; o++) dwacc[c][o] = __fmaf_rn(dz[o], xv, dwacc[c][o]);
+      }
+      if (a.do_dx) {
+        float v = 0.0f;
+#pragma unroll
+        for (int o = 0; o < kSkinnyMaxOut; o++) v = __fmaf_rn(dz[o], wv[c][o], v);
+        if (a.mask_by_x && !(xv > 0.0f)) v = 0.0f;
+        float* p = a.dx + (b0 + r) * a.lddx + i;
+        *p = a.dx_overwrite ? v : *p + v;
+      }
+    }
+  }
+  if (a.do_dw) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = tid + 256 * c;
+      if (i >= a.in) continue;
+      for (int o = 0; o < a.out; o++) atomicAdd(&a.dw[(int64_t)o * a.in + i], dwacc[c][o]);
+    }
+  }
+}
+
 bool act_ok(int act) { return act == FFH_AC_MODE_NONE || act == FFH_AC_MODE_RELU || act == FFH_AC_MODE_SIGMOID; }
 
 }  // namespace
@@ -804,6 +908,12 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   FFH_REQUIRE(c, batch < (1LL << 31), "linear_fwd: batch too large");
   if (!act_ok(act)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_fwd: activation not supported (NONE, RELU, SIGMOID)");
   if (batch == 0) return FFH_OK;
+  if (out <= kSkinnyMaxOut) {
+    hipLaunchKernelGGL(linear_skinny_fwd_kernel, dim3(ffh_grid(batch, 4, 2048)), dim3(256), 0, as_stream(s), x, ldx, y, ldy, w, bias, in, out,
+                       batch, act);
+    FFH_LAUNCH_CHECK(c, "linear_skinny_fwd_kernel");
+    return FFH_OK;
+  }
   GemmArgs g{};
   g.A = x; g.sAm = ldx; g.sAk = 1;
   g.B = w; g.sBn = in; g.sBk = 1;
@@ -837,6 +947,27 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   const bool do_dw = !(flags & FFH_LINEAR_ONLY_DX);
   const bool do_dx = !(flags & FFH_LINEAR_ONLY_DW);
   FFH_REQUIRE(c, do_dw || do_dx, "linear_bwd_ex: ONLY_DX and ONLY_DW are exclusive");
+  if (out <= kSkinnyMaxOut && in <= kSkinnyMaxIn) {
+    // one launch for the whole layer (the split ONLY_* forms keep their meaning; a forked dw stream is not needed)
+    const bool only_dx = !do_dw, only_dw = !do_dx;
+    SkinnyBwdArgs a{};
+    a.x = x; a.dx = dx; a.y = y; a.dy = dy; a.w = w; a.dw = dw; a.db = db;
+    a.ldx = ldx; a.lddx = lddx; a.ldy = ldy; a.lddy = lddy; a.batch = batch; a.in = in; a.out = out;
+    a.act = (only_dw && separate) ? FFH_AC_MODE_NONE : act;            // sigmoid: the ONLY_DX call transformed dy already
+    a.write_back = a.act != FFH_AC_MODE_NONE && !(only_dx && !separate);  // relu + ONLY_DX: dy is read through the mask, not written
+    a.do_db = only_dx ? separate : (only_dw ? !separate : 1);
+    a.do_dw = do_dw; a.do_dx = do_dx && dx != nullptr;
+    a.dx_overwrite = (flags & FFH_LINEAR_DX_OVERWRITE) ? 1 : 0;
+    a.mask_by_x = mask_by_x ? 1 : 0;
+    int64_t rpb = (batch + c->num_cus / 2 - 1) / (c->num_cus / 2);
+    if (rpb < 8) rpb = 8;
+    if (rpb > 256) rpb = 256;
+    a.rows_per_block = (int)rpb;
+    const unsigned grid = (unsigned)((batch + rpb - 1) / rpb);
+    hipLaunchKernelGGL(linear_skinny_bwd_kernel, dim3(grid), dim3(256), (size_t)rpb * out * sizeof(float), as_stream(s), a);
+    FFH_LAUNCH_CHECK(c, "linear_skinny_bwd_kernel");
+    return FFH_OK;
+  }
   if (separate && do_dx) {
     const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
     const int cols_v = v4 ? out / 4 : out;

@@ -103,6 +103,20 @@ def linear_bwd(x, y, dy, w, act=capi.AC_MODE_NONE, want_dx=True, use_bias=True):
     return dx, dw, db, dy
 
 
+def linear_bwd_ex(x, y, dy, w, act, flags, dx0=None, use_bias=True):
+    """ffh_linear_bwd_ex with explicit flags (capi.LINEAR_*); dx starts from dx0 (zeros if None).
+    Returns (dx, dw, db, dy_after)."""
+    x, y, w = _f32(x), _f32(y), _f32(w)
+    dy = _f32(dy).copy()
+    B, IN = x.shape
+    OUT = w.shape[0]
+    dx = np.zeros((B, IN), np.float32) if dx0 is None else _f32(dx0).copy()
+    dw = np.zeros((OUT, IN), np.float32)
+    db = np.zeros((OUT,), np.float32) if use_bias else None
+    lib().call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy, OUT, w, dw, db, IN, OUT, B, act, flags, None, None)
+    return dx, dw, db, dy
+
+
 def concat_fwd(parts):
     parts = [_f32(p) for p in parts]
     nb = parts[0].shape[0]

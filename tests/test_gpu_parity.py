@@ -307,7 +307,8 @@ def test_linear_torch_golden(hip):
     (2048, 13, 512, capi.AC_MODE_RELU), (2048, 512, 256, capi.AC_MODE_RELU), (2048, 256, 64, capi.AC_MODE_RELU),
     (2048, 64, 16, capi.AC_MODE_RELU), (2048, 432, 512, capi.AC_MODE_RELU), (2048, 256, 1, capi.AC_MODE_SIGMOID),
     (128, 144, 64, capi.AC_MODE_NONE), (4096, 1024, 1024, capi.AC_MODE_RELU), (333, 77, 45, capi.AC_MODE_SIGMOID),
-    (10, 2000, 1000, capi.AC_MODE_NONE)])
+    (10, 2000, 1000, capi.AC_MODE_NONE), (4096, 1024, 1, capi.AC_MODE_SIGMOID), (515, 300, 4, capi.AC_MODE_RELU),
+    (64, 1500, 2, capi.AC_MODE_NONE)])
 def test_linear_vs_oracle(hip, oracle, B, IN, OUT, act):
     """DLRM layer shapes of C1/C2/C4 plus ragged sizes and the reference harness shape
     (10,2000,1000) [ref: tests/ops/test_harness.py:201-283]."""
@@ -350,12 +351,13 @@ def test_linear_strided_operands_and_accumulate(hip, oracle):
     np.testing.assert_allclose(host(dwt), dw_e, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("OUT", [80, 1, 3])
 @pytest.mark.parametrize("act", [capi.AC_MODE_RELU, capi.AC_MODE_SIGMOID, capi.AC_MODE_NONE])
-def test_linear_bwd_ex_forms_equal_reference_form(hip, oracle, act):
+def test_linear_bwd_ex_forms_equal_reference_form(hip, oracle, act, OUT):
     """ffh_linear_bwd_ex: overwrite-mode dx, the forked weight-gradient stream, and the split
     ONLY_DX / ONLY_DW calls all give what one ffh_linear_bwd call gives (and what the oracle gives)."""
     rng = np.random.default_rng(act)
-    B, IN, OUT = 777, 96, 80
+    B, IN = 777, 96            # OUT = 1, 3: the one-launch skinny-output kernels (linear_skinny_*), OUT = 80: the GEMMs
     x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
     w = (rng.uniform(-1, 1, (OUT, IN)) / 8).astype(np.float32)
     b = rng.uniform(-1, 1, OUT).astype(np.float32)
@@ -385,6 +387,50 @@ def test_linear_bwd_ex_forms_equal_reference_form(hip, oracle, act):
         assert_gemm_close(dx, dx_e, a @ np.abs(w).astype(np.float64), f"dx {mode}")
         assert_gemm_close(dw, dw_e, a.T @ np.abs(x).astype(np.float64), f"dw {mode}")
         assert_gemm_close(db, db_e, a.sum(0), f"db {mode}")
+
+
+@pytest.mark.parametrize("B,IN,OUT", [(2048, 432, 512), (2048, 512, 256), (2050, 436, 260), (300, 1024, 512), (4096, 200, 256),
+                                      (1000, 256, 640)])
+def test_linear_lds_dma_kernel_shapes(hip, oracle, B, IN, OUT):
+    """The LDS-DMA GEMM (linear.hip, gemm_glds_kernel) on its own: the two Kaggle shapes it exists for, ragged M / N
+    (rows and columns served from the zero page), a k extent that is not a multiple of the 64-wide k-tile, the 32x64
+    tile form (few tiles), split-K over the batch for dW with db from the LDS image, strided operands, and the
+    producer-side relu' flags -- against the oracle's plain calls."""
+    rng = np.random.default_rng(B + IN + OUT)
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    for act in (capi.AC_MODE_RELU, capi.AC_MODE_NONE):
+        y = gpu_linear_fwd(hip, x, w, b, act, ldx=IN + 4, ldy=OUT + 8)
+        mass = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+        assert_gemm_close(y, oracle.linear_fwd(x, w, b, act), mass, f"y act {act}")
+    # layer taken as the LOWER one of a chain: dy arrives premasked; and as the UPPER one: dx masked by x > 0
+    y = oracle.linear_fwd(x, w, b, capi.AC_MODE_RELU)
+    xr = np.maximum(x, 0)                       # pretend x is itself a ReLU output
+    yr = oracle.linear_fwd(xr, w, b, capi.AC_MODE_RELU)
+    gm = np.where(yr > 0, gy, 0).astype(np.float32)
+    flags = capi.LINEAR_DY_PREMASKED | capi.LINEAR_DX_MASK_BY_X
+    dx_e, dw_e, db_e, _ = oracle.linear_bwd_ex(xr, yr, gm, w, capi.AC_MODE_RELU, flags | capi.LINEAR_DX_OVERWRITE)
+    a = np.abs(gm).astype(np.float64)
+    for mode in ("overwrite", "accumulate", "fork"):
+        dx0 = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+        dx, dw, db, dy = dev(dx0), torch.zeros(OUT, IN, device=DEV), torch.zeros(OUT, device=DEV), dev(gm)
+        f = flags | (0 if mode == "accumulate" else capi.LINEAR_DX_OVERWRITE)
+        s2 = torch.cuda.Stream()
+        hip.call("ffh_linear_bwd_ex", dev(xr), IN, dx, IN, dev(yr), OUT, dy, OUT, dev(w), dw, db, IN, OUT, B, capi.AC_MODE_RELU, f,
+                 None, s2.cuda_stream if mode == "fork" else None)
+        torch.cuda.synchronize()
+        assert bits_equal(host(dy), gm)                                       # premasked dy is not touched
+        exp_dx = dx_e + (dx0 if mode == "accumulate" else 0)
+        assert_gemm_close(host(dx), exp_dx, a @ np.abs(w).astype(np.float64) + (np.abs(dx0) if mode == "accumulate" else 0), f"dx {mode}")
+        assert (host(dx)[xr <= 0] == (dx0[xr <= 0] if mode == "accumulate" else 0)).all()    # the mask is exact
+        assert_gemm_close(host(dw), dw_e, a.T @ np.abs(xr).astype(np.float64), f"dw {mode}")
+        assert_gemm_close(host(db), db_e, a.sum(0), f"db {mode}")
+    # and the whole chain semantics on the GPU: plain two-call form == flagged form (1e-5)
+    dxp, dwp, dbp, _ = gpu_linear_bwd(hip, xr, yr, gy, w, capi.AC_MODE_RELU)
+    assert_gemm_close(dwp, dw_e, a.T @ np.abs(xr).astype(np.float64), "dw plain vs flagged")
+    assert_gemm_close(dbp, db_e, a.sum(0), "db plain vs flagged")
 
 
 def test_linear_unsupported_activation_is_an_error(hip):

@@ -246,6 +246,41 @@ def test_sgd_and_mse_match_torch_golden(oracle):
     assert abs(perf.mse_loss - float(g["mse_sum"])) <= 1e-5 * float(g["mse_sum"])
 
 
+def test_relu_mask_moved_to_the_producer_equals_plain_calls(oracle):
+    """FFH_LINEAR_DX_MASK_BY_X on the upper layer + FFH_LINEAR_DY_PREMASKED on the lower one compute exactly what two
+    plain Linear::backward calls compute (reluBackward [ref: src/runtime/cuda_helper.cu:71-78] applied where its
+    operand is produced) -- bit for bit in the oracle, and equal to torch autograd through relu."""
+    import torch
+    rng = np.random.default_rng(11)
+    B, I0, H, O = 37, 12, 20, 9
+    x0 = rng.uniform(-1, 1, (B, I0)).astype(np.float32)
+    w1, b1 = rng.uniform(-1, 1, (H, I0)).astype(np.float32), rng.uniform(-1, 1, H).astype(np.float32)
+    w2, b2 = rng.uniform(-1, 1, (O, H)).astype(np.float32), rng.uniform(-1, 1, O).astype(np.float32)
+    g2 = rng.uniform(-1, 1, (B, O)).astype(np.float32)
+    y1 = oracle.linear_fwd(x0, w1, b1, capi.AC_MODE_RELU)
+    y2 = oracle.linear_fwd(y1, w2, b2, capi.AC_MODE_NONE)
+    # plain: upper layer hands down dy1 unmasked, lower layer masks it in place
+    dy1, dw2, db2, _ = oracle.linear_bwd(y1, y2, g2, w2, capi.AC_MODE_NONE)
+    dx0, dw1, db1, dy1_after = oracle.linear_bwd(x0, y1, dy1, w1, capi.AC_MODE_RELU)
+    # moved: the mask is applied by the upper layer's data-gradient step
+    F = capi
+    dy1_m, dw2_m, db2_m, _ = oracle.linear_bwd_ex(y1, y2, g2, w2, capi.AC_MODE_NONE, F.LINEAR_DX_OVERWRITE | F.LINEAR_DX_MASK_BY_X,
+                                                 dx0=np.full((B, H), 7.0, np.float32))
+    dx0_m, dw1_m, db1_m, dy1_kept = oracle.linear_bwd_ex(x0, y1, dy1_m, w1, capi.AC_MODE_RELU, F.LINEAR_DY_PREMASKED)
+    assert np.array_equal(dy1_m, dy1_after) and np.array_equal(dy1_kept, dy1_m)
+    for a, b in ((dw2, dw2_m), (db2, db2_m), (dx0, dx0_m), (dw1, dw1_m), (db1, db1_m)):
+        assert np.array_equal(a, b)
+    # split calls carry the flags too
+    dxs, _, _, _ = oracle.linear_bwd_ex(x0, y1, dy1_m, w1, capi.AC_MODE_RELU, F.LINEAR_DY_PREMASKED | F.LINEAR_ONLY_DX)
+    _, dws, dbs, _ = oracle.linear_bwd_ex(x0, y1, dy1_m, w1, capi.AC_MODE_RELU, F.LINEAR_DY_PREMASKED | F.LINEAR_ONLY_DW)
+    assert np.array_equal(dxs, dx0) and np.array_equal(dws, dw1) and np.array_equal(dbs, db1)
+    t = {k: torch.tensor(v, requires_grad=True) for k, v in dict(x0=x0, w1=w1, b1=b1, w2=w2, b2=b2).items()}
+    out = torch.relu(t["x0"] @ t["w1"].T + t["b1"]) @ t["w2"].T + t["b2"]
+    out.backward(torch.from_numpy(g2))
+    for got, key in ((dx0_m, "x0"), (dw1_m, "w1"), (db1_m, "b1"), (dw2_m, "w2"), (db2_m, "b2")):
+        np.testing.assert_allclose(got, t[key].grad.numpy(), rtol=1e-5, atol=1e-5, err_msg=key)
+
+
 def test_adam_matches_torch_golden(oracle):
     """adam_update [ref: src/runtime/optimizer_kernel.cu:206-226] + AdamOptimizer::next [ref: optimizer.cc:248-254]
     against torch.optim.Adam over 5 steps (fixture: tests/golden/make_golden.py:adam_from_torch)."""
