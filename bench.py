@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="1 GPU: still run the all-to-all / all-reduce path (1-rank RCCL group)")
+    ap.add_argument("--shim-flags", default="", help="extra FFConfig flags for A/B runs, e.g. '--serial-dw --no-overlap'")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,7 +180,7 @@ def main():
         comm = TorchComm(on_gpu=True)
 
     w = workload(args.workload, args.per_gpu_batch, world)
-    extra = ["--device", str(local_rank)] + (["--no-trace"] if args.no_trace else []) + (["--force-exchange"] if args.force_exchange else [])
+    extra = ["--device", str(local_rank)] + (["--no-trace"] if args.no_trace else []) + (["--force-exchange"] if args.force_exchange else []) + args.shim_flags.split()
     app = ffmodel.DLRM(flags_of(w, extra), comm=comm.struct if comm else None)
     trace = not args.no_trace
 

@@ -641,7 +641,8 @@ int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const
   g.zeros = c->zeros;
   g.splitk = 1; g.k_per_split = (g.K + 63) / 64 * 64;
   if (atomic_splitk) {
-    int want = (int)((c->num_cus + tiles - 1) / tiles);
+    static const int split_ceil = getenv("FFH_GLDS_SPLIT_CEIL") ? atoi(getenv("FFH_GLDS_SPLIT_CEIL")) : 0;   // tuning aid
+    int want = split_ceil ? (int)((c->num_cus + tiles - 1) / tiles) : (int)(c->num_cus / tiles);   // default: one round of workgroups
     const int max_split = (g.K + 255) / 256;            // at least four k-tiles per workgroup
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
@@ -830,9 +831,11 @@ struct SkinnyBwdArgs {
   int do_db, do_dw, do_dx, dx_overwrite, mask_by_x;
 };
 
+// NC: 16-byte column chunks per lane (in <= 256 * NC), NO: output slots kept in registers (out <= NO)
+template <int NC, int NO>
 __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdArgs a) {
-  extern __shared__ float s_dz[];                       // [rows_per_block][out]
-  const int tid = threadIdx.x;
+  extern __shared__ float s_dz[];                       // [rows_per_block][out], then the cross-wave dW reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b0 = (int64_t)blockIdx.x * a.rows_per_block;
   const int rows = (int)((a.batch - b0) < a.rows_per_block ? (a.batch - b0) : a.rows_per_block);
   if (rows <= 0) return;
@@ -852,45 +855,81 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
     for (int r = 0; r < rows; r++) sum += s_dz[r * a.out + tid];
     atomicAdd(&a.db[tid], sum);
   }
-  // 2. a thread owns columns tid, tid + 256, ...: dX row by row, dW partial sums over the block's rows in registers
-  float wv[4][kSkinnyMaxOut], dwacc[4][kSkinnyMaxOut];
+  // 2. a wave takes rows wave, wave + 4, ...; a lane owns the 16-byte column chunks lane, lane + 64, ... of every row
+  //    (in <= 1024: at most 4 chunks), so a row is one coalesced pass; four rows are in flight per wave
+  const int nch = a.in / 4;
+  float4 wv[NC][NO];
+  float4 dwacc[NC][NO];
 #pragma unroll
-  for (int c = 0; c < 4; c++)
+  for (int c = 0; c < NC; c++)
 #pragma unroll
-    for (int o = 0; o < kSkinnyMaxOut; o++) {
-      const int i = tid + 256 * c;
-      wv[c][o] = (i < a.in && o < a.out) ? a.w[(int64_t)o * a.in + i] : 0.0f;
-      dwacc[c][o] = 0.0f;
+    for (int o = 0; o < NO; o++) {
+      const int ch = lane + 64 * c;
+      wv[c][o] = (ch < nch && o < a.out && a.do_dx) ? reinterpret_cast<const float4*>(a.w + (int64_t)o * a.in)[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+      dwacc[c][o] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  for (int r = 0; r < rows; r++) {
-    float dz[kSkinnyMaxOut];
+  for (int r0 = wave; r0 < rows; r0 += 16) {
+    float4 xv[4][NC];
 #pragma unroll
-    for (int o = 0; o < kSkinnyMaxOut; o++) dz[o] = o < a.out ? s_dz[r * a.out + o] : 0.0f;
+    for (int u = 0; u < 4; u++)
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int i = tid + 256 * c;
-      if (i >= a.in) continue;
-      const float xv = a.x[(b0 + r) * a.ldx + i];
-      if (a.do_dw) {
-#pragma unroll
-        for (int o = 0; o < kSkinnyMaxOut; o++) dwacc[c][o] = __fmaf_rn(dz[o], xv, dwacc[c][o]);
+      for (int c = 0; c < NC; c++) {
+        const int r = r0 + 4 * u, ch = lane + 64 * c;
+        xv[u][c] = (r < rows && ch < nch) ? reinterpret_cast<const float4*>(a.x + (b0 + r) * a.ldx)[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (a.do_dx) {
-        float v = 0.0f;
 #pragma unroll
-        for (int o = 0; o < kSkinnyMaxOut; o++) v = __fmaf_rn(dz[o], wv[c][o], v);
-        if (a.mask_by_x && !(xv > 0.0f)) v = 0.0f;
-        float* p = a.dx + (b0 + r) * a.lddx + i;
-        *p = a.dx_overwrite ? v : *p + v;
+    for (int u = 0; u < 4; u++) {
+      const int r = r0 + 4 * u;
+      if (r >= rows) continue;
+      float dz[NO];
+#pragma unroll
+      for (int o = 0; o < NO; o++) dz[o] = o < a.out ? s_dz[r * a.out + o] : 0.0f;
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        const int ch = lane + 64 * c;
+        if (ch >= nch) continue;
+        const float4 x4 = xv[u][c];
+        if (a.do_dw) {
+#pragma unroll
+          for (int o = 0; o < NO; o++) {
+            dwacc[c][o].x = __fmaf_rn(dz[o], x4.x, dwacc[c][o].x); dwacc[c][o].y = __fmaf_rn(dz[o], x4.y, dwacc[c][o].y);
+            dwacc[c][o].z = __fmaf_rn(dz[o], x4.z, dwacc[c][o].z); dwacc[c][o].w = __fmaf_rn(dz[o], x4.w, dwacc[c][o].w);
+          }
+        }
+        if (a.do_dx) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int o = 0; o < NO; o++) {
+            v.x = __fmaf_rn(dz[o], wv[c][o].x, v.x); v.y = __fmaf_rn(dz[o], wv[c][o].y, v.y);
+            v.z = __fmaf_rn(dz[o], wv[c][o].z, v.z); v.w = __fmaf_rn(dz[o], wv[c][o].w, v.w);
+          }
+          if (a.mask_by_x) {
+            v.x = x4.x > 0.0f ? v.x : 0.0f; v.y = x4.y > 0.0f ? v.y : 0.0f; v.z = x4.z > 0.0f ? v.z : 0.0f; v.w = x4.w > 0.0f ? v.w : 0.0f;
+          }
+          float4* p = reinterpret_cast<float4*>(a.dx + (b0 + r) * a.lddx) + ch;
+          if (!a.dx_overwrite) { const float4 q = *p; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+          *p = v;
+        }
       }
     }
   }
   if (a.do_dw) {
+    // the four waves' partial sums meet in LDS, one atomic per weight per workgroup
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(s_dz);       // [wave][out][nch]
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int i = tid + 256 * c;
-      if (i >= a.in) continue;
-      for (int o = 0; o < a.out; o++) atomicAdd(&a.dw[(int64_t)o * a.in + i], dwacc[c][o]);
+    for (int o = 0; o < NO; o++)
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        const int ch = lane + 64 * c;
+        if (o < a.out && ch < nch) red[((int64_t)wave * a.out + o) * nch + ch] = dwacc[c][o];
+      }
+    __syncthreads();
+    for (int e = tid; e < a.out * nch; e += 256) {
+      const float4 p0 = red[e], p1 = red[a.out * nch + e], p2 = red[2 * a.out * nch + e], p3 = red[3 * a.out * nch + e];
+      float* d = a.dw + (int64_t)e * 4;                 // e = o * nch + ch  ->  dw[o][4 ch]
+      atomicAdd(d + 0, (p0.x + p1.x) + (p2.x + p3.x)); atomicAdd(d + 1, (p0.y + p1.y) + (p2.y + p3.y));
+      atomicAdd(d + 2, (p0.z + p1.z) + (p2.z + p3.z)); atomicAdd(d + 3, (p0.w + p1.w) + (p2.w + p3.w));
     }
   }
 }
@@ -947,7 +986,9 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   const bool do_dw = !(flags & FFH_LINEAR_ONLY_DX);
   const bool do_dx = !(flags & FFH_LINEAR_ONLY_DW);
   FFH_REQUIRE(c, do_dw || do_dx, "linear_bwd_ex: ONLY_DX and ONLY_DW are exclusive");
-  if (out <= kSkinnyMaxOut && in <= kSkinnyMaxIn) {
+  static const int no_skinny = getenv("FFH_NO_SKINNY") ? atoi(getenv("FFH_NO_SKINNY")) : 0;   // tuning aid
+  const bool skinny_vec = !no_skinny && (in % 4 == 0) && glds_aligned(x, ldx) && (((uintptr_t)w & 15) == 0) && (!dx || glds_aligned(dx, lddx));
+  if (out <= kSkinnyMaxOut && in <= kSkinnyMaxIn && skinny_vec) {
     // one launch for the whole layer (the split ONLY_* forms keep their meaning; a forked dw stream is not needed)
     const bool only_dx = !do_dw, only_dw = !do_dx;
     SkinnyBwdArgs a{};
@@ -959,12 +1000,19 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     a.do_dw = do_dw; a.do_dx = do_dx && dx != nullptr;
     a.dx_overwrite = (flags & FFH_LINEAR_DX_OVERWRITE) ? 1 : 0;
     a.mask_by_x = mask_by_x ? 1 : 0;
-    int64_t rpb = (batch + c->num_cus / 2 - 1) / (c->num_cus / 2);
-    if (rpb < 8) rpb = 8;
+    int64_t rpb = (batch + c->num_cus - 1) / c->num_cus;               // about one workgroup per CU
+    rpb = (rpb + 15) / 16 * 16;                                            // 4 waves x 4 rows in flight
     if (rpb > 256) rpb = 256;
     a.rows_per_block = (int)rpb;
     const unsigned grid = (unsigned)((batch + rpb - 1) / rpb);
-    hipLaunchKernelGGL(linear_skinny_bwd_kernel, dim3(grid), dim3(256), (size_t)rpb * out * sizeof(float), as_stream(s), a);
+    size_t lds = (size_t)rpb * out * sizeof(float);
+    const size_t red = (size_t)4 * out * in * sizeof(float);            // cross-wave dW reduction
+    if (red > lds) lds = red;
+    const int nc = in <= 256 ? 1 : (in <= 512 ? 2 : 4);
+#define FFH_SKINNY(NCV, NOV) hipLaunchKernelGGL((linear_skinny_bwd_kernel<NCV, NOV>), dim3(grid), dim3(256), lds, as_stream(s), a)
+    if (out == 1) { if (nc == 1) FFH_SKINNY(1, 1); else if (nc == 2) FFH_SKINNY(2, 1); else FFH_SKINNY(4, 1); }
+    else { if (nc == 1) FFH_SKINNY(1, 4); else if (nc == 2) FFH_SKINNY(2, 4); else FFH_SKINNY(4, 4); }
+#undef FFH_SKINNY
     FFH_LAUNCH_CHECK(c, "linear_skinny_bwd_kernel");
     return FFH_OK;
   }

@@ -1,6 +1,8 @@
 // ffmodel_c.cc -- see ffmodel_c.h
 #include "ffmodel_c.h"
 
+#include <chrono>
+
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -157,6 +159,17 @@ float flexflow_dlrm_time_kernel(flexflow_dlrm_t h, int which, int iters) {
   };
   body(2);   // warm
   ff->sync();
+  if (which == 5) {
+    // host side only: wall time to ENQUEUE one eager step (the GPU drains behind; the queue never blocks at this depth)
+    which = 4;
+    const auto t0 = std::chrono::steady_clock::now();
+    body(iters);
+    const auto t1 = std::chrono::steady_clock::now();
+    ff->sync();
+    ff->api->ffh_event_destroy(ff->ctx, e0);
+    ff->api->ffh_event_destroy(ff->ctx, e1);
+    return (float)(std::chrono::duration<double, std::milli>(t1 - t0).count() / iters);
+  }
   ff->check(ff->api->ffh_event_record(ff->ctx, e0, ff->stream), "event");
   body(iters);
   ff->check(ff->api->ffh_event_record(ff->ctx, e1, ff->stream), "event");
