@@ -868,17 +868,18 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
       wv[c][o] = (ch < nch && o < a.out && a.do_dx) ? reinterpret_cast<const float4*>(a.w + (int64_t)o * a.in)[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
       dwacc[c][o] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  for (int r0 = wave; r0 < rows; r0 += 16) {
-    float4 xv[4][NC];
+  constexpr int U = 16 / NC;        // rows in flight per wave: U x NC 16-byte loads per lane
+  for (int r0 = wave; r0 < rows; r0 += 4 * U) {
+    float4 xv[U][NC];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < U; u++)
 #pragma unroll
       for (int c = 0; c < NC; c++) {
         const int r = r0 + 4 * u, ch = lane + 64 * c;
         xv[u][c] = (r < rows && ch < nch) ? reinterpret_cast<const float4*>(a.x + (b0 + r) * a.ldx)[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {
       const int r = r0 + 4 * u;
       if (r >= rows) continue;
       float dz[NO];
@@ -1000,9 +1001,11 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     a.do_dw = do_dw; a.do_dx = do_dx && dx != nullptr;
     a.dx_overwrite = (flags & FFH_LINEAR_DX_OVERWRITE) ? 1 : 0;
     a.mask_by_x = mask_by_x ? 1 : 0;
-    int64_t rpb = (batch + c->num_cus - 1) / c->num_cus;               // about one workgroup per CU
-    rpb = (rpb + 15) / 16 * 16;                                            // 4 waves x 4 rows in flight
-    if (rpb > 256) rpb = 256;
+    // dW / db are accumulated with one atomic per weight per workgroup: adds to ONE address serialise (~0.1 us each), so
+    // the number of workgroups is kept near 32 -- and every wave then keeps 16 / NC rows in flight to cover the latency
+    int64_t rpb = (batch + 31) / 32;
+    rpb = (rpb + 63) / 64 * 64;
+    if (rpb > 1024) rpb = 1024;
     a.rows_per_block = (int)rpb;
     const unsigned grid = (unsigned)((batch + rpb - 1) / rpb);
     size_t lds = (size_t)rpb * out * sizeof(float);
