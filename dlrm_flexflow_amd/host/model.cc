@@ -551,7 +551,11 @@ void Linear::backward(const FFModel& ff) {
   const Tensor& y = outputs[0];
   const int64_t b = local_rows(y, &ff);
   float* dx = discard_input_grad ? nullptr : x.impl->grad;
-  const bool fork = ff.config.parallel_dw;
+  // the weight-gradient GEMM gets its own stream only where it is long enough to pay for the fork and the join
+  // (two event records + two waits, each a packet the command processor has to retire): measured on the Kaggle shape,
+  // forking the 432x512 / 512x256 layers gains 22 us per step, forking the 256x64 / 64x16 / 13x512 ones loses 6
+  const double macs = (double)in_channels * out_channels * (double)b;
+  const bool fork = ff.config.parallel_dw && macs >= 1.0e8;
   const int flags = (dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0) | (dx_mask_by_x ? FFH_LINEAR_DX_MASK_BY_X : 0) | (dy_premasked ? FFH_LINEAR_DY_PREMASKED : 0);
   const float *xp = (const float*)x.impl->ptr, *yp = (const float*)y.impl->ptr, *wp = (const float*)weights[0].impl->ptr;
   float *dyp = y.impl->grad, *dwp = weights[0].impl->grad, *dbp = use_bias ? weights[1].impl->grad : nullptr;
