@@ -141,6 +141,21 @@ def terabyte_gather_probe(hip):
             "us_per_launch": round(sec * 1e6, 2), "algorithmic_bytes": nbytes}
 
 
+def largest_linear(w, B, t_fwd, t_bwd):
+    """MFMA roofline of the Linear layer with the most multiply-adds (Kaggle shape: top 432 -> 512), timed alone with HIP
+    events on the model's stream, back to back (so the ~2.5 us dependent-launch floor is inside the figure)."""
+    dims = [int(v) for v in w["bot"].split("-")], [int(v) for v in w["top"].split("-")]
+    pairs = [(a, b) for d in dims for a, b in zip(d[:-1], d[1:])]
+    i, o = max(pairs, key=lambda p: p[0] * p[1])
+    f = 2.0 * B * i * o
+    return {"layer": f"{i}->{o}, batch {B}", "bound": "mfma", "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "fwd": {"us": round(t_fwd * 1e6, 2), "achieved": round(f / t_fwd / 1e12, 1), "frac": round(f / t_fwd / 1e12 / F32_PEAK_TFLOPS, 3),
+                    "kernel": "gemm_glds_kernel<kc,kc> (LDS-DMA staged, 16 waves per 64x64 tile, bias + activation epilogue)"},
+            "bwd": {"us": round(t_bwd * 1e6, 2), "achieved": round(2 * f / t_bwd / 1e12, 1), "frac": round(2 * f / t_bwd / 1e12 / F32_PEAK_TFLOPS, 3),
+                    "kernel": "dX gemm_glds_kernel<kc,kr> (relu' of the layer below in the epilogue) beside dW gemm_glds_kernel<kr,kr> "
+                              "(split-K over the batch, db from the LDS image) on a second stream"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,7 +164,9 @@ def main():
     ap.add_argument("--workload", default="kaggle")
     ap.add_argument("--per-gpu-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="(default) kept for older command lines")
+    ap.add_argument("--probe", action="store_true", help="also time the gather at the Terabyte shape (4 tables x 40 M rows x 128, B = 32768): "
+                                                         "extra launches of emb_fwd_kernel, so off by default to keep the rocprof averages single-shape")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="1 GPU: still run the all-to-all / all-reduce path (1-rank RCCL group)")
     ap.add_argument("--shim-flags", default="", help="extra FFConfig flags for A/B runs, e.g. '--serial-dw --no-overlap'")
@@ -221,6 +238,8 @@ def main():
     t_fwd = app.time_kernel(0, 200) * 1e-3 if solo else None
     t_bwd = app.time_kernel(1, 100) * 1e-3 if solo else None
     t_step_dev = app.time_kernel(2 if trace else 4, 100) * 1e-3 if solo else None
+    t_lin_fwd = app.time_kernel(6, 200) * 1e-3 if solo else None      # largest Linear layer alone: forward, backward (dX + dW)
+    t_lin_bwd = app.time_kernel(7, 100) * 1e-3 if solo else None
     uses_graph = app.model.uses_graph and trace
     app.close()
 
@@ -260,10 +279,11 @@ def main():
             "embedding_bwd_sgd_fused": {"bound": "hbm", "achieved": round(bwd_bytes / t_bwd / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(bwd_bytes / t_bwd / 1e9 / HBM_PEAK_GBS, 4), "us_per_call": round(t_bwd * 1e6, 2),
                                         "note": "radix sort (hist+scatter per digit) + segmented reduce + two-level fold, all tables batched"},
+            "linear_largest_layer": largest_linear(w, B, t_lin_fwd, t_lin_bwd),
             "whole_step_device": {"us": round(t_step_dev * 1e6, 2), "mlp_gflop_per_step": round(flops / 1e9, 3),
                                   "mlp_tflops_over_whole_step": round(flops / t_step_dev / 1e12, 2), "f32_mfma_peak_tflops": F32_PEAK_TFLOPS},
         }
-        if not args.no_probe:
+        if args.probe and not args.no_probe:
             try:
                 out["kernels"]["embedding_gather_terabyte_shape"] = terabyte_gather_probe(capi.load_hip(local_rank))
             except Exception as e:  # noqa: BLE001

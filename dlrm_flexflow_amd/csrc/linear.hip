@@ -1003,8 +1003,9 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     a.mask_by_x = mask_by_x ? 1 : 0;
     // dW / db are accumulated with one atomic per weight per workgroup: adds to ONE address serialise (~0.1 us each), so
     // the number of workgroups is kept near 32 -- and every wave then keeps 16 / NC rows in flight to cover the latency
-    int64_t rpb = (batch + 31) / 32;
-    rpb = (rpb + 63) / 64 * 64;
+    static const int skinny_blocks = getenv("FFH_SKINNY_BLOCKS") ? atoi(getenv("FFH_SKINNY_BLOCKS")) : 32;   // tuning aid
+    int64_t rpb = (batch + skinny_blocks - 1) / skinny_blocks;
+    rpb = (rpb + 15) / 16 * 16;
     if (rpb > 1024) rpb = 1024;
     a.rows_per_block = (int)rpb;
     const unsigned grid = (unsigned)((batch + rpb - 1) / rpb);
