@@ -177,7 +177,9 @@ def gpu_fused(hip, idx, g, w, lr, aggr=capi.AGGR_MODE_SUM, gld=None):
 @pytest.mark.parametrize("B,L,D,R", [
     (32768, 1, 16, 3), (32768, 1, 128, 36), (8192, 1, 16, 1460), (4096, 1, 128, 100000), (2048, 1, 16, 10131227),
     (3000, 2, 64, 500), (1000, 3, 13, 40), (5000, 1, 20, 7), (1, 1, 16, 10), (129, 1, 8, 1), (2047, 1, 256, 2000),
-    (4096, 1, 512, 50)])
+    (4096, 1, 512, 50),
+    # batch * bag <= 2048: the single-launch small-batch kernel (all radix passes LDS-resident, then the same reduce / fold bodies)
+    (1024, 2, 16, 3), (1025, 1, 16, 5), (600, 3, 20, 17), (2048, 1, 64, 1), (512, 4, 32, 1 << 20), (33, 1, 16, 100000), (2048, 1, 16, 513)])
 def test_embedding_fused_bwd_sgd_bit_exact_vs_oracle(hip, oracle, ws, B, L, D, R):
     """Canonical-order reduction: the GPU result equals the oracle bit for bit, for heavy
     duplicates (R=3), rare duplicates, bags, odd D (scalar path) and rows untouched."""
@@ -207,11 +209,13 @@ def test_embedding_fused_bwd_sgd_bit_exact_vs_oracle(hip, oracle, ws, B, L, D, R
         assert torch.equal(wt[mask], before[mask])           # untouched rows keep their bits
 
 
-def test_embedding_fused_multi_table_strided_grad(hip, oracle, ws):
+@pytest.mark.parametrize("B", [4096, 2048, 300])
+def test_embedding_fused_multi_table_strided_grad(hip, oracle, ws, B):
     """Several tables in one call, gradients read as column slices of one [B][ld] buffer
-    (the concat gradient), exactly how the FFModel shim calls it."""
+    (the concat gradient), exactly how the FFModel shim calls it.  B <= 2048: the small-batch kernel with a different
+    number of radix passes per table."""
     rng = np.random.default_rng(5)
-    B, D = 4096, 16
+    D = 16
     rows = [3, 100, 5000, 250000, 17]
     ld = 16 + len(rows) * D
     G = rng.uniform(-1, 1, (B, ld)).astype(np.float32)
