@@ -243,6 +243,7 @@ void DataLoader::next_batch(FFModel& ff) {
   ff.check(ff.api->ffh_memcpy_d2d(ff.ctx, batch_label.impl->ptr, full_label + (int64_t)k * Bl, (size_t)Bl * sizeof(float), ff.stream),
            "load label");
   next_index += B;
+  ff.inputs_dirty = true;
 }
 
 // =============================================================================================

@@ -460,6 +460,8 @@ class FFModel {
   // trace / graph
   std::map<int, ffh_graph> graphs;
   int capturing_trace, replaying_trace;
+  mutable bool inputs_dirty;    // an input tensor was written on `stream` since the last forward(): the side-stream gather must be ordered behind it
+  mutable bool fork_recorded;   // this forward() recorded ev_fork
 
   std::vector<TensorImpl*> tensor_impls;
   std::vector<Tensor*> input_tensors;

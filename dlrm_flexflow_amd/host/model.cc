@@ -374,7 +374,7 @@ FFModel::FFModel(FFConfig& _config)
       ev_fork(nullptr), ev_join(nullptr), ev_grad_ready(nullptr), ev_update_done(nullptr), compiled(false),
       emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
       act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
-      xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1) {
+      xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1), inputs_dirty(true), fork_recorded(false) {
   dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
   rank = config.comm.world_size > 1 ? config.comm.rank : 0;
   world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
@@ -1366,7 +1366,13 @@ void FFModel::forward(int _seq_length) {
   emb_forward_issued = emb_forward_joined = false;
   // gather (+ all-to-all) go to the side stream beside the bottom MLP: the fork point is here (inputs ready)
   if (config.overlap_embedding && !embeddings.empty()) {
-    check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
+    // The side stream already runs behind everything it depends on from earlier steps (the table update is on it);
+    // what it must additionally see is a batch that was copied in on `stream`.  No new batch (the reference reuses
+    // the warm-up batch for random input), no event: each record / wait is a barrier packet on the critical stream.
+    static const bool old_events = getenv("FFM_OLD_EVENTS") && atoi(getenv("FFM_OLD_EVENTS"));   // A/B aid
+    fork_recorded = inputs_dirty || capturing_trace >= 0 || use_workers() || old_events;
+    if (fork_recorded) check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
+    inputs_dirty = false;
     // start the gather right now unless a host-side collective would stall THIS thread's launches
     if (!exchange || use_workers()) issue_embedding_forward_on_side_stream();
   }
@@ -1383,7 +1389,7 @@ void FFModel::issue_embedding_forward_on_side_stream() const {
       self->check(self->api->ffh_event_record(wc, self->ev_join, self->side_stream), "join");
     });
   } else {
-    check(api->ffh_stream_wait_event(ctx, side_stream, ev_fork), "fork");
+    if (fork_recorded) check(api->ffh_stream_wait_event(ctx, side_stream, ev_fork), "fork");
     embedding_group_forward(side_stream);
     check(api->ffh_event_record(ctx, ev_join, side_stream), "join");
   }
@@ -1495,7 +1501,11 @@ void FFModel::update() {
   }
   if (fused_embedding_update()) {
     if (config.overlap_embedding) {
-      if (!embeddings.empty()) check(api->ffh_stream_wait_event(ctx, stream, ev_update_done), "join update");   // launched in backward()
+      // launched in backward() on the side stream.  Its only consumer, the next gather, runs on that same stream, and
+      // every host read of a table syncs both streams -- so `stream` joins it only where a capture must close the fork
+      static const bool old_events = getenv("FFM_OLD_EVENTS") && atoi(getenv("FFM_OLD_EVENTS"));   // A/B aid
+      if (!embeddings.empty() && (capturing_trace >= 0 || use_workers() || old_events))
+        check(api->ffh_stream_wait_event(ctx, stream, ev_update_done), "join update");
     } else {
       embedding_group_update(stream);
     }
