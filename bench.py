@@ -152,8 +152,8 @@ def largest_linear(w, B, t_fwd, t_bwd):
             "fwd": {"us": round(t_fwd * 1e6, 2), "achieved": round(f / t_fwd / 1e12, 1), "frac": round(f / t_fwd / 1e12 / F32_PEAK_TFLOPS, 3),
                     "kernel": "gemm_glds_kernel<kc,kc> (LDS-DMA staged, 16 waves per 64x64 tile, bias + activation epilogue)"},
             "bwd": {"us": round(t_bwd * 1e6, 2), "achieved": round(2 * f / t_bwd / 1e12, 1), "frac": round(2 * f / t_bwd / 1e12 / F32_PEAK_TFLOPS, 3),
-                    "kernel": "dX gemm_glds_kernel<kc,kr> (relu' of the layer below in the epilogue) beside dW gemm_glds_kernel<kr,kr> "
-                              "(split-K over the batch, db from the LDS image) on a second stream"}}
+                    "kernel": "gemm_glds_bwd_kernel: dX (kc,kr; relu' of the layer below in the epilogue) and dW (kr,kr; split-K over "
+                              "the batch, db from the LDS image) as ONE launch"}}
 
 
 def main():

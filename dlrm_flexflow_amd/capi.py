@@ -100,6 +100,7 @@ _SIGS = {
     "ffh_linear_fwd": (I, [P, P, L, P, L, P, P, I, I, L, I, P]),
     "ffh_linear_bwd": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, P]),
     "ffh_linear_bwd_ex": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, P]),
+    "ffh_second_stream_used": (I, [P, I]),
     "ffh_mse_bwd_metrics": (I, [P, P, P, P, P, L, I, F, I, P]),
     "ffh_concat_fwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),
     "ffh_concat_bwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),

@@ -16,6 +16,7 @@ struct ffh_ctx {
   size_t      ws_bytes;
   int         num_cus;
   hipEvent_t  ev_fork;   // ffh_linear_bwd_ex: orders the weight-gradient stream behind the caller's stream
+  int         second_stream_used;   // ffh_second_stream_used()
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
   char        err[512];
 };

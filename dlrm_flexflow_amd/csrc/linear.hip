@@ -437,8 +437,9 @@ constexpr int kGldsWaves = 16;
 constexpr int kGldsStages = 3;
 
 // AKR / BKR: false = rows of the operand are m (n), k contiguous (x, w in fwd; dy in dx); true = rows are k, m (n) contiguous.
+// body of one workgroup: `lin` is its index in the nbx x nby x nbz tile space of THIS problem (a launch may carry two)
 template <bool AKR, bool BKR, int BM>
-__global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_kernel(const GldsArgs g) {
+__device__ __forceinline__ void glds_body(const GldsArgs& g, const unsigned lin, const unsigned nbx, const unsigned nby, const unsigned nbz) {
   constexpr int NW = kGldsWaves, NSTAGE = kGldsStages, BN = 64;
   constexpr int NSUB = (BM / 32) * 2;                   // 32x32 sub-tiles of the block tile
   constexpr int KS = NW / NSUB;                         // k-slices of every k-tile
@@ -452,9 +453,8 @@ __global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_kernel(const GldsAr
   const int lr = lane & 31, lh = lane >> 5;
   int bx, by, bz;
   {
-    const unsigned nbx = gridDim.x, nby = gridDim.y, nbz = gridDim.z;
     const unsigned total = nbx * nby * nbz;
-    const unsigned lin = (blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x;
+    if (lin >= total) return;                            // padding workgroup of a two-problem launch
     const unsigned xcd = lin & 7u, loc = lin >> 3, q = total >> 3, rem = total & 7u;
     const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
     bx = (int)(nlin % nbx); by = (int)((nlin / nbx) % nby); bz = (int)(nlin / (nbx * nby));
@@ -621,23 +621,42 @@ __global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_kernel(const GldsAr
   }
 }
 
+template <bool AKR, bool BKR, int BM>
+__global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_kernel(const GldsArgs g) {
+  glds_body<AKR, BKR, BM>(g, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, gridDim.z);
+}
+
+// One launch for a layer's backward: workgroups [0, na8) are the data-gradient GEMM (dy x w, rows = samples), the rest the
+// weight-gradient GEMM (dy^T x x, split-K over the batch).  Both read the same dy; no second stream, no fork / join
+// events (each is a barrier packet on the critical stream), one dispatch instead of two.  na8 = the dX tile count
+// rounded up to a multiple of 8 so that both problems keep their XCD-contiguous tile order.
+struct GldsDims { unsigned nbx, nby, nbz; };
+template <int BM_DX>
+__global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_bwd_kernel(const GldsArgs dxg, const GldsDims dxd, const unsigned na8,
+                                                                        const GldsArgs dwg, const GldsDims dwd) {
+  if (blockIdx.x < na8) glds_body<false, true, BM_DX>(dxg, blockIdx.x, dxd.nbx, dxd.nby, dxd.nbz);
+  else glds_body<true, true, 64>(dwg, blockIdx.x - na8, dwd.nbx, dwd.nby, dwd.nbz);
+}
+
 inline bool glds_aligned(const float* p, int64_t ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
 
-// Returns 1 if the LDS-DMA kernel took the GEMM, 0 if the shape is not its business, < 0 on error.
+struct GldsPlan { int bm; dim3 grid; int lds_bytes; };
+
+// Fills the plan (tile height, grid, split-K) if the LDS-DMA kernel should take this GEMM.
 template <bool AKR, bool BKR>
-int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const char* name) {
+bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p) {
   static const int off = getenv("FFH_GEMM_NO_GLDS") ? atoi(getenv("FFH_GEMM_NO_GLDS")) : 0;   // tuning aid
-  if (off || !c->zeros) return 0;
-  if (!glds_aligned(g.A, g.lda) || !glds_aligned(g.B, g.ldb)) return 0;
+  if (off || !c->zeros) return false;
+  if (!glds_aligned(g.A, g.lda) || !glds_aligned(g.B, g.ldb)) return false;
   // whole 16-byte chunks only: the contiguous extent of each operand must be a multiple of 4 floats
-  if ((AKR ? g.M : g.K) % 4 || (BKR ? g.N : g.K) % 4) return 0;
+  if ((AKR ? g.M : g.K) % 4 || (BKR ? g.N : g.K) % 4) return false;
   const double work = (double)g.M * g.N * g.K;
-  if (work < 1.5e8 || g.M < 64 || g.N < 64 || g.K < 128) return 0;     // the small layers are launch-bound either way
+  if (work < 1.5e8 || g.M < 64 || g.N < 64 || g.K < 128) return false;     // the small layers are launch-bound either way
   const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64);
   int bm = 64;
   int64_t tiles = tiles64;
   if (!atomic_splitk && tiles64 < (3 * c->num_cus) / 4) { bm = 32; tiles = (int64_t)((g.M + 31) / 32) * ((g.N + 63) / 64); }
-  if (!atomic_splitk && tiles > (3 * c->num_cus) / 2) return 0;        // bigger GEMMs: the register-staged kernels with their larger tiles
+  if (tiles > (3 * c->num_cus) / 2) return false;        // bigger GEMMs: the register-staged kernels with their larger tiles
   g.zeros = c->zeros;
   g.splitk = 1; g.k_per_split = (g.K + 63) / 64 * 64;
   if (atomic_splitk) {
@@ -652,23 +671,61 @@ int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const
     g.splitk = (g.K + kps - 1) / kps;
   }
   const int gy = (g.M + bm - 1) / bm, gx = (g.N + 63) / 64;
-  if (gy > 65535 || g.splitk > 65535) return 0;
-  dim3 grid(gx, gy, g.splitk);
-  const int lds_bytes = kGldsStages * (bm + 64) * 256 + 1024;
+  if (gy > 65535 || g.splitk > 65535) return false;
+  p.bm = bm;
+  p.grid = dim3(gx, gy, g.splitk);
+  p.lds_bytes = kGldsStages * (bm + 64) * 256 + 1024;
+  return true;
+}
+
+template <typename K>
+bool glds_set_lds(K kern, int bytes) {
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
+}
+
+// Returns 1 if the LDS-DMA kernel took the GEMM, 0 if the shape is not its business, < 0 on error.
+template <bool AKR, bool BKR>
+int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const char* name) {
+  GldsPlan p;
+  if (!plan_glds<AKR, BKR>(c, g, atomic_splitk, p)) return 0;
 #define FFH_GLDS_LAUNCH(BMV)                                                                                               \
   {                                                                                                                        \
     auto kern = gemm_glds_kernel<AKR, BKR, BMV>;                                                                           \
-    static bool attr_set = false;                                                                                          \
-    if (!attr_set) {                                                                                                       \
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kGldsStages * (BMV + 64) * 256 + 1024) != hipSuccess) { (void)hipGetLastError(); return 0; } \
-      attr_set = true;                                                                                                     \
-    }                                                                                                                      \
-    hipLaunchKernelGGL(kern, grid, dim3(kGldsWaves * 64), lds_bytes, as_stream(s), g);                                     \
+    static const bool ok = glds_set_lds(kern, kGldsStages * (BMV + 64) * 256 + 1024);                                      \
+    if (!ok) return 0;                                                                                                     \
+    hipLaunchKernelGGL(kern, p.grid, dim3(kGldsWaves * 64), p.lds_bytes, as_stream(s), g);                                 \
   }
-  if (bm == 64) FFH_GLDS_LAUNCH(64) else FFH_GLDS_LAUNCH(32)
+  if (p.bm == 64) FFH_GLDS_LAUNCH(64) else FFH_GLDS_LAUNCH(32)
 #undef FFH_GLDS_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+  return 1;
+}
+
+// dX and dW of one layer in ONE launch (gemm_glds_bwd_kernel); 1 = done, 0 = not applicable
+int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
+  static const int off = getenv("FFH_GLDS_NO_DUAL") ? atoi(getenv("FFH_GLDS_NO_DUAL")) : 0;   // tuning aid
+  if (off) return 0;
+  GldsPlan px, pw;
+  if (!plan_glds<false, true>(c, dxg, false, px) || !plan_glds<true, true>(c, dwg, true, pw)) return 0;
+  const unsigned na = px.grid.x * px.grid.y * px.grid.z, nb = pw.grid.x * pw.grid.y * pw.grid.z;
+  const unsigned na8 = (na + 7u) & ~7u;
+  const GldsDims dx{px.grid.x, px.grid.y, px.grid.z}, dw{pw.grid.x, pw.grid.y, pw.grid.z};
+  const int lds = px.lds_bytes > pw.lds_bytes ? px.lds_bytes : pw.lds_bytes;
+  if (px.bm == 64) {
+    auto kern = gemm_glds_bwd_kernel<64>;
+    static const bool ok = glds_set_lds(kern, kGldsStages * 128 * 256 + 1024);
+    if (!ok) return 0;
+    hipLaunchKernelGGL(kern, dim3(na8 + nb), dim3(kGldsWaves * 64), lds, as_stream(s), dxg, dx, na8, dwg, dw);
+  } else {
+    auto kern = gemm_glds_bwd_kernel<32>;
+    static const bool ok = glds_set_lds(kern, kGldsStages * 128 * 256 + 1024);
+    if (!ok) return 0;
+    hipLaunchKernelGGL(kern, dim3(na8 + nb), dim3(kGldsWaves * 64), lds, as_stream(s), dxg, dx, na8, dwg, dw);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ffh_fail_hip(c, e, "linear_bwd dx+dw (lds-dma, one launch)");
   return 1;
 }
 
@@ -1033,10 +1090,25 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(grid), dim3(256), 0, as_stream(s), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
     FFH_LAUNCH_CHECK(c, "act_bwd_bias_kernel");
   }
+  // mid-size layer with nothing to mask while loading: data- and weight-gradient GEMMs in ONE LDS-DMA launch on s
+  // (measured against the two-stream form: fewer barrier packets on the critical stream, one dispatch)
+  if (do_dw && do_dx && dx && act != FFH_AC_MODE_RELU) {
+    GldsArgs dxg{}, dwg{};
+    dxg.A = dy; dxg.lda = lddy; dxg.B = w; dxg.ldb = in; dxg.C = dx; dxg.ldc = lddx;
+    dxg.M = (int)batch; dxg.N = in; dxg.K = out; dxg.epi = (flags & FFH_LINEAR_DX_OVERWRITE) ? EPI_STORE : EPI_ADD; dxg.act = FFH_AC_MODE_NONE;
+    if (mask_by_x) { dxg.mask = x; dxg.ldmask = ldx; }
+    dwg.A = dy; dwg.lda = lddy; dwg.B = x; dwg.ldb = ldx; dwg.C = dw; dwg.ldc = in;
+    dwg.M = out; dwg.N = in; dwg.K = (int)batch; dwg.epi = EPI_ATOMIC; dwg.act = FFH_AC_MODE_NONE;
+    dwg.db = separate ? nullptr : db;
+    const int rc = launch_glds_bwd(c, dxg, dwg, s);
+    if (rc < 0) return rc;
+    if (rc == 1) return FFH_OK;
+  }
   // the weight-gradient GEMM may go to its own stream: it only needs dy (and y, x), which are ready on s now
   const bool forked = do_dw && do_dx && s_dw != nullptr && s_dw != s;
   ffh_stream sw = forked ? s_dw : s;
   if (forked) {
+    c->second_stream_used = 1;
     if (!c->ev_fork) FFH_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     FFH_HIP_TRY(c, hipEventRecord(c->ev_fork, as_stream(s)));
     FFH_HIP_TRY(c, hipStreamWaitEvent(as_stream(sw), c->ev_fork, 0));
@@ -1097,6 +1169,13 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     if (rc) return rc;
   }
   return FFH_OK;
+}
+
+int ffh_second_stream_used(ffh_ctx* c, int clear) {
+  if (!c) return 0;
+  const int v = c->second_stream_used;
+  if (clear) c->second_stream_used = 0;
+  return v;
 }
 
 int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,

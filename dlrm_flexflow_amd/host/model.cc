@@ -1472,6 +1472,7 @@ void FFModel::update() {
   if (!sgd && !adam) die("update(): unknown optimizer");
   // every rank must issue its collectives in the same order: the side thread's all-to-all (backward) first
   if (side_worker) side_worker->drain();
+  if (dw_forked && !dw_worker && !api->ffh_second_stream_used(ctx, 1)) dw_forked = false;   // the library kept everything on `stream`
   if (dw_forked) {   // the weight-gradient GEMMs ran on their own stream: join before the gradients are consumed
     if (dw_worker) dw_worker->drain();
     check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");

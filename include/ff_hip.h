@@ -255,6 +255,10 @@ int ffh_linear_bwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t
  * A layer run with DY_PREMASKED below a layer run with DX_MASK_BY_X computes exactly what two plain calls compute. */
 #define FFH_LINEAR_DY_PREMASKED 8
 #define FFH_LINEAR_DX_MASK_BY_X 16
+/* ffh_linear_bwd_ex is free NOT to use s_dw (e.g. when it issues both GEMMs of a mid-size layer as one launch on s).
+ * Returns 1 if any call on this ctx has issued work on a caller-supplied second stream since the flag was last
+ * cleared (clear != 0 clears it), else 0: a caller that joins s_dw only when this says so saves the join's packets. */
+int ffh_second_stream_used(ffh_ctx* ctx, int clear);
 int ffh_linear_bwd_ex(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,
                       const float* w, float* dw, float* db,
@@ -363,7 +367,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) \
-  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_concat_fwd) X(ffh_concat_bwd) \
+  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_second_stream_used) X(ffh_concat_fwd) X(ffh_concat_bwd) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

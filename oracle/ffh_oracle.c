@@ -421,6 +421,9 @@ int ffh_linear_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t l
   return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, 1, 1, 1, 1, 0, 0);
 }
 
+/* no streams on the host: nothing ever runs on a second one */
+int ffh_second_stream_used(ffh_ctx* c, int clear) { (void)c; (void)clear; return 0; }
+
 /* same arithmetic; streams mean nothing on the host.  DX_OVERWRITE: dx is zeroed here, then accumulated */
 int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,

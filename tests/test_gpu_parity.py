@@ -417,13 +417,18 @@ def test_linear_lds_dma_kernel_shapes(hip, oracle, B, IN, OUT):
     flags = capi.LINEAR_DY_PREMASKED | capi.LINEAR_DX_MASK_BY_X
     dx_e, dw_e, db_e, _ = oracle.linear_bwd_ex(xr, yr, gm, w, capi.AC_MODE_RELU, flags | capi.LINEAR_DX_OVERWRITE)
     a = np.abs(gm).astype(np.float64)
-    for mode in ("overwrite", "accumulate", "fork"):
+    # overwrite / accumulate / fork: both GEMMs in one launch (gemm_glds_bwd_kernel); split: the two single-GEMM kernels
+    for mode in ("overwrite", "accumulate", "fork", "split"):
         dx0 = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
         dx, dw, db, dy = dev(dx0), torch.zeros(OUT, IN, device=DEV), torch.zeros(OUT, device=DEV), dev(gm)
         f = flags | (0 if mode == "accumulate" else capi.LINEAR_DX_OVERWRITE)
         s2 = torch.cuda.Stream()
-        hip.call("ffh_linear_bwd_ex", dev(xr), IN, dx, IN, dev(yr), OUT, dy, OUT, dev(w), dw, db, IN, OUT, B, capi.AC_MODE_RELU, f,
-                 None, s2.cuda_stream if mode == "fork" else None)
+        args = (dev(xr), IN, dx, IN, dev(yr), OUT, dy, OUT, dev(w), dw, db, IN, OUT, B, capi.AC_MODE_RELU)
+        if mode == "split":
+            hip.call("ffh_linear_bwd_ex", *args, f | capi.LINEAR_ONLY_DX, None, None)
+            hip.call("ffh_linear_bwd_ex", *args, f | capi.LINEAR_ONLY_DW, None, None)
+        else:
+            hip.call("ffh_linear_bwd_ex", *args, f, None, s2.cuda_stream if mode == "fork" else None)
         torch.cuda.synchronize()
         assert bits_equal(host(dy), gm)                                       # premasked dy is not touched
         exp_dx = dx_e + (dx0 if mode == "accumulate" else 0)
