@@ -169,6 +169,8 @@ def main():
                                                          "extra launches of emb_fwd_kernel, so off by default to keep the rocprof averages single-shape")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="1 GPU: still run the all-to-all / all-reduce path (1-rank RCCL group)")
+    ap.add_argument("--torch-collectives", action="store_true", help="serve the all-to-all / all-reduce through torch.distributed callbacks "
+                                                                     "instead of calling RCCL from the C++ host layer")
     ap.add_argument("--shim-flags", default="", help="extra FFConfig flags for A/B runs, e.g. '--serial-dw --no-overlap'")
     args = ap.parse_args()
 
@@ -187,14 +189,23 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     comm = None
+    collectives = ""
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        from dlrm_flexflow_amd.comm import TorchComm
+        from dlrm_flexflow_amd.comm import RcclComm, TorchComm
         comm = TorchComm(on_gpu=True)
+        collectives = "torch.distributed (RCCL) callbacks"
+        if not args.torch_collectives and not os.environ.get("FFM_NO_DIRECT_RCCL"):
+            try:
+                comm = RcclComm(comm)       # the same callbacks served by RCCL from the C++ host layer, no Python per collective
+                collectives = "RCCL called from the C++ host layer"
+            except Exception as e:  # noqa: BLE001  every rank raises together (comm.py): fall back to the torch callbacks
+                if rank == 0:
+                    print("bench: direct RCCL not used:", e, file=sys.stderr, flush=True)
 
     w = workload(args.workload, args.per_gpu_batch, world)
     extra = ["--device", str(local_rank)] + (["--no-trace"] if args.no_trace else []) + (["--force-exchange"] if args.force_exchange else []) + args.shim_flags.split()
@@ -258,12 +269,12 @@ def main():
                                f"cat interaction, SGD lr 0.01, MSE loss",
                    "global_batch": w["B"], "per_gpu_batch": w["B"] // world,
                    "parallelism": ("single GPU, hipGraph-replayed step" if uses_graph else "single GPU, eager launches on 3 HIP streams") if world == 1 else
-                                  f"tables table-wise over {world} ranks (RCCL all-to-all fwd+bwd), MLPs data-parallel (1 all-reduce)",
+                                  f"tables table-wise over {world} ranks (RCCL all-to-all fwd+bwd), MLPs data-parallel (1 all-reduce); {collectives}",
                    "step_graph": bool(uses_graph), "step_us_graph_vs_eager": {k: round(v, 1) for k, v in step_us.items()}},
         "mse_over_timed_steps": round(2.0 * pm.mse_loss / max(pm.train_all, 1), 6),   # train_all is double-counted (1 class + accuracy), as in the reference
     }
     if args.force_exchange:
-        out["config"]["parallelism"] = "1 rank, exchange path forced (all-to-all fwd+bwd + all-reduce through the RCCL callbacks)"
+        out["config"]["parallelism"] = f"1 rank, exchange path forced (all-to-all fwd+bwd + all-reduce); {collectives}"
     if solo:
         fwd_bytes = owned * B * (8 + 4 * D + 4 * D)            # 3,536 B/sample at the Kaggle shape
         bwd_bytes = owned * B * (8 + 4 * D + 2 * 4 * D)

@@ -644,14 +644,14 @@ struct GldsPlan { int bm; dim3 grid; int lds_bytes; };
 
 // Fills the plan (tile height, grid, split-K) if the LDS-DMA kernel should take this GEMM.
 template <bool AKR, bool BKR>
-bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p) {
+bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p, double min_work = 1.5e8, int min_k = 128) {
   static const int off = getenv("FFH_GEMM_NO_GLDS") ? atoi(getenv("FFH_GEMM_NO_GLDS")) : 0;   // tuning aid
   if (off || !c->zeros) return false;
   if (!glds_aligned(g.A, g.lda) || !glds_aligned(g.B, g.ldb)) return false;
   // whole 16-byte chunks only: the contiguous extent of each operand must be a multiple of 4 floats
   if ((AKR ? g.M : g.K) % 4 || (BKR ? g.N : g.K) % 4) return false;
   const double work = (double)g.M * g.N * g.K;
-  if (work < 1.5e8 || g.M < 64 || g.N < 64 || g.K < 128) return false;     // the small layers are launch-bound either way
+  if (work < min_work || g.M < 64 || g.N < 64 || g.K < min_k) return false;   // the small layers are launch-bound either way
   const int64_t tiles64 = (int64_t)((g.M + 63) / 64) * ((g.N + 63) / 64);
   int bm = 64;
   int64_t tiles = tiles64;
@@ -708,7 +708,9 @@ int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
   static const int off = getenv("FFH_GLDS_NO_DUAL") ? atoi(getenv("FFH_GLDS_NO_DUAL")) : 0;   // tuning aid
   if (off) return 0;
   GldsPlan px, pw;
-  if (!plan_glds<false, true>(c, dxg, false, px) || !plan_glds<true, true>(c, dwg, true, pw)) return 0;
+  // as one launch the pair pays for itself at smaller sizes than a single GEMM does
+  static const double min_work = getenv("FFH_GLDS_DUAL_MINWORK") ? atof(getenv("FFH_GLDS_DUAL_MINWORK")) : 1.5e8;   // tuning aid
+  if (!plan_glds<false, true>(c, dxg, false, px, min_work, 64) || !plan_glds<true, true>(c, dwg, true, pw, min_work, 64)) return 0;
   const unsigned na = px.grid.x * px.grid.y * px.grid.z, nb = pw.grid.x * pw.grid.y * pw.grid.z;
   const unsigned na8 = (na + 7u) & ~7u;
   const GldsDims dx{px.grid.x, px.grid.y, px.grid.z}, dw{pw.grid.x, pw.grid.y, pw.grid.z};

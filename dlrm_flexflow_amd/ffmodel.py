@@ -63,6 +63,10 @@ def lib() -> C.CDLL:
         "flexflow_config_create": (H, []), "flexflow_config_destroy": (None, [H]),
         "flexflow_config_parse_args": (None, [H, C.POINTER(C.c_char_p), I]),
         "flexflow_config_set_comm": (None, [H, C.POINTER(FFComm)]),
+        "flexflow_rccl_available": (I, [C.c_char_p]), "flexflow_rccl_get_unique_id": (I, [C.POINTER(C.c_ubyte), C.c_char_p]),
+        "flexflow_rccl_comm_create": (I, [C.POINTER(C.c_ubyte), I, I, C.c_char_p, C.POINTER(FFComm)]),
+        "flexflow_rccl_comm_destroy": (None, [C.POINTER(FFComm)]), "flexflow_rccl_last_error": (C.c_char_p, []),
+        "flexflow_rccl_comm_calls": (None, [C.POINTER(FFComm), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "flexflow_config_set_batch_size": (None, [H, I]), "flexflow_config_get_batch_size": (I, [H]),
         "flexflow_config_set_backend": (None, [H, C.c_char_p]), "flexflow_config_set_seed": (None, [H, C.c_uint64]),
         "flexflow_config_set_device": (None, [H, I]), "flexflow_config_set_enable_graph": (None, [H, B]),

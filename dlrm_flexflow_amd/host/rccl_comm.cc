@@ -1,0 +1,140 @@
+// rccl_comm.cc -- see rccl_comm.h.  Only the stable core of the NCCL API is used; RCCL is found at run time.
+#include "rccl_comm.h"
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace {
+
+typedef struct { char internal[128]; } ncclUniqueId_t;
+typedef void* ncclComm_p;
+enum { kNcclSuccess = 0, kNcclFloat32 = 7, kNcclSum = 0 };
+
+struct Api {
+  void* lib = nullptr;
+  int (*GetUniqueId)(ncclUniqueId_t*);
+  int (*CommInitRank)(ncclComm_p*, int, ncclUniqueId_t, int);
+  int (*CommDestroy)(ncclComm_p);
+  int (*GroupStart)(void);
+  int (*GroupEnd)(void);
+  int (*Send)(const void*, size_t, int, int, ncclComm_p, void*);
+  int (*Recv)(void*, size_t, int, int, ncclComm_p, void*);
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_p, void*);
+  const char* (*GetErrorString)(int);
+};
+
+std::string g_err;
+Api g_api;
+
+bool load(const char* path) {
+  if (g_api.lib) return true;
+  void* h = nullptr;
+  if (path && *path) h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);     // the copy the process already has (torch's)
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { g_err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
+#define SYM(field, name)                                               \
+  *(void**)(&g_api.field) = dlsym(h, name);                             \
+  if (!g_api.field) { g_err = std::string("librccl lacks ") + name; return false; }
+  SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+  SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
+  SYM(AllReduce, "ncclAllReduce") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+  g_api.lib = h;
+  return true;
+}
+
+struct Comm {
+  ncclComm_p comm;
+  int rank, world;
+  int64_t n_alltoall, n_allreduce;
+};
+
+int fail(int rc, const char* what) {
+  g_err = std::string(what) + ": " + (g_api.GetErrorString ? g_api.GetErrorString(rc) : "?");
+  fprintf(stderr, "rccl_comm: %s\n", g_err.c_str());
+  return 1;
+}
+
+// uneven all-to-all: one grouped send/recv pair per peer, blocks contiguous in rank order (counts in floats)
+int alltoall_f32(void* user, const float* send, const int64_t* sc, float* recv, const int64_t* rc, void* stream) {
+  Comm* c = (Comm*)user;
+  int e = g_api.GroupStart();
+  if (e != kNcclSuccess) return fail(e, "ncclGroupStart");
+  int64_t so = 0, ro = 0;
+  for (int p = 0; p < c->world; p++) {
+    if (sc[p] > 0) { e = g_api.Send(send + so, (size_t)sc[p], kNcclFloat32, p, c->comm, stream); if (e != kNcclSuccess) { g_api.GroupEnd(); return fail(e, "ncclSend"); } }
+    if (rc[p] > 0) { e = g_api.Recv(recv + ro, (size_t)rc[p], kNcclFloat32, p, c->comm, stream); if (e != kNcclSuccess) { g_api.GroupEnd(); return fail(e, "ncclRecv"); } }
+    so += sc[p]; ro += rc[p];
+  }
+  e = g_api.GroupEnd();
+  if (e != kNcclSuccess) return fail(e, "ncclGroupEnd");
+  c->n_alltoall++;
+  return 0;
+}
+
+int allreduce_sum_f32(void* user, float* buf, int64_t count, void* stream) {
+  Comm* c = (Comm*)user;
+  if (count > 0) {
+    const int e = g_api.AllReduce(buf, buf, (size_t)count, kNcclFloat32, kNcclSum, c->comm, stream);
+    if (e != kNcclSuccess) return fail(e, "ncclAllReduce");
+  }
+  c->n_allreduce++;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* flexflow_rccl_last_error(void) { return g_err.c_str(); }
+
+int flexflow_rccl_available(const char* lib_path) { return load(lib_path) ? 0 : 1; }
+
+int flexflow_rccl_get_unique_id(unsigned char id[128], const char* lib_path) {
+  if (!load(lib_path)) return 1;
+  ncclUniqueId_t u;
+  const int e = g_api.GetUniqueId(&u);
+  if (e != kNcclSuccess) return fail(e, "ncclGetUniqueId");
+  memcpy(id, u.internal, 128);
+  return 0;
+}
+
+int flexflow_rccl_comm_create(const unsigned char id[128], int rank, int world_size, const char* lib_path, ffcomm* out) {
+  if (!out || rank < 0 || world_size < 1 || rank >= world_size) { g_err = "bad arguments"; return 1; }
+  if (!load(lib_path)) return 1;
+  ncclUniqueId_t u;
+  memcpy(u.internal, id, 128);
+  Comm* c = new Comm{nullptr, rank, world_size, 0, 0};
+  const int e = g_api.CommInitRank(&c->comm, world_size, u, rank);
+  if (e != kNcclSuccess) { delete c; return fail(e, "ncclCommInitRank"); }
+  memset(out, 0, sizeof *out);
+  out->rank = rank;
+  out->world_size = world_size;
+  out->user = c;
+  out->alltoall_f32 = alltoall_f32;
+  out->allreduce_sum_f32 = allreduce_sum_f32;
+  out->barrier = nullptr;          // the launcher supplies its own (it owns the bootstrap group)
+  return 0;
+}
+
+void flexflow_rccl_comm_destroy(ffcomm* comm) {
+  if (!comm || !comm->user) return;
+  Comm* c = (Comm*)comm->user;
+  if (c->comm) g_api.CommDestroy(c->comm);
+  delete c;
+  comm->user = nullptr;
+}
+
+void flexflow_rccl_comm_calls(const ffcomm* comm, int64_t* a2a, int64_t* ar) {
+  const Comm* c = comm ? (const Comm*)comm->user : nullptr;
+  if (a2a) *a2a = c ? c->n_alltoall : 0;
+  if (ar) *ar = c ? c->n_allreduce : 0;
+}
+
+}  // extern "C"

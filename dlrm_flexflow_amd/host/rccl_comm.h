@@ -1,0 +1,25 @@
+/* rccl_comm.h -- the ffcomm callbacks implemented directly on RCCL (dlopen'ed), for GPU runs with world_size > 1.
+ * The launcher still bootstraps: rank 0 makes a unique id (flexflow_rccl_get_unique_id), the launcher broadcasts the
+ * 128 bytes over whatever it has (torch.distributed in bench.py), every rank calls flexflow_rccl_comm_create.
+ * Replaces one ncclAllReduce per tensor [ref: src/runtime/optimizer_kernel.cu:170-171] with one per step, and the
+ * Legion zero-copy movement of embedding outputs [ref: src/ops/embedding.cu:295-299] with an all-to-all made of
+ * grouped ncclSend / ncclRecv pairs, enqueued on the model's own HIP streams (no host round trip per collective). */
+#ifndef RCCL_COMM_H_
+#define RCCL_COMM_H_
+#include "ffcomm.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* lib_path: the RCCL to use (NULL: the one already loaded in the process, else librccl.so from the loader path).
+ * Both return 0 on success; on failure nothing is left allocated and flexflow_rccl_last_error() says why. */
+int  flexflow_rccl_available(const char* lib_path);      /* 0 = the library loads and has the symbols */
+int  flexflow_rccl_get_unique_id(unsigned char id[128], const char* lib_path);
+int  flexflow_rccl_comm_create(const unsigned char id[128], int rank, int world_size, const char* lib_path, ffcomm* out);
+void flexflow_rccl_comm_destroy(ffcomm* comm);
+const char* flexflow_rccl_last_error(void);
+/* number of all-to-all / all-reduce calls served so far (tests) */
+void flexflow_rccl_comm_calls(const ffcomm* comm, int64_t* alltoall, int64_t* allreduce);
+#ifdef __cplusplus
+}
+#endif
+#endif

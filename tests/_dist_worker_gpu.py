@@ -13,16 +13,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from dlrm_flexflow_amd import capi  # noqa: E402
-from dlrm_flexflow_amd.comm import TorchComm  # noqa: E402
+from dlrm_flexflow_amd.comm import RcclComm, TorchComm  # noqa: E402
 import dlrm_helpers as H  # noqa: E402
 
 
 def main():
     outdir = sys.argv[1]
+    direct = len(sys.argv) > 2 and sys.argv[2] == "direct"     # RCCL called from the C++ host layer (host/rccl_comm.cc)
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group("nccl", init_method=f"tcp://{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}",
                             rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     comm = TorchComm(on_gpu=True)
+    if direct:
+        comm = RcclComm(comm)
     m, h = H.build_golden_dlrm(capi.HIP_LIB_PATH, comm=comm.struct, overlap=True, force_exchange=True)
     recs = H.run_steps(m, h, 2)
     out = {}

@@ -150,12 +150,14 @@ def test_dlrm_executable_on_gpu(hip):
     assert "THROUGHPUT = " in r.stdout and "[Metrics]" in r.stderr
 
 
-def test_single_rank_nccl_exchange_path_on_gpu(hip, tmp_path):
-    """--force-exchange with a 1-rank RCCL group: device pointers are wrapped zero-copy, the
-    all-to-all and all-reduce run on the model's HIP streams; result equals the plain run."""
+@pytest.mark.parametrize("how", ["torch", "direct"])
+def test_single_rank_nccl_exchange_path_on_gpu(hip, tmp_path, how):
+    """--force-exchange with a 1-rank RCCL group: the all-to-all and all-reduce run on the model's HIP streams, served
+    by torch.distributed callbacks (device pointers wrapped zero-copy) or by RCCL called from the C++ host layer
+    (grouped ncclSend/ncclRecv + ncclAllReduce on a communicator bootstrapped over the torch group); result equals the plain run."""
     worker = os.path.join(ROOT, "tests", "_dist_worker_gpu.py")
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500))
-    r = subprocess.run(["python", worker, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(["python", worker, str(tmp_path), how], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     z = np.load(os.path.join(tmp_path, "rank0.npz"))
     assert int(z["alltoall_calls"]) == 4 and int(z["allreduce_calls"]) == 2
