@@ -27,6 +27,7 @@ AGGR_MODE_NONE, AGGR_MODE_SUM, AGGR_MODE_AVG = 20, 21, 22
 MAX_TABLES = 64
 EMB_CHUNK, EMB_CHUNK1 = 32, 1024
 OPT_ZERO_GRAD = 1
+CONCAT_BWD_OVERWRITE = 1
 LINEAR_DX_OVERWRITE, LINEAR_ONLY_DW, LINEAR_ONLY_DX, LINEAR_DY_PREMASKED, LINEAR_DX_MASK_BY_X = 1, 2, 4, 8, 16
 METRIC_ACCURACY, METRIC_MSE, METRIC_RMSE, METRIC_MAE = 1, 2, 4, 8
 
@@ -104,6 +105,7 @@ _SIGS = {
     "ffh_mse_bwd_metrics": (I, [P, P, P, P, P, L, I, F, I, P]),
     "ffh_concat_fwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),
     "ffh_concat_bwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),
+    "ffh_concat_bwd_ex": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, I, P]),
     "ffh_bmm_fwd": (I, [P, P, P, P, I, I, I, L, I, I, I, P]),
     "ffh_bmm_bwd": (I, [P, P, P, P, P, P, I, I, I, L, P]),
     "ffh_transpose_fwd": (I, [P, P, P, I, C.POINTER(L), C.POINTER(I), P]),

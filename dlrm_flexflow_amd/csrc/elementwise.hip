@@ -17,6 +17,7 @@ struct ConcatArgs {
   int64_t out_blk;
   int64_t num_blocks;
   int     n;
+  int     overwrite;                      // bwd: store the slice instead of accumulating it
 };
 
 // grid.y = part; each workgroup streams rows of its part.  BWD adds (accumulates) into the part.
@@ -35,15 +36,16 @@ __global__ __launch_bounds__(256) void concat_kernel(const ConcatArgs a) {
     float* pp = part + b * ld + e;
     if (VEC == 4) {
       if (BWD) {
-        float4 x = *reinterpret_cast<float4*>(pp);
         const float4 g = *reinterpret_cast<const float4*>(bp);
+        if (a.overwrite) { *reinterpret_cast<float4*>(pp) = g; continue; }
+        float4 x = *reinterpret_cast<float4*>(pp);
         x.x += g.x; x.y += g.y; x.z += g.z; x.w += g.w;
         *reinterpret_cast<float4*>(pp) = x;
       } else {
         *reinterpret_cast<float4*>(bp) = *reinterpret_cast<const float4*>(pp);
       }
     } else {
-      if (BWD) *pp += *bp; else *bp = *pp;
+      if (BWD) *pp = a.overwrite ? *bp : *pp + *bp; else *bp = *pp;
     }
   }
 }
@@ -52,12 +54,12 @@ inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <bool BWD>
 int concat_impl(ffh_ctx* c, float* big, int64_t out_blk, float* const* parts, const int64_t* in_blk,
-                const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
+                const int64_t* in_ld, int n, int64_t nblk, ffh_stream s, int overwrite = 0) {
   if (n < 0 || n > FFH_MAX_CONCAT_INPUTS || nblk < 0 || out_blk < 0) return ffh_fail(c, FFH_ERR_BAD_ARG, "concat: bad dims");
   if (n && (!big || !parts || !in_blk)) return ffh_fail(c, FFH_ERR_BAD_ARG, "concat: null pointer");
   int64_t off = 0;
   ConcatArgs a;
-  a.big = big; a.out_blk = out_blk; a.num_blocks = nblk; a.n = 0;
+  a.big = big; a.out_blk = out_blk; a.num_blocks = nblk; a.n = 0; a.overwrite = overwrite;
   bool vec = al16(big) && (out_blk % 4 == 0);
   int64_t maxw = 0;
   auto flush = [&]() -> int {
@@ -352,6 +354,12 @@ int ffh_concat_fwd(ffh_ctx* c, float* out, int64_t out_blk, const float* const* 
 int ffh_concat_bwd(ffh_ctx* c, const float* og, int64_t out_blk, float* const* igs, const int64_t* in_blk,
                    const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
   return concat_impl<true>(c, const_cast<float*>(og), out_blk, igs, in_blk, in_ld, n, nblk, s);
+}
+
+int ffh_concat_bwd_ex(ffh_ctx* c, const float* og, int64_t out_blk, float* const* igs, const int64_t* in_blk,
+                      const int64_t* in_ld, int n, int64_t nblk, int flags, ffh_stream s) {
+  FFH_REQUIRE(c, (flags & ~FFH_CONCAT_BWD_OVERWRITE) == 0, "concat_bwd_ex: unknown flags");
+  return concat_impl<true>(c, const_cast<float*>(og), out_blk, igs, in_blk, in_ld, n, nblk, s, (flags & FFH_CONCAT_BWD_OVERWRITE) ? 1 : 0);
 }
 
 int ffh_transpose_fwd(ffh_ctx* c, float* out, const float* in, int nd, const int64_t* in_dims, const int* perm, ffh_stream s) {

@@ -43,7 +43,7 @@ BARRIER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
 class FFComm(C.Structure):
     """struct ffcomm (host/ffcomm.h)"""
     _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("user", C.c_void_p),
-                ("alltoall_f32", ALLTOALL_FN), ("allreduce_sum_f32", ALLREDUCE_FN), ("barrier", BARRIER_FN)]
+                ("alltoall_f32", ALLTOALL_FN), ("allreduce_sum_f32", ALLREDUCE_FN), ("barrier", BARRIER_FN), ("nonblocking", C.c_int)]
 
 
 _lib = None

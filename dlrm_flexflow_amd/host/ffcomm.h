@@ -27,6 +27,10 @@ typedef struct ffcomm {
                       float* recv, const int64_t* recv_counts, void* stream);
   int (*allreduce_sum_f32)(void* user, float* buf, int64_t count, void* stream);
   int (*barrier)(void* user);
+  /* 1: alltoall / allreduce only enqueue work on `stream` and return at once (RCCL called directly).  The model then
+   * issues them in stream order; with 0 (a callback that takes tens of microseconds of host time, e.g. through an
+   * interpreter) it first enqueues the kernels that do not depend on the collective. */
+  int nonblocking;
 } ffcomm;
 
 #ifdef __cplusplus

@@ -304,6 +304,7 @@ class Concat : public Op {
   void forward(const FFModel&) override;
   void backward(const FFModel&) override;
   int axis;                     // Legion axis (user axis flipped, [ref: src/ops/concat.cu:29-49,109-112])
+  bool bwd_overwrite;           // every input has this Concat as its only consumer: slices are stored, not accumulated
 };
 
 class BatchMatmul : public Op {
@@ -417,6 +418,7 @@ class FFModel {
   ffh_stream side_stream;      // embedding gather / exchange / sparse update
   ffh_stream dw_stream;        // weight-gradient GEMMs (parallel_dw)
   ffh_event ev_dw_done;
+  bool need_zero_gsend;        // some gradient in the exchange send buffer is accumulated rather than stored
   bool need_zero_act_grads;    // some activation gradient is accumulated by more than one producer
   mutable bool dw_forked;
   mutable bool mlp_grads_clean;   // the optimizer kernel cleared the MLP gradient slab (FFH_OPT_ZERO_GRAD): zero_gradients() skips it

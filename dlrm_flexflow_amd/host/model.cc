@@ -375,7 +375,7 @@ FFModel::FFModel(FFConfig& _config)
       emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
       act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1), inputs_dirty(true), fork_recorded(false) {
-  dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
+  dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; need_zero_gsend = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
   rank = config.comm.world_size > 1 ? config.comm.rank : 0;
   world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
   if (world_size == 1 && config.workersPerNode > 1)
@@ -636,7 +636,7 @@ void Embedding::backward(const FFModel& ff) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
       // backward(), after the host has enqueued the bottom-MLP backward it overlaps with
       ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
-      if (ff.exchange && !ff.use_workers()) {
+      if (ff.exchange && !ff.config.comm.nonblocking && !ff.use_workers()) {
         ff.emb_update_pending = true;      // host-side collectives on this thread: issue after the bottom-MLP backward is enqueued
       } else {
         ff.issue_embedding_update_on_side_stream();
@@ -665,6 +665,7 @@ Concat::Concat(FFModel& model, int n, const Tensor* _inputs, int _axis, const ch
   if (n < 1) die("%s: needs at least one input", this->name);
   const int nd = _inputs[0].numDim;
   axis = nd - 1 - _axis;   // user axis -> Legion axis [ref: src/ops/concat.cu:29-49]
+  bwd_overwrite = false;
   if (axis < 0 || axis >= nd) die("%s: axis out of range", this->name);
   outputs[0].numDim = nd;
   for (int d = 0; d < nd; d++) outputs[0].adim[d] = _inputs[0].adim[d];
@@ -732,8 +733,8 @@ void Concat::backward(const FFModel& ff) {
   std::vector<float*> ptrs;
   concat_geometry(this, ff, nb, ob, ib);
   concat_parts(this, ib, true, ptrs, blks, lds);
-  ff.check(ff.api->ffh_concat_bwd(ff.ctx, outputs[0].impl->grad, ob, ptrs.data(), blks.data(), lds.data(), (int)ptrs.size(), nb,
-                                  ff.stream), name);
+  ff.check(ff.api->ffh_concat_bwd_ex(ff.ctx, outputs[0].impl->grad, ob, ptrs.data(), blks.data(), lds.data(), (int)ptrs.size(), nb,
+                                     bwd_overwrite ? FFH_CONCAT_BWD_OVERWRITE : 0, ff.stream), name);
 }
 
 // =============================================================================================
@@ -1209,6 +1210,7 @@ void FFModel::allocate() {
 
   // ---- 4b. which activation gradients have exactly one producer (then nothing needs zeroing) ----
   need_zero_act_grads = false;
+  need_zero_gsend = false;
   for (Op* op : layers) {
     if (consumers[op->outputs[0].impl] > 1) need_zero_act_grads = true;           // several ops add into its gradient
     if (op->op_type == OP_BATCHMATMUL || op->op_type == OP_TRANSPOSE || op->op_type == OP_RESHAPE || op->op_type == OP_FLAT)
@@ -1225,12 +1227,18 @@ void FFModel::allocate() {
         below->dy_premasked = true;
       }
     }
-    if (Concat* c = dynamic_cast<Concat*>(op))
+    if (Concat* c = dynamic_cast<Concat*>(op)) {
+      // inputs that nothing else reads take their gradient slice as a plain store (FFH_CONCAT_BWD_OVERWRITE)
+      c->bwd_overwrite = true;
+      for (int i = 0; i < c->numInputs; i++)
+        if (consumers[c->inputs[i].impl] != 1) c->bwd_overwrite = false;
       for (int i = 0; i < c->numInputs; i++) {
         TensorImpl* im = c->inputs[i].impl;
         const bool via_exchange = exchange && c->inputs[i].owner_op && c->inputs[i].owner_op->op_type == OP_EMBEDDING;
-        if (im->grad && !im->grad_alias && !via_exchange && im->pieces.empty()) need_zero_act_grads = true;   // add_with_stride accumulates
+        if (via_exchange && !c->bwd_overwrite) need_zero_gsend = true;
+        if (im->grad && !im->grad_alias && !via_exchange && im->pieces.empty() && !c->bwd_overwrite) need_zero_act_grads = true;   // add_with_stride accumulates
       }
+    }
   }
 
   // ---- 5. parameters: one slab for every Linear tensor, tables on their own ---------------------
@@ -1374,7 +1382,7 @@ void FFModel::forward(int _seq_length) {
     if (fork_recorded) check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
     inputs_dirty = false;
     // start the gather right now unless a host-side collective would stall THIS thread's launches
-    if (!exchange || use_workers()) issue_embedding_forward_on_side_stream();
+    if (!exchange || config.comm.nonblocking || use_workers()) issue_embedding_forward_on_side_stream();
   }
   for (Op* op : layers) op->forward(*this);
   if (emb_forward_issued && !emb_forward_joined) join_embedding_forward();
@@ -1425,7 +1433,7 @@ void FFModel::zero_gradients() {
   // activation gradients with a single producer are stored, not accumulated: nothing to clear (0 + x == x)
   if (need_zero_act_grads) check(api->ffh_zero(ctx, act_grad_slab, act_grad_bytes, stream), "zero_gradients");
   if (!mlp_grads_clean) check(api->ffh_zero(ctx, mlp_grads, mlp_count * 4, stream), "zero_gradients");
-  if (exchange && gsend) {
+  if (exchange && gsend && need_zero_gsend) {
     size_t n = 0;
     for (int64_t c : fwd_recv_counts) n += (size_t)c;
     check(api->ffh_zero(ctx, gsend, n * 4, stream), "zero_gradients");

@@ -120,6 +120,7 @@ int flexflow_rccl_comm_create(const unsigned char id[128], int rank, int world_s
   out->alltoall_f32 = alltoall_f32;
   out->allreduce_sum_f32 = allreduce_sum_f32;
   out->barrier = nullptr;          // the launcher supplies its own (it owns the bootstrap group)
+  out->nonblocking = 1;
   return 0;
 }
 

@@ -285,6 +285,13 @@ int ffh_concat_bwd(ffh_ctx* ctx, const float* out_grad, int64_t out_blk, float* 
                    const int64_t* in_blk, const int64_t* in_ld, int num_inputs,
                    int64_t num_blocks, ffh_stream s);
 
+/* The same with flags.  FFH_CONCAT_BWD_OVERWRITE: in_grad_i = slice (stored, not accumulated) -- for inputs whose gradient
+ * has no other producer, so that it need not be zeroed first (0 + x == x), as FFH_LINEAR_DX_OVERWRITE. */
+#define FFH_CONCAT_BWD_OVERWRITE 1
+int ffh_concat_bwd_ex(ffh_ctx* ctx, const float* out_grad, int64_t out_blk, float* const* in_grads,
+                      const int64_t* in_blk, const int64_t* in_ld, int num_inputs,
+                      int64_t num_blocks, int flags, ffh_stream s);
+
 /* ------------------------------------------------------------------ */
 /* BatchMatmul                                                        */
 /* ------------------------------------------------------------------ */
@@ -367,7 +374,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) \
-  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_second_stream_used) X(ffh_concat_fwd) X(ffh_concat_bwd) \
+  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_second_stream_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

@@ -472,21 +472,30 @@ int ffh_concat_fwd(ffh_ctx* c, float* out, int64_t out_blk, const float* const* 
 }
 /* Concat::backward_kernel [ref: src/ops/concat.cu:325-360] + add_with_stride
  * [ref: src/runtime/cuda_helper.cu:110-126] */
-int ffh_concat_bwd(ffh_ctx* c, const float* og, int64_t out_blk, float* const* igs,
-                   const int64_t* in_blk, const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
+int ffh_concat_bwd_ex(ffh_ctx* c, const float* og, int64_t out_blk, float* const* igs,
+                      const int64_t* in_blk, const int64_t* in_ld, int n, int64_t nblk, int flags, ffh_stream s) {
   (void)s;
   if (n < 0 || n > FFH_MAX_CONCAT_INPUTS || nblk < 0) return fail(c, FFH_ERR_BAD_ARG, "concat_bwd: bad dims");
+  if (flags & ~FFH_CONCAT_BWD_OVERWRITE) return fail(c, FFH_ERR_BAD_ARG, "concat_bwd_ex: unknown flags");
+  const int ow = flags & FFH_CONCAT_BWD_OVERWRITE;
   int64_t off = 0;
   for (int i = 0; i < n; i++) {
     const int64_t ld = in_ld ? in_ld[i] : in_blk[i];
     if (in_blk[i] < 0 || ld < in_blk[i] || off + in_blk[i] > out_blk) return fail(c, FFH_ERR_BAD_ARG, "concat_bwd: widths");
     if (igs[i] && !(igs[i] == og + off && ld == out_blk))
       for (int64_t b = 0; b < nblk; b++)
-        for (int64_t e = 0; e < in_blk[i]; e++)
-          igs[i][b * ld + e] += og[b * out_blk + off + e];
+        for (int64_t e = 0; e < in_blk[i]; e++) {
+          const float g = og[b * out_blk + off + e];
+          igs[i][b * ld + e] = ow ? g : igs[i][b * ld + e] + g;   /* add_with_stride [ref: src/runtime/cuda_helper.cu:110-126] / plain store */
+        }
     off += in_blk[i];
   }
   return FFH_OK;
+}
+
+int ffh_concat_bwd(ffh_ctx* c, const float* og, int64_t out_blk, float* const* igs,
+                   const int64_t* in_blk, const int64_t* in_ld, int n, int64_t nblk, ffh_stream s) {
+  return ffh_concat_bwd_ex(c, og, out_blk, igs, in_blk, in_ld, n, nblk, 0, s);
 }
 
 /* ------------------------------------------------------------------ */

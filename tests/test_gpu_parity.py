@@ -8,6 +8,8 @@ reductions whose order differs (GEMMs, atomics), tolerance written at each check
 torch is used only to own device memory and, in the full-size property tests, as an
 independent checker of pure gathers.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -465,6 +467,15 @@ def test_concat_golden_and_alias(hip):
         hip.concat("ffh_concat_bwd", out, sum(widths), grads, widths, None, nb)
         for p, q in zip(parts, grads):
             assert np.array_equal(p, host(q))
+        # ffh_concat_bwd_ex: accumulate on top of existing values (the reference's add_with_stride) / overwrite them
+        for flags in (0, capi.CONCAT_BWD_OVERWRITE):
+            grads = [torch.full((nb, w_), 2.0, device=DEV) for w_ in widths]
+            n = len(parts)
+            pa = (C.c_void_p * n)(*[q.data_ptr() for q in grads])
+            ba = (C.c_int64 * n)(*widths)
+            hip.check(hip.lib.ffh_concat_bwd_ex(hip.ctx, out.data_ptr(), sum(widths), pa, ba, None, n, nb, flags, None), "concat_bwd_ex")
+            for p, q in zip(parts, grads):
+                assert np.array_equal(p if flags else p + 2.0, host(q))
     # aliased producers: inputs that already live in the output are skipped, others copied
     nb, widths = 64, [16, 16, 16]
     Z = torch.zeros(nb, 48, device=DEV)

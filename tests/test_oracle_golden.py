@@ -246,6 +246,24 @@ def test_sgd_and_mse_match_torch_golden(oracle):
     assert abs(perf.mse_loss - float(g["mse_sum"])) <= 1e-5 * float(g["mse_sum"])
 
 
+def test_concat_bwd_overwrite_flag(oracle):
+    """ffh_concat_bwd_ex: 0 = add_with_stride [ref: src/runtime/cuda_helper.cu:110-126], FFH_CONCAT_BWD_OVERWRITE = plain store."""
+    import ctypes as C
+    rng = np.random.default_rng(2)
+    nb, widths = 5, [3, 8, 1]
+    og = rng.uniform(-1, 1, (nb, sum(widths))).astype(np.float32)
+    lib = oracle.lib()
+    for flags in (0, capi.CONCAT_BWD_OVERWRITE):
+        grads = [np.full((nb, w), 2.0, np.float32) for w in widths]
+        pa = (C.c_void_p * 3)(*[g.ctypes.data for g in grads])
+        ba = (C.c_int64 * 3)(*widths)
+        lib.check(lib.lib.ffh_concat_bwd_ex(lib.ctx, og.ctypes.data, sum(widths), pa, ba, None, 3, nb, flags, None), "concat_bwd_ex")
+        off = 0
+        for g, w in zip(grads, widths):
+            assert np.array_equal(g, og[:, off:off + w] + (0 if flags else np.float32(2.0)))
+            off += w
+
+
 def test_relu_mask_moved_to_the_producer_equals_plain_calls(oracle):
     """FFH_LINEAR_DX_MASK_BY_X on the upper layer + FFH_LINEAR_DY_PREMASKED on the lower one compute exactly what two
     plain Linear::backward calls compute (reluBackward [ref: src/runtime/cuda_helper.cu:71-78] applied where its
