@@ -289,7 +289,7 @@ def main():
         out["kernels"] = {
             "embedding_bwd_sgd_fused": {"bound": "hbm", "achieved": round(bwd_bytes / t_bwd / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(bwd_bytes / t_bwd / 1e9 / HBM_PEAK_GBS, 4), "us_per_call": round(t_bwd * 1e6, 2),
-                                        "note": "radix sort (hist+scatter per digit) + segmented reduce + two-level fold, all tables batched"},
+                                        "note": "batch x bag <= 2048 per table: ONE launch, a 512-thread workgroup per table (LDS-resident radix sort, segmented reduce by two 256-thread teams, both folds); larger batches: tiled radix sort + reduce + fold launches, all tables batched"},
             "linear_largest_layer": largest_linear(w, B, t_lin_fwd, t_lin_bwd),
             "whole_step_device": {"us": round(t_step_dev * 1e6, 2), "mlp_gflop_per_step": round(flops / 1e9, 3),
                                   "mlp_tflops_over_whole_step": round(flops / t_step_dev / 1e12, 2), "f32_mfma_peak_tflops": F32_PEAK_TFLOPS},

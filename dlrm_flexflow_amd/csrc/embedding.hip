@@ -171,13 +171,17 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const SortArgs
 // exclusive scan of the per-digit totals over digits (digit d = threadIdx.x + q*256) plus `before_d`, then the
 // per-wave starting offsets: s_off[w][d] (in: count of digit d in wave w's entries) becomes the first
 // destination of wave w's entries with digit d.
-__device__ __forceinline__ void sort_scan_offsets(const uint32_t (&all_d)[2], const uint32_t (&before_d)[2], int radix,
+// NW = waves of the workgroup (4 in the tiled sort kernels, 16 in the small-batch kernel); a thread owns the digits
+// threadIdx.x + q * 64 NW, q < QN = ceil(kMaxRadix / (64 NW))
+template <int NW, int QN>
+__device__ __forceinline__ void sort_scan_offsets(const uint32_t (&all_d)[QN], const uint32_t (&before_d)[QN], int radix,
                                                   uint32_t (*s_off)[kMaxRadix], uint32_t* s_scan, uint32_t* s_wsum) {
+  constexpr int NT = NW * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t carry = 0;
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
-    if (q * kSortThreads >= radix) break;
+  for (int q = 0; q < QN; q++) {
+    if (q * NT >= radix) break;
     uint32_t v = all_d[q];
     uint32_t incl = v;
 #pragma unroll
@@ -187,21 +191,25 @@ __device__ __forceinline__ void sort_scan_offsets(const uint32_t (&all_d)[2], co
     }
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
-    uint32_t woff = 0;
-    for (int w2 = 0; w2 < wave; w2++) woff += s_wsum[w2];
-    const uint32_t total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    const int d = threadIdx.x + q * kSortThreads;
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < NW; w2++) {
+      const uint32_t t = s_wsum[w2];
+      if (w2 < wave) woff += t;
+      total += t;
+    }
+    const int d = threadIdx.x + q * NT;
     if (d < radix) s_scan[d] = carry + woff + incl - v + before_d[q];
     carry += total;
     __syncthreads();
   }
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int d = threadIdx.x + q * kSortThreads;
+  for (int q = 0; q < QN; q++) {
+    const int d = threadIdx.x + q * NT;
     if (d < radix) {
       uint32_t run = s_scan[d];
 #pragma unroll
-      for (int w2 = 0; w2 < 4; w2++) {
+      for (int w2 = 0; w2 < NW; w2++) {
         const uint32_t cnt = s_off[w2][d];
         s_off[w2][d] = run;
         run += cnt;
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
       all_d[q] = all; before_d[q] = before;
     }
   }
-  sort_scan_offsets(all_d, before_d, radix, s_off, s_scan, s_wsum);
+  sort_scan_offsets<4, 2>(all_d, before_d, radix, s_off, s_scan, s_wsum);
   sort_rank_and_scatter<kSortPerThread>(key, pos, valid, a.shift, a.bits, mask, s_off[wave], a.keys_dst + (int64_t)t * a.N,
                                         a.pos_dst + (int64_t)t * a.N);
 }
@@ -356,7 +364,7 @@ struct RedShared {
 template <int VEC>
 __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const uint32_t* keys, const uint32_t* posg,
                                                  float* partial_t, uint2* meta_t, int64_t N, int nchunks, int tile, int tile_index,
-                                                 int L, int D_, bool avg_, float lr_, RedShared& sh) {
+                                                 int L, int D_, bool avg_, float lr_, RedShared& sh, const int tid = threadIdx.x) {
   uint32_t* s_key = sh.key;
   uint32_t* s_pos = sh.pos;
   uint16_t* s_start = sh.start;
@@ -364,19 +372,19 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
   uint2* s_meta = sh.meta;
   struct { int64_t N; int nchunks, L, D, avg; float lr; } a = {N, nchunks, L, D_, avg_ ? 1 : 0, lr_};
   const int64_t tile0 = (int64_t)tile_index * tile;
-  const int n = (int)((N - tile0) < tile ? (N - tile0) : tile);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = tile0 >= N ? 0 : (int)((N - tile0) < tile ? (N - tile0) : tile);   // a tile past the end still walks the barriers
+  const int lane = tid & 63, wave = tid >> 6;
 
-  for (int i = threadIdx.x; i < n; i += kRedThreads) {
+  for (int i = tid; i < n; i += kRedThreads) {
     s_key[1 + i] = keys[tile0 + i];
     s_pos[i] = posg[tile0 + i];
   }
-  if (threadIdx.x == 0) {
-    s_key[0] = tile0 > 0 ? keys[tile0 - 1] : 0xFFFFFFFFu;            // no valid key equals it when tile0 == 0 (checked below)
+  if (tid == 0) {
+    s_key[0] = (tile0 > 0 && tile0 < N) ? keys[tile0 - 1] : 0xFFFFFFFFu;   // no valid key equals it when tile0 == 0 (checked below)
     s_key[1 + n] = (tile0 + n < N) ? keys[tile0 + n] : 0xFFFFFFFFu;
   }
   const int metas = 2 * (tile / FFH_EMB_CHUNK);
-  if (threadIdx.x < metas) s_meta[threadIdx.x] = make_uint2(kMetaNone, 0);
+  if (tid < metas) s_meta[tid] = make_uint2(kMetaNone, 0);
   __syncthreads();
 
   // sub-run starts: chunk boundaries and changes of row id; compacted in order
@@ -393,7 +401,7 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
     if (lane == 0) s_cnt[wave * 4 + e] = __popcll(bal);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     uint32_t run = 0;
     for (int q = 0; q < kRedTile / 64; q++) { const uint32_t c = s_cnt[q]; s_cnt[q] = run; run += c; }
     s_cnt[kRedTile / 64] = run;
@@ -406,7 +414,7 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
     if (st[e]) s_start[s_cnt[wave * 4 + e] + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
   }
   const int S = (int)s_cnt[kRedTile / 64];
-  if (threadIdx.x == 0) s_start[S] = (uint16_t)n;
+  if (tid == 0) s_start[S] = (uint16_t)n;
   __syncthreads();
 
   // lane-groups walk the sub-runs
@@ -470,9 +478,9 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
     }
   }
   __syncthreads();
-  if (threadIdx.x < metas) {
-    const int64_t slot = (tile0 / FFH_EMB_CHUNK) * 2 + threadIdx.x;
-    if (slot < 2 * (int64_t)a.nchunks) meta_t[slot] = s_meta[threadIdx.x];
+  if (tid < metas) {
+    const int64_t slot = (tile0 / FFH_EMB_CHUNK) * 2 + tid;
+    if (slot < 2 * (int64_t)a.nchunks) meta_t[slot] = s_meta[tid];
   }
 }
 
@@ -602,17 +610,33 @@ struct SmallArgs {
   float*    partial1;  uint2* meta1;   // level-1 slots [nt][2*nch1]
   int64_t   N;
   int nch0, nch1, rb, L, D, avg;
+  int tile;            // sorted entries per reduce team (multiple of FFH_EMB_CHUNK, <= kRedTile)
   float lr;
 };
 
+constexpr int kSmallWaves = 8;                        // threads per table = 64 x this: sort ranks kSmallMax / threads entries per thread, reduce = teams of 256
+constexpr int kSmallThreads = kSmallWaves * 64;
+constexpr int kSmallRedParts = kSmallThreads / kRedThreads;
+
+struct SmallSortShared {
+  uint32_t k[kSmallMax], p[kSmallMax];
+  uint32_t off[kSmallWaves][kMaxRadix];
+  uint32_t scan[kMaxRadix];
+  uint32_t wsum[kSmallWaves];
+};
+union SmallShared {                                    // the sort arrays are dead once the sorted list is in global memory
+  SmallSortShared sort;
+  RedShared red[kSmallRedParts];
+};
+
 template <int VEC>
-__global__ __launch_bounds__(kSortThreads) void emb_sgd_small_kernel(const SmallArgs a) {
-  constexpr int E = kSmallMax / kSortThreads;   // 8 entries per thread, wave w owns [512w, 512w+512)
-  __shared__ uint32_t s_k[kSmallMax], s_p[kSmallMax];
-  __shared__ uint32_t s_off[4][kMaxRadix];
-  __shared__ uint32_t s_scan[kMaxRadix];
-  __shared__ uint32_t s_wsum[4];
-  __shared__ RedShared sh;
+__global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const SmallArgs a) {
+  constexpr int NW = kSmallWaves;
+  constexpr int E = kSmallMax / kSmallThreads;         // 2 entries per thread, wave w owns [128 w, 128 w + 128)
+  __shared__ SmallShared sm;
+  uint32_t* s_k = sm.sort.k;
+  uint32_t* s_p = sm.sort.p;
+  uint32_t (*s_off)[kMaxRadix] = sm.sort.off;
   const int tix = blockIdx.x;
   const ffh_emb_table tb = a.t[tix];
   const int64_t N = a.N;
@@ -624,7 +648,7 @@ __global__ __launch_bounds__(kSortThreads) void emb_sgd_small_kernel(const Small
   bool valid[E];
 #pragma unroll
   for (int e = 0; e < E; e++) {
-    const int i = wave * (kSmallMax / 4) + e * 64 + lane;
+    const int i = wave * (kSmallMax / NW) + e * 64 + lane;
     valid[e] = i < N;
     key[e] = valid[e] ? (uint32_t)tb.idx[i] : 0u;
     pos[e] = (uint32_t)i;
@@ -632,25 +656,26 @@ __global__ __launch_bounds__(kSortThreads) void emb_sgd_small_kernel(const Small
   const int npass = a.npass[tix];
   for (int p = 0; p < npass; p++) {
     const int shift = p * a.rb;
-    for (int d = threadIdx.x; d < 4 * kMaxRadix; d += kSortThreads) (&s_off[0][0])[d] = 0;
+    for (int d = threadIdx.x; d < NW * kMaxRadix; d += kSmallThreads) (&s_off[0][0])[d] = 0;
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < E; e++)
       if (valid[e]) atomicAdd(&s_off[wave][(key[e] >> shift) & mask], 1u);
     __syncthreads();
-    uint32_t all_d[2] = {0, 0};
-    const uint32_t before_d[2] = {0, 0};
+    uint32_t all_d[1] = {0};
+    const uint32_t before_d[1] = {0};
+    if ((int)threadIdx.x < radix) {
+      uint32_t t = 0;
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const int d = threadIdx.x + q * kSortThreads;
-      if (d < radix) all_d[q] = s_off[0][d] + s_off[1][d] + s_off[2][d] + s_off[3][d];
+      for (int w2 = 0; w2 < NW; w2++) t += s_off[w2][threadIdx.x];
+      all_d[0] = t;
     }
-    sort_scan_offsets(all_d, before_d, radix, s_off, s_scan, s_wsum);
+    sort_scan_offsets<NW, 1>(all_d, before_d, radix, s_off, sm.sort.scan, sm.sort.wsum);
     sort_rank_and_scatter<E>(key, pos, valid, shift, a.rb, mask, s_off[wave], s_k, s_p);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < E; e++) {
-      const int i = wave * (kSmallMax / 4) + e * 64 + lane;
+      const int i = wave * (kSmallMax / NW) + e * 64 + lane;
       if (valid[e]) { key[e] = s_k[i]; pos[e] = s_p[i]; }
     }
     __syncthreads();
@@ -659,20 +684,22 @@ __global__ __launch_bounds__(kSortThreads) void emb_sgd_small_kernel(const Small
   uint32_t* posg = a.pos + (int64_t)tix * N;
 #pragma unroll
   for (int e = 0; e < E; e++) {
-    const int i = wave * (kSmallMax / 4) + e * 64 + lane;
+    const int i = wave * (kSmallMax / NW) + e * 64 + lane;
     if (valid[e]) { keys[i] = key[e]; posg[i] = pos[e]; }
   }
   uint2* m1 = a.meta1 + (int64_t)tix * 2 * a.nch1;
-  for (int i = threadIdx.x; i < 2 * a.nch1; i += kSortThreads) m1[i] = make_uint2(kMetaNone, 0);
+  for (int i = threadIdx.x; i < 2 * a.nch1; i += kSmallThreads) m1[i] = make_uint2(kMetaNone, 0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
+  // reduce: the 1024 threads act as four 256-thread teams, one tile of a.tile sorted entries each
   float* p0 = a.partial0 + (int64_t)tix * 2 * a.nch0 * a.D;
   uint2* m0 = a.meta0 + (int64_t)tix * 2 * a.nch0;
-  const int ntiles = (int)((N + kRedTile - 1) / kRedTile);
-  for (int ti = 0; ti < ntiles; ti++) {
-    reduce_tile_body<VEC>(tb, keys, posg, p0, m0, N, a.nch0, kRedTile, ti, a.L, a.D, a.avg != 0, a.lr, sh);
+  const int team = threadIdx.x / kRedThreads, ttid = threadIdx.x % kRedThreads;
+  const int ntiles = (int)((N + a.tile - 1) / a.tile);
+  for (int t0 = 0; t0 < ntiles; t0 += kSmallRedParts) {
+    reduce_tile_body<VEC>(tb, keys, posg, p0, m0, N, a.nch0, a.tile, t0 + team, a.L, a.D, a.avg != 0, a.lr, sm.red[team], ttid);
     __syncthreads();
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -683,7 +710,7 @@ __global__ __launch_bounds__(kSortThreads) void emb_sgd_small_kernel(const Small
   const int lpr = nvec < 64 ? nvec : 64;
   const int rpw = 64 / lpr;
   const int64_t group0 = (int64_t)wave * rpw + lane / lpr;
-  const int64_t ngroups = (int64_t)(kSortThreads >> 6) * rpw;
+  const int64_t ngroups = (int64_t)NW * rpw;
   float* p1 = a.partial1 + (int64_t)tix * 2 * a.nch1 * a.D;
   if (a.nch1 > 1) {
     fold_table_body<VEC>(tb, p0, m0, p1, m1, a.nch0, FFH_EMB_CHUNK1 / FFH_EMB_CHUNK, a.D, a.lr, group0, ngroups);
@@ -852,8 +879,11 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
     sm.partial1 = (float*)(ws + lay.partial1); sm.meta1 = (uint2*)(ws + lay.meta1);
     sm.N = N; sm.nch0 = lay.nchunks; sm.nch1 = lay.nchunks1; sm.rb = rb_s; sm.L = L; sm.D = D;
     sm.avg = aggr == FFH_AGGR_MODE_AVG ? 1 : 0; sm.lr = lr;
-    if (v4) hipLaunchKernelGGL((emb_sgd_small_kernel<4>), dim3(nt), dim3(kSortThreads), 0, as_stream(s), sm);
-    else hipLaunchKernelGGL((emb_sgd_small_kernel<1>), dim3(nt), dim3(kSortThreads), 0, as_stream(s), sm);
+    int tile = (int)((N + kSmallRedParts - 1) / kSmallRedParts);          // one tile per 256-thread team
+    tile = (tile + FFH_EMB_CHUNK - 1) / FFH_EMB_CHUNK * FFH_EMB_CHUNK;
+    sm.tile = tile < FFH_EMB_CHUNK ? FFH_EMB_CHUNK : tile;
+    if (v4) hipLaunchKernelGGL((emb_sgd_small_kernel<4>), dim3(nt), dim3(kSmallThreads), 0, as_stream(s), sm);
+    else hipLaunchKernelGGL((emb_sgd_small_kernel<1>), dim3(nt), dim3(kSmallThreads), 0, as_stream(s), sm);
     FFH_LAUNCH_CHECK(c, "emb_sgd_small_kernel");
     return FFH_OK;
   }
