@@ -645,7 +645,7 @@ struct GldsPlan { int bm; dim3 grid; int lds_bytes; };
 // Fills the plan (tile height, grid, split-K) if the LDS-DMA kernel should take this GEMM.
 template <bool AKR, bool BKR>
 bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p, double min_work = 1.5e8, int min_k = 128) {
-  static const int off = getenv("FFH_GEMM_NO_GLDS") ? atoi(getenv("FFH_GEMM_NO_GLDS")) : 0;   // tuning aid
+  static const int off = getenv("FFH_GEMM_NO_GLDS") ? atoi(getenv("FFH_GEMM_NO_GLDS")) : 0;   // A/B switch (tools/ab.sh)
   if (off || !c->zeros) return false;
   if (!glds_aligned(g.A, g.lda) || !glds_aligned(g.B, g.ldb)) return false;
   // whole 16-byte chunks only: the contiguous extent of each operand must be a multiple of 4 floats
@@ -660,8 +660,7 @@ bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p, double 
   g.zeros = c->zeros;
   g.splitk = 1; g.k_per_split = (g.K + 63) / 64 * 64;
   if (atomic_splitk) {
-    static const int split_ceil = getenv("FFH_GLDS_SPLIT_CEIL") ? atoi(getenv("FFH_GLDS_SPLIT_CEIL")) : 0;   // tuning aid
-    int want = split_ceil ? (int)((c->num_cus + tiles - 1) / tiles) : (int)(c->num_cus / tiles);   // default: one round of workgroups
+    int want = (int)(c->num_cus / tiles);               // one round of workgroups: never more of them than CUs
     const int max_split = (g.K + 255) / 256;            // at least four k-tiles per workgroup
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
@@ -705,12 +704,11 @@ int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const
 
 // dX and dW of one layer in ONE launch (gemm_glds_bwd_kernel); 1 = done, 0 = not applicable
 int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
-  static const int off = getenv("FFH_GLDS_NO_DUAL") ? atoi(getenv("FFH_GLDS_NO_DUAL")) : 0;   // tuning aid
+  static const int off = getenv("FFH_GLDS_NO_DUAL") ? atoi(getenv("FFH_GLDS_NO_DUAL")) : 0;   // A/B switch (tools/ab.sh)
   if (off) return 0;
   GldsPlan px, pw;
-  // as one launch the pair pays for itself at smaller sizes than a single GEMM does
-  static const double min_work = getenv("FFH_GLDS_DUAL_MINWORK") ? atof(getenv("FFH_GLDS_DUAL_MINWORK")) : 1.5e8;   // tuning aid
-  if (!plan_glds<false, true>(c, dxg, false, px, min_work, 64) || !plan_glds<true, true>(c, dwg, true, pw, min_work, 64)) return 0;
+  // (the 256x64 layer was tried as a pair too: no gain, so the work threshold of the single GEMMs stands; k >= 64 suffices)
+  if (!plan_glds<false, true>(c, dxg, false, px, 1.5e8, 64) || !plan_glds<true, true>(c, dwg, true, pw, 1.5e8, 64)) return 0;
   const unsigned na = px.grid.x * px.grid.y * px.grid.z, nb = pw.grid.x * pw.grid.y * pw.grid.z;
   const unsigned na8 = (na + 7u) & ~7u;
   const GldsDims dx{px.grid.x, px.grid.y, px.grid.z}, dw{pw.grid.x, pw.grid.y, pw.grid.z};
@@ -817,7 +815,7 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   } else if (tiles128 >= 2 * c->num_cus && g.M >= 128 && g.N >= 128) cfg = 0;
   else if (tiles64 >= 2 * c->num_cus || g.K < 64) cfg = 1;
   else cfg = 2;
-  static const int forced = getenv("FFH_GEMM_CFG") ? atoi(getenv("FFH_GEMM_CFG")) : -1;   // tuning aid
+  static const int forced = getenv("FFH_GEMM_CFG") ? atoi(getenv("FFH_GEMM_CFG")) : -1;   // A/B switch (tools/gemm_tune.py)
   if (forced >= 0 && forced <= 2) cfg = forced;
   const int BMv = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32);
   const int gx = (g.N + BMv - 1) / BMv, gy = (g.M + BMv - 1) / BMv;
@@ -828,8 +826,6 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
     // split K over workgroups so that about two of them per CU are in flight; each split is a multiple of kSplitGran
     const int64_t tiles = (int64_t)gx * gy;
     int want = (int)((2LL * c->num_cus + tiles - 1) / tiles);
-    static const int forced_split = getenv("FFH_GEMM_SPLIT") ? atoi(getenv("FFH_GEMM_SPLIT")) : 0;   // tuning aid
-    if (forced_split > 0) want = forced_split;
     const int max_split = (g.K + 4 * kSplitGran - 1) / (4 * kSplitGran);
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
@@ -1046,7 +1042,7 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   const bool do_dw = !(flags & FFH_LINEAR_ONLY_DX);
   const bool do_dx = !(flags & FFH_LINEAR_ONLY_DW);
   FFH_REQUIRE(c, do_dw || do_dx, "linear_bwd_ex: ONLY_DX and ONLY_DW are exclusive");
-  static const int no_skinny = getenv("FFH_NO_SKINNY") ? atoi(getenv("FFH_NO_SKINNY")) : 0;   // tuning aid
+  static const int no_skinny = getenv("FFH_NO_SKINNY") ? atoi(getenv("FFH_NO_SKINNY")) : 0;   // A/B switch (tools/ab.sh)
   const bool skinny_vec = !no_skinny && (in % 4 == 0) && glds_aligned(x, ldx) && (((uintptr_t)w & 15) == 0) && (!dx || glds_aligned(dx, lddx));
   if (out <= kSkinnyMaxOut && in <= kSkinnyMaxIn && skinny_vec) {
     // one launch for the whole layer (the split ONLY_* forms keep their meaning; a forked dw stream is not needed)
@@ -1062,8 +1058,7 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     a.mask_by_x = mask_by_x ? 1 : 0;
     // dW / db are accumulated with one atomic per weight per workgroup: adds to ONE address serialise (~0.1 us each), so
     // the number of workgroups is kept near 32 -- and every wave then keeps 16 / NC rows in flight to cover the latency
-    static const int skinny_blocks = getenv("FFH_SKINNY_BLOCKS") ? atoi(getenv("FFH_SKINNY_BLOCKS")) : 32;   // tuning aid
-    int64_t rpb = (batch + skinny_blocks - 1) / skinny_blocks;
+    int64_t rpb = (batch + 31) / 32;
     rpb = (rpb + 15) / 16 * 16;
     if (rpb > 1024) rpb = 1024;
     a.rows_per_block = (int)rpb;

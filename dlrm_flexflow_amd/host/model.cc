@@ -1377,8 +1377,7 @@ void FFModel::forward(int _seq_length) {
     // The side stream already runs behind everything it depends on from earlier steps (the table update is on it);
     // what it must additionally see is a batch that was copied in on `stream`.  No new batch (the reference reuses
     // the warm-up batch for random input), no event: each record / wait is a barrier packet on the critical stream.
-    static const bool old_events = getenv("FFM_OLD_EVENTS") && atoi(getenv("FFM_OLD_EVENTS"));   // A/B aid
-    fork_recorded = inputs_dirty || capturing_trace >= 0 || use_workers() || old_events;
+    fork_recorded = inputs_dirty || capturing_trace >= 0 || use_workers();
     if (fork_recorded) check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
     inputs_dirty = false;
     // start the gather right now unless a host-side collective would stall THIS thread's launches
@@ -1512,8 +1511,7 @@ void FFModel::update() {
     if (config.overlap_embedding) {
       // launched in backward() on the side stream.  Its only consumer, the next gather, runs on that same stream, and
       // every host read of a table syncs both streams -- so `stream` joins it only where a capture must close the fork
-      static const bool old_events = getenv("FFM_OLD_EVENTS") && atoi(getenv("FFM_OLD_EVENTS"));   // A/B aid
-      if (!embeddings.empty() && (capturing_trace >= 0 || use_workers() || old_events))
+      if (!embeddings.empty() && (capturing_trace >= 0 || use_workers()))
         check(api->ffh_stream_wait_event(ctx, stream, ev_update_done), "join update");
     } else {
       embedding_group_update(stream);
