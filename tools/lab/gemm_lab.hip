@@ -302,6 +302,126 @@ float run64(const float* A, const float* B, float* C, const float* bias, const f
   return ms * 1e3f / iters;
 }
 
+
+// 128x128 block tile, BK = 32, 16 waves as 4x4 sub-tiles of 32x32 (no k-split), NSTAGE stages of 32 KB.
+// LDS image per operand: [128 rows][8 chunks of 16 B], slot = chunk ^ ((row >> 1) & 7)  (conflict-free ds_read_b128)
+template <int NSTAGE>
+__global__ __launch_bounds__(1024) void gemm_kk128(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                   const float* __restrict__ bias, const float* __restrict__ zeros, int M, int N, int K,
+                                                   int64_t lda, int64_t ldb, int64_t ldc, int relu) {
+  constexpr int NW = 16;
+  constexpr int A_CH = 128 * 8, STAGE_CH = 2 * A_CH;    // 2048 chunks = 32 KB
+  constexpr int NIW = (STAGE_CH / 64) / NW;             // 2 DMA pieces per stage per wave
+  extern __shared__ float4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  int bx, by;
+  {
+    const unsigned nbx = gridDim.x, total = gridDim.x * gridDim.y;
+    const unsigned lin = blockIdx.y * nbx + blockIdx.x;
+    const unsigned xcd = lin & 7u, loc = lin >> 3, q = total >> 3, rem = total & 7u;
+    const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
+    bx = (int)(nlin % nbx); by = (int)(nlin / nbx);
+  }
+  const int m0 = by * 128, n0 = bx * 128;
+  const int wm = wave >> 2, wn = wave & 3;
+  const float* src_row[NIW];
+  int src_c4[NIW];
+#pragma unroll
+  for (int i = 0; i < NIW; i++) {
+    const int q = wave + NW * i;
+    const int ch = q * 64 + lane;
+    const bool isA = ch < A_CH;
+    const int cb = isA ? ch : ch - A_CH;
+    const int r = cb >> 3, s = cb & 7, c = s ^ ((r >> 1) & 7);
+    const int g = (isA ? m0 : n0) + r;
+    const bool ok = g < (isA ? M : N);
+    src_row[i] = ok ? (isA ? A + (int64_t)g * lda : B + (int64_t)g * ldb) + 4 * c : nullptr;
+    src_c4[i] = 4 * c;
+  }
+  const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)lds;
+  auto issue = [&](int kt, int buf, int i0, int i1) {
+    const int k0 = kt * 32;
+#pragma unroll
+    for (int i = i0; i < i1; i++) {
+      const int q = wave + NW * i;
+      const float* src = (src_row[i] != nullptr && k0 + src_c4[i] < K) ? src_row[i] + k0 : zeros;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * STAGE_CH + q * 64) * 16u);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+  const int nk = (K + 31) / 32;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; s++) issue(s, s, 0, NIW);
+  const int ra = wm * 32 + lr, rb = wn * 32 + lr;
+  int buf = 0, nbuf = NSTAGE - 1;
+  for (int t = 0; t < nk; t++) {
+    wait_vmcnt<(NSTAGE - 2) * NIW>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const float4* as = lds + buf * STAGE_CH;
+    const float4* bs = as + A_CH;
+    auto rd = [&](int j, float4& a, float4& b) {
+      const int c = 2 * j + lh;
+      a = as[ra * 8 + (c ^ ((ra >> 1) & 7))];
+      b = bs[rb * 8 + (c ^ ((rb >> 1) & 7))];
+    };
+    float4 a_cur, b_cur, a_nxt, b_nxt;
+    rd(0, a_cur, b_cur);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (j + 1 < 4) rd(j + 1, a_nxt, b_nxt);
+      if (j < NIW) issue(t + NSTAGE - 1, nbuf, j, j + 1);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur.w, acc, 0, 0, 0);
+      a_cur = a_nxt; b_cur = b_nxt;
+    }
+    buf = buf + 1 == NSTAGE ? 0 : buf + 1;
+    nbuf = nbuf + 1 == NSTAGE ? 0 : nbuf + 1;
+  }
+  wait_vmcnt<0>();
+  const int n = n0 + wn * 32 + lr;
+  if (n < N) {
+    const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < M) {
+        float v = acc[r] + bv;
+        if (relu) v = v > 0.0f ? v : 0.0f;
+        C[(int64_t)m * ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int NSTAGE>
+float run128(const float* A, const float* B, float* C, const float* bias, const float* zeros, int M, int N, int K, int iters) {
+  constexpr int lds_bytes = NSTAGE * 2048 * 16;
+  auto kern = gemm_kk128<NSTAGE>;
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  dim3 grid((N + 127) / 128, (M + 127) / 128);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, 0, A, B, C, bias, zeros, M, N, K, (int64_t)K, (int64_t)K, (int64_t)N, 1);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, 0, A, B, C, bias, zeros, M, N, K, (int64_t)K, (int64_t)K, (int64_t)N, 1);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  CK(hipGetLastError());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e3f / iters;
+}
+
 template <int BM, int BN, int NSTAGE, int MODE = 0>
 float run(const float* A, const float* B, float* C, const float* bias, const float* zeros, int M, int N, int K, int iters) {
   constexpr int lds_bytes = NSTAGE * (BM + BN) * 16 * 16;
@@ -324,7 +444,7 @@ float run(const float* A, const float* B, float* C, const float* bias, const flo
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 2048, N = argc > 2 ? atoi(argv[2]) : 512, K = argc > 3 ? atoi(argv[3]) : 432;
-  const int iters = 200;
+  const int iters = (double)M * N * K > 4e9 ? 30 : 200;
   std::vector<float> hA((size_t)M * K), hB((size_t)N * K), hb(N), hC((size_t)M * N);
   srand(1);
   for (auto& v : hA) v = (rand() % 2001 - 1000) / 1000.0f;
@@ -347,6 +467,8 @@ int main(int argc, char** argv) {
     printf("%-22s M=%d N=%d K=%d  %7.2f us  %6.1f TF/s  maxrelerr %.2e\n", name, M, N, K, us, 2.0 * M * N * K / us / 1e6, maxerr);
     CK(hipMemset(C, 0, hC.size() * 4));
   };
+  check("kk128 16w s3", run128<3>(A, B, C, bias, zeros, M, N, K, iters));
+  check("kk128 16w s4", run128<4>(A, B, C, bias, zeros, M, N, K, iters));
   check("kk64 4w s4", run64<4, 4>(A, B, C, bias, zeros, M, N, K, iters));
   check("kk64 8w s4", run64<8, 4>(A, B, C, bias, zeros, M, N, K, iters));
   check("kk64 8w s3", run64<8, 3>(A, B, C, bias, zeros, M, N, K, iters));

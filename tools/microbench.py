@@ -38,6 +38,11 @@ def emb(hip):
                                                585935, 12972, 108, 36]),
              ("kaggle-26", 26, 2048, 16, [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194,
                                           27, 14992, 5461306, 10, 5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]),
+             # what one of 2 / 4 / 8 ranks sees at the Kaggle shape (weak scaling: 2048 samples per rank, tables dealt round-robin)
+             ("kaggle-rank-of-2", 13, 4096, 16, [1460, 10131227, 305, 12517, 3, 5683, 3194, 14992, 10, 2173, 7046547, 15, 105]),
+             ("kaggle-rank-of-4", 7, 8192, 16, [1460, 305, 3, 3194, 10, 7046547, 105]),
+             ("kaggle-rank-of-8", 4, 16384, 16, [1460, 3, 10, 105]),
+             ("kaggle-rank2-of-8", 3, 16384, 16, [10131227, 5683, 2173]),
              ("giant-colshard", 1, 32768, 32, [200_000_000])]
     only = [a for a in sys.argv[2:]]
     for name, T, B, D, rows in cases:
