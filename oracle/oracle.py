@@ -259,3 +259,23 @@ def ref_embedding_fwd(idx, w, lengths=None, normalize=False):
     out = np.empty((B, D), np.float32)
     fn(D, B, flat.size, R, w.ctypes.data, flat.ctypes.data, lengths.ctypes.data, None, normalize, out.ctypes.data)
     return out
+
+
+_REF_BWD = "_Z14embed_backwardPKlPKiPKfPfiiii"   # embed_backward(const int64_t* in, const int* lengths, const float* out_grad, float* embed, block, B, index_size, data_size)
+
+
+def ref_embedding_bwd(idx, g, wgrad):
+    """The reference's CPU embed_backward [ref: src/ops/embedding.cc:344-374] (compiled from its source, oracle/Makefile):
+    wgrad[idx[b]] += g[b] for b ascending.  It reads ONE index per sample (the reference asserts in_dim == 1 on this
+    path, src/ops/embedding.cc:408), so idx is [B] or [B][1].  Returns the updated copy of wgrad."""
+    lib_ = C.CDLL(REF_LIB)
+    fn = getattr(lib_, _REF_BWD)
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    idx, g = _i64(idx).reshape(-1), _f32(g)
+    B, D = g.shape
+    assert idx.size == B
+    wg = _f32(wgrad).copy()
+    lengths = np.ones(B, np.int32)
+    fn(idx.ctypes.data, lengths.ctypes.data, g.ctypes.data, wg.ctypes.data, D, B, B, wg.shape[0])
+    return wg

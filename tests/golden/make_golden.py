@@ -72,6 +72,24 @@ def embedding_from_reference():
     save("embedding_fwd_ref", **cases)
 
 
+def embedding_bwd_from_reference():
+    """embed_backward of the reference's CPU path [ref: src/ops/embedding.cc:344-374], compiled from its source: one index
+    per sample, gradients accumulated on top of an existing dense table gradient, heavy duplicates included."""
+    assert oracle.ref_available(), "run `make -C oracle ref` with /root/reference present"
+    rng = np.random.default_rng(7)
+    cases = {}
+    k = 0
+    for (B, R, D) in ((200, 50, 16), (333, 7, 13), (64, 1000, 128), (1, 3, 4), (4096, 3, 16)):
+        idx = rng.integers(0, R, (B, 1)).astype(np.int64)
+        g = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+        wg0 = rng.uniform(-1, 1, (R, D)).astype(np.float32)
+        cases[f"c{k}_idx"], cases[f"c{k}_g"], cases[f"c{k}_wg0"] = idx, g, wg0
+        cases[f"c{k}_wg"] = oracle.ref_embedding_bwd(idx, g, wg0)
+        k += 1
+    cases["n_cases"] = np.array(k)
+    save("embedding_bwd_ref", **cases)
+
+
 def linear_from_torch():
     np.random.seed(0)
     cases = {}
@@ -263,6 +281,7 @@ def dlrm_step_from_torch():
 
 if __name__ == "__main__":
     embedding_from_reference()
+    embedding_bwd_from_reference()
     linear_from_torch()
     concat_from_numpy()
     bmm_from_torch()

@@ -236,6 +236,27 @@ def test_embedding_fused_multi_table_strided_grad(hip, oracle, ws, B):
         assert bits_equal(host(wt[t]), oracle.embedding_bwd_sgd_fused(idxs[t], gs, ws_[t], 0.05)), f"table {t}"
 
 
+def test_embedding_backward_reference_fixture_on_gpu(hip, oracle, ws):
+    """The reference's compiled CPU embed_backward (tests/golden/embedding_bwd_ref.npz) against the HIP kernels:
+    ffh_embedding_bwd_dense within 1e-5 of it (atomics: no fixed order), the fused update equal to
+    W - lr * (that gradient) within 1e-6 and bit-equal to the oracle's fused update."""
+    g = golden("embedding_bwd_ref")
+    for k in range(int(g["n_cases"])):
+        idx, gr, wg0, wg = g[f"c{k}_idx"], g[f"c{k}_g"], g[f"c{k}_wg0"], g[f"c{k}_wg"]
+        R, D = wg0.shape
+        B = idx.shape[0]
+        wgt = dev(wg0)
+        hip.call("ffh_embedding_bwd_dense", dev(idx), dev(gr), wgt, 1, D, B, R, D, capi.AGGR_MODE_SUM, None)
+        mass = np.abs(wg0).astype(np.float64)
+        np.add.at(mass, idx.reshape(-1), np.abs(gr.astype(np.float64)))
+        assert_gemm_close(host(wgt), wg, mass, f"dense case {k}")
+        w = np.random.default_rng(k).uniform(-1, 1, (R, D)).astype(np.float32)
+        fused = gpu_fused(hip, idx, gr, w, 0.05)
+        assert bits_equal(fused, oracle.embedding_bwd_sgd_fused(idx, gr, w, 0.05))
+        ref_grad = wg.astype(np.float64) - wg0.astype(np.float64)
+        np.testing.assert_allclose(fused, w - 0.05 * ref_grad, rtol=1e-5, atol=2e-6 * max(1.0, np.abs(ref_grad).max()), err_msg=f"fused case {k}")
+
+
 def test_embedding_fused_equals_reference_three_step_path(hip, oracle, ws):
     """zero_grad -> embed_backward (atomics) -> sgd_update, all three on the GPU, against the
     fused kernel: same table within 1e-5 (the dense path's atomics have no fixed order)."""

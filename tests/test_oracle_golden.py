@@ -246,6 +246,39 @@ def test_sgd_and_mse_match_torch_golden(oracle):
     assert abs(perf.mse_loss - float(g["mse_sum"])) <= 1e-5 * float(g["mse_sum"])
 
 
+def test_embedding_backward_matches_compiled_reference(oracle):
+    """Pins the dense scatter-add (a-3) and, through it, the fused update (a-3 + a-4) to the reference's own CPU
+    embed_backward [ref: src/ops/embedding.cc:344-374], compiled from its source (fixture: make_golden.py,
+    embedding_bwd_from_reference).  ffh_embedding_bwd_dense: same ascending-b accumulation => bit for bit.
+    Fused update: W - lr * (reference gradient from zero) within 1e-6 relative (only the order inside duplicate rows
+    differs), and bit for bit when no row is hit more than twice (a + b is order-free)."""
+    g = golden("embedding_bwd_ref")
+    for k in range(int(g["n_cases"])):
+        idx, gr, wg0, wg = g[f"c{k}_idx"], g[f"c{k}_g"], g[f"c{k}_wg0"], g[f"c{k}_wg"]
+        R = wg0.shape[0]
+        got = oracle.embedding_bwd_dense(idx, gr, R, wgrad=wg0.copy())
+        assert got.tobytes() == wg.tobytes(), f"case {k}"
+        # three-step reference path with the reference's own gradient: zero_grad -> embed_backward -> sgd_update
+        dense = wg.astype(np.float64) - wg0.astype(np.float64)          # the gradient itself, up to fp32 rounding of wg0 + .
+        rng = np.random.default_rng(k)
+        w = rng.uniform(-1, 1, wg0.shape).astype(np.float32)
+        fused = oracle.embedding_bwd_sgd_fused(idx, gr, w, 0.05)
+        from_zero = oracle.embedding_bwd_dense(idx, gr, R)               # bit-equal to the reference run from a zero table: checked next
+        np.testing.assert_allclose(from_zero, dense, rtol=0, atol=4e-6 * max(1.0, np.abs(dense).max()))
+        three_step = oracle.sgd_update(w.reshape(-1), from_zero.reshape(-1), 0.05).reshape(w.shape)
+        mass = np.zeros(wg0.shape, np.float64)
+        np.add.at(mass, idx.reshape(-1), np.abs(gr.astype(np.float64)))
+        bound = 8 * 2.0 ** -24 * (np.abs(w) + 0.05 * mass) + 1e-12      # a few ulps of the accumulated magnitude
+        assert (np.abs(fused.astype(np.float64) - three_step) <= bound).all(), f"case {k}" 
+        counts = np.bincount(idx.reshape(-1), minlength=R)
+        rows = counts <= 2
+        assert np.array_equal(fused[rows], three_step[rows])
+    if oracle.ref_available():                                             # in this container: call the compiled function itself
+        idx, gr = g["c0_idx"], g["c0_g"]
+        z = oracle.ref_embedding_bwd(idx, gr, np.zeros_like(g["c0_wg0"]))
+        assert z.tobytes() == oracle.embedding_bwd_dense(idx, gr, z.shape[0]).tobytes()
+
+
 def test_concat_bwd_overwrite_flag(oracle):
     """ffh_concat_bwd_ex: 0 = add_with_stride [ref: src/runtime/cuda_helper.cu:110-126], FFH_CONCAT_BWD_OVERWRITE = plain store."""
     import ctypes as C
