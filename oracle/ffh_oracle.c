@@ -9,14 +9,17 @@
  * path (dlrm_flexflow_amd/, the C++ FFModel shim's default backend) loads it.
  *
  * Pinning: the embedding forward is checked against the reference's own AVX2
- * lookup compiled from /root/reference (oracle/Makefile -> oracle/_ref/), and
- * the Linear / Concat / BatchMatmul / SGD / MSE functions against PyTorch-CPU
- * + numpy, the oracle the reference's op tests use (tests/ops/test_harness.py);
- * vectors are committed under tests/golden/ (tests/golden/make_golden.py).
- * The fused embedding backward + SGD, the metrics kernel and the multi-GPU
- * exchange have no reference test or golden vector: PARITY UNPINNED by the
- * reference for those three -- they are pinned only against the float64
- * mathematical result (tests/test_oracle_golden.py).
+ * lookup, and the embedding backward (dense scatter-add, and through it the
+ * fused backward + SGD) against the reference's own CPU embed_backward, both
+ * compiled from /root/reference (oracle/Makefile -> oracle/_ref/); the Linear /
+ * Concat / BatchMatmul / SGD / Adam / MSE functions against PyTorch-CPU + numpy,
+ * the oracle the reference's op tests use (tests/ops/test_harness.py); vectors
+ * are committed under tests/golden/ (tests/golden/make_golden.py).
+ * The metrics kernel's accumulation order, bags with more than one index in the
+ * backward, and the multi-GPU exchange have no reference function, test or
+ * golden vector: PARITY UNPINNED by the reference for those -- they are checked
+ * only against the float64 mathematical result / the single-rank run
+ * (tests/test_oracle_golden.py, tests/test_ffmodel_host.py).
  *
  * Each function cites the reference file:line it follows (paths relative to
  * the reference checkout).  Summation orders are fixed and documented so the
