@@ -211,6 +211,29 @@ def test_embedding_fused_bwd_sgd_bit_exact_vs_oracle(hip, oracle, ws, B, L, D, R
         assert torch.equal(wt[mask], before[mask])           # untouched rows keep their bits
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_embedding_fused_random_shapes_bit_exact(hip, oracle, ws, seed):
+    """Random (batch, bag, width, rows): the small-batch single launch and the tiled multi-launch form, vector and scalar
+    row paths, SUM and AVG, 1..4 radix passes -- always the oracle's bits; and the gather on the same draws."""
+    rng = np.random.default_rng(seed)
+    for case in range(10):
+        B = int(rng.choice([1, 7, 33, 500, 1024, 2048, 2049, 3000, 5000, 9000]))
+        L = int(rng.choice([1, 1, 2, 3]))
+        D = int(rng.choice([4, 8, 13, 16, 20, 32, 64, 128]))
+        R = int(rng.choice([1, 2, 17, 300, 513, 5000, 70000, 300000]))
+        if R * D > 2e7:
+            R = int(2e7 // D)
+        idx = rng.integers(0, R, (B, L))
+        if rng.integers(0, 3) == 0:
+            idx[:] = idx[0, 0]                                    # one row takes everything
+        g = rng.uniform(-1, 1, (B, D)).astype(np.float32)
+        w = rng.uniform(-1, 1, (R, D)).astype(np.float32)
+        aggr = capi.AGGR_MODE_AVG if (L > 1 and rng.integers(0, 2)) else capi.AGGR_MODE_SUM
+        what = f"seed {seed} case {case}: B={B} L={L} D={D} R={R} aggr={aggr}"
+        assert bits_equal(gpu_fused(hip, idx, g, w, 0.03, aggr), oracle.embedding_bwd_sgd_fused(idx, g, w, 0.03, aggr)), what
+        assert bits_equal(gpu_emb_fwd(hip, idx, w, aggr), oracle.embedding_fwd(idx, w, aggr)), what
+
+
 @pytest.mark.parametrize("B", [4096, 2048, 300])
 def test_embedding_fused_multi_table_strided_grad(hip, oracle, ws, B):
     """Several tables in one call, gradients read as column slices of one [B][ld] buffer
