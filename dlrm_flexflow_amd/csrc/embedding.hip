@@ -336,6 +336,8 @@ struct RedArgs {
   int       D;
   int       avg;
   float     lr;
+  uint2*    meta1;          // level-1 slots [nt][2*nchunks1]: cleared here (grid-stride) for the folds that follow
+  int       nchunks1;
 };
 
 template <int VEC>
@@ -488,6 +490,10 @@ template <int VEC>
 __global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedArgs a) {
   __shared__ RedShared sh;
   const int tix = blockIdx.y;
+  if (a.nchunks1 > 1) {      // the level-1 slots of this table start empty (saves the memset launch in front of the folds)
+    uint2* m1 = a.meta1 + (int64_t)tix * 2 * a.nchunks1;
+    for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < 2 * a.nchunks1; i += gridDim.x * kRedThreads) m1[i] = make_uint2(kMetaNone, 0);
+  }
   reduce_tile_body<VEC>(a.t[tix], a.keys[a.parity[tix]] + (int64_t)tix * a.N, a.pos[a.parity[tix]] + (int64_t)tix * a.N,
                         a.partial + (int64_t)tix * 2 * a.nchunks * a.D, a.meta + (int64_t)tix * 2 * a.nchunks, a.N, a.nchunks, a.tile,
                         (int)blockIdx.x, a.L, a.D, a.avg != 0, a.lr, sh);
@@ -938,6 +944,7 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
   ra.N = N; ra.nchunks = lay.nchunks; ra.L = L; ra.D = D;
   ra.avg = aggr == FFH_AGGR_MODE_AVG ? 1 : 0;
   ra.lr = lr;
+  ra.meta1 = (uint2*)(ws + lay.meta1); ra.nchunks1 = lay.nchunks1;
   dim3 rgrid((unsigned)((N + ra.tile - 1) / ra.tile), (unsigned)nt);
   const int lpr = nvec < 64 ? nvec : 64;
   if (v4) hipLaunchKernelGGL((emb_sgd_reduce_kernel<4>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
@@ -957,7 +964,6 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
   float* p1 = (float*)(ws + lay.partial1);
   uint2* m1 = (uint2*)(ws + lay.meta1);
   if (lay.nchunks1 > 1) {
-    FFH_HIP_TRY(c, hipMemsetAsync(m1, 0, (size_t)nt * 2 * lay.nchunks1 * sizeof(uint2), as_stream(s)));
     launch_fold(ra.partial, ra.meta, lay.nchunks, p1, m1, lay.nchunks1, FFH_EMB_CHUNK1 / FFH_EMB_CHUNK);
     launch_fold(p1, m1, lay.nchunks1, p1, m1, 1, 0);
   } else {
