@@ -53,6 +53,10 @@ def workload(name: str, per_gpu_batch: int | None, world: int):
         b = per_gpu_batch or 4096
         return dict(name="giant-table-column-wise", rows="200000000", D=256, bot="13-512-256", top="512-512-256-1", B=b * world,
                     extra=["--column-shard-rows", "100000000"])
+    if name == "mlperf":       # BASELINE configs[3]: dot interaction (all 27 x 27 pairwise products; the lower-triangle pick of
+        b = per_gpu_batch or 8192   # MLPerf has no reference op), emb_dim 128, 65536 samples over 8 GPUs
+        return dict(name="mlperf-dlrm-dot", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="857-1024-1024-512-256-1", B=b * world,
+                    extra=["--arch-interaction-op", "dot"])
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -161,7 +165,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="kaggle")
+    ap.add_argument("--workload", default="kaggle", help="kaggle (default, BASELINE configs[1]) | tiny | terabyte | mlperf | giant")
     ap.add_argument("--per-gpu-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="(default) kept for older command lines")
@@ -266,7 +270,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{w['name']}: {T} tables (rows {w['rows']}), emb_dim {D}, bag 1, bot {w['bot']}, top {w['top']}, "
-                               f"cat interaction, SGD lr 0.01, MSE loss",
+                               f"{'dot' if 'dot' in w.get('extra', []) else 'cat'} interaction, SGD lr 0.01, MSE loss",
                    "global_batch": w["B"], "per_gpu_batch": w["B"] // world,
                    "parallelism": ("single GPU, hipGraph-replayed step" if uses_graph else "single GPU, eager launches on 3 HIP streams") if world == 1 else
                                   f"tables table-wise over {world} ranks (RCCL all-to-all fwd+bwd), MLPs data-parallel (1 all-reduce); {collectives}",
