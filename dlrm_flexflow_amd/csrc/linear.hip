@@ -799,9 +799,66 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(float* __restrict__ d
   }
 }
 
+// Batched GEMMs whose matrices are a fraction of a tile (the pairwise-dot interaction: 27 x 128 times 128 x 27 per
+// sample, and its two backward products with k = 27): one WAVE per (batch item, 32x32 output tile), operands straight
+// from global memory into the MFMA registers -- a tile is read once by one wave, so LDS staging would only add a
+// round trip, and a 64x64 workgroup tile would be 80 % padding.  Lane (row r, half h) of v_mfma_f32_32x32x2_f32
+// loads A(m0 + r, k + h) and B(n0 + r, k + h); eight k-steps of loads are issued before their MFMAs.
+__global__ __launch_bounds__(256) void bmm_small_kernel(const GemmArgs g, const int tiles_m, const int tiles_n, const int64_t ntiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
+  const int per_batch = tiles_m * tiles_n;
+  const int64_t bz = tile / per_batch;
+  const int t2 = (int)(tile - bz * per_batch);
+  const int m0 = (t2 / tiles_n) * 32, n0 = (t2 % tiles_n) * 32;
+  const float* A = g.A + bz * g.bsA + (int64_t)(m0 + lr) * g.sAm;
+  const float* B = g.B + bz * g.bsB + (int64_t)(n0 + lr) * g.sBn;
+  const bool a_ok = m0 + lr < g.M, b_ok = n0 + lr < g.N;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+  for (int k0 = 0; k0 < g.K; k0 += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int k = k0 + 2 * u + lh;
+      a[u] = (a_ok && k < g.K) ? A[(int64_t)k * g.sAk] : 0.0f;
+      b[u] = (b_ok && k < g.K) ? B[(int64_t)k * g.sBk] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+  const int n = n0 + lr;
+  if (n < g.N) {
+    float* C = g.C + bz * g.bsC;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= g.M) continue;
+      float* cp = C + (int64_t)m * g.ldc + n;
+      if (g.epi == EPI_STORE) *cp = acc[r];
+      else *cp = *cp + acc[r];
+    }
+  }
+}
+
 template <bool AKC, bool BKC, bool FUSE_DY = false>
 int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char* name) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || batch <= 0) return FFH_OK;
+  if (batch > 1 && !FUSE_DY && g.epi != EPI_ATOMIC && !g.bias && !g.mask && g.act == FFH_AC_MODE_NONE &&
+      (g.M <= 48 || g.N <= 48) && g.K <= 1024 && (int64_t)g.M * g.N <= 64 * 256) {
+    // many matrices far smaller than a workgroup tile: one wave per 32x32 output tile, no LDS
+    const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
+    const int64_t ntiles = (int64_t)tm * tn * batch;
+    if ((ntiles + 3) / 4 <= 0x7fffffffLL) {
+      hipLaunchKernelGGL(bmm_small_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, as_stream(s), g, tm, tn, ntiles);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+      return FFH_OK;
+    }
+  }
   // tile choice: 128x128 when that alone fills the chip twice; 64x64 when it yields >= 2 workgroups
   // per CU; else one 32x32 tile per workgroup with the four waves splitting K
   const int64_t tiles128 = (int64_t)((g.M + 127) / 128) * ((g.N + 127) / 128) * batch;
@@ -1216,7 +1273,7 @@ int ffh_bmm_bwd(ffh_ctx* c, const float* og, const float* a, float* ag, const fl
     g.B = b; g.sBn = m; g.sBk = 1; g.bsB = sb;
     g.C = ag; g.ldc = k; g.bsC = sa;
     g.M = n; g.N = k; g.K = m;
-    g.epi = EPI_ADD;
+    g.epi = EPI_ADD; g.act = FFH_AC_MODE_NONE;
     int rc = launch_gemm<true, true>(c, g, batch, s, "bmm_bwd a_grad gemm");
     if (rc) return rc;
   }
@@ -1226,7 +1283,7 @@ int ffh_bmm_bwd(ffh_ctx* c, const float* og, const float* a, float* ag, const fl
     g.B = og; g.sBn = 1; g.sBk = m; g.bsB = so;
     g.C = bg; g.ldc = m; g.bsC = sb;
     g.M = k; g.N = m; g.K = n;
-    g.epi = EPI_ADD;
+    g.epi = EPI_ADD; g.act = FFH_AC_MODE_NONE;
     int rc = launch_gemm<false, false>(c, g, batch, s, "bmm_bwd b_grad gemm");
     if (rc) return rc;
   }

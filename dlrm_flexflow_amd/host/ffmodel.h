@@ -332,6 +332,7 @@ class Reshape : public Op {     // also serves Flat: a copy forward, an accumula
   void create_output_and_partition(FFModel&) override {}
   void forward(const FFModel&) override;
   void backward(const FFModel&) override;
+  bool is_view;                 // the output IS the input's buffer (contiguous input read by nothing else): no copy either way
 };
 
 // ---------------------------------------------------------------------------------------------

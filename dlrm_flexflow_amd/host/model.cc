@@ -818,8 +818,10 @@ Reshape::Reshape(FFModel& model, OperatorType type, const Tensor& input, const s
   if (shape[0] != input.adim[input.numDim - 1]) die("%s: the batch dimension must be preserved (it is sharded over ranks)", this->name);
   outputs[0].numDim = (int)shape.size();
   for (size_t i = 0; i < shape.size(); i++) outputs[0].adim[shape.size() - 1 - i] = shape[i];
+  is_view = false;
 }
 void Reshape::forward(const FFModel& ff) {
+  if (is_view) return;
   const Tensor &x = inputs[0], &y = outputs[0];
   if (!contiguous(y.impl, y)) die("%s: output must be contiguous", name);
   const int64_t rows = x.impl->rows_local, cols = x.adim[0];
@@ -833,6 +835,7 @@ void Reshape::forward(const FFModel& ff) {
   }
 }
 void Reshape::backward(const FFModel& ff) {
+  if (is_view) return;          // the gradient of the view is the gradient of the tensor
   const Tensor &x = inputs[0], &y = outputs[0];
   if (!x.impl->grad && x.impl->pieces.empty()) return;
   const int64_t rows = x.impl->rows_local, cols = x.adim[0];
@@ -1149,9 +1152,24 @@ void FFModel::allocate() {
   size_t act_bytes = 0;
   act_grad_bytes = 0;
   std::vector<Op*> need;   // ops whose output gets its own storage
+  // Reshape / Flat of a tensor that owns contiguous storage and is read by nothing else: the output is a VIEW of it
+  // (the reference copies, src/ops/reshape.cu:203-210 / flat.cu:117-124: same values, two passes over the tensor less)
+  std::vector<Reshape*> views;
+  for (Op* op : layers) {
+    Reshape* r = dynamic_cast<Reshape*>(op);
+    if (!r) continue;
+    r->is_view = false;
+    const Tensor& x = r->inputs[0];
+    if (!x.owner_op || consumers[x.impl] != 1 || alias_of.count(x.impl) || alias_of.count(r->outputs[0].impl)) continue;
+    if (exchange && x.owner_op->op_type == OP_EMBEDDING) continue;
+    if (x.get_volume() != r->outputs[0].get_volume()) continue;
+    r->is_view = true;
+    views.push_back(r);
+  }
   for (Op* op : layers) {
     TensorImpl* im = op->outputs[0].impl;
     if (alias_of.count(im)) continue;
+    if (Reshape* r = dynamic_cast<Reshape*>(op)) if (r->is_view) continue;
     if (exchange && op->op_type == OP_EMBEDDING) continue;   // lives in xrecv / gsend
     const Tensor& o = op->outputs[0];
     const size_t b = align_up((size_t)(o.rows() / world_size) * o.adim[0] * 4);
@@ -1174,6 +1192,16 @@ void FFModel::allocate() {
     im->rows_local = o.rows() / world_size;
     im->alias = true;        // slab-owned: not freed individually
     off_a += align_up(raw);
+  }
+  for (Reshape* r : views) {     // layer order: a view of a view resolves to the first owner
+    const TensorImpl* xi = r->inputs[0].impl;
+    const Tensor& o = r->outputs[0];
+    TensorImpl* im = o.impl;
+    im->ptr = xi->ptr; im->grad = xi->grad;
+    im->ld = im->grad_ld = o.adim[0];
+    im->rows_local = o.rows() / world_size;
+    im->bytes = xi->bytes;
+    im->alias = im->grad_alias = true;
   }
   for (auto& kv : alias_of) {
     TensorImpl* im = kv.first;
