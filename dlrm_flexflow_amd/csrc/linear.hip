@@ -59,12 +59,24 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+// 16-byte global access at 4-byte alignment: gfx950 (unaligned-access mode, the amdhsa default) serves a dwordx4 load /
+// store at any dword address, so leading dimensions that are not multiples of 4 floats keep the wide accesses
+typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float4 ld4u(const float* p) {
+  const float4u v = *reinterpret_cast<const float4u*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4u(float* p, const float4 v) {
+  float4u u; u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+  *reinterpret_cast<float4u*>(p) = u;
+}
+
 // Load 4 consecutive elements along the contiguous dimension (index c0..c0+3 < climit) of
 // row `r` (valid if r < rlimit).  p points at element (r, c0).
 __device__ __forceinline__ float4 load4_guard(const float* p, bool row_ok, int c0, int climit, bool vec_ok) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (!row_ok) return v;
-  if (vec_ok && c0 + 3 < climit) return *reinterpret_cast<const float4*>(p);
+  if (vec_ok && c0 + 3 < climit) return ld4u(p);
   if (c0 + 0 < climit) v.x = p[0];
   if (c0 + 1 < climit) v.y = p[1];
   if (c0 + 2 < climit) v.z = p[2];
@@ -120,12 +132,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   if (kb >= ke) return;
   const int nk = (ke - kb + BK - 1) / BK;
 
-  const bool a_vec = (AKC ? (g.sAm % 4 == 0) : (g.sAk % 4 == 0)) && (((uintptr_t)A & 15) == 0);
-  const bool b_vec = (BKC ? (g.sBn % 4 == 0) : (g.sBk % 4 == 0)) && (((uintptr_t)B & 15) == 0);
+  // 16-byte global accesses need only 4-byte alignment on gfx950 (ld4u / st4u): rows of 857 or 13 floats take the same
+  // unguarded dwordx4 loads as aligned ones
+  constexpr bool a_vec = true, b_vec = true;
 
   float4 ra2[2][NA], rb2[2][NB];     // two tiles in flight in registers (set = stage parity)
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool y_vec = FUSE_DY && (g.ld_act_y % 4 == 0) && (((uintptr_t)g.act_y & 15) == 0);
+  constexpr bool y_vec = FUSE_DY;
 
   // interior tiles (the common case) take unguarded 16-B loads: the branch is workgroup-uniform
   const bool a_in = a_vec && (m0 + BM <= g.M);
@@ -145,13 +158,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
       if (AKC) {   // rows of A are k-contiguous: BK/4 float4 per row
         const int k4 = tid % KQ, row = tid / KQ + i * RPP;
         const int m = m0 + row, k = k0 + k4 * 4;
-        if (FAST) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)m * g.sAm + k);
+        if (FAST) ra[i] = ld4u(A + (int64_t)m * g.sAm + k);
         else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, a_vec);
         if (FUSE_DY && (g.fuse & 1)) {
           // dx form: relu' applied to dy as it is loaded (the in-place result belongs to the dw GEMM,
           // which may run concurrently on another stream)
           float4 yv;
-          if (FAST) yv = *reinterpret_cast<const float4*>(g.act_y + (int64_t)m * g.ld_act_y + k);
+          if (FAST) yv = ld4u(g.act_y + (int64_t)m * g.ld_act_y + k);
           else yv = load4_guard(g.act_y + (int64_t)m * g.ld_act_y + k, m < g.M, k, ke, y_vec);
           ra[i].x = yv.x > 0.0f ? ra[i].x : 0.0f; ra[i].y = yv.y > 0.0f ? ra[i].y : 0.0f;
           ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
@@ -160,20 +173,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         constexpr int PER = BM / 4;
         const int m4 = tid % PER, kr = tid / PER + i * (256 / PER);
         const int m = m0 + m4 * 4, k = k0 + kr;
-        if (FAST) ra[i] = *reinterpret_cast<const float4*>(A + (int64_t)k * g.sAk + m);
+        if (FAST) ra[i] = ld4u(A + (int64_t)k * g.sAk + m);
         else ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, a_vec);
         if (FUSE_DY && !AKC) {
           if (g.fuse & 1) {
             // reluBackward [ref: src/runtime/cuda_helper.cu:71-78] on the fly; idempotent, so the
             // in-place write-back by column 0 may race with the other columns' reads harmlessly
             float4 yv;
-            if (FAST) yv = *reinterpret_cast<const float4*>(g.act_y + (int64_t)k * g.ld_act_y + m);
+            if (FAST) yv = ld4u(g.act_y + (int64_t)k * g.ld_act_y + m);
             else yv = load4_guard(g.act_y + (int64_t)k * g.ld_act_y + m, k < ke, m, g.M, y_vec);
             ra[i].x = yv.x > 0.0f ? ra[i].x : 0.0f; ra[i].y = yv.y > 0.0f ? ra[i].y : 0.0f;
             ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
             if (bx == 0 && (FAST || k < ke)) {
               float* wp = const_cast<float*>(A) + (int64_t)k * g.sAk + m;
-              if (FAST || (a_vec && m + 3 < g.M)) *reinterpret_cast<float4*>(wp) = ra[i];
+              if (FAST || (a_vec && m + 3 < g.M)) st4u(wp, ra[i]);
               else {
                 if (m + 0 < g.M) wp[0] = ra[i].x;
                 if (m + 1 < g.M) wp[1] = ra[i].y;
@@ -191,13 +204,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
       if (BKC) {
         const int k4 = tid % KQ, row = tid / KQ + i * RPP;
         const int n = n0 + row, k = k0 + k4 * 4;
-        if (FAST) rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)n * g.sBn + k);
+        if (FAST) rb[i] = ld4u(B + (int64_t)n * g.sBn + k);
         else rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, b_vec);
       } else {
         constexpr int PER = BN / 4;
         const int n4 = tid % PER, kr = tid / PER + i * (256 / PER);
         const int n = n0 + n4 * 4, k = k0 + kr;
-        if (FAST) rb[i] = *reinterpret_cast<const float4*>(B + (int64_t)k * g.sBk + n);
+        if (FAST) rb[i] = ld4u(B + (int64_t)k * g.sBk + n);
         else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, b_vec);
       }
     }
