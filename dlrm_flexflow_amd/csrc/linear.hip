@@ -1128,7 +1128,8 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     a.mask_by_x = mask_by_x ? 1 : 0;
     // dW / db are accumulated with one atomic per weight per workgroup: adds to ONE address serialise (~0.1 us each), so
     // the number of workgroups is kept near 32 -- and every wave then keeps 16 / NC rows in flight to cover the latency
-    int64_t rpb = (batch + 31) / 32;
+    const int64_t nblk = batch >= 8192 ? 64 : 32;                       // large batches: HBM traffic outweighs the longer atomic chains
+    int64_t rpb = (batch + nblk - 1) / nblk;
     rpb = (rpb + 15) / 16 * 16;
     if (rpb > 1024) rpb = 1024;
     a.rows_per_block = (int)rpb;
