@@ -21,12 +21,15 @@ struct ConcatArgs {
 };
 
 // grid.y = part; each workgroup streams rows of its part.  BWD adds (accumulates) into the part.
+// VEC == 4: groups of four floats per row moved as one 16-byte access at 4-byte alignment (ld4u / st4u), the last group
+// of a row whose width is not a multiple of four element by element -- so a 729-wide part of an 857-wide row (the dot
+// interaction) is still moved 16 bytes at a time.
 template <bool BWD, int VEC>
 __global__ __launch_bounds__(256) void concat_kernel(const ConcatArgs a) {
   const int p = blockIdx.y;
   float* part = a.part[p];
   const int64_t w = a.blk[p], ld = a.ld[p], off = a.off[p];
-  const int64_t wv = w / VEC;
+  const int64_t wv = (w + VEC - 1) / VEC;
   const int64_t total = a.num_blocks * wv;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -34,18 +37,21 @@ __global__ __launch_bounds__(256) void concat_kernel(const ConcatArgs a) {
     const int64_t e = (i - b * wv) * VEC;
     float* bp = a.big + b * a.out_blk + off + e;
     float* pp = part + b * ld + e;
-    if (VEC == 4) {
+    if (VEC == 4 && e + 4 <= w) {
       if (BWD) {
-        const float4 g = *reinterpret_cast<const float4*>(bp);
-        if (a.overwrite) { *reinterpret_cast<float4*>(pp) = g; continue; }
-        float4 x = *reinterpret_cast<float4*>(pp);
+        const float4 g = ld4u(bp);
+        if (a.overwrite) { st4u(pp, g); continue; }
+        float4 x = ld4u(pp);
         x.x += g.x; x.y += g.y; x.z += g.z; x.w += g.w;
-        *reinterpret_cast<float4*>(pp) = x;
+        st4u(pp, x);
       } else {
-        *reinterpret_cast<float4*>(bp) = *reinterpret_cast<const float4*>(pp);
+        st4u(bp, ld4u(pp));
       }
     } else {
-      if (BWD) *pp = a.overwrite ? *bp : *pp + *bp; else *bp = *pp;
+      const int n = (int)((w - e) < VEC ? (w - e) : VEC);
+      for (int q = 0; q < n; q++) {
+        if (BWD) pp[q] = a.overwrite ? bp[q] : pp[q] + bp[q]; else bp[q] = pp[q];
+      }
     }
   }
 }
@@ -60,7 +66,7 @@ int concat_impl(ffh_ctx* c, float* big, int64_t out_blk, float* const* parts, co
   int64_t off = 0;
   ConcatArgs a;
   a.big = big; a.out_blk = out_blk; a.num_blocks = nblk; a.n = 0; a.overwrite = overwrite;
-  bool vec = al16(big) && (out_blk % 4 == 0);
+  bool vec = true;   // 16-byte accesses at 4-byte alignment: no alignment or width condition left
   int64_t maxw = 0;
   auto flush = [&]() -> int {
     if (a.n == 0) return FFH_OK;
@@ -69,7 +75,7 @@ int concat_impl(ffh_ctx* c, float* big, int64_t out_blk, float* const* parts, co
     else hipLaunchKernelGGL((concat_kernel<BWD, 1>), grid, dim3(256), 0, as_stream(s), a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ffh_fail_hip(c, e, "concat_kernel");
-    a.n = 0; maxw = 0; vec = al16(big) && (out_blk % 4 == 0);
+    a.n = 0; maxw = 0; vec = true;
     return FFH_OK;
   };
   for (int i = 0; i < n; i++) {
@@ -78,7 +84,7 @@ int concat_impl(ffh_ctx* c, float* big, int64_t out_blk, float* const* parts, co
     float* p = parts[i];
     const bool aliased = (p == big + off) && (ld == out_blk);   // producer already wrote in place
     if (p && !aliased && in_blk[i] > 0 && nblk > 0) {
-      const bool v = al16(big) && (out_blk % 4 == 0) && al16(p) && (ld % 4 == 0) && (in_blk[i] % 4 == 0) && (off % 4 == 0);
+      const bool v = in_blk[i] >= 4;   // narrower parts: element by element
       if (a.n && v != vec) { int rc = flush(); if (rc) return rc; }
       vec = v;
       a.part[a.n] = p; a.blk[a.n] = in_blk[i]; a.ld[a.n] = ld; a.off[a.n] = off;

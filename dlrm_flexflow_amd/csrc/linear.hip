@@ -59,18 +59,6 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-// 16-byte global access at 4-byte alignment: gfx950 (unaligned-access mode, the amdhsa default) serves a dwordx4 load /
-// store at any dword address, so leading dimensions that are not multiples of 4 floats keep the wide accesses
-typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ float4 ld4u(const float* p) {
-  const float4u v = *reinterpret_cast<const float4u*>(p);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void st4u(float* p, const float4 v) {
-  float4u u; u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
-  *reinterpret_cast<float4u*>(p) = u;
-}
-
 // Load 4 consecutive elements along the contiguous dimension (index c0..c0+3 < climit) of
 // row `r` (valid if r < rlimit).  p points at element (r, c0).
 __device__ __forceinline__ float4 load4_guard(const float* p, bool row_ok, int c0, int climit, bool vec_ok) {
