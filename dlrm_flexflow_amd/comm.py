@@ -140,12 +140,42 @@ class RcclComm:
             raise RuntimeError("ncclCommInitRank failed on some rank: " + (L.flexflow_rccl_last_error() or b"").decode())
         self.struct.barrier = boot._bar
         self._L = L
+        # known-answer check of both collectives on the new communicator (uneven all-to-all with a zero-length block,
+        # all-reduce); every rank must pass or all fall back to the torch callbacks together
+        self._base = {"alltoall": 0, "allreduce": 0}
+        ok = self._self_test()
+        self._base = self.calls                    # `calls` counts the model's collectives only
+        flag.fill_(1 if ok else 0)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=boot.group)
+        if int(flag.item()) == 0:
+            self.close()
+            raise RuntimeError("direct RCCL communicator failed its self-test on some rank")
+
+    def _self_test(self) -> bool:
+        W, r = self.world, self.rank
+        # rank r sends (p + r) % 3 floats to peer p; element value = 1000 r + 10 p + j
+        sc = [(p + r) % 3 for p in range(W)]
+        rc = [(r + p) % 3 for p in range(W)]
+        send = torch.tensor([1000.0 * r + 10.0 * p + j for p in range(W) for j in range(sc[p])] or [0.0], dtype=torch.float32, device="cuda")
+        recv = torch.full((max(sum(rc), 1),), -1.0, dtype=torch.float32, device="cuda")
+        ar = torch.full((5,), float(r + 1), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        scA, rcA = (C.c_int64 * W)(*sc), (C.c_int64 * W)(*rc)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if self.struct.alltoall_f32(self.struct.user, send.data_ptr(), scA, recv.data_ptr(), rcA, stream) != 0:
+            return False
+        if self.struct.allreduce_sum_f32(self.struct.user, ar.data_ptr(), 5, stream) != 0:
+            return False
+        torch.cuda.synchronize()
+        exp = [1000.0 * p + 10.0 * r + j for p in range(W) for j in range(rc[p])]
+        got = recv[:len(exp)].cpu().tolist()
+        return got == exp and ar.cpu().tolist() == [W * (W + 1) / 2.0] * 5
 
     @property
     def calls(self):
         a, r = C.c_int64(0), C.c_int64(0)
         self._L.flexflow_rccl_comm_calls(C.byref(self.struct), C.byref(a), C.byref(r))
-        return {"alltoall": a.value, "allreduce": r.value}
+        return {"alltoall": a.value - self._base["alltoall"], "allreduce": r.value - self._base["allreduce"]}
 
     def close(self):
         if self._L is not None:
