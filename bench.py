@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- DLRM training throughput (samples/s) of the MI355X-native path, one JSON line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kaggle|terabyte|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kaggle|tiny|terabyte|mlperf|giant] [--probe]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
               --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one training iteration of the reference driver's loop -- forward, zero_gradients,
 backward, update [ref: examples/cpp/DLRM/dlrm.cc:166-182] -- on one resident synthetic batch (the
-reference reuses the warm-up batch for random input, :167-173), replayed from a captured hipGraph
-on one GPU (the reference's begin_trace/end_trace).  Workload at N = 1: BASELINE.json configs[1],
+reference reuses the warm-up batch for random input, :167-173).  On one GPU a hipGraph replay of the
+step (the reference's begin_trace/end_trace) is timed against eager launches and the faster one is
+used for the measured run (eager on ROCm 7.2).  Workload at N = 1: BASELINE.json configs[1],
 the Criteo-Kaggle shape (26 tables with run_criteo_kaggle.sh's row counts, emb_dim 16, batch 2048,
 bot 13-512-256-64-16, top 432-512-256-1).  N > 1 is weak scaling: 2048 samples per GPU, tables
 sharded table-wise (table t on rank t % N), all-to-all each way + one all-reduce of MLP gradients
-over RCCL (torch.distributed "nccl").  fp32 throughout (the reference's arithmetic type).
+over RCCL, called from the C++ host layer on a communicator bootstrapped over torch.distributed
+("nccl"); --torch-collectives serves them through torch.distributed instead.  fp32 throughout (the
+reference's arithmetic type).
 
 Besides the contract fields the line carries
   roofline      the embedding gather kernel (BASELINE's second metric): algorithmic bytes
                 (B*(L*(8+4D)+4D) per table = 3,536 B/sample here) / HIP-event time
-  kernels       the same for the fused embedding backward+SGD, plus a Terabyte-shaped probe of
-                the gather (D = 128, B = 32768, 40M-row tables) where the kernel is HBM-bound
+  kernels       the same for the fused embedding backward+SGD; the largest Linear layer alone (MFMA
+                roofline, forward and backward); the whole step; with --probe the gather at the
+                Terabyte shape (D = 128, B = 32768, 40M-row tables) where the kernel is HBM-bound
   cpu_baseline  the same application on the host cores with the CPU oracle as kernel library
                 (kind "port": the reference has no CPU path for this step), bounded sample
 """
