@@ -981,7 +981,7 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
       wv[c][o] = (ch < nch && o < a.out && a.do_dx) ? reinterpret_cast<const float4*>(a.w + (int64_t)o * a.in)[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
       dwacc[c][o] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  constexpr int U = 16 / NC;        // rows in flight per wave: U x NC 16-byte loads per lane
+  constexpr int U = NO > 4 ? 4 : 16 / NC;   // rows in flight per wave: U x NC 16-byte loads per lane (fewer when NO slots fill the registers)
   for (int r0 = wave; r0 < rows; r0 += 4 * U) {
     float4 xv[U][NC];
 #pragma unroll
@@ -1102,7 +1102,10 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   FFH_REQUIRE(c, do_dw || do_dx, "linear_bwd_ex: ONLY_DX and ONLY_DW are exclusive");
   static const int no_skinny = getenv("FFH_NO_SKINNY") ? atoi(getenv("FFH_NO_SKINNY")) : 0;   // A/B switch (tools/ab.sh)
   const bool skinny_vec = !no_skinny && (in % 4 == 0) && glds_aligned(x, ldx) && (((uintptr_t)w & 15) == 0) && (!dx || glds_aligned(dx, lddx));
-  if (out <= kSkinnyMaxOut && in <= kSkinnyMaxIn && skinny_vec) {
+  // up to 4 outputs with in <= 1024, or up to 16 outputs with in <= 256 (the 64 -> 16 layer in front of the interaction):
+  // whole backward in one launch
+  const bool skinny_shape = (out <= kSkinnyMaxOut && in <= kSkinnyMaxIn) || (out <= 16 && in <= 256);
+  if (skinny_shape && skinny_vec) {
     // one launch for the whole layer (the split ONLY_* forms keep their meaning; a forked dw stream is not needed)
     const bool only_dx = !do_dw, only_dw = !do_dx;
     SkinnyBwdArgs a{};
@@ -1128,7 +1131,8 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     const int nc = in <= 256 ? 1 : (in <= 512 ? 2 : 4);
 #define FFH_SKINNY(NCV, NOV) hipLaunchKernelGGL((linear_skinny_bwd_kernel<NCV, NOV>), dim3(grid), dim3(256), lds, as_stream(s), a)
     if (out == 1) { if (nc == 1) FFH_SKINNY(1, 1); else if (nc == 2) FFH_SKINNY(2, 1); else FFH_SKINNY(4, 1); }
-    else { if (nc == 1) FFH_SKINNY(1, 4); else if (nc == 2) FFH_SKINNY(2, 4); else FFH_SKINNY(4, 4); }
+    else if (out <= 4) { if (nc == 1) FFH_SKINNY(1, 4); else if (nc == 2) FFH_SKINNY(2, 4); else FFH_SKINNY(4, 4); }
+    else FFH_SKINNY(1, 16);
 #undef FFH_SKINNY
     FFH_LAUNCH_CHECK(c, "linear_skinny_bwd_kernel");
     return FFH_OK;

@@ -401,13 +401,13 @@ def test_linear_strided_operands_and_accumulate(hip, oracle):
     np.testing.assert_allclose(host(dwt), dw_e, rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("OUT", [80, 1, 3])
+@pytest.mark.parametrize("OUT", [80, 1, 3, 12])
 @pytest.mark.parametrize("act", [capi.AC_MODE_RELU, capi.AC_MODE_SIGMOID, capi.AC_MODE_NONE])
 def test_linear_bwd_ex_forms_equal_reference_form(hip, oracle, act, OUT):
     """ffh_linear_bwd_ex: overwrite-mode dx, the forked weight-gradient stream, and the split
     ONLY_DX / ONLY_DW calls all give what one ffh_linear_bwd call gives (and what the oracle gives)."""
     rng = np.random.default_rng(act)
-    B, IN = 777, 96            # OUT = 1, 3: the one-launch skinny-output kernels (linear_skinny_*), OUT = 80: the GEMMs
+    B, IN = 777, 96            # OUT = 1, 3, 12: the one-launch skinny-output kernels (linear_skinny_*), OUT = 80: the GEMMs
     x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
     w = (rng.uniform(-1, 1, (OUT, IN)) / 8).astype(np.float32)
     b = rng.uniform(-1, 1, OUT).astype(np.float32)

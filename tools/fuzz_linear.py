@@ -25,7 +25,7 @@ for case in range(ncases):
     elif kind == 1:    # anything goes (unaligned -> register-staged kernels)
         B = int(rng.integers(1, 600)); IN = int(rng.integers(1, 300)); OUT = int(rng.integers(5, 300))
     elif kind == 2:    # skinny outputs
-        B = int(rng.integers(1, 5000)); IN = 4 * int(rng.integers(1, 256)); OUT = int(rng.integers(1, 5))
+        B = int(rng.integers(1, 5000)); OUT = int(rng.integers(1, 17)); IN = 4 * int(rng.integers(1, 256 if OUT <= 4 else 65))
     else:              # wide and deep
         B = int(rng.integers(512, 4097)); IN = 4 * int(rng.integers(64, 300)); OUT = 4 * int(rng.integers(64, 300))
     act = int(rng.choice([capi.AC_MODE_NONE, capi.AC_MODE_RELU, capi.AC_MODE_SIGMOID]))
