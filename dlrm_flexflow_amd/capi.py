@@ -128,6 +128,14 @@ def header_symbols(header_path: str = HEADER_PATH) -> list[str]:
     return re.findall(r"X\((\w+)\)", m.group(1))
 
 
+def header_abi_version(header_path: str = HEADER_PATH) -> int:
+    """FFH_ABI_VERSION of include/ff_hip.h."""
+    m = re.search(r"#define\s+FFH_ABI_VERSION\s+(\d+)", open(header_path).read())
+    if not m:
+        raise RuntimeError("FFH_ABI_VERSION not found in " + header_path)
+    return int(m.group(1))
+
+
 class FFHError(RuntimeError):
     pass
 
@@ -157,8 +165,8 @@ class FFHLib:
             fn = getattr(self.lib, name)          # AttributeError => symbol missing => loud
             fn.restype = res
             fn.argtypes = args
-        if self.lib.ffh_abi_version() != 1:
-            raise FFHError("ABI version mismatch")
+        if self.lib.ffh_abi_version() != header_abi_version():
+            raise FFHError(f"{path}: ABI version {self.lib.ffh_abi_version()}, include/ff_hip.h says {header_abi_version()} (rebuild)")
         self.backend = self.lib.ffh_backend_name().decode()
         ctx = P()
         rc = self.lib.ffh_ctx_create(C.byref(ctx), device)

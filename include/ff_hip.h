@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 1
+#define FFH_ABI_VERSION 2   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used */
 
 /* status codes */
 #define FFH_OK               0

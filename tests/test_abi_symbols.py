@@ -37,7 +37,7 @@ def test_hip_library_exports_every_symbol():
     lib = ctypes.CDLL(path)                      # loads without a GPU; no compute call is made
     lib.ffh_abi_version.restype = ctypes.c_int
     lib.ffh_backend_name.restype = ctypes.c_char_p
-    assert lib.ffh_abi_version() == 1
+    assert lib.ffh_abi_version() == capi.header_abi_version()
     assert lib.ffh_backend_name() == b"hip-gfx950"
     # workspace sizing is host arithmetic: callable without a device
     lib.ffh_embedding_bwd_workspace_bytes.restype = ctypes.c_size_t
