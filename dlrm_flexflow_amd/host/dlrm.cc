@@ -60,9 +60,9 @@ Tensor create_mlp(FFModel* model, const Tensor& input, std::vector<int> ln, int 
   Tensor t = input;
   for (int i = 0; i < (int)(ln.size() - 1); i++) {
     float std_dev = std::sqrt(2.0f / (ln[i + 1] + ln[i]));
-    Initializer* weight_init = new NormInitializer(std::rand(), 0, std_dev);
+    Initializer* weight_init = new NormInitializer(model->next_seed(), 0, std_dev);
     std_dev = std::sqrt(2.0f / ln[i + 1]);
-    Initializer* bias_init = new NormInitializer(std::rand(), 0, std_dev);
+    Initializer* bias_init = new NormInitializer(model->next_seed(), 0, std_dev);
     ActiMode activation = i == sigmoid_layer ? AC_MODE_SIGMOID : AC_MODE_RELU;
     t = model->dense(t, ln[i + 1], activation, true /*bias*/, NULL /*weight_sharing*/, weight_init, bias_init);
   }
@@ -73,7 +73,7 @@ Tensor create_mlp(FFModel* model, const Tensor& input, std::vector<int> ln, int 
 Tensor create_emb(FFModel* model, const Tensor& input, int input_dim, int output_dim, int idx) {
   (void)idx;
   float range = std::sqrt(1.0f / input_dim);
-  Initializer* embed_init = new UniformInitializer(std::rand(), -range, range);
+  Initializer* embed_init = new UniformInitializer(model->next_seed(), -range, range);
   return model->embedding(input, input_dim, output_dim, AGGR_MODE_SUM, NULL /*weight_sharing*/, embed_init);
 }
 
@@ -260,7 +260,6 @@ DLRMApp::DLRMApp(int argc, char** argv, const ffcomm* comm) : ff(nullptr), loade
     print_vector("MLP Bot", dlrm.mlp_bot);
   }
   if (dlrm.embedding_size.size() > MAX_NUM_EMB) { fprintf(stderr, "FATAL: more than %d tables\n", MAX_NUM_EMB); abort(); }
-  std::srand(1 + (unsigned)ffconfig.seed);   // initializer seeds come from std::rand() as in the reference, but seeded
   ff = new FFModel(ffconfig);
 
   for (size_t i = 0; i < dlrm.embedding_size.size(); i++) {

@@ -397,7 +397,11 @@ class FFModel {
   void begin_trace(int trace_id);
   void end_trace(int trace_id);
   void sync();                                   // issue_execution_fence + wait
-  PerfMetrics get_perf_metrics();                // device -> host (synchronises)
+  PerfMetrics get_perf_metrics();
+  // seeds of the initializers: a private counter-hash sequence from config.seed (the reference draws them from the
+  // unseeded global std::rand(), [ref: examples/cpp/DLRM/dlrm.cc:32,34,45] -- any library calling rand() would shift it)
+  int next_seed();
+  uint64_t seed_counter;                // device -> host (synchronises)
   void print_layers(int id);
   std::string get_operator_type_name(OperatorType type) const;
 

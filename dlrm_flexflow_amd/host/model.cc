@@ -375,6 +375,7 @@ FFModel::FFModel(FFConfig& _config)
       emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
       act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1), inputs_dirty(true), fork_recorded(false) {
+  seed_counter = 0;
   dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; need_zero_gsend = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
   rank = config.comm.world_size > 1 ? config.comm.rank : 0;
   world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
@@ -481,7 +482,7 @@ template Parameter FFModel::create_weight<2>(const int[], const Op*, DataType, I
 Tensor FFModel::dense(const Tensor& input, int outDim, ActiMode activation, bool use_bias, const Op* shared_op,
                       Initializer* kernel_initializer, Initializer* bias_initializer, const char* name) {
   // default initialisers [ref: src/ops/linear.cu:19-39]
-  if (kernel_initializer == nullptr) kernel_initializer = new GlorotUniform(std::rand());
+  if (kernel_initializer == nullptr) kernel_initializer = new GlorotUniform(next_seed());
   if (bias_initializer == nullptr) bias_initializer = new ZeroInitializer();
   Linear* li = new Linear(*this, input, outDim, activation, use_bias, shared_op, kernel_initializer, bias_initializer, name);
   li->layer_index = (int)layers.size();
@@ -491,7 +492,7 @@ Tensor FFModel::dense(const Tensor& input, int outDim, ActiMode activation, bool
 
 Tensor FFModel::embedding(const Tensor& input, int num_entries, int outDim, AggrMode aggr, const Op* shared_op,
                           Initializer* kernel_initializer, const char* name) {
-  if (kernel_initializer == nullptr) kernel_initializer = new GlorotUniform(std::rand());   // [ref: src/ops/embedding.cu:19-34]
+  if (kernel_initializer == nullptr) kernel_initializer = new GlorotUniform(next_seed());   // [ref: src/ops/embedding.cu:19-34]
   Embedding* e = new Embedding(*this, input, num_entries, outDim, aggr, shared_op, kernel_initializer, name);
   e->layer_index = (int)layers.size();
   layers.push_back(e);
@@ -941,6 +942,10 @@ int FFModel::tables_of_rank(int r) const {
   int n = 0;
   for (const Embedding* e : embeddings) n += e->owner_rank == r;
   return n;
+}
+
+int FFModel::next_seed() {
+  return (int)(ffh_hash(config.seed * 0x9E3779B97F4A7C15ULL + 0x5EED, seed_counter++) & 0x7fffffffULL);
 }
 
 bool FFModel::fused_embedding_update() const {

@@ -13,22 +13,45 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from dlrm_flexflow_amd import capi  # noqa: E402
-from dlrm_flexflow_amd.comm import RcclComm, TorchComm  # noqa: E402
+from dlrm_flexflow_amd.comm import HostStagedComm, RcclComm, TorchComm  # noqa: E402
 import dlrm_helpers as H  # noqa: E402
 
 
 def main():
     outdir = sys.argv[1]
     direct = len(sys.argv) > 2 and sys.argv[2] == "direct"     # RCCL called from the C++ host layer (host/rccl_comm.cc)
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group("nccl", init_method=f"tcp://{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}",
+    staged = len(sys.argv) > 2 and sys.argv[2] == "staged"     # several ranks on ONE GPU: host-staged test transport over gloo
+    torch.cuda.set_device(0 if staged else int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("gloo" if staged else "nccl", init_method=f"tcp://{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}",
                             rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
-    comm = TorchComm(on_gpu=True)
+    comm = HostStagedComm() if staged else TorchComm(on_gpu=True)
     if direct:
         comm = RcclComm(comm)
-    m, h = H.build_golden_dlrm(capi.HIP_LIB_PATH, comm=comm.struct, overlap=True, force_exchange=True)
-    recs = H.run_steps(m, h, 2)
     out = {}
+    if len(sys.argv) > 3 and sys.argv[3] == "kaggle":
+        # the Criteo-Kaggle shape at 2048 samples per rank through the DLRM application object (driver flags)
+        from dlrm_flexflow_amd import ffmodel
+        world = dist.get_world_size()
+        app = ffmodel.DLRM(H.KAGGLE_ARGS(2048 * world) + ["--device", "0", "--force-exchange"], comm=comm.struct)
+        app.warmup()
+        app.train_steps(3, trace=False)
+        app.model.sync()
+        m = app.model
+        out["pred"] = m.layer_output(m.num_layers - 1).get()
+        for l in range(m.num_layers):
+            if m.layer_num_weights(l) and m.parameter(l, 0).is_local:
+                w = m.parameter(l, 0).get_weights()
+                out[f"p{l}"] = w if w.size <= 1 << 16 else np.array([w.astype(np.float64).sum(), np.abs(w).astype(np.float64).sum(),
+                                                                     float(w[:64].astype(np.float64).sum())])
+        out["alltoall_calls"] = np.array(comm.calls["alltoall"])
+        out["allreduce_calls"] = np.array(comm.calls["allreduce"])
+        np.savez(os.path.join(outdir, f"rank{dist.get_rank()}.npz"), **out)
+        app.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    m, h = H.build_golden_dlrm(capi.HIP_LIB_PATH, comm=comm.struct, overlap=True, force_exchange=True, extra_argv=["--device", "0"])
+    recs = H.run_steps(m, h, 2)
     for step, rec in enumerate(recs):
         for k, v in rec.items():
             out[f"s{step}/{k}"] = v

@@ -185,3 +185,13 @@ def make_criteo_like_hdf5(tmp_path, n=100, rows=(50, 7, 300), dense=13, seed=5, 
 
 HDF5_ARGS = ["-b", "16", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "50-7-300", "--arch-mlp-bot", "13-16-8",
              "--arch-mlp-top", "32-16-1"]
+
+
+KAGGLE_ROWS = "1396-550-1761917-507795-290-21-11948-608-3-58176-5237-1497287-3127-26-12153-1068715-10-4836-2085-4-1312273-17-15-110946-91-72655"
+
+
+def KAGGLE_ARGS(global_batch, backend=None):
+    """Driver flags of BASELINE configs[1] (Criteo-Kaggle shape) at the given global batch."""
+    a = ["-b", str(global_batch), "--arch-sparse-feature-size", "16", "--arch-embedding-size", KAGGLE_ROWS,
+         "--arch-mlp-bot", "13-512-256-64-16", "--arch-mlp-top", "432-512-256-1", "--data-size", str(global_batch)]
+    return (["--backend", backend] if backend else []) + a

@@ -166,3 +166,74 @@ def test_single_rank_nccl_exchange_path_on_gpu(hip, tmp_path, how):
     m.close()
     for k, v in ref[1].items():
         np.testing.assert_allclose(z[f"s1/{k}"], v, rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def _run_two_ranks_on_one_gpu(tmp_path, *mode):
+    worker = os.path.join(ROOT, "tests", "_dist_worker_gpu.py")
+    port = str(29600 + os.getpid() % 300)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen(["python", worker, str(tmp_path), "staged", *mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2)]
+
+
+def test_two_ranks_on_one_gpu_equal_single_rank(hip, tmp_path):
+    """world_size 2 on the HIP kernels: both ranks share this box's one GPU, the collectives go through the host-staged
+    test transport (comm.HostStagedComm over gloo; RCCL refuses two ranks on one device).  Table-wise shards, exchange
+    buffers, Concat unpack / pack, global-batch fused update and the gradient all-reduce must reproduce the
+    single-rank run: tables within 1e-6 (same canonical order), MLP within 1e-5."""
+    z = _run_two_ranks_on_one_gpu(tmp_path)
+    m, h = H.build_golden_dlrm(HIP, overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    B = int(h["g"]["B"])
+    seen = set()
+    for r in range(2):
+        sl = slice(r * B // 2, (r + 1) * B // 2)
+        for step in range(2):
+            np.testing.assert_allclose(z[r][f"s{step}/pred"], ref[step]["pred"][sl], rtol=1e-5, atol=1e-6)
+            for k, v in ref[step].items():
+                key = f"s{step}/{k}"
+                if k == "pred":
+                    continue
+                if k.startswith("emb"):
+                    t = int(k.split(".")[1])
+                    assert (key in z[r].files) == (t % 2 == r)
+                    if t % 2 == r:
+                        np.testing.assert_allclose(z[r][key], v, rtol=1e-6, atol=1e-7, err_msg=key)
+                        seen.add(t)
+                else:
+                    np.testing.assert_allclose(z[r][key], v, rtol=1e-5, atol=1e-6, err_msg=key)
+        assert int(z[r]["alltoall_calls"]) == 4 and int(z[r]["allreduce_calls"]) == 2
+    assert seen == set(range(len(h["g"]["rows"])))
+
+
+def test_two_ranks_on_one_gpu_kaggle_shape(hip, tmp_path):
+    """The same at the Criteo-Kaggle shape with 2048 samples per rank (global batch 4096: 13 tables per rank, 4096
+    lookups per table -> the tiled radix-sort form of the fused update, LDS-DMA GEMMs on each rank's half): after the
+    warm-up + 3 steps every rank's predictions, MLP weights and owned tables equal the one-rank run on all 4096 samples."""
+    z = _run_two_ranks_on_one_gpu(tmp_path, "kaggle")
+    app = ffmodel.DLRM(H.KAGGLE_ARGS(4096, HIP))
+    app.warmup(); app.train_steps(3, trace=False); app.model.sync()
+    m = app.model
+    pred = m.layer_output(m.num_layers - 1).get()
+    owned = [0, 0]
+    for r in range(2):
+        np.testing.assert_allclose(z[r]["pred"], pred[r * 2048:(r + 1) * 2048], rtol=2e-5, atol=2e-6)
+        for l in range(m.num_layers):
+            if not m.layer_num_weights(l):
+                continue
+            key = f"p{l}"
+            is_table = m.layer_name(l).startswith("Embedding")
+            if is_table and key not in z[r].files:
+                continue
+            owned[r] += is_table
+            w = m.parameter(l, 0).get_weights()
+            exp = w if w.size <= 1 << 16 else np.array([w.astype(np.float64).sum(), np.abs(w).astype(np.float64).sum(), float(w[:64].astype(np.float64).sum())])
+            np.testing.assert_allclose(z[r][key], exp, rtol=2e-5, atol=2e-6, err_msg=f"rank {r} layer {l}")
+    assert owned == [13, 13]
+    app.close()
