@@ -50,7 +50,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    m, h = H.build_golden_dlrm(capi.HIP_LIB_PATH, comm=comm.struct, overlap=True, force_exchange=True, extra_argv=["--device", "0"])
+    column = len(sys.argv) > 3 and sys.argv[3] == "column"     # the 50-row table of the golden model split column-wise over the ranks
+    m, h = H.build_golden_dlrm(capi.HIP_LIB_PATH, comm=comm.struct, overlap=True, force_exchange=True, extra_argv=["--device", "0"],
+                               column_shard_rows=40 if column else 0)
     recs = H.run_steps(m, h, 2)
     for step, rec in enumerate(recs):
         for k, v in rec.items():

@@ -168,17 +168,17 @@ def test_single_rank_nccl_exchange_path_on_gpu(hip, tmp_path, how):
         np.testing.assert_allclose(z[f"s1/{k}"], v, rtol=1e-5, atol=1e-6, err_msg=k)
 
 
-def _run_two_ranks_on_one_gpu(tmp_path, *mode):
+def _run_two_ranks_on_one_gpu(tmp_path, *mode, world=2):
     worker = os.path.join(ROOT, "tests", "_dist_worker_gpu.py")
     port = str(29600 + os.getpid() % 300)
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen(["python", worker, str(tmp_path), "staged", *mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=900)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
-    return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2)]
+    return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
 
 
 def test_two_ranks_on_one_gpu_equal_single_rank(hip, tmp_path):
@@ -212,17 +212,44 @@ def test_two_ranks_on_one_gpu_equal_single_rank(hip, tmp_path):
     assert seen == set(range(len(h["g"]["rows"])))
 
 
-def test_two_ranks_on_one_gpu_kaggle_shape(hip, tmp_path):
-    """The same at the Criteo-Kaggle shape with 2048 samples per rank (global batch 4096: 13 tables per rank, 4096
-    lookups per table -> the tiled radix-sort form of the fused update, LDS-DMA GEMMs on each rank's half): after the
-    warm-up + 3 steps every rank's predictions, MLP weights and owned tables equal the one-rank run on all 4096 samples."""
-    z = _run_two_ranks_on_one_gpu(tmp_path, "kaggle")
-    app = ffmodel.DLRM(H.KAGGLE_ARGS(4096, HIP))
+def test_two_ranks_on_one_gpu_column_sharded_table(hip, tmp_path):
+    """--column-shard-rows on the HIP kernels with two ranks (BASELINE config 5's sharding at toy size): every rank holds all
+    rows x D/2 columns of the big table, gathers its slice for the global batch and updates it from the matching gradient
+    columns; the other tables stay table-wise; one all-to-all carries both kinds."""
+    z = _run_two_ranks_on_one_gpu(tmp_path, "column")
+    m, h = H.build_golden_dlrm(HIP, overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    B, D = int(h["g"]["B"]), int(h["g"]["D"])
+    rows = list(h["g"]["rows"])
+    small_owner = {}
+    for r in range(2):
+        sl = slice(r * B // 2, (r + 1) * B // 2)
+        np.testing.assert_allclose(z[r]["s1/pred"], ref[1]["pred"][sl], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(z[r]["s1/top.0.weight"], ref[1]["top.0.weight"], rtol=1e-5, atol=1e-6)
+        got = z[r]["s1/emb.1.weight"]
+        assert got.shape == (rows[1], D // 2)
+        np.testing.assert_allclose(got, ref[1]["emb.1.weight"][:, r * D // 2:(r + 1) * D // 2], rtol=1e-6, atol=1e-7)
+        for t in range(len(rows)):
+            if t != 1 and f"s1/emb.{t}.weight" in z[r].files:
+                np.testing.assert_allclose(z[r][f"s1/emb.{t}.weight"], ref[1][f"emb.{t}.weight"], rtol=1e-6, atol=1e-7)
+                small_owner[t] = r
+    assert sorted(small_owner) == [0, 2, 3]
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_kaggle_shape(hip, tmp_path, world):
+    """The same at the Criteo-Kaggle shape with 2048 samples per rank (2 ranks: 13 tables each, 4096 lookups per table;
+    4 ranks: 7 + 7 + 6 + 6 tables, 8192 lookups per table, uneven all-to-all blocks -> the tiled radix-sort form of the
+    fused update, LDS-DMA GEMMs on each rank's slice): after the warm-up + 3 steps every rank's predictions, MLP weights
+    and owned tables equal the one-rank run on the whole batch."""
+    z = _run_two_ranks_on_one_gpu(tmp_path, "kaggle", world=world)
+    app = ffmodel.DLRM(H.KAGGLE_ARGS(2048 * world, HIP))
     app.warmup(); app.train_steps(3, trace=False); app.model.sync()
     m = app.model
     pred = m.layer_output(m.num_layers - 1).get()
-    owned = [0, 0]
-    for r in range(2):
+    owned = [0] * world
+    for r in range(world):
         np.testing.assert_allclose(z[r]["pred"], pred[r * 2048:(r + 1) * 2048], rtol=2e-5, atol=2e-6)
         for l in range(m.num_layers):
             if not m.layer_num_weights(l):
@@ -235,5 +262,5 @@ def test_two_ranks_on_one_gpu_kaggle_shape(hip, tmp_path):
             w = m.parameter(l, 0).get_weights()
             exp = w if w.size <= 1 << 16 else np.array([w.astype(np.float64).sum(), np.abs(w).astype(np.float64).sum(), float(w[:64].astype(np.float64).sum())])
             np.testing.assert_allclose(z[r][key], exp, rtol=2e-5, atol=2e-6, err_msg=f"rank {r} layer {l}")
-    assert owned == [13, 13]
+    assert owned == [len(range(r, 26, world)) for r in range(world)]
     app.close()
