@@ -237,10 +237,10 @@ def test_two_ranks_on_one_gpu_column_sharded_table(hip, tmp_path):
     assert sorted(small_owner) == [0, 2, 3]
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_ranks_on_one_gpu_kaggle_shape(hip, tmp_path, world):
     """The same at the Criteo-Kaggle shape with 2048 samples per rank (2 ranks: 13 tables each, 4096 lookups per table;
-    4 ranks: 7 + 7 + 6 + 6 tables, 8192 lookups per table, uneven all-to-all blocks -> the tiled radix-sort form of the
+    4 ranks: 7 + 7 + 6 + 6 tables, 8192 lookups per table; 8 ranks: 4 + 4 + 3 x 6 tables, 16384 lookups -- uneven all-to-all blocks -> the tiled radix-sort form of the
     fused update, LDS-DMA GEMMs on each rank's slice): after the warm-up + 3 steps every rank's predictions, MLP weights
     and owned tables equal the one-rank run on the whole batch."""
     z = _run_two_ranks_on_one_gpu(tmp_path, "kaggle", world=world)
