@@ -10,6 +10,7 @@
 #include <sstream>
 
 #include "backend.h"
+#include "../../include/ffh_rng.h"
 
 namespace {
 double now_us() {
@@ -24,7 +25,7 @@ void print_vector(const std::string& name, const std::vector<int>& v) {
 
 DLRMConfig::DLRMConfig(void)
     : sparse_feature_size(2), sigmoid_bot(-1), sigmoid_top(-1), embedding_bag_size(1), loss_threshold(0.0f),
-      arch_interaction_op("cat"), dataset_path(""), data_size(-1) {
+      arch_interaction_op("cat"), dataset_path(""), data_size(-1), zipf_alpha(0.0) {
   embedding_size.push_back(4);
   mlp_bot.push_back(4); mlp_bot.push_back(2);
   mlp_top.push_back(8); mlp_top.push_back(2);
@@ -51,6 +52,7 @@ void parse_input_args(char** argv, int argc, DLRMConfig& config) {
     if (!strcmp(argv[i], "--arch-interaction-op")) { config.arch_interaction_op = std::string(argv[++i]); continue; }
     if (!strcmp(argv[i], "--dataset")) { config.dataset_path = std::string(argv[++i]); continue; }
     if (!strcmp(argv[i], "--data-size")) { config.data_size = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--zipf-alpha")) { config.zipf_alpha = atof(argv[++i]); continue; }   // not a reference flag
   }
 }
 
@@ -135,7 +137,8 @@ void DataLoader::generate_random(FFModel& ff, const DLRMConfig& dlrm) {
     if (!batch_sparse_inputs[t].impl->ptr) continue;          // this rank neither owns the table nor holds a column block of it
     const int64_t n = (int64_t)num_samples * bag;
     full_sparse[t] = (int64_t*)ff.dmalloc((size_t)n * sizeof(int64_t));
-    ff.check(ff.api->ffh_gen_indices(ff.ctx, full_sparse[t], n, s0 + 17 + t, 0, dlrm.embedding_size[t], ff.stream), "gen_indices");
+    if (dlrm.zipf_alpha > 0.0) generate_zipf(ff, full_sparse[t], n, s0 + 17 + t, dlrm.embedding_size[t], dlrm.zipf_alpha);
+    else ff.check(ff.api->ffh_gen_indices(ff.ctx, full_sparse[t], n, s0 + 17 + t, 0, dlrm.embedding_size[t], ff.stream), "gen_indices");
   }
   // dense features and labels: this rank's slice [rank*Bl, (rank+1)*Bl) of every batch
   full_dense = (float*)ff.dmalloc((size_t)nb * Bl * dense_dim * sizeof(float));
@@ -145,6 +148,31 @@ void DataLoader::generate_random(FFModel& ff, const DLRMConfig& dlrm) {
     ff.check(ff.api->ffh_gen_uniform01(ff.ctx, full_dense + (int64_t)k * Bl * dense_dim, Bl * dense_dim, s0 + 5, n0 * dense_dim, ff.stream), "gen dense");
     ff.check(ff.api->ffh_gen_bernoulli(ff.ctx, full_label + (int64_t)k * Bl, Bl, s0 + 7, n0, ff.stream), "gen label");
   }
+}
+
+// --zipf-alpha A (not in the reference, whose ids are uniform: SURVEY 8d's duplicate-row stress).  Rank k of R is drawn
+// with probability ~ (k+1)^-A through the inverse CDF of the continuous power law on [1, R+1); ranks are spread over the
+// table by a golden-ratio multiplicative permutation so that hot rows are not neighbours.  Drawn on the host in double precision from
+// the counter hash -- the same code feeds the HIP backend and the oracle backend, so both see identical ids.
+void DataLoader::generate_zipf(FFModel& ff, int64_t* dst, int64_t n, uint64_t seed, int64_t rows, double alpha) {
+  std::vector<int64_t> ids((size_t)n);
+  const double a1 = 1.0 - alpha;
+  const bool log_law = std::fabs(a1) < 1e-9;                    // alpha == 1: x = (R+1)^u
+  const double top = log_law ? std::log((double)rows + 1.0) : std::pow((double)rows + 1.0, a1) - 1.0;
+  uint64_t stride = (uint64_t)((double)rows * 0.6180339887498949) + 1;   // golden-ratio step, made coprime with the row count
+  auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+  while (gcd(stride, (uint64_t)rows) != 1) stride++;
+  const uint64_t shift = ffh_hash(seed, ~0ULL) % (uint64_t)rows;
+  for (int64_t i = 0; i < n; i++) {
+    const double u = (double)(ffh_hash(seed, (uint64_t)i) >> 11) * (1.0 / 9007199254740992.0);
+    const double x = log_law ? std::exp(u * top) : std::pow(1.0 + u * top, 1.0 / a1);
+    int64_t k = (int64_t)x - 1;
+    if (k < 0) k = 0;
+    if (k >= rows) k = rows - 1;
+    ids[(size_t)i] = (int64_t)(((uint64_t)k * (stride % (uint64_t)rows) + shift) % (uint64_t)rows);
+  }
+  ff.check(ff.api->ffh_memcpy_h2d(ff.ctx, dst, ids.data(), (size_t)n * sizeof(int64_t), ff.stream), "zipf ids H2D");
+  ff.check(ff.api->ffh_stream_sync(ff.ctx, ff.stream), "zipf ids sync");
 }
 
 // The Criteo file of the reference [ref: examples/cpp/DLRM/dlrm.cc:279-326 (shape checks), :421-479 (H5Dread of X_cat as

@@ -17,6 +17,7 @@ struct DLRMConfig {
   std::vector<int> embedding_size, mlp_bot, mlp_top;
   std::string arch_interaction_op, dataset_path;
   int data_size;
+  double zipf_alpha;   // > 0: synthetic ids follow a power law instead of the reference's uniform draw (not a reference flag)
 };
 
 void parse_input_args(char** argv, int argc, DLRMConfig& config);
@@ -40,6 +41,7 @@ class DataLoader {
 
  private:
   void generate_random(FFModel& ff, const DLRMConfig& dlrm);
+  void generate_zipf(FFModel& ff, int64_t* dst, int64_t n, uint64_t seed, int64_t rows, double alpha);
   void load_hdf5(FFModel& ff, const DLRMConfig& dlrm);      // --dataset: X_int / X_cat / y of the reference's Criteo file
   std::vector<Tensor> batch_sparse_inputs;
   Tensor batch_dense_input, batch_label;

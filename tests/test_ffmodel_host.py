@@ -422,3 +422,39 @@ def test_two_rank_driver_flags(tmp_path):
     assert np.array_equal(z0["w_top"], z1["w_top"]) and np.array_equal(z0["w_bot"], z1["w_bot"])
     assert float(z0["mse_last"]) < float(z0["mse_first"])
     assert "THROUGHPUT" in outs[0]
+
+
+def test_zipf_index_stream():
+    """--zipf-alpha (not a reference flag) draws power-law ids for the duplicate-row stress: in range,
+    reproducible from --seed, rank frequencies follow (k+1)^-alpha, and the hot rows are spread over the table."""
+    R, B = 5000, 4096
+    args = ["--backend", H.oracle_backend(), "-b", str(B), "--arch-sparse-feature-size", "8", "--arch-embedding-size", f"{R}-{R}-3",
+            "--arch-mlp-bot", "13-16-8", "--arch-mlp-top", "32-16-1", "--embedding-bag-size", "2", "--data-size", str(4 * B)]
+    def ids(extra):
+        app = ffmodel.DLRM(args + extra)
+        app.warmup()
+        app.model.sync()
+        out = [app.sparse_input(t).get(np.int64).copy() for t in range(3)]
+        app.train_steps(2, trace=False)
+        pm = app.model.perf_metrics()
+        assert np.isfinite(pm.mse_loss)
+        app.close()
+        return out
+    z = ids(["--zipf-alpha", "1.05"])
+    assert all(a.shape == (B, 2) for a in z)
+    assert all(a.min() >= 0 for a in z) and z[0].max() < R and z[2].max() < 3
+    assert all(np.array_equal(a, b) for a, b in zip(z, ids(["--zipf-alpha", "1.05"])))          # same seed, same stream
+    assert not np.array_equal(z[0], ids(["--zipf-alpha", "1.05", "--seed", "3"])[0])
+    assert not np.array_equal(z[0], z[1])                                                       # tables draw independently
+    counts = np.sort(np.bincount(z[0].reshape(-1), minlength=R))[::-1].astype(np.float64)
+    n = counts.sum()
+    a1 = 1 - 1.05
+    cdf = lambda x: ((x ** a1) - 1) / (((R + 1.0) ** a1) - 1)
+    exp_top = cdf(2.0) - cdf(1.0)                                                               # the hottest row's share
+    assert abs(counts[0] / n - exp_top) < 4 * np.sqrt(exp_top / n) + 0.01
+    exp_top10 = cdf(11.0) - cdf(1.0)
+    assert abs(counts[:10].sum() / n - exp_top10) < 0.03
+    hot = np.argsort(np.bincount(z[0].reshape(-1), minlength=R))[::-1][:8]
+    assert np.ptp(hot) > R // 8                                                                 # not the first rows of the table
+    u = ids([])                                                                                 # the reference's uniform draw
+    assert np.bincount(u[0].reshape(-1), minlength=R).max() < 12

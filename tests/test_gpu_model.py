@@ -143,6 +143,28 @@ def test_hdf5_dataset_on_gpu(hip, tmp_path, trace):
         np.testing.assert_allclose(res["hip"][k], res["cpu"][k], rtol=2e-5, atol=2e-6, err_msg=k)
 
 
+@pytest.mark.parametrize("batch,bag", [(2048, 1), (512, 3), (8192, 1)])
+def test_zipf_duplicate_row_stress_on_gpu(hip, batch, bag):
+    """power-law ids (--zipf-alpha 1.05; a few rows take most of the batch) through the gather and the fused
+    update -- the single-launch kernel (batch x bag <= 2048) and the tiled path -- against the oracle backend."""
+    args = ["-b", str(batch), "--arch-sparse-feature-size", "16", "--arch-embedding-size", "100000-37-5000-2",
+            "--arch-mlp-bot", "13-32-16", "--arch-mlp-top", "80-32-1", "--embedding-bag-size", str(bag), "--data-size", str(2 * batch),
+            "--zipf-alpha", "1.05"]
+    res = {}
+    for name, backend in (("hip", HIP), ("cpu", H.oracle_backend())):
+        app = ffmodel.DLRM(["--backend", backend] + args)
+        app.warmup()
+        app.train_steps(3, trace=False)
+        app.model.sync()
+        res[name] = {f"p{l}": app.model.parameter(l, 0).get_weights() for l in range(app.model.num_layers) if app.model.layer_num_weights(l)}
+        res[name]["pred"] = app.model.layer_output(app.model.num_layers - 1).get()
+        res[name]["ids"] = app.sparse_input(0).get(np.int64).astype(np.float64)
+        app.close()
+    assert np.bincount(res["hip"]["ids"].astype(np.int64).reshape(-1)).max() > batch * bag // 20
+    for k in res["hip"]:
+        np.testing.assert_allclose(res["hip"][k], res["cpu"][k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
 def test_dlrm_executable_on_gpu(hip):
     exe = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
     r = subprocess.run([exe] + DRIVER_C1 + ["--epochs", "3"], capture_output=True, text=True, timeout=300)
