@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- DLRM training throughput (samples/s) of the MI355X-native path, one JSON line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kaggle|tiny|terabyte|mlperf|giant] [--probe]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kaggle|tiny|terabyte|mlperf|giant|giant-row] [--probe]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
               --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -62,6 +62,10 @@ def workload(name: str, per_gpu_batch: int | None, world: int):
         b = per_gpu_batch or 8192   # MLPerf has no reference op), emb_dim 128, 65536 samples over 8 GPUs
         return dict(name="mlperf-dlrm-dot", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="857-1024-1024-512-256-1", B=b * world,
                     extra=["--arch-interaction-op", "dot"])
+    if name == "giant-row":    # the same table split ROW-wise: partial bag sums + reduce-scatter forward, all-gather backward
+        b = per_gpu_batch or 4096   # (configs[4]'s "reduce-scatter stress"; one rank: pass --force-exchange to walk the collectives)
+        return dict(name="giant-table-row-wise", rows="200000000", D=256, bot="13-512-256", top="512-512-256-1", B=b * world,
+                    extra=["--row-shard-rows", "100000000"])
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -193,7 +197,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="kaggle", help="kaggle (default, BASELINE configs[1]) | tiny | terabyte | mlperf | giant")
+    ap.add_argument("--workload", default="kaggle", help="kaggle (default, BASELINE configs[1]) | tiny | terabyte | mlperf | giant | giant-row")
     ap.add_argument("--per-gpu-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="(default) kept for older command lines")
@@ -298,6 +302,9 @@ def main():
         return
 
     samples = w["B"] * args.steps
+    wx = w.get("extra", [])
+    layout = ("the table row-wise (partial bag sums + RCCL reduce-scatter fwd, all-gather bwd)" if "--row-shard-rows" in wx else
+              "the table column-wise (RCCL all-to-all fwd+bwd)" if "--column-shard-rows" in wx else "tables table-wise (RCCL all-to-all fwd+bwd)")
     out = {
         "metric": "dlrm_training_samples_per_sec", "value": round(samples / elapsed, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -306,12 +313,12 @@ def main():
                                f"{'dot' if 'dot' in w.get('extra', []) else 'cat'} interaction, SGD lr 0.01, MSE loss",
                    "global_batch": w["B"], "per_gpu_batch": w["B"] // world,
                    "parallelism": ("single GPU, hipGraph-replayed step" if uses_graph else "single GPU, eager launches on 3 HIP streams") if world == 1 else
-                                  f"tables table-wise over {world} ranks (RCCL all-to-all fwd+bwd), MLPs data-parallel (1 all-reduce); {collectives}",
+                                  f"{layout} over {world} ranks, MLPs data-parallel (1 all-reduce); {collectives}",
                    "step_graph": bool(uses_graph), "step_us_graph_vs_eager": {k: round(v, 1) for k, v in step_us.items()}},
         "mse_over_timed_steps": round(2.0 * pm.mse_loss / max(pm.train_all, 1), 6),   # train_all is double-counted (1 class + accuracy), as in the reference
     }
     if args.force_exchange:
-        out["config"]["parallelism"] = f"1 rank, exchange path forced (all-to-all fwd+bwd + all-reduce); {collectives}"
+        out["config"]["parallelism"] = f"1 rank, exchange path forced: {layout} + all-reduce; {collectives}"
     if solo:
         fwd_bytes = owned * B * (8 + 4 * D + 4 * D)            # 3,536 B/sample at the Kaggle shape
         bwd_bytes = owned * B * (8 + 4 * D + 2 * 4 * D)

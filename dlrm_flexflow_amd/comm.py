@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from .ffmodel import ALLREDUCE_FN, ALLTOALL_FN, BARRIER_FN, FFComm
+from .ffmodel import ALLGATHER_FN, ALLREDUCE_FN, ALLTOALL_FN, BARRIER_FN, REDUCE_SCATTER_FN, FFComm
 
 
 class _CudaView:
@@ -43,14 +43,16 @@ class TorchComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.calls = {"alltoall": 0, "allreduce": 0}
+        self.calls = {"alltoall": 0, "allreduce": 0, "reduce_scatter": 0, "allgather": 0}
         self._tensors = {}     # (ptr, count) -> zero-copy tensor view; the model's buffers are fixed after compile()
         self._streams = {}     # hipStream_t -> torch.cuda.ExternalStream
         self._splits = {}
         self._a2a = ALLTOALL_FN(self._alltoall)
         self._ar = ALLREDUCE_FN(self._allreduce)
         self._bar = BARRIER_FN(self._barrier)
-        self.struct = FFComm(self.rank, self.world, None, self._a2a, self._ar, self._bar)
+        self._rs = REDUCE_SCATTER_FN(self._reduce_scatter)
+        self._ag = ALLGATHER_FN(self._allgather)
+        self.struct = FFComm(self.rank, self.world, None, self._a2a, self._ar, self._bar, 0, self._rs, self._ag)
 
     def _stream_ctx(self, stream):
         if self.on_gpu and stream:
@@ -92,6 +94,35 @@ class TorchComm:
             return 0
         except Exception as e:  # noqa: BLE001
             print("ffcomm allreduce failed:", repr(e), flush=True)
+            return 1
+
+    def _reduce_scatter(self, user, send, recv, recv_count, stream):
+        """Row-wise sharded table, forward: partial bag sums of the global batch -> this rank's samples, summed."""
+        try:
+            n = int(recv_count)
+            with self._stream_ctx(stream):
+                src = self._view(send, n * self.world)
+                if self.on_gpu:
+                    dist.reduce_scatter_tensor(self._view(recv, n), src, op=dist.ReduceOp.SUM, group=self.group)
+                else:            # gloo has no reduce-scatter: all-reduce a copy, keep this rank's block
+                    tmp = src.clone()
+                    dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+                    self._view(recv, n).copy_(tmp[self.rank * n:(self.rank + 1) * n])
+            self.calls["reduce_scatter"] += 1
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("ffcomm reduce_scatter failed:", repr(e), flush=True)
+            return 1
+
+    def _allgather(self, user, send, recv, send_count, stream):
+        try:
+            n = int(send_count)
+            with self._stream_ctx(stream):
+                dist.all_gather_into_tensor(self._view(recv, n * self.world), self._view(send, n), group=self.group)
+            self.calls["allgather"] += 1
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("ffcomm allgather failed:", repr(e), flush=True)
             return 1
 
     def _barrier(self, user):
@@ -146,6 +177,35 @@ class HostStagedComm(TorchComm):
             return 1
 
 
+    def _reduce_scatter(self, user, send, recv, recv_count, stream):
+        try:
+            n = int(recv_count)
+            torch.cuda.synchronize()
+            h = self._view(send, n * self.world).cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            self._view(recv, n).copy_(h[self.rank * n:(self.rank + 1) * n])
+            torch.cuda.synchronize()
+            self.calls["reduce_scatter"] += 1
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("ffcomm reduce_scatter (host-staged) failed:", repr(e), flush=True)
+            return 1
+
+    def _allgather(self, user, send, recv, send_count, stream):
+        try:
+            n = int(send_count)
+            torch.cuda.synchronize()
+            dst = torch.empty(n * self.world, dtype=torch.float32)
+            dist.all_gather_into_tensor(dst, self._view(send, n).cpu(), group=self.group)
+            self._view(recv, n * self.world).copy_(dst)
+            torch.cuda.synchronize()
+            self.calls["allgather"] += 1
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print("ffcomm allgather (host-staged) failed:", repr(e), flush=True)
+            return 1
+
+
 class RcclComm:
     """The same FFComm callbacks served by RCCL directly from the C++ host layer (host/rccl_comm.cc): the collectives
     are enqueued on the model's HIP streams without a round trip through Python (measured with a 1-rank group on the
@@ -181,9 +241,9 @@ class RcclComm:
             raise RuntimeError("ncclCommInitRank failed on some rank: " + (L.flexflow_rccl_last_error() or b"").decode())
         self.struct.barrier = boot._bar
         self._L = L
-        # known-answer check of both collectives on the new communicator (uneven all-to-all with a zero-length block,
-        # all-reduce); every rank must pass or all fall back to the torch callbacks together
-        self._base = {"alltoall": 0, "allreduce": 0}
+        # known-answer check of the collectives on the new communicator (uneven all-to-all with a zero-length block,
+        # all-reduce, reduce-scatter, all-gather); every rank must pass or all fall back to the torch callbacks together
+        self._base = {"alltoall": 0, "allreduce": 0, "reduce_scatter": 0, "allgather": 0}
         ok = self._self_test()
         self._base = self.calls                    # `calls` counts the model's collectives only
         flag.fill_(1 if ok else 0)
@@ -207,16 +267,30 @@ class RcclComm:
             return False
         if self.struct.allreduce_sum_f32(self.struct.user, ar.data_ptr(), 5, stream) != 0:
             return False
+        # reduce-scatter: rank r contributes (r + 1) * (block index + 1) in every element; all-gather: 3 floats of 100 r + j
+        rs_in = torch.tensor([(r + 1.0) * (p + 1.0) for p in range(W) for _ in range(3)], dtype=torch.float32, device="cuda")
+        rs_out = torch.full((3,), -1.0, dtype=torch.float32, device="cuda")
+        ag_in = torch.tensor([100.0 * r + j for j in range(3)], dtype=torch.float32, device="cuda")
+        ag_out = torch.full((3 * W,), -1.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        if self.struct.reduce_scatter_sum_f32(self.struct.user, rs_in.data_ptr(), rs_out.data_ptr(), 3, stream) != 0:
+            return False
+        if self.struct.allgather_f32(self.struct.user, ag_in.data_ptr(), ag_out.data_ptr(), 3, stream) != 0:
+            return False
         torch.cuda.synchronize()
         exp = [1000.0 * p + 10.0 * r + j for p in range(W) for j in range(rc[p])]
         got = recv[:len(exp)].cpu().tolist()
-        return got == exp and ar.cpu().tolist() == [W * (W + 1) / 2.0] * 5
+        return (got == exp and ar.cpu().tolist() == [W * (W + 1) / 2.0] * 5
+                and rs_out.cpu().tolist() == [(r + 1.0) * W * (W + 1) / 2.0] * 3
+                and ag_out.cpu().tolist() == [100.0 * p + j for p in range(W) for j in range(3)])
 
     @property
     def calls(self):
-        a, r = C.c_int64(0), C.c_int64(0)
+        a, r, s, g = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self._L.flexflow_rccl_comm_calls(C.byref(self.struct), C.byref(a), C.byref(r))
-        return {"alltoall": a.value - self._base["alltoall"], "allreduce": r.value - self._base["allreduce"]}
+        self._L.flexflow_rccl_comm_calls2(C.byref(self.struct), C.byref(s), C.byref(g))
+        return {"alltoall": a.value - self._base["alltoall"], "allreduce": r.value - self._base["allreduce"],
+                "reduce_scatter": s.value - self._base["reduce_scatter"], "allgather": g.value - self._base["allgather"]}
 
     def close(self):
         if self._L is not None:

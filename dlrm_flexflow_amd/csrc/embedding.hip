@@ -797,6 +797,15 @@ bool can_vec4(const ffh_emb_table* t, int nt, int D) {
 
 }  // namespace
 
+// row-wise sharded table: global id -> local id, rows held elsewhere -> the zero row behind the local slice
+__global__ __launch_bounds__(256) void emb_localize_kernel(const int64_t* __restrict__ idx, int64_t* __restrict__ local, int64_t n,
+                                                           int64_t row_begin, int64_t rows_local) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = idx[i] - row_begin;
+    local[i] = (r >= 0 && r < rows_local) ? r : rows_local;
+  }
+}
+
 extern "C" {
 
 int ffh_embedding_fwd_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch, int aggr, ffh_stream s) {
@@ -840,6 +849,14 @@ int ffh_embedding_bwd_dense(ffh_ctx* c, const int64_t* idx, const float* g, floa
   hipLaunchKernelGGL(emb_bwd_dense_kernel, dim3(ffh_grid(batch * D, 256, 4096)), dim3(256), 0, as_stream(s),
                      idx, g, wg, L, D, batch, gld, aggr == FFH_AGGR_MODE_AVG ? 1 : 0);
   FFH_LAUNCH_CHECK(c, "emb_bwd_dense_kernel");
+  return FFH_OK;
+}
+
+int ffh_embedding_localize_rows(ffh_ctx* c, const int64_t* idx, int64_t* local, int64_t n, int64_t row_begin, int64_t rows_local, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && row_begin >= 0 && rows_local >= 0 && ((idx && local) || n == 0), "embedding_localize_rows: bad args");
+  if (n == 0) return FFH_OK;
+  hipLaunchKernelGGL(emb_localize_kernel, dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), idx, local, n, row_begin, rows_local);
+  FFH_LAUNCH_CHECK(c, "embedding_localize_rows");
   return FFH_OK;
 }
 

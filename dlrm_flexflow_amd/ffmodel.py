@@ -38,12 +38,15 @@ class PerfMetrics(C.Structure):
 ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 BARRIER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+REDUCE_SCATTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 class FFComm(C.Structure):
     """struct ffcomm (host/ffcomm.h)"""
     _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("user", C.c_void_p),
-                ("alltoall_f32", ALLTOALL_FN), ("allreduce_sum_f32", ALLREDUCE_FN), ("barrier", BARRIER_FN), ("nonblocking", C.c_int)]
+                ("alltoall_f32", ALLTOALL_FN), ("allreduce_sum_f32", ALLREDUCE_FN), ("barrier", BARRIER_FN), ("nonblocking", C.c_int),
+                ("reduce_scatter_sum_f32", REDUCE_SCATTER_FN), ("allgather_f32", ALLGATHER_FN)]
 
 
 _lib = None
@@ -67,6 +70,7 @@ def lib() -> C.CDLL:
         "flexflow_rccl_comm_create": (I, [C.POINTER(C.c_ubyte), I, I, C.c_char_p, C.POINTER(FFComm)]),
         "flexflow_rccl_comm_destroy": (None, [C.POINTER(FFComm)]), "flexflow_rccl_last_error": (C.c_char_p, []),
         "flexflow_rccl_comm_calls": (None, [C.POINTER(FFComm), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+        "flexflow_rccl_comm_calls2": (None, [C.POINTER(FFComm), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "flexflow_config_set_batch_size": (None, [H, I]), "flexflow_config_get_batch_size": (I, [H]),
         "flexflow_config_set_backend": (None, [H, C.c_char_p]), "flexflow_config_set_seed": (None, [H, C.c_uint64]),
         "flexflow_config_set_device": (None, [H, I]), "flexflow_config_set_enable_graph": (None, [H, B]),

@@ -8,6 +8,9 @@
  * with the "nccl" backend = RCCL over xGMI; "gloo" in the CPU tests) provides:
  *   alltoall   uneven all-to-all of fp32 blocks  (embedding rows forward, their gradients backward)
  *   allreduce  in-place fp32 sum                 (one bucket = all MLP gradients)
+ *   reduce_scatter / allgather   (row-wise sharded giant table only, --row-shard-rows: every rank's partial bag sums
+ *              for the global batch are summed and each rank keeps its own samples; the gradients of those
+ *              samples are gathered back to every rank).  May be NULL when no table is row-sharded.
  * All calls are asynchronous on `stream` (a hipStream_t): they must be ordered after work already
  * enqueued on it and work enqueued later must see their result.  world_size == 1 needs no callbacks.
  */
@@ -31,6 +34,10 @@ typedef struct ffcomm {
    * issues them in stream order; with 0 (a callback that takes tens of microseconds of host time, e.g. through an
    * interpreter) it first enqueues the kernels that do not depend on the collective. */
   int nonblocking;
+  /* recv[i] = sum over ranks of their send[rank * recv_count + i]: send is [world_size * recv_count], recv is [recv_count] */
+  int (*reduce_scatter_sum_f32)(void* user, const float* send, float* recv, int64_t recv_count, void* stream);
+  /* recv[r * send_count + i] = rank r's send[i]: send is [send_count], recv is [world_size * send_count] */
+  int (*allgather_f32)(void* user, const float* send, float* recv, int64_t send_count, void* stream);
 } ffcomm;
 
 #ifdef __cplusplus

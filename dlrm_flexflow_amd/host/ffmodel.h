@@ -102,6 +102,7 @@ class FFConfig {
   bool overlap_embedding;      // embedding gather (+exchange) on a side stream beside the bottom MLP
   bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
   int64_t column_shard_rows;   // tables with at least this many rows are sharded column-wise over the ranks (0: never)
+  int64_t row_shard_rows;      // ... row-wise instead: partial bag sums + reduce-scatter (0: never; wins over column_shard_rows)
   bool async_launch;           // auxiliary streams are fed by their own host threads (HIP backend only)
   bool parallel_dw;            // weight-gradient GEMMs on their own stream beside the data-gradient chain
   bool force_exchange;         // run the all-to-all / all-reduce path even with one rank (tests the collectives on 1 GPU)
@@ -295,6 +296,15 @@ class Embedding : public Op {
   int owner_rank;               // table-wise sharding: table_index % world_size
   bool column_sharded;          // every rank holds out_channels / world_size columns of all rows
   int local_cols;               // columns of the table held by this rank
+  // row-wise sharding (--row-shard-rows): this rank holds rows [row_begin, row_begin + rows_local) plus one all-zero row
+  // that stands for every row held elsewhere; forward = gather of partial bag sums for the GLOBAL batch + reduce-scatter,
+  // backward = all-gather of the output gradients + fused update of the local rows
+  bool row_sharded;
+  int64_t row_begin, rows_local;
+  int64_t* local_idx;           // [batch][bag] ids relative to row_begin (rows held elsewhere -> rows_local)
+  float *partial, *gfull;       // [batch][out_channels]: partial sums (reduce-scatter input), gathered gradients
+  void set_row_sharding(const FFModel& model, bool on);
+  bool held_here(int rank) const { return owner_rank == rank || column_sharded || row_sharded; }
 };
 
 class Concat : public Op {

@@ -125,6 +125,7 @@ FFConfig::FFConfig() {
   parallel_dw = true;
   async_launch = false;   // measured on MI355X / ROCm 7.2: no gain over one issuing thread (280 vs 272 us per Kaggle step)
   column_shard_rows = 0;
+  row_shard_rows = 0;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
   comm.world_size = 1;
@@ -169,6 +170,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--inline-launch")) { async_launch = false; continue; }
     if (is("--async-launch")) { async_launch = true; continue; }
     if (is("--column-shard-rows")) { column_shard_rows = atoll(next()); continue; }
+    if (is("--row-shard-rows")) { row_shard_rows = atoll(next()); continue; }
   }
 }
 
@@ -421,6 +423,9 @@ FFModel::~FFModel() {
   for (void* p : {(void*)mlp_weights, (void*)mlp_grads, (void*)act_grad_slab, workspace, (void*)d_perf, (void*)xsend,
                   (void*)xrecv, (void*)gsend, (void*)grecv})
     if (p) api->ffh_free(ctx, p);
+  for (Embedding* e : embeddings)
+    for (void* p : {(void*)e->local_idx, (void*)e->partial, (void*)e->gfull})
+      if (p) api->ffh_free(ctx, p);
   api->ffh_event_destroy(ctx, ev_fork); api->ffh_event_destroy(ctx, ev_join);
   api->ffh_event_destroy(ctx, ev_grad_ready); api->ffh_event_destroy(ctx, ev_update_done);
   api->ffh_event_destroy(ctx, ev_dw_done);
@@ -608,11 +613,33 @@ Embedding::Embedding(FFModel& model, const Tensor& input, int _num_entries, int 
   column_sharded = model.world_size > 1 && model.config.column_shard_rows > 0 && num_entries >= model.config.column_shard_rows;
   if (column_sharded && outDim % model.world_size != 0) die("%s: out_dim %d is not divisible by %d ranks", this->name, outDim, model.world_size);
   local_cols = column_sharded ? outDim / model.world_size : outDim;
+  // ... or row-wise: every rank holds num_entries / G rows of all columns and contributes partial bag sums that a
+  // reduce-scatter adds up (BASELINE configs[4]'s "reduce-scatter stress"; column-wise stays the primary layout)
+  local_idx = nullptr; partial = gfull = nullptr;
+  row_sharded = false; row_begin = 0; rows_local = num_entries;
+  set_row_sharding(model, model.exchange && model.config.row_shard_rows > 0 && num_entries >= model.config.row_shard_rows);
   model.embeddings.push_back(this);
+}
+void Embedding::set_row_sharding(const FFModel& model, bool on) {
+  if (on && (!model.config.comm.reduce_scatter_sum_f32 || !model.config.comm.allgather_f32))
+    die("%s: --row-shard-rows needs the reduce_scatter / allgather callbacks of ffcomm", this->name);
+  if (on && num_entries < model.world_size) die("%s: %d rows cannot be split over %d ranks", this->name, num_entries, model.world_size);
+  row_sharded = on;
+  if (on) {
+    column_sharded = false;
+    local_cols = out_channels;
+    owner_rank = -1;                                   // no single owner
+    row_begin = (int64_t)num_entries * model.rank / model.world_size;
+    rows_local = (int64_t)num_entries * (model.rank + 1) / model.world_size - row_begin;
+  } else {
+    row_begin = 0;
+    rows_local = num_entries;
+    if (owner_rank < 0) owner_rank = table_index % model.world_size;
+  }
 }
 void Embedding::create_output_and_partition(FFModel&) {}
 void Embedding::create_weights(FFModel& model) {
-  const int dims[2] = {num_entries, local_cols};   // column-sharded: this rank's slice only
+  const int dims[2] = {row_sharded ? (int)rows_local : num_entries, local_cols};   // column- / row-sharded: this rank's slice only
   weights[0] = model.create_weight<2>(dims, this, DT_FLOAT, kernel_initializer);
 }
 void Embedding::forward(const FFModel& ff) {
@@ -975,11 +1002,13 @@ void FFModel::apply_strategies() {
         if (e->out_channels % world_size) die("%s: out_dim %d is not divisible by %d ranks", op->name, e->out_channels, world_size);
         for (size_t j = 0; j < pc.device_ids.size(); j++)
           if (pc.device_ids[j] != (int)j) die("%s: column blocks must sit on devices 0..%d in order", op->name, world_size - 1);
+        e->set_row_sharding(*this, false);
         e->column_sharded = true;
         e->local_cols = e->out_channels / world_size;
         continue;
       }
       if (pc.num_parts() != 1) die("%s: an embedding can only be placed whole on one device (dims all 1), the strategy splits it %d ways", op->name, pc.num_parts());
+      e->set_row_sharding(*this, false);
       e->owner_rank = pc.device_ids.empty() ? 0 : pc.device_ids[0];
       e->column_sharded = false;
       e->local_cols = e->out_channels;
@@ -998,6 +1027,7 @@ void FFModel::apply_strategies() {
       ParallelConfig pc;
       pc.nDims = op->outputs[0].numDim;
       Embedding* e = dynamic_cast<Embedding*>(op);
+      if (e && e->row_sharded) continue;              // no output dim is split: the file format cannot say it; the flag stays in charge
       if (e && !e->column_sharded) {
         pc.device_ids.push_back(e->owner_rank);
       } else if (e) {
@@ -1060,7 +1090,7 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
       li->kernel_initializer->init(this, &li->weights[0]);
       if (li->use_bias) li->bias_initializer->init(this, &li->weights[1]);
     } else if (Embedding* e = dynamic_cast<Embedding*>(op)) {
-      if (e->owner_rank == rank || e->column_sharded) e->kernel_initializer->init(this, &e->weights[0]);
+      if (e->held_here(rank)) e->kernel_initializer->init(this, &e->weights[0]);
     }
   }
   compiled = true;
@@ -1091,7 +1121,7 @@ void FFModel::allocate() {
     auto it = sparse_of.find(t->impl);
     if (it != sparse_of.end()) {
       // sparse ids of a table: the owner gathers for the GLOBAL batch; other ranks hold nothing
-      if (it->second->owner_rank == rank || it->second->column_sharded) alloc_rows(*t, t->rows());
+      if (it->second->held_here(rank)) alloc_rows(*t, t->rows());
     } else {
       alloc_rows(*t, t->rows() / world_size);
     }
@@ -1116,7 +1146,13 @@ void FFModel::allocate() {
   shards.clear();
   rank_width.assign(world_size, 0);
   for (Embedding* e : embeddings) {
-    if (e->column_sharded) {
+    if (e->row_sharded) {
+      // not part of the all-to-all: its own buffers, a reduce-scatter forward and an all-gather backward
+      const size_t ids = (size_t)config.batchSize * L, fl = (size_t)config.batchSize * D;
+      e->local_idx = (int64_t*)dmalloc(ids * sizeof(int64_t));
+      e->partial = (float*)dmalloc(fl * 4);
+      e->gfull = (float*)dmalloc(fl * 4);
+    } else if (e->column_sharded) {
       for (int g = 0; g < world_size; g++) shards.push_back({e, g, g * e->local_cols, e->local_cols, 0});
     } else {
       shards.push_back({e, e->owner_rank, 0, e->out_channels, 0});
@@ -1148,6 +1184,7 @@ void FFModel::allocate() {
     for (int i = 0; i < c->numInputs; i++) {
       const Tensor& in = c->inputs[i];
       const bool producer_ok = in.owner_op && (in.owner_op->op_type == OP_LINEAR || in.owner_op->op_type == OP_EMBEDDING);
+      // (a row-sharded table's output is the contiguous receive buffer of its reduce-scatter: own storage as well)
       const bool via_exchange = exchange && in.owner_op && in.owner_op->op_type == OP_EMBEDDING;
       if (producer_ok && !via_exchange && consumers[in.impl] == 1 && !alias_of.count(in.impl)) alias_of[in.impl] = {c, off};
       off += in.adim[0];
@@ -1175,7 +1212,7 @@ void FFModel::allocate() {
     TensorImpl* im = op->outputs[0].impl;
     if (alias_of.count(im)) continue;
     if (Reshape* r = dynamic_cast<Reshape*>(op)) if (r->is_view) continue;
-    if (exchange && op->op_type == OP_EMBEDDING) continue;   // lives in xrecv / gsend
+    if (exchange && op->op_type == OP_EMBEDDING && !static_cast<Embedding*>(op)->row_sharded) continue;   // lives in xrecv / gsend
     const Tensor& o = op->outputs[0];
     const size_t b = align_up((size_t)(o.rows() / world_size) * o.adim[0] * 4);
     act_bytes += b;
@@ -1267,7 +1304,8 @@ void FFModel::allocate() {
         if (consumers[c->inputs[i].impl] != 1) c->bwd_overwrite = false;
       for (int i = 0; i < c->numInputs; i++) {
         TensorImpl* im = c->inputs[i].impl;
-        const bool via_exchange = exchange && c->inputs[i].owner_op && c->inputs[i].owner_op->op_type == OP_EMBEDDING;
+        const bool via_exchange = exchange && c->inputs[i].owner_op && c->inputs[i].owner_op->op_type == OP_EMBEDDING &&
+                                  !static_cast<const Embedding*>(c->inputs[i].owner_op)->row_sharded;
         if (via_exchange && !c->bwd_overwrite) need_zero_gsend = true;
         if (im->grad && !im->grad_alias && !via_exchange && im->pieces.empty() && !c->bwd_overwrite) need_zero_act_grads = true;   // add_with_stride accumulates
       }
@@ -1297,9 +1335,10 @@ void FFModel::allocate() {
       off_p += (p.get_volume() + 3) / 4 * 4;
     } else {
       Embedding* e = static_cast<Embedding*>(p.owner_op);
-      if (e->owner_rank != rank && !e->column_sharded) continue;   // sole owner (or one column block per rank): never replicated, never all-reduced
+      if (!e->held_here(rank)) continue;   // sole owner (or one column / row block per rank): never replicated, never all-reduced
       im->bytes = p.get_volume() * 4;
-      im->ptr = dmalloc(im->bytes);
+      im->ptr = dmalloc(im->bytes + (e->row_sharded ? (size_t)e->out_channels * 4 : 0));   // row block: + the zero row
+      if (e->row_sharded) check(api->ffh_zero(ctx, (char*)im->ptr + im->bytes, (size_t)e->out_channels * 4, stream), "zero row");
       if (!fused) {
         im->grad = (float*)dmalloc(im->bytes);
         im->grad_ld = im->ld;
@@ -1314,6 +1353,8 @@ void FFModel::allocate() {
     const int chunk = std::min(owned_shards, FFH_MAX_TABLES);
     workspace_bytes = api->ffh_embedding_bwd_workspace_bytes(chunk, L, D, config.batchSize) + 256;
   }
+  for (Embedding* e : embeddings)
+    if (e->row_sharded) workspace_bytes = std::max(workspace_bytes, api->ffh_embedding_bwd_workspace_bytes(1, L, D, config.batchSize) + 256);
   workspace = dmalloc(workspace_bytes);
   check(api->ffh_ctx_set_workspace(ctx, workspace, workspace_bytes), "set workspace");
   if (side_worker) check(api->ffh_ctx_set_workspace(side_worker->ctx(), workspace, workspace_bytes), "set workspace");   // the only other user
@@ -1378,8 +1419,21 @@ void FFModel::embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx) const {
   launch_shard_groups(this, true, s, on_ctx ? on_ctx : ctx);
   if (exchange) {
     // each owner gathered its tables / column blocks for the global batch; rows go to the rank that owns the sample
-    if (config.comm.alltoall_f32(config.comm.user, xsend, fwd_send_counts.data(), xrecv, fwd_recv_counts.data(), s) != 0)
+    if (!shards.empty() && config.comm.alltoall_f32(config.comm.user, xsend, fwd_send_counts.data(), xrecv, fwd_recv_counts.data(), s) != 0)
       die("alltoall (embedding forward) failed");
+  }
+  // row-wise sharded tables: partial bag sums of the GLOBAL batch over the rows held here (rows held elsewhere read the
+  // zero row), then the ranks' partials are added and every rank keeps its own samples
+  ffh_ctx* cx = on_ctx ? on_ctx : ctx;
+  for (const Embedding* e : embeddings) {
+    if (!e->row_sharded) continue;
+    const int L = e->inputs[0].adim[0], D = e->out_channels;
+    check(api->ffh_embedding_localize_rows(cx, (const int64_t*)e->inputs[0].impl->ptr, e->local_idx, (int64_t)config.batchSize * L,
+                                           e->row_begin, e->rows_local, s), "embedding_localize_rows");
+    check(api->ffh_embedding_fwd(cx, e->local_idx, e->partial, (const float*)e->weights[0].impl->ptr, L, D, config.batchSize,
+                                 e->rows_local + 1, D, (int)e->aggr, s), e->name);
+    if (config.comm.reduce_scatter_sum_f32(config.comm.user, e->partial, (float*)e->outputs[0].impl->ptr, local_batch * D, s) != 0)
+      die("reduce-scatter (row-sharded embedding forward) failed");
   }
 }
 
@@ -1387,10 +1441,24 @@ void FFModel::embedding_group_update(ffh_stream s, ffh_ctx* on_ctx) const {
   if (embeddings.empty()) return;
   if (exchange) {
     // gradients of the rows go back to the owners (transposed exchange)
-    if (config.comm.alltoall_f32(config.comm.user, gsend, fwd_recv_counts.data(), grecv, fwd_send_counts.data(), s) != 0)
+    if (!shards.empty() && config.comm.alltoall_f32(config.comm.user, gsend, fwd_recv_counts.data(), grecv, fwd_send_counts.data(), s) != 0)
       die("alltoall (embedding backward) failed");
   }
   launch_shard_groups(this, false, s, on_ctx ? on_ctx : ctx);
+  // row-wise sharded tables: every rank needs the gradient rows of the global batch; the fused update then touches the
+  // rows held here, and whatever the other ranks' rows piled onto the zero row is wiped
+  ffh_ctx* cx = on_ctx ? on_ctx : ctx;
+  const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(optimizer);
+  for (const Embedding* e : embeddings) {
+    if (!e->row_sharded) continue;
+    const int L = e->inputs[0].adim[0], D = e->out_channels;
+    if (config.comm.allgather_f32(config.comm.user, e->outputs[0].impl->grad, e->gfull, local_batch * D, s) != 0)
+      die("all-gather (row-sharded embedding backward) failed");
+    float* w = (float*)e->weights[0].impl->ptr;
+    check(api->ffh_embedding_bwd_sgd_fused(cx, e->local_idx, e->gfull, w, L, D, config.batchSize, e->rows_local + 1, D, (int)e->aggr,
+                                           (float)sgd->lr, s), e->name);
+    check(api->ffh_zero(cx, w + e->rows_local * (int64_t)D, (size_t)D * 4, s), "zero row");
+  }
 }
 
 // =============================================================================================

@@ -23,6 +23,8 @@ struct Api {
   int (*Send)(const void*, size_t, int, int, ncclComm_p, void*);
   int (*Recv)(void*, size_t, int, int, ncclComm_p, void*);
   int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_p, void*);
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_p, void*);
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_p, void*);
   const char* (*GetErrorString)(int);
 };
 
@@ -43,7 +45,8 @@ bool load(const char* path) {
   if (!g_api.field) { g_err = std::string("librccl lacks ") + name; return false; }
   SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
   SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
-  SYM(AllReduce, "ncclAllReduce") SYM(GetErrorString, "ncclGetErrorString")
+  SYM(AllReduce, "ncclAllReduce") SYM(ReduceScatter, "ncclReduceScatter") SYM(AllGather, "ncclAllGather")
+  SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
   g_api.lib = h;
   return true;
@@ -52,7 +55,7 @@ bool load(const char* path) {
 struct Comm {
   ncclComm_p comm;
   int rank, world;
-  int64_t n_alltoall, n_allreduce;
+  int64_t n_alltoall, n_allreduce, n_reduce_scatter, n_allgather;
 };
 
 int fail(int rc, const char* what) {
@@ -88,6 +91,28 @@ int allreduce_sum_f32(void* user, float* buf, int64_t count, void* stream) {
   return 0;
 }
 
+// row-wise sharded table, forward: partial bag sums of the global batch -> this rank's samples, summed over the ranks
+int reduce_scatter_sum_f32(void* user, const float* send, float* recv, int64_t recv_count, void* stream) {
+  Comm* c = (Comm*)user;
+  if (recv_count > 0) {
+    const int e = g_api.ReduceScatter(send, recv, (size_t)recv_count, kNcclFloat32, kNcclSum, c->comm, stream);
+    if (e != kNcclSuccess) return fail(e, "ncclReduceScatter");
+  }
+  c->n_reduce_scatter++;
+  return 0;
+}
+
+// ... backward: every rank's gradient rows -> every rank
+int allgather_f32(void* user, const float* send, float* recv, int64_t send_count, void* stream) {
+  Comm* c = (Comm*)user;
+  if (send_count > 0) {
+    const int e = g_api.AllGather(send, recv, (size_t)send_count, kNcclFloat32, c->comm, stream);
+    if (e != kNcclSuccess) return fail(e, "ncclAllGather");
+  }
+  c->n_allgather++;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -110,7 +135,7 @@ int flexflow_rccl_comm_create(const unsigned char id[128], int rank, int world_s
   if (!load(lib_path)) return 1;
   ncclUniqueId_t u;
   memcpy(u.internal, id, 128);
-  Comm* c = new Comm{nullptr, rank, world_size, 0, 0};
+  Comm* c = new Comm{nullptr, rank, world_size, 0, 0, 0, 0};
   const int e = g_api.CommInitRank(&c->comm, world_size, u, rank);
   if (e != kNcclSuccess) { delete c; return fail(e, "ncclCommInitRank"); }
   memset(out, 0, sizeof *out);
@@ -121,6 +146,8 @@ int flexflow_rccl_comm_create(const unsigned char id[128], int rank, int world_s
   out->allreduce_sum_f32 = allreduce_sum_f32;
   out->barrier = nullptr;          // the launcher supplies its own (it owns the bootstrap group)
   out->nonblocking = 1;
+  out->reduce_scatter_sum_f32 = reduce_scatter_sum_f32;
+  out->allgather_f32 = allgather_f32;
   return 0;
 }
 
@@ -136,6 +163,12 @@ void flexflow_rccl_comm_calls(const ffcomm* comm, int64_t* a2a, int64_t* ar) {
   const Comm* c = comm ? (const Comm*)comm->user : nullptr;
   if (a2a) *a2a = c ? c->n_alltoall : 0;
   if (ar) *ar = c ? c->n_allreduce : 0;
+}
+
+void flexflow_rccl_comm_calls2(const ffcomm* comm, int64_t* rs, int64_t* ag) {
+  const Comm* c = comm ? (const Comm*)comm->user : nullptr;
+  if (rs) *rs = c ? c->n_reduce_scatter : 0;
+  if (ag) *ag = c ? c->n_allgather : 0;
 }
 
 }  // extern "C"

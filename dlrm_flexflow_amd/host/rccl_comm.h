@@ -3,7 +3,8 @@
  * 128 bytes over whatever it has (torch.distributed in bench.py), every rank calls flexflow_rccl_comm_create.
  * Replaces one ncclAllReduce per tensor [ref: src/runtime/optimizer_kernel.cu:170-171] with one per step, and the
  * Legion zero-copy movement of embedding outputs [ref: src/ops/embedding.cu:295-299] with an all-to-all made of
- * grouped ncclSend / ncclRecv pairs, enqueued on the model's own HIP streams (no host round trip per collective). */
+ * grouped ncclSend / ncclRecv pairs, enqueued on the model's own HIP streams (no host round trip per collective).
+ * A row-wise sharded table (--row-shard-rows) adds ncclReduceScatter forward and ncclAllGather backward. */
 #ifndef RCCL_COMM_H_
 #define RCCL_COMM_H_
 #include "ffcomm.h"
@@ -19,6 +20,7 @@ void flexflow_rccl_comm_destroy(ffcomm* comm);
 const char* flexflow_rccl_last_error(void);
 /* number of all-to-all / all-reduce calls served so far (tests) */
 void flexflow_rccl_comm_calls(const ffcomm* comm, int64_t* alltoall, int64_t* allreduce);
+void flexflow_rccl_comm_calls2(const ffcomm* comm, int64_t* reduce_scatter, int64_t* allgather);
 #ifdef __cplusplus
 }
 #endif

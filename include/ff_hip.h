@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 2   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used */
+#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows */
 
 /* status codes */
 #define FFH_OK               0
@@ -206,6 +206,14 @@ int ffh_embedding_bwd_sgd_fused(ffh_ctx* ctx, const int64_t* idx, const float* o
 int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int ntables,
                                       int in_dim, int out_dim, int64_t batch, int aggr, float lr, ffh_stream s);
 size_t ffh_embedding_bwd_workspace_bytes(int ntables, int in_dim, int out_dim, int64_t batch);
+
+/* Row-wise sharded table (no reference counterpart: the reference splits an embedding on the sample dim only,
+ * [ref: src/ops/embedding.cu:84-85]).  A rank holds rows [row_begin, row_begin + rows_local) followed by ONE extra
+ * all-zero row; this maps global ids to local ones: local[i] = idx[i] - row_begin when the row is held here, else
+ * rows_local (the zero row: the gather then adds +0 for it, and the update's writes to it are discarded by the caller
+ * clearing the row again).  idx and local may be the same buffer. */
+int ffh_embedding_localize_rows(ffh_ctx* ctx, const int64_t* idx, int64_t* local, int64_t count,
+                                int64_t row_begin, int64_t rows_local, ffh_stream s);
 
 /* ------------------------------------------------------------------ */
 /* Linear                                                             */
@@ -373,7 +381,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_gen_indices) X(ffh_gen_uniform01) X(ffh_gen_bernoulli) \
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
-  X(ffh_embedding_bwd_workspace_bytes) \
+  X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
   X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_second_stream_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)

@@ -299,6 +299,17 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* t, int nt
   }
   return FFH_OK;
 }
+/* row-wise sharded table (this build's extension; include/ff_hip.h): ids of rows held elsewhere -> the zero row */
+int ffh_embedding_localize_rows(ffh_ctx* c, const int64_t* idx, int64_t* local, int64_t n, int64_t row_begin, int64_t rows_local, ffh_stream s) {
+  (void)s;
+  if (n < 0 || row_begin < 0 || rows_local < 0 || (n > 0 && (!idx || !local))) return fail(c, FFH_ERR_BAD_ARG, "embedding_localize_rows: bad args");
+  for (int64_t i = 0; i < n; i++) {
+    const int64_t r = idx[i] - row_begin;
+    local[i] = (r >= 0 && r < rows_local) ? r : rows_local;
+  }
+  return FFH_OK;
+}
+
 size_t ffh_embedding_bwd_workspace_bytes(int nt, int L, int D, int64_t B) { (void)nt; (void)L; (void)D; (void)B; return 0; }
 
 /* ------------------------------------------------------------------ */

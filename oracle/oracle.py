@@ -216,6 +216,15 @@ def gen_indices(count, seed, first, R):
     return p
 
 
+def embedding_localize_rows(idx, row_begin, rows_local):
+    """Row-wise sharded table (this build's extension): global ids -> ids relative to row_begin, rows held elsewhere ->
+    rows_local (the zero row behind the local slice)."""
+    idx = _i64(idx)
+    out = np.empty_like(idx)
+    lib().call("ffh_embedding_localize_rows", idx, out, idx.size, row_begin, rows_local, None)
+    return out
+
+
 def gen_uniform01(count, seed, first):
     p = np.empty(count, np.float32)
     lib().call("ffh_gen_uniform01", p, count, seed, first, None)

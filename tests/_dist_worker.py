@@ -24,10 +24,10 @@ def main():
     rank = dist.get_rank()
     comm = TorchComm(on_gpu=False)
     out = {}
-    if mode in ("golden", "column", "strategy"):
+    if mode in ("golden", "column", "strategy", "row"):
         extra = ["--import", os.path.join(outdir, "strategy.txt"), "--export", os.path.join(outdir, "export.txt")] if mode == "strategy" else []
         m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True,
-                                   column_shard_rows=40 if mode == "column" else 0, extra_argv=extra)
+                                   column_shard_rows=40 if mode == "column" else 0, row_shard_rows=40 if mode == "row" else 0, extra_argv=extra)
         recs = H.run_steps(m, h, 2)
         for step, rec in enumerate(recs):
             for k, v in rec.items():
@@ -63,6 +63,8 @@ def main():
         app.close()
     out["alltoall_calls"] = np.array(comm.calls["alltoall"])
     out["allreduce_calls"] = np.array(comm.calls["allreduce"])
+    out["reduce_scatter_calls"] = np.array(comm.calls["reduce_scatter"])
+    out["allgather_calls"] = np.array(comm.calls["allgather"])
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), **out)
     dist.barrier()
     dist.destroy_process_group()

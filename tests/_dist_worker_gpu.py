@@ -51,14 +51,17 @@ def main():
         dist.destroy_process_group()
         return
     column = len(sys.argv) > 3 and sys.argv[3] == "column"     # the 50-row table of the golden model split column-wise over the ranks
+    row = len(sys.argv) > 3 and sys.argv[3] == "row"           # ... row-wise: partial sums + reduce-scatter, all-gather backward
     m, h = H.build_golden_dlrm(capi.HIP_LIB_PATH, comm=comm.struct, overlap=True, force_exchange=True, extra_argv=["--device", "0"],
-                               column_shard_rows=40 if column else 0)
+                               column_shard_rows=40 if column else 0, row_shard_rows=40 if row else 0)
     recs = H.run_steps(m, h, 2)
     for step, rec in enumerate(recs):
         for k, v in rec.items():
             out[f"s{step}/{k}"] = v
     out["alltoall_calls"] = np.array(comm.calls["alltoall"])
     out["allreduce_calls"] = np.array(comm.calls["allreduce"])
+    out["reduce_scatter_calls"] = np.array(comm.calls["reduce_scatter"])
+    out["allgather_calls"] = np.array(comm.calls["allgather"])
     np.savez(os.path.join(outdir, f"rank{dist.get_rank()}.npz"), **out)
     m.close()
     dist.barrier()

@@ -20,7 +20,7 @@ def oracle_backend():
 
 
 def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dense_update=False, g=None, force_exchange=False,
-                      column_shard_rows=0, extra_argv=(), adam=None):
+                      column_shard_rows=0, extra_argv=(), adam=None, row_shard_rows=0):
     """Returns (model, handles) with weights and inputs of the golden fixture loaded.
     With `comm` (world_size > 1) each rank loads its batch slice / its tables."""
     g = g or golden("dlrm_step_torch")
@@ -31,6 +31,8 @@ def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dens
     argv = ["-b", str(B)] + (["--force-exchange"] if force_exchange else [])
     if column_shard_rows:
         argv += ["--column-shard-rows", str(column_shard_rows)]
+    if row_shard_rows:
+        argv += ["--row-shard-rows", str(row_shard_rows)]
     cfg = ffmodel.FFConfig(argv=argv + list(extra_argv), backend=backend, comm=comm)
     cfg.set(enable_graph=enable_graph, overlap_embedding=overlap, dense_embedding_update=dense_update)
     m = ffmodel.FFModel(cfg)
@@ -68,6 +70,10 @@ def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dens
             if p.is_local:
                 w0 = g[f"init/{k}.weight"]
                 cols = p.dims[1]                      # column-sharded giant table: this rank holds D/G columns of every row
+                if p.dims[0] != w0.shape[0]:          # row-sharded: rows [R r / G, R (r + 1) / G)
+                    R = w0.shape[0]
+                    w0 = np.ascontiguousarray(w0[R * rank // world:R * (rank + 1) // world])
+                    assert w0.shape[0] == p.dims[0]
                 p.set_weights(w0 if cols == w0.shape[1] else np.ascontiguousarray(w0[:, rank * cols:(rank + 1) * cols]))
         else:
             m.parameter(li, 0).set_weights(g[f"init/{k}.weight"])

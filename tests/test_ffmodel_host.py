@@ -241,6 +241,38 @@ def test_two_rank_column_sharded_giant_table(tmp_path):
     assert sorted(owner_of_small) == [0, 2, 3]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_sharded_giant_table(tmp_path, world):
+    """--row-shard-rows 40 (BASELINE configs[4]'s reduce-scatter variant): the 50-row table is split row-wise, every rank
+    gathers partial bag sums for the global batch (rows held elsewhere read the zero row), a reduce-scatter adds the
+    partials and leaves each rank its samples; backward all-gathers the output gradients and each rank updates its rows.
+    The other tables stay table-wise in the all-to-all (world 4: rank 1 owns none of them).  Every rank's rows must equal the same rows of the 1-rank table."""
+    _run_ranks(world, tmp_path, "row")
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    B = int(h["g"]["B"])
+    rows = list(h["g"]["rows"])
+    assert [t for t, r in enumerate(rows) if r >= 40] == [1]
+    small_seen = set()
+    for r in range(world):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        sl = slice(r * B // world, (r + 1) * B // world)
+        np.testing.assert_allclose(z["s0/pred"], ref[0]["pred"][sl], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(z["s1/pred"], ref[1]["pred"][sl], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(z["s1/top.0.weight"], ref[1]["top.0.weight"], rtol=1e-5, atol=1e-6)
+        got = z["s1/emb.1.weight"]
+        r0, r1 = rows[1] * r // world, rows[1] * (r + 1) // world      # 50 rows over 4 ranks: 12, 13, 12, 13
+        assert got.shape == (r1 - r0, ref[1]["emb.1.weight"].shape[1])
+        np.testing.assert_allclose(got, ref[1]["emb.1.weight"][r0:r1], rtol=1e-6, atol=1e-7)
+        for t in range(len(rows)):
+            if t != 1 and f"s1/emb.{t}.weight" in z.files:
+                np.testing.assert_allclose(z[f"s1/emb.{t}.weight"], ref[1][f"emb.{t}.weight"], rtol=1e-6, atol=1e-7)
+                small_seen.add(t)
+        assert int(z["reduce_scatter_calls"]) == 2 and int(z["allgather_calls"]) == 2 and int(z["alltoall_calls"]) == 4
+    assert small_seen == {0, 2, 3}
+
+
 def _strategy_text(entries):
     """The reference's text format [ref: src/runtime/strategy.cc:147-189]: count, then per op name / device type /
     nDims / dims / number of ids / ids, one per line, lists tab-separated."""

@@ -259,6 +259,45 @@ def test_two_ranks_on_one_gpu_column_sharded_table(hip, tmp_path):
     assert sorted(small_owner) == [0, 2, 3]
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_row_sharded_table(hip, tmp_path, world):
+    """--row-shard-rows on the HIP kernels (BASELINE configs[4]'s reduce-scatter variant at toy size): every rank holds
+    50 / world rows plus the zero row, gathers partial bag sums for the global batch, the reduce-scatter leaves each rank
+    its samples; backward all-gathers the gradients and the fused update touches the local rows only."""
+    z = _run_two_ranks_on_one_gpu(tmp_path, "row", world=world)
+    m, h = H.build_golden_dlrm(HIP, overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    B = int(h["g"]["B"])
+    rows = list(h["g"]["rows"])
+    for r in range(world):
+        sl = slice(r * B // world, (r + 1) * B // world)
+        for step in range(2):
+            np.testing.assert_allclose(z[r][f"s{step}/pred"], ref[step]["pred"][sl], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(z[r]["s1/top.0.weight"], ref[1]["top.0.weight"], rtol=1e-5, atol=1e-6)
+        r0, r1 = rows[1] * r // world, rows[1] * (r + 1) // world
+        got = z[r]["s1/emb.1.weight"]
+        assert got.shape[0] == r1 - r0
+        np.testing.assert_allclose(got, ref[1]["emb.1.weight"][r0:r1], rtol=1e-6, atol=1e-7)
+        assert int(z[r]["reduce_scatter_calls"]) == 2 and int(z[r]["allgather_calls"]) == 2
+
+
+def test_single_rank_rccl_reduce_scatter_path_on_gpu(hip, tmp_path):
+    """The same row-sharded step with a 1-rank RCCL group served from the C++ host layer: ncclReduceScatter /
+    ncclAllGather are really enqueued on the model's side stream (with one rank they move the data unchanged)."""
+    worker = os.path.join(ROOT, "tests", "_dist_worker_gpu.py")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29450 + os.getpid() % 400))
+    r = subprocess.run(["python", worker, str(tmp_path), "direct", "row"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    z = np.load(os.path.join(tmp_path, "rank0.npz"))
+    assert int(z["reduce_scatter_calls"]) == 2 and int(z["allgather_calls"]) == 2 and int(z["alltoall_calls"]) == 4
+    m, h = H.build_golden_dlrm(HIP, overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    for k, v in ref[1].items():
+        np.testing.assert_allclose(z[f"s1/{k}"], v, rtol=1e-5, atol=1e-6, err_msg=k)
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_ranks_on_one_gpu_kaggle_shape(hip, tmp_path, world):
     """The same at the Criteo-Kaggle shape with 2048 samples per rank (2 ranks: 13 tables each, 4096 lookups per table;

@@ -70,6 +70,21 @@ def test_rng_kernels_bit_exact(hip, oracle):
     assert h[0] == 1.5 and (h[1:] == -2.0).all()
 
 
+def test_embedding_localize_rows_bit_exact(hip, oracle):
+    """Row-wise sharded table: ids relative to the local block, everything else -> the zero row; in place too."""
+    rng = np.random.default_rng(8)
+    for n, R, r0, nloc in ((1, 10, 0, 10), (100003, 200_000_000, 75_000_000, 25_000_000), (4096, 50, 12, 13), (777, 9, 9, 0)):
+        idx = rng.integers(0, R, n)
+        d = dev(idx)
+        out = torch.empty_like(d)
+        hip.call("ffh_embedding_localize_rows", d, out, n, r0, nloc, None)
+        assert np.array_equal(host(out), oracle.embedding_localize_rows(idx, r0, nloc))
+        hip.call("ffh_embedding_localize_rows", d, d, n, r0, nloc, None)
+        assert np.array_equal(host(d), host(out))
+    with pytest.raises(capi.FFHError):
+        hip.call("ffh_embedding_localize_rows", None, None, 5, 0, 1, None)
+
+
 # ---------------------------------------------------------------------------
 # Embedding forward
 # ---------------------------------------------------------------------------

@@ -390,3 +390,36 @@ def test_rng_contract(oracle):
         assert y[i] == float((h >> 33) & 1)
     w = oracle.init_uniform(1000, 5, -0.25, 0.25)
     assert w.min() >= -0.25 and w.max() < 0.25 and abs(float(w.mean())) < 0.02
+
+
+def test_row_sharded_table_equals_whole_table(oracle):
+    """The row-wise sharding arithmetic (this build's extension, SURVEY 8e 'reduce-scatter variant') on plain arrays:
+    G row blocks, each followed by a zero row; ids localized per block; the blocks' partial bag sums add up to the
+    whole-table gather (bit-exact for bag 1, 1e-6 for longer bags whose adds are re-associated), and per-block fused
+    updates with the zero row discarded rebuild the whole-table update (1e-6: a row's gradients are the same and in the
+    same order, but the canonical order cuts runs at fixed positions of the sorted list, which differ per block)."""
+    rng = np.random.default_rng(3)
+    R, D, B, G = 53, 8, 64, 4
+    w = rng.standard_normal((R, D)).astype(np.float32)
+    for L in (1, 3):
+        idx = rng.integers(0, R, (B, L))
+        g = rng.standard_normal((B, D)).astype(np.float32)
+        whole = oracle.embedding_fwd(idx, w)
+        whole_upd = oracle.embedding_bwd_sgd_fused(idx, g, w, 0.05)
+        total = np.zeros((B, D), np.float32)
+        rebuilt = []
+        for r in range(G):
+            r0, r1 = R * r // G, R * (r + 1) // G
+            loc = oracle.embedding_localize_rows(idx, r0, r1 - r0)
+            exp = np.where((idx >= r0) & (idx < r1), idx - r0, r1 - r0)
+            assert np.array_equal(loc, exp)
+            block = np.concatenate([w[r0:r1], np.zeros((1, D), np.float32)])
+            total = total + oracle.embedding_fwd(loc, block)
+            rebuilt.append(oracle.embedding_bwd_sgd_fused(loc, g, block, 0.05)[:-1])
+        if L == 1:
+            assert np.array_equal(total, whole)
+        else:
+            np.testing.assert_allclose(total, whole, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(np.concatenate(rebuilt), whole_upd, rtol=1e-6, atol=1e-7)
+        untouched = np.setdiff1d(np.arange(R), idx.reshape(-1))
+        assert np.array_equal(np.concatenate(rebuilt)[untouched], w[untouched])
