@@ -92,7 +92,7 @@ def mlp_flops_per_sample(w):
     return 3 * f   # forward + dX + dW
 
 
-def cpu_baseline_leg(name, per_gpu_batch, budget_s):
+def cpu_baseline_leg(name, per_gpu_batch, budget_s, out):
     """One timed leg in its own process (OMP_NUM_THREADS is read when libgomp starts): prints {steps, seconds, threads}."""
     from oracle import oracle
     from dlrm_flexflow_amd import ffmodel
@@ -112,7 +112,7 @@ def cpu_baseline_leg(name, per_gpu_batch, budget_s):
     app.model.sync()
     dt = time.perf_counter() - t0
     app.close()
-    print("CPU_LEG " + json.dumps({"steps": n, "seconds": dt, "threads": threads}), flush=True)
+    print("CPU_LEG " + json.dumps({"steps": n, "seconds": dt, "threads": threads}), file=out, flush=True)
 
 
 def cpu_baseline(w, args, budget_s=21.0):
@@ -211,8 +211,13 @@ def main():
     ap.add_argument("--leg-budget", type=float, default=7.0, help=argparse.SUPPRESS)
     ap.add_argument("--shim-flags", default="", help="extra FFConfig flags for A/B runs, e.g. '--serial-dw --no-overlap'")
     args = ap.parse_args()
+    # stdout carries the ONE JSON line and nothing else: the C++ driver's printf banner ("[DLRM] ...", flushed by the C
+    # runtime at exit) is sent to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.cpu_baseline_leg:          # child of cpu_baseline(): host only, never touches the GPU
-        cpu_baseline_leg(args.workload, args.per_gpu_batch, args.leg_budget)
+        cpu_baseline_leg(args.workload, args.per_gpu_batch, args.leg_budget, json_out)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -345,7 +350,7 @@ def main():
                 out["kernels"]["embedding_gather_terabyte_shape"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args)
-    print(json.dumps(out), flush=True)
+    print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
