@@ -58,9 +58,13 @@ def workload(name: str, per_gpu_batch: int | None, world: int):
         b = per_gpu_batch or 4096
         return dict(name="giant-table-column-wise", rows="200000000", D=256, bot="13-512-256", top="512-512-256-1", B=b * world,
                     extra=["--column-shard-rows", "100000000"])
-    if name == "mlperf":       # BASELINE configs[3]: dot interaction (all 27 x 27 pairwise products; the lower-triangle pick of
-        b = per_gpu_batch or 8192   # MLPerf has no reference op), emb_dim 128, 65536 samples over 8 GPUs
-        return dict(name="mlperf-dlrm-dot", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="857-1024-1024-512-256-1", B=b * world,
+    if name == "mlperf":       # BASELINE configs[3]: dot interaction keeping the 351 products i > j of the 27 x 27 matrix
+        b = per_gpu_batch or 8192   # (FFModel::tril; top MLP input 128 + 351 = 479), emb_dim 128, 65536 samples over 8 GPUs
+        return dict(name="mlperf-dlrm-dot", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="479-1024-1024-512-256-1", B=b * world,
+                    extra=["--arch-interaction-op", "dot-tril"])
+    if name == "mlperf-allpairs":   # the same with all 729 products, the composition of the reference's op tests (test_harness.py:125-177)
+        b = per_gpu_batch or 8192
+        return dict(name="mlperf-dlrm-dot-allpairs", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="857-1024-1024-512-256-1", B=b * world,
                     extra=["--arch-interaction-op", "dot"])
     if name == "giant-row":    # the same table split ROW-wise: partial bag sums + reduce-scatter forward, all-gather backward
         b = per_gpu_batch or 4096   # (configs[4]'s "reduce-scatter stress"; one rank: pass --force-exchange to walk the collectives)
@@ -87,7 +91,8 @@ def pmc_traffic(key):
 def mlp_flops_per_sample(w):
     bot = [int(x) for x in w["bot"].split("-")]
     top = [int(x) for x in w["top"].split("-")]
-    top[0] = bot[-1] + len(w["rows"].split("-")) * w["D"]     # input width comes from the tensor, not the flag
+    if "--arch-interaction-op" not in w.get("extra", []):
+        top[0] = bot[-1] + len(w["rows"].split("-")) * w["D"]     # cat: input width comes from the tensor, not the flag
     f = sum(2 * a * b for a, b in zip(bot[:-1], bot[1:])) + sum(2 * a * b for a, b in zip(top[:-1], top[1:]))
     return 3 * f   # forward + dX + dW
 
@@ -197,7 +202,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="kaggle", help="kaggle (default, BASELINE configs[1]) | tiny | terabyte | mlperf | giant | giant-row")
+    ap.add_argument("--workload", default="kaggle", help="kaggle (default, BASELINE configs[1]) | tiny | terabyte | mlperf | giant | giant-row | mlperf-allpairs")
     ap.add_argument("--per-gpu-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="(default) kept for older command lines")
@@ -315,7 +320,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{w['name']}: {T} tables (rows {w['rows']}), emb_dim {D}, bag 1, bot {w['bot']}, top {w['top']}, "
-                               f"{'dot' if 'dot' in w.get('extra', []) else 'cat'} interaction, SGD lr 0.01, MSE loss",
+                               f"{'dot (strict lower triangle)' if 'dot-tril' in w.get('extra', []) else 'dot (all pairs)' if 'dot' in w.get('extra', []) else 'cat'} interaction, SGD lr 0.01, MSE loss",
                    "global_batch": w["B"], "per_gpu_batch": w["B"] // world,
                    "parallelism": ("single GPU, hipGraph-replayed step" if uses_graph else "single GPU, eager launches on 3 HIP streams") if world == 1 else
                                   f"{layout} over {world} ranks, MLPs data-parallel (1 all-reduce); {collectives}",

@@ -351,6 +351,34 @@ __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ d, 
 
 }  // namespace
 
+namespace {
+// strict lower triangle of [n][n] per sample.  The pair table p -> i*n + j is built once per workgroup in LDS; threads
+// walk the kept entries of all samples in output order, so stores (and the gradient loads of the backward) are
+// contiguous and a row's kept entries are read as one run.
+constexpr int kTrilMaxN = 64;
+template <bool BWD>
+__global__ __launch_bounds__(256) void tril_kernel(float* __restrict__ tri, int64_t tri_ld, float* __restrict__ full, int64_t batch, int n) {
+  __shared__ uint16_t tab[kTrilMaxN * (kTrilMaxN - 1) / 2];
+  const int P = n * (n - 1) / 2;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+    while (i * (i - 1) / 2 > p) i--;
+    while ((i + 1) * i / 2 <= p) i++;
+    tab[p] = (uint16_t)(i * n + (p - i * (i - 1) / 2));
+  }
+  __syncthreads();
+  const int64_t nn = (int64_t)n * n, total = batch * P;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+    const int64_t b = q / P;
+    const int p = (int)(q - b * P);
+    float* f = full + b * nn + tab[p];
+    float* t = tri + b * tri_ld + p;
+    if (BWD) *f = *f + *t;
+    else *t = *f;
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int ffh_concat_fwd(ffh_ctx* c, float* out, int64_t out_blk, const float* const* ins, const int64_t* in_blk,
@@ -373,6 +401,21 @@ int ffh_transpose_fwd(ffh_ctx* c, float* out, const float* in, int nd, const int
 }
 int ffh_transpose_bwd(ffh_ctx* c, float* in_grad, const float* out_grad, int nd, const int64_t* in_dims, const int* perm, ffh_stream s) {
   return transpose_launch(c, in_grad, out_grad, nd, in_dims, perm, true, s);
+}
+
+int ffh_tril_fwd(ffh_ctx* c, float* out, int64_t out_ld, const float* in, int64_t batch, int n, ffh_stream s) {
+  FFH_REQUIRE(c, batch >= 0 && n >= 2 && n <= kTrilMaxN && out_ld >= (int64_t)n * (n - 1) / 2 && ((out && in) || batch == 0), "tril_fwd: bad args");
+  if (batch == 0) return FFH_OK;
+  hipLaunchKernelGGL((tril_kernel<false>), dim3(ffh_grid(batch * ((int64_t)n * (n - 1) / 2), 1024, 4096)), dim3(256), 0, as_stream(s), out, out_ld, const_cast<float*>(in), batch, n);
+  FFH_LAUNCH_CHECK(c, "tril_fwd");
+  return FFH_OK;
+}
+int ffh_tril_bwd(ffh_ctx* c, float* in_grad, const float* out_grad, int64_t grad_ld, int64_t batch, int n, ffh_stream s) {
+  FFH_REQUIRE(c, batch >= 0 && n >= 2 && n <= kTrilMaxN && grad_ld >= (int64_t)n * (n - 1) / 2 && ((in_grad && out_grad) || batch == 0), "tril_bwd: bad args");
+  if (batch == 0) return FFH_OK;
+  hipLaunchKernelGGL((tril_kernel<true>), dim3(ffh_grid(batch * ((int64_t)n * (n - 1) / 2), 1024, 4096)), dim3(256), 0, as_stream(s), const_cast<float*>(out_grad), grad_ld, in_grad, batch, n);
+  FFH_LAUNCH_CHECK(c, "tril_bwd");
+  return FFH_OK;
 }
 
 int ffh_mse_bwd(ffh_ctx* c, float* lg, const float* logit, const float* label, int64_t n, float scale, ffh_stream s) {

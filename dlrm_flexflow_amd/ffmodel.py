@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
         "flexflow_model_add_concat": (H, [H, I, C.POINTER(H), I, C.c_char_p]),
         "flexflow_model_add_batch_matmul": (H, [H, H, H, I, I]),
         "flexflow_model_add_flat": (H, [H, H, C.c_char_p]),
+        "flexflow_model_add_tril": (H, [H, H, C.c_char_p]),
         "flexflow_model_add_transpose": (H, [H, H, I, IP, C.c_char_p]),
         "flexflow_model_add_reshape": (H, [H, H, I, IP, C.c_char_p]),
         "flexflow_zero_initializer_create": (H, []), "flexflow_uniform_initializer_create": (H, [I, F, F]),
@@ -236,6 +237,10 @@ class FFModel:
 
     def flat(self, input: Tensor, name=None) -> Tensor:
         return Tensor(lib().flexflow_model_add_flat(self.h, input.h, name.encode() if name else None), self)
+
+    def tril(self, input: Tensor, name=None) -> Tensor:
+        """Strict lower triangle of [batch][n][n] -> [batch][n (n - 1) / 2] (MLPerf-DLRM's pick of the pairwise dots)."""
+        return Tensor(lib().flexflow_model_add_tril(self.h, input.h, name.encode() if name else None), self)
 
     def transpose(self, input: Tensor, perm, name=None) -> Tensor:
         p = (C.c_int * len(perm))(*perm)

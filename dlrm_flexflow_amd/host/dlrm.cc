@@ -83,13 +83,14 @@ Tensor create_emb(FFModel* model, const Tensor& input, int input_dim, int output
 // "dot" here is the composition the reference's own op tests spell out for the pairwise interaction
 // [ref: tests/ops/test_harness.py:125-177]: cat -> reshape [B][C][D] -> transpose -> batch_matmul -> flat,
 // concatenated with the bottom-MLP output: [x | vec(Z Z^T)], width D + C*C with C = 1 + #tables.
-// (MLPerf's variant keeps only the strict lower triangle; the reference has no op for that extraction.)
+// "dot-tril" is MLPerf-DLRM's variant: only the strict lower triangle of Z Z^T is kept (C (C - 1) / 2 products: 351 of 729
+// for 26 tables), through FFModel::tril -- an operator the reference does not have; width D + C (C - 1) / 2 (479).
 Tensor interact_features(FFModel* model, const Tensor& x, const std::vector<Tensor>& ly, std::string interaction) {
   std::vector<Tensor> inputs;
   inputs.push_back(x);
   for (size_t i = 0; i < ly.size(); i++) inputs.push_back(ly[i]);
   if (interaction == "cat") return model->concat((int)inputs.size(), inputs.data(), 1 /*axis*/);
-  if (interaction == "dot") {
+  if (interaction == "dot" || interaction == "dot-tril") {
     const int batch = x.adim[1], d = x.adim[0], c = (int)inputs.size();
     for (const Tensor& t : inputs)
       if (t.adim[0] != d) {
@@ -100,11 +101,11 @@ Tensor interact_features(FFModel* model, const Tensor& x, const std::vector<Tens
     Tensor z = model->reshape(cat, {batch, c, d});
     Tensor zt = model->transpose(z, {0, 2, 1});
     Tensor p = model->batch_matmul(z, zt);            // [batch][c][c]
-    Tensor pf = model->flat(p);
+    Tensor pf = interaction == "dot" ? model->flat(p) : model->tril(p);
     Tensor both[2] = {x, pf};
     return model->concat(2, both, 1 /*axis*/);
   }
-  fprintf(stderr, "FATAL: --arch-interaction-op %s: 'cat' or 'dot'\n", interaction.c_str());
+  fprintf(stderr, "FATAL: --arch-interaction-op %s: 'cat', 'dot' or 'dot-tril'\n", interaction.c_str());
   abort();
 }
 

@@ -47,7 +47,7 @@ enum MetricsType {
   METRICS_ROOT_MEAN_SQUARED_ERROR = 1016,
   METRICS_MEAN_ABSOLUTE_ERROR = 1032,
 };
-enum OperatorType { OP_INPUT, OP_LINEAR, OP_EMBEDDING, OP_CONCAT, OP_BATCHMATMUL, OP_TRANSPOSE, OP_RESHAPE, OP_FLAT };
+enum OperatorType { OP_INPUT, OP_LINEAR, OP_EMBEDDING, OP_CONCAT, OP_BATCHMATMUL, OP_TRANSPOSE, OP_RESHAPE, OP_FLAT, OP_TRIL };
 
 #define MAX_TENSOR_DIM 4
 #define MAX_NUM_INPUTS 256
@@ -344,6 +344,16 @@ class Reshape : public Op {     // also serves Flat: a copy forward, an accumula
   void backward(const FFModel&) override;
   bool is_view;                 // the output IS the input's buffer (contiguous input read by nothing else): no copy either way
 };
+// Strict lower triangle of [batch][n][n] -> [batch][n (n - 1) / 2]: the extraction MLPerf-DLRM's dot interaction applies to
+// Z Z^T.  No reference operator (its dot interaction is a TODO, examples/cpp/DLRM/dlrm.cc:53-54); parity is against torch.
+class Tril : public Op {
+ public:
+  Tril(FFModel& model, const Tensor& input, const char* name);
+  void create_output_and_partition(FFModel&) override {}
+  void forward(const FFModel&) override;
+  void backward(const FFModel&) override;
+  int n;
+};
 
 // ---------------------------------------------------------------------------------------------
 // A host thread that issues the launches of one auxiliary HIP stream.  The training step is bound by
@@ -385,6 +395,7 @@ class FFModel {
                Initializer* bias_initializer = NULL, const char* name = NULL);
   Tensor concat(int n, const Tensor* tensors, int axis, const char* name = NULL);
   Tensor flat(const Tensor& input, const char* name = NULL);
+  Tensor tril(const Tensor& input, const char* name = NULL);   // strict lower triangle of [batch][n][n] (this build's addition)
   Tensor transpose(const Tensor& input, const std::vector<int>& perm, const char* name = NULL);
   Tensor reshape(const Tensor& input, const std::vector<int>& shape, const char* name = NULL);
   template <int NDIM>

@@ -340,6 +340,7 @@ std::string FFModel::get_operator_type_name(OperatorType type) const {
     case OP_TRANSPOSE: return "Transpose";
     case OP_RESHAPE: return "Reshape";
     case OP_FLAT: return "Flat";
+    case OP_TRIL: return "Tril";
     default: return "Unknown";
   }
 }
@@ -877,6 +878,32 @@ void Reshape::backward(const FFModel& ff) {
   }
 }
 
+Tril::Tril(FFModel& model, const Tensor& input, const char* name) : Op(model, OP_TRIL, name, 1, &input) {
+  if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
+  if (input.numDim != 3 || input.adim[0] != input.adim[1]) die("%s: input must be [batch][n][n]", this->name);
+  n = input.adim[0];
+  if (n < 2 || n > 64) die("%s: n = %d, supported 2..64", this->name, n);
+  outputs[0].numDim = 2;
+  outputs[0].adim[0] = n * (n - 1) / 2;
+  outputs[0].adim[1] = input.adim[2];
+}
+void Tril::forward(const FFModel& ff) {
+  const Tensor &x = inputs[0], &y = outputs[0];
+  if (!contiguous(x.impl, x) || !y.impl->pieces.empty()) die("%s: input must be contiguous", name);
+  ff.check(ff.api->ffh_tril_fwd(ff.ctx, (float*)y.impl->ptr, y.impl->ld, (const float*)x.impl->ptr, x.impl->rows_local / n, n, ff.stream), name);
+}
+void Tril::backward(const FFModel& ff) {
+  const Tensor &x = inputs[0], &y = outputs[0];
+  if (!x.impl->grad) return;
+  if (x.impl->grad_ld != x.adim[0]) die("%s: input gradient must be contiguous", name);
+  ff.check(ff.api->ffh_tril_bwd(ff.ctx, x.impl->grad, y.impl->grad, y.impl->grad_ld, x.impl->rows_local / n, n, ff.stream), name);
+}
+Tensor FFModel::tril(const Tensor& input, const char* name) {
+  Tril* t = new Tril(*this, input, name);
+  t->layer_index = (int)layers.size();
+  layers.push_back(t);
+  return t->outputs[0];
+}
 Tensor FFModel::transpose(const Tensor& input, const std::vector<int>& perm, const char* name) {
   Transpose* t = new Transpose(*this, input, perm, name);
   t->layer_index = (int)layers.size();
@@ -1183,7 +1210,7 @@ void FFModel::allocate() {
     int64_t off = 0;
     for (int i = 0; i < c->numInputs; i++) {
       const Tensor& in = c->inputs[i];
-      const bool producer_ok = in.owner_op && (in.owner_op->op_type == OP_LINEAR || in.owner_op->op_type == OP_EMBEDDING);
+      const bool producer_ok = in.owner_op && (in.owner_op->op_type == OP_LINEAR || in.owner_op->op_type == OP_EMBEDDING || in.owner_op->op_type == OP_TRIL);
       // (a row-sharded table's output is the contiguous receive buffer of its reduce-scatter: own storage as well)
       const bool via_exchange = exchange && in.owner_op && in.owner_op->op_type == OP_EMBEDDING;
       if (producer_ok && !via_exchange && consumers[in.impl] == 1 && !alias_of.count(in.impl)) alias_of[in.impl] = {c, off};
@@ -1283,7 +1310,7 @@ void FFModel::allocate() {
   need_zero_gsend = false;
   for (Op* op : layers) {
     if (consumers[op->outputs[0].impl] > 1) need_zero_act_grads = true;           // several ops add into its gradient
-    if (op->op_type == OP_BATCHMATMUL || op->op_type == OP_TRANSPOSE || op->op_type == OP_RESHAPE || op->op_type == OP_FLAT)
+    if (op->op_type == OP_BATCHMATMUL || op->op_type == OP_TRANSPOSE || op->op_type == OP_RESHAPE || op->op_type == OP_FLAT || op->op_type == OP_TRIL)
       need_zero_act_grads = true;                                                // these accumulate into their operands' gradients
     if (Linear* li = dynamic_cast<Linear*>(op)) {
       li->dx_overwrite = consumers[li->inputs[0].impl] == 1;

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows */
+#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_fwd / ffh_tril_bwd */
 
 /* status codes */
 #define FFH_OK               0
@@ -325,6 +325,17 @@ int ffh_transpose_fwd(ffh_ctx* ctx, float* out, const float* in, int ndim, const
 int ffh_transpose_bwd(ffh_ctx* ctx, float* in_grad, const float* out_grad, int ndim, const int64_t* in_dims, const int* perm, ffh_stream s);
 
 /* ------------------------------------------------------------------ */
+/* Strict lower triangle of the pairwise-dot matrix (MLPerf-DLRM's interaction keeps the 351 products
+ * i > j of the 27 x 27 matrix; the reference has no operator for it -- its dot interaction is a TODO,
+ * [ref: examples/cpp/DLRM/dlrm.cc:53-54] -- so parity is against torch: Z[:, li, lj] with tril_indices(n, n, -1)) */
+/* ------------------------------------------------------------------ */
+/* out[b][p] = in[b][i][j], p = i (i - 1) / 2 + j over i > j in row-major order; in [batch][n][n] contiguous,
+ * out [batch][out_ld] with out_ld >= n (n - 1) / 2 (it may be a column slice of a concat buffer); 2 <= n <= 64 */
+int ffh_tril_fwd(ffh_ctx* ctx, float* out, int64_t out_ld, const float* in, int64_t batch, int n, ffh_stream s);
+/* in_grad[b][i][j] += out_grad[b][p] for i > j; the other entries of in_grad are left as they are */
+int ffh_tril_bwd(ffh_ctx* ctx, float* in_grad, const float* out_grad, int64_t grad_ld, int64_t batch, int n, ffh_stream s);
+
+/* ------------------------------------------------------------------ */
 /* Loss, metrics, optimizer                                           */
 /* ------------------------------------------------------------------ */
 /* mean_squared_error_avg_loss_backward + scale_kernel(0, scale)
@@ -383,7 +394,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
   X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_second_stream_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
-  X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
+  X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 
 #endif /* FF_HIP_H_ */

@@ -607,6 +607,31 @@ int ffh_transpose_bwd(ffh_ctx* c, float* in_grad, const float* out_grad, int nd,
 /* mean_squared_error_avg_loss_backward [ref: src/loss_functions/loss_functions.cu:65-76]
  * then scale_kernel(ptr, n, 0, scale) [ref: :160-166; src/runtime/cuda_helper.cu:33-40]:
  * ptr = (scale - 0)*ptr + 0  == fl(scale * fl(logit - label)) */
+/* strict lower triangle of the pairwise-dot matrix (no reference operator; MLPerf-DLRM / torch: Z[:, li, lj] with
+ * tril_indices(n, n, -1), i.e. i ascending, j < i ascending) */
+int ffh_tril_fwd(ffh_ctx* c, float* out, int64_t out_ld, const float* in, int64_t batch, int n, ffh_stream s) {
+  (void)s;
+  if (batch < 0 || n < 2 || n > 64 || out_ld < (int64_t)n * (n - 1) / 2 || (batch > 0 && (!out || !in))) return fail(c, FFH_ERR_BAD_ARG, "tril_fwd: bad args");
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < batch; b++) {
+    int64_t p = 0;
+    for (int i = 1; i < n; i++)
+      for (int j = 0; j < i; j++) out[b * out_ld + p++] = in[(b * n + i) * n + j];
+  }
+  return FFH_OK;
+}
+int ffh_tril_bwd(ffh_ctx* c, float* in_grad, const float* out_grad, int64_t grad_ld, int64_t batch, int n, ffh_stream s) {
+  (void)s;
+  if (batch < 0 || n < 2 || n > 64 || grad_ld < (int64_t)n * (n - 1) / 2 || (batch > 0 && (!in_grad || !out_grad))) return fail(c, FFH_ERR_BAD_ARG, "tril_bwd: bad args");
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < batch; b++) {
+    int64_t p = 0;
+    for (int i = 1; i < n; i++)
+      for (int j = 0; j < i; j++) in_grad[(b * n + i) * n + j] += out_grad[b * grad_ld + p++];
+  }
+  return FFH_OK;
+}
+
 int ffh_mse_bwd(ffh_ctx* c, float* lg, const float* logit, const float* label, int64_t n, float scale, ffh_stream s) {
   (void)c; (void)s;
   for (int64_t i = 0; i < n; i++) {

@@ -225,6 +225,25 @@ def embedding_localize_rows(idx, row_begin, rows_local):
     return out
 
 
+def tril_fwd(z, out_ld=None, col_off=0):
+    """out[:, col_off : col_off + n(n-1)/2] = strict lower triangle of z [B][n][n]; the rest of out stays 777."""
+    z = _f32(z)
+    B, n, _ = z.shape
+    P = n * (n - 1) // 2
+    out_ld = out_ld or P
+    out = np.full((B, out_ld), 777.0, np.float32)
+    lib().call("ffh_tril_fwd", out[:, col_off:], out_ld, z, B, n, None)
+    return out
+
+
+def tril_bwd(g, in_grad):
+    """Returns in_grad with g [B][n(n-1)/2] added into its strict lower triangle."""
+    g, out = _f32(g), _f32(in_grad).copy()
+    B, n, _ = out.shape
+    lib().call("ffh_tril_bwd", out, g, g.shape[1], B, n, None)
+    return out
+
+
 def gen_uniform01(count, seed, first):
     p = np.empty(count, np.float32)
     lib().call("ffh_gen_uniform01", p, count, seed, first, None)

@@ -7,8 +7,9 @@ from dlrm_flexflow_amd import ffmodel
 
 
 class TorchDotDLRM(torch.nn.Module):
-    def __init__(self, bot, top, rows, D):
+    def __init__(self, bot, top, rows, D, tril=False):
         super().__init__()
+        self.tril = tril
         self.bot = torch.nn.ModuleList([torch.nn.Linear(bot[i], bot[i + 1]) for i in range(len(bot) - 1)])
         self.emb = torch.nn.ModuleList([torch.nn.EmbeddingBag(r, D, mode="sum") for r in rows])
         self.top = torch.nn.ModuleList([torch.nn.Linear(top[i], top[i + 1]) for i in range(len(top) - 1)])
@@ -21,19 +22,23 @@ class TorchDotDLRM(torch.nn.Module):
         cat = torch.cat([x] + ly, dim=1)
         z = cat.reshape(x.shape[0], 1 + len(ly), x.shape[1])
         p = torch.bmm(z, z.transpose(1, 2))
-        out = torch.cat([x, p.flatten(1, 2)], dim=1)
+        if self.tril:                                  # facebookresearch/dlrm's interact_features: Z[:, li, lj], i > j
+            li, lj = torch.tril_indices(p.shape[1], p.shape[2], offset=-1)
+            out = torch.cat([x, p[:, li, lj]], dim=1)
+        else:
+            out = torch.cat([x, p.flatten(1, 2)], dim=1)
         for i, l in enumerate(self.top):
             out = l(out)
             out = torch.sigmoid(out) if i == len(self.top) - 1 else torch.relu(out)
         return out
 
 
-def run_dot_dlrm(backend, steps=2, trace=False, B=24, D=8, rows=(11, 40, 5), bot=(6, 16, 8)):
+def run_dot_dlrm(backend, steps=2, trace=False, B=24, D=8, rows=(11, 40, 5), bot=(6, 16, 8), tril=False):
     C = 1 + len(rows)
-    top = (D + C * C, 20, 1)
+    top = (D + (C * (C - 1) // 2 if tril else C * C), 20, 1)
     args = ["--backend", backend, "-b", str(B), "--arch-sparse-feature-size", str(D), "--arch-embedding-size",
             "-".join(map(str, rows)), "--arch-mlp-bot", "-".join(map(str, bot)), "--arch-mlp-top", "-".join(map(str, top)),
-            "--arch-interaction-op", "dot", "--data-size", str(B), "--embedding-bag-size", "2"]
+            "--arch-interaction-op", "dot-tril" if tril else "dot", "--data-size", str(B), "--embedding-bag-size", "2"]
     app = ffmodel.DLRM(args)
     m = app.model
     # read the seeded state out of the shim and mirror it in torch
@@ -41,8 +46,8 @@ def run_dot_dlrm(backend, steps=2, trace=False, B=24, D=8, rows=(11, 40, 5), bot
     names = [m.layer_name(i) for i in range(m.num_layers)]
     dense_layers = [i for i, n in enumerate(names) if n.startswith("Dense")]
     emb_layers = [i for i, n in enumerate(names) if n.startswith("Embedding")]
-    assert [n.split("_")[0] for n in names] == ["Dense"] * nb + ["Embedding"] * T + ["Concat", "Reshape", "Transpose", "BatchMatmul", "Flat", "Concat"] + ["Dense"] * 2
-    tm = TorchDotDLRM(bot, top, rows, D)
+    assert [n.split("_")[0] for n in names] == ["Dense"] * nb + ["Embedding"] * T + ["Concat", "Reshape", "Transpose", "BatchMatmul", "Tril" if tril else "Flat", "Concat"] + ["Dense"] * 2
+    tm = TorchDotDLRM(bot, top, rows, D, tril=tril)
     with torch.no_grad():
         for k, li in enumerate(dense_layers):
             lin = tm.bot[k] if k < nb else tm.top[k - nb]

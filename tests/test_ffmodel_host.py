@@ -49,11 +49,13 @@ def test_launch_worker_threads_on_cpu(monkeypatch):
     m.close()
 
 
-def test_dot_interaction_matches_torch():
-    """--arch-interaction-op dot (Reshape / Transpose / BatchMatmul / Flat composition):
+@pytest.mark.parametrize("tril", [False, True])
+def test_dot_interaction_matches_torch(tril):
+    """--arch-interaction-op dot (Reshape / Transpose / BatchMatmul / Flat composition) and dot-tril
+    (MLPerf-DLRM's strict lower triangle of Z Z^T, SURVEY 8a-8: torch's Z[:, li, lj] is the only oracle there is):
     predictions and every parameter after warm-up + 2 steps against a torch model, 1e-5."""
     import dot_helpers
-    out, got, exp = dot_helpers.run_dot_dlrm(H.oracle_backend(), steps=2)
+    out, got, exp = dot_helpers.run_dot_dlrm(H.oracle_backend(), steps=2, tril=tril)
     for g, e in out:
         for k in g:
             np.testing.assert_allclose(g[k], e[k], rtol=1e-5, atol=1e-6, err_msg=k)
@@ -129,7 +131,7 @@ def test_driver_rejects_what_the_reference_rejects():
     base = [exe, "--backend", H.oracle_backend(), "-b", "8", "--arch-embedding-size", "10-10", "--arch-sparse-feature-size", "4",
             "--arch-mlp-bot", "3-4", "--arch-mlp-top", "12-1"]
     r = subprocess.run(base + ["--arch-interaction-op", "sum"], capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "'cat' or 'dot'" in r.stderr
+    assert r.returncode != 0 and "'cat', 'dot' or 'dot-tril'" in r.stderr
     r = subprocess.run(base + ["--dataset", "x.h5"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "HDF5" in r.stderr
     r = subprocess.run(base + ["-ll:gpu", "4"], capture_output=True, text=True, timeout=60)

@@ -595,6 +595,27 @@ def test_transpose_bit_exact(hip, dims, perm):
     np.testing.assert_array_equal(host(ig), ig0 + np.transpose(g, np.argsort(perm)))
 
 
+@pytest.mark.parametrize("B,n", [(1, 2), (33, 5), (2048, 27), (257, 64)])
+def test_tril_bit_exact(hip, oracle, B, n):
+    """Strict lower triangle of [B][n][n] (MLPerf-DLRM's pick of the pairwise dots), into a column slice of a wider
+    buffer; backward adds into the kept entries only.  Copies and single adds: bit-exact with the oracle."""
+    rng = np.random.default_rng(B + n)
+    P = n * (n - 1) // 2
+    z = rng.standard_normal((B, n, n)).astype(np.float32)
+    out = torch.full((B, P + 5), 777.0, dtype=torch.float32, device=DEV)
+    hip.call("ffh_tril_fwd", out[:, 3:], P + 5, dev(z), B, n, None)
+    assert bits_equal(host(out), oracle.tril_fwd(z, out_ld=P + 5, col_off=3))
+    g = rng.standard_normal((B, P + 5)).astype(np.float32)
+    base = rng.standard_normal((B, n, n)).astype(np.float32)
+    gd, bd = dev(g), dev(base)
+    hip.call("ffh_tril_bwd", bd, gd[:, 3:], P + 5, B, n, None)
+    assert bits_equal(host(bd), oracle.tril_bwd(np.ascontiguousarray(g[:, 3:3 + P]), base))
+    with pytest.raises(capi.FFHError):
+        hip.call("ffh_tril_fwd", out, P - 1, dev(z), B, n, None)      # out_ld too small
+    with pytest.raises(capi.FFHError):
+        hip.call("ffh_tril_fwd", out, P + 5, dev(z), B, 65, None)     # n > 64
+
+
 def test_adam_and_zero_grad(hip, oracle):
     """ffh_adam_update / ffh_sgd_update_ex: bit-exact with the oracle, within 1e-5 of torch.optim.Adam (fixture)."""
     g = golden("adam_torch")

@@ -423,3 +423,22 @@ def test_row_sharded_table_equals_whole_table(oracle):
         np.testing.assert_allclose(np.concatenate(rebuilt), whole_upd, rtol=1e-6, atol=1e-7)
         untouched = np.setdiff1d(np.arange(R), idx.reshape(-1))
         assert np.array_equal(np.concatenate(rebuilt)[untouched], w[untouched])
+
+
+@pytest.mark.parametrize("n", [2, 5, 27, 64])
+def test_tril_matches_torch(oracle, n):
+    """Strict lower triangle of the pairwise-dot matrix (no reference op): torch's Z[:, li, lj] with
+    tril_indices(n, n, -1); the backward adds into the kept entries only.  Pure copies and x + g: bit-exact."""
+    import torch
+    rng = np.random.default_rng(n)
+    B, P = 7, n * (n - 1) // 2
+    z = rng.standard_normal((B, n, n)).astype(np.float32)
+    li, lj = torch.tril_indices(n, n, offset=-1)
+    got = oracle.tril_fwd(z, out_ld=P + 3, col_off=2)
+    assert np.array_equal(got[:, 2:2 + P], z[:, li.numpy(), lj.numpy()])
+    assert (got[:, :2] == 777).all() and (got[:, 2 + P:] == 777).all()
+    g = rng.standard_normal((B, P)).astype(np.float32)
+    base = rng.standard_normal((B, n, n)).astype(np.float32)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    (zt[:, li, lj] * torch.from_numpy(g)).sum().backward()
+    assert np.array_equal(oracle.tril_bwd(g, base), base + zt.grad.numpy())
