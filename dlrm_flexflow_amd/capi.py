@@ -113,6 +113,8 @@ _SIGS = {
     "ffh_transpose_bwd": (I, [P, P, P, I, C.POINTER(L), C.POINTER(I), P]),
     "ffh_tril_fwd": (I, [P, P, L, P, L, I, P]),
     "ffh_tril_bwd": (I, [P, P, P, L, L, I, P]),
+    "ffh_dot_interaction_fwd": (I, [P, P, L, P, L, L, I, I, P]),
+    "ffh_dot_interaction_bwd": (I, [P, P, L, P, L, P, L, L, I, I, I, P]),
     "ffh_mse_bwd": (I, [P, P, P, P, L, F, P]),
     "ffh_metrics_update": (I, [P, P, P, P, L, I, I, P]),
     "ffh_sgd_update": (I, [P, P, P, P, L, F, F, F, I, P]),

@@ -1,0 +1,216 @@
+// interaction.hip -- the pairwise-dot feature interaction of DLRM as ONE kernel each way (north_star: "the pairwise-dot
+// feature interaction ... MFMA-tiled").
+//
+// The reference spells the interaction as an operator chain -- cat -> reshape -> transpose -> batch_matmul -> flatten
+// [ref: tests/ops/test_harness.py:125-177]; its driver leaves it a TODO [ref: examples/cpp/DLRM/dlrm.cc:53-54] -- and
+// MLPerf-DLRM keeps only the strict lower triangle of Z Z^T.  That chain moves each sample's 27 x 128 block through HBM
+// five times forward and eight times backward.  Here a WAVE owns a sample:
+//   forward   Z (c <= 32 rows of d floats) goes straight from global memory into the A and B registers of
+//             v_mfma_f32_32x32x2_f32 -- they are the SAME registers, because B = Z^T: lane (row r, half h) supplies
+//             A(r, k) and B(k, r) = Z(r, k); which k a lane holds is free as long as A and B agree, so every lane
+//             reads its half of a row as 16-byte pieces.  The 32 x 32 accumulator then holds Z Z^T; the entries i > j
+//             leave as runs of consecutive floats (out[d + i (i - 1) / 2 + j]), next to a copy of row 0 (the
+//             bottom-MLP output) in out[0 .. d).
+//   backward  dZ = (G + G^T) Z with G the strict-lower matrix of the incoming gradient, plus the direct path of row 0.
+//             S = G + G^T is assembled per wave in LDS (4.2 KB), A = S (32 x 32), B = Z in 128-column chunks whose
+//             columns are permuted so that a lane loads and stores float4 (column 4 n' + t belongs to lane n' of
+//             MFMA tile t); 64 MFMAs per 128 columns.
+// HBM-bound: 4 (c d + d + c (c - 1) / 2) bytes per sample forward, about twice that backward; the MFMA work (64
+// instructions per sample and direction at d = 128) is a few microseconds at 8192 samples.
+#include "ffh_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxC = 32;           // rows of Z (1 + number of tables)
+
+// lane (r, h) of the wave holds 16 consecutive floats of row r per 32-wide k chunk: floats [32 q + 16 h, 32 q + 16 h + 16)
+template <int VEC>
+__device__ __forceinline__ void load_row_piece(float (&v)[16], const float* row, int k0, int d, bool row_ok) {
+#pragma unroll
+  for (int u = 0; u < 16; u += VEC) {
+    const int k = k0 + u;
+    if (VEC == 4) {
+      if (row_ok && k + 3 < d) {
+        const float4 t = *reinterpret_cast<const float4*>(row + k);
+        v[u] = t.x; v[u + 1] = t.y; v[u + 2] = t.z; v[u + 3] = t.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[u + e] = (row_ok && k + e < d) ? row[k + e] : 0.0f;
+      }
+    } else {
+      v[u] = (row_ok && k < d) ? row[k] : 0.0f;
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* __restrict__ z, int64_t ldz, float* __restrict__ out, int64_t ldo,
+                                                                  int64_t batch, int c, int d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < batch; b += nwaves) {
+    const float* zb = z + b * ldz;
+    const float* row = zb + (int64_t)r * d;
+    const bool row_ok = r < c;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    for (int k0 = 0; k0 < d; k0 += 64) {          // two 32-wide chunks in flight
+      float v0[16], v1[16];
+      load_row_piece<VEC>(v0, row, k0 + 16 * h, d, row_ok);
+      load_row_piece<VEC>(v1, row, k0 + 32 + 16 * h, d, row_ok);
+#pragma unroll
+      for (int u = 0; u < 16; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[u], v0[u], acc, 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 16; u++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[u], v1[u], acc, 0, 0, 0);
+    }
+    float* ob = out + b * ldo;
+    // the bottom-MLP output passes through: out[0 .. d) = Z[0][:]
+    for (int k = lane * VEC; k < d; k += 64 * VEC) {
+      if (VEC == 4 && k + 3 < d) {
+        *reinterpret_cast<float4*>(ob + k) = *reinterpret_cast<const float4*>(zb + k);
+      } else {
+        for (int e = 0; e < VEC && k + e < d; e++) ob[k + e] = zb[k + e];
+      }
+    }
+    // accumulator: lane holds column j = r, rows i = 8 (v / 4) + 4 h + v % 4
+    float* tri = ob + d;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+      if (i < c && r < i) tri[i * (i - 1) / 2 + r] = acc[v];
+    }
+  }
+}
+
+// backward: one wave per sample; s_S[w] is the wave's symmetric 32 x 32 (stride 33) matrix G + G^T
+template <int VEC, bool ACCUM>
+__global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ og, int64_t ldg,
+                                                                  float* __restrict__ zg, int64_t ldzg, int64_t batch, int c, int d) {
+  __shared__ float s_S[4][32 * 33];
+  __shared__ uint16_t s_pair[kMaxC * (kMaxC - 1) / 2];     // p -> i * 33 + j
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int P = c * (c - 1) / 2;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+    while (i * (i - 1) / 2 > p) i--;
+    while ((i + 1) * i / 2 <= p) i++;
+    s_pair[p] = (uint16_t)(i * 33 + (p - i * (i - 1) / 2));
+  }
+  float* S = s_S[wave];
+  for (int e = lane; e < 32 * 33; e += 64) S[e] = 0.0f;      // diagonal and padding stay zero for every sample
+  __syncthreads();
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < batch; b += nwaves) {
+    const float* gb = og + b * ldg;
+    for (int p = lane; p < P; p += 64) {
+      const float g = gb[d + p];
+      const int ij = s_pair[p], i = ij / 33, j = ij - i * 33;
+      S[ij] = g;
+      S[j * 33 + i] = g;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the wave's own LDS writes have landed
+    // A operand: S[r][k], lane (r, h) supplies k = 16 h + s at step s
+    float a[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) a[s] = S[r * 33 + 16 * h + s];
+    __builtin_amdgcn_wave_barrier();
+    const float* zb = z + b * ldz;
+    float* zgb = zg + b * ldzg;
+    for (int n0 = 0; n0 < d; n0 += 128) {
+      // B operand: Z[k][n0 + 4 r + t] for the four MFMA tiles t; lane (r, h) supplies row k = 16 h + s at step s
+      const int col = n0 + 4 * r;
+      f32x16 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.0f;
+#pragma unroll
+      for (int s0 = 0; s0 < 16; s0 += 4) {
+        float bv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int k = 16 * h + s0 + u;
+          const float* p = zb + (int64_t)k * d + col;
+          if (VEC == 4 && k < c && col + 3 < d) {
+            const float4 t4 = *reinterpret_cast<const float4*>(p);
+            bv[u][0] = t4.x; bv[u][1] = t4.y; bv[u][2] = t4.z; bv[u][3] = t4.w;
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; t++) bv[u][t] = (k < c && col + t < d) ? p[t] : 0.0f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0 + u], bv[u][t], acc[t], 0, 0, 0);
+      }
+      // accumulator of tile t: lane holds column col + t, rows i = 8 (v / 4) + 4 h + v % 4
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+        if (i >= c) continue;
+        float o[4] = {acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
+        float* dst = zgb + (int64_t)i * d + col;
+        if (i == 0) {                                          // direct path of the bottom-MLP output
+#pragma unroll
+          for (int t = 0; t < 4; t++) if (col + t < d) o[t] = o[t] + gb[col + t];
+        }
+        if (VEC == 4 && col + 3 < d) {
+          float4* d4 = reinterpret_cast<float4*>(dst);
+          if (ACCUM) { const float4 old = *d4; o[0] += old.x; o[1] += old.y; o[2] += old.z; o[3] += old.w; }
+          *d4 = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; t++)
+            if (col + t < d) dst[t] = ACCUM ? dst[t] + o[t] : o[t];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                           // S is rewritten for the next sample
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int ffh_dot_interaction_fwd(ffh_ctx* c, const float* z, int64_t ldz, float* out, int64_t ldo, int64_t batch, int nrows, int d, ffh_stream s) {
+  FFH_REQUIRE(c, batch >= 0 && nrows >= 2 && nrows <= kMaxC && d >= 1 && ldz >= (int64_t)nrows * d &&
+                     ldo >= d + (int64_t)nrows * (nrows - 1) / 2 && ((z && out) || batch == 0),
+              "dot_interaction_fwd: bad args");
+  if (batch == 0) return FFH_OK;
+  const bool v4 = d % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 && aligned16(z) && aligned16(out);
+  const unsigned grid = ffh_grid(batch, 4, 4096);
+  if (v4) hipLaunchKernelGGL((dot_interaction_fwd_kernel<4>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
+  else hipLaunchKernelGGL((dot_interaction_fwd_kernel<1>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
+  FFH_LAUNCH_CHECK(c, "dot_interaction_fwd");
+  return FFH_OK;
+}
+
+int ffh_dot_interaction_bwd(ffh_ctx* c, const float* z, int64_t ldz, const float* out_grad, int64_t ldg, float* z_grad, int64_t ldzg,
+                            int64_t batch, int nrows, int d, int flags, ffh_stream s) {
+  FFH_REQUIRE(c, batch >= 0 && nrows >= 2 && nrows <= kMaxC && d >= 1 && ldz >= (int64_t)nrows * d && ldzg >= (int64_t)nrows * d &&
+                     ldg >= d + (int64_t)nrows * (nrows - 1) / 2 && ((z && out_grad && z_grad) || batch == 0) &&
+                     (flags & ~FFH_DOT_BWD_OVERWRITE) == 0,
+              "dot_interaction_bwd: bad args");
+  if (batch == 0) return FFH_OK;
+  const bool v4 = d % 4 == 0 && ldz % 4 == 0 && ldzg % 4 == 0 && aligned16(z) && aligned16(z_grad);
+  const bool over = (flags & FFH_DOT_BWD_OVERWRITE) != 0;
+  const unsigned grid = ffh_grid(batch, 4, 4096);
+#define FFH_DOT_BWD(V, A) hipLaunchKernelGGL((dot_interaction_bwd_kernel<V, A>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out_grad, ldg, z_grad, ldzg, batch, nrows, d)
+  if (v4) { if (over) FFH_DOT_BWD(4, false); else FFH_DOT_BWD(4, true); }
+  else { if (over) FFH_DOT_BWD(1, false); else FFH_DOT_BWD(1, true); }
+#undef FFH_DOT_BWD
+  FFH_LAUNCH_CHECK(c, "dot_interaction_bwd");
+  return FFH_OK;
+}
+
+}  // extern "C"

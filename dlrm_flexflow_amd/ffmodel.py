@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
         "flexflow_model_add_batch_matmul": (H, [H, H, H, I, I]),
         "flexflow_model_add_flat": (H, [H, H, C.c_char_p]),
         "flexflow_model_add_tril": (H, [H, H, C.c_char_p]),
+        "flexflow_model_add_dot_interaction": (H, [H, H, I, C.c_char_p]),
         "flexflow_model_add_transpose": (H, [H, H, I, IP, C.c_char_p]),
         "flexflow_model_add_reshape": (H, [H, H, I, IP, C.c_char_p]),
         "flexflow_zero_initializer_create": (H, []), "flexflow_uniform_initializer_create": (H, [I, F, F]),
@@ -237,6 +238,11 @@ class FFModel:
 
     def flat(self, input: Tensor, name=None) -> Tensor:
         return Tensor(lib().flexflow_model_add_flat(self.h, input.h, name.encode() if name else None), self)
+
+    def dot_interaction(self, input: Tensor, d: int, name=None) -> Tensor:
+        """[batch][c * d] (concat of the bottom-MLP output and the embedding outputs) -> [batch][d + c (c - 1) / 2]:
+        row 0 passed through, then the pairwise dot products i > j -- the whole interaction in one launch each way."""
+        return Tensor(lib().flexflow_model_add_dot_interaction(self.h, input.h, d, name.encode() if name else None), self)
 
     def tril(self, input: Tensor, name=None) -> Tensor:
         """Strict lower triangle of [batch][n][n] -> [batch][n (n - 1) / 2] (MLPerf-DLRM's pick of the pairwise dots)."""

@@ -84,13 +84,15 @@ Tensor create_emb(FFModel* model, const Tensor& input, int input_dim, int output
 // [ref: tests/ops/test_harness.py:125-177]: cat -> reshape [B][C][D] -> transpose -> batch_matmul -> flat,
 // concatenated with the bottom-MLP output: [x | vec(Z Z^T)], width D + C*C with C = 1 + #tables.
 // "dot-tril" is MLPerf-DLRM's variant: only the strict lower triangle of Z Z^T is kept (C (C - 1) / 2 products: 351 of 729
-// for 26 tables), through FFModel::tril -- an operator the reference does not have; width D + C (C - 1) / 2 (479).
+// for 26 tables; width D + C (C - 1) / 2 = 479) -- through FFModel::dot_interaction, the whole interaction as one
+// MFMA kernel each way (csrc/interaction.hip); "dot-tril-ops" spells the same thing as the operator chain with
+// FFModel::tril (neither operator exists in the reference).
 Tensor interact_features(FFModel* model, const Tensor& x, const std::vector<Tensor>& ly, std::string interaction) {
   std::vector<Tensor> inputs;
   inputs.push_back(x);
   for (size_t i = 0; i < ly.size(); i++) inputs.push_back(ly[i]);
   if (interaction == "cat") return model->concat((int)inputs.size(), inputs.data(), 1 /*axis*/);
-  if (interaction == "dot" || interaction == "dot-tril") {
+  if (interaction == "dot" || interaction == "dot-tril" || interaction == "dot-tril-ops") {
     const int batch = x.adim[1], d = x.adim[0], c = (int)inputs.size();
     for (const Tensor& t : inputs)
       if (t.adim[0] != d) {
@@ -98,14 +100,15 @@ Tensor interact_features(FFModel* model, const Tensor& x, const std::vector<Tens
         abort();
       }
     Tensor cat = model->concat(c, inputs.data(), 1 /*axis*/);
+    if (interaction == "dot-tril") return model->dot_interaction(cat, d);   // the chain below (with tril) as one launch each way
     Tensor z = model->reshape(cat, {batch, c, d});
     Tensor zt = model->transpose(z, {0, 2, 1});
     Tensor p = model->batch_matmul(z, zt);            // [batch][c][c]
-    Tensor pf = interaction == "dot" ? model->flat(p) : model->tril(p);
+    Tensor pf = interaction == "dot" ? model->flat(p) : model->tril(p);   // "dot-tril-ops": the operator chain, kept for parity tests
     Tensor both[2] = {x, pf};
     return model->concat(2, both, 1 /*axis*/);
   }
-  fprintf(stderr, "FATAL: --arch-interaction-op %s: 'cat', 'dot' or 'dot-tril'\n", interaction.c_str());
+  fprintf(stderr, "FATAL: --arch-interaction-op %s: 'cat', 'dot', 'dot-tril' or 'dot-tril-ops'\n", interaction.c_str());
   abort();
 }
 

@@ -47,7 +47,7 @@ enum MetricsType {
   METRICS_ROOT_MEAN_SQUARED_ERROR = 1016,
   METRICS_MEAN_ABSOLUTE_ERROR = 1032,
 };
-enum OperatorType { OP_INPUT, OP_LINEAR, OP_EMBEDDING, OP_CONCAT, OP_BATCHMATMUL, OP_TRANSPOSE, OP_RESHAPE, OP_FLAT, OP_TRIL };
+enum OperatorType { OP_INPUT, OP_LINEAR, OP_EMBEDDING, OP_CONCAT, OP_BATCHMATMUL, OP_TRANSPOSE, OP_RESHAPE, OP_FLAT, OP_TRIL, OP_DOT_INTERACTION };
 
 #define MAX_TENSOR_DIM 4
 #define MAX_NUM_INPUTS 256
@@ -354,6 +354,18 @@ class Tril : public Op {
   void backward(const FFModel&) override;
   int n;
 };
+// The pairwise-dot interaction in one launch each way (csrc/interaction.hip): input [batch][c * d] (the Concat of the
+// bottom-MLP output and the c - 1 embedding outputs), output [batch][d + c (c - 1) / 2] = [row 0 | <z_i, z_j>, i > j] --
+// what concat -> reshape -> transpose -> batch_matmul -> tril -> concat(x, .) computes with 13 passes over the block.
+class DotInteraction : public Op {
+ public:
+  DotInteraction(FFModel& model, const Tensor& input, int d, const char* name);
+  void create_output_and_partition(FFModel&) override {}
+  void forward(const FFModel&) override;
+  void backward(const FFModel&) override;
+  int c, d;
+  bool bwd_overwrite;           // the input has no other consumer: its gradient is stored, not accumulated
+};
 
 // ---------------------------------------------------------------------------------------------
 // A host thread that issues the launches of one auxiliary HIP stream.  The training step is bound by
@@ -395,7 +407,8 @@ class FFModel {
                Initializer* bias_initializer = NULL, const char* name = NULL);
   Tensor concat(int n, const Tensor* tensors, int axis, const char* name = NULL);
   Tensor flat(const Tensor& input, const char* name = NULL);
-  Tensor tril(const Tensor& input, const char* name = NULL);   // strict lower triangle of [batch][n][n] (this build's addition)
+  Tensor tril(const Tensor& input, const char* name = NULL);
+  Tensor dot_interaction(const Tensor& input, int d, const char* name = NULL);   // fused pairwise-dot interaction (this build's addition)   // strict lower triangle of [batch][n][n] (this build's addition)
   Tensor transpose(const Tensor& input, const std::vector<int>& perm, const char* name = NULL);
   Tensor reshape(const Tensor& input, const std::vector<int>& shape, const char* name = NULL);
   template <int NDIM>

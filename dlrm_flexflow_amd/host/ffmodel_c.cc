@@ -62,6 +62,7 @@ flexflow_tensor_t flexflow_model_add_concat(flexflow_model_t m, int n, const fle
   return wrap(M(m)->concat(n, v.data(), axis, name));
 }
 flexflow_tensor_t flexflow_model_add_flat(flexflow_model_t m, flexflow_tensor_t in, const char* name) { return wrap(M(m)->flat(*T(in), name)); }
+flexflow_tensor_t flexflow_model_add_dot_interaction(flexflow_model_t m, flexflow_tensor_t in, int d, const char* name) { return wrap(M(m)->dot_interaction(*T(in), d, name)); }
 flexflow_tensor_t flexflow_model_add_tril(flexflow_model_t m, flexflow_tensor_t in, const char* name) { return wrap(M(m)->tril(*T(in), name)); }
 flexflow_tensor_t flexflow_model_add_transpose(flexflow_model_t m, flexflow_tensor_t in, int n, const int* perm, const char* name) {
   return wrap(M(m)->transpose(*T(in), dims_vec(perm, n), name));

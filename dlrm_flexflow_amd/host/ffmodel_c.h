@@ -50,6 +50,7 @@ flexflow_tensor_t flexflow_model_add_embedding(flexflow_model_t, flexflow_tensor
                                                flexflow_initializer_t kernel_init, const char* name);
 flexflow_tensor_t flexflow_model_add_concat(flexflow_model_t, int n, const flexflow_tensor_t* inputs, int axis, const char* name);
 flexflow_tensor_t flexflow_model_add_flat(flexflow_model_t, flexflow_tensor_t input, const char* name);
+flexflow_tensor_t flexflow_model_add_dot_interaction(flexflow_model_t, flexflow_tensor_t input, int d, const char* name);   /* [batch][c*d] -> [batch][d + c(c-1)/2] */
 flexflow_tensor_t flexflow_model_add_tril(flexflow_model_t, flexflow_tensor_t input, const char* name);   /* strict lower triangle of [batch][n][n] */
 flexflow_tensor_t flexflow_model_add_transpose(flexflow_model_t, flexflow_tensor_t input, int n, const int* perm, const char* name);
 flexflow_tensor_t flexflow_model_add_reshape(flexflow_model_t, flexflow_tensor_t input, int n, const int* shape, const char* name);

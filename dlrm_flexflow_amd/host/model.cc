@@ -341,6 +341,7 @@ std::string FFModel::get_operator_type_name(OperatorType type) const {
     case OP_RESHAPE: return "Reshape";
     case OP_FLAT: return "Flat";
     case OP_TRIL: return "Tril";
+    case OP_DOT_INTERACTION: return "DotInteraction";
     default: return "Unknown";
   }
 }
@@ -904,6 +905,34 @@ Tensor FFModel::tril(const Tensor& input, const char* name) {
   layers.push_back(t);
   return t->outputs[0];
 }
+DotInteraction::DotInteraction(FFModel& model, const Tensor& input, int _d, const char* name)
+    : Op(model, OP_DOT_INTERACTION, name, 1, &input), d(_d), bwd_overwrite(false) {
+  if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
+  if (input.numDim != 2 || d < 1 || input.adim[0] % d != 0) die("%s: input must be [batch][c * %d]", this->name, d);
+  c = input.adim[0] / d;
+  if (c < 2 || c > 32) die("%s: %d feature vectors, supported 2..32", this->name, c);
+  outputs[0].numDim = 2;
+  outputs[0].adim[0] = d + c * (c - 1) / 2;
+  outputs[0].adim[1] = input.adim[1];
+}
+void DotInteraction::forward(const FFModel& ff) {
+  const Tensor &x = inputs[0], &y = outputs[0];
+  if (!x.impl->pieces.empty() || !y.impl->pieces.empty()) die("%s: operands must be single buffers", name);
+  ff.check(ff.api->ffh_dot_interaction_fwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, (float*)y.impl->ptr, y.impl->ld, x.impl->rows_local, c, d,
+                                           ff.stream), name);
+}
+void DotInteraction::backward(const FFModel& ff) {
+  const Tensor &x = inputs[0], &y = outputs[0];
+  if (!x.impl->grad) return;
+  ff.check(ff.api->ffh_dot_interaction_bwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, y.impl->grad, y.impl->grad_ld, x.impl->grad, x.impl->grad_ld,
+                                           x.impl->rows_local, c, d, bwd_overwrite ? FFH_DOT_BWD_OVERWRITE : 0, ff.stream), name);
+}
+Tensor FFModel::dot_interaction(const Tensor& input, int d, const char* name) {
+  DotInteraction* t = new DotInteraction(*this, input, d, name);
+  t->layer_index = (int)layers.size();
+  layers.push_back(t);
+  return t->outputs[0];
+}
 Tensor FFModel::transpose(const Tensor& input, const std::vector<int>& perm, const char* name) {
   Transpose* t = new Transpose(*this, input, perm, name);
   t->layer_index = (int)layers.size();
@@ -1323,6 +1352,10 @@ void FFModel::allocate() {
         li->dx_mask_by_x = true;
         below->dy_premasked = true;
       }
+    }
+    if (DotInteraction* di = dynamic_cast<DotInteraction*>(op)) {
+      di->bwd_overwrite = consumers[di->inputs[0].impl] == 1;
+      if (!di->bwd_overwrite) need_zero_act_grads = true;
     }
     if (Concat* c = dynamic_cast<Concat*>(op)) {
       // inputs that nothing else reads take their gradient slice as a plain store (FFH_CONCAT_BWD_OVERWRITE)

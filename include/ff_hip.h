@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_fwd / ffh_tril_bwd */
+#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_* */
 
 /* status codes */
 #define FFH_OK               0
@@ -335,6 +335,20 @@ int ffh_tril_fwd(ffh_ctx* ctx, float* out, int64_t out_ld, const float* in, int6
 /* in_grad[b][i][j] += out_grad[b][p] for i > j; the other entries of in_grad are left as they are */
 int ffh_tril_bwd(ffh_ctx* ctx, float* in_grad, const float* out_grad, int64_t grad_ld, int64_t batch, int n, ffh_stream s);
 
+/* The whole pairwise-dot interaction as one launch each way (what the chain cat -> reshape -> transpose -> batch_matmul
+ * -> tril -> cat computes, [ref: tests/ops/test_harness.py:125-177] + MLPerf's triangle; one wave per sample, Z Z^T on
+ * v_mfma_f32_32x32x2_f32 -- csrc/interaction.hip).  z: [batch][nrows][d] (sample stride ldz >= nrows * d; row 0 is the
+ * bottom-MLP output, rows 1.. the embedding outputs), 2 <= nrows <= 32.
+ *   out[b][0 .. d)                 = z[b][0][:]
+ *   out[b][d + i (i - 1) / 2 + j]  = <z[b][i], z[b][j]>   for i > j          (fp32, k ascending within MFMA order: 1e-5) */
+int ffh_dot_interaction_fwd(ffh_ctx* ctx, const float* z, int64_t ldz, float* out, int64_t ldo,
+                            int64_t batch, int nrows, int d, ffh_stream s);
+/* z_grad[b][i][:] += sum_{j != i} g(i, j) z[b][j][:]  (g(i, j) = out_grad[b][d + pair(max, min)]),  row 0 also
+ * += out_grad[b][0 .. d).  FFH_DOT_BWD_OVERWRITE: store instead of add (z has no other consumer). */
+#define FFH_DOT_BWD_OVERWRITE 1
+int ffh_dot_interaction_bwd(ffh_ctx* ctx, const float* z, int64_t ldz, const float* out_grad, int64_t ldg,
+                            float* z_grad, int64_t ldzg, int64_t batch, int nrows, int d, int flags, ffh_stream s);
+
 /* ------------------------------------------------------------------ */
 /* Loss, metrics, optimizer                                           */
 /* ------------------------------------------------------------------ */
@@ -394,7 +408,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
   X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_second_stream_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
-  X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
+  X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 
 #endif /* FF_HIP_H_ */

@@ -632,6 +632,53 @@ int ffh_tril_bwd(ffh_ctx* c, float* in_grad, const float* out_grad, int64_t grad
   return FFH_OK;
 }
 
+/* the fused pairwise-dot interaction (include/ff_hip.h): plain loops, k ascending */
+int ffh_dot_interaction_fwd(ffh_ctx* c, const float* z, int64_t ldz, float* out, int64_t ldo, int64_t batch, int nrows, int d, ffh_stream s) {
+  (void)s;
+  if (batch < 0 || nrows < 2 || nrows > 32 || d < 1 || ldz < (int64_t)nrows * d || ldo < d + (int64_t)nrows * (nrows - 1) / 2 ||
+      (batch > 0 && (!z || !out)))
+    return fail(c, FFH_ERR_BAD_ARG, "dot_interaction_fwd: bad args");
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < batch; b++) {
+    const float* zb = z + b * ldz;
+    float* ob = out + b * ldo;
+    for (int k = 0; k < d; k++) ob[k] = zb[k];
+    int64_t p = d;
+    for (int i = 1; i < nrows; i++)
+      for (int j = 0; j < i; j++) {
+        float acc = 0.0f;
+        for (int k = 0; k < d; k++) acc = acc + zb[(int64_t)i * d + k] * zb[(int64_t)j * d + k];
+        ob[p++] = acc;
+      }
+  }
+  return FFH_OK;
+}
+int ffh_dot_interaction_bwd(ffh_ctx* c, const float* z, int64_t ldz, const float* og, int64_t ldg, float* zg, int64_t ldzg,
+                            int64_t batch, int nrows, int d, int flags, ffh_stream s) {
+  (void)s;
+  if (batch < 0 || nrows < 2 || nrows > 32 || d < 1 || ldz < (int64_t)nrows * d || ldzg < (int64_t)nrows * d ||
+      ldg < d + (int64_t)nrows * (nrows - 1) / 2 || (batch > 0 && (!z || !og || !zg)) || (flags & ~FFH_DOT_BWD_OVERWRITE))
+    return fail(c, FFH_ERR_BAD_ARG, "dot_interaction_bwd: bad args");
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < batch; b++) {
+    const float* zb = z + b * ldz;
+    const float* gb = og + b * ldg;
+    float* db = zg + b * ldzg;
+    for (int i = 0; i < nrows; i++)
+      for (int k = 0; k < d; k++) {
+        float acc = 0.0f;
+        for (int j = 0; j < nrows; j++) {
+          if (j == i) continue;
+          const int hi = i > j ? i : j, lo = i > j ? j : i;
+          acc = acc + gb[d + (int64_t)hi * (hi - 1) / 2 + lo] * zb[(int64_t)j * d + k];
+        }
+        if (i == 0) acc = acc + gb[k];
+        db[(int64_t)i * d + k] = (flags & FFH_DOT_BWD_OVERWRITE) ? acc : db[(int64_t)i * d + k] + acc;
+      }
+  }
+  return FFH_OK;
+}
+
 int ffh_mse_bwd(ffh_ctx* c, float* lg, const float* logit, const float* label, int64_t n, float scale, ffh_stream s) {
   (void)c; (void)s;
   for (int64_t i = 0; i < n; i++) {

@@ -244,6 +244,24 @@ def tril_bwd(g, in_grad):
     return out
 
 
+def dot_interaction_fwd(z):
+    """z [B][c][d] -> [B][d + c(c-1)/2]: row 0 passed through, then <z_i, z_j> for i > j."""
+    z = _f32(z)
+    B, c, d = z.shape
+    out = np.empty((B, d + c * (c - 1) // 2), np.float32)
+    lib().call("ffh_dot_interaction_fwd", z, c * d, out, out.shape[1], B, c, d, None)
+    return out
+
+
+def dot_interaction_bwd(z, g, z_grad=None):
+    """Gradient wrt z of dot_interaction_fwd given g [B][d + c(c-1)/2]; added to z_grad when given."""
+    z, g = _f32(z), _f32(g)
+    B, c, d = z.shape
+    out = np.zeros_like(z) if z_grad is None else _f32(z_grad).copy()
+    lib().call("ffh_dot_interaction_bwd", z, c * d, g, g.shape[1], out, c * d, B, c, d, 1 if z_grad is None else 0, None)
+    return out
+
+
 def gen_uniform01(count, seed, first):
     p = np.empty(count, np.float32)
     lib().call("ffh_gen_uniform01", p, count, seed, first, None)

@@ -48,6 +48,19 @@ def main():
         out["w_bot"] = app.model.parameter(0, 0).get_weights()
         out["w_top"] = app.model.parameter(app.model.num_layers - 1, 0).get_weights()
         app.close()
+    elif mode == "dot":
+        # the fused pairwise-dot interaction behind the exchange: embedding outputs arrive by all-to-all, the Concat in
+        # front of the interaction unpacks them, its backward packs the gradients for the way back
+        app = ffmodel.DLRM(["--backend", H.oracle_backend()] + H.DOT_ARGS + ["--arch-interaction-op", "dot-tril"], comm=comm.struct)
+        app.warmup()
+        app.train_steps(3, trace=False)
+        app.model.sync()
+        m = app.model
+        out["pred"] = m.layer_output(m.num_layers - 1).get()
+        for l in range(m.num_layers):
+            if m.layer_num_weights(l) and m.parameter(l, 0).is_local:
+                out[f"p{l}"] = m.parameter(l, 0).get_weights()
+        app.close()
     else:
         args = ["--backend", H.oracle_backend(), "-b", "64", "--arch-sparse-feature-size", "8", "--arch-embedding-size",
                 "50-7-300-3-1000-20-11", "--arch-mlp-bot", "13-32-8", "--arch-mlp-top", "64-32-1", "--data-size", "128", "--epochs", "6"]

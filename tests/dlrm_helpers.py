@@ -193,6 +193,11 @@ HDF5_ARGS = ["-b", "16", "--arch-sparse-feature-size", "8", "--arch-embedding-si
              "--arch-mlp-top", "32-16-1"]
 
 
+# dot interaction through the driver: 5 tables + the bottom output = 6 vectors of 8 -> 8 + 15 = 23 inputs of the top MLP
+DOT_ARGS = ["-b", "32", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "50-7-300-11-23", "--arch-mlp-bot", "13-16-8",
+            "--arch-mlp-top", "23-16-1", "--data-size", "32", "--embedding-bag-size", "2"]
+
+
 KAGGLE_ROWS = "1396-550-1761917-507795-290-21-11948-608-3-58176-5237-1497287-3127-26-12153-1068715-10-4836-2085-4-1312273-17-15-110946-91-72655"
 
 

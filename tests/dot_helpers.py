@@ -33,12 +33,12 @@ class TorchDotDLRM(torch.nn.Module):
         return out
 
 
-def run_dot_dlrm(backend, steps=2, trace=False, B=24, D=8, rows=(11, 40, 5), bot=(6, 16, 8), tril=False):
+def run_dot_dlrm(backend, steps=2, trace=False, B=24, D=8, rows=(11, 40, 5), bot=(6, 16, 8), tril=False, fused=False):
     C = 1 + len(rows)
     top = (D + (C * (C - 1) // 2 if tril else C * C), 20, 1)
     args = ["--backend", backend, "-b", str(B), "--arch-sparse-feature-size", str(D), "--arch-embedding-size",
             "-".join(map(str, rows)), "--arch-mlp-bot", "-".join(map(str, bot)), "--arch-mlp-top", "-".join(map(str, top)),
-            "--arch-interaction-op", "dot-tril" if tril else "dot", "--data-size", str(B), "--embedding-bag-size", "2"]
+            "--arch-interaction-op", ("dot-tril" if fused else "dot-tril-ops") if tril else "dot", "--data-size", str(B), "--embedding-bag-size", "2"]
     app = ffmodel.DLRM(args)
     m = app.model
     # read the seeded state out of the shim and mirror it in torch
@@ -46,7 +46,7 @@ def run_dot_dlrm(backend, steps=2, trace=False, B=24, D=8, rows=(11, 40, 5), bot
     names = [m.layer_name(i) for i in range(m.num_layers)]
     dense_layers = [i for i, n in enumerate(names) if n.startswith("Dense")]
     emb_layers = [i for i, n in enumerate(names) if n.startswith("Embedding")]
-    assert [n.split("_")[0] for n in names] == ["Dense"] * nb + ["Embedding"] * T + ["Concat", "Reshape", "Transpose", "BatchMatmul", "Tril" if tril else "Flat", "Concat"] + ["Dense"] * 2
+    assert [n.split("_")[0] for n in names] == ["Dense"] * nb + ["Embedding"] * T + (["Concat", "DotInteraction"] if fused else ["Concat", "Reshape", "Transpose", "BatchMatmul", "Tril" if tril else "Flat", "Concat"]) + ["Dense"] * 2
     tm = TorchDotDLRM(bot, top, rows, D, tril=tril)
     with torch.no_grad():
         for k, li in enumerate(dense_layers):

@@ -49,13 +49,13 @@ def test_launch_worker_threads_on_cpu(monkeypatch):
     m.close()
 
 
-@pytest.mark.parametrize("tril", [False, True])
-def test_dot_interaction_matches_torch(tril):
+@pytest.mark.parametrize("tril,fused", [(False, False), (True, False), (True, True)])
+def test_dot_interaction_matches_torch(tril, fused):
     """--arch-interaction-op dot (Reshape / Transpose / BatchMatmul / Flat composition) and dot-tril
     (MLPerf-DLRM's strict lower triangle of Z Z^T, SURVEY 8a-8: torch's Z[:, li, lj] is the only oracle there is):
     predictions and every parameter after warm-up + 2 steps against a torch model, 1e-5."""
     import dot_helpers
-    out, got, exp = dot_helpers.run_dot_dlrm(H.oracle_backend(), steps=2, tril=tril)
+    out, got, exp = dot_helpers.run_dot_dlrm(H.oracle_backend(), steps=2, tril=tril, fused=fused)
     for g, e in out:
         for k in g:
             np.testing.assert_allclose(g[k], e[k], rtol=1e-5, atol=1e-6, err_msg=k)
@@ -131,7 +131,7 @@ def test_driver_rejects_what_the_reference_rejects():
     base = [exe, "--backend", H.oracle_backend(), "-b", "8", "--arch-embedding-size", "10-10", "--arch-sparse-feature-size", "4",
             "--arch-mlp-bot", "3-4", "--arch-mlp-top", "12-1"]
     r = subprocess.run(base + ["--arch-interaction-op", "sum"], capture_output=True, text=True, timeout=60)
-    assert r.returncode != 0 and "'cat', 'dot' or 'dot-tril'" in r.stderr
+    assert r.returncode != 0 and "'cat', 'dot', 'dot-tril' or 'dot-tril-ops'" in r.stderr
     r = subprocess.run(base + ["--dataset", "x.h5"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "HDF5" in r.stderr
     r = subprocess.run(base + ["-ll:gpu", "4"], capture_output=True, text=True, timeout=60)
@@ -445,6 +445,36 @@ def test_single_rank_forced_exchange_equals_plain_run(tmp_path):
     m.close()
     for k, v in ref[1].items():
         np.testing.assert_allclose(z[f"s1/{k}"], v, rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+def test_two_rank_fused_dot_interaction(tmp_path):
+    """--arch-interaction-op dot-tril (one launch each way) under 2 ranks equals the single-rank run of the operator
+    chain (dot-tril-ops): predictions, MLPs, and every table on its owner."""
+    _run_ranks(2, tmp_path, "dot")
+    app = ffmodel.DLRM(["--backend", H.oracle_backend()] + H.DOT_ARGS + ["--arch-interaction-op", "dot-tril-ops"])
+    app.warmup()
+    app.train_steps(3, trace=False)
+    m = app.model
+    m.sync()
+    pred = m.layer_output(m.num_layers - 1).get()
+    names = [m.layer_name(l) for l in range(m.num_layers)]
+    ref = {names[l]: m.parameter(l, 0).get_weights() for l in range(m.num_layers) if m.layer_num_weights(l)}
+    app.close()
+    B = pred.shape[0]
+    seen = set()
+    for r in range(2):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        np.testing.assert_allclose(z["pred"], pred[r * B // 2:(r + 1) * B // 2], rtol=1e-5, atol=1e-6)
+        # layer numbering differs after the interaction (2 ops instead of 6): match Dense / Embedding layers in order
+        mine = [k for k in z.files if k.startswith("p") and k[1:].isdigit()]
+        fused_names = [n for n in names if n.split("_")[0] in ("Dense", "Embedding")]
+        dense_emb = sorted(mine, key=lambda k: int(k[1:]))
+        held = [n for n in fused_names if n.startswith("Dense") or (int(n.split("_")[1]) - 102) % 2 == r]
+        assert len(dense_emb) == len(held)
+        for k, n in zip(dense_emb, held):
+            np.testing.assert_allclose(z[k], ref[n], rtol=1e-5, atol=1e-6, err_msg=n)
+            seen.add(n)
+    assert seen == set(fused_names)
 
 
 def test_two_rank_driver_flags(tmp_path):

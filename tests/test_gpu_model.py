@@ -109,12 +109,12 @@ def test_driver_kaggle_shape_hip_equals_oracle_backend(hip, trace):
         np.testing.assert_allclose(g[k], c[k], rtol=2e-5, atol=2e-6, err_msg=k)
 
 
-@pytest.mark.parametrize("tril", [False, True])
+@pytest.mark.parametrize("tril,fused", [(False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("trace", [False, True])
-def test_dot_interaction_matches_torch_on_gpu(hip, trace, tril):
+def test_dot_interaction_matches_torch_on_gpu(hip, trace, tril, fused):
     """--arch-interaction-op dot / dot-tril on the MI355X: Reshape / Transpose / BatchMatmul / Flat (or Tril) vs torch."""
     import dot_helpers
-    out, got, exp = dot_helpers.run_dot_dlrm(HIP, steps=3, trace=trace, tril=tril)
+    out, got, exp = dot_helpers.run_dot_dlrm(HIP, steps=3, trace=trace, tril=tril, fused=fused)
     for g, e in out:
         for k in g:
             np.testing.assert_allclose(g[k], e[k], rtol=2e-5, atol=2e-6, err_msg=k)

@@ -616,6 +616,36 @@ def test_tril_bit_exact(hip, oracle, B, n):
         hip.call("ffh_tril_fwd", out, P + 5, dev(z), B, 65, None)     # n > 64
 
 
+@pytest.mark.parametrize("B,c,d", [(1, 2, 1), (7, 4, 8), (2048, 27, 128), (130, 32, 36), (33, 9, 130), (64, 27, 16)])
+def test_dot_interaction_vs_oracle(hip, oracle, B, c, d):
+    """The fused pairwise-dot interaction (one wave per sample, Z Z^T on fp32 MFMA) against the oracle's plain loops:
+    pass-through columns bit-exact, dot products within 1e-5 (the MFMA adds the k terms in another order); strided
+    sample rows and output rows (a concat buffer), accumulate and overwrite backward."""
+    rng = np.random.default_rng(B + c + d)
+    P = c * (c - 1) // 2
+    ldz, ldo = c * d + 4, d + P + 8
+    z = rng.uniform(-1, 1, (B, ldz)).astype(np.float32)
+    zz = np.ascontiguousarray(z[:, :c * d]).reshape(B, c, d)
+    out = torch.full((B, ldo), 777.0, dtype=torch.float32, device=DEV)
+    hip.call("ffh_dot_interaction_fwd", dev(z), ldz, out, ldo, B, c, d, None)
+    got, exp = host(out), oracle.dot_interaction_fwd(zz)
+    assert bits_equal(got[:, :d], exp[:, :d])
+    np.testing.assert_allclose(got[:, d:d + P], exp[:, d:], rtol=1e-5, atol=1e-5)
+    assert (got[:, d + P:] == 777).all()
+    g = rng.uniform(-1, 1, (B, ldo)).astype(np.float32)
+    gg = np.ascontiguousarray(g[:, :d + P])
+    base = rng.uniform(-1, 1, (B, ldz)).astype(np.float32)
+    for flags in (0, 1):
+        zg = dev(base)
+        hip.call("ffh_dot_interaction_bwd", dev(z), ldz, dev(g), ldo, zg, ldz, B, c, d, flags, None)
+        h = host(zg)
+        want = oracle.dot_interaction_bwd(zz, gg, None if flags else base[:, :c * d].reshape(B, c, d))
+        np.testing.assert_allclose(h[:, :c * d].reshape(B, c, d), want, rtol=1e-5, atol=2e-5)
+        assert bits_equal(h[:, c * d:], base[:, c * d:])
+    with pytest.raises(capi.FFHError):
+        hip.call("ffh_dot_interaction_fwd", dev(z), ldz, out, ldo, B, 33, d, None)
+
+
 def test_adam_and_zero_grad(hip, oracle):
     """ffh_adam_update / ffh_sgd_update_ex: bit-exact with the oracle, within 1e-5 of torch.optim.Adam (fixture)."""
     g = golden("adam_torch")

@@ -442,3 +442,23 @@ def test_tril_matches_torch(oracle, n):
     zt = torch.from_numpy(z).requires_grad_(True)
     (zt[:, li, lj] * torch.from_numpy(g)).sum().backward()
     assert np.array_equal(oracle.tril_bwd(g, base), base + zt.grad.numpy())
+
+
+@pytest.mark.parametrize("B,c,d", [(3, 2, 1), (5, 4, 8), (4, 27, 128), (2, 32, 36), (3, 9, 130)])
+def test_dot_interaction_matches_torch(oracle, B, c, d):
+    """The fused pairwise-dot interaction against the torch composition the reference's op tests use
+    (cat -> reshape -> bmm with the transpose, tests/ops/test_harness.py:125-177) + MLPerf's tril pick; 1e-5."""
+    import torch
+    rng = np.random.default_rng(B * 100 + c)
+    z = rng.uniform(-1, 1, (B, c, d)).astype(np.float32)
+    zt = torch.from_numpy(z).requires_grad_(True)
+    p = torch.bmm(zt, zt.transpose(1, 2))
+    li, lj = torch.tril_indices(c, c, offset=-1)
+    exp = torch.cat([zt[:, 0, :], p[:, li, lj]], dim=1)
+    got = oracle.dot_interaction_fwd(z)
+    np.testing.assert_allclose(got, exp.detach().numpy(), rtol=1e-5, atol=1e-5)
+    g = rng.uniform(-1, 1, got.shape).astype(np.float32)
+    (exp * torch.from_numpy(g)).sum().backward()
+    np.testing.assert_allclose(oracle.dot_interaction_bwd(z, g), zt.grad.numpy(), rtol=1e-5, atol=1e-5)
+    base = rng.uniform(-1, 1, z.shape).astype(np.float32)
+    np.testing.assert_allclose(oracle.dot_interaction_bwd(z, g, base), base + zt.grad.numpy(), rtol=1e-5, atol=1e-5)
