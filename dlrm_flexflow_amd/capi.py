@@ -102,6 +102,7 @@ _SIGS = {
     "ffh_linear_fwd": (I, [P, P, L, P, L, P, P, I, I, L, I, P]),
     "ffh_linear_bwd": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, P]),
     "ffh_linear_bwd_ex": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, P]),
+    "ffh_linear_bwd_mse": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, F, P, I, P]),
     "ffh_second_stream_used": (I, [P, I]),
     "ffh_mse_bwd_metrics": (I, [P, P, P, P, P, L, I, F, I, P]),
     "ffh_concat_fwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),

@@ -45,7 +45,9 @@ __device__ __forceinline__ void load_row_piece(float (&v)[16], const float* row,
   }
 }
 
-template <int VEC>
+// VEC: floats per load of z (4 needs 16-byte aligned rows); OV: floats per store of the pass-through columns (the output
+// row is often odd-sized -- 479 floats for MLPerf -- so its alignment is a separate matter)
+template <int VEC, int OV>
 __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* __restrict__ z, int64_t ldz, float* __restrict__ out, int64_t ldo,
                                                                   int64_t batch, int c, int d) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -69,11 +71,11 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* _
     }
     float* ob = out + b * ldo;
     // the bottom-MLP output passes through: out[0 .. d) = Z[0][:]
-    for (int k = lane * VEC; k < d; k += 64 * VEC) {
-      if (VEC == 4 && k + 3 < d) {
+    for (int k = lane * OV; k < d; k += 64 * OV) {
+      if (OV == 4 && k + 3 < d) {
         *reinterpret_cast<float4*>(ob + k) = *reinterpret_cast<const float4*>(zb + k);
       } else {
-        for (int e = 0; e < VEC && k + e < d; e++) ob[k + e] = zb[k + e];
+        for (int e = 0; e < OV && k + e < d; e++) ob[k + e] = zb[k + e];
       }
     }
     // accumulator: lane holds column j = r, rows i = 8 (v / 4) + 4 h + v % 4
@@ -187,10 +189,12 @@ int ffh_dot_interaction_fwd(ffh_ctx* c, const float* z, int64_t ldz, float* out,
                      ldo >= d + (int64_t)nrows * (nrows - 1) / 2 && ((z && out) || batch == 0),
               "dot_interaction_fwd: bad args");
   if (batch == 0) return FFH_OK;
-  const bool v4 = d % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 && aligned16(z) && aligned16(out);
+  const bool v4 = d % 4 == 0 && ldz % 4 == 0 && aligned16(z);
+  const bool o4 = v4 && ldo % 4 == 0 && aligned16(out);
   const unsigned grid = ffh_grid(batch, 4, 4096);
-  if (v4) hipLaunchKernelGGL((dot_interaction_fwd_kernel<4>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
-  else hipLaunchKernelGGL((dot_interaction_fwd_kernel<1>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
+  if (o4) hipLaunchKernelGGL((dot_interaction_fwd_kernel<4, 4>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
+  else if (v4) hipLaunchKernelGGL((dot_interaction_fwd_kernel<4, 1>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
+  else hipLaunchKernelGGL((dot_interaction_fwd_kernel<1, 1>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
   FFH_LAUNCH_CHECK(c, "dot_interaction_fwd");
   return FFH_OK;
 }

@@ -942,6 +942,8 @@ struct SkinnyBwdArgs {
   int act;          // activation whose derivative is applied to dy here (NONE: dy is taken as it is)
   int write_back;   // store the activation gradient into dy (the reference mutates dy in place)
   int do_db, do_dw, do_dx, dx_overwrite, mask_by_x;
+  // MSE loss step folded in (ffh_linear_bwd_mse): dy is not read but made here from y and label; metrics as metrics_kernel
+  const float* label;  float loss_scale;  ffh_perf_metrics* perf;  int metrics_flags;
 };
 
 // NC: 16-byte column chunks per lane (in <= 256 * NC), NO: output slots kept in registers (out <= NO)
@@ -954,13 +956,67 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
   if (rows <= 0) return;
   // 1. activation gradient of this block's rows: reluBackward [ref: src/runtime/cuda_helper.cu:71-78] /
   //    sigmoid_backward [ref: src/ops/linear.cu:600-607], once per element, then shared through LDS
+  float mse_s = 0.f, rmse_s = 0.f, mae_s = 0.f;
+  int m_all = 0, m_correct = 0;
   for (int e = tid; e < rows * a.out; e += 256) {
     const int r = e / a.out, o = e - r * a.out;
-    float d = a.dy[(b0 + r) * a.lddy + o];
+    float d;
+    if (a.label) {
+      // mean_squared_error_avg_loss_backward + scale [ref: src/loss_functions/loss_functions.cu:65-76,160-166], same rounding as metrics_kernel
+      d = __fmaf_rn(a.loss_scale - 0.0f, a.y[(b0 + r) * a.ldy + o] - a.label[(b0 + r) * a.out + o], 0.0f);
+      if (o == 0) {   // per-sample metrics [ref: src/metrics_functions/metrics_functions.cu:108-173], as metrics_kernel computes them
+        const float* lg = a.y + (b0 + r) * a.ldy;
+        const float* lb = a.label + (b0 + r) * a.out;
+        m_all += 1;
+        if (a.metrics_flags & 1) {
+          if (a.out == 1) { m_all += 1; m_correct += 1; }
+          else {
+            float max_val = 0.0f; int my = -1, tr = -1;
+            for (int i = 0; i < a.out; i++) {
+              const float lv = lg[i];
+              if (my == -1 || lv > max_val) { max_val = lv; my = i; }
+              if (lb[i] > 0.9f) tr = i;
+            }
+            if (tr == my) m_correct += 1;
+          }
+        }
+        if (a.metrics_flags & (2 | 4 | 8)) {
+          float mse = 0.f, mae = 0.f;
+          for (int i = 0; i < a.out; i++) {
+            const float diff = lg[i] - lb[i];
+            mse = __fmaf_rn(diff, diff, mse);
+            mae += fabsf(diff);
+          }
+          mse_s += mse; rmse_s += sqrtf(mse); mae_s += mae;
+        }
+      }
+    } else {
+      d = a.dy[(b0 + r) * a.lddy + o];
+    }
     if (a.act == FFH_AC_MODE_RELU) d = a.y[(b0 + r) * a.ldy + o] > 0.0f ? d : 0.0f;
     else if (a.act == FFH_AC_MODE_SIGMOID) { const float yo = a.y[(b0 + r) * a.ldy + o]; d = d * yo * (1 - yo); }
     if (a.write_back) a.dy[(b0 + r) * a.lddy + o] = d;
     s_dz[e] = d;
+  }
+  if (a.label) {   // one atomic per counter per workgroup (uniform branch: label is a kernel argument)
+    __shared__ float s_mf[3][4];
+    __shared__ int s_mi[2][4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mse_s += __shfl_down(mse_s, o); rmse_s += __shfl_down(rmse_s, o); mae_s += __shfl_down(mae_s, o);
+      m_all += __shfl_down(m_all, o); m_correct += __shfl_down(m_correct, o);
+    }
+    if (lane == 0) { s_mf[0][wave] = mse_s; s_mf[1][wave] = rmse_s; s_mf[2][wave] = mae_s; s_mi[0][wave] = m_all; s_mi[1][wave] = m_correct; }
+    __syncthreads();
+    if (tid == 0) {
+      const int al = s_mi[0][0] + s_mi[0][1] + s_mi[0][2] + s_mi[0][3];
+      const int co = s_mi[1][0] + s_mi[1][1] + s_mi[1][2] + s_mi[1][3];
+      if (al) atomicAdd(&a.perf->train_all, al);
+      if (co) atomicAdd(&a.perf->train_correct, co);
+      if (a.metrics_flags & 2) atomicAdd(&a.perf->mse_loss, (s_mf[0][0] + s_mf[0][1]) + (s_mf[0][2] + s_mf[0][3]));
+      if (a.metrics_flags & 4) atomicAdd(&a.perf->rmse_loss, (s_mf[1][0] + s_mf[1][1]) + (s_mf[1][2] + s_mf[1][3]));
+      if (a.metrics_flags & 8) atomicAdd(&a.perf->mae_loss, (s_mf[2][0] + s_mf[2][1]) + (s_mf[2][2] + s_mf[2][3]));
+    }
   }
   __syncthreads();
   if (a.do_db && a.db && tid < a.out) {
@@ -1083,9 +1139,15 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   return launch_gemm<true, true>(c, g, 1, s, "linear_fwd gemm");
 }
 
-int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
-                      float* dy, int64_t lddy, const float* w, float* dw, float* db,
-                      int in, int out, int64_t batch, int act, int flags, ffh_stream s, ffh_stream s_dw) {
+}  // extern "C"
+
+namespace {
+// label != NULL: the MSE loss step is folded into the one-launch backward (ffh_linear_bwd_mse); layers that path does
+// not serve return FFH_ERR_UNSUPPORTED before anything is launched
+int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
+                    float* dy, int64_t lddy, const float* w, float* dw, float* db,
+                    int in, int out, int64_t batch, int act, int flags, ffh_stream s, ffh_stream s_dw,
+                    const float* label, float loss_scale, ffh_perf_metrics* perf, int metrics_flags) {
   FFH_REQUIRE(c, in > 0 && out > 0 && batch >= 0 && ldx >= in && ldy >= out && lddy >= out && (!dx || lddx >= in), "linear_bwd: bad dims");
   FFH_REQUIRE(c, batch == 0 || (x && y && dy && w && dw), "linear_bwd: null pointer");
   FFH_REQUIRE(c, batch < (1LL << 31), "linear_bwd: batch too large");
@@ -1117,6 +1179,11 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     a.do_dw = do_dw; a.do_dx = do_dx && dx != nullptr;
     a.dx_overwrite = (flags & FFH_LINEAR_DX_OVERWRITE) ? 1 : 0;
     a.mask_by_x = mask_by_x ? 1 : 0;
+    if (label) {
+      if (only_dx || only_dw || premasked || out > kSkinnyMaxOut) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: not a whole one-launch layer");
+      a.label = label; a.loss_scale = loss_scale; a.perf = perf; a.metrics_flags = metrics_flags;
+      a.write_back = 1;              // dy must end up holding what the loss step + the layer's in-place pass leave there
+    }
     // dW / db are accumulated with one atomic per weight per workgroup: adds to ONE address serialise (~0.1 us each), so
     // the number of workgroups is kept near 32 -- and every wave then keeps 16 / NC rows in flight to cover the latency
     const int64_t nblk = batch >= 8192 ? 64 : 32;                       // large batches: HBM traffic outweighs the longer atomic chains
@@ -1137,6 +1204,7 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     FFH_LAUNCH_CHECK(c, "linear_skinny_bwd_kernel");
     return FFH_OK;
   }
+  if (label) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: not a one-launch layer (out_dim <= 4, in_dim <= 1024, aligned)");
   if (separate && do_dx) {
     const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
     const int cols_v = v4 ? out / 4 : out;
@@ -1229,6 +1297,26 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     if (rc) return rc;
   }
   return FFH_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
+                      float* dy, int64_t lddy, const float* w, float* dw, float* db,
+                      int in, int out, int64_t batch, int act, int flags, ffh_stream s, ffh_stream s_dw) {
+  return linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, s_dw, nullptr, 0.0f, nullptr, 0);
+}
+
+int ffh_linear_bwd_mse(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
+                       float* dy, int64_t lddy, const float* w, float* dw, float* db,
+                       int in, int out, int64_t batch, int act, int flags,
+                       const float* label, float scale, ffh_perf_metrics* perf, int metrics_flags, ffh_stream s) {
+  FFH_REQUIRE(c, label && perf, "linear_bwd_mse: label and perf are required");
+  if (flags & (FFH_LINEAR_ONLY_DX | FFH_LINEAR_ONLY_DW | FFH_LINEAR_DY_PREMASKED)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: split / premasked forms");
+  if (ldy != out || lddy != out) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: y and dy must be contiguous [batch][out_dim]");
+  if (batch == 0) return FFH_OK;
+  return linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, nullptr, label, scale, perf, metrics_flags);
 }
 
 int ffh_second_stream_used(ffh_ctx* c, int clear) {

@@ -102,6 +102,7 @@ class FFConfig {
   bool overlap_embedding;      // embedding gather (+exchange) on a side stream beside the bottom MLP
   bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
   int64_t column_shard_rows;   // tables with at least this many rows are sharded column-wise over the ranks (0: never)
+  bool fuse_loss;              // loss step + metrics inside the last layer's one-launch backward (A/B: --no-fused-loss)
   int64_t row_shard_rows;      // ... row-wise instead: partial bag sums + reduce-scatter (0: never; wins over column_shard_rows)
   bool async_launch;           // auxiliary streams are fed by their own host threads (HIP backend only)
   bool parallel_dw;            // weight-gradient GEMMs on their own stream beside the data-gradient chain

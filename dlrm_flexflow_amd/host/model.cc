@@ -126,6 +126,7 @@ FFConfig::FFConfig() {
   async_launch = false;   // measured on MI355X / ROCm 7.2: no gain over one issuing thread (280 vs 272 us per Kaggle step)
   column_shard_rows = 0;
   row_shard_rows = 0;
+  fuse_loss = true;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
   comm.world_size = 1;
@@ -171,6 +172,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--async-launch")) { async_launch = true; continue; }
     if (is("--column-shard-rows")) { column_shard_rows = atoll(next()); continue; }
     if (is("--row-shard-rows")) { row_shard_rows = atoll(next()); continue; }
+    if (is("--no-fused-loss")) { fuse_loss = false; continue; }
   }
 }
 
@@ -1620,11 +1622,29 @@ void FFModel::backward(int _seq_length) {
   const float scale = loss_type == LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE ? 1.0f / (float)fin.adim[fin.numDim - 1] : 1.0f;
   if (fin.impl->grad_ld != fin.adim[0] || fin.impl->ld != fin.adim[0]) die("final layer output must be contiguous");
   dw_forked = false;
-  check(api->ffh_mse_bwd_metrics(ctx, fin.impl->grad, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, d_perf,
-                                 local_rows(fin, this), fin.adim[0], scale, metrics_flags, stream), "metrics + loss backward");
+  // the click-probability layer (out = 1): loss step + metrics + the layer's whole backward in ONE launch; any other last
+  // layer: the loss kernel, then the layer's own backward
+  int first = (int)layers.size() - 1;
   emb_update_pending = false;
   mlp_grads_clean = false;
-  for (int l = (int)layers.size() - 1; l >= 0; l--) layers[l]->backward(*this);
+  Linear* last = config.fuse_loss ? dynamic_cast<Linear*>(layers.back()) : nullptr;
+  int rc = FFH_ERR_UNSUPPORTED;
+  if (last) {
+    const Tensor& x = last->inputs[0];
+    const int flags = (last->dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0) | (last->dx_mask_by_x ? FFH_LINEAR_DX_MASK_BY_X : 0);
+    rc = api->ffh_linear_bwd_mse(ctx, (const float*)x.impl->ptr, x.impl->ld, last->discard_input_grad ? nullptr : x.impl->grad, x.impl->grad_ld,
+                                 (const float*)fin.impl->ptr, fin.impl->ld, fin.impl->grad, fin.impl->grad_ld,
+                                 (const float*)last->weights[0].impl->ptr, last->weights[0].impl->grad,
+                                 last->use_bias ? last->weights[1].impl->grad : nullptr, last->in_channels, last->out_channels,
+                                 local_rows(fin, this), (int)last->activation, flags, (const float*)label_tensor.impl->ptr, scale, d_perf,
+                                 metrics_flags, stream);
+    if (rc == FFH_OK) first--;                          // the last layer is done
+    else if (rc != FFH_ERR_UNSUPPORTED) check(rc, "loss + last layer backward");
+  }
+  if (rc != FFH_OK)
+    check(api->ffh_mse_bwd_metrics(ctx, fin.impl->grad, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, d_perf,
+                                   local_rows(fin, this), fin.adim[0], scale, metrics_flags, stream), "metrics + loss backward");
+  for (int l = first; l >= 0; l--) layers[l]->backward(*this);
   if (emb_update_pending) {
     // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
     issue_embedding_update_on_side_stream();

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_* */
+#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse */
 
 /* status codes */
 #define FFH_OK               0
@@ -324,6 +324,19 @@ int ffh_transpose_fwd(ffh_ctx* ctx, float* out, const float* in, int ndim, const
 /* Transpose::backward_kernel [ref: src/ops/transpose.cu:262-330]: in_grad += inverse-permute(out_grad) */
 int ffh_transpose_bwd(ffh_ctx* ctx, float* in_grad, const float* out_grad, int ndim, const int64_t* in_dims, const int* perm, ffh_stream s);
 
+/* The last layer's backward with the MSE loss step folded in: exactly
+ *   ffh_mse_bwd_metrics(ctx, dy, y, label, perf, batch, out_dim, scale, metrics_flags, s)   (dy = (y - label) * scale, metrics)
+ *   ffh_linear_bwd_ex(ctx, x, ..., activation, flags, s, s_dw)
+ * as ONE launch (the loss gradient never goes through memory on its own; dy ends up holding what the two calls leave
+ * there).  Only for the layers the one-launch backward serves (out_dim <= 4 and in_dim <= 1024, 16-byte aligned
+ * operands) without FFH_LINEAR_ONLY_* / FFH_LINEAR_DY_PREMASKED: anything else returns FFH_ERR_UNSUPPORTED and nothing has
+ * been launched -- the caller then makes the two calls.  label is [batch][out_dim] contiguous. */
+int ffh_linear_bwd_mse(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                       const float* y, int64_t ldy, float* dy, int64_t lddy,
+                       const float* w, float* dw, float* db,
+                       int in_dim, int out_dim, int64_t batch, int activation, int flags,
+                       const float* label, float scale, ffh_perf_metrics* perf, int metrics_flags, ffh_stream s);
+
 /* ------------------------------------------------------------------ */
 /* Strict lower triangle of the pairwise-dot matrix (MLPerf-DLRM's interaction keeps the 351 products
  * i > j of the 27 x 27 matrix; the reference has no operator for it -- its dot interaction is a TODO,
@@ -407,7 +420,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_second_stream_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_second_stream_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

@@ -463,6 +463,17 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   return linear_bwd_parts(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, 1, 1, 1, 1, 0, mbx);
 }
 
+/* the two calls it stands for, in order (include/ff_hip.h) */
+int ffh_linear_bwd_mse(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy, float* dy, int64_t lddy,
+                       const float* w, float* dw, float* db, int in, int out, int64_t B, int act, int flags,
+                       const float* label, float scale, ffh_perf_metrics* perf, int metrics_flags, ffh_stream s) {
+  if (flags & (FFH_LINEAR_ONLY_DX | FFH_LINEAR_ONLY_DW | FFH_LINEAR_DY_PREMASKED)) return fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: split / premasked forms");
+  if (out > 4 || in > 1024 || ldy != out || lddy != out) return fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: not a one-launch layer");
+  const int rc = ffh_mse_bwd_metrics(c, dy, y, label, perf, B, out, scale, metrics_flags, s);
+  if (rc != FFH_OK) return rc;
+  return ffh_linear_bwd_ex(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, flags, s, s);
+}
+
 /* ------------------------------------------------------------------ */
 /* Concat                                                             */
 /* ------------------------------------------------------------------ */

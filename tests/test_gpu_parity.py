@@ -720,6 +720,49 @@ def test_sgd_mse_metrics(hip, oracle):
     np.testing.assert_array_equal(host(d), (w0.astype(np.float64) + gr.astype(np.float64) * 0.5).astype(np.float32))
 
 
+@pytest.mark.parametrize("B,IN,OUT,act", [(2048, 256, 1, capi.AC_MODE_SIGMOID), (100, 64, 3, capi.AC_MODE_NONE), (777, 1024, 4, capi.AC_MODE_RELU),
+                                         (8192, 256, 1, capi.AC_MODE_SIGMOID)])
+def test_linear_bwd_mse_equals_the_two_calls(hip, oracle, B, IN, OUT, act):
+    """ffh_linear_bwd_mse (loss step + metrics folded into the last layer's one-launch backward) against
+    ffh_mse_bwd_metrics followed by ffh_linear_bwd_ex: dy and dX bit-exact (same operations per element), dW / db / the
+    metric sums within 1e-5 (atomics); the oracle's restatement (the two calls) agrees."""
+    rng = np.random.default_rng(B + OUT)
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = rng.uniform(-1, 1, (OUT, IN)).astype(np.float32)
+    y = rng.uniform(0.05, 0.95, (B, OUT)).astype(np.float32)
+    label = (rng.uniform(0, 1, (B, OUT)) > 0.5).astype(np.float32)
+    flags = capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DX_MASK_BY_X
+    mf = capi.METRIC_ACCURACY | capi.METRIC_MSE
+    res = []
+    for fused in (True, False):
+        dx = torch.full((B, IN), 3.0, dtype=torch.float32, device=DEV)
+        dy = torch.full((B, OUT), 9.0, dtype=torch.float32, device=DEV)
+        dw, db = torch.zeros(OUT, IN, device=DEV), torch.zeros(OUT, device=DEV)
+        perf = torch.zeros(8, dtype=torch.int32, device=DEV)
+        if fused:
+            hip.call("ffh_linear_bwd_mse", dev(x), IN, dx, IN, dev(y), OUT, dy, OUT, dev(w), dw, db, IN, OUT, B, act, flags,
+                     dev(label), 1.0 / B, perf, mf, None)
+        else:
+            hip.call("ffh_mse_bwd_metrics", dy, dev(y), dev(label), perf, B, OUT, 1.0 / B, mf, None)
+            hip.call("ffh_linear_bwd_ex", dev(x), IN, dx, IN, dev(y), OUT, dy, OUT, dev(w), dw, db, IN, OUT, B, act, flags, None, None)
+        res.append([host(t) for t in (dx, dy, dw, db, perf)])
+    f, t = res
+    assert bits_equal(f[0], t[0]) and bits_equal(f[1], t[1])
+    np.testing.assert_allclose(f[2], t[2], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(f[3], t[3], rtol=1e-5, atol=1e-6)
+    assert f[4][:2].tolist() == t[4][:2].tolist()
+    np.testing.assert_allclose(f[4][4:5].view(np.float32), t[4][4:5].view(np.float32), rtol=1e-5)
+    # the oracle's own restatement
+    lg = oracle.mse_bwd(y, label, 1.0 / B)
+    odx, odw, odb, ody = oracle.linear_bwd_ex(x, y, lg, w, act, flags)
+    assert bits_equal(f[1], ody)
+    np.testing.assert_allclose(f[0], odx, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(f[2], odw, rtol=1e-5, atol=1e-6)
+    with pytest.raises(capi.FFHError):     # a layer the one-launch backward does not serve: nothing launched, caller makes two calls
+        hip.call("ffh_linear_bwd_mse", dev(x), IN, dx, IN, dev(y), OUT, dy, OUT, dev(w), dw, db, IN, OUT, B, act, capi.LINEAR_ONLY_DX,
+                 dev(label), 1.0 / B, perf, mf, None)
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties
 # ---------------------------------------------------------------------------
