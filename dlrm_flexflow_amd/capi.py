@@ -77,6 +77,7 @@ _SIGS = {
     "ffh_stream_sync": (I, [P, P]),
     "ffh_device_sync": (I, [P]),
     "ffh_event_create": (I, [P, C.POINTER(P)]),
+    "ffh_event_create_sync": (I, [P, C.POINTER(P)]),
     "ffh_event_destroy": (I, [P, P]),
     "ffh_event_record": (I, [P, P, P]),
     "ffh_event_sync": (I, [P, P]),
@@ -104,6 +105,7 @@ _SIGS = {
     "ffh_linear_bwd_ex": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, P]),
     "ffh_linear_bwd_mse": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, F, P, I, P]),
     "ffh_second_stream_used": (I, [P, I]),
+    "ffh_event_record_with_next_linear_bwd": (I, [P, P]),
     "ffh_mse_bwd_metrics": (I, [P, P, P, P, P, L, I, F, I, P]),
     "ffh_concat_fwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),
     "ffh_concat_bwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),

@@ -19,6 +19,8 @@
 // cublasSgemmStridedBatched [ref: src/ops/batch_matmul.cu:238-241,393-398].
 #include "ffh_common.h"
 
+#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: a launch that carries its own completion event
+
 #include <stdlib.h>
 #include <type_traits>
 
@@ -439,9 +441,11 @@ constexpr int kGldsStages = 3;
 
 // AKR / BKR: false = rows of the operand are m (n), k contiguous (x, w in fwd; dy in dx); true = rows are k, m (n) contiguous.
 // body of one workgroup: `lin` is its index in the nbx x nby x nbz tile space of THIS problem (a launch may carry two)
-template <bool AKR, bool BKR, int BM>
+// NSTAGE: LDS stages of the k pipeline.  3 (97 KB) when a CU holds one workgroup anyway; 2 (65 KB) lets two workgroups share a
+// CU, so that one's prologue / epilogue runs under the other's main loop (launches with more workgroups than CUs)
+template <bool AKR, bool BKR, int BM, int NSTAGE = kGldsStages>
 __device__ __forceinline__ void glds_body(const GldsArgs& g, const unsigned lin, const unsigned nbx, const unsigned nby, const unsigned nbz) {
-  constexpr int NW = kGldsWaves, NSTAGE = kGldsStages, BN = 64;
+  constexpr int NW = kGldsWaves, BN = 64;
   constexpr int NSUB = (BM / 32) * 2;                   // 32x32 sub-tiles of the block tile
   constexpr int KS = NW / NSUB;                         // k-slices of every k-tile
   constexpr int JW = 8 / KS;                            // k-octets per wave per k-tile
@@ -622,9 +626,9 @@ __device__ __forceinline__ void glds_body(const GldsArgs& g, const unsigned lin,
   }
 }
 
-template <bool AKR, bool BKR, int BM>
+template <bool AKR, bool BKR, int BM, int NSTAGE = kGldsStages>
 __global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_kernel(const GldsArgs g) {
-  glds_body<AKR, BKR, BM>(g, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, gridDim.z);
+  glds_body<AKR, BKR, BM, NSTAGE>(g, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, gridDim.z);
 }
 
 // One launch for a layer's backward: workgroups [0, na8) are the data-gradient GEMM (dy x w, rows = samples), the rest the
@@ -632,11 +636,11 @@ __global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_kernel(const GldsAr
 // events (each is a barrier packet on the critical stream), one dispatch instead of two.  na8 = the dX tile count
 // rounded up to a multiple of 8 so that both problems keep their XCD-contiguous tile order.
 struct GldsDims { unsigned nbx, nby, nbz; };
-template <int BM_DX>
+template <int BM_DX, int NSTAGE = kGldsStages>
 __global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_bwd_kernel(const GldsArgs dxg, const GldsDims dxd, const unsigned na8,
                                                                         const GldsArgs dwg, const GldsDims dwd) {
-  if (blockIdx.x < na8) glds_body<false, true, BM_DX>(dxg, blockIdx.x, dxd.nbx, dxd.nby, dxd.nbz);
-  else glds_body<true, true, 64>(dwg, blockIdx.x - na8, dwd.nbx, dwd.nby, dwd.nbz);
+  if (blockIdx.x < na8) glds_body<false, true, BM_DX, NSTAGE>(dxg, blockIdx.x, dxd.nbx, dxd.nby, dxd.nbz);
+  else glds_body<true, true, 64, NSTAGE>(dwg, blockIdx.x - na8, dwd.nbx, dwd.nby, dwd.nbz);
 }
 
 inline bool glds_aligned(const float* p, int64_t ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
@@ -657,7 +661,10 @@ bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p, double 
   int bm = 64;
   int64_t tiles = tiles64;
   if (!atomic_splitk && tiles64 < (3 * c->num_cus) / 4) { bm = 32; tiles = (int64_t)((g.M + 31) / 32) * ((g.N + 63) / 64); }
-  if (tiles > (3 * c->num_cus) / 2) return false;        // bigger GEMMs: the register-staged kernels with their larger tiles
+  // bigger GEMMs: the register-staged kernels with their larger tiles (measured again with the two-stage form at the
+  // MLPerf / Terabyte layer sizes: 3-8 % slower per step through this kernel).  Splitting a 256-tile forward GEMM into
+  // 512 half-height tiles to get two workgroups per CU also lost (Kaggle step +16 us).
+  if (tiles > (3 * c->num_cus) / 2) return false;
   g.zeros = c->zeros;
   g.splitk = 1; g.k_per_split = (g.K + 63) / 64 * 64;
   if (atomic_splitk) {
@@ -689,14 +696,18 @@ template <bool AKR, bool BKR>
 int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const char* name) {
   GldsPlan p;
   if (!plan_glds<AKR, BKR>(c, g, atomic_splitk, p)) return 0;
-#define FFH_GLDS_LAUNCH(BMV)                                                                                               \
+  // more workgroups than CUs: two stages (65 KB) so that two of them share a CU
+  const bool two = (int64_t)p.grid.x * p.grid.y * p.grid.z > (int64_t)c->num_cus;
+  const int lds2 = 2 * 128 * 256 + 1024;       // the epilogue's cross-wave reduction needs 64 KB whatever the tile
+#define FFH_GLDS_LAUNCH(BMV, NS, LDSV)                                                                                     \
   {                                                                                                                        \
-    auto kern = gemm_glds_kernel<AKR, BKR, BMV>;                                                                           \
-    static const bool ok = glds_set_lds(kern, kGldsStages * (BMV + 64) * 256 + 1024);                                      \
+    auto kern = gemm_glds_kernel<AKR, BKR, BMV, NS>;                                                                       \
+    static const bool ok = glds_set_lds(kern, NS * 128 * 256 + 1024);                                                      \
     if (!ok) return 0;                                                                                                     \
-    hipLaunchKernelGGL(kern, p.grid, dim3(kGldsWaves * 64), p.lds_bytes, as_stream(s), g);                                 \
+    hipLaunchKernelGGL(kern, p.grid, dim3(kGldsWaves * 64), LDSV, as_stream(s), g);                                        \
   }
-  if (p.bm == 64) FFH_GLDS_LAUNCH(64) else FFH_GLDS_LAUNCH(32)
+  if (p.bm == 64) { if (two) FFH_GLDS_LAUNCH(64, 2, lds2) else FFH_GLDS_LAUNCH(64, 3, p.lds_bytes) }
+  else { if (two) FFH_GLDS_LAUNCH(32, 2, lds2) else FFH_GLDS_LAUNCH(32, 3, p.lds_bytes) }
 #undef FFH_GLDS_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, name);
@@ -714,19 +725,25 @@ int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
   const unsigned na8 = (na + 7u) & ~7u;
   const GldsDims dx{px.grid.x, px.grid.y, px.grid.z}, dw{pw.grid.x, pw.grid.y, pw.grid.z};
   const int lds = px.lds_bytes > pw.lds_bytes ? px.lds_bytes : pw.lds_bytes;
-  if (px.bm == 64) {
-    auto kern = gemm_glds_bwd_kernel<64>;
-    static const bool ok = glds_set_lds(kern, kGldsStages * 128 * 256 + 1024);
-    if (!ok) return 0;
-    hipLaunchKernelGGL(kern, dim3(na8 + nb), dim3(kGldsWaves * 64), lds, as_stream(s), dxg, dx, na8, dwg, dw);
-  } else {
-    auto kern = gemm_glds_bwd_kernel<32>;
-    static const bool ok = glds_set_lds(kern, kGldsStages * 128 * 256 + 1024);
-    if (!ok) return 0;
-    hipLaunchKernelGGL(kern, dim3(na8 + nb), dim3(kGldsWaves * 64), lds, as_stream(s), dxg, dx, na8, dwg, dw);
+  hipEvent_t ev = (hipEvent_t)c->attach_event;   // ffh_event_record_with_next_linear_bwd: this launch is the call's last kernel on s
+  // more workgroups than CUs: two stages (65 KB) so that two workgroups share a CU
+  static const int forced_stages = getenv("FFH_GLDS_BWD_STAGES") ? atoi(getenv("FFH_GLDS_BWD_STAGES")) : 0;   // A/B switch (tools/ab.sh)
+  const bool two = forced_stages ? forced_stages == 2 : (na8 + nb) > (unsigned)c->num_cus;
+  const int lds2 = 2 * 128 * 256 + 1024;
+#define FFH_DUAL(BMV, NS, LDSV)                                                                                                   \
+  {                                                                                                                               \
+    auto kern = gemm_glds_bwd_kernel<BMV, NS>;                                                                                    \
+    static const bool ok = glds_set_lds(kern, NS * 128 * 256 + 1024);                                                             \
+    if (!ok) return 0;                                                                                                            \
+    if (ev) hipExtLaunchKernelGGL(kern, dim3(na8 + nb), dim3(kGldsWaves * 64), LDSV, as_stream(s), nullptr, ev, 0, dxg, dx, na8, dwg, dw); \
+    else hipLaunchKernelGGL(kern, dim3(na8 + nb), dim3(kGldsWaves * 64), LDSV, as_stream(s), dxg, dx, na8, dwg, dw);              \
   }
+  if (px.bm == 64) { if (two) FFH_DUAL(64, 2, lds2) else FFH_DUAL(64, 3, lds) }
+  else { if (two) FFH_DUAL(32, 2, lds2) else FFH_DUAL(32, 3, lds) }
+#undef FFH_DUAL
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, "linear_bwd dx+dw (lds-dma, one launch)");
+  if (ev) c->attach_event = nullptr;        // signalled by this kernel's own completion: no separate packet on s
   return 1;
 }
 
@@ -1305,7 +1322,19 @@ extern "C" {
 int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
                       float* dy, int64_t lddy, const float* w, float* dw, float* db,
                       int in, int out, int64_t batch, int act, int flags, ffh_stream s, ffh_stream s_dw) {
-  return linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, s_dw, nullptr, 0.0f, nullptr, 0);
+  const int rc = linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, s_dw, nullptr, 0.0f, nullptr, 0);
+  if (c && c->attach_event) {        // no launch could carry it: the ordinary record behind everything this call put on s
+    hipEvent_t ev = (hipEvent_t)c->attach_event;
+    c->attach_event = nullptr;
+    if (rc == FFH_OK) FFH_HIP_TRY(c, hipEventRecord(ev, as_stream(s)));
+  }
+  return rc;
+}
+
+int ffh_event_record_with_next_linear_bwd(ffh_ctx* c, ffh_event e) {
+  if (!c || !e) return FFH_ERR_BAD_ARG;
+  c->attach_event = e;
+  return FFH_OK;
 }
 
 int ffh_linear_bwd_mse(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,

@@ -93,6 +93,13 @@ int ffh_event_create(ffh_ctx* c, ffh_event* e) {
   *e = (ffh_event)ev;
   return FFH_OK;
 }
+int ffh_event_create_sync(ffh_ctx* c, ffh_event* e) {
+  if (!e) return FFH_ERR_BAD_ARG;
+  hipEvent_t ev;
+  FFH_HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  *e = (ffh_event)ev;
+  return FFH_OK;
+}
 int ffh_event_destroy(ffh_ctx* c, ffh_event e) { if (e) FFH_HIP_TRY(c, hipEventDestroy((hipEvent_t)e)); return FFH_OK; }
 int ffh_event_record(ffh_ctx* c, ffh_event e, ffh_stream s) { FFH_HIP_TRY(c, hipEventRecord((hipEvent_t)e, as_stream(s))); return FFH_OK; }
 int ffh_event_sync(ffh_ctx* c, ffh_event e) { FFH_HIP_TRY(c, hipEventSynchronize((hipEvent_t)e)); return FFH_OK; }

@@ -102,6 +102,8 @@ class FFConfig {
   bool overlap_embedding;      // embedding gather (+exchange) on a side stream beside the bottom MLP
   bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
   int64_t column_shard_rows;   // tables with at least this many rows are sharded column-wise over the ranks (0: never)
+  bool attach_events;          // hang ev_grad_ready on the producing kernel's completion instead of a record packet (A/B: --no-attach-event)
+  bool timing_events;          // A/B: stream-ordering events created with timestamps, as before
   bool fuse_loss;              // loss step + metrics inside the last layer's one-launch backward (A/B: --no-fused-loss)
   int64_t row_shard_rows;      // ... row-wise instead: partial bag sums + reduce-scatter (0: never; wins over column_shard_rows)
   bool async_launch;           // auxiliary streams are fed by their own host threads (HIP backend only)
@@ -483,6 +485,8 @@ class FFModel {
   void join_embedding_forward() const;
   void issue_embedding_update_on_side_stream() const;
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
+  int grad_attach_layer;        // the Linear whose backward completes the embedding output gradients (-1: none / not attachable)
+  mutable bool grad_ready_attached;
 
   // slabs
   float *mlp_weights, *mlp_grads;  size_t mlp_count;          // all Linear params, contiguous (one all-reduce, one SGD launch)

@@ -127,6 +127,8 @@ FFConfig::FFConfig() {
   column_shard_rows = 0;
   row_shard_rows = 0;
   fuse_loss = true;
+  timing_events = false;
+  attach_events = true;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
   comm.world_size = 1;
@@ -173,6 +175,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--column-shard-rows")) { column_shard_rows = atoll(next()); continue; }
     if (is("--row-shard-rows")) { row_shard_rows = atoll(next()); continue; }
     if (is("--no-fused-loss")) { fuse_loss = false; continue; }
+    if (is("--timing-events")) { timing_events = true; continue; }
+    if (is("--no-attach-event")) { attach_events = false; continue; }
   }
 }
 
@@ -400,17 +404,17 @@ FFModel::FFModel(FFConfig& _config)
   check(api->ffh_stream_create(ctx, &stream), "stream create");
   check(api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
-  check(api->ffh_event_create(ctx, &ev_dw_done), "event create");
+  check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw_done), "event create");
   dw_worker = side_worker = nullptr;
   if (config.async_launch && (std::string(api->ffh_backend_name()).rfind("hip", 0) == 0 || getenv("FFM_FORCE_ASYNC_LAUNCH"))) {
     // asynchronous devices only: on the CPU oracle a "launch" is the computation itself
     dw_worker = new LaunchWorker(api, config.device);
     side_worker = new LaunchWorker(api, config.device);
   }
-  check(api->ffh_event_create(ctx, &ev_fork), "event create");
-  check(api->ffh_event_create(ctx, &ev_join), "event create");
-  check(api->ffh_event_create(ctx, &ev_grad_ready), "event create");
-  check(api->ffh_event_create(ctx, &ev_update_done), "event create");
+  check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_fork), "event create");
+  check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_join), "event create");
+  check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_grad_ready), "event create");
+  check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_update_done), "event create");
 }
 
 FFModel::~FFModel() {
@@ -667,7 +671,7 @@ void Embedding::backward(const FFModel& ff) {
     if (ff.config.overlap_embedding) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
       // backward(), after the host has enqueued the bottom-MLP backward it overlaps with
-      ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
+      if (!ff.grad_ready_attached) ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
       if (ff.exchange && !ff.config.comm.nonblocking && !ff.use_workers()) {
         ff.emb_update_pending = true;      // host-side collectives on this thread: issue after the bottom-MLP backward is enqueued
       } else {
@@ -1374,6 +1378,27 @@ void FFModel::allocate() {
     }
   }
 
+  // ---- 4c. the kernel that completes the embedding output gradients -----------------------------
+  // In reverse layer order the tables come right after the Concat that gathers them; when that Concat's backward has
+  // nothing to launch (every input writes its gradient slice in place) the op before it -- the first top-MLP layer --
+  // produces those gradients, and the "gradients ready" event for the side-stream update can ride on its kernel.
+  grad_attach_layer = -1;
+  if (!embeddings.empty() && config.attach_events && config.overlap_embedding && !exchange && !use_workers() && fused_embedding_update()) {
+    size_t l = (size_t)embeddings.back()->layer_index + 1;
+    while (l < layers.size()) {
+      Concat* c = dynamic_cast<Concat*>(layers[l]);
+      if (!c) break;
+      bool noop = true;
+      for (int i = 0; i < c->numInputs; i++) {
+        auto it = alias_of.find(c->inputs[i].impl);
+        if (it == alias_of.end() || it->second.first != c) noop = false;
+      }
+      if (!noop) { l = layers.size(); break; }
+      l++;
+    }
+    if (l < layers.size() && layers[l]->op_type == OP_LINEAR && l == (size_t)embeddings.back()->layer_index + 2) grad_attach_layer = (int)l;
+  }
+
   // ---- 5. parameters: one slab for every Linear tensor, tables on their own ---------------------
   mlp_count = 0;
   for (Parameter& p : parameters)
@@ -1644,7 +1669,14 @@ void FFModel::backward(int _seq_length) {
   if (rc != FFH_OK)
     check(api->ffh_mse_bwd_metrics(ctx, fin.impl->grad, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, d_perf,
                                    local_rows(fin, this), fin.adim[0], scale, metrics_flags, stream), "metrics + loss backward");
-  for (int l = first; l >= 0; l--) layers[l]->backward(*this);
+  grad_ready_attached = false;
+  for (int l = first; l >= 0; l--) {
+    if (l == grad_attach_layer) {
+      check(api->ffh_event_record_with_next_linear_bwd(ctx, ev_grad_ready), "attach event");
+      grad_ready_attached = true;
+    }
+    layers[l]->backward(*this);
+  }
   if (emb_update_pending) {
     // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
     issue_embedding_update_on_side_stream();

@@ -137,6 +137,8 @@ int ffh_stream_destroy(ffh_ctx* ctx, ffh_stream s);
 int ffh_stream_sync(ffh_ctx* ctx, ffh_stream s);
 int ffh_device_sync(ffh_ctx* ctx);
 int ffh_event_create(ffh_ctx* ctx, ffh_event* e);
+/* an event that only orders streams: no timestamps (ffh_event_elapsed_ms refuses it), cheaper to record */
+int ffh_event_create_sync(ffh_ctx* ctx, ffh_event* e);
 int ffh_event_destroy(ffh_ctx* ctx, ffh_event e);
 int ffh_event_record(ffh_ctx* ctx, ffh_event e, ffh_stream s);
 int ffh_event_sync(ffh_ctx* ctx, ffh_event e);
@@ -267,6 +269,10 @@ int ffh_linear_bwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t
  * Returns 1 if any call on this ctx has issued work on a caller-supplied second stream since the flag was last
  * cleared (clear != 0 clears it), else 0: a caller that joins s_dw only when this says so saves the join's packets. */
 int ffh_second_stream_used(ffh_ctx* ctx, int clear);
+/* The next ffh_linear_bwd_ex on this ctx also records `e` on its stream s, behind everything it puts there -- the same
+ * as calling ffh_event_record(ctx, e, s) right after it, except that the library may hang the event on its last kernel's
+ * own completion signal (hipExtLaunchKernelGGL's stop event) instead of sending a separate barrier packet down s. */
+int ffh_event_record_with_next_linear_bwd(ffh_ctx* ctx, ffh_event e);
 int ffh_linear_bwd_ex(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,
                       const float* w, float* dw, float* db,
@@ -412,7 +418,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) \
   X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
   X(ffh_stream_create) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
-  X(ffh_event_create) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \
+  X(ffh_event_create) X(ffh_event_create_sync) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \
   X(ffh_stream_wait_event) X(ffh_event_elapsed_ms) \
   X(ffh_graph_begin_capture) X(ffh_graph_end_capture) X(ffh_graph_launch) X(ffh_graph_destroy) \
   X(ffh_fill_f32) X(ffh_zero) X(ffh_init_uniform) \
@@ -420,7 +426,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_second_stream_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

@@ -1,8 +1,12 @@
 #!/bin/bash
-# one GPU-box visit: the whole -m gpu suite, then bench lines of the variants added last
-mkdir -p gpurun_out
-timeout 1700 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^\[DLRM\]" | tail -15 > gpurun_out/pytest_gpu.txt
-tail -3 gpurun_out/pytest_gpu.txt
-for wl in mlperf mlperf-allpairs; do
-  timeout 600 python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/bench_$wl.json 2> gpurun_out/bench_$wl.err; head -c 400 gpurun_out/bench_$wl.json; echo; tail -2 gpurun_out/bench_$wl.err
+# one GPU-box visit: A/B of the LDS-DMA GEMM knobs
+python -c "import torch" 2>/dev/null
+bash tools/ab.sh 3 "FFH_GLDS_SPLIT_ROWS=1" 2>/dev/null | grep round
+for v in "FFH_NONE=0" "FFH_GLDS_MAX_TILES=100000" "FFH_NONE=0" "FFH_GLDS_MAX_TILES=100000"; do
+  us=$(env $v timeout 300 python bench.py --workload mlperf --no-cpu-baseline --steps 50 --warmup 5 2>/dev/null | grep "^{" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f' % (d['ms_per_step']*1e3))")
+  echo "mlperf $v $us us"
+done
+for v in "FFH_NONE=0" "FFH_GLDS_MAX_TILES=100000"; do
+  us=$(env $v timeout 300 python bench.py --workload terabyte --no-cpu-baseline --steps 50 --warmup 5 2>/dev/null | grep "^{" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%.1f' % (d['ms_per_step']*1e3))")
+  echo "terabyte $v $us us"
 done

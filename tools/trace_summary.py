@@ -4,13 +4,16 @@ import csv, sys, collections
 path = sys.argv[1]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# locate the last mse_bwd_kernel occurrences to delimit one steady-state step
+# a step is delimited by the kernel that opens backward(): the loss + metrics launch, or the last layer's one-launch
+# backward that now carries the loss step (linear_skinny_bwd_kernel<*, 1> / <*, 4> right after a skinny forward)
 idx = [i for i, r in enumerate(rows) if "metrics_kernel" in r["Kernel_Name"]]
+if len(idx) < 25:
+    idx = [i for i, r in enumerate(rows) if i > 0 and "linear_skinny_bwd_kernel" in r["Kernel_Name"] and "linear_skinny_fwd_kernel" in rows[i - 1]["Kernel_Name"]]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -20
 a, b = idx[which], idx[which + 1]
 # a step spans from the first kernel after previous step's last kernel ... approximate: window between consecutive mse kernels
 t0 = int(rows[a]["Start_Timestamp"])
-print(f"window between two consecutive metrics+loss kernels: {(int(rows[b]['Start_Timestamp']) - t0) / 1e3:.1f} us, {b - a} kernels")
+print(f"window between two consecutive loss (+ last layer backward) kernels: {(int(rows[b]['Start_Timestamp']) - t0) / 1e3:.1f} us, {b - a} kernels")
 busy = 0
 last_end = t0
 for r in rows[a:b]:
