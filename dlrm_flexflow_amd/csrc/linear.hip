@@ -963,9 +963,13 @@ struct SkinnyBwdArgs {
   const float* label;  float loss_scale;  ffh_perf_metrics* perf;  int metrics_flags;
 };
 
-// NC: 16-byte column chunks per lane (in <= 256 * NC), NO: output slots kept in registers (out <= NO)
-template <int NC, int NO>
+// NC: 16-byte column chunks per lane (in <= 256 * NC), NO: output slots kept in registers (out <= NO),
+// RPW: rows per wave-instruction -- a row of in = 256 / RPW floats fills 64 / RPW lanes, so RPW rows go side by side
+// (lane = rsub * (64 / RPW) + chunk) instead of leaving three quarters of the wave idle on the 64-wide layer
+template <int NC, int NO, int RPW = 1>
 __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdArgs a) {
+  static_assert(RPW == 1 || NC == 1, "row packing is for rows narrower than a wave");
+  constexpr int LPR = 64 / RPW;
   extern __shared__ float s_dz[];                       // [rows_per_block][out], then the cross-wave dW reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t b0 = (int64_t)blockIdx.x * a.rows_per_block;
@@ -1044,36 +1048,37 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
   // 2. a wave takes rows wave, wave + 4, ...; a lane owns the 16-byte column chunks lane, lane + 64, ... of every row
   //    (in <= 1024: at most 4 chunks), so a row is one coalesced pass; four rows are in flight per wave
   const int nch = a.in / 4;
+  const int rsub = lane / LPR, lch = lane - rsub * LPR;          // RPW == 1: rsub = 0, lch = lane
   float4 wv[NC][NO];
   float4 dwacc[NC][NO];
 #pragma unroll
   for (int c = 0; c < NC; c++)
 #pragma unroll
     for (int o = 0; o < NO; o++) {
-      const int ch = lane + 64 * c;
+      const int ch = lch + 64 * c;
       wv[c][o] = (ch < nch && o < a.out && a.do_dx) ? reinterpret_cast<const float4*>(a.w + (int64_t)o * a.in)[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
       dwacc[c][o] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  constexpr int U = NO > 4 ? 4 : 16 / NC;   // rows in flight per wave: U x NC 16-byte loads per lane (fewer when NO slots fill the registers)
-  for (int r0 = wave; r0 < rows; r0 += 4 * U) {
+  constexpr int U = NO > 4 ? 4 : 16 / NC;   // rows in flight per lane: U x NC 16-byte loads (fewer when NO slots fill the registers)
+  for (int r0 = wave * RPW + rsub; r0 < rows + rsub; r0 += 4 * RPW * U) {
     float4 xv[U][NC];
 #pragma unroll
     for (int u = 0; u < U; u++)
 #pragma unroll
       for (int c = 0; c < NC; c++) {
-        const int r = r0 + 4 * u, ch = lane + 64 * c;
+        const int r = r0 + 4 * RPW * u, ch = lch + 64 * c;
         xv[u][c] = (r < rows && ch < nch) ? reinterpret_cast<const float4*>(a.x + (b0 + r) * a.ldx)[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      const int r = r0 + 4 * u;
+      const int r = r0 + 4 * RPW * u;
       if (r >= rows) continue;
       float dz[NO];
 #pragma unroll
       for (int o = 0; o < NO; o++) dz[o] = o < a.out ? s_dz[r * a.out + o] : 0.0f;
 #pragma unroll
       for (int c = 0; c < NC; c++) {
-        const int ch = lane + 64 * c;
+        const int ch = lch + 64 * c;
         if (ch >= nch) continue;
         const float4 x4 = xv[u][c];
         if (a.do_dw) {
@@ -1100,6 +1105,16 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
       }
     }
   }
+  if (RPW > 1 && a.do_dw) {
+    // the RPW row slots of a lane's chunk meet in the slot-0 lanes
+#pragma unroll
+    for (int o = 0; o < NO; o++)
+#pragma unroll
+      for (int m = LPR; m < 64; m <<= 1) {
+        dwacc[0][o].x += __shfl_xor(dwacc[0][o].x, m); dwacc[0][o].y += __shfl_xor(dwacc[0][o].y, m);
+        dwacc[0][o].z += __shfl_xor(dwacc[0][o].z, m); dwacc[0][o].w += __shfl_xor(dwacc[0][o].w, m);
+      }
+  }
   if (a.do_dw) {
     // the four waves' partial sums meet in LDS, one atomic per weight per workgroup
     __syncthreads();
@@ -1108,8 +1123,8 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
     for (int o = 0; o < NO; o++)
 #pragma unroll
       for (int c = 0; c < NC; c++) {
-        const int ch = lane + 64 * c;
-        if (o < a.out && ch < nch) red[((int64_t)wave * a.out + o) * nch + ch] = dwacc[c][o];
+        const int ch = lch + 64 * c;
+        if (o < a.out && ch < nch && rsub == 0) red[((int64_t)wave * a.out + o) * nch + ch] = dwacc[c][o];
       }
     __syncthreads();
     for (int e = tid; e < a.out * nch; e += 256) {
@@ -1216,6 +1231,8 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
 #define FFH_SKINNY(NCV, NOV) hipLaunchKernelGGL((linear_skinny_bwd_kernel<NCV, NOV>), dim3(grid), dim3(256), lds, as_stream(s), a)
     if (out == 1) { if (nc == 1) FFH_SKINNY(1, 1); else if (nc == 2) FFH_SKINNY(2, 1); else FFH_SKINNY(4, 1); }
     else if (out <= 4) { if (nc == 1) FFH_SKINNY(1, 4); else if (nc == 2) FFH_SKINNY(2, 4); else FFH_SKINNY(4, 4); }
+    else if (in == 64) hipLaunchKernelGGL((linear_skinny_bwd_kernel<1, 16, 4>), dim3(grid), dim3(256), lds, as_stream(s), a);
+    else if (in == 128) hipLaunchKernelGGL((linear_skinny_bwd_kernel<1, 16, 2>), dim3(grid), dim3(256), lds, as_stream(s), a);
     else FFH_SKINNY(1, 16);
 #undef FFH_SKINNY
     FFH_LAUNCH_CHECK(c, "linear_skinny_bwd_kernel");
