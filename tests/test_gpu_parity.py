@@ -373,7 +373,8 @@ def test_linear_torch_golden(hip):
     (2048, 64, 16, capi.AC_MODE_RELU), (2048, 432, 512, capi.AC_MODE_RELU), (2048, 256, 1, capi.AC_MODE_SIGMOID),
     (128, 144, 64, capi.AC_MODE_NONE), (4096, 1024, 1024, capi.AC_MODE_RELU), (333, 77, 45, capi.AC_MODE_SIGMOID),
     (10, 2000, 1000, capi.AC_MODE_NONE), (4096, 1024, 1, capi.AC_MODE_SIGMOID), (515, 300, 4, capi.AC_MODE_RELU),
-    (64, 1500, 2, capi.AC_MODE_NONE), (300, 20, 100, capi.AC_MODE_RELU), (64, 32, 64, capi.AC_MODE_NONE), (4096, 13, 512, capi.AC_MODE_RELU)])
+    (64, 1500, 2, capi.AC_MODE_NONE), (300, 20, 100, capi.AC_MODE_RELU), (64, 32, 64, capi.AC_MODE_NONE), (4096, 13, 512, capi.AC_MODE_RELU),
+    (37, 5, 16, capi.AC_MODE_SIGMOID), (1001, 16, 1024, capi.AC_MODE_NONE), (33, 1, 64, capi.AC_MODE_RELU), (2048, 13, 96, capi.AC_MODE_RELU)])
 def test_linear_vs_oracle(hip, oracle, B, IN, OUT, act):
     """DLRM layer shapes of C1/C2/C4 plus ragged sizes and the reference harness shape
     (10,2000,1000) [ref: tests/ops/test_harness.py:201-283]."""
