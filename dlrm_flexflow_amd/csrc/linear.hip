@@ -1136,6 +1136,123 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
   }
 }
 
+// =============================================================================================
+// Two narrow layers at the end of a chain (DLRM's bottom MLP ends 256 -> 64 -> 16): the UPPER layer's whole backward and the
+// LOWER layer's data gradient in ONE launch.  As separate launches these are three latency-bound kernels (out <= 16
+// one-launch backward, then the lower layer's dX GEMM) whose operands are a few KB per 32 samples; here a workgroup of eight
+// waves owns 32 samples and keeps the 32 x in_u activation gradient between the layers in LDS:
+//   g_l = (dy_u W_u) . act_l'(x_u)          MFMA, K = out_u <= 16      -> LDS and dy_l (the lower layer's premasked dy)
+//   dW_u += dy_u^T x_u, db_u += sum dy_u    MFMA, K = the 32 samples   -> atomics (out_u x in_u values per workgroup)
+//   dX_l = g_l W_l (. relu'(x_l))           MFMA, K = in_u <= 64, one 32-column tile per wave
+// The lower layer's dW / db stay a GEMM over the whole batch (a per-workgroup partial of in_u x in_l values would cost
+// more in atomics than the launch saves).
+// =============================================================================================
+struct PairBwdArgs {
+  const float* xu; int64_t ldxu;                         // upper layer's input = lower layer's output  [B][in_u]
+  float* dyu; int64_t lddyu; const float* yu; int64_t ldyu;   // upper layer's output gradient (activation gradient written back) and output
+  const float* wu; float* dwu; float* dbu;               // W_u [out_u][in_u]
+  int in_u, out_u, act_u;                                // act_u: NONE when dy_u is premasked
+  const float* xl; int64_t ldxl;                         // lower layer's input  [B][in_l] (read for the mask only)
+  float* dxl; int64_t lddxl;                             // lower layer's data gradient
+  float* dyl; int64_t lddyl;                             // lower layer's output gradient, written premasked
+  const float* wl;                                       // W_l [in_u][in_l]
+  int in_l, act_l, dxl_overwrite, dxl_mask_by_x;
+  int64_t batch;
+};
+
+__global__ __launch_bounds__(512) void linear_pair_bwd_kernel(const PairBwdArgs a) {
+  __shared__ float s_gu[32][17];                         // dy_u tile after its activation gradient
+  __shared__ float s_gl[32][65];                         // g_l tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t b0 = (int64_t)blockIdx.x * 32;
+  const int rows = (int)((a.batch - b0) < 32 ? (a.batch - b0) : 32);
+  {   // 1. the upper layer's activation gradient, once per element (in place, as the reference)
+    const int i = tid >> 4, o = tid & 15;
+    float d = 0.0f;
+    if (i < rows && o < a.out_u) {
+      d = a.dyu[(b0 + i) * a.lddyu + o];
+      if (a.act_u == FFH_AC_MODE_RELU) d = a.yu[(b0 + i) * a.ldyu + o] > 0.0f ? d : 0.0f;
+      else if (a.act_u == FFH_AC_MODE_SIGMOID) { const float yo = a.yu[(b0 + i) * a.ldyu + o]; d = d * yo * (1 - yo); }
+      if (a.act_u != FFH_AC_MODE_NONE) a.dyu[(b0 + i) * a.lddyu + o] = d;
+    }
+    s_gu[i][o] = d;
+  }
+  __syncthreads();
+  const int ntu = a.in_u / 32;                           // 32-column tiles of the upper layer's input (1 or 2)
+  if (wave < ntu) {
+    // 2a. g_l tile: A = dy_u (rows = samples, k = out_u padded to 16), B = W_u[k][n]
+    const int n0 = wave * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; v++) acc[v] = 0.0f;
+    float bv[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int k = 8 * h + q; bv[q] = k < a.out_u ? a.wu[(int64_t)k * a.in_u + n0 + r] : 0.0f; }
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_gu[r][8 * h + q], bv[q], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+      float g = acc[v];
+      if (i < rows) {
+        if (a.act_l == FFH_AC_MODE_RELU) g = a.xu[(b0 + i) * a.ldxu + n0 + r] > 0.0f ? g : 0.0f;
+        a.dyl[(b0 + i) * a.lddyl + n0 + r] = g;
+      } else {
+        g = 0.0f;
+      }
+      s_gl[i][n0 + r] = g;
+    }
+  } else if (wave < 2 * ntu) {
+    // 2b. dW_u tile: A = dy_u^T (rows = out_u padded to 32, k = the 32 samples), B = x_u[k][n]
+    const int n0 = (wave - ntu) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; v++) acc[v] = 0.0f;
+    float bv[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const int i = 16 * h + q; bv[q] = i < rows ? a.xu[(b0 + i) * a.ldxu + n0 + r] : 0.0f; }
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(r < 16 ? s_gu[16 * h + q][r] : 0.0f, bv[q], acc, 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int m = 8 * (v >> 2) + 4 * h + (v & 3);
+      if (m < a.out_u) atomicAdd(&a.dwu[(int64_t)m * a.in_u + n0 + r], acc[v]);
+    }
+  } else if (wave == 2 * ntu && a.dbu) {
+    if (lane < a.out_u) {
+      float sum = 0.0f;
+      for (int i = 0; i < 32; i++) sum += s_gu[i][lane];
+      atomicAdd(&a.dbu[lane], sum);
+    }
+  }
+  __syncthreads();
+  // 3. dX_l: one 32-column tile per wave; A = g_l (k = in_u), B = W_l[k][n]
+  const int half = a.in_u / 2;                           // lane half h supplies k = half * h + q
+  for (int n0 = wave * 32; n0 < a.in_l; n0 += 8 * 32) {
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; v++) acc[v] = 0.0f;
+    for (int q0 = 0; q0 < half; q0 += 16) {
+      float bv[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) bv[q] = a.wl[(int64_t)(half * h + q0 + q) * a.in_l + n0 + r];
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s_gl[r][half * h + q0 + q], bv[q], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+      if (i >= rows) continue;
+      float g = acc[v];
+      if (a.dxl_mask_by_x) g = a.xl[(b0 + i) * a.ldxl + n0 + r] > 0.0f ? g : 0.0f;
+      float* p = a.dxl + (b0 + i) * a.lddxl + n0 + r;
+      *p = a.dxl_overwrite ? g : *p + g;
+    }
+  }
+}
+
+
 bool act_ok(int act) { return act == FFH_AC_MODE_NONE || act == FFH_AC_MODE_RELU || act == FFH_AC_MODE_SIGMOID; }
 
 }  // namespace
@@ -1363,6 +1480,30 @@ int ffh_linear_bwd_mse(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64
   if (ldy != out || lddy != out) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: y and dy must be contiguous [batch][out_dim]");
   if (batch == 0) return FFH_OK;
   return linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, nullptr, label, scale, perf, metrics_flags);
+}
+
+int ffh_linear_pair_bwd(ffh_ctx* c, const float* x_u, int64_t ldx_u, const float* y_u, int64_t ldy_u, float* dy_u, int64_t lddy_u,
+                        const float* w_u, float* dw_u, float* db_u, int in_u, int out_u, int act_u, int flags_u,
+                        const float* x_l, int64_t ldx_l, float* dx_l, int64_t lddx_l, float* dy_l, int64_t lddy_l, const float* w_l,
+                        int in_l, int act_l, int flags_l, int64_t batch, ffh_stream s) {
+  FFH_REQUIRE(c, in_u > 0 && out_u > 0 && in_l > 0 && batch >= 0 && ldx_u >= in_u && ldy_u >= out_u && lddy_u >= out_u && ldx_l >= in_l &&
+                     lddx_l >= in_l && lddy_l >= in_u, "linear_pair_bwd: bad dims");
+  FFH_REQUIRE(c, batch == 0 || (x_u && y_u && dy_u && w_u && dw_u && x_l && dx_l && dy_l && w_l), "linear_pair_bwd: null pointer");
+  if (!act_ok(act_u)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_bwd: activation not supported (NONE, RELU, SIGMOID)");
+  if ((flags_u & ~FFH_LINEAR_DY_PREMASKED) || (flags_l & ~(FFH_LINEAR_DX_OVERWRITE | FFH_LINEAR_DX_MASK_BY_X)))
+    return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_bwd: flags");
+  if (out_u > 16 || (in_u != 32 && in_u != 64) || in_l % 32 != 0 || (act_l != FFH_AC_MODE_RELU && act_l != FFH_AC_MODE_NONE) || batch >= (1LL << 31))
+    return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_bwd: shapes (out_u <= 16, in_u 32 or 64, in_l a multiple of 32; lower activation relu / none)");
+  if (batch == 0) return FFH_OK;
+  PairBwdArgs a{};
+  a.xu = x_u; a.ldxu = ldx_u; a.dyu = dy_u; a.lddyu = lddy_u; a.yu = y_u; a.ldyu = ldy_u; a.wu = w_u; a.dwu = dw_u; a.dbu = db_u;
+  a.in_u = in_u; a.out_u = out_u; a.act_u = (flags_u & FFH_LINEAR_DY_PREMASKED) ? FFH_AC_MODE_NONE : act_u;
+  a.xl = x_l; a.ldxl = ldx_l; a.dxl = dx_l; a.lddxl = lddx_l; a.dyl = dy_l; a.lddyl = lddy_l; a.wl = w_l;
+  a.in_l = in_l; a.act_l = act_l; a.dxl_overwrite = (flags_l & FFH_LINEAR_DX_OVERWRITE) ? 1 : 0; a.dxl_mask_by_x = (flags_l & FFH_LINEAR_DX_MASK_BY_X) ? 1 : 0;
+  a.batch = batch;
+  hipLaunchKernelGGL(linear_pair_bwd_kernel, dim3((unsigned)((batch + 31) / 32)), dim3(512), 0, as_stream(s), a);
+  FFH_LAUNCH_CHECK(c, "linear_pair_bwd_kernel");
+  return FFH_OK;
 }
 
 int ffh_second_stream_used(ffh_ctx* c, int clear) {

@@ -102,6 +102,7 @@ class FFConfig {
   bool overlap_embedding;      // embedding gather (+exchange) on a side stream beside the bottom MLP
   bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
   int64_t column_shard_rows;   // tables with at least this many rows are sharded column-wise over the ranks (0: never)
+  bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)
   bool attach_events;          // hang ev_grad_ready on the producing kernel's completion instead of a record packet (A/B: --no-attach-event)
   bool timing_events;          // A/B: stream-ordering events created with timestamps, as before
   bool fuse_loss;              // loss step + metrics inside the last layer's one-launch backward (A/B: --no-fused-loss)
@@ -280,6 +281,8 @@ class Linear : public Op {
   bool use_bias;
   bool discard_input_grad;      // first layer on a model input: dX is never consumed
   bool dx_overwrite;            // input has no other consumer: dX may be stored instead of accumulated
+  Linear* pair_lower;           // the layer below, when its data gradient rides in this layer's backward launch (ffh_linear_pair_bwd)
+  int backward_pair(const FFModel&);   // FFH_OK: this layer's backward and the lower layer's whole backward are enqueued
   bool dx_mask_by_x, dy_premasked;   // relu' of the layer below applied by this layer's dX epilogue / already applied by the layer above
   Initializer *kernel_initializer, *bias_initializer;
 };

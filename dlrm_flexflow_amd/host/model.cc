@@ -129,6 +129,7 @@ FFConfig::FFConfig() {
   fuse_loss = true;
   timing_events = false;
   attach_events = true;
+  fuse_pair = true;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
   comm.world_size = 1;
@@ -177,6 +178,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-fused-loss")) { fuse_loss = false; continue; }
     if (is("--timing-events")) { timing_events = true; continue; }
     if (is("--no-attach-event")) { attach_events = false; continue; }
+    if (is("--no-fused-pair")) { fuse_pair = false; continue; }
   }
 }
 
@@ -532,7 +534,7 @@ Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_
 Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activation, bool _use_bias, const Op* shared_op,
                Initializer* ki, Initializer* bi, const char* name)
     : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), activation(_activation),
-      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), dx_mask_by_x(false), dy_premasked(false),
+      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false),
       kernel_initializer(ki), bias_initializer(bi) {
   if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
   if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
@@ -559,6 +561,25 @@ void Linear::forward(const FFModel& ff) {
   ff.check(ff.api->ffh_linear_fwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, (float*)y.impl->ptr, y.impl->ld,
                                   (const float*)weights[0].impl->ptr, use_bias ? (const float*)weights[1].impl->ptr : nullptr,
                                   in_channels, out_channels, b, (int)activation, ff.stream), name);
+}
+int Linear::backward_pair(const FFModel& ff) {
+  Linear* lo = pair_lower;
+  const Tensor &xu = inputs[0], &yu = outputs[0], &xl = lo->inputs[0];
+  const int64_t b = local_rows(yu, &ff);
+  const int flags_u = dy_premasked ? FFH_LINEAR_DY_PREMASKED : 0;
+  const int flags_l = (lo->dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0) | (lo->dx_mask_by_x ? FFH_LINEAR_DX_MASK_BY_X : 0);
+  const int rc = ff.api->ffh_linear_pair_bwd(
+      ff.ctx, (const float*)xu.impl->ptr, xu.impl->ld, (const float*)yu.impl->ptr, yu.impl->ld, yu.impl->grad, yu.impl->grad_ld,
+      (const float*)weights[0].impl->ptr, weights[0].impl->grad, use_bias ? weights[1].impl->grad : nullptr, in_channels, out_channels,
+      (int)activation, flags_u, (const float*)xl.impl->ptr, xl.impl->ld, xl.impl->grad, xl.impl->grad_ld, xu.impl->grad, xu.impl->grad_ld,
+      (const float*)lo->weights[0].impl->ptr, lo->in_channels, (int)lo->activation, flags_l, b, ff.stream);
+  if (rc != FFH_OK) return rc;
+  // what is left of the lower layer: dW / db over the whole batch, from the gradient the launch above wrote (premasked)
+  ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, (const float*)xl.impl->ptr, xl.impl->ld, nullptr, xl.impl->grad_ld, (const float*)xu.impl->ptr, xu.impl->ld,
+                                     xu.impl->grad, xu.impl->grad_ld, (const float*)lo->weights[0].impl->ptr, lo->weights[0].impl->grad,
+                                     lo->use_bias ? lo->weights[1].impl->grad : nullptr, lo->in_channels, lo->out_channels, b, (int)lo->activation,
+                                     FFH_LINEAR_ONLY_DW | FFH_LINEAR_DY_PREMASKED, ff.stream, nullptr), lo->name);
+  return FFH_OK;
 }
 void Linear::backward(const FFModel& ff) {
   const Tensor& x = inputs[0];
@@ -1358,6 +1379,13 @@ void FFModel::allocate() {
         li->dx_mask_by_x = true;
         below->dy_premasked = true;
       }
+      // ... and two NARROW layers in a row (256 -> 64 -> 16 at the end of DLRM's bottom MLP): the upper layer's backward launch
+      // also produces the lower layer's data gradient (ffh_linear_pair_bwd); shapes it does not serve fall back at run time
+      li->pair_lower = nullptr;
+      if (config.fuse_pair && below && li->dx_overwrite && !below->discard_input_grad && below->inputs[0].impl->pieces.empty() &&
+          ((below->activation == AC_MODE_RELU && li->dx_mask_by_x) || below->activation == AC_MODE_NONE) && li->out_channels <= 16 &&
+          (li->in_channels == 32 || li->in_channels == 64) && below->in_channels % 32 == 0)
+        li->pair_lower = below;
     }
     if (DotInteraction* di = dynamic_cast<DotInteraction*>(op)) {
       di->bwd_overwrite = consumers[di->inputs[0].impl] == 1;
@@ -1674,6 +1702,13 @@ void FFModel::backward(int _seq_length) {
     if (l == grad_attach_layer) {
       check(api->ffh_event_record_with_next_linear_bwd(ctx, ev_grad_ready), "attach event");
       grad_ready_attached = true;
+    }
+    Linear* up = layers[l]->op_type == OP_LINEAR ? static_cast<Linear*>(layers[l]) : nullptr;
+    if (up && up->pair_lower && !use_workers() && l != grad_attach_layer && l >= 1 && layers[l - 1] == up->pair_lower) {
+      const int prc = up->backward_pair(*this);
+      if (prc == FFH_OK) { l--; continue; }                   // the lower layer is done as well
+      if (prc != FFH_ERR_UNSUPPORTED) check(prc, up->name);
+      up->pair_lower = nullptr;                                // not a shape the pair launch serves: the ordinary calls from now on
     }
     layers[l]->backward(*this);
   }

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse */
+#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_bwd */
 
 /* status codes */
 #define FFH_OK               0
@@ -343,6 +343,22 @@ int ffh_linear_bwd_mse(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int
                        int in_dim, int out_dim, int64_t batch, int activation, int flags,
                        const float* label, float scale, ffh_perf_metrics* perf, int metrics_flags, ffh_stream s);
 
+/* Two narrow layers at the end of a chain (DLRM's bottom MLP ends 256 -> 64 -> 16), x_l -> [LOWER: W_l, act_l] -> x_u ->
+ * [UPPER: W_u, act_u] -> y_u: the upper layer's whole backward and the lower layer's data gradient as ONE launch.  Exactly
+ *   ffh_linear_bwd_ex(ctx, x_u, ldx_u, dy_l, lddy_l, y_u, ldy_u, dy_u, lddy_u, w_u, dw_u, db_u, in_u, out_u, batch, act_u,
+ *                     flags_u | FFH_LINEAR_DX_OVERWRITE | (act_l == RELU ? FFH_LINEAR_DX_MASK_BY_X : 0), s, NULL)
+ *   ffh_linear_bwd_ex(ctx, x_l, ldx_l, dx_l, lddx_l, x_u, ldx_u, dy_l, lddy_l, w_l, NULL, NULL, in_l, in_u, batch, act_l,
+ *                     flags_l | FFH_LINEAR_ONLY_DX | FFH_LINEAR_DY_PREMASKED, s, NULL)
+ * (dy_l, the gradient between the layers, is written with the lower layer's activation derivative applied; the lower
+ * layer's dW / db remain one ffh_linear_bwd_ex(..., FFH_LINEAR_ONLY_DW | FFH_LINEAR_DY_PREMASKED) over the batch).
+ * flags_u: FFH_LINEAR_DY_PREMASKED or 0; flags_l: FFH_LINEAR_DX_OVERWRITE, FFH_LINEAR_DX_MASK_BY_X.  Served shapes:
+ * out_u <= 16, in_u 32 or 64, in_l a multiple of 32, act_l RELU or NONE; anything else returns FFH_ERR_UNSUPPORTED with
+ * nothing launched and the caller makes the two calls.  w_u is [out_u][in_u], w_l is [in_u][in_l]. */
+int ffh_linear_pair_bwd(ffh_ctx* ctx, const float* x_u, int64_t ldx_u, const float* y_u, int64_t ldy_u, float* dy_u, int64_t lddy_u,
+                        const float* w_u, float* dw_u, float* db_u, int in_u, int out_u, int act_u, int flags_u,
+                        const float* x_l, int64_t ldx_l, float* dx_l, int64_t lddx_l, float* dy_l, int64_t lddy_l, const float* w_l,
+                        int in_l, int act_l, int flags_l, int64_t batch, ffh_stream s);
+
 /* ------------------------------------------------------------------ */
 /* Strict lower triangle of the pairwise-dot matrix (MLPerf-DLRM's interaction keeps the 351 products
  * i > j of the 27 x 27 matrix; the reference has no operator for it -- its dot interaction is a TODO,
@@ -426,7 +442,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

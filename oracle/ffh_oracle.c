@@ -482,6 +482,22 @@ int ffh_linear_bwd_mse(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64
   return ffh_linear_bwd_ex(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, flags, s, s);
 }
 
+/* the two calls it stands for (include/ff_hip.h) */
+int ffh_linear_pair_bwd(ffh_ctx* c, const float* x_u, int64_t ldx_u, const float* y_u, int64_t ldy_u, float* dy_u, int64_t lddy_u,
+                        const float* w_u, float* dw_u, float* db_u, int in_u, int out_u, int act_u, int flags_u,
+                        const float* x_l, int64_t ldx_l, float* dx_l, int64_t lddx_l, float* dy_l, int64_t lddy_l, const float* w_l,
+                        int in_l, int act_l, int flags_l, int64_t B, ffh_stream s) {
+  if ((flags_u & ~FFH_LINEAR_DY_PREMASKED) || (flags_l & ~(FFH_LINEAR_DX_OVERWRITE | FFH_LINEAR_DX_MASK_BY_X)))
+    return fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_bwd: flags");
+  if (out_u > 16 || (in_u != 32 && in_u != 64) || in_l % 32 != 0 || (act_l != FFH_AC_MODE_RELU && act_l != FFH_AC_MODE_NONE))
+    return fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_bwd: shapes");
+  int rc = ffh_linear_bwd_ex(c, x_u, ldx_u, dy_l, lddy_l, y_u, ldy_u, dy_u, lddy_u, w_u, dw_u, db_u, in_u, out_u, B, act_u,
+                             flags_u | FFH_LINEAR_DX_OVERWRITE | (act_l == FFH_AC_MODE_RELU ? FFH_LINEAR_DX_MASK_BY_X : 0), s, s);
+  if (rc != FFH_OK) return rc;
+  return ffh_linear_bwd_ex(c, x_l, ldx_l, dx_l, lddx_l, x_u, ldx_u, dy_l, lddy_l, w_l, NULL, NULL, in_l, in_u, B, act_l,
+                           flags_l | FFH_LINEAR_ONLY_DX | FFH_LINEAR_DY_PREMASKED, s, s);
+}
+
 /* ------------------------------------------------------------------ */
 /* Concat                                                             */
 /* ------------------------------------------------------------------ */

@@ -477,6 +477,26 @@ def test_two_rank_fused_dot_interaction(tmp_path):
     assert seen == set(fused_names)
 
 
+def test_narrow_layer_pair_path_equals_plain_calls():
+    """A bottom MLP ending 96 -> 64 -> 16 takes the ffh_linear_pair_bwd route of the host layer (upper backward + lower dX
+    in one call, then the lower dW): on the oracle backend that is the same arithmetic as --no-fused-pair, bit for bit."""
+    args = ["--backend", H.oracle_backend(), "-b", "48", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "30-11",
+            "--arch-mlp-bot", "13-96-64-16", "--arch-mlp-top", "48-24-1", "--data-size", "48"]
+    res = []
+    for extra in ([], ["--no-fused-pair"]):
+        app = ffmodel.DLRM(args + extra)
+        app.warmup()
+        app.train_steps(3, trace=False)
+        m = app.model
+        m.sync()
+        res.append({l: m.parameter(l, 0).get_weights() for l in range(m.num_layers) if m.layer_num_weights(l)})
+        res[-1]["pred"] = m.layer_output(m.num_layers - 1).get()
+        app.close()
+    assert set(res[0]) == set(res[1])
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+
+
 def test_two_rank_driver_flags(tmp_path):
     """The DLRM application object under 2 ranks with the driver's flags (7 tables over 2 ranks:
     4 + 3, uneven all-to-all splits); loss decreases and both ranks hold identical MLPs."""

@@ -764,6 +764,58 @@ def test_linear_bwd_mse_equals_the_two_calls(hip, oracle, B, IN, OUT, act):
                  dev(label), 1.0 / B, perf, mf, None)
 
 
+@pytest.mark.parametrize("B,INL,INU,OUTU,act_u,act_l,fu,fl", [
+    (2048, 256, 64, 16, capi.AC_MODE_RELU, capi.AC_MODE_RELU, capi.LINEAR_DY_PREMASKED, capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DX_MASK_BY_X),
+    (2048, 256, 64, 16, capi.AC_MODE_RELU, capi.AC_MODE_RELU, 0, capi.LINEAR_DX_OVERWRITE),
+    (100, 96, 32, 5, capi.AC_MODE_SIGMOID, capi.AC_MODE_NONE, 0, 0),
+    (33, 32, 64, 16, capi.AC_MODE_NONE, capi.AC_MODE_RELU, 0, capi.LINEAR_DX_MASK_BY_X),
+    (4097, 512, 64, 1, capi.AC_MODE_RELU, capi.AC_MODE_RELU, 0, capi.LINEAR_DX_OVERWRITE)])
+def test_linear_pair_bwd_equals_the_two_calls(hip, oracle, B, INL, INU, OUTU, act_u, act_l, fu, fl):
+    """ffh_linear_pair_bwd (upper layer's backward + lower layer's dX in one launch, the gradient between them kept in
+    LDS) against the two ffh_linear_bwd_ex calls it stands for, on the GPU and in the oracle: activation gradients
+    bit-exact, everything that sums (dX_l, dW_u, db_u, dy_l) within 1e-5 of its absolute mass."""
+    rng = np.random.default_rng(B + INL + OUTU)
+    xl = rng.uniform(-1, 1, (B, INL)).astype(np.float32)
+    xu = rng.uniform(-1, 1, (B, INU)).astype(np.float32)          # the lower layer's output (relu: some entries <= 0)
+    yu = rng.uniform(-1, 1, (B, OUTU)).astype(np.float32)
+    if act_u == capi.AC_MODE_SIGMOID:
+        yu = np.abs(yu) * 0.9 + 0.05
+    gu = rng.uniform(-1, 1, (B, OUTU)).astype(np.float32)
+    wu = (rng.uniform(-1, 1, (OUTU, INU)) / np.sqrt(INU)).astype(np.float32)
+    wl = (rng.uniform(-1, 1, (INU, INL)) / np.sqrt(INL)).astype(np.float32)
+    dx0 = rng.uniform(-1, 1, (B, INL)).astype(np.float32)         # accumulate form starts from this
+
+    def run(fused):
+        dyu, dxl = dev(gu), dev(dx0)
+        dyl = torch.full((B, INU), 5.0, dtype=torch.float32, device=DEV)
+        dwu, dbu = torch.zeros(OUTU, INU, device=DEV), torch.zeros(OUTU, device=DEV)
+        dwl, dbl = torch.zeros(INU, INL, device=DEV), torch.zeros(INU, device=DEV)
+        X = dict(xu=dev(xu), yu=dev(yu), wu=dev(wu), xl=dev(xl), wl=dev(wl))
+        if fused:
+            hip.call("ffh_linear_pair_bwd", X["xu"], INU, X["yu"], OUTU, dyu, OUTU, X["wu"], dwu, dbu, INU, OUTU, act_u, fu,
+                     X["xl"], INL, dxl, INL, dyl, INU, X["wl"], INL, act_l, fl, B, None)
+        else:
+            up = fu | capi.LINEAR_DX_OVERWRITE | (capi.LINEAR_DX_MASK_BY_X if act_l == capi.AC_MODE_RELU else 0)
+            hip.call("ffh_linear_bwd_ex", X["xu"], INU, dyl, INU, X["yu"], OUTU, dyu, OUTU, X["wu"], dwu, dbu, INU, OUTU, B, act_u, up, None, None)
+            hip.call("ffh_linear_bwd_ex", X["xl"], INL, dxl, INL, X["xu"], INU, dyl, INU, X["wl"], dwl, dbl, INL, INU, B, act_l,
+                     fl | capi.LINEAR_ONLY_DX | capi.LINEAR_DY_PREMASKED, None, None)
+        return [host(t) for t in (dyu, dyl, dxl, dwu, dbu)]
+
+    f, t = run(True), run(False)
+    assert bits_equal(f[0], t[0])                                  # dy_u after the upper activation gradient
+    au = np.abs(t[0]).astype(np.float64)
+    assert_gemm_close(f[1], t[1], au @ np.abs(wu).astype(np.float64), "dy_l")
+    al = np.abs(t[1]).astype(np.float64)
+    assert_gemm_close(f[2], t[2], al @ np.abs(wl).astype(np.float64) + np.abs(dx0), "dx_l")
+    assert_gemm_close(f[3], t[3], au.T @ np.abs(xu).astype(np.float64), "dw_u")
+    assert_gemm_close(f[4], t[4], au.sum(0), "db_u")
+    if act_l == capi.AC_MODE_RELU:
+        assert (f[1][xu <= 0] == 0).all()                          # premasked for the lower layer
+    with pytest.raises(capi.FFHError):                             # in_u = 48: not served, nothing launched
+        hip.call("ffh_linear_pair_bwd", dev(xu), INU, dev(yu), OUTU, dev(gu), OUTU, dev(wu), torch.zeros(OUTU, INU, device=DEV), None, 48, OUTU,
+                 act_u, fu, dev(xl), INL, dev(dx0), INL, torch.zeros(B, INU, device=DEV), INU, dev(wl), INL, act_l, fl, B, None)
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties
 # ---------------------------------------------------------------------------
