@@ -111,7 +111,7 @@ def cpu_baseline_leg(name, per_gpu_batch, budget_s, out):
     app.train_steps(1, trace=False)
     app.model.sync()
     t1 = time.perf_counter() - t0
-    n = max(1, min(50, int(budget_s / max(t1, 1e-3))))
+    n = max(1, min(5000, int(budget_s / max(t1, 1e-5))))      # a few seconds of CPU work per leg
     t0 = time.perf_counter()
     app.train_steps(n, trace=False)
     app.model.sync()
