@@ -546,6 +546,25 @@ def test_concat_golden_and_alias(hip):
     assert (z[:, :16] == 1).all() and (z[:, 16:32] == 7).all() and (z[:, 32:] == 2).all()
 
 
+def test_concat_maximum_fan_in_and_ragged_widths(hip, oracle):
+    """256 inputs (MAX_NUM_INPUTS, [ref: include/config.h:30-37]) of ragged widths 1..7 in one launch each way, bit-exact;
+    an empty batch is a no-op; 257 inputs are refused."""
+    rng = np.random.default_rng(4)
+    nb = 37
+    widths = [int(w_) for w_ in rng.integers(1, 8, 256)]
+    parts = [rng.standard_normal((nb, w_)).astype(np.float32) for w_ in widths]
+    out = torch.empty(nb, sum(widths), device=DEV)
+    hip.concat("ffh_concat_fwd", out, sum(widths), [dev(p) for p in parts], widths, None, nb)
+    assert bits_equal(host(out), np.concatenate(parts, 1)) and bits_equal(host(out), oracle.concat_fwd(parts))
+    grads = [torch.zeros(nb, w_, device=DEV) for w_ in widths]
+    hip.concat("ffh_concat_bwd", out, sum(widths), grads, widths, None, nb)
+    for p, q in zip(parts, grads):
+        assert np.array_equal(p, host(q))
+    hip.concat("ffh_concat_fwd", out, sum(widths), [dev(p) for p in parts], widths, None, 0)      # empty batch
+    with pytest.raises(capi.FFHError):
+        hip.concat("ffh_concat_fwd", out, sum(widths) + 1, [dev(p) for p in parts] + [dev(parts[0])], widths + [1], None, nb)
+
+
 def test_bmm_golden_and_harness_shape(hip, oracle):
     g = golden("bmm_torch")
     for k in range(int(g["n_cases"])):
