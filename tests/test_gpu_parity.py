@@ -666,6 +666,32 @@ def test_dot_interaction_vs_oracle(hip, oracle, B, c, d):
         hip.call("ffh_dot_interaction_fwd", dev(z), ldz, out, ldo, B, 33, d, None)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_dot_interaction_random_shapes(hip, oracle, seed):
+    """Random (batch, vectors, width, strides) for the fused interaction and the tril kernels against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    B, c, d = int(rng.integers(1, 300)), int(rng.integers(2, 33)), int(rng.integers(1, 200))
+    P = c * (c - 1) // 2
+    ldz, ldo = c * d + int(rng.integers(0, 3)) * 4, d + P + int(rng.integers(0, 9))
+    z = rng.uniform(-1, 1, (B, ldz)).astype(np.float32)
+    zz = np.ascontiguousarray(z[:, :c * d]).reshape(B, c, d)
+    out = torch.full((B, ldo), 777.0, dtype=torch.float32, device=DEV)
+    hip.call("ffh_dot_interaction_fwd", dev(z), ldz, out, ldo, B, c, d, None)
+    got, exp = host(out), oracle.dot_interaction_fwd(zz)
+    assert bits_equal(got[:, :d], exp[:, :d]) and (got[:, d + P:] == 777).all()
+    np.testing.assert_allclose(got[:, d:d + P], exp[:, d:], rtol=1e-5, atol=1e-5 * max(1, d // 16))
+    g = rng.uniform(-1, 1, (B, ldo)).astype(np.float32)
+    zg = torch.zeros(B, ldz, device=DEV)
+    hip.call("ffh_dot_interaction_bwd", dev(z), ldz, dev(g), ldo, zg, ldz, B, c, d, 1, None)
+    np.testing.assert_allclose(host(zg)[:, :c * d].reshape(B, c, d), oracle.dot_interaction_bwd(zz, np.ascontiguousarray(g[:, :d + P])),
+                               rtol=1e-5, atol=2e-5 * max(1, c // 8))
+    n = c if c >= 2 else 2
+    m = rng.standard_normal((B, n, n)).astype(np.float32)
+    t = torch.full((B, n * (n - 1) // 2 + 2), 777.0, dtype=torch.float32, device=DEV)
+    hip.call("ffh_tril_fwd", t[:, 1:], t.shape[1], dev(m), B, n, None)
+    assert bits_equal(host(t), oracle.tril_fwd(m, out_ld=t.shape[1], col_off=1))
+
+
 def test_adam_and_zero_grad(hip, oracle):
     """ffh_adam_update / ffh_sgd_update_ex: bit-exact with the oracle, within 1e-5 of torch.optim.Adam (fixture)."""
     g = golden("adam_torch")
