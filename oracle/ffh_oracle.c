@@ -15,6 +15,12 @@
  * Concat / BatchMatmul / SGD / Adam / MSE functions against PyTorch-CPU + numpy,
  * the oracle the reference's op tests use (tests/ops/test_harness.py); vectors
  * are committed under tests/golden/ (tests/golden/make_golden.py).
+ * The pairwise-dot interaction (ffh_tril_*, ffh_dot_interaction_*) has no reference
+ * operator at all (the driver's "dot" is a TODO, examples/cpp/DLRM/dlrm.cc:53-54): it
+ * is pinned against torch.bmm + tril_indices, the composition the reference's op
+ * tests spell (tests/ops/test_harness.py:125-177) plus MLPerf's triangle.  The fused
+ * entry points ffh_linear_bwd_mse / ffh_linear_pair_bwd are, here, literally the two
+ * calls each stands for.
  * The metrics kernel's accumulation order, bags with more than one index in the
  * backward, and the multi-GPU exchange have no reference function, test or
  * golden vector: PARITY UNPINNED by the reference for those -- they are checked
