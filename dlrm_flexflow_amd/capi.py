@@ -105,6 +105,7 @@ _SIGS = {
     "ffh_linear_bwd_ex": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, P]),
     "ffh_linear_bwd_mse": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, F, P, I, P]),
     "ffh_linear_pair_bwd": (I, [P, P, L, P, L, P, L, P, P, P, I, I, I, I, P, L, P, L, P, L, P, I, I, I, L, P]),
+    "ffh_linear_pair_fwd": (I, [P, P, L, P, P, I, I, P, L, I, P, P, I, I, P, L, L, P]),
     "ffh_second_stream_used": (I, [P, I]),
     "ffh_event_record_with_next_linear_bwd": (I, [P, P]),
     "ffh_mse_bwd_metrics": (I, [P, P, P, P, P, L, I, F, I, P]),

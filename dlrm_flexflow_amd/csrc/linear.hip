@@ -1253,6 +1253,101 @@ __global__ __launch_bounds__(512) void linear_pair_bwd_kernel(const PairBwdArgs 
 }
 
 
+// The same two narrow layers forward: y_l = act_l(x_l W_l^T + b_l) and y_u = act_u(y_l W_u^T + b_u) in ONE launch.  Eight
+// waves own 32 samples: (mid / 32) output tiles x (8 / tiles) k-slices of the first product, operands straight from global
+// memory as 16-byte pieces (both are k-contiguous; which k a lane half holds is free as long as A and B agree); the
+// k-slices meet in LDS, bias + activation, y_l goes to memory and stays in LDS as the A operand of the second product.
+struct PairFwdArgs {
+  const float* xl; int64_t ldxl; const float* wl; const float* bl; int in_l, act_l;
+  float* yl; int64_t ldyl; int mid;
+  const float* wu; const float* bu; int out_u, act_u;
+  float* yu; int64_t ldyu;
+  int64_t batch;
+};
+
+__global__ __launch_bounds__(512) void linear_pair_fwd_kernel(const PairFwdArgs a) {
+  __shared__ float s_red[8 * 16 * 64];                   // [wave][reg][lane]: the k-slices of the first product
+  __shared__ float s_yl[32][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t b0 = (int64_t)blockIdx.x * 32;
+  const int rows = (int)((a.batch - b0) < 32 ? (a.batch - b0) : 32);
+  const int nt = a.mid / 32, ks = 8 / nt;                // output tiles, k-slices per tile
+  const int tile = wave % nt, slice = wave / nt;
+  const int kper = a.in_l / ks;                          // a multiple of 32 (checked by the caller)
+  const int n0 = tile * 32;
+  // second product's B operand (W_u[n][k], n < out_u): requested now, used last (wave 0)
+  float4 wu4[8];
+  const int half2 = a.mid / 2;                           // lane half h supplies k = half2 * h + q, q < half2 <= 32
+  if (wave == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      wu4[q] = (r < a.out_u && 4 * q < half2) ? *reinterpret_cast<const float4*>(a.wu + (int64_t)r * a.mid + half2 * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; v++) acc[v] = 0.0f;
+  const float* xrow = a.xl + (b0 + r) * a.ldxl;
+  const float* wrow = a.wl + (int64_t)(n0 + r) * a.in_l;
+  const bool xok = r < rows;
+  for (int k0 = slice * kper; k0 < (slice + 1) * kper; k0 += 32) {
+    float4 av[4], bv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      av[q] = xok ? *reinterpret_cast<const float4*>(xrow + k0 + 16 * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[q] = *reinterpret_cast<const float4*>(wrow + k0 + 16 * h + 4 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 16; v++) s_red[(wave * 16 + v) * 64 + lane] = acc[v];
+  __syncthreads();
+  {
+    // wave (tile, slice) finishes registers slice * (16 / ks) ... of its tile: ((s0 + s1) + s2) + ..., bias, activation
+    const int rpw = 16 / ks;
+    const float bias = a.bl ? a.bl[n0 + r] : 0.0f;
+    for (int q = 0; q < rpw; q++) {
+      const int v = slice * rpw + q;
+      float sum = s_red[((0 * nt + tile) * 16 + v) * 64 + lane];
+      for (int s2 = 1; s2 < ks; s2++) sum += s_red[((s2 * nt + tile) * 16 + v) * 64 + lane];
+      const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+      const float y = act_apply(sum + bias, a.act_l);
+      s_yl[i][n0 + r] = i < rows ? y : 0.0f;
+      if (i < rows) a.yl[(b0 + i) * a.ldyl + n0 + r] = y;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    f32x16 acc2;
+#pragma unroll
+    for (int v = 0; v < 16; v++) acc2[v] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (4 * q < half2) {
+        const float* ap = &s_yl[r][half2 * h + 4 * q];
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[0], wu4[q].x, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[1], wu4[q].y, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2], wu4[q].z, acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[3], wu4[q].w, acc2, 0, 0, 0);
+      }
+    }
+    if (r < a.out_u) {
+      const float bias = a.bu ? a.bu[r] : 0.0f;
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+        if (i < rows) a.yu[(b0 + i) * a.ldyu + r] = act_apply(acc2[v] + bias, a.act_u);
+      }
+    }
+  }
+}
+
 bool act_ok(int act) { return act == FFH_AC_MODE_NONE || act == FFH_AC_MODE_RELU || act == FFH_AC_MODE_SIGMOID; }
 
 }  // namespace
@@ -1480,6 +1575,25 @@ int ffh_linear_bwd_mse(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64
   if (ldy != out || lddy != out) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: y and dy must be contiguous [batch][out_dim]");
   if (batch == 0) return FFH_OK;
   return linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, nullptr, label, scale, perf, metrics_flags);
+}
+
+int ffh_linear_pair_fwd(ffh_ctx* c, const float* x_l, int64_t ldx_l, const float* w_l, const float* b_l, int in_l, int act_l,
+                        float* y_l, int64_t ldy_l, int mid, const float* w_u, const float* b_u, int out_u, int act_u,
+                        float* y_u, int64_t ldy_u, int64_t batch, ffh_stream s) {
+  FFH_REQUIRE(c, in_l > 0 && mid > 0 && out_u > 0 && batch >= 0 && ldx_l >= in_l && ldy_l >= mid && ldy_u >= out_u, "linear_pair_fwd: bad dims");
+  FFH_REQUIRE(c, batch == 0 || (x_l && w_l && y_l && w_u && y_u), "linear_pair_fwd: null pointer");
+  if (!act_ok(act_l) || !act_ok(act_u)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_fwd: activation not supported (NONE, RELU, SIGMOID)");
+  const int ks = (mid == 32 || mid == 64) ? 8 / (mid / 32) : 1;
+  if (out_u > 16 || (mid != 32 && mid != 64) || in_l % (32 * ks) != 0 || batch >= (1LL << 31) || ldx_l % 4 != 0 ||
+      (((uintptr_t)x_l | (uintptr_t)w_l | (uintptr_t)w_u) & 15) != 0)
+    return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_fwd: shapes (out_u <= 16, mid 32 or 64, in_l a multiple of 32 k-slices, 16-byte aligned operands)");
+  if (batch == 0) return FFH_OK;
+  PairFwdArgs a{};
+  a.xl = x_l; a.ldxl = ldx_l; a.wl = w_l; a.bl = b_l; a.in_l = in_l; a.act_l = act_l; a.yl = y_l; a.ldyl = ldy_l; a.mid = mid;
+  a.wu = w_u; a.bu = b_u; a.out_u = out_u; a.act_u = act_u; a.yu = y_u; a.ldyu = ldy_u; a.batch = batch;
+  hipLaunchKernelGGL(linear_pair_fwd_kernel, dim3((unsigned)((batch + 31) / 32)), dim3(512), 0, as_stream(s), a);
+  FFH_LAUNCH_CHECK(c, "linear_pair_fwd_kernel");
+  return FFH_OK;
 }
 
 int ffh_linear_pair_bwd(ffh_ctx* c, const float* x_u, int64_t ldx_u, const float* y_u, int64_t ldy_u, float* dy_u, int64_t lddy_u,

@@ -281,6 +281,8 @@ class Linear : public Op {
   bool use_bias;
   bool discard_input_grad;      // first layer on a model input: dX is never consumed
   bool dx_overwrite;            // input has no other consumer: dX may be stored instead of accumulated
+  Linear* pair_upper;           // the narrow layer above, when its forward rides in this layer's launch (ffh_linear_pair_fwd)
+  mutable bool fwd_done_by_pair;   // set by the layer below for this forward()
   Linear* pair_lower;           // the layer below, when its data gradient rides in this layer's backward launch (ffh_linear_pair_bwd)
   int backward_pair(const FFModel&);   // FFH_OK: this layer's backward and the lower layer's whole backward are enqueued
   bool dx_mask_by_x, dy_premasked;   // relu' of the layer below applied by this layer's dX epilogue / already applied by the layer above

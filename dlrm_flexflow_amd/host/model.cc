@@ -534,7 +534,7 @@ Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_
 Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activation, bool _use_bias, const Op* shared_op,
                Initializer* ki, Initializer* bi, const char* name)
     : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), activation(_activation),
-      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false),
+      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), pair_upper(nullptr), fwd_done_by_pair(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false),
       kernel_initializer(ki), bias_initializer(bi) {
   if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
   if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
@@ -558,6 +558,19 @@ void Linear::forward(const FFModel& ff) {
   const Tensor& x = inputs[0];
   const Tensor& y = outputs[0];
   const int64_t b = local_rows(y, &ff);
+  if (fwd_done_by_pair) { fwd_done_by_pair = false; return; }      // the layer below computed this output in its launch
+  if (pair_upper) {
+    Linear* up = pair_upper;
+    const Tensor& yu = up->outputs[0];
+    const int rc = ff.api->ffh_linear_pair_fwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, (const float*)weights[0].impl->ptr,
+                                               use_bias ? (const float*)weights[1].impl->ptr : nullptr, in_channels, (int)activation, (float*)y.impl->ptr,
+                                               y.impl->ld, out_channels, (const float*)up->weights[0].impl->ptr,
+                                               up->use_bias ? (const float*)up->weights[1].impl->ptr : nullptr, up->out_channels, (int)up->activation,
+                                               (float*)yu.impl->ptr, yu.impl->ld, b, ff.stream);
+    if (rc == FFH_OK) { up->fwd_done_by_pair = true; return; }
+    if (rc != FFH_ERR_UNSUPPORTED) ff.check(rc, name);
+    pair_upper = nullptr;                                          // not a shape the pair launch serves
+  }
   ff.check(ff.api->ffh_linear_fwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, (float*)y.impl->ptr, y.impl->ld,
                                   (const float*)weights[0].impl->ptr, use_bias ? (const float*)weights[1].impl->ptr : nullptr,
                                   in_channels, out_channels, b, (int)activation, ff.stream), name);
@@ -1386,6 +1399,10 @@ void FFModel::allocate() {
           ((below->activation == AC_MODE_RELU && li->dx_mask_by_x) || below->activation == AC_MODE_NONE) && li->out_channels <= 16 &&
           (li->in_channels == 32 || li->in_channels == 64) && below->in_channels % 32 == 0)
         li->pair_lower = below;
+      // the forward of such a pair needs less: the lower output read by the upper layer only, both outputs single buffers
+      if (config.fuse_pair && below && consumers[li->inputs[0].impl] == 1 && li->out_channels <= 16 && (li->in_channels == 32 || li->in_channels == 64) &&
+          below->inputs[0].impl->pieces.empty() && li->outputs[0].impl->pieces.empty() && li->layer_index == below->layer_index + 1)
+        below->pair_upper = li;
     }
     if (DotInteraction* di = dynamic_cast<DotInteraction*>(op)) {
       di->bwd_overwrite = consumers[di->inputs[0].impl] == 1;

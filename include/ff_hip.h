@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_bwd */
+#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd */
 
 /* status codes */
 #define FFH_OK               0
@@ -358,6 +358,14 @@ int ffh_linear_pair_bwd(ffh_ctx* ctx, const float* x_u, int64_t ldx_u, const flo
                         const float* w_u, float* dw_u, float* db_u, int in_u, int out_u, int act_u, int flags_u,
                         const float* x_l, int64_t ldx_l, float* dx_l, int64_t lddx_l, float* dy_l, int64_t lddy_l, const float* w_l,
                         int in_l, int act_l, int flags_l, int64_t batch, ffh_stream s);
+/* ... and the forward of the same two layers as one launch: exactly
+ *   ffh_linear_fwd(ctx, x_l, ldx_l, y_l, ldy_l, w_l, b_l, in_l, mid, batch, act_l, s)
+ *   ffh_linear_fwd(ctx, y_l, ldy_l, y_u, ldy_u, w_u, b_u, mid, out_u, batch, act_u, s)
+ * for mid 32 or 64, out_u <= 16, in_l a multiple of 128 (mid 64) / 256 (mid 32), 16-byte aligned x_l / w_l / w_u rows;
+ * anything else: FFH_ERR_UNSUPPORTED, nothing launched.  w_l is [mid][in_l], w_u is [out_u][mid]. */
+int ffh_linear_pair_fwd(ffh_ctx* ctx, const float* x_l, int64_t ldx_l, const float* w_l, const float* b_l, int in_l, int act_l,
+                        float* y_l, int64_t ldy_l, int mid, const float* w_u, const float* b_u, int out_u, int act_u,
+                        float* y_u, int64_t ldy_u, int64_t batch, ffh_stream s);
 
 /* ------------------------------------------------------------------ */
 /* Strict lower triangle of the pairwise-dot matrix (MLPerf-DLRM's interaction keeps the 351 products
@@ -442,7 +450,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

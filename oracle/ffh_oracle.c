@@ -488,6 +488,16 @@ int ffh_linear_bwd_mse(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64
   return ffh_linear_bwd_ex(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, flags, s, s);
 }
 
+int ffh_linear_pair_fwd(ffh_ctx* c, const float* x_l, int64_t ldx_l, const float* w_l, const float* b_l, int in_l, int act_l,
+                        float* y_l, int64_t ldy_l, int mid, const float* w_u, const float* b_u, int out_u, int act_u,
+                        float* y_u, int64_t ldy_u, int64_t B, ffh_stream s) {
+  const int ks = (mid == 32 || mid == 64) ? 8 / (mid / 32) : 1;
+  if (out_u > 16 || (mid != 32 && mid != 64) || in_l % (32 * ks) != 0) return fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_fwd: shapes");
+  const int rc = ffh_linear_fwd(c, x_l, ldx_l, y_l, ldy_l, w_l, b_l, in_l, mid, B, act_l, s);
+  if (rc != FFH_OK) return rc;
+  return ffh_linear_fwd(c, y_l, ldy_l, y_u, ldy_u, w_u, b_u, mid, out_u, B, act_u, s);
+}
+
 /* the two calls it stands for (include/ff_hip.h) */
 int ffh_linear_pair_bwd(ffh_ctx* c, const float* x_u, int64_t ldx_u, const float* y_u, int64_t ldy_u, float* dy_u, int64_t lddy_u,
                         const float* w_u, float* dw_u, float* db_u, int in_u, int out_u, int act_u, int flags_u,

@@ -809,6 +809,32 @@ def test_linear_bwd_mse_equals_the_two_calls(hip, oracle, B, IN, OUT, act):
                  dev(label), 1.0 / B, perf, mf, None)
 
 
+@pytest.mark.parametrize("B,INL,MID,OUTU,act_l,act_u", [
+    (2048, 256, 64, 16, capi.AC_MODE_RELU, capi.AC_MODE_RELU), (100, 256, 32, 5, capi.AC_MODE_NONE, capi.AC_MODE_SIGMOID),
+    (33, 128, 64, 1, capi.AC_MODE_SIGMOID, capi.AC_MODE_NONE), (4097, 512, 64, 16, capi.AC_MODE_RELU, capi.AC_MODE_RELU)])
+def test_linear_pair_fwd_equals_the_two_calls(hip, oracle, B, INL, MID, OUTU, act_l, act_u):
+    """ffh_linear_pair_fwd (two narrow layers forward in one launch, the middle activation kept in LDS) against two
+    ffh_linear_fwd calls on the GPU and in the oracle; the upper output goes into a wider buffer (a concat slice)."""
+    rng = np.random.default_rng(B + INL + MID)
+    x = rng.uniform(-1, 1, (B, INL)).astype(np.float32)
+    wl = (rng.uniform(-1, 1, (MID, INL)) / np.sqrt(INL)).astype(np.float32)
+    bl = rng.uniform(-1, 1, MID).astype(np.float32)
+    wu = (rng.uniform(-1, 1, (OUTU, MID)) / np.sqrt(MID)).astype(np.float32)
+    bu = rng.uniform(-1, 1, OUTU).astype(np.float32)
+    ldu = OUTU + 7
+    yl = torch.full((B, MID), 9.0, dtype=torch.float32, device=DEV)
+    yu = torch.full((B, ldu), 777.0, dtype=torch.float32, device=DEV)
+    hip.call("ffh_linear_pair_fwd", dev(x), INL, dev(wl), dev(bl), INL, act_l, yl, MID, MID, dev(wu), dev(bu), OUTU, act_u, yu[:, 3:], ldu, B, None)
+    yl_e = oracle.linear_fwd(x, wl, bl, act_l)
+    yu_e = oracle.linear_fwd(yl_e, wu, bu, act_u)
+    assert_gemm_close(host(yl), yl_e, np.abs(x).astype(np.float64) @ np.abs(wl).astype(np.float64).T + np.abs(bl), "y_l")
+    got = host(yu)
+    assert_gemm_close(got[:, 3:3 + OUTU], yu_e, np.abs(yl_e).astype(np.float64) @ np.abs(wu).astype(np.float64).T + np.abs(bu) + 1e-2, "y_u")
+    assert (got[:, :3] == 777).all() and (got[:, 3 + OUTU:] == 777).all()
+    with pytest.raises(capi.FFHError):                             # mid = 48: not served
+        hip.call("ffh_linear_pair_fwd", dev(x), INL, dev(wl), dev(bl), INL, act_l, yl, MID, 48, dev(wu), dev(bu), OUTU, act_u, yu, ldu, B, None)
+
+
 @pytest.mark.parametrize("B,INL,INU,OUTU,act_u,act_l,fu,fl", [
     (2048, 256, 64, 16, capi.AC_MODE_RELU, capi.AC_MODE_RELU, capi.LINEAR_DY_PREMASKED, capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DX_MASK_BY_X),
     (2048, 256, 64, 16, capi.AC_MODE_RELU, capi.AC_MODE_RELU, 0, capi.LINEAR_DX_OVERWRITE),
