@@ -17,6 +17,9 @@ struct ffh_ctx {
   int         num_cus;
   hipEvent_t  ev_fork;   // ffh_linear_bwd_ex: orders the weight-gradient stream behind the caller's stream
   int         second_stream_used;   // ffh_second_stream_used()
+  const void* scatter_map;          // ffh_linear_bwd_set_dx_scatter(): ffh_col_dest[scatter_ncols] in device memory, or NULL
+  int         scatter_ncols, scatter_used;
+  void*       scatter_event;        // hipEvent_t attached to the launch that takes the map (else dropped)
   void*       attach_event;         // ffh_event_record_with_next_linear_bwd(): hipEvent_t to signal behind the next backward's last kernel
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
   char        err[512];

@@ -432,6 +432,7 @@ struct GldsArgs {
   int M, N, K;
   int k_per_split, splitk;   // grid.z = splitk; k_per_split is a multiple of 64
   int epi, act;
+  const ffh_col_dest* colmap;   // epilogue: column n of C lives at colmap[n].base[m * colmap[n].ld] (a Concat backward folded in), or null
 };
 
 template <int N_> __device__ __forceinline__ void glds_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
@@ -611,6 +612,9 @@ __device__ __forceinline__ void glds_body(const GldsArgs& g, const unsigned lin,
   const int n = n0 + wn * 32 + lr;
   if (n < g.N) {
     const float bv = (g.epi == EPI_STORE && g.bias) ? g.bias[n] : 0.0f;
+    float* cbase = g.C + n;
+    int64_t cld = g.ldc;
+    if (g.colmap) { const ffh_col_dest cd = g.colmap[n]; cbase = cd.base; cld = cd.ld; }
 #pragma unroll
     for (int q = 0; q < RPW; q++) {
       const int r = KS > 1 ? ks * RPW + q : q;
@@ -618,7 +622,7 @@ __device__ __forceinline__ void glds_body(const GldsArgs& g, const unsigned lin,
       if (m >= g.M) continue;
       float v = out[q];
       if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) v = 0.0f;
-      float* cp = g.C + (int64_t)m * g.ldc + n;
+      float* cp = cbase + (int64_t)m * cld;
       if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
       else if (g.epi == EPI_ADD) *cp = *cp + v;
       else atomicAdd(cp, v);
@@ -726,6 +730,12 @@ int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
   const GldsDims dx{px.grid.x, px.grid.y, px.grid.z}, dw{pw.grid.x, pw.grid.y, pw.grid.z};
   const int lds = px.lds_bytes > pw.lds_bytes ? px.lds_bytes : pw.lds_bytes;
   hipEvent_t ev = (hipEvent_t)c->attach_event;   // ffh_event_record_with_next_linear_bwd: this launch is the call's last kernel on s
+  if (c->scatter_map && c->scatter_ncols == dxg.N && dxg.epi == EPI_STORE) {
+    // ffh_linear_bwd_set_dx_scatter: the data gradient goes where a Concat backward would copy it; its event rides on this launch
+    dxg.colmap = (const ffh_col_dest*)c->scatter_map;
+    c->scatter_used = 1;
+    if (c->scatter_event && !ev) ev = (hipEvent_t)c->scatter_event;
+  }
   // more workgroups than CUs: two stages (65 KB) so that two workgroups share a CU
   static const int forced_stages = getenv("FFH_GLDS_BWD_STAGES") ? atoi(getenv("FFH_GLDS_BWD_STAGES")) : 0;   // A/B switch (tools/ab.sh)
   const bool two = forced_stages ? forced_stages == 2 : (na8 + nb) > (unsigned)c->num_cus;
@@ -1551,7 +1561,9 @@ extern "C" {
 int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
                       float* dy, int64_t lddy, const float* w, float* dw, float* db,
                       int in, int out, int64_t batch, int act, int flags, ffh_stream s, ffh_stream s_dw) {
+  if (c) c->scatter_used = 0;
   const int rc = linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, s_dw, nullptr, 0.0f, nullptr, 0);
+  if (c) { c->scatter_map = nullptr; c->scatter_event = nullptr; }       // one call only, taken or not
   if (c && c->attach_event) {        // no launch could carry it: the ordinary record behind everything this call put on s
     hipEvent_t ev = (hipEvent_t)c->attach_event;
     c->attach_event = nullptr;
@@ -1559,6 +1571,13 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   }
   return rc;
 }
+
+int ffh_linear_bwd_set_dx_scatter(ffh_ctx* c, const ffh_col_dest* map, int ncols, ffh_event attach_if_used) {
+  if (!c || !map || ncols <= 0) return FFH_ERR_BAD_ARG;
+  c->scatter_map = map; c->scatter_ncols = ncols; c->scatter_event = attach_if_used; c->scatter_used = 0;
+  return FFH_OK;
+}
+int ffh_linear_dx_scatter_used(ffh_ctx* c) { return c ? c->scatter_used : 0; }
 
 int ffh_event_record_with_next_linear_bwd(ffh_ctx* c, ffh_event e) {
   if (!c || !e) return FFH_ERR_BAD_ARG;

@@ -102,6 +102,7 @@ class FFConfig {
   bool overlap_embedding;      // embedding gather (+exchange) on a side stream beside the bottom MLP
   bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
   int64_t column_shard_rows;   // tables with at least this many rows are sharded column-wise over the ranks (0: never)
+  bool dx_scatter;             // exchange mode: the layer above the feature Concat writes its dX into the send buffer itself (A/B: --no-dx-scatter)
   bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)
   bool attach_events;          // hang ev_grad_ready on the producing kernel's completion instead of a record packet (A/B: --no-attach-event)
   bool timing_events;          // A/B: stream-ordering events created with timestamps, as before
@@ -281,6 +282,8 @@ class Linear : public Op {
   bool use_bias;
   bool discard_input_grad;      // first layer on a model input: dX is never consumed
   bool dx_overwrite;            // input has no other consumer: dX may be stored instead of accumulated
+  ffh_col_dest* dx_map;         // device array [in_channels]: where each column of dX goes when the Concat below is folded in (exchange mode)
+  class Concat* dx_map_concat;  // ... and the Concat whose backward that replaces
   Linear* pair_upper;           // the narrow layer above, when its forward rides in this layer's launch (ffh_linear_pair_fwd)
   mutable bool fwd_done_by_pair;   // set by the layer below for this forward()
   Linear* pair_lower;           // the layer below, when its data gradient rides in this layer's backward launch (ffh_linear_pair_bwd)
@@ -321,6 +324,7 @@ class Concat : public Op {
   void create_output_and_partition(FFModel& model) override;
   void forward(const FFModel&) override;
   void backward(const FFModel&) override;
+  mutable bool bwd_done;        // the consumer stored its data gradient straight into this Concat's inputs (ffh_linear_bwd_set_dx_scatter)
   int axis;                     // Legion axis (user axis flipped, [ref: src/ops/concat.cu:29-49,109-112])
   bool bwd_overwrite;           // every input has this Concat as its only consumer: slices are stored, not accumulated
 };
@@ -490,6 +494,7 @@ class FFModel {
   void join_embedding_forward() const;
   void issue_embedding_update_on_side_stream() const;
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
+  int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
   int grad_attach_layer;        // the Linear whose backward completes the embedding output gradients (-1: none / not attachable)
   mutable bool grad_ready_attached;
 

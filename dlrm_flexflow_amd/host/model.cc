@@ -130,6 +130,7 @@ FFConfig::FFConfig() {
   timing_events = false;
   attach_events = true;
   fuse_pair = true;
+  dx_scatter = true;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
   comm.world_size = 1;
@@ -179,6 +180,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--timing-events")) { timing_events = true; continue; }
     if (is("--no-attach-event")) { attach_events = false; continue; }
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
+    if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
   }
 }
 
@@ -436,6 +438,8 @@ FFModel::~FFModel() {
   for (Embedding* e : embeddings)
     for (void* p : {(void*)e->local_idx, (void*)e->partial, (void*)e->gfull})
       if (p) api->ffh_free(ctx, p);
+  for (Op* op : layers)
+    if (op->op_type == OP_LINEAR && static_cast<Linear*>(op)->dx_map) api->ffh_free(ctx, static_cast<Linear*>(op)->dx_map);
   api->ffh_event_destroy(ctx, ev_fork); api->ffh_event_destroy(ctx, ev_join);
   api->ffh_event_destroy(ctx, ev_grad_ready); api->ffh_event_destroy(ctx, ev_update_done);
   api->ffh_event_destroy(ctx, ev_dw_done);
@@ -534,7 +538,7 @@ Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_
 Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activation, bool _use_bias, const Op* shared_op,
                Initializer* ki, Initializer* bi, const char* name)
     : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), activation(_activation),
-      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), pair_upper(nullptr), fwd_done_by_pair(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false),
+      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), dx_map(nullptr), dx_map_concat(nullptr), pair_upper(nullptr), fwd_done_by_pair(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false),
       kernel_initializer(ki), bias_initializer(bi) {
   if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
   if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
@@ -736,6 +740,7 @@ Concat::Concat(FFModel& model, int n, const Tensor* _inputs, int _axis, const ch
   const int nd = _inputs[0].numDim;
   axis = nd - 1 - _axis;   // user axis -> Legion axis [ref: src/ops/concat.cu:29-49]
   bwd_overwrite = false;
+  bwd_done = false;
   if (axis < 0 || axis >= nd) die("%s: axis out of range", this->name);
   outputs[0].numDim = nd;
   for (int d = 0; d < nd; d++) outputs[0].adim[d] = _inputs[0].adim[d];
@@ -798,6 +803,7 @@ void Concat::forward(const FFModel& ff) {
                                   (int)ptrs.size(), nb, ff.stream), name);
 }
 void Concat::backward(const FFModel& ff) {
+  if (bwd_done) { bwd_done = false; return; }            // the layer above stored its data gradient into the inputs' buffers itself
   int64_t nb, ob;
   std::vector<int64_t> ib, blks, lds;
   std::vector<float*> ptrs;
@@ -1444,6 +1450,40 @@ void FFModel::allocate() {
     if (l < layers.size() && layers[l]->op_type == OP_LINEAR && l == (size_t)embeddings.back()->layer_index + 2) grad_attach_layer = (int)l;
   }
 
+  // ---- 4d. exchange mode: the feature Concat's backward folded into the layer above it ----------
+  // There the embedding gradients have to reach the all-to-all send buffer, which Concat::backward does with a pack
+  // kernel on the critical stream.  The Linear that consumes the Concat can store each column of its data gradient where
+  // that kernel would copy it (ffh_linear_bwd_set_dx_scatter); the column -> (buffer, leading dimension) map is fixed here.
+  scatter_attach_layer = -1;
+  for (Op* op : layers) {
+    Linear* li = dynamic_cast<Linear*>(op);
+    if (!li) continue;
+    Concat* c = li->inputs[0].owner_op ? dynamic_cast<Concat*>(const_cast<Op*>(li->inputs[0].owner_op)) : nullptr;
+    if (!exchange || !config.dx_scatter || !c || c->axis != 0 || !li->dx_overwrite || !c->bwd_overwrite || li->discard_input_grad) continue;
+    std::vector<ffh_col_dest> map;
+    bool ok = true;
+    for (int i = 0; i < c->numInputs && ok; i++) {
+      const TensorImpl* im = c->inputs[i].impl;
+      if (!im->pieces.empty()) {
+        for (const TensorPiece& pc : im->pieces)
+          for (int64_t k = 0; k < pc.cols; k++) map.push_back({pc.grad + k, pc.ld});
+      } else if (im->grad) {
+        for (int k = 0; k < c->inputs[i].adim[0]; k++) map.push_back({im->grad + k, im->grad_ld});
+      } else {
+        ok = false;
+      }
+    }
+    if (!ok || (int)map.size() != li->in_channels) continue;
+    li->dx_map = (ffh_col_dest*)dmalloc(map.size() * sizeof(ffh_col_dest));
+    check(api->ffh_memcpy_h2d(ctx, li->dx_map, map.data(), map.size() * sizeof(ffh_col_dest), stream), "dx map");
+    check(api->ffh_stream_sync(ctx, stream), "dx map");
+    li->dx_map_concat = c;
+    // the tables come right after this Concat in reverse order: the scattered dX also completes their gradients
+    if (!embeddings.empty() && config.attach_events && config.overlap_embedding && fused_embedding_update() &&
+        c->layer_index == embeddings.back()->layer_index + 1 && li->layer_index == c->layer_index + 1)
+      scatter_attach_layer = li->layer_index;
+  }
+
   // ---- 5. parameters: one slab for every Linear tensor, tables on their own ---------------------
   mlp_count = 0;
   for (Parameter& p : parameters)
@@ -1721,6 +1761,16 @@ void FFModel::backward(int _seq_length) {
       grad_ready_attached = true;
     }
     Linear* up = layers[l]->op_type == OP_LINEAR ? static_cast<Linear*>(layers[l]) : nullptr;
+    if (up && up->dx_map && !use_workers()) {
+      const bool attach = l == scatter_attach_layer;
+      check(api->ffh_linear_bwd_set_dx_scatter(ctx, up->dx_map, up->in_channels, attach ? ev_grad_ready : nullptr), "dx scatter");
+      up->backward(*this);
+      if (api->ffh_linear_dx_scatter_used(ctx)) {
+        up->dx_map_concat->bwd_done = true;                    // its pack kernel is not needed this step
+        if (attach) grad_ready_attached = true;
+      }
+      continue;
+    }
     if (up && up->pair_lower && !use_workers() && l != grad_attach_layer && l >= 1 && layers[l - 1] == up->pair_lower) {
       const int prc = up->backward_pair(*this);
       if (prc == FFH_OK) { l--; continue; }                   // the lower layer is done as well

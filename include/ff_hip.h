@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd */
+#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -273,6 +273,15 @@ int ffh_second_stream_used(ffh_ctx* ctx, int clear);
  * as calling ffh_event_record(ctx, e, s) right after it, except that the library may hang the event on its last kernel's
  * own completion signal (hipExtLaunchKernelGGL's stop event) instead of sending a separate barrier packet down s. */
 int ffh_event_record_with_next_linear_bwd(ffh_ctx* ctx, ffh_event e);
+/* Storing a data gradient where a Concat backward would copy it afterwards.  The NEXT ffh_linear_bwd_ex on this ctx, if it is
+ * called with FFH_LINEAR_DX_OVERWRITE for in_dim == ncols and runs as the one-launch LDS-DMA form, writes column n of dX to
+ * map[n].base[row * map[n].ld] instead of dx[row * lddx + n] (map: device memory, ncols entries, must stay valid until that
+ * call's kernels have run).  `attach_if_used` (may be NULL) is then signalled by that launch's completion, like
+ * ffh_event_record_with_next_linear_bwd; if the call cannot take the map it writes dx as always and records nothing.
+ * ffh_linear_dx_scatter_used() says which of the two happened (it reports on the last such call). */
+typedef struct ffh_col_dest { float* base; int64_t ld; } ffh_col_dest;
+int ffh_linear_bwd_set_dx_scatter(ffh_ctx* ctx, const ffh_col_dest* map, int ncols, ffh_event attach_if_used);
+int ffh_linear_dx_scatter_used(ffh_ctx* ctx);
 int ffh_linear_bwd_ex(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,
                       const float* w, float* dw, float* db,
@@ -450,7 +459,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

@@ -45,6 +45,8 @@ struct ffh_ctx {
   void*  ws;
   size_t ws_bytes;
   char   err[256];
+  const ffh_col_dest* scatter_map;   /* ffh_linear_bwd_set_dx_scatter: pending for the next ffh_linear_bwd_ex */
+  int    scatter_ncols, scatter_used;
 };
 
 static int fail(ffh_ctx* c, int code, const char* msg) {
@@ -453,11 +455,40 @@ int ffh_event_record_with_next_linear_bwd(ffh_ctx* c, ffh_event e) { (void)c; (v
 int ffh_second_stream_used(ffh_ctx* c, int clear) { (void)c; (void)clear; return 0; }
 
 /* same arithmetic; streams mean nothing on the host.  DX_OVERWRITE: dx is zeroed here, then accumulated */
+static int linear_bwd_ex_plain(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                               const float* y, int64_t ldy, float* dy, int64_t lddy,
+                               const float* w, float* dw, float* db, int in, int out, int64_t B, int act, int flags);
+
+/* the data gradient of the next call goes where a Concat backward would copy it (include/ff_hip.h); on the host the map is
+ * always taken when the call qualifies */
+int ffh_linear_bwd_set_dx_scatter(ffh_ctx* c, const ffh_col_dest* map, int ncols, ffh_event attach_if_used) {
+  (void)attach_if_used;
+  if (!c || !map || ncols <= 0) return FFH_ERR_BAD_ARG;
+  c->scatter_map = map; c->scatter_ncols = ncols; c->scatter_used = 0;
+  return FFH_OK;
+}
+int ffh_linear_dx_scatter_used(ffh_ctx* c) { return c ? c->scatter_used : 0; }
+
 int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,
                       const float* w, float* dw, float* db, int in, int out, int64_t B, int act,
                       int flags, ffh_stream s, ffh_stream s_dw) {
   (void)s; (void)s_dw;
+  const ffh_col_dest* map = c ? c->scatter_map : NULL;
+  const int take = map && c->scatter_ncols == in && (flags & FFH_LINEAR_DX_OVERWRITE) && !(flags & FFH_LINEAR_ONLY_DW) && dx;
+  if (c) { c->scatter_map = NULL; c->scatter_used = 0; }
+  const int rc = linear_bwd_ex_plain(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, flags);
+  if (rc == FFH_OK && take) {
+    for (int64_t b = 0; b < B; b++)
+      for (int n = 0; n < in; n++) map[n].base[b * map[n].ld] = dx[b * lddx + n];
+    c->scatter_used = 1;
+  }
+  return rc;
+}
+
+static int linear_bwd_ex_plain(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                               const float* y, int64_t ldy, float* dy, int64_t lddy,
+                               const float* w, float* dw, float* db, int in, int out, int64_t B, int act, int flags) {
   const int only_dx = flags & FFH_LINEAR_ONLY_DX, only_dw = flags & FFH_LINEAR_ONLY_DW;
   if (only_dx && only_dw) return fail(c, FFH_ERR_BAD_ARG, "linear_bwd_ex: ONLY_DX and ONLY_DW are exclusive");
   if ((flags & FFH_LINEAR_DX_OVERWRITE) && !only_dw && dx && in > 0 && lddx >= in)
