@@ -962,6 +962,40 @@ __global__ __launch_bounds__(256) void linear_skinny_fwd_kernel(const float* __r
   }
 }
 
+// Linear with a handful of INPUTS (the 13 dense features in front of DLRM's bottom MLP): k is shorter than one LDS k-tile, so
+// the tiled kernels spend their time on padding and staging.  Here a wave owns a 32 x 32 output tile and takes both
+// operands straight from global memory (in <= 16 values per row: at most eight MFMAs), bias + activation, one store pass.
+__global__ __launch_bounds__(512) void linear_thin_fwd_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+                                                              const float* __restrict__ w, const float* __restrict__ bias, int in, int out,
+                                                              int64_t batch, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t b0 = (int64_t)blockIdx.x * 32;
+  const int n0 = (blockIdx.y * 8 + wave) * 32;
+  if (n0 >= out) return;
+  const bool xok = b0 + r < batch, wok = n0 + r < out;
+  float av[8], bv[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const int k = 2 * q + h;
+    av[q] = (xok && k < in) ? x[(b0 + r) * ldx + k] : 0.0f;
+    bv[q] = (wok && k < in) ? w[(int64_t)(n0 + r) * in + k] : 0.0f;
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int v = 0; v < 16; v++) acc[v] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 8; q++)
+    if (2 * q < in) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+  if (!wok) return;
+  const float bs = bias ? bias[n0 + r] : 0.0f;
+#pragma unroll
+  for (int v = 0; v < 16; v++) {
+    const int64_t i = b0 + 8 * (v >> 2) + 4 * h + (v & 3);
+    if (i < batch) y[i * ldy + n0 + r] = act_apply(acc[v] + bs, act);
+  }
+}
+
 struct SkinnyBwdArgs {
   const float* x;  float* dx;  const float* y;  float* dy;  const float* w;  float* dw;  float* db;
   int64_t ldx, lddx, ldy, lddy, batch;
@@ -1375,6 +1409,13 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
     hipLaunchKernelGGL(linear_skinny_fwd_kernel, dim3(ffh_grid(batch, 4, 2048)), dim3(256), 0, as_stream(s), x, ldx, y, ldy, w, bias, in, out,
                        batch, act);
     FFH_LAUNCH_CHECK(c, "linear_skinny_fwd_kernel");
+    return FFH_OK;
+  }
+  static const int no_thin = getenv("FFH_NO_THIN") ? atoi(getenv("FFH_NO_THIN")) : 0;   // A/B switch (tools/ab.sh)
+  if (!no_thin && in <= 16 && out >= 64) {
+    hipLaunchKernelGGL(linear_thin_fwd_kernel, dim3((unsigned)((batch + 31) / 32), (unsigned)((out + 255) / 256)), dim3(512), 0, as_stream(s), x, ldx, y, ldy,
+                       w, bias, in, out, batch, act);
+    FFH_LAUNCH_CHECK(c, "linear_thin_fwd_kernel");
     return FFH_OK;
   }
   GemmArgs g{};
