@@ -1,37 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- DLRM training throughput (samples/s) of the MI355X-native path, one JSON line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kaggle|tiny|terabyte|mlperf|giant|giant-row] [--probe]
-  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-              --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload terabyte|kaggle|tiny|mlperf|giant|giant-row]
+                  [--scaling strong|weak] [--per-gpu-batch B]
 
-A "step" is one training iteration of the reference driver's loop -- forward, zero_gradients,
-backward, update [ref: examples/cpp/DLRM/dlrm.cc:166-182] -- on one resident synthetic batch (the
-reference reuses the warm-up batch for random input, :167-173).  On one GPU a hipGraph replay of the
-step (the reference's begin_trace/end_trace) is timed against eager launches and the faster one is
-used for the measured run (eager on ROCm 7.2).  Workload at N = 1: BASELINE.json configs[1],
-the Criteo-Kaggle shape (26 tables with run_criteo_kaggle.sh's row counts, emb_dim 16, batch 2048,
-bot 13-512-256-64-16, top 432-512-256-1).  N > 1 is weak scaling: 2048 samples per GPU, tables
-sharded table-wise (table t on rank t % N), all-to-all each way + one all-reduce of MLP gradients
-over RCCL, called from the C++ host layer on a communicator bootstrapped over torch.distributed
-("nccl"); --torch-collectives serves them through torch.distributed instead.  fp32 throughout (the
-reference's arithmetic type).
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process never touches a GPU -- it starts N child
+ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays rank 0's single
+JSON line and exits non-zero if any child fails.  Under `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N` (WORLD_SIZE already set) it is one of the ranks.
+
+A "step" is one training iteration of the reference driver's loop -- forward, zero_gradients, backward, update
+[ref: examples/cpp/DLRM/dlrm.cc:166-182] -- on one resident synthetic batch (the reference reuses the warm-up batch
+for random input, :167-173).  Default workload = the configuration BASELINE.json's metric is quoted on: the
+Criteo-Terabyte shape (26 tables with the MLPerf 40M-capped row counts, 96 GB fp32, emb_dim 128, bot 13-512-256-128,
+top 3456-1024-1024-512-256-1, cat interaction) at GLOBAL batch 32768.  It fits one MI355X, so N = 1 runs exactly it;
+N > 1 shards the tables table-wise (table t on rank t % N, the reference strategy generator's policy), keeps the MLPs
+data-parallel and, by default, keeps the global batch at 32768 ("scaling": "strong", BASELINE configs[2]);
+`--scaling weak` gives every rank 32768 samples instead.  All-to-all each way + one all-reduce of the MLP gradients
+over RCCL, called from the C++ host layer on a communicator bootstrapped over torch.distributed ("nccl");
+`--torch-collectives` serves them through torch.distributed instead.  fp32 throughout (the reference's arithmetic).
 
 Besides the contract fields the line carries
-  roofline      the embedding gather kernel (BASELINE's second metric): algorithmic bytes
-                (B*(L*(8+4D)+4D) per table = 3,536 B/sample here) / HIP-event time
-  kernels       the same for the fused embedding backward+SGD; the largest Linear layer alone (MFMA
-                roofline, forward and backward); the whole step; with --probe the gather at the
-                Terabyte shape (D = 128, B = 32768, 40M-row tables) where the kernel is HBM-bound
-  cpu_baseline  the same application on the host cores with the CPU oracle as kernel library
-                (kind "port": the reference has no CPU path for this step), bounded sample, timed
-                with 1 thread, a quarter of the cores and all cores; `value` is the fastest leg
+  roofline      the embedding gather kernel (BASELINE's second metric) of THIS workload on rank 0: algorithmic bytes
+                (B*(L*(8+4D)+4D) per table; 26,832 B/sample at the Terabyte shape = 879 MB per launch at
+                N = 1) / average HIP-event time of back-to-back launches on the model's own stream; `traffic` = HBM
+                bytes per launch from the committed rocprofv3 --pmc passes (profiles/), `achieved_from_traffic` the
+                same rate priced on those bytes
+  kernels       the fused embedding backward+SGD (same treatment); the largest Linear layer alone (MFMA roofline,
+                forward and backward); the whole step; `kaggle_secondary` = BASELINE configs[1] (B = 2048) timed in
+                the same process after the headline (skipped with --no-secondary and for N > 1)
+  cpu_baseline  the same application on the host cores with the CPU oracle as kernel library (kind "port": the
+                reference has no CPU path for this step), N = 1 only, on a bounded sample (stated in `sample`)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,33 +49,29 @@ KAGGLE_ROWS = "1396-550-1761917-507795-290-21-11948-608-3-58176-5237-1497287-312
 TERABYTE_ROWS = "39884406-39043-17289-7420-20263-3-7120-1543-63-38532951-2953546-403346-10-2208-11938-155-4-976-14-39979771-25641295-39664984-585935-12972-108-36"
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured streaming ceiling
 F32_PEAK_TFLOPS = 157.3     # v_mfma_f32_32x32x2_f32 dense peak
+BF16_PEAK_TFLOPS = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak (no sparsity)
+DEFAULT_BATCH = {"terabyte": 32768, "kaggle": 2048, "tiny": 128, "giant": 4096, "giant-row": 4096, "mlperf": 8192, "mlperf-allpairs": 8192}
 
 
-def workload(name: str, per_gpu_batch: int | None, world: int):
+def workload(name: str, global_batch: int):
+    B = global_batch
+    if name == "terabyte":     # BASELINE configs[2]: all 26 tables (96 GB fp32) fit one MI355X; table-wise for N > 1
+        return dict(name="criteo-terabyte-shape", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="3456-1024-1024-512-256-1", B=B)
     if name == "kaggle":       # BASELINE configs[1]
-        b = per_gpu_batch or 2048
-        return dict(name="criteo-kaggle-shape", rows=KAGGLE_ROWS, D=16, bot="13-512-256-64-16", top="432-512-256-1", B=b * world)
-    if name == "terabyte":     # BASELINE configs[2] (all 26 tables: 96 GB fp32, fits one MI355X; sharded for N > 1)
-        b = per_gpu_batch or 4096
-        return dict(name="criteo-terabyte-shape", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="3456-1024-1024-512-256-1", B=b * world)
+        return dict(name="criteo-kaggle-shape", rows=KAGGLE_ROWS, D=16, bot="13-512-256-64-16", top="432-512-256-1", B=B)
     if name == "tiny":         # BASELINE configs[0]
-        b = per_gpu_batch or 128
-        return dict(name="tiny", rows="-".join(["1000"] * 8), D=16, bot="13-64-16", top="144-64-1", B=b * world)
+        return dict(name="tiny", rows="-".join(["1000"] * 8), D=16, bot="13-64-16", top="144-64-1", B=B)
     if name == "giant":        # BASELINE configs[4]: one 200M-row x 256 table (204.8 GB), column-wise over the ranks
-        b = per_gpu_batch or 4096
-        return dict(name="giant-table-column-wise", rows="200000000", D=256, bot="13-512-256", top="512-512-256-1", B=b * world,
+        return dict(name="giant-table-column-wise", rows="200000000", D=256, bot="13-512-256", top="512-512-256-1", B=B,
                     extra=["--column-shard-rows", "100000000"])
     if name == "mlperf":       # BASELINE configs[3]: dot interaction keeping the 351 products i > j of the 27 x 27 matrix
-        b = per_gpu_batch or 8192   # (FFModel::tril; top MLP input 128 + 351 = 479), emb_dim 128, 65536 samples over 8 GPUs
-        return dict(name="mlperf-dlrm-dot", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="479-1024-1024-512-256-1", B=b * world,
+        return dict(name="mlperf-dlrm-dot", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="479-1024-1024-512-256-1", B=B,
                     extra=["--arch-interaction-op", "dot-tril"])
     if name == "mlperf-allpairs":   # the same with all 729 products, the composition of the reference's op tests (test_harness.py:125-177)
-        b = per_gpu_batch or 8192
-        return dict(name="mlperf-dlrm-dot-allpairs", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="857-1024-1024-512-256-1", B=b * world,
+        return dict(name="mlperf-dlrm-dot-allpairs", rows=TERABYTE_ROWS, D=128, bot="13-512-256-128", top="857-1024-1024-512-256-1", B=B,
                     extra=["--arch-interaction-op", "dot"])
     if name == "giant-row":    # the same table split ROW-wise: partial bag sums + reduce-scatter forward, all-gather backward
-        b = per_gpu_batch or 4096   # (configs[4]'s "reduce-scatter stress"; one rank: pass --force-exchange to walk the collectives)
-        return dict(name="giant-table-row-wise", rows="200000000", D=256, bot="13-512-256", top="512-512-256-1", B=b * world,
+        return dict(name="giant-table-row-wise", rows="200000000", D=256, bot="13-512-256", top="512-512-256-1", B=B,
                     extra=["--row-shard-rows", "100000000"])
     raise SystemExit(f"unknown workload {name}")
 
@@ -79,13 +82,12 @@ def flags_of(w, extra=()):
 
 
 def pmc_traffic(key):
-    """HBM bytes per launch of the gather from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    """HBM bytes per launch of the embedding kernels from the committed rocprofv3 --pmc passes (profiles/), or {}."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None, None
-    d = json.load(open(files[-1])).get(key)
-    return (d["traffic_bytes_per_launch"], os.path.relpath(files[-1], ROOT)) if d else (None, None)
+        return {}, None
+    return json.load(open(files[-1])).get(key) or {}, os.path.relpath(files[-1], ROOT)
 
 
 def mlp_flops_per_sample(w):
@@ -97,13 +99,28 @@ def mlp_flops_per_sample(w):
     return 3 * f   # forward + dX + dW
 
 
-def cpu_baseline_leg(name, per_gpu_batch, budget_s, out):
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (host only; the oracle is the kernel library of the same C++ application)
+# ------------------------------------------------------------------------------------------------------------------
+CPU_ROW_CAP = 1_000_000     # rows per table in the CPU sample: initialising 24 G table elements on the host would take minutes
+CPU_BATCH = 512             # samples per CPU step (a 32768-sample step is ~1 TFLOP: minutes on one thread)
+
+
+def cpu_sample_workload(name):
+    w = workload(name, min(CPU_BATCH, DEFAULT_BATCH.get(name, CPU_BATCH)))
+    rows = [min(int(r), CPU_ROW_CAP) for r in w["rows"].split("-")]
+    w = dict(w, rows="-".join(str(r) for r in rows))
+    w["extra"] = [x for x in w.get("extra", []) if x not in ("--column-shard-rows", "--row-shard-rows", "100000000")]
+    return w
+
+
+def cpu_baseline_leg(name, budget_s, out):
     """One timed leg in its own process (OMP_NUM_THREADS is read when libgomp starts): prints {steps, seconds, threads}."""
     from oracle import oracle
     from dlrm_flexflow_amd import ffmodel
     oracle.build()
     import ctypes
-    w = workload(name, per_gpu_batch, 1)
+    w = cpu_sample_workload(name)
     threads = int(ctypes.CDLL("libgomp.so.1").omp_get_max_threads())     # threads the oracle's OpenMP loops will use
     app = ffmodel.DLRM(flags_of(w, ["--backend", oracle.ORACLE_LIB, "--no-trace"]))
     app.warmup()
@@ -117,97 +134,141 @@ def cpu_baseline_leg(name, per_gpu_batch, budget_s, out):
     app.model.sync()
     dt = time.perf_counter() - t0
     app.close()
-    print("CPU_LEG " + json.dumps({"steps": n, "seconds": dt, "threads": threads}), file=out, flush=True)
+    print("CPU_LEG " + json.dumps({"steps": n, "seconds": dt, "threads": threads, "batch": w["B"]}), file=out, flush=True)
 
 
-def cpu_baseline(w, args, budget_s=21.0):
+def cpu_baseline(args, budget_s=24.0):
     """The same DLRM application with the CPU oracle as its kernel library, timed on the host: one thread (the reference's
-    CPU embedding loop is serial), every core, and a quarter of them (128 OpenMP threads over loops this short
-    pay more in fork/join than they gain); `value` is the fastest of the three."""
-    import subprocess
+    CPU embedding loop is serial), a quarter of the hardware threads and all of them; `value` is the fastest."""
     ncpu = os.cpu_count() or 1
+    w = cpu_sample_workload(args.workload)
     legs = {}
     for threads in sorted({1, max(1, ncpu // 4), ncpu}):
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="false")
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-leg", "--workload", args.workload, "--leg-budget", str(budget_s / 3)]
-        if args.per_gpu_batch:
-            cmd += ["--per-gpu-batch", str(args.per_gpu_batch)]
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         line = [l for l in r.stdout.splitlines() if l.startswith("CPU_LEG ")]
         if r.returncode != 0 or not line:
             raise RuntimeError(f"cpu baseline leg ({threads} threads) failed:\n{r.stdout[-500:]}{r.stderr[-500:]}")
         leg = json.loads(line[-1][8:])
-        legs[leg["threads"]] = {"value": round(leg["steps"] * w["B"] / leg["seconds"], 2), "steps": leg["steps"], "seconds": round(leg["seconds"], 2)}
+        legs[leg["threads"]] = {"value": round(leg["steps"] * leg["batch"] / leg["seconds"], 2), "steps": leg["steps"], "seconds": round(leg["seconds"], 2)}
     best = max(legs, key=lambda t: legs[t]["value"])
     b = legs[best]
+    capped = w["rows"] != workload(args.workload, 1)["rows"]
     return {"value": b["value"], "unit": "samples/s", "cores": best, "kind": "port",
-            "sample": f"{b['steps']} training steps of the same {w['name']} config (batch {w['B']}) in {b['seconds']:.1f} s, "
-                      f"oracle/ffh_oracle.c (OpenMP over the batch) behind the same C++ FFModel host code",
+            "sample": f"{b['steps']} training steps of the same {w['name']} model (emb_dim {w['D']}, bot {w['bot']}, top {w['top']}) at batch {w['B']} in "
+                      f"{b['seconds']:.1f} s" + (f", rows per table capped at {CPU_ROW_CAP} (host-side table init; favours the CPU's caches)" if capped else "") +
+                      "; oracle/ffh_oracle.c (OpenMP over the batch) behind the same C++ FFModel host code",
             "host_cpus": ncpu,
             "by_threads": {str(t): legs[t]["value"] for t in sorted(legs)}}
 
 
-def terabyte_gather_probe(hip):
-    """Embedding gather where it is HBM-bound: 4 tables of the Terabyte shape, B = 32768, D = 128."""
-    import torch
-    from dlrm_flexflow_amd import capi
-    rows = [39884406, 38532951, 39979771, 25641295]
-    B, D, T = 32768, 128, len(rows)
-    W, I = [], []
-    for t, R in enumerate(rows):
-        w = torch.empty(R, D, device="cuda")
-        hip.call("ffh_init_uniform", w, R * D, t, -0.01, 0.01, None)
-        i = torch.empty(B, 1, dtype=torch.int64, device="cuda")
-        hip.call("ffh_gen_indices", i, B, 100 + t, 0, R, None)
-        W.append(w); I.append(i)
-    Z = torch.empty(B, T * D, device="cuda")
-    arr = hip.emb_tables([(I[t], W[t], Z[:, t * D:], rows[t], T * D) for t in range(T)])
-    launch = lambda: hip.check(hip.lib.ffh_embedding_fwd_multi(hip.ctx, arr, T, 1, D, B, capi.AGGR_MODE_SUM, None), "fwd")
-    for _ in range(3):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # launches go to the null stream = torch's current stream
-    torch.cuda.synchronize()
-    iters = 50
-    e0.record()
-    for _ in range(iters):
-        launch()
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
-    nbytes = T * B * (8 + 4 * D + 4 * D)
-    del W, I, Z
-    torch.cuda.empty_cache()
-    return {"kernel": "emb_fwd_kernel<4,4>", "shape": f"{T} tables x ~40M rows x {D} fp32, batch {B}", "bound": "hbm",
-            "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4),
-            "us_per_launch": round(sec * 1e6, 2), "algorithmic_bytes": nbytes}
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks ourselves, before anything initialises a GPU
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n: int) -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FFM_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)   # rank 0 prints the one JSON line
+    reader.start()
+    deadline = time.time() + float(os.environ.get("FFM_SPAWN_TIMEOUT", "1500"))
+    while True:
+        rcs = [p.poll() for p in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        if any(rc not in (None, 0) for rc in rcs) or time.time() > deadline:
+            time.sleep(2.0)                  # let the failing rank's peers print what they have
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                 # exactly the children started above, by handle
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = buf[0] if buf else ""
+    bad = [i for i, rc in enumerate(rcs) if rc != 0]
+    line = [l for l in out0.splitlines() if l.startswith("{")]
+    if bad or not line:
+        sys.stderr.write(f"bench.py: rank(s) {bad} failed (exit codes {rcs}); rank 0 printed {len(line)} JSON line(s)\n")
+        return 1
+    print(line[-1], flush=True)
+    return 0
 
 
-def largest_linear(w, B, t_fwd, t_bwd):
-    """MFMA roofline of the Linear layer with the most multiply-adds (Kaggle shape: top 432 -> 512), timed alone with HIP
-    events on the model's stream, back to back (so the ~2.5 us dependent-launch floor is inside the figure)."""
-    dims = [int(v) for v in w["bot"].split("-")], [int(v) for v in w["top"].split("-")]
-    pairs = [(a, b) for d in dims for a, b in zip(d[:-1], d[1:])]
+def largest_linear(w, B, t_fwd, t_bwd, bf16):
+    """MFMA roofline of the Linear layer with the most multiply-adds, timed alone with HIP events on the model's stream,
+    back to back."""
+    bot, top = [int(v) for v in w["bot"].split("-")], [int(v) for v in w["top"].split("-")]
+    if "--arch-interaction-op" not in w.get("extra", []):
+        top[0] = bot[-1] + len(w["rows"].split("-")) * w["D"]
+    pairs = [(a, b) for d in (bot, top) for a, b in zip(d[:-1], d[1:])]
     i, o = max(pairs, key=lambda p: p[0] * p[1])
     f = 2.0 * B * i * o
-    return {"layer": f"{i}->{o}, batch {B}", "bound": "mfma", "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "fwd": {"us": round(t_fwd * 1e6, 2), "achieved": round(f / t_fwd / 1e12, 1), "frac": round(f / t_fwd / 1e12 / F32_PEAK_TFLOPS, 3),
-                    "kernel": "gemm_glds_kernel<kc,kc> (LDS-DMA staged, 16 waves per 64x64 tile, bias + activation epilogue)"},
-            "bwd": {"us": round(t_bwd * 1e6, 2), "achieved": round(2 * f / t_bwd / 1e12, 1), "frac": round(2 * f / t_bwd / 1e12 / F32_PEAK_TFLOPS, 3),
-                    "kernel": "gemm_glds_bwd_kernel: dX (kc,kr; relu' of the layer below in the epilogue) and dW (kr,kr; split-K over "
-                              "the batch, db from the LDS image) as ONE launch"}}
+    peak = BF16_PEAK_TFLOPS if bf16 else F32_PEAK_TFLOPS
+    return {"layer": f"{i}->{o}, batch {B}", "bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+            "dtype": "bf16 operands, f32 accumulate" if bf16 else "f32",
+            "fwd": {"us": round(t_fwd * 1e6, 2), "achieved": round(f / t_fwd / 1e12, 1), "frac": round(f / t_fwd / 1e12 / peak, 3)},
+            "bwd": {"us": round(t_bwd * 1e6, 2), "achieved": round(2 * f / t_bwd / 1e12, 1), "frac": round(2 * f / t_bwd / 1e12 / peak, 3),
+                    "note": "dX and dW GEMMs of the layer (dW on its own stream where the layer is large enough), interval on the model's stream incl. the join"}}
+
+
+def hbm_block(kernel, nbytes, sec, traffic=None, src=None, note=None):
+    d = {"kernel": kernel, "bound": "hbm", "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src if traffic else None,
+         "us_per_launch": round(sec * 1e6, 2), "algorithmic_bytes_per_launch": nbytes}
+    if traffic:
+        d["achieved_from_traffic"] = round(traffic / sec / 1e9, 1)     # HBM GB/s priced on the PMC bytes instead of the formula
+        d["traffic_over_algorithmic"] = round(traffic / nbytes, 3)
+    if note:
+        d["note"] = note
+    return d
+
+
+def kaggle_secondary(ffmodel, local_rank):
+    """BASELINE configs[1] (Criteo-Kaggle shape, B = 2048) in the same process: the launch-latency regime of the path."""
+    w = workload("kaggle", 2048)
+    app = ffmodel.DLRM(flags_of(w, ["--device", str(local_rank)]))
+    app.warmup()
+    g = min(app.time_kernel(2, 30), app.time_kernel(2, 30))
+    e = min(app.time_kernel(4, 30), app.time_kernel(4, 30))
+    trace = g <= e
+    app.train_steps(30, trace=trace)
+    app.model.sync()
+    t0 = time.perf_counter()
+    app.train_steps(300, trace=trace)
+    app.model.sync()
+    dt = time.perf_counter() - t0
+    t_fwd = app.time_kernel(8, 200) * 1e-3
+    t_bwd = app.time_kernel(9, 100) * 1e-3
+    app.close()
+    T, B, D = 26, 2048, 16
+    return {"workload": "criteo-kaggle-shape (BASELINE configs[1]): 26 tables, emb_dim 16, batch 2048, bot 13-512-256-64-16, top 432-512-256-1",
+            "value": round(300 * B / dt, 1), "unit": "samples/s", "us_per_step": round(dt / 300 * 1e6, 1), "step_graph": bool(trace),
+            "step_us_graph_vs_eager": {"graph": round(g * 1e3, 1), "eager": round(e * 1e3, 1)},
+            "gather": {"us_per_launch": round(t_fwd * 1e6, 2), "GB/s": round(T * B * (8 + 8 * D) / t_fwd / 1e9, 1)},
+            "fused_update": {"us_per_launch": round(t_bwd * 1e6, 2), "GB/s": round(T * B * (8 + 12 * D) / t_bwd / 1e9, 1)}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="kaggle", help="kaggle (default, BASELINE configs[1]) | tiny | terabyte | mlperf | giant | giant-row | mlperf-allpairs")
-    ap.add_argument("--per-gpu-batch", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="terabyte", help="terabyte (default, BASELINE configs[2] shape at global batch 32768) | kaggle | tiny | mlperf | giant | giant-row | mlperf-allpairs")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: keep the GLOBAL batch (strong, default: BASELINE configs[2]) or the per-GPU batch (weak)")
+    ap.add_argument("--per-gpu-batch", type=int, default=None, help="samples per GPU and step (implies weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-probe", action="store_true", help="(default) kept for older command lines")
-    ap.add_argument("--probe", action="store_true", help="also time the gather at the Terabyte shape (4 tables x 40 M rows x 128, B = 32768): "
-                                                         "extra launches of emb_fwd_kernel, so off by default to keep the rocprof averages single-shape")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Kaggle-shape block under `kernels` (profile runs: keeps the rocprof averages single-shape)")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="1 GPU: still run the all-to-all / all-reduce path (1-rank RCCL group)")
     ap.add_argument("--torch-collectives", action="store_true", help="serve the all-to-all / all-reduce through torch.distributed callbacks "
@@ -215,26 +276,38 @@ def main():
     ap.add_argument("--cpu-baseline-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--leg-budget", type=float, default=7.0, help=argparse.SUPPRESS)
     ap.add_argument("--shim-flags", default="", help="extra FFConfig flags for A/B runs, e.g. '--serial-dw --no-overlap'")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: ranks rendezvous over gloo and report, no GPU
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_leg:
+        sys.exit(spawn_ranks(args.gpus))   # the parent: no torch import, no HIP call, nothing that initialises a GPU
     # stdout carries the ONE JSON line and nothing else: the C++ driver's printf banner ("[DLRM] ...", flushed by the C
     # runtime at exit) is sent to stderr
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     if args.cpu_baseline_leg:          # child of cpu_baseline(): host only, never touches the GPU
-        cpu_baseline_leg(args.workload, args.per_gpu_batch, args.leg_budget, json_out)
+        cpu_baseline_leg(args.workload, args.leg_budget, json_out)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with\n"
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus {args.gpus}` (it starts its own ranks) or\n"
                          f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
                          f"--master-port 29511 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
     import torch
     import torch.distributed as dist
-    from dlrm_flexflow_amd import capi, ffmodel
+    if args.dry_run:                   # launcher test (CPU): the ranks meet over gloo, rank 0 reports what it saw
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "ranks_observed": dist.get_world_size(), "sum": float(t.item())}), file=json_out, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    from dlrm_flexflow_amd import ffmodel
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
@@ -258,7 +331,16 @@ def main():
                 if rank == 0:
                     print("bench: direct RCCL not used:", e, file=sys.stderr, flush=True)
 
-    w = workload(args.workload, args.per_gpu_batch, world)
+    weak = args.scaling == "weak" or args.per_gpu_batch is not None
+    base = args.per_gpu_batch or DEFAULT_BATCH[args.workload]
+    if weak:
+        gb = base * world
+    else:
+        gb = base
+        if gb % world:
+            raise SystemExit(f"global batch {gb} is not divisible by {world} ranks")
+    w = workload(args.workload, gb)
+    bf16 = "--allow-tensor-op-math-conversion" in args.shim_flags.split()
     extra = ["--device", str(local_rank)] + (["--no-trace"] if args.no_trace else []) + (["--force-exchange"] if args.force_exchange else []) + args.shim_flags.split()
     app = ffmodel.DLRM(flags_of(w, extra), comm=comm.struct if comm else None)
     trace = not args.no_trace
@@ -271,12 +353,14 @@ def main():
     app.warmup()                                   # the reference's own warm-up iteration (loads the batch)
     # hipGraph replay (the reference's Legion trace) vs eager launches: keep whichever is faster on this box
     step_us = {}
-    if args.force_exchange:
-        trace = False
-    if trace and world == 1:
+    solo = world == 1 and not args.force_exchange
+    if not solo:
+        trace = False                              # collectives are host callbacks: not captured
+    if trace:
         # best of two short measurements each: one hiccup in either must not pick the slower mode for the whole timed region
-        step_us["graph"] = min(app.time_kernel(2, 30), app.time_kernel(2, 30)) * 1e3
-        step_us["eager"] = min(app.time_kernel(4, 30), app.time_kernel(4, 30)) * 1e3
+        n_probe = 30 if w["B"] <= 4096 else 5
+        step_us["graph"] = min(app.time_kernel(2, n_probe), app.time_kernel(2, n_probe)) * 1e3
+        step_us["eager"] = min(app.time_kernel(4, n_probe), app.time_kernel(4, n_probe)) * 1e3
         trace = step_us["graph"] <= step_us["eager"]
     app.train_steps(args.warmup, trace=trace)      # W untimed steps
     app.model.reset_metrics()
@@ -297,14 +381,18 @@ def main():
     T = len(w["rows"].split("-"))
     owned = len([t for t in range(T) if t % world == rank])
     B, D = w["B"], w["D"]
-    solo = world == 1 and not args.force_exchange
-    t_fwd = app.time_kernel(0, 200) * 1e-3 if solo else None
-    t_bwd = app.time_kernel(1, 100) * 1e-3 if solo else None
-    t_step_dev = app.time_kernel(2 if trace else 4, 100) * 1e-3 if solo else None
-    t_lin_fwd = app.time_kernel(6, 200) * 1e-3 if solo else None      # largest Linear layer alone: forward, backward (dX + dW)
-    t_lin_bwd = app.time_kernel(7, 100) * 1e-3 if solo else None
+    table_wise = not any(f in w.get("extra", []) for f in ("--column-shard-rows", "--row-shard-rows")) or world == 1
+    n_g = 200 if B * owned <= 65536 else 40
+    t_fwd = app.time_kernel(8, n_g) * 1e-3 if (rank == 0 and table_wise and owned) else None           # gather kernel alone (no exchange)
+    t_bwd = app.time_kernel(9, max(10, n_g // 2)) * 1e-3 if (rank == 0 and table_wise and owned) else None   # fused update kernels alone
+    t_step_dev = app.time_kernel(2 if trace else 4, 20 if B > 4096 else 100) * 1e-3 if solo else None
+    t_lin_fwd = app.time_kernel(6, 20 if B > 4096 else 200) * 1e-3 if solo else None      # largest Linear layer alone: forward, backward (dX + dW)
+    t_lin_bwd = app.time_kernel(7, 20 if B > 4096 else 100) * 1e-3 if solo else None
     uses_graph = app.model.uses_graph and trace
+    calls = dict(comm.calls) if comm is not None and hasattr(comm, "calls") else None
     app.close()
+    if world > 1:
+        barrier()                                  # the probes above are rank 0's: nobody tears the group down under them
 
     if rank != 0:
         if dist.is_initialized():
@@ -315,47 +403,52 @@ def main():
     samples = w["B"] * args.steps
     wx = w.get("extra", [])
     layout = ("the table row-wise (partial bag sums + RCCL reduce-scatter fwd, all-gather bwd)" if "--row-shard-rows" in wx else
-              "the table column-wise (RCCL all-to-all fwd+bwd)" if "--column-shard-rows" in wx else "tables table-wise (RCCL all-to-all fwd+bwd)")
+              "the table column-wise (RCCL all-to-all fwd+bwd)" if "--column-shard-rows" in wx else "tables table-wise, table t on rank t % N (RCCL all-to-all fwd+bwd)")
     out = {
         "metric": "dlrm_training_samples_per_sec", "value": round(samples / elapsed, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
+        "dtype": "f32" if not bf16 else "bf16 GEMM operands (fp32 accumulate, fp32 master weights); fp32 elsewhere", "data": "synthetic",
         "config": {"workload": f"{w['name']}: {T} tables (rows {w['rows']}), emb_dim {D}, bag 1, bot {w['bot']}, top {w['top']}, "
-                               f"{'dot (strict lower triangle)' if 'dot-tril' in w.get('extra', []) else 'dot (all pairs)' if 'dot' in w.get('extra', []) else 'cat'} interaction, SGD lr 0.01, MSE loss",
+                               f"{'dot (strict lower triangle)' if 'dot-tril' in wx else 'dot (all pairs)' if 'dot' in wx else 'cat'} interaction, SGD lr 0.01, MSE loss",
                    "global_batch": w["B"], "per_gpu_batch": w["B"] // world,
                    "parallelism": ("single GPU, hipGraph-replayed step" if uses_graph else "single GPU, eager launches on 3 HIP streams") if world == 1 else
-                                  f"{layout} over {world} ranks, MLPs data-parallel (1 all-reduce); {collectives}",
+                                  f"{layout} over {world} ranks, MLPs data-parallel (1 all-reduce of the gradient slab); {collectives}",
                    "step_graph": bool(uses_graph), "step_us_graph_vs_eager": {k: round(v, 1) for k, v in step_us.items()}},
         "mse_over_timed_steps": round(2.0 * pm.mse_loss / max(pm.train_all, 1), 6),   # train_all is double-counted (1 class + accuracy), as in the reference
     }
+    if world > 1 or args.force_exchange:
+        out["config"]["ranks_observed"] = dist.get_world_size()
+        out["config"]["collective_calls_rank0"] = calls
     if args.force_exchange:
         out["config"]["parallelism"] = f"1 rank, exchange path forced: {layout} + all-reduce; {collectives}"
+    out["kernels"] = {}
+    if t_fwd:
+        key = args.workload if (world == 1 and w["B"] == DEFAULT_BATCH[args.workload]) else None
+        pmc, src = pmc_traffic(key) if key else ({}, None)
+        fwd_bytes = owned * B * (8 + 4 * D + 4 * D)            # indices + gathered rows + output write
+        bwd_bytes = owned * B * (8 + 4 * D + 2 * 4 * D)        #            indices + out-grad read + row read-modify-write
+        out["roofline"] = hbm_block("emb_fwd_kernel (embedding gather + bag-sum, this rank's tables in one launch)", fwd_bytes, t_fwd,
+                                    pmc.get("gather_bytes_per_launch"), src)
+        out["roofline"]["bytes_per_sample"] = fwd_bytes // B
+        out["roofline"]["tables_in_launch"] = owned
+        out["kernels"]["embedding_bwd_sgd_fused"] = hbm_block(
+            "radix_hist/radix_scatter (LDS-histogram LSD radix sort of the ids) + emb_sgd_reduce (segmented sum + W -= lr*sum) + emb_sgd_fold; "
+            "batch x bag <= 2048 per table: emb_sgd_small_kernel, one launch", bwd_bytes, t_bwd, pmc.get("update_bytes_per_call"), src)
     if solo:
-        fwd_bytes = owned * B * (8 + 4 * D + 4 * D)            # 3,536 B/sample at the Kaggle shape
-        bwd_bytes = owned * B * (8 + 4 * D + 2 * 4 * D)
-        out["roofline"] = {"kernel": "emb_fwd_kernel (embedding gather + bag-sum, all tables in one launch)", "bound": "hbm",
-                           "achieved": round(fwd_bytes / t_fwd / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(fwd_bytes / t_fwd / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": pmc_traffic("kaggle")[0] if args.workload == "kaggle" and not args.per_gpu_batch else None,
-                           "traffic_source": pmc_traffic("kaggle")[1],
-                           "us_per_launch": round(t_fwd * 1e6, 2), "algorithmic_bytes_per_launch": fwd_bytes,
-                           "bytes_per_sample": fwd_bytes // B}
         flops = mlp_flops_per_sample(w) * B
-        out["kernels"] = {
-            "embedding_bwd_sgd_fused": {"bound": "hbm", "achieved": round(bwd_bytes / t_bwd / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": round(bwd_bytes / t_bwd / 1e9 / HBM_PEAK_GBS, 4), "us_per_call": round(t_bwd * 1e6, 2),
-                                        "note": "batch x bag <= 2048 per table: ONE launch, a 512-thread workgroup per table (LDS-resident radix sort, segmented reduce by two 256-thread teams, both folds); larger batches: tiled radix sort + reduce + fold launches, all tables batched"},
-            "linear_largest_layer": largest_linear(w, B, t_lin_fwd, t_lin_bwd),
-            "whole_step_device": {"us": round(t_step_dev * 1e6, 2), "mlp_gflop_per_step": round(flops / 1e9, 3),
-                                  "mlp_tflops_over_whole_step": round(flops / t_step_dev / 1e12, 2), "f32_mfma_peak_tflops": F32_PEAK_TFLOPS},
-        }
-        if args.probe and not args.no_probe:
+        peak = BF16_PEAK_TFLOPS if bf16 else F32_PEAK_TFLOPS
+        out["kernels"]["linear_largest_layer"] = largest_linear(w, B, t_lin_fwd, t_lin_bwd, bf16)
+        out["kernels"]["whole_step_device"] = {"us": round(t_step_dev * 1e6, 2), "mlp_gflop_per_step": round(flops / 1e9, 3),
+                                               "mlp_tflops_over_whole_step": round(flops / t_step_dev / 1e12, 2), "mfma_peak_tflops": peak,
+                                               "frac_of_mfma_peak": round(flops / t_step_dev / 1e12 / peak, 3)}
+        if not args.no_secondary and args.workload != "kaggle":
             try:
-                out["kernels"]["embedding_gather_terabyte_shape"] = terabyte_gather_probe(capi.load_hip(local_rank))
+                out["kernels"]["kaggle_secondary"] = kaggle_secondary(ffmodel, local_rank)
             except Exception as e:  # noqa: BLE001
-                out["kernels"]["embedding_gather_terabyte_shape"] = {"error": repr(e)}
+                out["kernels"]["kaggle_secondary"] = {"error": repr(e)}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, args)
+            out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -730,12 +730,19 @@ int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
   const GldsDims dx{px.grid.x, px.grid.y, px.grid.z}, dw{pw.grid.x, pw.grid.y, pw.grid.z};
   const int lds = px.lds_bytes > pw.lds_bytes ? px.lds_bytes : pw.lds_bytes;
   hipEvent_t ev = (hipEvent_t)c->attach_event;   // ffh_event_record_with_next_linear_bwd: this launch is the call's last kernel on s
-  if (c->scatter_map && c->scatter_ncols == dxg.N && dxg.epi == EPI_STORE) {
+  const bool scatter = c->scatter_map && c->scatter_ncols == dxg.N && dxg.epi == EPI_STORE;
+  if (scatter) {
     // ffh_linear_bwd_set_dx_scatter: the data gradient goes where a Concat backward would copy it; its event rides on this launch
     dxg.colmap = (const ffh_col_dest*)c->scatter_map;
-    c->scatter_used = 1;
     if (c->scatter_event && !ev) ev = (hipEvent_t)c->scatter_event;
   }
+  // Inside a stream capture a launch's stop event is NOT a captured event-record node: the graph would carry no edge
+  // from this kernel to whoever waits on the event.  There the event is recorded by an ordinary hipEventRecord behind
+  // the launch (a captured node) instead.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (ev && hipStreamIsCapturing(as_stream(s), &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  hipEvent_t ev_after = nullptr;
+  if (ev && cap != hipStreamCaptureStatusNone) { ev_after = ev; ev = nullptr; }
   // more workgroups than CUs: two stages (65 KB) so that two workgroups share a CU
   static const int forced_stages = getenv("FFH_GLDS_BWD_STAGES") ? atoi(getenv("FFH_GLDS_BWD_STAGES")) : 0;   // A/B switch (tools/ab.sh)
   const bool two = forced_stages ? forced_stages == 2 : (na8 + nb) > (unsigned)c->num_cus;
@@ -753,7 +760,13 @@ int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
 #undef FFH_DUAL
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, "linear_bwd dx+dw (lds-dma, one launch)");
-  if (ev) c->attach_event = nullptr;        // signalled by this kernel's own completion: no separate packet on s
+  if (scatter) c->scatter_used = 1;         // only once the launch that scatters is really in the stream
+  if (ev_after) {
+    e = hipEventRecord(ev_after, as_stream(s));
+    if (e != hipSuccess) return ffh_fail_hip(c, e, "linear_bwd dx+dw: event record (capturing)");
+    ev = ev_after;
+  }
+  if (ev && ev == (hipEvent_t)c->attach_event) c->attach_event = nullptr;   // signalled behind this kernel: no second record by the caller
   return 1;
 }
 

@@ -265,6 +265,7 @@ void DataLoader::next_batch(FFModel& ff) {
   if (next_index + B > num_samples) next_index = 0;
   const int64_t Bl = ff.local_batch;
   const int k = next_index / B;
+  ff.order_input_writes_behind_update();       // eager steps: the last step's table update may still be reading the ids
   for (size_t t = 0; t < batch_sparse_inputs.size(); t++) {
     if (!full_sparse[t]) continue;
     ff.check(ff.api->ffh_memcpy_d2d(ff.ctx, batch_sparse_inputs[t].impl->ptr, full_sparse[t] + (int64_t)next_index * bag,

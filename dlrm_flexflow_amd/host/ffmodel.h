@@ -489,10 +489,12 @@ class FFModel {
   std::vector<Embedding*> embeddings;
   void embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx = nullptr) const;   // on_ctx: the issuing thread's ctx
   void embedding_group_update(ffh_stream s, ffh_ctx* on_ctx = nullptr) const;
+  void embedding_kernels_only(bool fwd, ffh_stream s) const;                      // this rank's gather / fused update kernels, no exchange
   bool fused_embedding_update() const;
   void issue_embedding_forward_on_side_stream() const;
   void join_embedding_forward() const;
   void issue_embedding_update_on_side_stream() const;
+  void order_input_writes_behind_update() const;
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
   int grad_attach_layer;        // the Linear whose backward completes the embedding output gradients (-1: none / not attachable)

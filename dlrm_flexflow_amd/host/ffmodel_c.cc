@@ -158,7 +158,9 @@ float flexflow_dlrm_time_kernel(flexflow_dlrm_t h, int which, int iters) {
         if (which == 6) big->forward(*ff); else big->backward(*ff);
         continue;
       }
-      if (which == 0) ff->embedding_group_forward(ff->stream);
+      if (which == 8) ff->embedding_kernels_only(true, ff->stream);          // gather kernels of this rank's shards, no exchange
+      else if (which == 9) ff->embedding_kernels_only(false, ff->stream);    // fused update kernels alone
+      else if (which == 0) ff->embedding_group_forward(ff->stream);
       else if (which == 1) ff->embedding_group_update(ff->stream);
       else if (which == 3) {   // launch floor: a trivial dependent kernel (MSE gradient of the batch)
         const Tensor& fin = ff->layers.back()->outputs[0];

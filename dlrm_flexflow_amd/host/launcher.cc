@@ -1,0 +1,201 @@
+// launcher.cc -- `dlrm -ll:gpu N`: the reference's one-command multi-GPU invocation
+// [ref: examples/cpp/DLRM/run_random.sh:3, src/runtime/cpp_driver.cc:22-44] as one process per GPU.
+//
+// The parent never touches a GPU: it starts N copies of its own executable (rank r on device r), which rendezvous
+// through a private directory -- rank 0 writes the 128-byte RCCL unique id, the others wait for the file -- and build
+// the RCCL communicator from C++ (rccl_comm.cc).  No interpreter, no torch.distributed.  The parent waits for every
+// rank, ends the others if one fails, and returns non-zero then.
+#include "launcher.h"
+
+#include <dlfcn.h>
+#include <signal.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "backend.h"
+#include "dlrm.h"
+#include "rccl_comm.h"
+
+namespace {
+
+int gpus_requested(int argc, char** argv) {
+  int n = 0;
+  for (int i = 1; i + 1 < argc; i++)
+    if (!strcmp(argv[i], "-ll:gpu")) n = atoi(argv[i + 1]);
+  return n;
+}
+
+std::string backend_of(int argc, char** argv) {
+  for (int i = 1; i + 1 < argc; i++)
+    if (!strcmp(argv[i], "--backend")) return argv[i + 1];
+  return "";
+}
+
+bool read_file(const std::string& p, unsigned char* dst, size_t n) {
+  FILE* f = fopen(p.c_str(), "rb");
+  if (!f) return false;
+  const size_t got = fread(dst, 1, n, f);
+  fclose(f);
+  return got == n;
+}
+
+bool write_file_atomic(const std::string& p, const unsigned char* src, size_t n) {
+  const std::string tmp = p + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return false;
+  const bool ok = fwrite(src, 1, n, f) == n;
+  fclose(f);
+  return ok && rename(tmp.c_str(), p.c_str()) == 0;
+}
+
+// barrier of the launcher's ranks: a one-float all-reduce on a private stream, then a host wait for it
+struct BarrierState {
+  const KernelApi* api;
+  ffh_ctx* ctx;
+  ffh_stream stream;
+  float* buf;
+  ffcomm* comm;
+};
+BarrierState g_bar;
+int launcher_barrier(void*) {
+  if (!g_bar.comm) return 0;
+  if (g_bar.comm->allreduce_sum_f32(g_bar.comm->user, g_bar.buf, 1, g_bar.stream) != 0) return 1;
+  return g_bar.api->ffh_stream_sync(g_bar.ctx, g_bar.stream) == FFH_OK ? 0 : 1;
+}
+
+int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv) {
+  const bool dry = getenv("FFM_LAUNCH_DRYRUN") != nullptr;     // tests: process management + rendezvous without a GPU
+  unsigned char id[128];
+  memset(id, 0, sizeof id);
+  const char* rccl = getenv("FFM_RCCL_LIB");
+  const KernelApi* api = nullptr;
+  ffh_ctx* ctx = nullptr;
+  if (!dry) {
+    // bind this process to its GPU before RCCL looks at the current device
+    api = load_kernel_api(backend_of(argc, argv));
+    if (api->ffh_ctx_create(&ctx, rank) != FFH_OK || !ctx) {
+      fprintf(stderr, "dlrm rank %d: no usable device %d\n", rank, rank);
+      return 3;
+    }
+  }
+  const std::string idfile = rdv + "/rccl_unique_id";
+  if (rank == 0) {
+    if (dry) { for (int i = 0; i < 128; i++) id[i] = (unsigned char)(i * 7 + 1); }
+    else if (flexflow_rccl_get_unique_id(id, rccl) != 0) {
+      fprintf(stderr, "dlrm rank 0: ncclGetUniqueId failed: %s\n", flexflow_rccl_last_error());
+      return 4;
+    }
+    if (!write_file_atomic(idfile, id, sizeof id)) { perror("dlrm rank 0: rendezvous file"); return 4; }
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    while (!read_file(idfile, id, sizeof id)) {
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+        fprintf(stderr, "dlrm rank %d: no unique id from rank 0 after 120 s\n", rank);
+        return 4;
+      }
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+  }
+  if (dry) {
+    unsigned sum = 0;
+    for (int i = 0; i < 128; i++) sum += id[i];
+    printf("[launcher] rank %d of %d: rendezvous ok (id checksum %u)\n", rank, world, sum);
+    return 0;
+  }
+  ffcomm comm;
+  if (flexflow_rccl_comm_create(id, rank, world, rccl, &comm) != 0) {
+    fprintf(stderr, "dlrm rank %d: ncclCommInitRank failed: %s\n", rank, flexflow_rccl_last_error());
+    return 5;
+  }
+  g_bar.api = api; g_bar.ctx = ctx; g_bar.comm = &comm;
+  void* p = nullptr;
+  if (api->ffh_stream_create(ctx, &g_bar.stream) != FFH_OK || api->ffh_malloc(ctx, &p, 256) != FFH_OK) return 5;
+  g_bar.buf = (float*)p;
+  api->ffh_zero(ctx, p, 256, g_bar.stream);
+  comm.barrier = launcher_barrier;
+  // the rank's own argv: the same flags + its device
+  std::vector<char*> av(argv, argv + argc);
+  std::string dev = std::to_string(rank);
+  char dflag[] = "--device";
+  av.push_back(dflag);
+  av.push_back(const_cast<char*>(dev.c_str()));
+  const int rc = dlrm_main((int)av.size(), av.data(), &comm);
+  launcher_barrier(nullptr);
+  g_bar.comm = nullptr;
+  flexflow_rccl_comm_destroy(&comm);
+  return rc;
+}
+
+}  // namespace
+
+int dlrm_launch(int argc, char** argv) {
+  const char* er = getenv("FFM_LAUNCH_RANK");
+  if (er) {   // one of the ranks
+    const int rank = atoi(er), world = atoi(getenv("FFM_LAUNCH_WORLD") ? getenv("FFM_LAUNCH_WORLD") : "1");
+    const char* rdv = getenv("FFM_LAUNCH_RDV");
+    if (!rdv || world < 1 || rank < 0 || rank >= world) { fprintf(stderr, "dlrm: bad FFM_LAUNCH_* environment\n"); return 2; }
+    return run_rank(argc, argv, rank, world, rdv);
+  }
+  int n = gpus_requested(argc, argv);
+  const bool force = getenv("FFM_FORCE_LAUNCHER") != nullptr;                 // tests: walk the launcher with one rank
+  if (n <= 1 && !force) return dlrm_main(argc, argv, nullptr);                // -ll:gpu 0 / 1: this process is the one rank
+  if (n < 1) n = 1;
+
+  // ---- parent: no GPU call from here on ------------------------------------------------------------------------
+  char tmpl[] = "/tmp/ffm_launch_XXXXXX";
+  const char* dir = mkdtemp(tmpl);
+  if (!dir) { perror("dlrm: mkdtemp"); return 2; }
+  char exe[4096];
+  const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
+  if (k <= 0) { perror("dlrm: /proc/self/exe"); return 2; }
+  exe[k] = 0;
+  std::vector<pid_t> pids;
+  for (int r = 0; r < n; r++) {
+    const pid_t pid = fork();
+    if (pid < 0) { perror("dlrm: fork"); break; }
+    if (pid == 0) {
+      setenv("FFM_LAUNCH_RANK", std::to_string(r).c_str(), 1);
+      setenv("FFM_LAUNCH_WORLD", std::to_string(n).c_str(), 1);
+      setenv("FFM_LAUNCH_RDV", dir, 1);
+      setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+      execv(exe, argv);          // nothing in this process has initialised a GPU
+      perror("dlrm: execv");
+      _exit(127);
+    }
+    pids.push_back(pid);
+  }
+  int failed = (int)pids.size() != n;
+  size_t left = pids.size();
+  std::vector<bool> done(pids.size(), false);
+  while (left > 0) {
+    int st = 0;
+    const pid_t p = wait(&st);
+    if (p < 0) break;
+    for (size_t i = 0; i < pids.size(); i++) {
+      if (pids[i] != p || done[i]) continue;
+      done[i] = true; left--;
+      const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+      if (rc != 0) {
+        fprintf(stderr, "dlrm: rank %zu ended with %d\n", i, rc);
+        if (!failed) {
+          failed = 1;
+          for (size_t j = 0; j < pids.size(); j++)
+            if (!done[j]) kill(pids[j], SIGTERM);      // the ranks this process started, by pid: peers of a dead rank would wait for ever
+        }
+      }
+    }
+  }
+  unlink((std::string(dir) + "/rccl_unique_id").c_str());
+  unlink((std::string(dir) + "/rccl_unique_id.tmp").c_str());
+  rmdir(dir);
+  return failed ? 1 : 0;
+}

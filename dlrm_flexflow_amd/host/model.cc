@@ -217,6 +217,12 @@ bool Tensor::set_tensor(const FFModel* model, const std::vector<int>& dims, cons
   const int64_t nrows = (int64_t)(vol / (size_t)cols_);
   if (vol % (size_t)cols_ != 0 || nrows != impl->rows_local)
     die("set_tensor: %zu elements given, this rank holds %lld x %lld", vol, (long long)impl->rows_local, (long long)cols_);
+  // the fused table update (side stream) still reads the sparse ids and writes the tables, a forked weight-gradient GEMM
+  // (dw stream) still reads activations: a host write must land behind both, as every host read does (copy_out)
+  if (model->dw_worker) model->dw_worker->drain();
+  if (model->side_worker) model->side_worker->drain();
+  model->check(model->api->ffh_stream_sync(model->ctx, model->side_stream), "set_tensor sync");
+  model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream), "set_tensor sync");
   if (impl->ld == cols_) {
     model->check(model->api->ffh_memcpy_h2d(model->ctx, impl->ptr, data, vol * sizeof(T), model->stream), "set_tensor");
   } else {
@@ -394,8 +400,8 @@ FFModel::FFModel(FFConfig& _config)
   rank = config.comm.world_size > 1 ? config.comm.rank : 0;
   world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
   if (world_size == 1 && config.workersPerNode > 1)
-    die("-ll:gpu %d: this build runs one process per GPU; launch %d ranks with\n"
-        "       python -m torch.distributed.run --nproc-per-node %d dlrm_flexflow_amd/run_dlrm.py <flags>",
+    die("-ll:gpu %d: one process per GPU and no communicator was supplied; use the `dlrm` binary (it starts its own %d ranks),\n"
+        "       python dlrm_flexflow_amd/run_dlrm.py <flags>, or bench.py --gpus %d",
         config.workersPerNode, config.workersPerNode, config.workersPerNode);
   if (world_size > 1 && (!config.comm.alltoall_f32 || !config.comm.allreduce_sum_f32))
     die("world_size %d needs the ffcomm callbacks", world_size);
@@ -1586,6 +1592,13 @@ static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s, ffh_c
   }
 }
 
+// the batched gather (fwd) or fused update kernels of this rank's shards alone, no exchange: what bench.py times as the
+// roofline kernels of a multi-rank job
+void FFModel::embedding_kernels_only(bool fwd, ffh_stream s) const {
+  if (embeddings.empty()) return;
+  launch_shard_groups(this, fwd, s, ctx);
+}
+
 void FFModel::embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx) const {
   if (embeddings.empty()) return;
   launch_shard_groups(this, true, s, on_ctx ? on_ctx : ctx);
@@ -1698,6 +1711,14 @@ void FFModel::issue_embedding_update_on_side_stream() const {
   }
 }
 
+// Writers of the model inputs on `stream` (the data loader's next batch) go behind the side-stream table update of the
+// step before, which still sorts and reads the sparse ids.
+void FFModel::order_input_writes_behind_update() const {
+  if (embeddings.empty() || !config.overlap_embedding || !fused_embedding_update()) return;
+  if (side_worker) side_worker->drain();       // the record of ev_update_done must have been issued
+  check(api->ffh_stream_wait_event(ctx, stream, ev_update_done), "inputs behind the table update");
+}
+
 void FFModel::zero_gradients() {
   if (replaying_trace >= 0) return;
   // Op::zero_grad for every layer [ref: src/runtime/model.cc:466-490]: two slabs instead of ~34 tasks.
@@ -1799,6 +1820,10 @@ void FFModel::update() {
     if (dw_worker) dw_worker->drain();
     check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");
     check(api->ffh_stream_wait_event(ctx, stream, ev_dw_done), "join dw");
+    // the next gather (side stream) overwrites embedding outputs that alias the Concat output -- the x operand of the first
+    // top-MLP layer, which a forked dW GEMM may still be reading: write-after-read across streams
+    if (config.overlap_embedding && !embeddings.empty() && !use_workers())
+      check(api->ffh_stream_wait_event(ctx, side_stream, ev_dw_done), "join dw (embedding stream)");
     dw_forked = false;
   }
   // data-parallel MLP gradients: ONE bucket [ref: one ncclAllReduce per tensor, src/runtime/optimizer_kernel.cu:170-171].

@@ -1,0 +1,123 @@
+"""The three launchers of the multi-GPU path -- `bench.py --gpus N`, `dlrm -ll:gpu N` (host/launcher.cc) and
+`run_dlrm.py -ll:gpu N` -- start their own ranks before anything touches a GPU
+[ref: one command with -ll:gpu N, examples/cpp/DLRM/run_random.sh:3, src/runtime/cpp_driver.cc:22-44].
+
+CPU tests: process management, rendezvous and the world_size-2 path over gloo with the oracle as kernel library.
+GPU tests (-m gpu): the same entry points with a 1-rank RCCL group on the box's one GPU.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+from dlrm_flexflow_amd import build
+
+EXE = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
+RUN_DLRM = os.path.join(ROOT, "dlrm_flexflow_amd", "run_dlrm.py")
+BENCH = os.path.join(ROOT, "bench.py")
+SMALL = ["-b", "64", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "100-200-50", "--arch-mlp-bot", "13-16-8",
+         "--arch-mlp-top", "32-16-1", "--data-size", "128", "--epochs", "2"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    build.build_host()
+
+
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` with no WORLD_SIZE: the parent spawns two ranks (env RANK / WORLD_SIZE / MASTER_*), they meet
+    over 127.0.0.1 and rank 0's single JSON line is relayed on the parent's stdout."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["ranks_observed"] == 2 and d["sum"] == 2.0 and d["n_gpus"] == 2
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU: there the ranks refuse to run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == "" and "failed" in r.stderr
+
+
+def test_bench_rejects_mismatched_world_size():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_dlrm_binary_starts_its_own_ranks_dry():
+    """`dlrm -ll:gpu 3`: three child ranks of the binary, rendezvous through the private directory (rank 0 publishes the
+    id file atomically, the others wait for it); FFM_LAUNCH_DRYRUN stops before the first GPU call."""
+    env = dict(os.environ, FFM_LAUNCH_DRYRUN="1")
+    r = subprocess.run([EXE, "-ll:gpu", "3", *SMALL], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    got = sorted(l for l in r.stdout.splitlines() if l.startswith("[launcher]"))
+    assert len(got) == 3
+    sums = {l.split("checksum")[1] for l in got}
+    assert len(sums) == 1                      # every rank read the id rank 0 wrote
+    for k in range(3):
+        assert f"rank {k} of 3" in got[k]
+
+
+def test_dlrm_binary_reports_a_failing_rank():
+    """A rank that cannot come up (no GPU here / no such device) makes the parent end the others and return non-zero."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = subprocess.run([EXE, "-ll:gpu", "2", *SMALL], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
+def test_run_dlrm_two_ranks_gloo(oracle):
+    """run_dlrm.py -ll:gpu 2 with the oracle as kernel library: two ranks over gloo run the driver's warm-up + epochs and
+    rank 0 prints the reference's THROUGHPUT line once."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, RUN_DLRM, "-ll:gpu", "2", *SMALL, "--backend", oracle.ORACLE_LIB], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("THROUGHPUT = ") == 1
+    assert "[DLRM] batchSize(64) workersPerNodes(2)" in r.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_dlrm_binary_launcher_one_rccl_rank_on_gpu(hip):
+    """The C++ launcher end to end with one rank: child process, id file, ncclCommInitRank from C++, the exchange path
+    (all-to-all each way + all-reduce) on the HIP streams, the launcher's all-reduce barrier, THROUGHPUT line."""
+    env = dict(os.environ, FFM_FORCE_LAUNCHER="1")
+    r = subprocess.run([EXE, "-ll:gpu", "1", "--force-exchange", *SMALL], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "THROUGHPUT = " in r.stdout
+    plain = subprocess.run([EXE, *SMALL], capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr
+    mse = lambda txt: [l for l in txt.splitlines() if "mean_squared_error" in l][-1].split("mean_squared_error:")[1].split()[0]
+    assert abs(float(mse(r.stderr)) - float(mse(plain.stderr))) < 1e-5        # same model, same data: same loss through the exchange path
+
+
+@pytest.mark.gpu
+def test_run_dlrm_one_rank_on_gpu(hip):
+    r = subprocess.run([sys.executable, RUN_DLRM, "-ll:gpu", "1", *SMALL], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("THROUGHPUT = ") == 1
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_exchange_line_on_gpu(hip):
+    """bench.py through the exchange path on one RCCL rank: the line carries roofline, the collective counts and the rank count."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-exchange", "--workload", "kaggle", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["ranks_observed"] == 1
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+    c = d["config"]["collective_calls_rank0"]
+    assert c["alltoall"] >= 2 * 7 and c["allreduce"] >= 7
