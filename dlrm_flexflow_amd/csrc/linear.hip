@@ -400,6 +400,210 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 }
 
 // =============================================================================================
+// Tensor-op math mode (ffh_ctx_set_math_mode(FFH_MATH_TENSOR_OP_BF16); the reference's
+// --allow-tensor-op-math-conversion -> cublasSetMathMode(CUBLAS_TENSOR_OP_MATH) [ref: src/runtime/model.cu:81-83]):
+// the same three GEMM forms with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 16x the fp32 MFMA rate).
+// Activations, weights and gradients stay fp32 in HBM; a tile is rounded to bf16 (v_cvt_pk_bf16_f32, nearest even)
+// between its global load and its LDS image, so nothing outside this kernel knows about the mode.
+//   128 x 128 x 64 block tile, 4 waves (2 x 2), each 64 x 64 = 2 x 2 MFMA tiles; double-buffered LDS (64 KB: two
+//   workgroups per CU), one barrier per k-tile, global loads of tile t+1 in flight under the MFMAs of tile t.
+//   k-contiguous operand (x, w forward; dy in dX): image [row][64 bf16] = 128-byte rows, 16-byte chunks XOR-swizzled by
+//     (row >> 1) & 7 -> the fragment of lane (row r, half h) at k-step s is ONE conflict-free ds_read_b128 (chunk 2s + h);
+//   rows-are-k operand (w in dX; dy, x in dW): image [k][128 bf16] = 256-byte rows, stored as it arrives (one ds_write_b64
+//     per float4, coalesced), read TRANSPOSED by ds_read_b64_tr_b16: a 16-lane group fetches a 4 (k) x 16 (column) block and
+//     every lane receives the 4 k-values of its own column; two such reads make the 8-element MFMA fragment.  Chunk swizzle
+//     ch ^ (((k & 3) << 2) | ((k >> 2) & 3)) keeps both the stores and the transposed reads conflict-free.
+// With fp32 operands in memory the kernel is bound by the global -> LDS path (32 flop per staged byte), not by the matrix
+// pipe: ~0.8-1 PFLOP/s, i.e. 6-8x the fp32 mode.
+// =============================================================================================
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint2 pack_bf16x4(const float4 v) {
+  const bf16x2_t lo = {(__bf16)v.x, (__bf16)v.y}, hi = {(__bf16)v.z, (__bf16)v.w};
+  return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+}
+
+constexpr int kBfBM = 128, kBfBN = 128, kBfBK = 64;
+constexpr int kBfImage = 128 * 64 * 2;                    // bytes of one operand image (either layout)
+constexpr int kBfLds = 2 * 2 * kBfImage;                  // two operands, two buffers
+
+__device__ __forceinline__ unsigned bf_off_kc(int row, int chunk) { return (unsigned)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); }
+__device__ __forceinline__ unsigned bf_off_kr(int krow, int chunk) { return (unsigned)(krow * 256 + ((chunk ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4)); }
+
+// MASK_A: the A operand (k-contiguous dy of the dX form) is read through relu'(act_y) (FFH_LINEAR_ONLY_DX / forked dW)
+template <bool AKC, bool BKC, bool MASK_A = false>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
+  constexpr int BM = kBfBM, BN = kBfBN, BK = kBfBK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bx, by, bz;
+  {
+    const unsigned nbx = gridDim.x, nby = gridDim.y, nbz = gridDim.z;
+    const unsigned total = nbx * nby * nbz;
+    const unsigned lin = (blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x;
+    const unsigned xcd = lin & 7u, loc = lin >> 3;
+    const unsigned q = total >> 3, rem = total & 7u;
+    const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
+    bx = (int)(nlin % nbx);
+    by = (int)((nlin / nbx) % nby);
+    bz = (int)(nlin / (nbx * nby));
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  int kb = 0, ke = g.K;
+  if (g.splitk > 1) {
+    kb = bz * g.k_per_split;
+    ke = kb + g.k_per_split < g.K ? kb + g.k_per_split : g.K;
+  }
+  if (kb >= ke) return;
+  const int nk = (ke - kb + BK - 1) / BK;
+  const float* A = g.A;
+  const float* B = g.B;
+
+  float4 ra[8], rb[8];
+  const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
+  auto load_tile = [&](int kt, auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const int k0 = kb + kt * BK;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (AKC) {
+        const int k4 = tid & 15, row = (tid >> 4) + 16 * i;
+        const int m = m0 + row, k = k0 + 4 * k4;
+        if (FAST) ra[i] = ld4u(A + (int64_t)m * g.sAm + k);
+        else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, true);
+        if (MASK_A) {
+          float4 yv;
+          if (FAST) yv = ld4u(g.act_y + (int64_t)m * g.ld_act_y + k);
+          else yv = load4_guard(g.act_y + (int64_t)m * g.ld_act_y + k, m < g.M, k, ke, true);
+          ra[i].x = yv.x > 0.0f ? ra[i].x : 0.0f; ra[i].y = yv.y > 0.0f ? ra[i].y : 0.0f;
+          ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
+        }
+      } else {
+        const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        const int m = m0 + 4 * m4, k = k0 + kr;
+        if (FAST) ra[i] = ld4u(A + (int64_t)k * g.sAk + m);
+        else ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, true);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (BKC) {
+        const int k4 = tid & 15, row = (tid >> 4) + 16 * i;
+        const int n = n0 + row, k = k0 + 4 * k4;
+        if (FAST) rb[i] = ld4u(B + (int64_t)n * g.sBn + k);
+        else rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, true);
+      } else {
+        const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        const int n = n0 + 4 * n4, k = k0 + kr;
+        if (FAST) rb[i] = ld4u(B + (int64_t)k * g.sBk + n);
+        else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, true);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* as = bf_smem + buf * 2 * kBfImage;
+    unsigned char* bs = as + kBfImage;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (AKC) {
+        const int k4 = tid & 15, row = (tid >> 4) + 16 * i;
+        *reinterpret_cast<uint2*>(as + bf_off_kc(row, k4 >> 1) + 8 * (k4 & 1)) = pack_bf16x4(ra[i]);
+      } else {
+        const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        *reinterpret_cast<uint2*>(as + bf_off_kr(kr, m4 >> 1) + 8 * (m4 & 1)) = pack_bf16x4(ra[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (BKC) {
+        const int k4 = tid & 15, row = (tid >> 4) + 16 * i;
+        *reinterpret_cast<uint2*>(bs + bf_off_kc(row, k4 >> 1) + 8 * (k4 & 1)) = pack_bf16x4(rb[i]);
+      } else {
+        const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        *reinterpret_cast<uint2*>(bs + bf_off_kr(kr, n4 >> 1) + 8 * (n4 & 1)) = pack_bf16x4(rb[i]);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int lr = lane & 31, lh = lane >> 5;
+  // transposed-read lane roles: 16-lane group tg, row tq and column quad tp of the 4 x 16 block
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+
+  // fragment of the 32-row (or 32-column) tile starting at `o` of an image, k-step s (16 k)
+  auto frag = [&](const unsigned char* img, bool kc, int o, int s) -> bf16x8_t {
+    if (kc) return *reinterpret_cast<const bf16x8_t*>(img + bf_off_kc(o + lr, 2 * s + lh));
+    typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
+    const int ch = (o >> 3) + 2 * (tg & 1) + (tp >> 1);
+    const int k0r = 16 * s + 8 * (tg >> 1) + tq;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr(k0r, ch) + 8 * (tp & 1)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr(k0r + 4, ch) + 8 * (tp & 1)));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto compute_tile = [&](int buf) {
+    const unsigned char* as = bf_smem + buf * 2 * kBfImage;
+    const unsigned char* bs = as + kBfImage;
+#pragma unroll
+    for (int s = 0; s < BK / 16; s++) {
+      bf16x8_t a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) a[i] = frag(as, AKC, wm0 + 32 * i, s);
+#pragma unroll
+      for (int j = 0; j < 2; j++) b[j] = frag(bs, BKC, wn0 + 32 * j, s);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // k-tiles fully inside the matrices take the unguarded loader (workgroup-uniform choice)
+  const int nfull = (a_in && b_in) ? (ke - kb) / BK : 0;
+  if (nfull > 0) load_tile(0, std::true_type{}); else load_tile(0, std::false_type{});
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nk; t++) {
+    const int buf = t & 1;
+    if (t + 1 < nk) { if (t + 1 < nfull) load_tile(t + 1, std::true_type{}); else load_tile(t + 1, std::false_type{}); }
+    compute_tile(buf);
+    if (t + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* C = g.C;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int n = n0 + wn0 + j * 32 + lr;
+      if (n >= g.N) continue;
+      const float bv = (g.epi == EPI_STORE && g.bias) ? g.bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.M) continue;
+        float* cp = C + (int64_t)m * g.ldc + n;
+        float v = acc[i][j][r];
+        if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) v = 0.0f;
+        if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
+        else if (g.epi == EPI_ADD) *cp = *cp + v;
+        else atomicAdd(cp, v);
+      }
+    }
+}
+
+// =============================================================================================
 // LDS-DMA GEMM for the mid-size layers of the 2048-sample step (432x512, 512x256 ...): outputs of only
 // ~1 M elements, i.e. ONE 64x64 tile per CU.  What bounds such a launch is not the matrix pipe but how the
 // operand bytes get on chip next to it, so:
@@ -914,9 +1118,10 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   else if (tiles64 >= 2 * c->num_cus || g.K < 64) cfg = 1;
   else cfg = 2;
   static const int forced = getenv("FFH_GEMM_CFG") ? atoi(getenv("FFH_GEMM_CFG")) : -1;   // A/B switch (tools/gemm_tune.py)
-  if (forced >= 0 && forced <= 2) cfg = forced;
-  const int BMv = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32);
-  const int gx = (g.N + BMv - 1) / BMv, gy = (g.M + BMv - 1) / BMv;
+  if (forced >= 0 && forced <= 5 && (forced <= 2 || cfg == 0)) cfg = forced;
+  const int BMv = cfg == 3 ? 256 : (cfg == 5 ? 128 : (cfg == 0 || cfg == 4 ? 128 : (cfg == 1 ? 64 : 32)));
+  const int BNv = cfg == 3 ? 128 : (cfg == 5 ? 256 : BMv);
+  const int gx = (g.N + BNv - 1) / BNv, gy = (g.M + BMv - 1) / BMv;
   int gz = (int)batch;
   g.splitk = 1;
   g.k_per_split = g.K;
@@ -937,9 +1142,47 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   }
   if (gy > 65535 || gz > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm: grid too large");
   dim3 grid(gx, gy, gz);
-  if (cfg == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
+  if (cfg == 3) hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
+  else if (cfg == 4) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 32, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
+  else if (cfg == 5) hipLaunchKernelGGL((gemm_f32_kernel<128, 256, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
+  else if (cfg == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
   else if (cfg == 1) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
   else hipLaunchKernelGGL((gemm_f32_kernel<32, 32, 64, AKC, BKC, true, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+  return FFH_OK;
+}
+
+inline bool use_bf16(const ffh_ctx* c, int in, int out) {
+  return c->math_mode == FFH_MATH_TENSOR_OP_BF16 && in >= FFH_BF16_MIN_DIM && out >= FFH_BF16_MIN_DIM;
+}
+
+// bf16-operand form of launch_gemm (tensor-op math mode): 128 x 128 tiles; EPI_ATOMIC splits K over workgroups
+template <bool AKC, bool BKC, bool MASK_A = false>
+int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return FFH_OK;
+  const int gx = (g.N + kBfBN - 1) / kBfBN, gy = (g.M + kBfBM - 1) / kBfBM;
+  g.splitk = 1;
+  g.k_per_split = g.K;
+  int gz = 1;
+  if (g.epi == EPI_ATOMIC) {
+    const int64_t tiles = (int64_t)gx * gy;
+    int want = (int)((2LL * c->num_cus + tiles - 1) / tiles);
+    const int max_split = (g.K + 4 * kBfBK - 1) / (4 * kBfBK);     // at least four k-tiles per workgroup
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    int kps = (g.K + want - 1) / want;
+    kps = (kps + kBfBK - 1) / kBfBK * kBfBK;
+    g.k_per_split = kps;
+    g.splitk = (g.K + kps - 1) / kps;
+    if (g.splitk <= 1) g.splitk = 2;             // keeps blockIdx.z meaning "split" (the second split is empty)
+    gz = g.splitk;
+  }
+  if (gy > 65535 || gz > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm (bf16): grid too large");
+  auto kern = gemm_bf16_kernel<AKC, BKC, MASK_A>;
+  static const bool ok = glds_set_lds(kern, kBfLds);
+  if (!ok) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16): cannot reserve 64 KB of LDS");
+  hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), kBfLds, as_stream(s), g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, name);
   return FFH_OK;
@@ -1437,6 +1680,7 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   g.C = y; g.ldc = ldy; g.bias = bias;
   g.M = (int)batch; g.N = out; g.K = in;
   g.epi = EPI_STORE; g.act = act;
+  if (use_bf16(c, in, out)) return launch_gemm_bf16<true, true>(c, g, s, "linear_fwd gemm (bf16)");
   {
     GldsArgs d{};
     d.A = x; d.lda = ldx; d.B = w; d.ldb = in; d.C = y; d.ldc = ldy; d.bias = bias;
@@ -1515,6 +1759,64 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     return FFH_OK;
   }
   if (label) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: not a one-launch layer (out_dim <= 4, in_dim <= 1024, aligned)");
+  if (use_bf16(c, in, out)) {
+    // tensor-op math mode: the activation gradient (and db) as its own fp32 pass over dy, then the two GEMMs on bf16 operands
+    const bool relu_ = act == FFH_AC_MODE_RELU;
+    auto act_pass = [&](ffh_stream st, int a) -> int {
+      if (a == FFH_AC_MODE_NONE && !db) return FFH_OK;
+      const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
+      const int cols_v = v4 ? out / 4 : out;
+      int tx = 1;
+      while (tx < cols_v && tx < 256) tx <<= 1;
+      const int ty = 256 / tx;
+      int64_t rows = (batch + 2 * c->num_cus - 1) / (2 * c->num_cus);
+      if (rows < 4 * ty) rows = 4 * ty;
+      const unsigned grid = (unsigned)((batch + rows - 1) / rows);
+      if (v4) hipLaunchKernelGGL((act_bwd_bias_kernel<4>), dim3(grid), dim3(256), 0, as_stream(st), dy, lddy, y, ldy, db, out, batch, (int)rows, a, tx);
+      else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(grid), dim3(256), 0, as_stream(st), dy, lddy, y, ldy, db, out, batch, (int)rows, a, tx);
+      FFH_LAUNCH_CHECK(c, "act_bwd_bias_kernel");
+      return FFH_OK;
+    };
+    if (separate && do_dx) { const int rc = act_pass(s, act); if (rc) return rc; }       // sigmoid: in place, with db, before any fork
+    const bool forked_ = do_dw && do_dx && s_dw != nullptr && s_dw != s;
+    ffh_stream sw_ = forked_ ? s_dw : s;
+    if (forked_) {
+      c->second_stream_used = 1;
+      if (!c->ev_fork) FFH_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      FFH_HIP_TRY(c, hipEventRecord(c->ev_fork, as_stream(s)));
+      FFH_HIP_TRY(c, hipStreamWaitEvent(as_stream(sw_), c->ev_fork, 0));
+    }
+    if (do_dw) {
+      if (!separate) { const int rc = act_pass(sw_, act); if (rc) return rc; }          // relu: mask written back in place (idempotent); db
+      GemmArgs gw{};
+      gw.A = dy; gw.sAm = 1; gw.sAk = lddy;
+      gw.B = x; gw.sBn = 1; gw.sBk = ldx;
+      gw.C = dw; gw.ldc = in;
+      gw.M = out; gw.N = in; gw.K = (int)batch;
+      gw.epi = EPI_ATOMIC; gw.act = FFH_AC_MODE_NONE;
+      const int rc = launch_gemm_bf16<false, false>(c, gw, sw_, "linear_bwd dw gemm (bf16)");
+      if (rc) return rc;
+    }
+    if (dx && do_dx) {
+      GemmArgs gx{};
+      gx.A = dy; gx.sAm = lddy; gx.sAk = 1;
+      gx.B = w; gx.sBn = 1; gx.sBk = in;
+      gx.C = dx; gx.ldc = lddx;
+      gx.M = (int)batch; gx.N = in; gx.K = out;
+      gx.epi = (flags & FFH_LINEAR_DX_OVERWRITE) ? EPI_STORE : EPI_ADD;
+      gx.act = FFH_AC_MODE_NONE;
+      if (mask_by_x) { gx.mask = x; gx.ldmask = ldx; }
+      int rc;
+      if ((forked_ || !do_dw) && relu_) {          // dy is (being) masked by someone else: read it through relu'(y)
+        gx.act_y = y; gx.ld_act_y = ldy;
+        rc = launch_gemm_bf16<true, false, true>(c, gx, s, "linear_bwd dx gemm (bf16, masking)");
+      } else {
+        rc = launch_gemm_bf16<true, false>(c, gx, s, "linear_bwd dx gemm (bf16)");
+      }
+      if (rc) return rc;
+    }
+    return FFH_OK;
+  }
   if (separate && do_dx) {
     const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
     const int cols_v = v4 ? out / 4 : out;

@@ -60,6 +60,12 @@ int ffh_ctx_set_workspace(ffh_ctx* c, void* ws, size_t bytes) {
   return FFH_OK;
 }
 
+int ffh_ctx_set_math_mode(ffh_ctx* c, int mode) {
+  if (!c || (mode != FFH_MATH_DEFAULT && mode != FFH_MATH_TENSOR_OP_BF16)) return FFH_ERR_BAD_ARG;
+  c->math_mode = mode;
+  return FFH_OK;
+}
+
 int ffh_malloc(ffh_ctx* c, void** p, size_t bytes) {
   if (!c || !p) return FFH_ERR_BAD_ARG;
   *p = nullptr;

@@ -131,6 +131,7 @@ FFConfig::FFConfig() {
   attach_events = true;
   fuse_pair = true;
   dx_scatter = true;
+  allow_tensor_op_math_conversion = false;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
   comm.world_size = 1;
@@ -161,8 +162,10 @@ void FFConfig::parse_args(char** argv, int argc) {
         is("--alpha") || is("--search-alpha") || is("--simulator-workspace-size") || is("--strategy") ||
         is("--machine-model-version") || is("--machine-model-file") || is("--simulator-segment-size") ||
         is("--simulator-max-num-segments") || is("--taskgraph")) { next(); continue; }
+    // cublasSetMathMode(CUBLAS_TENSOR_OP_MATH) on every handle [ref: src/runtime/model.cc:2282-2403, src/runtime/model.cu:81-83]
+    if (is("--allow-tensor-op-math-conversion")) { allow_tensor_op_math_conversion = true; continue; }
     if (is("-dm:memoize") || is("-dm:memorize") || is("--overlap") || is("--enable-parameter-parallel") ||
-        is("--enable-attribute-parallel") || is("--allow-tensor-op-math-conversion") || is("--enable-propagation")) continue;
+        is("--enable-attribute-parallel") || is("--enable-propagation")) continue;
     // this build
     if (is("--seed")) { seed = strtoull(next(), nullptr, 10); continue; }
     if (is("--backend")) { backend_lib = next(); continue; }
@@ -411,6 +414,7 @@ FFModel::FFModel(FFConfig& _config)
   api = load_kernel_api(config.backend_lib);
   int rc = api->ffh_ctx_create(&ctx, config.device);
   if (rc != FFH_OK || !ctx) die("ffh_ctx_create(device %d) failed with %d on %s -- no usable GPU?", config.device, rc, api->path.c_str());
+  if (config.allow_tensor_op_math_conversion) check(api->ffh_ctx_set_math_mode(ctx, FFH_MATH_TENSOR_OP_BF16), "tensor-op math mode");
   check(api->ffh_stream_create(ctx, &stream), "stream create");
   check(api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
@@ -420,6 +424,10 @@ FFModel::FFModel(FFConfig& _config)
     // asynchronous devices only: on the CPU oracle a "launch" is the computation itself
     dw_worker = new LaunchWorker(api, config.device);
     side_worker = new LaunchWorker(api, config.device);
+    if (config.allow_tensor_op_math_conversion) {
+      check(api->ffh_ctx_set_math_mode(dw_worker->ctx(), FFH_MATH_TENSOR_OP_BF16), "tensor-op math mode");
+      check(api->ffh_ctx_set_math_mode(side_worker->ctx(), FFH_MATH_TENSOR_OP_BF16), "tensor-op math mode");
+    }
   }
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_fork), "event create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_join), "event create");

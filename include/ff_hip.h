@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 3   /* 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 4   /* 4: ffh_ctx_set_math_mode; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -123,6 +123,21 @@ const char* ffh_last_error_string(const ffh_ctx* ctx);
 int         ffh_device_query(ffh_ctx* ctx, ffh_device_info* info);
 /* attach caller-owned scratch; replaces FFHandler.workSpace/workSpaceSize */
 int         ffh_ctx_set_workspace(ffh_ctx* ctx, void* ws, size_t bytes);
+/* Math mode of the handle: cublasSetMathMode(handle.blas, CUBLAS_TENSOR_OP_MATH) behind --allow-tensor-op-math-conversion
+ * [ref: src/runtime/model.cu:81-83; flag src/runtime/model.cc:2282-2403; call sites src/ops/linear.cu:436-453,624-659].
+ *   FFH_MATH_DEFAULT          every GEMM in exact fp32 (v_mfma_f32_32x32x2_f32): the reference's default arithmetic
+ *   FFH_MATH_TENSOR_OP_BF16   Linear GEMMs with in_dim >= FFH_BF16_MIN_DIM and out_dim >= FFH_BF16_MIN_DIM (forward, dX and
+ *                             dW alike) round both operands to bfloat16 (nearest-even) as they are staged and multiply them
+ *                             on v_mfma_f32_32x32x16_bf16: products are exact in fp32, accumulation is fp32, outputs, bias,
+ *                             activations, master weights and the dW / db accumulators stay fp32.  Narrower layers, the
+ *                             pair / skinny entry points, BatchMatmul and the dot interaction keep the fp32 kernels.
+ * Tolerance of the bf16 mode against the fp32 result: |err| <= 2^-8 * sum_k |a_k b_k| per element (two roundings of 2^-9
+ * relative each); against a twin that rounds the same operands (the oracle in the same mode) the fp32 summation-order
+ * bound of the fp32 mode applies.  Returns FFH_ERR_BAD_ARG for an unknown mode. */
+#define FFH_MATH_DEFAULT 0
+#define FFH_MATH_TENSOR_OP_BF16 1
+#define FFH_BF16_MIN_DIM 128
+int         ffh_ctx_set_math_mode(ffh_ctx* ctx, int mode);
 
 /* memory / streams / events / graphs: what Legion+Realm provide to the
  * reference ops (regions, get_legion_stream [ref: src/runtime/cuda_helper.cu:5-31],
@@ -448,7 +463,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
  * FFModel shim and by tests/test_abi_symbols.py). */
 #define FFH_API_LIST(X) \
   X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) \
-  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) \
+  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) \
   X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
   X(ffh_stream_create) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
   X(ffh_event_create) X(ffh_event_create_sync) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \

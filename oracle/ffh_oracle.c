@@ -47,6 +47,7 @@ struct ffh_ctx {
   char   err[256];
   const ffh_col_dest* scatter_map;   /* ffh_linear_bwd_set_dx_scatter: pending for the next ffh_linear_bwd_ex */
   int    scatter_ncols, scatter_used;
+  int    math_mode;                  /* ffh_ctx_set_math_mode */
 };
 
 static int fail(ffh_ctx* c, int code, const char* msg) {
@@ -82,6 +83,25 @@ int ffh_ctx_set_workspace(ffh_ctx* c, void* ws, size_t bytes) {
   if (!c) return FFH_ERR_BAD_ARG;
   c->ws = ws; c->ws_bytes = bytes;
   return FFH_OK;
+}
+/* cublasSetMathMode(CUBLAS_TENSOR_OP_MATH) [ref: src/runtime/model.cu:81-83]: see include/ff_hip.h for what it selects */
+int ffh_ctx_set_math_mode(ffh_ctx* c, int mode) {
+  if (!c || (mode != FFH_MATH_DEFAULT && mode != FFH_MATH_TENSOR_OP_BF16)) return FFH_ERR_BAD_ARG;
+  c->math_mode = mode;
+  return FFH_OK;
+}
+/* float -> bfloat16 (round to nearest even, NaN kept) -> float: what v_cvt_pk_bf16_f32 leaves in the MFMA operand */
+static inline float bf16_round(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;          /* NaN stays a (quiet) NaN */
+  else u += 0x7fffu + ((u >> 16) & 1u);
+  u &= 0xffff0000u;
+  memcpy(&v, &u, 4);
+  return v;
+}
+static inline int use_bf16(const ffh_ctx* c, int in, int out) {
+  return c && c->math_mode == FFH_MATH_TENSOR_OP_BF16 && in >= FFH_BF16_MIN_DIM && out >= FFH_BF16_MIN_DIM;
 }
 int ffh_malloc(ffh_ctx* c, void** p, size_t bytes) {
   if (!c || !p) return FFH_ERR_BAD_ARG;
@@ -348,14 +368,15 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
     return fail(c, FFH_ERR_UNSUPPORTED, "linear_fwd: activation");
   float* wt = (float*)malloc(sizeof(float) * (size_t)in * (size_t)out);   /* [in][out] */
   if (!wt) return fail(c, FFH_ERR_NOMEM, "oom");
-  for (int o = 0; o < out; o++) for (int i = 0; i < in; i++) wt[(size_t)i * out + o] = w[(size_t)o * in + i];
+  const int bf = use_bf16(c, in, out);      /* tensor-op mode: both operands rounded to bfloat16, fp32 products and sums */
+  for (int o = 0; o < out; o++) for (int i = 0; i < in; i++) wt[(size_t)i * out + o] = bf ? bf16_round(w[(size_t)o * in + i]) : w[(size_t)o * in + i];
 #pragma omp parallel for schedule(static)
   for (int64_t b = 0; b < B; b++) {
     float* yr = y + b * ldy;
     const float* xr = x + b * ldx;
     for (int o = 0; o < out; o++) yr[o] = 0.0f;
     for (int i = 0; i < in; i++) {
-      const float xi = xr[i];
+      const float xi = bf ? bf16_round(xr[i]) : xr[i];
       const float* wr = wt + (size_t)i * out;
       for (int o = 0; o < out; o++) yr[o] = fmaf(xi, wr[o], yr[o]);
     }
@@ -395,6 +416,7 @@ static int linear_bwd_parts(ffh_ctx* c, const float* x, int64_t ldx, float* dx, 
         dy[b * lddy + o] = act_grad(dy[b * lddy + o], y[b * ldy + o], act);
   }
   const int m = mask_on_load ? act : FFH_AC_MODE_NONE;
+  const int bf = use_bf16(c, in, out);      /* tensor-op mode: GEMM operands rounded to bfloat16 (db stays an fp32 sum of fp32 values) */
   if (do_dw) {
 #pragma omp parallel
     {
@@ -403,9 +425,10 @@ static int linear_bwd_parts(ffh_ctx* c, const float* x, int64_t ldx, float* dx, 
       for (int o = 0; o < out; o++) {
         for (int i = 0; i < in; i++) tmp[i] = 0.0f;
         for (int64_t b = 0; b < B; b++) {
-          const float d = act_grad(dy[b * lddy + o], y[b * ldy + o], m);
+          float d = act_grad(dy[b * lddy + o], y[b * ldy + o], m);
           const float* xr = x + b * ldx;
-          for (int i = 0; i < in; i++) tmp[i] = fmaf(d, xr[i], tmp[i]);
+          if (bf) { d = bf16_round(d); for (int i = 0; i < in; i++) tmp[i] = fmaf(d, bf16_round(xr[i]), tmp[i]); }
+          else for (int i = 0; i < in; i++) tmp[i] = fmaf(d, xr[i], tmp[i]);
         }
         for (int i = 0; i < in; i++) dw[(size_t)o * in + i] += tmp[i];
       }
@@ -427,9 +450,10 @@ static int linear_bwd_parts(ffh_ctx* c, const float* x, int64_t ldx, float* dx, 
       for (int64_t b = 0; b < B; b++) {
         for (int i = 0; i < in; i++) tmp[i] = 0.0f;
         for (int o = 0; o < out; o++) {
-          const float d = act_grad(dy[b * lddy + o], y[b * ldy + o], m);
+          float d = act_grad(dy[b * lddy + o], y[b * ldy + o], m);
           const float* wr = w + (size_t)o * in;
-          for (int i = 0; i < in; i++) tmp[i] = fmaf(d, wr[i], tmp[i]);
+          if (bf) { d = bf16_round(d); for (int i = 0; i < in; i++) tmp[i] = fmaf(d, bf16_round(wr[i]), tmp[i]); }
+          else for (int i = 0; i < in; i++) tmp[i] = fmaf(d, wr[i], tmp[i]);
         }
         /* DX_MASK_BY_X: reluBackward of the layer below, applied to what this layer hands down */
         for (int i = 0; i < in; i++) dx[b * lddx + i] += (mask_by_x && !(x[b * ldx + i] > 0.0f)) ? 0.0f : tmp[i];

@@ -1,0 +1,255 @@
+"""Tensor-op math mode (--allow-tensor-op-math-conversion -> ffh_ctx_set_math_mode(FFH_MATH_TENSOR_OP_BF16))
+[ref: cublasSetMathMode(CUBLAS_TENSOR_OP_MATH), src/runtime/model.cu:81-83; call sites src/ops/linear.cu:436-453,624-659].
+
+Numerics contract (include/ff_hip.h): Linear GEMMs with in_dim, out_dim >= 128 round BOTH operands to bfloat16
+(nearest even), multiply exactly, accumulate in fp32; everything else is unchanged fp32.
+  * CPU: the oracle in that mode against a numpy restatement of the rounding (independent code), and against the
+    fp32 result inside the stated bound 2^-8 * sum |a_k b_k|;
+  * GPU (-m gpu): the HIP kernels (v_mfma_f32_32x32x16_bf16) against the oracle IN THE SAME MODE at the fp32-mode
+    tolerance (1e-5 of the term mass: only the fp32 summation order differs), forward / dX / dW, every flag form,
+    ragged shapes; and the whole DLRM step with the driver flag, HIP vs the oracle backend.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from dlrm_flexflow_amd import capi
+
+MATH_BF16 = 1
+
+
+def bf16_round(a):
+    """float32 -> bfloat16 (round to nearest even) -> float32, on the bits"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def act_fwd(v, act):
+    if act == capi.AC_MODE_RELU:
+        return np.maximum(v, 0)
+    if act == capi.AC_MODE_SIGMOID:
+        return 1 / (1 + np.exp(-v))
+    return v
+
+
+def emulated(x, w, b, gy, act):
+    """float64 sums over bf16-rounded operands (products of two bf16 numbers are exact in fp32 and in float64)"""
+    xb, wb = bf16_round(x).astype(np.float64), bf16_round(w).astype(np.float64)
+    y = act_fwd(xb @ wb.T + b, act)
+    yf = y.astype(np.float32)
+    d = gy.astype(np.float64)
+    if act == capi.AC_MODE_RELU:
+        d = np.where(yf > 0, d, 0)
+    elif act == capi.AC_MODE_SIGMOID:
+        d = (gy * yf * (1 - yf)).astype(np.float64)
+    df = d.astype(np.float32)
+    db = df.astype(np.float64).sum(0)
+    dB = bf16_round(df).astype(np.float64)
+    return y, dB.T @ xb, db, dB @ wb, df
+
+
+@pytest.fixture()
+def oracle_bf16(oracle):
+    lib = oracle.lib()
+    assert lib.lib.ffh_ctx_set_math_mode(lib.ctx, MATH_BF16) == 0
+    yield oracle
+    assert lib.lib.ffh_ctx_set_math_mode(lib.ctx, 0) == 0
+
+
+def test_math_mode_rejects_unknown_values(oracle):
+    lib = oracle.lib()
+    assert lib.lib.ffh_ctx_set_math_mode(lib.ctx, 7) == -1
+    assert lib.lib.ffh_ctx_set_math_mode(lib.ctx, 0) == 0
+
+
+@pytest.mark.parametrize("B,IN,OUT,act", [(96, 256, 128, capi.AC_MODE_RELU), (33, 130, 200, capi.AC_MODE_NONE), (64, 128, 128, capi.AC_MODE_SIGMOID)])
+def test_oracle_bf16_mode_matches_numpy_emulation(oracle_bf16, B, IN, OUT, act):
+    rng = np.random.default_rng(B + IN)
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    y = oracle_bf16.linear_fwd(x, w, b, act)
+    y_e, dw_e, db_e, dx_e, dy_e = emulated(x, w, b, gy, act)
+    np.testing.assert_allclose(y, y_e, rtol=2e-6, atol=2e-6)
+    dx, dw, db, dy_after = oracle_bf16.linear_bwd(x, y, gy, w, act)
+    np.testing.assert_allclose(dy_after, dy_e, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(dw, dw_e, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(db, db_e, rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(dx, dx_e, rtol=1e-5, atol=2e-5)
+
+
+def test_oracle_bf16_mode_is_within_the_stated_bound_of_fp32_and_differs(oracle):
+    rng = np.random.default_rng(1)
+    B, IN, OUT = 64, 512, 256
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    y32 = oracle.linear_fwd(x, w, None)
+    lib = oracle.lib()
+    lib.lib.ffh_ctx_set_math_mode(lib.ctx, MATH_BF16)
+    try:
+        y16 = oracle.linear_fwd(x, w, None)
+    finally:
+        lib.lib.ffh_ctx_set_math_mode(lib.ctx, 0)
+    mass = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T
+    err = np.abs(y16.astype(np.float64) - y32)
+    assert np.all(err <= 2.0 ** -8 * mass + 1e-6)
+    assert err.max() > 1e-5                      # the mode really rounds
+
+
+def test_narrow_layers_stay_fp32_in_bf16_mode(oracle, oracle_bf16):
+    """in_dim or out_dim below FFH_BF16_MIN_DIM (128): bit-identical to the fp32 mode (the pair / skinny layers of DLRM)."""
+    rng = np.random.default_rng(2)
+    for IN, OUT in ((127, 256), (256, 64), (13, 512)):
+        x = rng.uniform(-1, 1, (40, IN)).astype(np.float32)
+        w = rng.uniform(-1, 1, (OUT, IN)).astype(np.float32)
+        y16 = oracle_bf16.linear_fwd(x, w, None)
+        lib = oracle.lib()
+        lib.lib.ffh_ctx_set_math_mode(lib.ctx, 0)
+        y32 = oracle.linear_fwd(x, w, None)
+        lib.lib.ffh_ctx_set_math_mode(lib.ctx, MATH_BF16)
+        assert y16.tobytes() == y32.tobytes()
+
+
+def test_driver_flag_reaches_the_kernels_cpu(oracle):
+    """--allow-tensor-op-math-conversion through FFConfig -> ffh_ctx_set_math_mode: the whole step changes (bf16 GEMMs
+    in the 256-wide layers) but stays within bf16 distance of the fp32 run."""
+    from dlrm_flexflow_amd import ffmodel
+    args = ["--backend", oracle.ORACLE_LIB, "-b", "64", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "100-200-50",
+            "--arch-mlp-bot", "13-256-128-16", "--arch-mlp-top", "64-256-128-1", "--data-size", "64"]
+    preds = {}
+    for flag in (False, True):
+        app = ffmodel.DLRM(args + (["--allow-tensor-op-math-conversion"] if flag else []))
+        app.warmup()
+        app.train_steps(2, trace=False)
+        app.model.sync()
+        preds[flag] = app.model.layer_output(app.model.num_layers - 1).get()
+        app.close()
+    d = np.abs(preds[True] - preds[False]).max()
+    assert 1e-7 < d < 2e-2, d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------------------------------
+def _gpu_helpers():
+    import test_gpu_parity as T
+    return T
+
+
+@pytest.fixture()
+def hip_bf16(hip, oracle_bf16):
+    assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, MATH_BF16) == 0
+    yield hip
+    assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, 0) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,IN,OUT,act", [
+    (2048, 512, 256, capi.AC_MODE_RELU), (2048, 432, 512, capi.AC_MODE_RELU), (4096, 1024, 1024, capi.AC_MODE_RELU),
+    (1024, 3456, 1024, capi.AC_MODE_RELU), (512, 479, 1024, capi.AC_MODE_RELU), (512, 857, 1024, capi.AC_MODE_NONE),
+    (333, 130, 200, capi.AC_MODE_SIGMOID), (65, 128, 128, capi.AC_MODE_NONE), (1000, 257, 129, capi.AC_MODE_RELU),
+    (8192, 256, 128, capi.AC_MODE_RELU), (100, 2000, 1000, capi.AC_MODE_NONE)])
+def test_linear_bf16_mode_hip_vs_oracle_same_mode(hip_bf16, oracle_bf16, B, IN, OUT, act):
+    T = _gpu_helpers()
+    rng = np.random.default_rng(IN * OUT + 1)
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    y = T.gpu_linear_fwd(hip_bf16, x, w, b, act)
+    y_exp = oracle_bf16.linear_fwd(x, w, b, act)
+    mass = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+    T.assert_gemm_close(y, y_exp, mass, "y (bf16 mode)")
+    dx, dw, db, dy_after = T.gpu_linear_bwd(hip_bf16, x, y_exp, gy, w, act)
+    dx_e, dw_e, db_e, dy_e = oracle_bf16.linear_bwd(x, y_exp, gy, w, act)
+    np.testing.assert_allclose(dy_after, dy_e, rtol=1e-6, atol=1e-7)
+    a = np.abs(dy_e).astype(np.float64)
+    T.assert_gemm_close(dw, dw_e, a.T @ np.abs(x).astype(np.float64), "dw (bf16 mode)")
+    T.assert_gemm_close(db, db_e, a.sum(0), "db (bf16 mode)")
+    T.assert_gemm_close(dx, dx_e, a @ np.abs(w).astype(np.float64), "dx (bf16 mode)")
+    # and the mode is really on: the fp32 oracle is further away than the summation-order tolerance somewhere
+    lib = oracle_bf16.lib()
+    lib.lib.ffh_ctx_set_math_mode(lib.ctx, 0)
+    y32 = oracle_bf16.linear_fwd(x, w, b, act)
+    lib.lib.ffh_ctx_set_math_mode(lib.ctx, MATH_BF16)
+    err32 = np.abs(y.astype(np.float64) - y32)
+    assert np.all(err32 <= 2.0 ** -8 * mass + 1e-5)
+    if act != capi.AC_MODE_SIGMOID:
+        assert err32.max() > 1e-5 * mass.max() / 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", [capi.AC_MODE_RELU, capi.AC_MODE_SIGMOID, capi.AC_MODE_NONE])
+def test_linear_bf16_mode_bwd_ex_forms(hip_bf16, oracle_bf16, act):
+    """overwrite / accumulate dX, mask-by-x, premasked dy, ONLY_DX + ONLY_DW split, forked dW stream, strided operands."""
+    import torch
+    T = _gpu_helpers()
+    rng = np.random.default_rng(7 + act)
+    B, IN, OUT = 700, 384, 256
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    y = oracle_bf16.linear_fwd(x, w, None, act)
+    dx0 = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    a = np.abs(gy).astype(np.float64)
+    mdx, mdw = a @ np.abs(w).astype(np.float64), a.T @ np.abs(x).astype(np.float64)
+    s2 = torch.cuda.Stream()
+    for flags in (0, capi.LINEAR_DX_OVERWRITE, capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DX_MASK_BY_X, capi.LINEAR_DY_PREMASKED):
+        for forked in (False, True):
+            dx = T.dev(dx0); dw = torch.zeros(OUT, IN, device=T.DEV); db = torch.zeros(OUT, device=T.DEV); dy = T.dev(gy)
+            hip_bf16.call("ffh_linear_bwd_ex", T.dev(x), IN, dx, IN, T.dev(y), OUT, dy, OUT, T.dev(w), dw, db, IN, OUT, B, act, flags,
+                          None, s2.cuda_stream if forked else None)
+            torch.cuda.synchronize()
+            dx_e, dw_e, db_e, dy_e = oracle_bf16.linear_bwd_ex(x, y, gy, w, act, flags, dx0=dx0)
+            T.assert_gemm_close(T.host(dx), dx_e, mdx + np.abs(dx0), f"dx flags={flags} forked={forked}")
+            T.assert_gemm_close(T.host(dw), dw_e, mdw, f"dw flags={flags}")
+            T.assert_gemm_close(T.host(db), db_e, a.sum(0), f"db flags={flags}")
+            np.testing.assert_allclose(T.host(dy), dy_e, rtol=1e-6, atol=1e-7)
+    # the split pair on two streams equals the one call
+    dx = torch.zeros(B, IN, device=T.DEV); dw = torch.zeros(OUT, IN, device=T.DEV); db = torch.zeros(OUT, device=T.DEV); dy = T.dev(gy)
+    hip_bf16.call("ffh_linear_bwd_ex", T.dev(x), IN, dx, IN, T.dev(y), OUT, dy, OUT, T.dev(w), dw, db, IN, OUT, B, act, capi.LINEAR_ONLY_DX, None, None)
+    torch.cuda.synchronize()
+    hip_bf16.call("ffh_linear_bwd_ex", T.dev(x), IN, dx, IN, T.dev(y), OUT, dy, OUT, T.dev(w), dw, db, IN, OUT, B, act, capi.LINEAR_ONLY_DW, None, None)
+    torch.cuda.synchronize()
+    dx_e, dw_e, db_e, _ = oracle_bf16.linear_bwd_ex(x, y, gy, w, act, 0)
+    T.assert_gemm_close(T.host(dx), dx_e, mdx, "dx split")
+    T.assert_gemm_close(T.host(dw), dw_e, mdw, "dw split")
+    T.assert_gemm_close(T.host(db), db_e, a.sum(0), "db split")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("trace", [False, True])
+def test_dlrm_step_bf16_mode_hip_vs_oracle_backend(hip, oracle, trace):
+    """The driver flag end to end at the Kaggle widths (432->512, 512->256 layers take bf16 operands): 1 warm-up + 3 steps
+    on the GPU vs the same host code on the oracle, both in tensor-op mode; and the fp32 run differs."""
+    import dlrm_helpers as H
+    from dlrm_flexflow_amd import ffmodel
+    args = H.KAGGLE_ARGS(2048) + ["--allow-tensor-op-math-conversion"]
+    out = {}
+    for name, backend in (("hip", capi.HIP_LIB_PATH), ("cpu", oracle.ORACLE_LIB)):
+        app = ffmodel.DLRM(["--backend", backend] + args)
+        app.warmup()
+        app.train_steps(3, trace=trace and name == "hip")
+        app.model.sync()
+        m = app.model
+        out[name] = {f"{m.layer_name(l)}/{i}": m.parameter(l, i).get_weights() for l in range(m.num_layers) for i in range(m.layer_num_weights(l))}
+        out[name]["pred"] = m.layer_output(m.num_layers - 1).get()
+        app.close()
+    # Chained layers: an fp32 summation-order difference of one ulp in an activation can land on the other side of a bf16
+    # rounding boundary of the NEXT layer's operand (a 2^-9 relative step in that one operand).  So: at least 99 % of the
+    # elements inside the fp32-mode tolerance, every element inside a bf16-step-sized one.
+    for k in out["hip"]:
+        g, e = out["hip"][k].astype(np.float64), out["cpu"][k].astype(np.float64)
+        tight = np.abs(g - e) <= 2e-5 * np.abs(e) + 2e-6
+        assert tight.mean() >= 0.99, (k, float(tight.mean()))
+        np.testing.assert_allclose(g, e, rtol=2e-3, atol=2e-4, err_msg=k)
+    app = ffmodel.DLRM(["--backend", capi.HIP_LIB_PATH] + H.KAGGLE_ARGS(2048))
+    app.warmup(); app.train_steps(3, trace=False); app.model.sync()
+    p32 = app.model.layer_output(app.model.num_layers - 1).get()
+    app.close()
+    d = np.abs(p32 - out["hip"]["pred"]).max()
+    assert 1e-7 < d < 2e-2, d
