@@ -234,6 +234,30 @@ def hbm_block(kernel, nbytes, sec, traffic=None, src=None, note=None):
     return d
 
 
+def bf16_mode_block(ffmodel, w, local_rank, B):
+    """The same workload with --allow-tensor-op-math-conversion (bf16 operands on v_mfma_f32_32x32x16_bf16 for the wide Linear
+    layers, fp32 accumulate / master weights / everything else): reported beside the fp32 headline, never as it."""
+    app = ffmodel.DLRM(flags_of(w, ["--device", str(local_rank), "--allow-tensor-op-math-conversion", "--no-trace"]))
+    app.warmup()
+    app.train_steps(3, trace=False)
+    app.model.sync()
+    n = 20 if B > 4096 else 100
+    t0 = time.perf_counter()
+    app.train_steps(n, trace=False)
+    app.model.sync()
+    dt = (time.perf_counter() - t0) / n
+    t_f = app.time_kernel(6, 20) * 1e-3
+    t_b = app.time_kernel(7, 20) * 1e-3
+    app.close()
+    flops = mlp_flops_per_sample(w) * B
+    blk = largest_linear(w, B, t_f, t_b, True)
+    return {"flag": "--allow-tensor-op-math-conversion (ffh_ctx_set_math_mode(FFH_MATH_TENSOR_OP_BF16))",
+            "dtype": "bf16 GEMM operands rounded from fp32 in the kernel, fp32 accumulate, fp32 master weights and activations in HBM",
+            "samples_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mlp_tflops_over_whole_step": round(flops / dt / 1e12, 1),
+            "linear_largest_layer": blk,
+            "note": "operands stay fp32 in memory, so the kernel is bound by the global->LDS staging path (32 flop per staged byte), not by the bf16 matrix pipe"}
+
+
 def kaggle_secondary(ffmodel, local_rank):
     """BASELINE configs[1] (Criteo-Kaggle shape, B = 2048) in the same process: the launch-latency regime of the path."""
     w = workload("kaggle", 2048)
@@ -442,6 +466,11 @@ def main():
         out["kernels"]["whole_step_device"] = {"us": round(t_step_dev * 1e6, 2), "mlp_gflop_per_step": round(flops / 1e9, 3),
                                                "mlp_tflops_over_whole_step": round(flops / t_step_dev / 1e12, 2), "mfma_peak_tflops": peak,
                                                "frac_of_mfma_peak": round(flops / t_step_dev / 1e12 / peak, 3)}
+        if not args.no_secondary and not bf16:
+            try:
+                out["kernels"]["tensor_op_bf16_mode"] = bf16_mode_block(ffmodel, w, local_rank, B)
+            except Exception as e:  # noqa: BLE001
+                out["kernels"]["tensor_op_bf16_mode"] = {"error": repr(e)}
         if not args.no_secondary and args.workload != "kaggle":
             try:
                 out["kernels"]["kaggle_secondary"] = kaggle_secondary(ffmodel, local_rank)

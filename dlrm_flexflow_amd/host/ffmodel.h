@@ -496,6 +496,7 @@ class FFModel {
   void join_embedding_forward() const;
   void issue_embedding_update_on_side_stream() const;
   void order_input_writes_behind_update() const;
+  void profiled(const Op* op, bool fwd, const std::function<void()>& fn) const;   // --profiling: one op between two events
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
   int grad_attach_layer;        // the Linear whose backward completes the embedding output gradients (-1: none / not attachable)

@@ -391,8 +391,18 @@ void Op::print_layer(const FFModel&) const {
 // =============================================================================================
 // FFModel: construction, graph building
 // =============================================================================================
+// --profiling [ref: src/runtime/model.cc:2358-2362]: every op is bracketed by two events and waited for, as the reference's
+// tasks do (src/ops/linear.cu:525-546) -- so nothing may overlap or fuse across ops while it is on
+static FFConfig& profiling_schedule(FFConfig& c) {
+  if (c.profiling) {
+    c.overlap_embedding = false; c.enable_graph = false; c.parallel_dw = false; c.async_launch = false;
+    c.fuse_pair = false; c.attach_events = false; c.dx_scatter = false; c.timing_events = true;
+  }
+  return c;
+}
+
 FFModel::FFModel(FFConfig& _config)
-    : op_global_guid(100), config(_config), optimizer(nullptr), loss_type(LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE),
+    : op_global_guid(100), config(profiling_schedule(_config)), optimizer(nullptr), loss_type(LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE),
       metrics_flags(0), seq_length(-1), api(nullptr), ctx(nullptr), stream(nullptr), side_stream(nullptr),
       ev_fork(nullptr), ev_join(nullptr), ev_grad_ready(nullptr), ev_update_done(nullptr), compiled(false),
       emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
@@ -1677,8 +1687,40 @@ void FFModel::forward(int _seq_length) {
     // start the gather right now unless a host-side collective would stall THIS thread's launches
     if (!exchange || config.comm.nonblocking || use_workers()) issue_embedding_forward_on_side_stream();
   }
-  for (Op* op : layers) op->forward(*this);
+  for (Op* op : layers) {
+    if (!config.profiling) { op->forward(*this); continue; }
+    if (op->op_type == OP_EMBEDDING && emb_forward_issued) continue;      // the first table launched the whole group
+    profiled(op, true, [&] { op->forward(*this); });
+  }
   if (emb_forward_issued && !emb_forward_joined) join_embedding_forward();
+}
+
+// One op between two events on `stream`, waited for and printed in the reference's formats
+// [ref: src/ops/linear.cu:525-546,761; src/ops/concat.cu:282-297,400-412; src/ops/batch_matmul.cu:303-318,476-494].
+void FFModel::profiled(const Op* op, bool fwd, const std::function<void()>& fn) const {
+  ffh_event e0, e1;
+  check(api->ffh_event_create(ctx, &e0), "event");
+  check(api->ffh_event_create(ctx, &e1), "event");
+  check(api->ffh_event_record(ctx, e0, stream), "event");
+  fn();
+  check(api->ffh_event_record(ctx, e1, stream), "event");
+  check(api->ffh_event_sync(ctx, e1), "event");
+  float ms = 0.0f;
+  check(api->ffh_event_elapsed_ms(ctx, e0, e1, &ms), "event");
+  api->ffh_event_destroy(ctx, e0);
+  api->ffh_event_destroy(ctx, e1);
+  const char* dir = fwd ? "forward" : "backward";
+  switch (op->op_type) {
+    case OP_LINEAR:
+      if (fwd) printf("%s [Linear] forward time = %.2lfms\n", op->name, (double)ms);
+      else printf("Linear backward time = %.2lfms\n", (double)ms);
+      break;
+    case OP_BATCHMATMUL: printf("BatchMatmul %s time = %.2lfms\n", dir, (double)ms); break;
+    case OP_EMBEDDING:   // the reference dumps tensors here (src/ops/embedding.cu:266-271); one launch serves every table
+      printf("[Embedding x%zu] %s time = %.4f ms\n", embeddings.size(), dir, ms);
+      break;
+    default: printf("[%s] %s time = %.4f ms\n", op->name, dir, ms); break;   // Concat's format (its backward also says "forward" in the reference, :412)
+  }
 }
 
 void FFModel::issue_embedding_forward_on_side_stream() const {
@@ -1766,7 +1808,7 @@ void FFModel::backward(int _seq_length) {
   int first = (int)layers.size() - 1;
   emb_update_pending = false;
   mlp_grads_clean = false;
-  Linear* last = config.fuse_loss ? dynamic_cast<Linear*>(layers.back()) : nullptr;
+  Linear* last = (config.fuse_loss && !config.profiling) ? dynamic_cast<Linear*>(layers.back()) : nullptr;   // --profiling: the loss kernel and every layer on their own
   int rc = FFH_ERR_UNSUPPORTED;
   if (last) {
     const Tensor& x = last->inputs[0];
@@ -1798,6 +1840,15 @@ void FFModel::backward(int _seq_length) {
         up->dx_map_concat->bwd_done = true;                    // its pack kernel is not needed this step
         if (attach) grad_ready_attached = true;
       }
+      continue;
+    }
+    if (config.profiling) {
+      if (layers[l]->op_type == OP_EMBEDDING && static_cast<Embedding*>(layers[l])->table_index != (int)embeddings.size() - 1) continue;
+      profiled(layers[l], false, [&] {
+        layers[l]->backward(*this);
+        // the fused sparse update of the tables is the embedding group's backward here (it runs in update() otherwise)
+        if (layers[l]->op_type == OP_EMBEDDING && fused_embedding_update()) embedding_group_update(stream);
+      });
       continue;
     }
     if (up && up->pair_lower && !use_workers() && l != grad_attach_layer && l >= 1 && layers[l - 1] == up->pair_lower) {
@@ -1861,7 +1912,7 @@ void FFModel::update() {
       // every host read of a table syncs both streams -- so `stream` joins it only where a capture must close the fork
       if (!embeddings.empty() && (capturing_trace >= 0 || use_workers()))
         check(api->ffh_stream_wait_event(ctx, stream, ev_update_done), "join update");
-    } else {
+    } else if (!config.profiling) {     // (--profiling: timed as the embedding group's backward)
       embedding_group_update(stream);
     }
   } else {

@@ -542,3 +542,22 @@ def test_zipf_index_stream():
     assert np.ptp(hot) > R // 8                                                                 # not the first rows of the table
     u = ids([])                                                                                 # the reference's uniform draw
     assert np.bincount(u[0].reshape(-1), minlength=R).max() < 12
+
+
+def test_profiling_flag_prints_per_op_times(oracle):
+    """--profiling [ref: src/runtime/model.cc:2358-2362]: every op bracketed by two events and printed in the reference's
+    formats [ref: src/ops/linear.cu:541,761; src/ops/concat.cu:297]; the result of the step is unchanged."""
+    exe = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
+    args = ["--backend", oracle.ORACLE_LIB, "-b", "64", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "100-200-50",
+            "--arch-mlp-bot", "13-16-8", "--arch-mlp-top", "32-16-1", "--data-size", "64", "--epochs", "1"]
+    r = subprocess.run([exe] + args + ["--profiling"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert out.count("[Linear] forward time = ") == 2 * 4          # warm-up + 1 iteration, four Dense layers
+    assert out.count("Linear backward time = ") == 2 * 4
+    assert "Dense_100 [Linear] forward time = " in out and "[Concat_105] forward time = " in out
+    assert out.count("[Embedding x3] forward time = ") == 2 and out.count("[Embedding x3] backward time = ") == 2
+    plain = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    assert "forward time" not in plain.stdout
+    mse = lambda txt: [l for l in txt.splitlines() if "mean_squared_error" in l][-1]
+    assert mse(r.stderr) == mse(plain.stderr)
