@@ -294,6 +294,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Kaggle-shape block under `kernels` (profile runs: keeps the rocprof averages single-shape)")
     ap.add_argument("--no-trace", action="store_true")
+    ap.add_argument("--force-graph", action="store_true", help="time the hipGraph-replayed step even where eager launches are faster (diagnosis)")
     ap.add_argument("--force-exchange", action="store_true", help="1 GPU: still run the all-to-all / all-reduce path (1-rank RCCL group)")
     ap.add_argument("--torch-collectives", action="store_true", help="serve the all-to-all / all-reduce through torch.distributed callbacks "
                                                                      "instead of calling RCCL from the C++ host layer")
@@ -385,7 +386,7 @@ def main():
         n_probe = 30 if w["B"] <= 4096 else 5
         step_us["graph"] = min(app.time_kernel(2, n_probe), app.time_kernel(2, n_probe)) * 1e3
         step_us["eager"] = min(app.time_kernel(4, n_probe), app.time_kernel(4, n_probe)) * 1e3
-        trace = step_us["graph"] <= step_us["eager"]
+        trace = step_us["graph"] <= step_us["eager"] or args.force_graph
     app.train_steps(args.warmup, trace=trace)      # W untimed steps
     app.model.reset_metrics()
     app.model.sync()

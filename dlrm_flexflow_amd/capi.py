@@ -68,6 +68,7 @@ _SIGS = {
     "ffh_device_query": (I, [P, C.POINTER(DeviceInfo)]),
     "ffh_ctx_set_workspace": (I, [P, P, SZ]),
     "ffh_ctx_set_math_mode": (I, [P, I]),
+    "ffh_ctx_set_deterministic": (I, [P, I]),
     "ffh_malloc": (I, [P, C.POINTER(P), SZ]),
     "ffh_free": (I, [P, P]),
     "ffh_memcpy_h2d": (I, [P, P, P, SZ, P]),

@@ -21,6 +21,7 @@ struct ffh_ctx {
   int         scatter_ncols, scatter_used;
   void*       scatter_event;        // hipEvent_t attached to the launch that takes the map (else dropped)
   void*       attach_event;         // ffh_event_record_with_next_linear_bwd(): hipEvent_t to signal behind the next backward's last kernel
+  int         deterministic;   // ffh_ctx_set_deterministic(): no fp atomics in weight / bias gradients
   int         math_mode; // ffh_ctx_set_math_mode(): FFH_MATH_DEFAULT | FFH_MATH_TENSOR_OP_BF16
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
   char        err[512];

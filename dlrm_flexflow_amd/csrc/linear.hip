@@ -860,6 +860,7 @@ template <bool AKR, bool BKR>
 bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p, double min_work = 1.5e8, int min_k = 128) {
   static const int off = getenv("FFH_GEMM_NO_GLDS") ? atoi(getenv("FFH_GEMM_NO_GLDS")) : 0;   // A/B switch (tools/ab.sh)
   if (off || !c->zeros) return false;
+  if (c->deterministic && atomic_splitk) return false;
   if (!glds_aligned(g.A, g.lda) || !glds_aligned(g.B, g.ldb)) return false;
   // whole 16-byte chunks only: the contiguous extent of each operand must be a multiple of 4 floats
   if ((AKR ? g.M : g.K) % 4 || (BKR ? g.N : g.K) % 4) return false;
@@ -925,7 +926,7 @@ int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const
 // dX and dW of one layer in ONE launch (gemm_glds_bwd_kernel); 1 = done, 0 = not applicable
 int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
   static const int off = getenv("FFH_GLDS_NO_DUAL") ? atoi(getenv("FFH_GLDS_NO_DUAL")) : 0;   // A/B switch (tools/ab.sh)
-  if (off) return 0;
+  if (off || c->deterministic) return 0;
   GldsPlan px, pw;
   // (the 256x64 layer was tried as a pair too: no gain, so the work threshold of the single GEMMs stands; k >= 64 suffices)
   if (!plan_glds<false, true>(c, dxg, false, px, 1.5e8, 64) || !plan_glds<true, true>(c, dwg, true, pw, 1.5e8, 64)) return 0;
@@ -1125,6 +1126,7 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   int gz = (int)batch;
   g.splitk = 1;
   g.k_per_split = g.K;
+  if (g.epi == EPI_ATOMIC && c->deterministic) g.epi = EPI_ADD;      // one workgroup per output tile adds its whole-K sum: no atomics
   if (g.epi == EPI_ATOMIC) {
     // split K over workgroups so that about two of them per CU are in flight; each split is a multiple of kSplitGran
     const int64_t tiles = (int64_t)gx * gy;
@@ -1165,6 +1167,7 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
   g.splitk = 1;
   g.k_per_split = g.K;
   int gz = 1;
+  if (g.epi == EPI_ATOMIC && c->deterministic) g.epi = EPI_ADD;
   if (g.epi == EPI_ATOMIC) {
     const int64_t tiles = (int64_t)gx * gy;
     int want = (int)((2LL * c->num_cus + tiles - 1) / tiles);
@@ -1719,7 +1722,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
   // up to 4 outputs with in <= 1024, or up to 16 outputs with in <= 256 (the 64 -> 16 layer in front of the interaction):
   // whole backward in one launch
   const bool skinny_shape = (out <= kSkinnyMaxOut && in <= kSkinnyMaxIn) || (out <= 16 && in <= 256);
-  if (skinny_shape && skinny_vec) {
+  if (skinny_shape && skinny_vec && !c->deterministic) {
     // one launch for the whole layer (the split ONLY_* forms keep their meaning; a forked dw stream is not needed)
     const bool only_dx = !do_dw, only_dw = !do_dx;
     SkinnyBwdArgs a{};
@@ -1771,6 +1774,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       const int ty = 256 / tx;
       int64_t rows = (batch + 2 * c->num_cus - 1) / (2 * c->num_cus);
       if (rows < 4 * ty) rows = 4 * ty;
+      if (c->deterministic) rows = batch;        // one workgroup: the column sums meet in a fixed order
       const unsigned grid = (unsigned)((batch + rows - 1) / rows);
       if (v4) hipLaunchKernelGGL((act_bwd_bias_kernel<4>), dim3(grid), dim3(256), 0, as_stream(st), dy, lddy, y, ldy, db, out, batch, (int)rows, a, tx);
       else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(grid), dim3(256), 0, as_stream(st), dy, lddy, y, ldy, db, out, batch, (int)rows, a, tx);
@@ -1825,6 +1829,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     const int ty = 256 / tx;
     int64_t rows = (batch + 2 * c->num_cus - 1) / (2 * c->num_cus);
     if (rows < 4 * ty) rows = 4 * ty;
+    if (c->deterministic) rows = batch;          // one workgroup: the column sums meet in a fixed order
     const unsigned grid = (unsigned)((batch + rows - 1) / rows);
     if (v4) hipLaunchKernelGGL((act_bwd_bias_kernel<4>), dim3(grid), dim3(256), 0, as_stream(s), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
     else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(grid), dim3(256), 0, as_stream(s), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
@@ -1981,6 +1986,7 @@ int ffh_linear_pair_bwd(ffh_ctx* c, const float* x_u, int64_t ldx_u, const float
   if (!act_ok(act_u)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_bwd: activation not supported (NONE, RELU, SIGMOID)");
   if ((flags_u & ~FFH_LINEAR_DY_PREMASKED) || (flags_l & ~(FFH_LINEAR_DX_OVERWRITE | FFH_LINEAR_DX_MASK_BY_X)))
     return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_bwd: flags");
+  if (c->deterministic) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_bwd: its dW / db partials meet by atomics (deterministic mode)");
   if (out_u > 16 || (in_u != 32 && in_u != 64) || in_l % 32 != 0 || (act_l != FFH_AC_MODE_RELU && act_l != FFH_AC_MODE_NONE) || batch >= (1LL << 31))
     return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_pair_bwd: shapes (out_u <= 16, in_u 32 or 64, in_l a multiple of 32; lower activation relu / none)");
   if (batch == 0) return FFH_OK;

@@ -66,6 +66,12 @@ int ffh_ctx_set_math_mode(ffh_ctx* c, int mode) {
   return FFH_OK;
 }
 
+int ffh_ctx_set_deterministic(ffh_ctx* c, int on) {
+  if (!c) return FFH_ERR_BAD_ARG;
+  c->deterministic = on ? 1 : 0;
+  return FFH_OK;
+}
+
 int ffh_malloc(ffh_ctx* c, void** p, size_t bytes) {
   if (!c || !p) return FFH_ERR_BAD_ARG;
   *p = nullptr;

@@ -132,6 +132,7 @@ FFConfig::FFConfig() {
   fuse_pair = true;
   dx_scatter = true;
   allow_tensor_op_math_conversion = false;
+  deterministic = false;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
   comm.world_size = 1;
@@ -168,6 +169,7 @@ void FFConfig::parse_args(char** argv, int argc) {
         is("--enable-attribute-parallel") || is("--enable-propagation")) continue;
     // this build
     if (is("--seed")) { seed = strtoull(next(), nullptr, 10); continue; }
+    if (is("--deterministic")) { deterministic = true; continue; }
     if (is("--backend")) { backend_lib = next(); continue; }
     if (is("--device")) { device = atoi(next()); continue; }
     if (is("--no-trace")) { enable_graph = false; continue; }
@@ -425,6 +427,7 @@ FFModel::FFModel(FFConfig& _config)
   int rc = api->ffh_ctx_create(&ctx, config.device);
   if (rc != FFH_OK || !ctx) die("ffh_ctx_create(device %d) failed with %d on %s -- no usable GPU?", config.device, rc, api->path.c_str());
   if (config.allow_tensor_op_math_conversion) check(api->ffh_ctx_set_math_mode(ctx, FFH_MATH_TENSOR_OP_BF16), "tensor-op math mode");
+  if (config.deterministic) { check(api->ffh_ctx_set_deterministic(ctx, 1), "deterministic mode"); config.async_launch = false; }
   check(api->ffh_stream_create(ctx, &stream), "stream create");
   check(api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");

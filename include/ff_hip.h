@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 4   /* 4: ffh_ctx_set_math_mode; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 4   /* 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -138,6 +138,13 @@ int         ffh_ctx_set_workspace(ffh_ctx* ctx, void* ws, size_t bytes);
 #define FFH_MATH_TENSOR_OP_BF16 1
 #define FFH_BF16_MIN_DIM 128
 int         ffh_ctx_set_math_mode(ffh_ctx* ctx, int mode);
+/* on != 0: every weight / bias gradient is produced WITHOUT floating-point atomics -- no split-K over workgroups (one
+ * workgroup owns an output element and adds its k-ordered sum once), no per-workgroup partials meeting in one address;
+ * the one-launch skinny / pair / dX+dW forms that rely on such atomics report FFH_ERR_UNSUPPORTED or are bypassed.  Results
+ * are then bit-identical from run to run (the default mode differs in the last bits: fp32 atomic order), at a fraction of
+ * the speed: a debugging mode for diffing two runs, the GPU counterpart of comparing against the sequential oracle.
+ * (The embedding kernels are deterministic in both modes: their order is part of the ABI, FFH_EMB_CHUNK.) */
+int         ffh_ctx_set_deterministic(ffh_ctx* ctx, int on);
 
 /* memory / streams / events / graphs: what Legion+Realm provide to the
  * reference ops (regions, get_legion_stream [ref: src/runtime/cuda_helper.cu:5-31],
@@ -463,7 +470,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
  * FFModel shim and by tests/test_abi_symbols.py). */
 #define FFH_API_LIST(X) \
   X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) \
-  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) \
+  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) \
   X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
   X(ffh_stream_create) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
   X(ffh_event_create) X(ffh_event_create_sync) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \

@@ -246,3 +246,20 @@ def test_profiling_flag_on_gpu(hip):
     plain = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600)
     mse = lambda txt: float([l for l in txt.splitlines() if "mean_squared_error" in l][-1].split("mean_squared_error:")[1].split()[0])
     assert abs(mse(r.stderr) - mse(plain.stderr)) <= 1e-5
+
+
+def test_deterministic_mode_is_bit_reproducible(hip):
+    """--deterministic (ffh_ctx_set_deterministic): no floating-point atomics in any weight / bias gradient, so two runs of
+    the Kaggle-shape model give bit-identical parameters after 3 steps -- and stay within 1e-5 of the default (atomic) mode."""
+    args = H.KAGGLE_ARGS(2048)
+    runs = []
+    for flags in (["--deterministic"], ["--deterministic"], []):
+        app = ffmodel.DLRM(["--backend", HIP] + args + flags)
+        app.warmup()
+        app.train_steps(3, trace=False)
+        app.model.sync()
+        runs.append(_tables_and_mlp(app))
+        app.close()
+    for k in runs[0]:
+        assert runs[0][k].tobytes() == runs[1][k].tobytes(), k
+        np.testing.assert_allclose(runs[0][k], runs[2][k], rtol=2e-5, atol=2e-6, err_msg=k)
