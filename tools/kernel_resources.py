@@ -1,12 +1,13 @@
 """Prints VGPR / SGPR / scratch / LDS / occupancy of every kernel (hipcc -Rpass-analysis)."""
 import os, re, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "dlrm_flexflow_amd", "csrc")
 for f in sorted(os.listdir(CSRC)):
     if not f.endswith(".hip"):
         continue
     r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-                        "-I", os.path.join(HERE, "..", "include"), "-c", os.path.join(CSRC, f), "-o", "/dev/null",
+                        "-I", os.path.join(ROOT, "include"), "-c", os.path.join(CSRC, f), "-o", "/dev/null",
                         "-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
     cur = {}
     for line in r.stderr.splitlines():
