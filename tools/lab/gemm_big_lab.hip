@@ -285,6 +285,135 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma(const float* __restri
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Candidate "plr": register-staged (global_load_dwordx4 -> ds_write_b128, no transpose: the LDS image is k-contiguous and
+// XOR-swizzled), THREE LDS buffers so that the fragments of the next k-tile's first k-octet can be read BEFORE the barrier
+// that ends the current k-tile: the MFMA stream of a wave never waits for an LDS round trip, and the barrier only has to
+// absorb wave skew.  One barrier per k-tile.  Forward form (both operands k-contiguous), interior tiles only (lab).
+template <int BK, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_plr(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                const float* __restrict__ bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int relu) {
+  constexpr int BM = 2 * WM * 32, BN = 2 * WN * 32;
+  constexpr int CPR = BK / 4, RPB = 16 / CPR;
+  constexpr int A_CH = BM * CPR, B_CH = BN * CPR, STAGE_CH = A_CH + B_CH;
+  constexpr int NA = A_CH / 256, NB = B_CH / 256;        // float4 per thread per operand per k-tile
+  constexpr int KG = BK / 8;
+  extern __shared__ float4 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  int bx, by;
+  tile_of_block(bx, by, N / BN, M / BM);
+  const int m0 = by * BM, n0 = bx * BN;
+  const int wm0 = (wave >> 1) * WM * 32, wn0 = (wave & 1) * WN * 32;
+  // staging roles
+  const int sc = tid % CPR, sr = tid / CPR;              // chunk, row (+ i * 256 / CPR)
+  constexpr int RPP = 256 / CPR;
+  const float* ga[NA];
+  const float* gb[NB];
+  int wa[NA], wb[NB];
+#pragma unroll
+  for (int i = 0; i < NA; i++) { const int r = sr + i * RPP; ga[i] = A + (int64_t)(m0 + r) * lda + 4 * sc; wa[i] = r * CPR + (sc ^ ((r / RPB) & (CPR - 1))); }
+#pragma unroll
+  for (int i = 0; i < NB; i++) { const int r = sr + i * RPP; gb[i] = B + (int64_t)(n0 + r) * ldb + 4 * sc; wb[i] = A_CH + r * CPR + (sc ^ ((r / RPB) & (CPR - 1))); }
+  float4 ra[NA], rb[NB];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < NA; i++) ra[i] = ld4(ga[i] + kt * BK);
+#pragma unroll
+    for (int i = 0; i < NB; i++) rb[i] = ld4(gb[i] + kt * BK);
+  };
+  auto lwrite = [&](int buf) {
+    float4* d = lds + buf * STAGE_CH;
+#pragma unroll
+    for (int i = 0; i < NA; i++) d[wa[i]] = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; i++) d[wb[i]] = rb[i];
+  };
+  // fragment addresses (chunk index inside a stage) for k-octet j: row * CPR + ((2j + lh) ^ sw(row))
+  int fa[WM], fb[WN], sa[WM], sb[WN];
+#pragma unroll
+  for (int i = 0; i < WM; i++) { const int r = wm0 + i * 32 + lr; fa[i] = r * CPR; sa[i] = (r / RPB) & (CPR - 1); }
+#pragma unroll
+  for (int i = 0; i < WN; i++) { const int r = wn0 + i * 32 + lr; fb[i] = A_CH + r * CPR; sb[i] = (r / RPB) & (CPR - 1); }
+  auto rd = [&](int buf, int j, float4 (&a)[WM], float4 (&b)[WN]) {
+    const float4* s4 = lds + buf * STAGE_CH;
+#pragma unroll
+    for (int i = 0; i < WM; i++) a[i] = s4[fa[i] + ((2 * j + lh) ^ sa[i])];
+#pragma unroll
+    for (int i = 0; i < WN; i++) b[i] = s4[fb[i] + ((2 * j + lh) ^ sb[i])];
+  };
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; i++)
+#pragma unroll
+    for (int j = 0; j < WN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+  auto mfmas = [&](const float4 (&a)[WM], const float4 (&b)[WN]) {
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+#pragma unroll
+      for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int jn = 0; jn < WN; jn++) {
+          const float av = e == 0 ? a[i].x : e == 1 ? a[i].y : e == 2 ? a[i].z : a[i].w;
+          const float bv = e == 0 ? b[jn].x : e == 1 ? b[jn].y : e == 2 ? b[jn].z : b[jn].w;
+          acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][jn], 0, 0, 0);
+        }
+  };
+  const int nk = K / BK;
+  unsigned long long c0 = 0, r0 = 0;
+  if (blockIdx.x == 0 && tid == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+  // prologue: tiles 0 and 1 in LDS, tile 2 in registers (tile indices beyond the last are clamped: the extra loads are
+  // harmless and keep the loop body free of branches)
+  const int last = nk - 1;
+  gload(0); lwrite(0);
+  gload(1 < last ? 1 : last); lwrite(1);
+  gload(2 < last ? 2 : last);
+  __syncthreads();
+  float4 a0[WM], b0[WN], a1[WM], b1[WN];
+  rd(0, 0, a0, b0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);                               // lgkmcnt(0): the loop is entered with nothing pending
+  int b_cur = 0, b_nxt = 1, b_wr = 2;
+  for (int t = 0; t < nk; t++) {
+#pragma unroll
+    for (int j = 0; j < KG; j += 2) {
+      // even octet j: operands in (a0, b0); fetch octet j + 1 into (a1, b1)
+      if (j + 1 < KG) rd(b_cur, j + 1, a1, b1); else rd(b_nxt, 0, a1, b1);
+      if (j == 0) lwrite(b_wr);                                     // tile t + 2: registers -> LDS (loaded one iteration ago)
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j == 0) gload(t + 3 < last ? t + 3 : last);               // tile t + 3 -> registers
+      if (j + 1 < KG) {
+        if (j + 2 < KG) rd(b_cur, j + 2, a0, b0); else rd(b_nxt, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the LDS writes of this iteration (older than the last WM + WN fragment reads) must have landed; those reads may fly on
+    __builtin_amdgcn_s_waitcnt(0xC07F | ((WM + WN) << 8) & 0x0F00);
+    __builtin_amdgcn_s_barrier();
+    const int tmp = b_cur; b_cur = b_nxt; b_nxt = b_wr; b_wr = tmp;
+  }
+  if (blockIdx.x == 0 && tid == 0) { g_clk[0] = __builtin_amdgcn_s_memtime() - c0; g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
+#pragma unroll
+  for (int i = 0; i < WM; i++)
+#pragma unroll
+    for (int j = 0; j < WN; j++) {
+      const int n = n0 + wn0 + j * 32 + lr;
+      const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float v = acc[i][j][r] + bv;
+        if (relu) v = v > 0.0f ? v : 0.0f;
+        C[(int64_t)m * ldc + n] = v;
+      }
+    }
+}
+
 // pure MFMA loops on random register operands: what the matrix pipe delivers at the clock the chip holds
 template <int SHAPE>
 __global__ __launch_bounds__(256) void mfma_only(const float* __restrict__ src, float* __restrict__ dst, int iters) {
@@ -401,9 +530,9 @@ int main(int argc, char** argv) {
   }
   {
     float* dst; CK(hipMalloc(&dst, 2048 * 256 * 4));
-    for (int cfg = 0; cfg < 6; cfg++) {
+    for (int cfg = 0; cfg < 10; cfg++) {
       const int shape = cfg & 1 ? 16 : 32;
-      const int nblk = cfg < 2 ? 2048 : (cfg < 4 ? 512 : 256);
+      const int nblk = cfg < 2 ? 2048 : (cfg < 4 ? 512 : (cfg < 6 ? 256 : (cfg < 8 ? 768 : 1024)));
       const int it = 4000 * (2048 / nblk);
       auto f = [&] { if (shape == 32) hipLaunchKernelGGL(mfma_only<32>, dim3(nblk), dim3(256), 0, 0, A, dst, it); else hipLaunchKernelGGL(mfma_only<16>, dim3(nblk), dim3(256), 0, 0, A, dst, it); };
       const float us = time_it(f, 3);
@@ -420,7 +549,37 @@ int main(int argc, char** argv) {
     const float us = time_it(f, iters);
     printf("rocblas_sgemm (no bias/relu)  %8.1f us  %6.1f TF/s\n", us, 2.0 * M * N * K / us / 1e6);
   }
+#define RUNP(BK, WM, WN)                                                                                                                   \
+  {                                                                                                                                        \
+    constexpr int BM = 2 * WM * 32, BN = 2 * WN * 32;                                                                                      \
+    constexpr int ldsb = 3 * (BM + BN) * BK * 4;                                                                                           \
+    auto kern = gemm_plr<BK, WM, WN>;                                                                                                      \
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));                                          \
+    if (M % BM == 0 && N % BN == 0 && K % BK == 0) {                                                                                       \
+      const unsigned grid = (unsigned)((M / BM) * (N / BN));                                                                               \
+      auto f = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, 0, A, B, C, bias, M, N, K, (int64_t)K, (int64_t)K, (int64_t)N, 1); }; \
+      check("plr BK" #BK " w" #WM "x" #WN, time_it(f, iters));                                                                             \
+    }                                                                                                                                      \
+  }
+  RUNP(16, 2, 2)
+#define RUNPL(BK, WM, WN, LDSB)                                                                                                            \
+  {                                                                                                                                        \
+    constexpr int BM = 2 * WM * 32, BN = 2 * WN * 32;                                                                                      \
+    auto kern = gemm_plr<BK, WM, WN>;                                                                                                      \
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB));                                          \
+    const unsigned grid = (unsigned)((M / BM) * (N / BN));                                                                                 \
+    auto f = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDSB, 0, A, B, C, bias, M, N, K, (int64_t)K, (int64_t)K, (int64_t)N, 1); }; \
+    check("plr BK" #BK " w" #WM "x" #WN " lds" #LDSB, time_it(f, iters));                                                                  \
+  }
+  RUNPL(16, 2, 2, 72 * 1024)
+  RUNPL(16, 2, 2, 120 * 1024)
+  RUNP(32, 2, 2)
+  RUNP(16, 4, 2)
+  RUNP(16, 2, 4)
+  RUNP(32, 4, 2)
   RUND(2, 2, 2, 2, 32, 2)
+  RUND(4, 4, 2, 2, 16, 2)
+  if (0) {
   RUND(2, 2, 2, 2, 32, 3)
   RUND(2, 2, 2, 2, 16, 3)
   RUND(2, 2, 2, 2, 16, 2)
@@ -430,7 +589,7 @@ int main(int argc, char** argv) {
   RUND(2, 2, 2, 4, 32, 2)
   RUND(2, 2, 4, 2, 32, 2)
   RUND(4, 4, 2, 2, 16, 2)
-  RUN(2, 4, 16, 3)
+  }
   if (0) {
   RUN(2, 2, 16, 2)
   RUN(2, 2, 16, 3)
