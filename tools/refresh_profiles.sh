@@ -1,19 +1,54 @@
 #!/bin/bash
-# Regenerates the judged artefacts under profiles/ on one GPU box (outputs land in gpurun_out/refresh, copied by hand).
-R=$(pwd); O=$R/gpurun_out/refresh; mkdir -p $O
+# Regenerates the judged artefacts under profiles/ on one GPU box.  Outputs land in gpurun_out/refresh/ with their final
+# names (r02_*); copy them into profiles/ afterwards.   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh'
+R=$(pwd); O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $R
-python3 bench.py --probe 2> $O/bench_probe.err | grep '^{' > $O/r01_bench_kaggle.json
-python3 bench.py 2> $O/bench_default.err | grep '^{' > $O/r01_bench_kaggle_default.json
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline 2> $O/prof.err | grep '^{' > $O/r01_bench_kaggle_under_rocprof.json
-S=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp $S $O/r01_bench_kaggle_kernel_stats.csv
+P=r02
+line() { grep '^{' | tail -1; }
+
+# 1. the default command, unprofiled: headline + roofline + kernels (bf16 mode, Kaggle secondary) + cpu_baseline
+python3 bench.py 2> $O/bench_default.err | line > $O/${P}_bench_terabyte.json
+
+# 2. the same command under the kernel trace (program directly after --; single-shape: no secondary blocks)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --no-cpu-baseline --no-secondary 2> $O/prof.err | line > $O/${P}_bench_terabyte_under_rocprof.json
+S=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp $S $O/${P}_bench_terabyte_kernel_stats.csv
 T=$(find $O/prof -name "*kernel_trace.csv" | head -1)
-python3 tools/trace_summary.py $T > $O/r01_bench_kaggle_step_timeline.txt
-for k in emb_fwd_kernel emb_sgd_small_kernel "gemm_glds_kernel<false, false, 64" gemm_glds_bwd_kernel; do python3 tools/kernel_avg.py $T "$k"; done > $O/r01_bench_kaggle_probe_averages.txt
+python3 tools/trace_summary.py $T > $O/${P}_bench_terabyte_step_timeline.txt
+for k in emb_fwd_kernel emb_sgd_reduce_kernel radix_scatter_kernel "gemm_f32_kernel<128, 128, 16, true, true" "gemm_f32_kernel<128, 128, 16, true, false, false, false" "gemm_f32_kernel<128, 128, 16, false, false, false, true"; do
+  python3 tools/kernel_avg.py $T "$k"
+done > $O/${P}_bench_terabyte_probe_averages.txt
 find $O/prof -name "*.csv" -size +10M -delete
-python3 bench.py --no-cpu-baseline --shim-flags "--zipf-alpha 1.05" 2>/dev/null | grep '^{' > $O/r01_bench_kaggle_zipf.json
-python3 bench.py --force-exchange --no-cpu-baseline 2>/dev/null | grep '^{' > $O/r01_bench_kaggle_exchange_1rank.json
-for wl in terabyte mlperf giant; do python3 bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/r01_bench_$wl.json; done
-python3 bench.py --workload giant-row --force-exchange --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/r01_bench_giant_row.json
-python3 bench.py --workload giant --force-exchange --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | grep '^{' > $O/r01_bench_giant_col.json
-for f in $O/*.json; do echo "$(basename $f): $(python3 -c "import json,sys; d=json.load(open('$f')); print(d['value'], d['ms_per_step'])")"; done
-cat $O/r01_bench_kaggle_step_timeline.txt $O/r01_bench_kaggle_probe_averages.txt
+
+# 3. HBM traffic of the embedding kernels (two counter-only passes) and SQ counters of the step's kernels
+bash tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1; cp gpurun_out/pmc_traffic/pmc_traffic.json $O/${P}_pmc_traffic.json
+bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.json $O/${P}_pmc_sq_counters.json
+
+# 4. the other workloads (one GPU)
+python3 bench.py --no-cpu-baseline --no-secondary --shim-flags=--allow-tensor-op-math-conversion 2>/dev/null | line > $O/${P}_bench_terabyte_bf16_mode.json
+python3 bench.py --workload kaggle --steps 300 --warmup 30 2>/dev/null | line > $O/${P}_bench_kaggle.json
+python3 bench.py --workload tiny --steps 500 --warmup 50 2>/dev/null | line > $O/${P}_bench_tiny.json
+python3 bench.py --workload mlperf --steps 50 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | line > $O/${P}_bench_mlperf.json
+python3 bench.py --workload giant --steps 100 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | line > $O/${P}_bench_giant.json
+python3 bench.py --force-exchange --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | line > $O/${P}_bench_terabyte_exchange_1rank.json
+python3 bench.py --workload kaggle --force-exchange --steps 300 --warmup 30 --no-cpu-baseline --no-secondary 2>/dev/null | line > $O/${P}_bench_kaggle_exchange_1rank.json
+python3 bench.py --per-gpu-batch 4096 --steps 100 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | line > $O/${P}_bench_terabyte_b4096.json
+
+# 5. hipGraph replay against eager launches, one step each
+for mode in graph eager; do
+  F="--force-graph"; [ $mode = eager ] && F="--no-trace"
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_$mode -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary $F 2>/dev/null | line > $O/tb_$mode.json
+  T=$(find $O/prof_$mode -name "*kernel_trace.csv" | head -1); python3 tools/trace_summary.py $T -3 > $O/${P}_terabyte_${mode}_step_timeline.txt
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/profk_$mode -- python3 bench.py --workload kaggle --steps 20 --warmup 5 --no-cpu-baseline --no-secondary $F 2>/dev/null | line > $O/kg_$mode.json
+  T=$(find $O/profk_$mode -name "*kernel_trace.csv" | head -1); python3 tools/trace_summary.py $T > $O/${P}_kaggle_${mode}_step_timeline.txt
+  find $O/prof_$mode $O/profk_$mode -name "*.csv" -size +10M -delete
+done
+
+# 6. GEMM microbenchmarks: fp32 kernels next to hipBLASLt (torch.mm) in one process; fp32 vs tensor-op (bf16) mode; the lab
+python3 tools/gemm_big.py -1 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_vs_hipblaslt.txt
+python3 tools/gemm_bf16_bench.py 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_bf16_mode.txt
+[ -x tools/lab/gemm_big_lab ] && timeout 300 tools/lab/gemm_big_lab 32768 1024 3456 > $O/${P}_lab_gemm_big.txt 2>&1
+python3 tools/microbench.py emb > $O/${P}_microbench_embedding.txt 2>&1
+
+for f in $O/${P}_bench_*.json; do echo "$(basename $f): $(python3 -c "import json,sys; d=json.load(open('$f')); print(d['value'], d['ms_per_step'], d.get('roofline',{}).get('frac'))" 2>&1 | tail -1)"; done
+cat $O/${P}_bench_terabyte_probe_averages.txt
+ls -la $O | head -60
