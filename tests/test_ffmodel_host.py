@@ -134,7 +134,10 @@ def test_driver_rejects_what_the_reference_rejects():
     assert r.returncode != 0 and "'cat', 'dot', 'dot-tril' or 'dot-tril-ops'" in r.stderr
     r = subprocess.run(base + ["--dataset", "x.h5"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "HDF5" in r.stderr
-    r = subprocess.run(base + ["-ll:gpu", "4"], capture_output=True, text=True, timeout=60)
+    # -ll:gpu 4 through the library API without a communicator: the model refuses (the `dlrm` binary and run_dlrm.py start
+    # their own ranks instead, tests/test_launchers.py)
+    code = ("import sys; sys.path.insert(0, %r); from dlrm_flexflow_amd import ffmodel; ffmodel.DLRM(sys.argv[1:])" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code] + base[1:] + ["-ll:gpu", "4"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "one process per GPU" in r.stderr
     r = subprocess.run([exe, "--backend", "/nonexistent/libffhip.so", "-b", "8"], capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "cannot load kernel library" in r.stderr     # no silent fallback
