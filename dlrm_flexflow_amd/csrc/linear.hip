@@ -861,6 +861,13 @@ bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p, double 
   static const int off = getenv("FFH_GEMM_NO_GLDS") ? atoi(getenv("FFH_GEMM_NO_GLDS")) : 0;   // A/B switch (tools/ab.sh)
   if (off || !c->zeros) return false;
   if (c->deterministic && atomic_splitk) return false;
+  // weight-gradient GEMMs of the big-batch steps: above ~1e9 MACs the register-staged 128 x 128 split-K kernel wins (whole
+  // Terabyte-shape step, interleaved A/B on one box: 1.27 vs 1.36 ms at 4096 samples, 2.48 vs 2.59 at 8192, 4.62 vs 4.78 at
+  // 16384) -- except at 32768 samples, where this kernel's 16-wave workgroups share the chip better with the dX GEMM running
+  // beside them on the other stream (9.11 vs 9.24-9.31 ms), so there it stays
+  static const double dw_max = getenv("FFH_GLDS_DW_MAX") ? atof(getenv("FFH_GLDS_DW_MAX")) : 1.0e9;   // A/B switches
+  static const int dw_kmax = getenv("FFH_GLDS_DW_KMAX") ? atoi(getenv("FFH_GLDS_DW_KMAX")) : 16384;
+  if (atomic_splitk && (double)g.M * g.N * g.K >= dw_max && g.K <= dw_kmax) return false;
   if (!glds_aligned(g.A, g.lda) || !glds_aligned(g.B, g.ldb)) return false;
   // whole 16-byte chunks only: the contiguous extent of each operand must be a multiple of 4 floats
   if ((AKR ? g.M : g.K) % 4 || (BKR ? g.N : g.K) % 4) return false;
