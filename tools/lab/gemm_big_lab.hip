@@ -290,7 +290,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_dma(const float* __restri
 // XOR-swizzled), THREE LDS buffers so that the fragments of the next k-tile's first k-octet can be read BEFORE the barrier
 // that ends the current k-tile: the MFMA stream of a wave never waits for an LDS round trip, and the barrier only has to
 // absorb wave skew.  One barrier per k-tile.  Forward form (both operands k-contiguous), interior tiles only (lab).
-template <int BK, int WM, int WN>
+template <int BK, int WM, int WN, int ABL = 0>   // ABL 1: every k-tile re-reads tile 0 (operands stay in L1 / L2); 2: no global loads in the loop
 __global__ __launch_bounds__(256) void gemm_plr(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                 const float* __restrict__ bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int relu) {
   constexpr int BM = 2 * WM * 32, BN = 2 * WN * 32;
@@ -316,7 +316,9 @@ __global__ __launch_bounds__(256) void gemm_plr(const float* __restrict__ A, con
 #pragma unroll
   for (int i = 0; i < NB; i++) { const int r = sr + i * RPP; gb[i] = B + (int64_t)(n0 + r) * ldb + 4 * sc; wb[i] = A_CH + r * CPR + (sc ^ ((r / RPB) & (CPR - 1))); }
   float4 ra[NA], rb[NB];
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt0) {
+    const int kt = ABL == 1 ? (kt0 & 1) : kt0;
+    if (ABL == 2 && kt0 > 2) return;
 #pragma unroll
     for (int i = 0; i < NA; i++) ra[i] = ld4(ga[i] + kt * BK);
 #pragma unroll
@@ -571,6 +573,19 @@ int main(int argc, char** argv) {
     auto f = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDSB, 0, A, B, C, bias, M, N, K, (int64_t)K, (int64_t)K, (int64_t)N, 1); }; \
     check("plr BK" #BK " w" #WM "x" #WN " lds" #LDSB, time_it(f, iters));                                                                  \
   }
+#define RUNPA(BK, WM, WN, ABL)                                                                                                             \
+  {                                                                                                                                        \
+    constexpr int BM = 2 * WM * 32, BN = 2 * WN * 32;                                                                                      \
+    constexpr int ldsb = 3 * (BM + BN) * BK * 4;                                                                                           \
+    auto kern = gemm_plr<BK, WM, WN, ABL>;                                                                                                 \
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));                                          \
+    const unsigned grid = (unsigned)((M / BM) * (N / BN));                                                                                 \
+    auto f = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, 0, A, B, C, bias, M, N, K, (int64_t)K, (int64_t)K, (int64_t)N, 1); }; \
+    const float us = time_it(f, iters);                                                                                                    \
+    printf("plr BK" #BK " ablation " #ABL ": %.1f us  %.1f TF/s (results wrong by construction)\n", us, 2.0 * M * N * K / us / 1e6);      \
+  }
+  RUNPA(16, 2, 2, 1)
+  RUNPA(16, 2, 2, 2)
   RUNPL(16, 2, 2, 72 * 1024)
   RUNPL(16, 2, 2, 120 * 1024)
   RUNP(32, 2, 2)
