@@ -31,6 +31,10 @@ Besides the contract fields the line carries
                 the same process after the headline (skipped with --no-secondary and for N > 1)
   cpu_baseline  the same application on the host cores with the CPU oracle as kernel library (kind "port": the
                 reference has no CPU path for this step), N = 1 only, on a bounded sample (stated in `sample`)
+
+The measured path always runs the HIP library and refuses to start without a GPU.  (tests/test_launchers.py walks this
+file's N > 1 rank code on the CPU through the hidden --functional-test-backend <kernel library> flag -- gloo collectives, an
+explicitly named kernel library, the line marked FUNCTIONAL_TEST_NOT_A_MEASUREMENT; nothing is measured or reported there.)
 """
 from __future__ import annotations
 
@@ -302,6 +306,8 @@ def main():
     ap.add_argument("--leg-budget", type=float, default=7.0, help=argparse.SUPPRESS)
     ap.add_argument("--shim-flags", default="", help="extra FFConfig flags for A/B runs, e.g. '--serial-dw --no-overlap'")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: ranks rendezvous over gloo and report, no GPU
+    ap.add_argument("--functional-test-backend", default="", help=argparse.SUPPRESS)   # tests only: walk this file's whole rank path on the
+    #                      CPU (gloo + the given kernel library, i.e. the oracle); the line it prints is not a measurement
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_leg:
         sys.exit(spawn_ranks(args.gpus))   # the parent: no torch import, no HIP call, nothing that initialises a GPU
@@ -334,9 +340,11 @@ def main():
         return
     from dlrm_flexflow_amd import ffmodel
 
-    if not torch.cuda.is_available():
+    ftest = args.functional_test_backend           # tests only (see the flag): everything below runs, nothing is measured
+    if not ftest and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    if not ftest:
+        torch.cuda.set_device(local_rank)
     comm = None
     collectives = ""
     if world > 1 or args.force_exchange:
@@ -344,11 +352,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from dlrm_flexflow_amd.comm import RcclComm, TorchComm
-        comm = TorchComm(on_gpu=True)
-        collectives = "torch.distributed (RCCL) callbacks"
-        if not args.torch_collectives and not os.environ.get("FFM_NO_DIRECT_RCCL"):
+        if ftest:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = TorchComm(on_gpu=not ftest)
+        collectives = "torch.distributed (RCCL) callbacks" if not ftest else "torch.distributed (gloo) callbacks: FUNCTIONAL TEST, not a measurement"
+        if not ftest and not args.torch_collectives and not os.environ.get("FFM_NO_DIRECT_RCCL"):
             try:
                 comm = RcclComm(comm)       # the same callbacks served by RCCL from the C++ host layer, no Python per collective
                 collectives = "RCCL called from the C++ host layer"
@@ -366,12 +377,13 @@ def main():
             raise SystemExit(f"global batch {gb} is not divisible by {world} ranks")
     w = workload(args.workload, gb)
     bf16 = "--allow-tensor-op-math-conversion" in args.shim_flags.split()
-    extra = ["--device", str(local_rank)] + (["--no-trace"] if args.no_trace else []) + (["--force-exchange"] if args.force_exchange else []) + args.shim_flags.split()
+    extra = (["--backend", ftest] if ftest else ["--device", str(local_rank)]) + (["--no-trace"] if args.no_trace else []) + (["--force-exchange"] if args.force_exchange else []) + args.shim_flags.split()
     app = ffmodel.DLRM(flags_of(w, extra), comm=comm.struct if comm else None)
     trace = not args.no_trace
 
     def barrier():
-        torch.cuda.synchronize()
+        if not ftest:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
@@ -397,7 +409,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if ftest else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -432,7 +444,7 @@ def main():
     out = {
         "metric": "dlrm_training_samples_per_sec", "value": round(samples / elapsed, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, **({"FUNCTIONAL_TEST_NOT_A_MEASUREMENT": True} if ftest else {}),
         "dtype": "f32" if not bf16 else "bf16 GEMM operands (fp32 accumulate, fp32 master weights); fp32 elsewhere", "data": "synthetic",
         "config": {"workload": f"{w['name']}: {T} tables (rows {w['rows']}), emb_dim {D}, bag 1, bot {w['bot']}, top {w['top']}, "
                                f"{'dot (strict lower triangle)' if 'dot-tril' in wx else 'dot (all pairs)' if 'dot' in wx else 'cat'} interaction, SGD lr 0.01, MSE loss",
@@ -467,17 +479,17 @@ def main():
         out["kernels"]["whole_step_device"] = {"us": round(t_step_dev * 1e6, 2), "mlp_gflop_per_step": round(flops / 1e9, 3),
                                                "mlp_tflops_over_whole_step": round(flops / t_step_dev / 1e12, 2), "mfma_peak_tflops": peak,
                                                "frac_of_mfma_peak": round(flops / t_step_dev / 1e12 / peak, 3)}
-        if not args.no_secondary and not bf16:
+        if not args.no_secondary and not bf16 and not ftest:
             try:
                 out["kernels"]["tensor_op_bf16_mode"] = bf16_mode_block(ffmodel, w, local_rank, B)
             except Exception as e:  # noqa: BLE001
                 out["kernels"]["tensor_op_bf16_mode"] = {"error": repr(e)}
-        if not args.no_secondary and args.workload != "kaggle":
+        if not args.no_secondary and args.workload != "kaggle" and not ftest:
             try:
                 out["kernels"]["kaggle_secondary"] = kaggle_secondary(ffmodel, local_rank)
             except Exception as e:  # noqa: BLE001
                 out["kernels"]["kaggle_secondary"] = {"error": repr(e)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not ftest:
             out["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():

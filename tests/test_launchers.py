@@ -121,3 +121,45 @@ def test_bench_one_rank_exchange_line_on_gpu(hip):
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
     c = d["config"]["collective_calls_rank0"]
     assert c["alltoall"] >= 2 * 7 and c["allreduce"] >= 7
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bench.py's rank path end to end on the CPU: gloo for the collectives, the oracle as kernel library.  The line it prints is
+# marked as not a measurement; what is checked is that the N > 1 code of bench.py (batch split, table ownership, the
+# roofline probes on rank 0, barriers, MAX-reduced time, the single JSON line) runs and reports what it saw.
+# ---------------------------------------------------------------------------------------------------------------------
+def _bench_env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_two_ranks_functional_on_cpu(oracle, scaling):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1", "--scaling", scaling,
+                        "--functional-test-backend", oracle.ORACLE_LIB], env=_bench_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["FUNCTIONAL_TEST_NOT_A_MEASUREMENT"] is True
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 3 and d["metric"] == "dlrm_training_samples_per_sec"
+    assert d["config"]["ranks_observed"] == 2
+    assert d["config"]["global_batch"] == (128 if scaling == "strong" else 256) and d["config"]["per_gpu_batch"] == d["config"]["global_batch"] // 2
+    c = d["config"]["collective_calls_rank0"]
+    assert c["alltoall"] == 2 * (1 + 1 + 3) and c["allreduce"] == 1 + 1 + 3        # the driver's warm-up + W + K steps
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["tables_in_launch"] == 4      # rank 0 owns tables 0, 2, 4, 6 of 8
+    assert d["value"] > 0 and "cpu_baseline" not in d
+
+
+def test_bench_as_a_rank_under_torchrun_functional_on_cpu(oracle):
+    """the driver's launch line: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N"""
+    with __import__("socket").socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                        "--functional-test-backend", oracle.ORACLE_LIB], env=_bench_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_observed"] == 2 and d["steps"] == 2
