@@ -238,10 +238,12 @@ def hbm_block(kernel, nbytes, sec, traffic=None, src=None, note=None):
     return d
 
 
-def bf16_mode_block(ffmodel, w, local_rank, B):
-    """The same workload with --allow-tensor-op-math-conversion (bf16 operands on v_mfma_f32_32x32x16_bf16 for the wide Linear
-    layers, fp32 accumulate / master weights / everything else): reported beside the fp32 headline, never as it."""
-    app = ffmodel.DLRM(flags_of(w, ["--device", str(local_rank), "--allow-tensor-op-math-conversion", "--no-trace"]))
+def bf16_mode_block(ffmodel, w, local_rank, B, split=False):
+    """The same workload in one of the two bf16-pipe math modes, reported beside the exact-fp32 headline, never as it:
+    --allow-tensor-op-math-conversion (bf16 operands, fp32 accumulate: the reference's tensor-op switch) or, split=True,
+    --fp32-split-bf16x3 (fp32-accurate: three bf16 terms per operand, six products; held to the fp32 parity bound)."""
+    flag = "--fp32-split-bf16x3" if split else "--allow-tensor-op-math-conversion"
+    app = ffmodel.DLRM(flags_of(w, ["--device", str(local_rank), flag, "--no-trace"]))
     app.warmup()
     app.train_steps(3, trace=False)
     app.model.sync()
@@ -254,7 +256,14 @@ def bf16_mode_block(ffmodel, w, local_rank, B):
     t_b = app.time_kernel(7, 20) * 1e-3
     app.close()
     flops = mlp_flops_per_sample(w) * B
-    blk = largest_linear(w, B, t_f, t_b, True)
+    blk = largest_linear(w, B, t_f, t_b, not split)
+    if split:
+        blk["dtype"] = "f32 result from three bf16 terms per operand (six v_mfma_f32_32x32x16_bf16 products per k-step, fp32 accumulate)"
+        blk["note"] = "achieved / frac are fp32-equivalent flops (2*B*in*out) against the fp32 MFMA peak: above 1.0 means faster than any exact-fp32 MFMA kernel can be"
+        return {"flag": "--fp32-split-bf16x3 (ffh_ctx_set_math_mode(FFH_MATH_FP32_SPLIT_BF16X3)); opt-in, not the headline",
+                "parity": "same 1e-5-of-term-mass bound as the exact-fp32 kernels against the fp32 oracle; error against float64 within 4x theirs (tests/test_bf16_mode.py)",
+                "samples_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mlp_tflops_over_whole_step_fp32_equivalent": round(flops / dt / 1e12, 1),
+                "frac_of_fp32_mfma_peak": round(flops / dt / 1e12 / F32_PEAK_TFLOPS, 3), "linear_largest_layer": blk}
     return {"flag": "--allow-tensor-op-math-conversion (ffh_ctx_set_math_mode(FFH_MATH_TENSOR_OP_BF16))",
             "dtype": "bf16 GEMM operands rounded from fp32 in the kernel, fp32 accumulate, fp32 master weights and activations in HBM",
             "samples_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mlp_tflops_over_whole_step": round(flops / dt / 1e12, 1),
@@ -484,6 +493,10 @@ def main():
                 out["kernels"]["tensor_op_bf16_mode"] = bf16_mode_block(ffmodel, w, local_rank, B)
             except Exception as e:  # noqa: BLE001
                 out["kernels"]["tensor_op_bf16_mode"] = {"error": repr(e)}
+            try:
+                out["kernels"]["fp32_split_bf16x3_mode"] = bf16_mode_block(ffmodel, w, local_rank, B, split=True)
+            except Exception as e:  # noqa: BLE001
+                out["kernels"]["fp32_split_bf16x3_mode"] = {"error": repr(e)}
         if not args.no_secondary and args.workload != "kaggle" and not ftest:
             try:
                 out["kernels"]["kaggle_secondary"] = kaggle_secondary(ffmodel, local_rank)

@@ -604,6 +604,229 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
 }
 
 // =============================================================================================
+// fp32 GEMM on the bf16 matrix pipe: FFH_MATH_FP32_SPLIT_BF16X3.  gfx950's fp32 MFMA runs at 1/16 of the bf16 rate, so an
+// fp32-ACCURATE product can be had faster from bf16 pieces: every operand element is split into three bfloat16 terms
+//     x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)      (both residuals are exact in fp32;
+//                                                                                       |x - x1 - x2 - x3| <= 2^-27 |x|)
+// and a*b is accumulated from the six products a_i b_j with i + j <= 4 -- each exact in fp32 (8 x 8 significant bits), summed
+// in fp32 by v_mfma_f32_32x32x16_bf16, small terms first; the three dropped products are <= 2^-26 |a b|, below fp32's own
+// rounding.  Six bf16 MFMAs of 32 cycles per 16 k against eight fp32 MFMAs of 64 cycles: 2.67x the fp32 pipe rate at the
+// same result to within the fp32 summation-order bound (the parity tests hold this mode to the SAME 1e-5-of-term-mass bound
+// as the exact-fp32 kernels, and compare both against float64).  Same tile / layouts as gemm_bf16_kernel with BK = 32 and
+// three planes per operand in a single 48 KB LDS buffer (two workgroups per CU: one splits and stores while the other
+// multiplies); the split happens between the global load and the LDS store.  Not the default: an opt-in math mode.
+// =============================================================================================
+constexpr int kX3BK = 32;
+constexpr int kX3Plane = 128 * kX3BK * 2;               // bytes of one bf16 plane of one operand image
+constexpr int kX3Lds = 2 * 3 * kX3Plane;                // two operands x three planes, single buffer
+
+__device__ __forceinline__ unsigned x3_off_kc(int row, int chunk) { return (unsigned)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4)); }
+
+__device__ __forceinline__ float4 bf16x4_as_f32(const uint2 p) {
+  return make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u));
+}
+// x -> (x1, x2, x3): 22 VALU instructions per four elements.  (An infinite x gives x - x1 = NaN: such an operand turns its
+// outputs into NaN where fp32 arithmetic gives an infinity -- stated in ff_hip.h.)
+__device__ __forceinline__ void split_bf16x3(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
+  p1 = pack_bf16x4(v);
+  const float4 f1 = bf16x4_as_f32(p1);
+  const float4 r = make_float4(v.x - f1.x, v.y - f1.y, v.z - f1.z, v.w - f1.w);
+  p2 = pack_bf16x4(r);
+  const float4 f2 = bf16x4_as_f32(p2);
+  p3 = pack_bf16x4(make_float4(r.x - f2.x, r.y - f2.y, r.z - f2.z, r.w - f2.w));
+}
+
+template <bool AKC, bool BKC, bool MASK_A = false>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
+  constexpr int BM = 128, BN = 128, BK = kX3BK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bx, by, bz;
+  {
+    const unsigned nbx = gridDim.x, nby = gridDim.y, nbz = gridDim.z;
+    const unsigned total = nbx * nby * nbz;
+    const unsigned lin = (blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x;
+    const unsigned xcd = lin & 7u, loc = lin >> 3;
+    const unsigned q = total >> 3, rem = total & 7u;
+    const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
+    bx = (int)(nlin % nbx);
+    by = (int)((nlin / nbx) % nby);
+    bz = (int)(nlin / (nbx * nby));
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  int kb = 0, ke = g.K;
+  if (g.splitk > 1) {
+    kb = bz * g.k_per_split;
+    ke = kb + g.k_per_split < g.K ? kb + g.k_per_split : g.K;
+  }
+  if (kb >= ke) return;
+  const int nk = (ke - kb + BK - 1) / BK;
+  const float* A = g.A;
+  const float* B = g.B;
+
+  float4 ra0[4], rb0[4];
+  const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
+  auto load_tile = [&](int kt, auto fast_tag, float4 (&ra)[4], float4 (&rb)[4]) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const int k0 = kb + kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (AKC) {
+        const int k4 = tid & 7, row = (tid >> 3) + 32 * i;
+        const int m = m0 + row, k = k0 + 4 * k4;
+        if (FAST) ra[i] = ld4u(A + (int64_t)m * g.sAm + k);
+        else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, true);
+        if (MASK_A) {
+          float4 yv;
+          if (FAST) yv = ld4u(g.act_y + (int64_t)m * g.ld_act_y + k);
+          else yv = load4_guard(g.act_y + (int64_t)m * g.ld_act_y + k, m < g.M, k, ke, true);
+          ra[i].x = yv.x > 0.0f ? ra[i].x : 0.0f; ra[i].y = yv.y > 0.0f ? ra[i].y : 0.0f;
+          ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
+        }
+      } else {
+        const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        const int m = m0 + 4 * m4, k = k0 + kr;
+        if (FAST) ra[i] = ld4u(A + (int64_t)k * g.sAk + m);
+        else ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, true);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (BKC) {
+        const int k4 = tid & 7, row = (tid >> 3) + 32 * i;
+        const int n = n0 + row, k = k0 + 4 * k4;
+        if (FAST) rb[i] = ld4u(B + (int64_t)n * g.sBn + k);
+        else rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, true);
+      } else {
+        const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        const int n = n0 + 4 * n4, k = k0 + kr;
+        if (FAST) rb[i] = ld4u(B + (int64_t)k * g.sBk + n);
+        else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, true);
+      }
+    }
+  };
+  auto split_store = [&](const float4 (&ra)[4], const float4 (&rb)[4]) {
+    unsigned char* as = x3_smem;
+    unsigned char* bs = x3_smem + 3 * kX3Plane;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint2 p1, p2, p3;
+      split_bf16x3(ra[i], p1, p2, p3);
+      unsigned o;
+      if (AKC) { const int k4 = tid & 7, row = (tid >> 3) + 32 * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
+      else     { const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;  o = bf_off_kr(kr, m4 >> 1) + 8 * (m4 & 1); }
+      *reinterpret_cast<uint2*>(as + o) = p1;
+      *reinterpret_cast<uint2*>(as + kX3Plane + o) = p2;
+      *reinterpret_cast<uint2*>(as + 2 * kX3Plane + o) = p3;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint2 p1, p2, p3;
+      split_bf16x3(rb[i], p1, p2, p3);
+      unsigned o;
+      if (BKC) { const int k4 = tid & 7, row = (tid >> 3) + 32 * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
+      else     { const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;  o = bf_off_kr(kr, n4 >> 1) + 8 * (n4 & 1); }
+      *reinterpret_cast<uint2*>(bs + o) = p1;
+      *reinterpret_cast<uint2*>(bs + kX3Plane + o) = p2;
+      *reinterpret_cast<uint2*>(bs + 2 * kX3Plane + o) = p3;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  auto frag = [&](const unsigned char* img, bool kc, int o, int s) -> bf16x8_t {
+    if (kc) return *reinterpret_cast<const bf16x8_t*>(img + x3_off_kc(o + lr, 2 * s + lh));
+    typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
+    const int ch = (o >> 3) + 2 * (tg & 1) + (tp >> 1);
+    const int k0r = 16 * s + 8 * (tg >> 1) + tq;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr(k0r, ch) + 8 * (tp & 1)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr(k0r + 4, ch) + 8 * (tp & 1)));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto compute_tile = [&]() {
+    const unsigned char* as = x3_smem;
+    const unsigned char* bs = x3_smem + 3 * kX3Plane;
+#pragma unroll
+    for (int s = 0; s < BK / 16; s++) {
+      bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; p++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) a[i][p] = frag(as + p * kX3Plane, AKC, wm0 + 32 * i, s);
+#pragma unroll
+        for (int j = 0; j < 2; j++) b[j][p] = frag(bs + p * kX3Plane, BKC, wn0 + 32 * j, s);
+      }
+      // the six products with i + j <= 4, small terms first
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nfull = (a_in && b_in) ? (ke - kb) / BK : 0;
+  auto load_any = [&](int kt, float4 (&ra)[4], float4 (&rb)[4]) {
+    if (kt >= nk) return;
+    if (kt < nfull) load_tile(kt, std::true_type{}, ra, rb); else load_tile(kt, std::false_type{}, ra, rb);
+  };
+  load_any(0, ra0, rb0);
+  split_store(ra0, rb0);
+  __syncthreads();
+  for (int t = 0; t < nk; t++) {
+    load_any(t + 1, ra0, rb0);            // in flight under this tile's MFMAs (a second register set, two tiles ahead, was
+    compute_tile();                       //   measured: +2 % forward, -12 % dW -- its 194 VGPRs leave one workgroup per CU)
+    __syncthreads();                      // every wave has read this tile's fragments
+    if (t + 1 < nk) { split_store(ra0, rb0); __syncthreads(); }
+  }
+
+  float* C = g.C;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int n = n0 + wn0 + j * 32 + lr;
+      if (n >= g.N) continue;
+      const float bv = (g.epi == EPI_STORE && g.bias) ? g.bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.M) continue;
+        float* cp = C + (int64_t)m * g.ldc + n;
+        float v = acc[i][j][r];
+        if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) v = 0.0f;
+        if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
+        else if (g.epi == EPI_ADD) *cp = *cp + v;
+        else atomicAdd(cp, v);
+      }
+    }
+}
+
+// =============================================================================================
 // LDS-DMA GEMM for the mid-size layers of the 2048-sample step (432x512, 512x256 ...): outputs of only
 // ~1 M elements, i.e. ONE 64x64 tile per CU.  What bounds such a launch is not the matrix pipe but how the
 // operand bytes get on chip next to it, so:
@@ -1162,14 +1385,15 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   return FFH_OK;
 }
 
-inline bool use_bf16(const ffh_ctx* c, int in, int out) {
-  return c->math_mode == FFH_MATH_TENSOR_OP_BF16 && in >= FFH_BF16_MIN_DIM && out >= FFH_BF16_MIN_DIM;
+inline bool use_bf16(const ffh_ctx* c, int in, int out) {     // either bf16-pipe mode: same layers, same launch paths
+  return (c->math_mode == FFH_MATH_TENSOR_OP_BF16 || c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3) && in >= FFH_BF16_MIN_DIM && out >= FFH_BF16_MIN_DIM;
 }
 
 // bf16-operand form of launch_gemm (tensor-op math mode): 128 x 128 tiles; EPI_ATOMIC splits K over workgroups
 template <bool AKC, bool BKC, bool MASK_A = false>
 int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return FFH_OK;
+  const bool x3 = c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3;      // three bf16 planes per operand: fp32-accurate
   const int gx = (g.N + kBfBN - 1) / kBfBN, gy = (g.M + kBfBM - 1) / kBfBM;
   g.splitk = 1;
   g.k_per_split = g.K;
@@ -1189,6 +1413,15 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     gz = g.splitk;
   }
   if (gy > 65535 || gz > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm (bf16): grid too large");
+  if (x3) {
+    auto kern3 = gemm_bf16x3_kernel<AKC, BKC, MASK_A>;
+    static const bool ok3 = glds_set_lds(kern3, kX3Lds);
+    if (!ok3) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16x3): cannot reserve 48 KB of LDS");
+    hipLaunchKernelGGL(kern3, dim3(gx, gy, gz), dim3(256), kX3Lds, as_stream(s), g);
+    hipError_t e3 = hipGetLastError();
+    if (e3 != hipSuccess) return ffh_fail_hip(c, e3, name);
+    return FFH_OK;
+  }
   auto kern = gemm_bf16_kernel<AKC, BKC, MASK_A>;
   static const bool ok = glds_set_lds(kern, kBfLds);
   if (!ok) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16): cannot reserve 64 KB of LDS");

@@ -103,6 +103,7 @@ class FFConfig {
   bool dense_embedding_update; // reference's dense zero/scatter/sweep path instead of the fused sparse update
   int64_t column_shard_rows;   // tables with at least this many rows are sharded column-wise over the ranks (0: never)
   bool deterministic;          // --deterministic: weight / bias gradients without fp atomics (ffh_ctx_set_deterministic): bit-identical runs
+  bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
   bool dx_scatter;             // exchange mode: the layer above the feature Concat writes its dX into the send buffer itself (A/B: --no-dx-scatter)
   bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)

@@ -132,6 +132,7 @@ FFConfig::FFConfig() {
   fuse_pair = true;
   dx_scatter = true;
   allow_tensor_op_math_conversion = false;
+  fp32_split_bf16x3 = false;
   deterministic = false;
   memset(&comm, 0, sizeof comm);
   comm.rank = 0;
@@ -165,6 +166,7 @@ void FFConfig::parse_args(char** argv, int argc) {
         is("--simulator-max-num-segments") || is("--taskgraph")) { next(); continue; }
     // cublasSetMathMode(CUBLAS_TENSOR_OP_MATH) on every handle [ref: src/runtime/model.cc:2282-2403, src/runtime/model.cu:81-83]
     if (is("--allow-tensor-op-math-conversion")) { allow_tensor_op_math_conversion = true; continue; }
+    if (is("--fp32-split-bf16x3")) { fp32_split_bf16x3 = true; continue; }      // this build: fp32-accurate GEMMs on the bf16 pipe (ff_hip.h)
     if (is("-dm:memoize") || is("-dm:memorize") || is("--overlap") || is("--enable-parameter-parallel") ||
         is("--enable-attribute-parallel") || is("--enable-propagation")) continue;
     // this build
@@ -427,6 +429,7 @@ FFModel::FFModel(FFConfig& _config)
   int rc = api->ffh_ctx_create(&ctx, config.device);
   if (rc != FFH_OK || !ctx) die("ffh_ctx_create(device %d) failed with %d on %s -- no usable GPU?", config.device, rc, api->path.c_str());
   if (config.allow_tensor_op_math_conversion) check(api->ffh_ctx_set_math_mode(ctx, FFH_MATH_TENSOR_OP_BF16), "tensor-op math mode");
+  else if (config.fp32_split_bf16x3) check(api->ffh_ctx_set_math_mode(ctx, FFH_MATH_FP32_SPLIT_BF16X3), "split-bf16x3 math mode");
   if (config.deterministic) { check(api->ffh_ctx_set_deterministic(ctx, 1), "deterministic mode"); config.async_launch = false; }
   check(api->ffh_stream_create(ctx, &stream), "stream create");
   check(api->ffh_stream_create(ctx, &side_stream), "stream create");
@@ -437,9 +440,10 @@ FFModel::FFModel(FFConfig& _config)
     // asynchronous devices only: on the CPU oracle a "launch" is the computation itself
     dw_worker = new LaunchWorker(api, config.device);
     side_worker = new LaunchWorker(api, config.device);
-    if (config.allow_tensor_op_math_conversion) {
-      check(api->ffh_ctx_set_math_mode(dw_worker->ctx(), FFH_MATH_TENSOR_OP_BF16), "tensor-op math mode");
-      check(api->ffh_ctx_set_math_mode(side_worker->ctx(), FFH_MATH_TENSOR_OP_BF16), "tensor-op math mode");
+    const int mm = config.allow_tensor_op_math_conversion ? FFH_MATH_TENSOR_OP_BF16 : (config.fp32_split_bf16x3 ? FFH_MATH_FP32_SPLIT_BF16X3 : FFH_MATH_DEFAULT);
+    if (mm != FFH_MATH_DEFAULT) {
+      check(api->ffh_ctx_set_math_mode(dw_worker->ctx(), mm), "math mode");
+      check(api->ffh_ctx_set_math_mode(side_worker->ctx(), mm), "math mode");
     }
   }
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_fork), "event create");

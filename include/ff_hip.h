@@ -136,6 +136,15 @@ int         ffh_ctx_set_workspace(ffh_ctx* ctx, void* ws, size_t bytes);
  * bound of the fp32 mode applies.  Returns FFH_ERR_BAD_ARG for an unknown mode. */
 #define FFH_MATH_DEFAULT 0
 #define FFH_MATH_TENSOR_OP_BF16 1
+/*   FFH_MATH_FP32_SPLIT_BF16X3 the same layers, fp32-ACCURATE on the bf16 pipe (no reference counterpart; gfx950's fp32 MFMA
+ *                             runs at 1/16 of the bf16 rate): each operand element is split into three bfloat16 terms
+ *                             x1 + x2 + x3 (|x - x1 - x2 - x3| <= 2^-27 |x|) and a*b is the fp32 sum of the six exact
+ *                             products a_i b_j with i + j <= 4 (dropped terms <= 2^-26 |a b|).  Held to the SAME tolerance
+ *                             as FFH_MATH_DEFAULT (1e-5 of the term mass; measured error against float64 is of the size of
+ *                             the exact-fp32 kernels' own).  Not bit-identical to the default mode; an INFINITE operand element
+ *                             gives NaN outputs where fp32 arithmetic gives an infinity (x - x1 = inf - inf), and so does a
+ *                             finite one above the largest bfloat16 (3.39e38); NaN stays NaN.  Opt-in. */
+#define FFH_MATH_FP32_SPLIT_BF16X3 2
 #define FFH_BF16_MIN_DIM 128
 int         ffh_ctx_set_math_mode(ffh_ctx* ctx, int mode);
 /* on != 0: every weight / bias gradient is produced WITHOUT floating-point atomics -- no split-K over workgroups (one

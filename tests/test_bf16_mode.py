@@ -253,3 +253,84 @@ def test_dlrm_step_bf16_mode_hip_vs_oracle_backend(hip, oracle, trace):
     app.close()
     d = np.abs(p32 - out["hip"]["pred"]).max()
     assert 1e-7 < d < 2e-2, d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FFH_MATH_FP32_SPLIT_BF16X3: fp32-accurate GEMMs on the bf16 pipe (three bf16 terms per operand, six products).  Held to the
+# SAME bound as the exact-fp32 kernels against the fp32 oracle, and its error against float64 must be of the same size.
+# ---------------------------------------------------------------------------------------------------------------------
+MATH_X3 = 2
+
+
+@pytest.fixture()
+def hip_x3(hip):
+    assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, MATH_X3) == 0
+    yield hip
+    assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, 0) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,IN,OUT,act", [
+    (2048, 512, 256, capi.AC_MODE_RELU), (2048, 432, 512, capi.AC_MODE_RELU), (4096, 1024, 1024, capi.AC_MODE_RELU),
+    (1024, 3456, 1024, capi.AC_MODE_RELU), (512, 479, 1024, capi.AC_MODE_RELU), (333, 130, 200, capi.AC_MODE_SIGMOID),
+    (65, 128, 128, capi.AC_MODE_NONE), (1000, 257, 129, capi.AC_MODE_RELU), (100, 2000, 1000, capi.AC_MODE_NONE)])
+def test_linear_split_bf16x3_mode_meets_the_fp32_bound(hip_x3, oracle, B, IN, OUT, act):
+    T = _gpu_helpers()
+    rng = np.random.default_rng(IN * OUT + 5)
+    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    y = T.gpu_linear_fwd(hip_x3, x, w, b, act)
+    y_exp = oracle.linear_fwd(x, w, b, act)                                   # the fp32 oracle, default mode
+    mass = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+    T.assert_gemm_close(y, y_exp, mass, "y (split mode vs fp32 oracle)")
+    dx, dw, db, dy_after = T.gpu_linear_bwd(hip_x3, x, y_exp, gy, w, act)
+    dx_e, dw_e, db_e, dy_e = oracle.linear_bwd(x, y_exp, gy, w, act)
+    a = np.abs(dy_e).astype(np.float64)
+    T.assert_gemm_close(dw, dw_e, a.T @ np.abs(x).astype(np.float64), "dw (split mode)")
+    T.assert_gemm_close(db, db_e, a.sum(0), "db (split mode)")
+    T.assert_gemm_close(dx, dx_e, a @ np.abs(w).astype(np.float64), "dx (split mode)")
+
+
+@pytest.mark.gpu
+def test_split_bf16x3_error_against_float64_is_fp32_sized(hip, oracle):
+    """|error vs float64| of the split mode next to the exact-fp32 kernel's on the same operands, wide dynamic range
+    included (entries spread over 2^-20 .. 2^20): the split mode's worst error stays within 4x the fp32 kernel's."""
+    T = _gpu_helpers()
+    rng = np.random.default_rng(11)
+    B, IN, OUT = 512, 1024, 256
+    for spread in (0, 20):
+        x = (rng.uniform(-1, 1, (B, IN)) * 2.0 ** rng.integers(-spread, spread + 1, (B, IN))).astype(np.float32)
+        w = (rng.uniform(-1, 1, (OUT, IN)) * 2.0 ** rng.integers(-spread, spread + 1, (OUT, IN))).astype(np.float32)
+        exact = x.astype(np.float64) @ w.astype(np.float64).T
+        mass = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T
+        err = {}
+        for mode in (0, MATH_X3):
+            assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, mode) == 0
+            y = T.gpu_linear_fwd(hip, x, w, None, capi.AC_MODE_NONE)
+            err[mode] = float((np.abs(y - exact) / mass).max())
+        hip.lib.ffh_ctx_set_math_mode(hip.ctx, 0)
+        assert err[MATH_X3] <= 4 * err[0] + 1e-8, (spread, err)
+        assert err[MATH_X3] < 2e-6, (spread, err)
+
+
+@pytest.mark.gpu
+def test_dlrm_step_split_bf16x3_mode_matches_the_fp32_oracle_backend(hip, oracle):
+    """--fp32-split-bf16x3 end to end at the Kaggle widths: 1 warm-up + 3 steps on the GPU against the oracle backend in its
+    DEFAULT fp32 mode, at the tolerance of the fp32 driver tests."""
+    import dlrm_helpers as H
+    from dlrm_flexflow_amd import ffmodel
+    args = H.KAGGLE_ARGS(2048)
+    out = {}
+    for name, backend, extra in (("hip", capi.HIP_LIB_PATH, ["--fp32-split-bf16x3"]), ("cpu", oracle.ORACLE_LIB, [])):
+        app = ffmodel.DLRM(["--backend", backend] + args + extra)
+        app.warmup()
+        app.train_steps(3, trace=False)
+        app.model.sync()
+        m = app.model
+        out[name] = {f"{m.layer_name(l)}/{i}": m.parameter(l, i).get_weights() for l in range(m.num_layers) for i in range(m.layer_num_weights(l))}
+        out[name]["pred"] = m.layer_output(m.num_layers - 1).get()
+        app.close()
+    for k in out["hip"]:
+        np.testing.assert_allclose(out["hip"][k], out["cpu"][k], rtol=2e-5, atol=2e-6, err_msg=k)

@@ -20,12 +20,12 @@ for B, IN, OUT in shapes:
     dw = torch.zeros(OUT, IN, device="cuda"); db = torch.zeros(OUT, device="cuda")
     fl = 2.0 * B * IN * OUT
     line = f"{B:6d} {IN:5d} {OUT:5d} "
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         hip.lib.ffh_ctx_set_math_mode(hip.ctx, mode)
         tf = timeit(lambda: hip.call("ffh_linear_fwd", x, IN, y, OUT, w, b, IN, OUT, B, capi.AC_MODE_NONE, None))
         tx = timeit(lambda: hip.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy, OUT, w, dw, db, IN, OUT, B, capi.AC_MODE_NONE, 4 | 1, None, None))
         tw = timeit(lambda: hip.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy, OUT, w, dw, db, IN, OUT, B, capi.AC_MODE_NONE, 2, None, None))
-        line += f"| {'bf16' if mode else 'fp32'} fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF  dX {tx:7.1f} us {fl/tx/1e6:6.1f} TF  dW {tw:7.1f} us {fl/tw/1e6:6.1f} TF "
+        line += f"| {('fp32', 'bf16', 'bf16x3')[mode]} fwd {tf:7.1f} us {fl/tf/1e6:6.1f} TF  dX {tx:7.1f} us {fl/tx/1e6:6.1f} TF  dW {tw:7.1f} us {fl/tw/1e6:6.1f} TF "
     hip.lib.ffh_ctx_set_math_mode(hip.ctx, 0)
     xb, wb = x.bfloat16(), w.bfloat16()
     t1 = timeit(lambda: torch.mm(xb, wb.t()))
