@@ -613,8 +613,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
 // rounding.  Six bf16 MFMAs of 32 cycles per 16 k against eight fp32 MFMAs of 64 cycles: 2.67x the fp32 pipe rate at the
 // same result to within the fp32 summation-order bound (the parity tests hold this mode to the SAME 1e-5-of-term-mass bound
 // as the exact-fp32 kernels, and compare both against float64).  Same tile / layouts as gemm_bf16_kernel with BK = 32 and
-// three planes per operand in a single 48 KB LDS buffer (two workgroups per CU: one splits and stores while the other
-// multiplies); the split happens between the global load and the LDS store.  Not the default: an opt-in math mode.
+// three planes per operand in a single 48 KB LDS buffer (two workgroups per CU); the split happens between the global load
+// and the LDS store.  Not the default: an opt-in math mode.
+// What bounds it (measured by ablation, 3456 -> 1024 at batch 32768, 1,212 us): not the 48 MFMAs per k-tile (59 % of the
+// SIMD cycles at the 1.9 GHz the chip holds under this load) but the staging path -- fp32 operands from L2 (7.2 GB per
+// launch: ~410 us by itself) and 48 KB of ds_write_b64 per k-tile (LDS stores run at ~85 B/clk/CU: ~260 us by itself); the
+// split's VALU work costs ~20 us once it is spelled as below.  A wave-specialised variant (four waves multiply, four load /
+// split / store into a second or third LDS buffer, three k-tiles of loads in flight) measured 186 / 165 / 174 TFLOP/s
+// (fwd / dX / dW) against 191 / 172 / 138 here, and the same 6.52 ms for the whole step: not kept.
 // =============================================================================================
 constexpr int kX3BK = 32;
 constexpr int kX3Plane = 128 * kX3BK * 2;               // bytes of one bf16 plane of one operand image
@@ -622,18 +628,22 @@ constexpr int kX3Lds = 2 * 3 * kX3Plane;                // two operands x three 
 
 __device__ __forceinline__ unsigned x3_off_kc(int row, int chunk) { return (unsigned)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4)); }
 
-__device__ __forceinline__ float4 bf16x4_as_f32(const uint2 p) {
-  return make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u));
+// The unpack and the subtraction are spelled as instructions: left to itself hipcc re-converts the low element
+// (v_cvt_pk_bf16_f32 + shift instead of a shift of the packed word: 80 conversions per tile where 48 are needed) and packs the
+// subtractions into v_pk_add_f32, which costs four times a v_sub_f32 in the shadow of an MFMA.
+__device__ __forceinline__ float bf16_lo_as_f32(const unsigned p) { unsigned r; asm("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(p)); return __uint_as_float(r); }
+__device__ __forceinline__ float bf16_hi_as_f32(const unsigned p) { unsigned r; asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(r) : "v"(p)); return __uint_as_float(r); }
+__device__ __forceinline__ float sub_f32(const float a, const float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float4 residual_f32x4(const float4 v, const uint2 p) {
+  return make_float4(sub_f32(v.x, bf16_lo_as_f32(p.x)), sub_f32(v.y, bf16_hi_as_f32(p.x)), sub_f32(v.z, bf16_lo_as_f32(p.y)), sub_f32(v.w, bf16_hi_as_f32(p.y)));
 }
 // x -> (x1, x2, x3): 22 VALU instructions per four elements.  (An infinite x gives x - x1 = NaN: such an operand turns its
 // outputs into NaN where fp32 arithmetic gives an infinity -- stated in ff_hip.h.)
 __device__ __forceinline__ void split_bf16x3(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
   p1 = pack_bf16x4(v);
-  const float4 f1 = bf16x4_as_f32(p1);
-  const float4 r = make_float4(v.x - f1.x, v.y - f1.y, v.z - f1.z, v.w - f1.w);
+  const float4 r = residual_f32x4(v, p1);
   p2 = pack_bf16x4(r);
-  const float4 f2 = bf16x4_as_f32(p2);
-  p3 = pack_bf16x4(make_float4(r.x - f2.x, r.y - f2.y, r.z - f2.z, r.w - f2.w));
+  p3 = pack_bf16x4(residual_f32x4(r, p2));
 }
 
 template <bool AKC, bool BKC, bool MASK_A = false>
