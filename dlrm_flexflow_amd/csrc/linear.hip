@@ -58,6 +58,10 @@ constexpr int kSplitGran = 32;   // split-K granularity; splits are multiples of
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == FFH_AC_MODE_RELU) return v > 0.0f ? v : 0.0f;
   if (act == FFH_AC_MODE_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  if (act == FFH_AC_MODE_GELU) {     // tanh form, forward only [ref: gelu_forward_kernel, src/runtime/cuda_helper.cu:81-90; src/ops/linear.cu:454-459]
+    constexpr float B = 0.7978845608028654f, C = 0.035677408136300125f;
+    return v * (0.5f + 0.5f * tanhf(v * (C * v * v + B)));
+  }
   return v;
 }
 
@@ -1902,6 +1906,8 @@ __global__ __launch_bounds__(512) void linear_pair_fwd_kernel(const PairFwdArgs 
 }
 
 bool act_ok(int act) { return act == FFH_AC_MODE_NONE || act == FFH_AC_MODE_RELU || act == FFH_AC_MODE_SIGMOID; }
+// forward also serves GELU; the reference's backward does not [ref: src/ops/linear.cu:632-635 asserts NONE / RELU / SIGMOID]
+bool act_ok_fwd(int act) { return act_ok(act) || act == FFH_AC_MODE_GELU; }
 
 }  // namespace
 
@@ -1912,7 +1918,7 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   FFH_REQUIRE(c, in > 0 && out > 0 && batch >= 0 && ldx >= in && ldy >= out, "linear_fwd: bad dims");
   FFH_REQUIRE(c, batch == 0 || (x && y && w), "linear_fwd: null pointer");
   FFH_REQUIRE(c, batch < (1LL << 31), "linear_fwd: batch too large");
-  if (!act_ok(act)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_fwd: activation not supported (NONE, RELU, SIGMOID)");
+  if (!act_ok_fwd(act)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_fwd: activation not supported (NONE, RELU, SIGMOID, GELU)");
   if (batch == 0) return FFH_OK;
   if (out <= kSkinnyMaxOut) {
     hipLaunchKernelGGL(linear_skinny_fwd_kernel, dim3(ffh_grid(batch, 4, 2048)), dim3(256), 0, as_stream(s), x, ldx, y, ldy, w, bias, in, out,
@@ -1956,7 +1962,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
   FFH_REQUIRE(c, in > 0 && out > 0 && batch >= 0 && ldx >= in && ldy >= out && lddy >= out && (!dx || lddx >= in), "linear_bwd: bad dims");
   FFH_REQUIRE(c, batch == 0 || (x && y && dy && w && dw), "linear_bwd: null pointer");
   FFH_REQUIRE(c, batch < (1LL << 31), "linear_bwd: batch too large");
-  if (!act_ok(act)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd: activation not supported (NONE, RELU, SIGMOID)");
+  if (!act_ok(act)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd: activation not supported (NONE, RELU, SIGMOID; GELU is forward-only, as in the reference)");
   if (batch == 0) return FFH_OK;
   // 1. sigmoid: its gradient is not idempotent, so it gets its own in-place pass (with the bias sums).
   //    relu / none: folded into the GEMMs' operand loads below (no separate pass over dy).

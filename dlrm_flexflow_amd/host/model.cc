@@ -573,8 +573,8 @@ Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activ
       kernel_initializer(ki), bias_initializer(bi) {
   if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
   if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
-  if (activation != AC_MODE_NONE && activation != AC_MODE_RELU && activation != AC_MODE_SIGMOID)
-    die("%s: activation %d not supported (NONE, RELU, SIGMOID)", this->name, (int)activation);
+  if (activation != AC_MODE_NONE && activation != AC_MODE_RELU && activation != AC_MODE_SIGMOID && activation != AC_MODE_GELU)
+    die("%s: activation %d not supported (NONE, RELU, SIGMOID, GELU)", this->name, (int)activation);
   outputs[0].numDim = input.numDim;
   for (int i = 1; i < input.numDim; i++) outputs[0].adim[i] = input.adim[i];
   outputs[0].adim[0] = out_dim;   // [ref: src/ops/linear.cu:41-71]
@@ -630,6 +630,8 @@ int Linear::backward_pair(const FFModel& ff) {
   return FFH_OK;
 }
 void Linear::backward(const FFModel& ff) {
+  // [ref: src/ops/linear.cu:632-635: "only support relu and sigmoid for now" -- an assert there, a named error here]
+  if (activation == AC_MODE_GELU) die("%s: GELU has no backward (forward / inference only, as in the reference)", name);
   const Tensor& x = inputs[0];
   const Tensor& y = outputs[0];
   const int64_t b = local_rows(y, &ff);

@@ -253,7 +253,8 @@ int ffh_embedding_localize_rows(ffh_ctx* ctx, const int64_t* idx, int64_t* local
 /* ------------------------------------------------------------------ */
 /* Linear::forward_kernel [ref: include/model.h:1011-1017, src/ops/linear.cu:425-465]
  * y[b][o] = act( sum_i x[b][i]*w[o][i] + bias[o] ); bias may be NULL; fp32 throughout
- * (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32). activation: NONE, RELU, SIGMOID (GELU/TANH: unsupported). */
+ * (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32). activation: NONE, RELU, SIGMOID, and GELU forward-only as in the reference
+ * (tanh form, [ref: src/ops/linear.cu:454-459; its backward asserts NONE / RELU / SIGMOID, :632-635]); TANH: unsupported. */
 int ffh_linear_fwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy,
                    const float* w, const float* bias,
                    int in_dim, int out_dim, int64_t batch, int activation, ffh_stream s);

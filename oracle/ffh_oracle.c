@@ -353,6 +353,10 @@ size_t ffh_embedding_bwd_workspace_bytes(int nt, int L, int D, int64_t B) { (voi
 static float act_fwd(float v, int act) {
   if (act == FFH_AC_MODE_RELU) return v > 0.0f ? v : 0.0f;        /* CUDNN_ACTIVATION_RELU */
   if (act == FFH_AC_MODE_SIGMOID) return 1.0f / (1.0f + expf(-v)); /* CUDNN_ACTIVATION_SIGMOID */
+  if (act == FFH_AC_MODE_GELU) {                                   /* gelu_forward_kernel [ref: src/runtime/cuda_helper.cu:81-90] */
+    const float B = 0.7978845608028654f, C = 0.035677408136300125f;
+    return v * (0.5f + 0.5f * tanhf(v * (C * v * v + B)));
+  }
   return v;
 }
 
@@ -366,7 +370,7 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
                    const float* w, const float* bias, int in, int out, int64_t B, int act, ffh_stream s) {
   (void)s;
   if (in <= 0 || out <= 0 || B < 0 || ldx < in || ldy < out) return fail(c, FFH_ERR_BAD_ARG, "linear_fwd: bad dims");
-  if (act != FFH_AC_MODE_NONE && act != FFH_AC_MODE_RELU && act != FFH_AC_MODE_SIGMOID)
+  if (act != FFH_AC_MODE_NONE && act != FFH_AC_MODE_RELU && act != FFH_AC_MODE_SIGMOID && act != FFH_AC_MODE_GELU)
     return fail(c, FFH_ERR_UNSUPPORTED, "linear_fwd: activation");
   float* wt = (float*)malloc(sizeof(float) * (size_t)in * (size_t)out);   /* [in][out] */
   if (!wt) return fail(c, FFH_ERR_NOMEM, "oom");

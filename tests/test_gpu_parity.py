@@ -507,7 +507,27 @@ def test_linear_lds_dma_kernel_shapes(hip, oracle, B, IN, OUT):
 def test_linear_unsupported_activation_is_an_error(hip):
     t = torch.zeros(4, 4, device=DEV)
     with pytest.raises(capi.FFHError):
-        hip.call("ffh_linear_fwd", t, 4, t, 4, t, None, 4, 4, 4, capi.AC_MODE_GELU, None)
+        hip.call("ffh_linear_fwd", t, 4, t, 4, t, None, 4, 4, 4, capi.AC_MODE_TANH, None)
+    # GELU: forward only, as in the reference [ref: src/ops/linear.cu:454-459 forward, :632-635 backward asserts]
+    with pytest.raises(capi.FFHError):
+        hip.call("ffh_linear_bwd", t, 4, t, 4, t, 4, t, 4, t, t, t, 4, 4, 4, capi.AC_MODE_GELU, None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,IN,OUT", [(64, 32, 16), (300, 432, 512), (2048, 512, 256), (4096, 1024, 1024), (1000, 13, 512), (777, 100, 3)])
+def test_linear_gelu_forward(hip, oracle, B, IN, OUT):
+    """AC_MODE_GELU [ref: gelu_forward_kernel, src/runtime/cuda_helper.cu:81-90: x * (0.5 + 0.5 tanh(x (C x^2 + B)))] through every
+    forward kernel family (thin input, skinny output, LDS-DMA, register-staged); oracle and torch's tanh-form gelu as checkers."""
+    rng = np.random.default_rng(IN + OUT)
+    x = rng.uniform(-2, 2, (B, IN)).astype(np.float32)
+    w = (rng.uniform(-2, 2, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    y = gpu_linear_fwd(hip, x, w, b, capi.AC_MODE_GELU)
+    y_exp = oracle.linear_fwd(x, w, b, capi.AC_MODE_GELU)
+    mass = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b)
+    assert_gemm_close(y, y_exp, mass, "y")                      # |gelu'| <= 1.13: the pre-activation bound carries over
+    t = torch.nn.functional.gelu(torch.from_numpy(x) @ torch.from_numpy(w).T + torch.from_numpy(b), approximate="tanh").numpy()
+    np.testing.assert_allclose(y, t, rtol=1e-4, atol=2e-5)
 
 
 # ---------------------------------------------------------------------------

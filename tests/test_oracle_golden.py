@@ -171,6 +171,21 @@ def test_linear_matches_torch_golden(oracle):
         np.testing.assert_allclose(w_after, g[f"c{k}_w_after"], rtol=1e-5, atol=1e-6)
 
 
+def test_linear_gelu_forward_matches_torch_tanh_form(oracle):
+    """AC_MODE_GELU is the tanh form with the reference's constants [ref: src/ops/linear.cu:454-459]; no backward, as there."""
+    import torch
+    from dlrm_flexflow_amd import capi
+    rng = np.random.default_rng(14)
+    x = rng.uniform(-3, 3, (50, 40)).astype(np.float32)
+    w = rng.uniform(-0.5, 0.5, (24, 40)).astype(np.float32)
+    b = rng.uniform(-1, 1, 24).astype(np.float32)
+    y = oracle.linear_fwd(x, w, b, capi.AC_MODE_GELU)
+    t = torch.nn.functional.gelu(torch.from_numpy(x) @ torch.from_numpy(w).T + torch.from_numpy(b), approximate="tanh").numpy()
+    np.testing.assert_allclose(y, t, rtol=1e-5, atol=1e-5)
+    with pytest.raises(Exception):
+        oracle.linear_bwd(x, y, y, w, capi.AC_MODE_GELU)
+
+
 def test_linear_reference_harness_shape(oracle):
     """LinearTest (10, 2000, 1000) regenerated from np.random.seed(0) with torch as the
     oracle, exactly as the reference harness does; its tolerance is mean signed error < 1e-3."""
