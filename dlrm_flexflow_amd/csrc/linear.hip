@@ -430,16 +430,26 @@ __device__ __forceinline__ uint2 pack_bf16x4(const float4 v) {
 }
 
 constexpr int kBfBM = 128, kBfBN = 128, kBfBK = 64;
-constexpr int kBfImage = 128 * 64 * 2;                    // bytes of one operand image (either layout)
+constexpr int kBfImage = 128 * 64 * 2;                    // bytes of one 128-row operand image (either layout)
 constexpr int kBfLds = 2 * 2 * kBfImage;                  // two operands, two buffers
+constexpr int bf_lds_bytes(int bm, int bn) { return 2 * (bm + bn) * kBfBK * 2; }
 
 __device__ __forceinline__ unsigned bf_off_kc(int row, int chunk) { return (unsigned)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); }
-__device__ __forceinline__ unsigned bf_off_kr(int krow, int chunk) { return (unsigned)(krow * 256 + ((chunk ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4)); }
+// rows-are-k image of an operand with ROWLEN (128 or 256) columns: 2 * ROWLEN bytes per k-row, the swizzle acts on the low four chunk bits
+template <int ROWLEN = 128>
+__device__ __forceinline__ unsigned bf_off_kr(int krow, int chunk) { return (unsigned)(krow * (2 * ROWLEN) + ((chunk ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4)); }
 
 // MASK_A: the A operand (k-contiguous dy of the dX form) is read through relu'(act_y) (FFH_LINEAR_ONLY_DX / forked dW)
-template <bool AKC, bool BKC, bool MASK_A = false>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
-  constexpr int BM = kBfBM, BN = kBfBN, BK = kBfBK;
+// BM x BN block tile, one wave per WM x 64 of it: 128 x 128 (4 waves of 64 x 64, two workgroups per CU) or, where the output
+// has enough tiles to fill the chip with them, 256 x 256 (8 waves of 128 x 64, 128 KB of LDS, one workgroup per CU): the fp32
+// operands cross the L2 -> CU path half as often, and that path is what bounds this kernel
+template <bool AKC, bool BKC, bool MASK_A = false, int BM = kBfBM, int BN = kBfBN, int WM = 64>
+__global__ __launch_bounds__(BM / WM * BN) void gemm_bf16_kernel(const GemmArgs g) {
+  constexpr int BK = kBfBK, NT = BM / WM * BN;                 // one wave per WM x 64 of the tile
+  constexpr int TM = WM / 32;
+  constexpr int NA = BM * 16 / NT, NB = BN * 16 / NT;          // float4 per thread per k-tile
+  constexpr int IMG_A = BM * BK * 2, IMG_B = BN * BK * 2;     // bytes of the operand images
+  static_assert(NT <= 1024 && NA >= 1 && NB >= 1, "tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bx, by, bz;
@@ -465,15 +475,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
   const float* A = g.A;
   const float* B = g.B;
 
-  float4 ra[8], rb[8];
+  float4 ra[NA], rb[NB];
   const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
   auto load_tile = [&](int kt, auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
     const int k0 = kb + kt * BK;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < NA; i++) {
       if (AKC) {
-        const int k4 = tid & 15, row = (tid >> 4) + 16 * i;
+        const int k4 = tid & 15, row = (tid >> 4) + (NT / 16) * i;
         const int m = m0 + row, k = k0 + 4 * k4;
         if (FAST) ra[i] = ld4u(A + (int64_t)m * g.sAm + k);
         else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, true);
@@ -485,21 +495,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
           ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
         }
       } else {
-        const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        const int m4 = tid % (BM / 4), kr = tid / (BM / 4) + (4 * NT / BM) * i;
         const int m = m0 + 4 * m4, k = k0 + kr;
         if (FAST) ra[i] = ld4u(A + (int64_t)k * g.sAk + m);
         else ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, true);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < NB; i++) {
       if (BKC) {
-        const int k4 = tid & 15, row = (tid >> 4) + 16 * i;
+        const int k4 = tid & 15, row = (tid >> 4) + (NT / 16) * i;
         const int n = n0 + row, k = k0 + 4 * k4;
         if (FAST) rb[i] = ld4u(B + (int64_t)n * g.sBn + k);
         else rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, true);
       } else {
-        const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;
         const int n = n0 + 4 * n4, k = k0 + kr;
         if (FAST) rb[i] = ld4u(B + (int64_t)k * g.sBk + n);
         else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, true);
@@ -507,66 +517,67 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
     }
   };
   auto store_tile = [&](int buf) {
-    unsigned char* as = bf_smem + buf * 2 * kBfImage;
-    unsigned char* bs = as + kBfImage;
+    unsigned char* as = bf_smem + buf * (IMG_A + IMG_B);
+    unsigned char* bs = as + IMG_A;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < NA; i++) {
       if (AKC) {
-        const int k4 = tid & 15, row = (tid >> 4) + 16 * i;
+        const int k4 = tid & 15, row = (tid >> 4) + (NT / 16) * i;
         *reinterpret_cast<uint2*>(as + bf_off_kc(row, k4 >> 1) + 8 * (k4 & 1)) = pack_bf16x4(ra[i]);
       } else {
-        const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;
-        *reinterpret_cast<uint2*>(as + bf_off_kr(kr, m4 >> 1) + 8 * (m4 & 1)) = pack_bf16x4(ra[i]);
+        const int m4 = tid % (BM / 4), kr = tid / (BM / 4) + (4 * NT / BM) * i;
+        *reinterpret_cast<uint2*>(as + bf_off_kr<BM>(kr, m4 >> 1) + 8 * (m4 & 1)) = pack_bf16x4(ra[i]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < NB; i++) {
       if (BKC) {
-        const int k4 = tid & 15, row = (tid >> 4) + 16 * i;
+        const int k4 = tid & 15, row = (tid >> 4) + (NT / 16) * i;
         *reinterpret_cast<uint2*>(bs + bf_off_kc(row, k4 >> 1) + 8 * (k4 & 1)) = pack_bf16x4(rb[i]);
       } else {
-        const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;
-        *reinterpret_cast<uint2*>(bs + bf_off_kr(kr, n4 >> 1) + 8 * (n4 & 1)) = pack_bf16x4(rb[i]);
+        const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;
+        *reinterpret_cast<uint2*>(bs + bf_off_kr<BN>(kr, n4 >> 1) + 8 * (n4 & 1)) = pack_bf16x4(rb[i]);
       }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][2];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < TM; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave / (BN / 64)) * WM, wn0 = (wave % (BN / 64)) * 64;
   const int lr = lane & 31, lh = lane >> 5;
   // transposed-read lane roles: 16-lane group tg, row tq and column quad tp of the 4 x 16 block
   const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
 
   // fragment of the 32-row (or 32-column) tile starting at `o` of an image, k-step s (16 k)
-  auto frag = [&](const unsigned char* img, bool kc, int o, int s) -> bf16x8_t {
+  auto frag = [&](const unsigned char* img, bool kc, auto rowlen_tag, int o, int s) -> bf16x8_t {
+    constexpr int RL = decltype(rowlen_tag)::value;
     if (kc) return *reinterpret_cast<const bf16x8_t*>(img + bf_off_kc(o + lr, 2 * s + lh));
     typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
     const int ch = (o >> 3) + 2 * (tg & 1) + (tp >> 1);
     const int k0r = 16 * s + 8 * (tg >> 1) + tq;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr(k0r, ch) + 8 * (tp & 1)));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr(k0r + 4, ch) + 8 * (tp & 1)));
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<RL>(k0r, ch) + 8 * (tp & 1)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<RL>(k0r + 4, ch) + 8 * (tp & 1)));
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
   auto compute_tile = [&](int buf) {
-    const unsigned char* as = bf_smem + buf * 2 * kBfImage;
-    const unsigned char* bs = as + kBfImage;
+    const unsigned char* as = bf_smem + buf * (IMG_A + IMG_B);
+    const unsigned char* bs = as + IMG_A;
 #pragma unroll
     for (int s = 0; s < BK / 16; s++) {
-      bf16x8_t a[2], b[2];
+      bf16x8_t a[TM], b[2];
 #pragma unroll
-      for (int i = 0; i < 2; i++) a[i] = frag(as, AKC, wm0 + 32 * i, s);
+      for (int i = 0; i < TM; i++) a[i] = frag(as, AKC, std::integral_constant<int, BM>{}, wm0 + 32 * i, s);
 #pragma unroll
-      for (int j = 0; j < 2; j++) b[j] = frag(bs, BKC, wn0 + 32 * j, s);
+      for (int j = 0; j < 2; j++) b[j] = frag(bs, BKC, std::integral_constant<int, BN>{}, wn0 + 32 * j, s);
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmArgs g) {
 
   float* C = g.C;
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < TM; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int n = n0 + wn0 + j * 32 + lr;
@@ -728,7 +739,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
       split_bf16x3(ra[i], p1, p2, p3);
       unsigned o;
       if (AKC) { const int k4 = tid & 7, row = (tid >> 3) + 32 * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
-      else     { const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;  o = bf_off_kr(kr, m4 >> 1) + 8 * (m4 & 1); }
+      else     { const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;  o = bf_off_kr<128>(kr, m4 >> 1) + 8 * (m4 & 1); }
       *reinterpret_cast<uint2*>(as + o) = p1;
       *reinterpret_cast<uint2*>(as + kX3Plane + o) = p2;
       *reinterpret_cast<uint2*>(as + 2 * kX3Plane + o) = p3;
@@ -739,7 +750,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
       split_bf16x3(rb[i], p1, p2, p3);
       unsigned o;
       if (BKC) { const int k4 = tid & 7, row = (tid >> 3) + 32 * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
-      else     { const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;  o = bf_off_kr(kr, n4 >> 1) + 8 * (n4 & 1); }
+      else     { const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;  o = bf_off_kr<128>(kr, n4 >> 1) + 8 * (n4 & 1); }
       *reinterpret_cast<uint2*>(bs + o) = p1;
       *reinterpret_cast<uint2*>(bs + kX3Plane + o) = p2;
       *reinterpret_cast<uint2*>(bs + 2 * kX3Plane + o) = p3;
@@ -761,8 +772,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
     typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
     const int ch = (o >> 3) + 2 * (tg & 1) + (tp >> 1);
     const int k0r = 16 * s + 8 * (tg >> 1) + tq;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr(k0r, ch) + 8 * (tp & 1)));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr(k0r + 4, ch) + 8 * (tp & 1)));
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<128>(k0r, ch) + 8 * (tp & 1)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<128>(k0r + 4, ch) + 8 * (tp & 1)));
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
@@ -1408,14 +1419,24 @@ template <bool AKC, bool BKC, bool MASK_A = false>
 int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return FFH_OK;
   const bool x3 = c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3;      // three bf16 planes per operand: fp32-accurate
-  const int gx = (g.N + kBfBN - 1) / kBfBN, gy = (g.M + kBfBM - 1) / kBfBM;
+  // 256 x 256 tiles (one 8-wave workgroup per CU, 128 x 64 per wave) where the output still fills the chip with them: half
+  // the operand traffic per flop.  Measured at batch 32768: forward 3456 -> 1024 492 -> 353 us, 1024 -> 1024 162 -> 143;
+  // dX +3...6 % from a reduction depth of 1024 up, slower below; the split-K weight-gradient form is slower (-8 %): 128 x 128.
+  static const int tile_env = getenv("FFH_BF16_TILE") ? atoi(getenv("FFH_BF16_TILE")) : 0;
+  const int64_t tiles_big = (int64_t)((g.N + 255) / 256) * ((g.M + 255) / 256);
+  const bool big_form = (AKC && BKC) || (AKC && !BKC && g.K >= 1024);
+  bool big = !x3 && big_form && g.M >= 256 && g.N >= 256 && tiles_big >= c->num_cus;
+  if (tile_env == 128) big = false;
+  if (tile_env == 256 && !x3 && g.M >= 256 && g.N >= 256) big = true;
+  const int bm = big ? 256 : kBfBM, bn = big ? 256 : kBfBN;
+  const int gx = (g.N + bn - 1) / bn, gy = (g.M + bm - 1) / bm;
   g.splitk = 1;
   g.k_per_split = g.K;
   int gz = 1;
   if (g.epi == EPI_ATOMIC && c->deterministic) g.epi = EPI_ADD;
   if (g.epi == EPI_ATOMIC) {
     const int64_t tiles = (int64_t)gx * gy;
-    int want = (int)((2LL * c->num_cus + tiles - 1) / tiles);
+    int want = (int)(((big ? 1LL : 2LL) * c->num_cus + tiles - 1) / tiles);
     const int max_split = (g.K + 4 * kBfBK - 1) / (4 * kBfBK);     // at least four k-tiles per workgroup
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
@@ -1434,6 +1455,15 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     hipLaunchKernelGGL(kern3, dim3(gx, gy, gz), dim3(256), kX3Lds, as_stream(s), g);
     hipError_t e3 = hipGetLastError();
     if (e3 != hipSuccess) return ffh_fail_hip(c, e3, name);
+    return FFH_OK;
+  }
+  if (big) {
+    auto kernw = gemm_bf16_kernel<AKC, BKC, MASK_A, 256, 256, 128>;
+    static const bool okw = glds_set_lds(kernw, bf_lds_bytes(256, 256));
+    if (!okw) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16): cannot reserve 128 KB of LDS");
+    hipLaunchKernelGGL(kernw, dim3(gx, gy, gz), dim3(512), bf_lds_bytes(256, 256), as_stream(s), g);
+    hipError_t ew = hipGetLastError();
+    if (ew != hipSuccess) return ffh_fail_hip(c, ew, name);
     return FFH_OK;
   }
   auto kern = gemm_bf16_kernel<AKC, BKC, MASK_A>;
