@@ -25,6 +25,7 @@ bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.json $O/
 
 # 4. the other workloads (one GPU)
 python3 bench.py --no-cpu-baseline --no-secondary --shim-flags=--allow-tensor-op-math-conversion 2>/dev/null | line > $O/${P}_bench_terabyte_bf16_mode.json
+python3 bench.py --no-cpu-baseline --no-secondary --shim-flags=--fp32-split-bf16x3 2>/dev/null | line > $O/${P}_bench_terabyte_split_bf16x3_mode.json
 python3 bench.py --workload kaggle --steps 300 --warmup 30 2>/dev/null | line > $O/${P}_bench_kaggle.json
 python3 bench.py --workload tiny --steps 500 --warmup 50 2>/dev/null | line > $O/${P}_bench_tiny.json
 python3 bench.py --workload mlperf --steps 50 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | line > $O/${P}_bench_mlperf.json
@@ -48,6 +49,8 @@ python3 tools/gemm_big.py -1 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbe
 python3 tools/gemm_bf16_bench.py 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_bf16_mode.txt
 [ -x tools/lab/gemm_big_lab ] && timeout 300 tools/lab/gemm_big_lab 32768 1024 3456 > $O/${P}_lab_gemm_big.txt 2>&1
 python3 tools/microbench.py emb > $O/${P}_microbench_embedding.txt 2>&1
+# SQ counters of the split-bf16x3 forward GEMM alone (MFMA busy cycles against GRBM_GUI_ACTIVE: what bounds that kernel)
+bash tools/pmc_x3.sh 2 > $O/pmc_x3.log 2>&1; cp gpurun_out/pmc_x3/summary.json $O/${P}_pmc_split_bf16x3_gemm.json
 
 for f in $O/${P}_bench_*.json; do echo "$(basename $f): $(python3 -c "import json,sys; d=json.load(open('$f')); print(d['value'], d['ms_per_step'], d.get('roofline',{}).get('frac'))" 2>&1 | tail -1)"; done
 cat $O/${P}_bench_terabyte_probe_averages.txt
