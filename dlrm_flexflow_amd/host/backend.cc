@@ -19,7 +19,7 @@ std::string default_backend_path() {
 }
 
 const KernelApi* load_kernel_api(const std::string& path_in) {
-  static std::map<std::string, KernelApi*> cache;
+  static std::map<std::string, KernelApi*>& cache = *new std::map<std::string, KernelApi*>();   // one table per library for the life of the process
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
   const std::string path = path_in.empty() ? default_backend_path() : path_in;

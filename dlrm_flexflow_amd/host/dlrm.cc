@@ -62,9 +62,9 @@ Tensor create_mlp(FFModel* model, const Tensor& input, std::vector<int> ln, int 
   Tensor t = input;
   for (int i = 0; i < (int)(ln.size() - 1); i++) {
     float std_dev = std::sqrt(2.0f / (ln[i + 1] + ln[i]));
-    Initializer* weight_init = new NormInitializer(model->next_seed(), 0, std_dev);
+    Initializer* weight_init = model->own(new NormInitializer(model->next_seed(), 0, std_dev));
     std_dev = std::sqrt(2.0f / ln[i + 1]);
-    Initializer* bias_init = new NormInitializer(model->next_seed(), 0, std_dev);
+    Initializer* bias_init = model->own(new NormInitializer(model->next_seed(), 0, std_dev));
     ActiMode activation = i == sigmoid_layer ? AC_MODE_SIGMOID : AC_MODE_RELU;
     t = model->dense(t, ln[i + 1], activation, true /*bias*/, NULL /*weight_sharing*/, weight_init, bias_init);
   }
@@ -75,7 +75,7 @@ Tensor create_mlp(FFModel* model, const Tensor& input, std::vector<int> ln, int 
 Tensor create_emb(FFModel* model, const Tensor& input, int input_dim, int output_dim, int idx) {
   (void)idx;
   float range = std::sqrt(1.0f / input_dim);
-  Initializer* embed_init = new UniformInitializer(model->next_seed(), -range, range);
+  Initializer* embed_init = model->own(new UniformInitializer(model->next_seed(), -range, range));
   return model->embedding(input, input_dim, output_dim, AGGR_MODE_SUM, NULL /*weight_sharing*/, embed_init);
 }
 
@@ -315,7 +315,7 @@ DLRMApp::DLRMApp(int argc, char** argv, const ffcomm* comm) : ff(nullptr), loade
     abort();
   }
   // Use SGD Optimizer
-  Optimizer* optimizer = new SGDOptimizer(ff, 0.01f);
+  optimizer = new SGDOptimizer(ff, 0.01f);
   std::vector<MetricsType> metrics;
   metrics.push_back(METRICS_ACCURACY);
   metrics.push_back(METRICS_MEAN_SQUARED_ERROR);
@@ -328,6 +328,7 @@ DLRMApp::~DLRMApp() {
   if (ff) ff->sync();
   delete loader;
   delete ff;
+  delete optimizer;
 }
 
 void DLRMApp::warmup() {

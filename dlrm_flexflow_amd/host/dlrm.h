@@ -57,6 +57,7 @@ struct DLRMApp {
   DLRMConfig dlrm;
   FFModel* ff;
   DataLoader* loader;
+  Optimizer* optimizer = nullptr;
   std::vector<Tensor> sparse_inputs;
   Tensor dense_input;
   bool warmed_up;

@@ -449,6 +449,7 @@ class FFModel {
   PerfMetrics get_perf_metrics();
   // seeds of the initializers: a private counter-hash sequence from config.seed (the reference draws them from the
   // unseeded global std::rand(), [ref: examples/cpp/DLRM/dlrm.cc:32,34,45] -- any library calling rand() would shift it)
+  Initializer* own(Initializer* init) { owned_initializers.push_back(init); return init; }   // deleted with the model (the reference leaks these)
   int next_seed();
   uint64_t seed_counter;                // device -> host (synchronises)
   void print_layers(int id);
@@ -501,11 +502,13 @@ class FFModel {
   void profiled(const Op* op, bool fwd, const std::function<void()>& fn) const;   // --profiling: one op between two events
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
+  std::vector<Initializer*> owned_initializers;
   int grad_attach_layer;        // the Linear whose backward completes the embedding output gradients (-1: none / not attachable)
   mutable bool grad_ready_attached;
 
   // slabs
   float *mlp_weights, *mlp_grads;  size_t mlp_count;          // all Linear params, contiguous (one all-reduce, one SGD launch)
+  char* act_slab;                                             // every activation that needs its own storage
   char* act_grad_slab;  size_t act_grad_bytes;                // every activation gradient (one memset per step)
   void* workspace;  size_t workspace_bytes;
   ffh_perf_metrics* d_perf;

@@ -410,7 +410,7 @@ FFModel::FFModel(FFConfig& _config)
       metrics_flags(0), seq_length(-1), api(nullptr), ctx(nullptr), stream(nullptr), side_stream(nullptr),
       ev_fork(nullptr), ev_join(nullptr), ev_grad_ready(nullptr), ev_update_done(nullptr), compiled(false),
       emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
-      act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
+      act_slab(nullptr), act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1), inputs_dirty(true), fork_recorded(false) {
   seed_counter = 0;
   dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; need_zero_gsend = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
@@ -463,7 +463,7 @@ FFModel::~FFModel() {
     if (t->ptr && !t->alias && t->bytes) api->ffh_free(ctx, t->ptr);
     delete t;
   }
-  for (void* p : {(void*)mlp_weights, (void*)mlp_grads, (void*)act_grad_slab, workspace, (void*)d_perf, (void*)xsend,
+  for (void* p : {(void*)mlp_weights, (void*)mlp_grads, (void*)act_slab, (void*)act_grad_slab, workspace, (void*)d_perf, (void*)xsend,
                   (void*)xrecv, (void*)gsend, (void*)grecv})
     if (p) api->ffh_free(ctx, p);
   for (Embedding* e : embeddings)
@@ -476,6 +476,9 @@ FFModel::~FFModel() {
   api->ffh_event_destroy(ctx, ev_dw_done);
   api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream);
   api->ffh_ctx_destroy(ctx);
+  for (Op* op : layers) delete op;
+  for (Initializer* i : owned_initializers) delete i;
+  for (Tensor* t : input_tensors) delete t;
 }
 
 void FFModel::check(int rc, const char* what) const {
@@ -1354,7 +1357,7 @@ void FFModel::allocate() {
     act_grad_bytes += b;
     need.push_back(op);
   }
-  char* act_slab = (char*)dmalloc(std::max<size_t>(act_bytes, 256));
+  act_slab = (char*)dmalloc(std::max<size_t>(act_bytes, 256));
   act_grad_slab = (char*)dmalloc(std::max<size_t>(act_grad_bytes, 256));
   size_t off_a = 0;
   for (Op* op : need) {
