@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Random-shape check of ffh_linear_fwd / ffh_linear_bwd_ex on the GPU against the CPU oracle (test infrastructure):
 shapes drawn so that every kernel family of linear.hip is hit (LDS-DMA single / paired launches, register-staged tiles,
-skinny outputs), ragged sizes, strides, all flag combinations.  Usage: tools/fuzz_linear.py [cases] [seed]"""
+skinny outputs), ragged sizes, strides, all flag combinations.  Usage: tools/fuzz_linear.py [cases] [seed] [math_mode]
+math_mode 1 (tensor-op bf16 operands): both sides run in that mode; 2 (fp32-accurate bf16x3 split): the GPU runs in it, the
+oracle computes in fp32 -- same tolerance either way."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -12,6 +14,9 @@ oracle.build()
 hip = capi.load_hip(0)
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+math_mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, math_mode) == 0
+assert oracle.lib().lib.ffh_ctx_set_math_mode(oracle.lib().ctx, math_mode) == 0
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 def close(got, exp, mass, what):
     tol = 2e-5 * mass + 1e-6
@@ -28,6 +33,8 @@ for case in range(ncases):
         B = int(rng.integers(1, 5000)); OUT = int(rng.integers(1, 17)); IN = 4 * int(rng.integers(1, 256 if OUT <= 4 else 65))
     else:              # wide and deep
         B = int(rng.integers(512, 4097)); IN = 4 * int(rng.integers(64, 300)); OUT = 4 * int(rng.integers(64, 300))
+    if math_mode and kind != 2 and rng.integers(0, 4):   # mostly layers the bf16-pipe modes serve (both dims >= 128), any alignment
+        IN = max(IN, 128) + int(rng.integers(0, 4)) * (kind == 1); OUT = max(OUT, 128) + int(rng.integers(0, 4)) * (kind == 1)
     act = int(rng.choice([capi.AC_MODE_NONE, capi.AC_MODE_RELU, capi.AC_MODE_SIGMOID]))
     padx, pady = 4 * int(rng.integers(0, 3)), 4 * int(rng.integers(0, 3))
     x = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32) if rng.integers(0, 2) else rng.uniform(-1, 1, (B, IN)).astype(np.float32)
@@ -66,4 +73,4 @@ for case in range(ncases):
     close(dw.cpu().numpy(), dw_e, a.T @ np.abs(x).astype(np.float64), what + " dw")
     close(db.cpu().numpy(), db_e, a.sum(0), what + " db")
     assert (dxt[:, IN:].cpu().numpy() == 0).all() and (yt[:, OUT:].cpu().numpy() == 7.0).all(), what + ": wrote into the padding"
-print(f"fuzz_linear: {ncases} random cases agree with the oracle")
+print(f"fuzz_linear: {ncases} random cases agree with the oracle" + (f" (math mode {math_mode})" if math_mode else ""))

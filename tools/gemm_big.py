@@ -20,6 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     ref = os.environ.get("FFH_GEMM_CFG", "-1") == "-1"
     for B, IN, OUT in shapes:
         x = torch.randn(B, IN, device="cuda"); w = torch.randn(OUT, IN, device="cuda") * 0.05; b = torch.randn(OUT, device="cuda")
+        if os.environ.get("GEMM_BIG_RELU_X"): x = torch.relu(x)      # operands as the step has them: activations behind a ReLU (half zeros)
         y = torch.empty(B, OUT, device="cuda"); dy = torch.randn(B, OUT, device="cuda"); dx = torch.zeros(B, IN, device="cuda")
         dw = torch.zeros(OUT, IN, device="cuda"); db = torch.zeros(OUT, device="cuda")
         fl = 2.0 * B * IN * OUT
