@@ -313,6 +313,8 @@ def main():
                                                                      "instead of calling RCCL from the C++ host layer")
     ap.add_argument("--cpu-baseline-leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--leg-budget", type=float, default=7.0, help=argparse.SUPPRESS)
+    ap.add_argument("--replicate-embedding-rows", type=int, default=0, help="N > 1: tables with at most this many rows are data-parallel (a copy on every "
+                    "rank, dense gradient in the MLP's all-reduce bucket) instead of table-wise in the all-to-all; 0 (default): every table table-wise")
     ap.add_argument("--shim-flags", default="", help="extra FFConfig flags for A/B runs, e.g. '--serial-dw --no-overlap'")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: ranks rendezvous over gloo and report, no GPU
     ap.add_argument("--functional-test-backend", default="", help=argparse.SUPPRESS)   # tests only: walk this file's whole rank path on the
@@ -386,7 +388,8 @@ def main():
             raise SystemExit(f"global batch {gb} is not divisible by {world} ranks")
     w = workload(args.workload, gb)
     bf16 = "--allow-tensor-op-math-conversion" in args.shim_flags.split()
-    extra = (["--backend", ftest] if ftest else ["--device", str(local_rank)]) + (["--no-trace"] if args.no_trace else []) + (["--force-exchange"] if args.force_exchange else []) + args.shim_flags.split()
+    extra = (["--backend", ftest] if ftest else ["--device", str(local_rank)]) + (["--no-trace"] if args.no_trace else []) + (["--force-exchange"] if args.force_exchange else []) + \
+            (["--replicate-embedding-rows", str(args.replicate_embedding_rows)] if args.replicate_embedding_rows > 0 else []) + args.shim_flags.split()
     app = ffmodel.DLRM(flags_of(w, extra), comm=comm.struct if comm else None)
     trace = not args.no_trace
 
@@ -425,7 +428,9 @@ def main():
     pm = app.model.perf_metrics()                  # loss over the K timed steps (before the kernel probes below touch the tables)
     # per-kernel device time, HIP events on the stream the kernels are launched on (the model's stream)
     T = len(w["rows"].split("-"))
-    owned = len([t for t in range(T) if t % world == rank])
+    rows_of = [int(r) for r in w["rows"].split("-")]
+    replicated = [t for t in range(T) if world > 1 and 0 < rows_of[t] <= args.replicate_embedding_rows]
+    owned = len([t for t in range(T) if t % world == rank and t not in replicated])      # tables in this rank's gather launch / all-to-all
     B, D = w["B"], w["D"]
     table_wise = not any(f in w.get("extra", []) for f in ("--column-shard-rows", "--row-shard-rows")) or world == 1
     n_g = 200 if B * owned <= 65536 else 40
@@ -450,6 +455,8 @@ def main():
     wx = w.get("extra", [])
     layout = ("the table row-wise (partial bag sums + RCCL reduce-scatter fwd, all-gather bwd)" if "--row-shard-rows" in wx else
               "the table column-wise (RCCL all-to-all fwd+bwd)" if "--column-shard-rows" in wx else "tables table-wise, table t on rank t % N (RCCL all-to-all fwd+bwd)")
+    if replicated:
+        layout += f"; the {len(replicated)} tables of <= {args.replicate_embedding_rows} rows data-parallel (a copy per rank, dense gradients in the all-reduce bucket)"
     out = {
         "metric": "dlrm_training_samples_per_sec", "value": round(samples / elapsed, 1), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),

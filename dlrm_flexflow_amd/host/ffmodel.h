@@ -110,6 +110,7 @@ class FFConfig {
   bool attach_events;          // hang ev_grad_ready on the producing kernel's completion instead of a record packet (A/B: --no-attach-event)
   bool timing_events;          // A/B: stream-ordering events created with timestamps, as before
   bool fuse_loss;              // loss step + metrics inside the last layer's one-launch backward (A/B: --no-fused-loss)
+  int64_t replicate_embedding_rows;   // world_size > 1: tables with at most this many rows are data-parallel (replicated) instead of owned by one rank (0: none)
   int64_t row_shard_rows;      // ... row-wise instead: partial bag sums + reduce-scatter (0: never; wins over column_shard_rows)
   bool async_launch;           // auxiliary streams are fed by their own host threads (HIP backend only)
   bool parallel_dw;            // weight-gradient GEMMs on their own stream beside the data-gradient chain
@@ -318,7 +319,14 @@ class Embedding : public Op {
   int64_t* local_idx;           // [batch][bag] ids relative to row_begin (rows held elsewhere -> rows_local)
   float *partial, *gfull;       // [batch][out_channels]: partial sums (reduce-scatter input), gathered gradients
   void set_row_sharding(const FFModel& model, bool on);
-  bool held_here(int rank) const { return owner_rank == rank || column_sharded || row_sharded; }
+  // data-parallel table (the reference's DEFAULT placement: an op without a strategy entry is split on the sample dim and its
+  // weights replicated [ref: src/runtime/model.cc:500-510], gradient synchronised like any parameter's [ref: ncclAllReduce,
+  // src/runtime/optimizer_kernel.cu:170-171]): every rank holds the whole table, gathers its own samples, scatter-adds a dense
+  // gradient [ref: embed_backward, src/ops/embedding.cu:192-217]; table and gradient live in the dense parameter slab, so the
+  // MLP all-reduce bucket and the slab SGD / Adam launch cover them.  --replicate-embedding-rows N or a strategy file.
+  bool replicated;
+  void set_replicated(const FFModel& model, bool on);
+  bool held_here(int rank) const { return owner_rank == rank || column_sharded || row_sharded || replicated; }
 };
 
 class Concat : public Op {

@@ -126,6 +126,7 @@ FFConfig::FFConfig() {
   async_launch = false;   // measured on MI355X / ROCm 7.2: no gain over one issuing thread (280 vs 272 us per Kaggle step)
   column_shard_rows = 0;
   row_shard_rows = 0;
+  replicate_embedding_rows = 0;
   fuse_loss = true;
   timing_events = false;
   attach_events = true;
@@ -183,6 +184,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--async-launch")) { async_launch = true; continue; }
     if (is("--column-shard-rows")) { column_shard_rows = atoll(next()); continue; }
     if (is("--row-shard-rows")) { row_shard_rows = atoll(next()); continue; }
+    if (is("--replicate-embedding-rows")) { replicate_embedding_rows = atoll(next()); continue; }
     if (is("--no-fused-loss")) { fuse_loss = false; continue; }
     if (is("--timing-events")) { timing_events = true; continue; }
     if (is("--no-attach-event")) { attach_events = false; continue; }
@@ -700,7 +702,22 @@ Embedding::Embedding(FFModel& model, const Tensor& input, int _num_entries, int 
   local_idx = nullptr; partial = gfull = nullptr;
   row_sharded = false; row_begin = 0; rows_local = num_entries;
   set_row_sharding(model, model.exchange && model.config.row_shard_rows > 0 && num_entries >= model.config.row_shard_rows);
+  replicated = false;
+  set_replicated(model, model.exchange && model.world_size > 1 && !row_sharded && !column_sharded && model.config.replicate_embedding_rows > 0 &&
+                            num_entries <= model.config.replicate_embedding_rows);
   model.embeddings.push_back(this);
+}
+void Embedding::set_replicated(const FFModel& model, bool on) {
+  if (on && !model.config.comm.allreduce_sum_f32) die("%s: a data-parallel table needs the allreduce callback of ffcomm", this->name);
+  replicated = on;
+  if (on) {
+    set_row_sharding(model, false);
+    column_sharded = false;
+    local_cols = out_channels;
+    owner_rank = -1;                                   // every rank holds it
+  } else if (owner_rank < 0 && !row_sharded) {
+    owner_rank = table_index % model.world_size;
+  }
 }
 void Embedding::set_row_sharding(const FFModel& model, bool on) {
   if (on && (!model.config.comm.reduce_scatter_sum_f32 || !model.config.comm.allgather_f32))
@@ -741,6 +758,18 @@ void Embedding::backward(const FFModel& ff) {
   // reverse layer order: the LAST table is visited first; every table's output gradient is
   // complete by then (their only consumer ran already), so the group update can start.
   if (table_index != (int)ff.embeddings.size() - 1) return;
+  // data-parallel (replicated) tables: the reference's own backward [ref: embed_backward, src/ops/embedding.cu:192-217,308-320]
+  // -- a dense scatter-add of this rank's samples into the table's gradient in the dense slab, on the compute stream: the
+  // slab's all-reduce and optimizer launch in update() then treat it like any MLP parameter
+  for (Embedding* e : ff.embeddings) {
+    if (!e->replicated) continue;
+    const Tensor& in = e->inputs[0];
+    const Tensor& out = e->outputs[0];
+    const int Lr = in.adim[0];
+    ff.check(ff.api->ffh_embedding_bwd_dense(ff.ctx, (const int64_t*)in.impl->ptr + (int64_t)ff.rank * ff.local_batch * Lr, out.impl->grad,
+                                             e->weights[0].impl->grad, Lr, e->out_channels, ff.local_batch, e->num_entries, out.impl->grad_ld,
+                                             (int)e->aggr, ff.stream), e->name);
+  }
   if (ff.fused_embedding_update()) {
     if (ff.config.overlap_embedding) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
@@ -756,7 +785,7 @@ void Embedding::backward(const FFModel& ff) {
   }
   // reference path: dense scatter-add into the full-table gradient [ref: src/ops/embedding.cu:308-320]
   for (Embedding* e : ff.embeddings) {
-    if (e->owner_rank != ff.rank) continue;
+    if (e->owner_rank != ff.rank || e->replicated) continue;
     const Tensor& in = e->inputs[0];
     const Tensor& out = e->outputs[0];
     const float* g = out.impl->grad;
@@ -1036,6 +1065,13 @@ Tensor FFModel::flat(const Tensor& input, const char* name) {
   return r->outputs[0];
 }
 
+// Parameters that live in the dense slab (one all-reduce bucket, one optimizer launch): Linear weights / biases and the
+// tables of data-parallel (replicated) embeddings.
+static bool in_dense_slab(const Parameter& p) {
+  if (p.owner_op->op_type == OP_LINEAR) return true;
+  return p.owner_op->op_type == OP_EMBEDDING && static_cast<const Embedding*>(p.owner_op)->replicated;
+}
+
 // =============================================================================================
 // SGDOptimizer [ref: src/runtime/optimizer.cc:43-189]
 // =============================================================================================
@@ -1075,7 +1111,7 @@ void AdamOptimizer::init(void) {
   };
   if (model->mlp_count) { mlp_m = zeros(model->mlp_count); mlp_v = zeros(model->mlp_count); }
   for (const Parameter& p : model->parameters) {
-    if (p.owner_op->op_type == OP_LINEAR || !p.impl->grad) continue;
+    if (in_dense_slab(p) || !p.impl->grad) continue;
     mv_values[p.impl->ptr] = std::make_pair(zeros(p.get_volume()), zeros(p.get_volume()));
   }
 }
@@ -1088,7 +1124,7 @@ void AdamOptimizer::next(void) {
 void AdamOptimizer::update(const Parameter* p) {
   if (!p->impl->grad) return;
   float *m, *v;
-  if (p->owner_op->op_type == OP_LINEAR) {
+  if (in_dense_slab(*p)) {
     const size_t off = (size_t)((float*)p->impl->ptr - model->mlp_weights);
     m = mlp_m + off; v = mlp_v + off;
   } else {
@@ -1133,19 +1169,27 @@ void FFModel::apply_strategies() {
     for (int id : pc.device_ids)
       if (id < 0 || id >= world_size) die("%s: strategy names device %d, the job has %d rank(s)", op->name, id, world_size);
     if (Embedding* e = dynamic_cast<Embedding*>(op)) {
-      // one table on one device (what dlrm_strategy.cc emits); a table split over the sample dim would be a
-      // replicated table with an all-reduced dense gradient -- the reference's default, not built here
+      // one table on one device (what dlrm_strategy.cc emits), or split over the sample dim: a data-parallel table, replicated
+      // with an all-reduced dense gradient -- what the reference does with an op that has no strategy entry
+      if (pc.num_parts() == world_size && world_size > 1 && pc.is_data_parallel()) {
+        for (size_t j = 0; j < pc.device_ids.size(); j++)
+          if (pc.device_ids[j] != (int)j) die("%s: data-parallel parts must sit on devices 0..%d in order", op->name, world_size - 1);
+        e->set_replicated(*this, true);
+        continue;
+      }
       if (pc.num_parts() == world_size && world_size > 1 && pc.dim[0] == world_size) {
         // this build's own extension, as --export writes it: the table split column-wise over all ranks
         if (e->out_channels % world_size) die("%s: out_dim %d is not divisible by %d ranks", op->name, e->out_channels, world_size);
         for (size_t j = 0; j < pc.device_ids.size(); j++)
           if (pc.device_ids[j] != (int)j) die("%s: column blocks must sit on devices 0..%d in order", op->name, world_size - 1);
+        e->set_replicated(*this, false);
         e->set_row_sharding(*this, false);
         e->column_sharded = true;
         e->local_cols = e->out_channels / world_size;
         continue;
       }
       if (pc.num_parts() != 1) die("%s: an embedding can only be placed whole on one device (dims all 1), the strategy splits it %d ways", op->name, pc.num_parts());
+      e->set_replicated(*this, false);
       e->set_row_sharding(*this, false);
       e->owner_rank = pc.device_ids.empty() ? 0 : pc.device_ids[0];
       e->column_sharded = false;
@@ -1166,9 +1210,9 @@ void FFModel::apply_strategies() {
       pc.nDims = op->outputs[0].numDim;
       Embedding* e = dynamic_cast<Embedding*>(op);
       if (e && e->row_sharded) continue;              // no output dim is split: the file format cannot say it; the flag stays in charge
-      if (e && !e->column_sharded) {
+      if (e && !e->column_sharded && !e->replicated) {
         pc.device_ids.push_back(e->owner_rank);
-      } else if (e) {
+      } else if (e && e->column_sharded) {
         pc.dim[0] = world_size;                       // column-wise giant table: split on the channel dim (this build's extension)
         for (int j = 0; j < world_size; j++) pc.device_ids.push_back(j);
       } else {
@@ -1221,7 +1265,12 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
   }
   if (exchange && config.enable_graph) config.enable_graph = false;   // collectives are host callbacks: not capturable
   if (dynamic_cast<AdamOptimizer*>(optimizer) && config.enable_graph) config.enable_graph = false;   // alpha_t is a new launch argument every step
-  if (exchange && !fused_embedding_update()) die("multi-rank runs need the fused embedding update (plain SGD)");
+  // tables that one rank owns (or holds a slice of) are updated by the fused sparse kernel; only a purely data-parallel job --
+  // every table replicated, the reference's default placement -- can run any optimizer on several ranks
+  bool all_replicated = true;
+  for (const Embedding* e : embeddings) all_replicated = all_replicated && e->replicated;
+  if (exchange && !all_replicated && !fused_embedding_update())
+    die("multi-rank runs need the fused embedding update (plain SGD) unless every table is data-parallel (--replicate-embedding-rows)");
   allocate();
   for (Op* op : layers) {
     if (Linear* li = dynamic_cast<Linear*>(op)) {
@@ -1290,6 +1339,8 @@ void FFModel::allocate() {
       e->local_idx = (int64_t*)dmalloc(ids * sizeof(int64_t));
       e->partial = (float*)dmalloc(fl * 4);
       e->gfull = (float*)dmalloc(fl * 4);
+    } else if (e->replicated) {
+      // data-parallel: every rank gathers its own samples from its copy; nothing of it crosses the all-to-all
     } else if (e->column_sharded) {
       for (int g = 0; g < world_size; g++) shards.push_back({e, g, g * e->local_cols, e->local_cols, 0});
     } else {
@@ -1323,7 +1374,7 @@ void FFModel::allocate() {
       const Tensor& in = c->inputs[i];
       const bool producer_ok = in.owner_op && (in.owner_op->op_type == OP_LINEAR || in.owner_op->op_type == OP_EMBEDDING || in.owner_op->op_type == OP_TRIL);
       // (a row-sharded table's output is the contiguous receive buffer of its reduce-scatter: own storage as well)
-      const bool via_exchange = exchange && in.owner_op && in.owner_op->op_type == OP_EMBEDDING;
+      const bool via_exchange = exchange && in.owner_op && in.owner_op->op_type == OP_EMBEDDING && !static_cast<const Embedding*>(in.owner_op)->replicated;
       if (producer_ok && !via_exchange && consumers[in.impl] == 1 && !alias_of.count(in.impl)) alias_of[in.impl] = {c, off};
       off += in.adim[0];
     }
@@ -1350,7 +1401,7 @@ void FFModel::allocate() {
     TensorImpl* im = op->outputs[0].impl;
     if (alias_of.count(im)) continue;
     if (Reshape* r = dynamic_cast<Reshape*>(op)) if (r->is_view) continue;
-    if (exchange && op->op_type == OP_EMBEDDING && !static_cast<Embedding*>(op)->row_sharded) continue;   // lives in xrecv / gsend
+    if (exchange && op->op_type == OP_EMBEDDING && !static_cast<Embedding*>(op)->row_sharded && !static_cast<Embedding*>(op)->replicated) continue;   // lives in xrecv / gsend
     const Tensor& o = op->outputs[0];
     const size_t b = align_up((size_t)(o.rows() / world_size) * o.adim[0] * 4);
     act_bytes += b;
@@ -1458,7 +1509,8 @@ void FFModel::allocate() {
       for (int i = 0; i < c->numInputs; i++) {
         TensorImpl* im = c->inputs[i].impl;
         const bool via_exchange = exchange && c->inputs[i].owner_op && c->inputs[i].owner_op->op_type == OP_EMBEDDING &&
-                                  !static_cast<const Embedding*>(c->inputs[i].owner_op)->row_sharded;
+                                  !static_cast<const Embedding*>(c->inputs[i].owner_op)->row_sharded &&
+                                  !static_cast<const Embedding*>(c->inputs[i].owner_op)->replicated;
         if (via_exchange && !c->bwd_overwrite) need_zero_gsend = true;
         if (im->grad && !im->grad_alias && !via_exchange && im->pieces.empty() && !c->bwd_overwrite) need_zero_act_grads = true;   // add_with_stride accumulates
       }
@@ -1523,7 +1575,7 @@ void FFModel::allocate() {
   // ---- 5. parameters: one slab for every Linear tensor, tables on their own ---------------------
   mlp_count = 0;
   for (Parameter& p : parameters)
-    if (p.owner_op->op_type == OP_LINEAR) mlp_count += (p.get_volume() + 3) / 4 * 4;
+    if (in_dense_slab(p)) mlp_count += (p.get_volume() + 3) / 4 * 4;
   mlp_weights = (float*)dmalloc(std::max<size_t>(mlp_count, 64) * 4);
   mlp_grads = (float*)dmalloc(std::max<size_t>(mlp_count, 64) * 4);
   check(api->ffh_zero(ctx, mlp_weights, std::max<size_t>(mlp_count, 64) * 4, stream), "zero");
@@ -1534,7 +1586,7 @@ void FFModel::allocate() {
     TensorImpl* im = p.impl;
     im->ld = p.adim[0];
     im->rows_local = (int64_t)(p.get_volume() / (size_t)p.adim[0]);
-    if (p.owner_op->op_type == OP_LINEAR) {
+    if (in_dense_slab(p)) {
       im->ptr = mlp_weights + off_p;
       im->grad = mlp_grads + off_p;
       im->grad_ld = im->ld;
@@ -1637,9 +1689,29 @@ void FFModel::embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx) const {
     if (!shards.empty() && config.comm.alltoall_f32(config.comm.user, xsend, fwd_send_counts.data(), xrecv, fwd_recv_counts.data(), s) != 0)
       die("alltoall (embedding forward) failed");
   }
+  ffh_ctx* cx = on_ctx ? on_ctx : ctx;
+  // data-parallel (replicated) tables: this rank's samples from this rank's copy, straight into the outputs; one launch
+  {
+    std::vector<ffh_emb_table> tabs;
+    const int Lr = embeddings[0]->inputs[0].adim[0];
+    for (const Embedding* e : embeddings) {
+      if (!e->replicated) continue;
+      ffh_emb_table t;
+      t.idx = (const int64_t*)e->inputs[0].impl->ptr + (int64_t)rank * local_batch * Lr;   // every rank holds the ids of the global batch
+      t.weight = (float*)e->weights[0].impl->ptr;
+      t.num_entries = e->num_entries;
+      t.io = (float*)e->outputs[0].impl->ptr;
+      t.ld = e->outputs[0].impl->ld;
+      tabs.push_back(t);
+    }
+    for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
+      const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
+      check(api->ffh_embedding_fwd_multi(cx, tabs.data() + b, n, Lr, embeddings[0]->out_channels, local_batch, (int)embeddings[0]->aggr, s),
+            "embedding_fwd_multi (data-parallel tables)");
+    }
+  }
   // row-wise sharded tables: partial bag sums of the GLOBAL batch over the rows held here (rows held elsewhere read the
   // zero row), then the ranks' partials are added and every rank keeps its own samples
-  ffh_ctx* cx = on_ctx ? on_ctx : ctx;
   for (const Embedding* e : embeddings) {
     if (!e->row_sharded) continue;
     const int L = e->inputs[0].adim[0], D = e->out_channels;
@@ -1912,7 +1984,7 @@ void FFModel::update() {
     }
   } else if (sgd->momentum > 0.0) {
     for (const Parameter& p : parameters)
-      if (p.owner_op->op_type == OP_LINEAR) sgd->update(&p);
+      if (in_dense_slab(p)) sgd->update(&p);
   } else if (mlp_count) {
     check(api->ffh_sgd_update_ex(ctx, mlp_weights, mlp_grads, nullptr, (int64_t)mlp_count, (float)sgd->lr, (float)sgd->weight_decay, 0.0f,
                                  0, FFH_OPT_ZERO_GRAD, stream), "sgd_update (MLP slab)");

@@ -24,10 +24,12 @@ def main():
     rank = dist.get_rank()
     comm = TorchComm(on_gpu=False)
     out = {}
-    if mode in ("golden", "column", "strategy", "row"):
+    if mode in ("golden", "column", "strategy", "row", "replicated", "replicated_all", "replicated_adam"):
         extra = ["--import", os.path.join(outdir, "strategy.txt"), "--export", os.path.join(outdir, "export.txt")] if mode == "strategy" else []
         m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True,
-                                   column_shard_rows=40 if mode == "column" else 0, row_shard_rows=40 if mode == "row" else 0, extra_argv=extra)
+                                   column_shard_rows=40 if mode == "column" else 0, row_shard_rows=40 if mode == "row" else 0, extra_argv=extra,
+                                   replicate_rows={"replicated": 39, "replicated_all": 1000, "replicated_adam": 1000}.get(mode, 0),
+                                   adam=dict(alpha=0.001) if mode == "replicated_adam" else None)
         recs = H.run_steps(m, h, 2)
         for step, rec in enumerate(recs):
             for k, v in rec.items():

@@ -53,9 +53,10 @@ def main():
     column = len(sys.argv) > 3 and sys.argv[3] == "column"     # the 50-row table of the golden model split column-wise over the ranks
     row = len(sys.argv) > 3 and sys.argv[3] == "row"           # ... row-wise: partial sums + reduce-scatter, all-gather backward
     strategy = len(sys.argv) > 3 and sys.argv[3] == "strategy" # table owners from <outdir>/strategy.txt (reference text format)
+    replicated = len(sys.argv) > 3 and sys.argv[3] == "replicated"   # tables of <= 39 rows data-parallel (every rank holds a copy)
     sx = ["--import", os.path.join(outdir, "strategy.txt"), "--export", os.path.join(outdir, "export.txt")] if strategy else []
     m, h = H.build_golden_dlrm(capi.HIP_LIB_PATH, comm=comm.struct, overlap=True, force_exchange=True, extra_argv=["--device", "0"] + sx,
-                               column_shard_rows=40 if column else 0, row_shard_rows=40 if row else 0)
+                               column_shard_rows=40 if column else 0, row_shard_rows=40 if row else 0, replicate_rows=39 if replicated else 0)
     recs = H.run_steps(m, h, 2)
     for step, rec in enumerate(recs):
         for k, v in rec.items():

@@ -20,7 +20,7 @@ def oracle_backend():
 
 
 def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dense_update=False, g=None, force_exchange=False,
-                      column_shard_rows=0, extra_argv=(), adam=None, row_shard_rows=0):
+                      column_shard_rows=0, extra_argv=(), adam=None, row_shard_rows=0, replicate_rows=0):
     """Returns (model, handles) with weights and inputs of the golden fixture loaded.
     With `comm` (world_size > 1) each rank loads its batch slice / its tables."""
     g = g or golden("dlrm_step_torch")
@@ -33,6 +33,8 @@ def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dens
         argv += ["--column-shard-rows", str(column_shard_rows)]
     if row_shard_rows:
         argv += ["--row-shard-rows", str(row_shard_rows)]
+    if replicate_rows:
+        argv += ["--replicate-embedding-rows", str(replicate_rows)]
     cfg = ffmodel.FFConfig(argv=argv + list(extra_argv), backend=backend, comm=comm)
     cfg.set(enable_graph=enable_graph, overlap_embedding=overlap, dense_embedding_update=dense_update)
     m = ffmodel.FFModel(cfg)

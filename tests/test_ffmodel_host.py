@@ -278,6 +278,74 @@ def test_row_sharded_giant_table(tmp_path, world):
     assert small_seen == {0, 2, 3}
 
 
+@pytest.mark.parametrize("world,mode", [(2, "replicated"), (4, "replicated"), (2, "replicated_all")])
+def test_data_parallel_replicated_tables(tmp_path, world, mode):
+    """--replicate-embedding-rows N: tables with at most N rows are data-parallel -- the reference's default placement for an
+    op without a strategy entry [ref: src/runtime/model.cc:500-510]: every rank holds the table, gathers its own samples and
+    scatter-adds a dense gradient that rides in the MLP's all-reduce bucket; the 50-row table stays table-wise in the
+    all-to-all (mode replicated) or nothing is exchanged at all (replicated_all).  Every copy must equal the 1-rank table."""
+    _run_ranks(world, tmp_path, mode)
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    B = int(h["g"]["B"])
+    rows = list(h["g"]["rows"])
+    repl = [t for t, r in enumerate(rows) if r <= (39 if mode == "replicated" else 1000)]
+    assert repl == ([0, 2, 3] if mode == "replicated" else [0, 1, 2, 3])
+    owners_of_big = []
+    for r in range(world):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        sl = slice(r * B // world, (r + 1) * B // world)
+        for step in range(2):
+            np.testing.assert_allclose(z[f"s{step}/pred"], ref[step]["pred"][sl], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(z[f"s{step}/top.0.weight"], ref[step]["top.0.weight"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(z[f"s{step}/bot.0.bias"], ref[step]["bot.0.bias"], rtol=1e-5, atol=1e-6)
+            for t in repl:       # a copy on every rank; dense atomics + all-reduce instead of the canonical order: 1e-5, not bit-exact
+                np.testing.assert_allclose(z[f"s{step}/emb.{t}.weight"], ref[step][f"emb.{t}.weight"], rtol=1e-5, atol=1e-6, err_msg=f"rank {r} table {t}")
+        if mode == "replicated":
+            if "s1/emb.1.weight" in z.files:
+                owners_of_big.append(r)
+                np.testing.assert_allclose(z["s1/emb.1.weight"], ref[1]["emb.1.weight"], rtol=1e-6, atol=1e-7)
+            assert int(z["alltoall_calls"]) == 4 and int(z["allreduce_calls"]) == 2
+        else:
+            assert int(z["alltoall_calls"]) == 0 and int(z["allreduce_calls"]) == 2
+    if mode == "replicated":
+        assert owners_of_big == [1]
+
+
+def test_data_parallel_tables_from_a_strategy_file_and_under_adam(tmp_path):
+    """A strategy file that splits two tables over the sample dim (the reference's data-parallel config) replicates them;
+    --export writes that placement back.  And a purely data-parallel job (every table replicated: the reference's default
+    placement) under Adam, whose moments for the tables live in the slab: the one multi-rank case that can leave plain SGD."""
+    g = golden("dlrm_step_torch")
+    nb = len(g["bot"]) - 1
+    entries = [(f"Embedding_{100 + nb + 0}", [1, 2], [0, 1]), (f"Embedding_{100 + nb + 2}", [1, 2], [0, 1])]
+    (tmp_path / "strategy.txt").write_text(_strategy_text(entries))
+    _run_ranks(2, tmp_path, "strategy")
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    for r in range(2):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        for t in (0, 2):
+            np.testing.assert_allclose(z[f"s1/emb.{t}.weight"], ref[1][f"emb.{t}.weight"], rtol=1e-5, atol=1e-6)
+        assert ("s1/emb.1.weight" in z.files) == (r == 1) and ("s1/emb.3.weight" in z.files) == (r == 1)   # the others: table t on rank t % 2
+        np.testing.assert_allclose(z["s1/top.0.weight"], ref[1]["top.0.weight"], rtol=1e-5, atol=1e-6)
+    exp = _parse_strategy(tmp_path / "export.txt")
+    assert exp[f"Embedding_{100 + nb + 0}"] == (0, [1, 2], [0, 1]) and exp[f"Embedding_{100 + nb + 1}"] == (0, [1, 1], [1])
+    # Adam
+    (tmp_path / "adam").mkdir()
+    _run_ranks(2, tmp_path / "adam", "replicated_adam")
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=False, adam=dict(alpha=0.001))
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    for r in range(2):
+        z = np.load(os.path.join(tmp_path / "adam", f"rank{r}.npz"))
+        for t in (0, 1, 2, 3):
+            np.testing.assert_allclose(z[f"s1/emb.{t}.weight"], ref[1][f"emb.{t}.weight"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(z["s1/top.0.weight"], ref[1]["top.0.weight"], rtol=1e-5, atol=2e-6)
+
+
 def _strategy_text(entries):
     """The reference's text format [ref: src/runtime/strategy.cc:147-189]: count, then per op name / device type /
     nDims / dims / number of ids / ids, one per line, lists tab-separated."""

@@ -283,6 +283,31 @@ def test_ranks_on_one_gpu_row_sharded_table(hip, tmp_path, world):
         assert int(z[r]["reduce_scatter_calls"]) == 2 and int(z[r]["allgather_calls"]) == 2
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_data_parallel_tables(hip, tmp_path, world):
+    """--replicate-embedding-rows on the HIP kernels: the three small tables are data-parallel (every rank a copy in the dense
+    slab: own-sample gather, ffh_embedding_bwd_dense into the slab gradient, the MLP's all-reduce bucket and SGD launch), the
+    50-row table stays table-wise in the all-to-all.  Every copy equals the single-rank table to 1e-5."""
+    z = _run_two_ranks_on_one_gpu(tmp_path, "replicated", world=world)
+    m, h = H.build_golden_dlrm(HIP, overlap=False)
+    ref = H.run_steps(m, h, 2)
+    m.close()
+    B = int(h["g"]["B"])
+    owners = []
+    for r in range(world):
+        sl = slice(r * B // world, (r + 1) * B // world)
+        for step in range(2):
+            np.testing.assert_allclose(z[r][f"s{step}/pred"], ref[step]["pred"][sl], rtol=1e-5, atol=1e-6)
+            for t in (0, 2, 3):
+                np.testing.assert_allclose(z[r][f"s{step}/emb.{t}.weight"], ref[step][f"emb.{t}.weight"], rtol=1e-5, atol=1e-6, err_msg=f"rank {r} table {t}")
+        np.testing.assert_allclose(z[r]["s1/top.0.weight"], ref[1]["top.0.weight"], rtol=1e-5, atol=1e-6)
+        if "s1/emb.1.weight" in z[r].files:
+            owners.append(r)
+            np.testing.assert_allclose(z[r]["s1/emb.1.weight"], ref[1]["emb.1.weight"], rtol=1e-6, atol=1e-7)
+        assert int(z[r]["alltoall_calls"]) == 4 and int(z[r]["allreduce_calls"]) == 2
+    assert owners == [1]
+
+
 def test_single_rank_rccl_reduce_scatter_path_on_gpu(hip, tmp_path):
     """The same row-sharded step with a 1-rank RCCL group served from the C++ host layer: ncclReduceScatter /
     ncclAllGather are really enqueued on the model's side stream (with one rank they move the data unchanged)."""

@@ -163,3 +163,17 @@ def test_bench_as_a_rank_under_torchrun_functional_on_cpu(oracle):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["ranks_observed"] == 2 and d["steps"] == 2
+
+
+def test_bench_two_ranks_with_data_parallel_tables_functional_on_cpu(oracle):
+    """--replicate-embedding-rows: all eight 1000-row tables of the tiny workload become data-parallel -- no all-to-all is
+    issued at all, the table gradients ride in the one all-reduce per step, and the line says which layout ran."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1", "--replicate-embedding-rows", "1000",
+                        "--functional-test-backend", oracle.ORACLE_LIB], env=_bench_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_observed"] == 2
+    assert "data-parallel" in d["config"]["parallelism"]
+    c = d["config"]["collective_calls_rank0"]
+    assert c["alltoall"] == 0 and c["allreduce"] == 1 + 1 + 3
+    assert d["value"] > 0
