@@ -500,6 +500,7 @@ class FFModel {
   // embedding group (all Embedding ops share L, D, aggr in DLRM): batched launches + exchange
   std::vector<Embedding*> embeddings;
   void embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx = nullptr) const;   // on_ctx: the issuing thread's ctx
+  void replicated_embedding_grads() const;                     // dense gradient of the data-parallel tables into the slab (compute stream)
   void embedding_group_update(ffh_stream s, ffh_ctx* on_ctx = nullptr) const;
   void embedding_kernels_only(bool fwd, ffh_stream s) const;                      // this rank's gather / fused update kernels, no exchange
   bool fused_embedding_update() const;
@@ -519,6 +520,7 @@ class FFModel {
   char* act_slab;                                             // every activation that needs its own storage
   char* act_grad_slab;  size_t act_grad_bytes;                // every activation gradient (one memset per step)
   void* workspace;  size_t workspace_bytes;
+  void* repl_workspace;  size_t repl_workspace_bytes;          // scratch of the data-parallel tables' gradient (own buffer: it runs beside the side-stream update)
   ffh_perf_metrics* d_perf;
   // one unit of the exchange: a whole table (table-wise) or a column block of a giant table (column-wise)
   struct EmbShard { Embedding* e; int owner; int col0; int cols; int64_t off; };

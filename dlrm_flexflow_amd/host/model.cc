@@ -412,7 +412,7 @@ FFModel::FFModel(FFConfig& _config)
       metrics_flags(0), seq_length(-1), api(nullptr), ctx(nullptr), stream(nullptr), side_stream(nullptr),
       ev_fork(nullptr), ev_join(nullptr), ev_grad_ready(nullptr), ev_update_done(nullptr), compiled(false),
       emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
-      act_slab(nullptr), act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), d_perf(nullptr),
+      act_slab(nullptr), act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), repl_workspace(nullptr), repl_workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1), inputs_dirty(true), fork_recorded(false) {
   seed_counter = 0;
   dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; need_zero_gsend = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
@@ -465,7 +465,7 @@ FFModel::~FFModel() {
     if (t->ptr && !t->alias && t->bytes) api->ffh_free(ctx, t->ptr);
     delete t;
   }
-  for (void* p : {(void*)mlp_weights, (void*)mlp_grads, (void*)act_slab, (void*)act_grad_slab, workspace, (void*)d_perf, (void*)xsend,
+  for (void* p : {(void*)mlp_weights, (void*)mlp_grads, (void*)act_slab, (void*)act_grad_slab, workspace, repl_workspace, (void*)d_perf, (void*)xsend,
                   (void*)xrecv, (void*)gsend, (void*)grecv})
     if (p) api->ffh_free(ctx, p);
   for (Embedding* e : embeddings)
@@ -758,18 +758,10 @@ void Embedding::backward(const FFModel& ff) {
   // reverse layer order: the LAST table is visited first; every table's output gradient is
   // complete by then (their only consumer ran already), so the group update can start.
   if (table_index != (int)ff.embeddings.size() - 1) return;
-  // data-parallel (replicated) tables: the reference's own backward [ref: embed_backward, src/ops/embedding.cu:192-217,308-320]
-  // -- a dense scatter-add of this rank's samples into the table's gradient in the dense slab, on the compute stream: the
-  // slab's all-reduce and optimizer launch in update() then treat it like any MLP parameter
-  for (Embedding* e : ff.embeddings) {
-    if (!e->replicated) continue;
-    const Tensor& in = e->inputs[0];
-    const Tensor& out = e->outputs[0];
-    const int Lr = in.adim[0];
-    ff.check(ff.api->ffh_embedding_bwd_dense(ff.ctx, (const int64_t*)in.impl->ptr + (int64_t)ff.rank * ff.local_batch * Lr, out.impl->grad,
-                                             e->weights[0].impl->grad, Lr, e->out_channels, ff.local_batch, e->num_entries, out.impl->grad_ld,
-                                             (int)e->aggr, ff.stream), e->name);
-  }
+  // data-parallel (replicated) tables: their dense gradient [ref: embed_backward, src/ops/embedding.cu:192-217,308-320] goes
+  // into the dense slab on the compute stream; the slab's all-reduce and optimizer launch in update() then treat it like any
+  // MLP parameter
+  ff.replicated_embedding_grads();
   if (ff.fused_embedding_update()) {
     if (ff.config.overlap_embedding) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
@@ -1617,6 +1609,13 @@ void FFModel::allocate() {
     if (e->row_sharded) workspace_bytes = std::max(workspace_bytes, api->ffh_embedding_bwd_workspace_bytes(1, L, D, config.batchSize) + 256);
   workspace = dmalloc(workspace_bytes);
   check(api->ffh_ctx_set_workspace(ctx, workspace, workspace_bytes), "set workspace");
+  int n_replicated = 0;
+  for (Embedding* e : embeddings) n_replicated += e->replicated;
+  repl_workspace = nullptr; repl_workspace_bytes = 0;
+  if (n_replicated) {
+    repl_workspace_bytes = api->ffh_embedding_bwd_workspace_bytes(std::min(n_replicated, FFH_MAX_TABLES), L, D, local_batch) + 256;
+    repl_workspace = dmalloc(repl_workspace_bytes);
+  }
   if (side_worker) check(api->ffh_ctx_set_workspace(side_worker->ctx(), workspace, workspace_bytes), "set workspace");   // the only other user
   layer_events.resize(layers.size(), nullptr);
   for (ffh_event& e : layer_events) check(api->ffh_event_create(ctx, &e), "event create");
@@ -1722,6 +1721,35 @@ void FFModel::embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx) const {
     if (config.comm.reduce_scatter_sum_f32(config.comm.user, e->partial, (float*)e->outputs[0].impl->ptr, local_batch * D, s) != 0)
       die("reduce-scatter (row-sharded embedding forward) failed");
   }
+}
+
+// Gradient of the data-parallel tables: G[row] += sum of this rank's gradient rows that looked the row up.  The reference
+// scatter-adds with atomics; these are the SMALL tables (3 ... a few thousand rows), where a rank's samples pile hundreds of
+// adds onto one address and atomics serialise.  The fused sparse kernels already compute exactly these segmented sums
+// (sort + reduce, W[row] -= lr * sum): pointed at the zeroed slab gradient with lr = -1 they leave G = 0 + sum -- no
+// atomics, a fixed order.  They need the scratch workspace, which the side-stream update of the owned tables may be using:
+// this call brings its own (workspace pointers are read at launch time, so switching between launches is safe).
+void FFModel::replicated_embedding_grads() const {
+  if (!repl_workspace) return;
+  std::vector<ffh_emb_table> tabs;
+  const int L = embeddings[0]->inputs[0].adim[0], D = embeddings[0]->out_channels;
+  for (const Embedding* e : embeddings) {
+    if (!e->replicated) continue;
+    ffh_emb_table t;
+    t.idx = (const int64_t*)e->inputs[0].impl->ptr + (int64_t)rank * local_batch * L;
+    t.weight = e->weights[0].impl->grad;
+    t.num_entries = e->num_entries;
+    t.io = e->outputs[0].impl->grad;
+    t.ld = e->outputs[0].impl->grad_ld;
+    tabs.push_back(t);
+  }
+  check(api->ffh_ctx_set_workspace(ctx, repl_workspace, repl_workspace_bytes), "set workspace");
+  for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
+    const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
+    check(api->ffh_embedding_bwd_sgd_fused_multi(ctx, tabs.data() + b, n, L, D, local_batch, (int)embeddings[0]->aggr, -1.0f, stream),
+          "embedding gradient (data-parallel tables)");
+  }
+  check(api->ffh_ctx_set_workspace(ctx, workspace, workspace_bytes), "set workspace");
 }
 
 void FFModel::embedding_group_update(ffh_stream s, ffh_ctx* on_ctx) const {
