@@ -88,6 +88,96 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* _
   }
 }
 
+// Forward for the shape the models use (d = 128, 16-byte aligned rows).  The register-fed kernel above reads each row as
+// 16-byte pieces 64 bytes apart (32 rows x 2 pieces per instruction) because that is the MFMA operand layout: 0.40 of the
+// HBM rate.  Here the sample goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes = two whole 512-byte
+// rows per instruction, fully coalesced, no staging registers, no ds_write), double-buffered per wave: the next sample's 14
+// pieces are issued one per four MFMAs of this one.  The MFMA operand is then one conflict-free ds_read_b128 per four k
+// (lane (r, h) takes k = 8 j + 4 h + e).  The image is lane-linear (a DMA writes base + 16 lane), so the swizzle that keeps the
+// rows of a ds_read_b128 off each other's banks sits on the SOURCE side: position p of row r holds chunk p ^ (r & 15) (the
+// lane groups of ds_read_b128 -- {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... -- hold sixteen distinct r & 15 each).  Rows >= c
+// of the image are never written: whatever they hold only reaches accumulator entries with i >= c or j >= c, which are not
+// stored.  8192 samples: 40.2 -> 28.5 us (0.57); 65536: 336 -> 247 us.  Measured and not better: operands read whole into
+// registers with two samples in flight (29.4 us: latency is not what is left), a second accumulator chain (29.5), coalesced
+// register loads + ds_write with two workgroups per CU instead of the DMA (40 us).  Issuing a 1-KiB DMA piece blocks its wave
+// ~100-150 cycles; with one wave per SIMD that adds to the 64 dependent MFMAs of a sample instead of hiding under them.
+typedef __attribute__((address_space(3))) void* dot_lds_ptr_t;
+constexpr int kDotD = 128;                               // floats per row in this kernel
+constexpr int kDotImage = kMaxC * kDotD * 4;             // 16 KB per sample image
+constexpr int kDotLds = 4 * 2 * kDotImage;               // 4 waves x 2 buffers = 128 KB: one workgroup per CU
+
+template <int OV>
+__global__ __launch_bounds__(256) void dot_interaction_fwd_lds_kernel(const float* __restrict__ z, int64_t ldz, float* __restrict__ out, int64_t ldo,
+                                                                      int64_t batch, int c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dot_smem[];
+  constexpr int d = kDotD;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  unsigned char* img = dot_smem + wave * 2 * kDotImage;
+  const unsigned lds_base = (unsigned)(size_t)(dot_lds_ptr_t)img;
+  const int npieces = (c + 1) / 2;                       // DMA instructions per sample: two rows each (<= 16)
+  // lane-linear piece i: LDS bytes [1024 i, 1024 i + 1024) = rows 2 i (lanes 0-31) and 2 i + 1 (lanes 32-63), position p = lane & 31
+  auto issue_piece = [&](const float* zb, int buf, int i) {
+    int row = 2 * i + (lane >> 5);
+    if (row >= c) row = c - 1;                           // the odd row behind the last one: a valid address, an unused image row
+    const int p = lane & 31;
+    const float* src = zb + (int64_t)row * d + 4 * (p ^ (row & 15));
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * kDotImage + i * 1024));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+  };
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  int buf = 0;
+  if (b < batch) {
+    const float* zb = z + b * ldz;
+    for (int i = 0; i < npieces; i++) issue_piece(zb, 0, i);
+  }
+  for (; b < batch; b += nwaves, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this sample's image is complete (its pieces were issued between the previous sample's MFMAs)
+    const int64_t bn = b + nwaves;
+    const bool more = bn < batch;
+    const float* zn = z + (more ? bn : b) * ldz;
+    const unsigned char* im = img + buf * kDotImage + r * (d * 4);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+#pragma unroll
+    for (int j0 = 0; j0 < 16; j0 += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4*>(im + ((((2 * (j0 + u) + h) ^ (r & 15))) << 4));
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u].x, v[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u].y, v[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u].z, v[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u].w, v[u].w, acc, 0, 0, 0);
+        // the next sample streams into the other buffer one 1-KiB piece per four MFMAs
+        const int piece = j0 + u;
+        if (more && piece < npieces) issue_piece(zn, buf ^ 1, piece);
+      }
+    }
+    float* ob = out + b * ldo;
+    // the bottom-MLP output passes through: out[0 .. d) = Z[0][:] (row 0 of the image: position p holds chunk p ^ 0)
+    if (OV == 4) {
+      if (lane < d / 4) *reinterpret_cast<float4*>(ob + 4 * lane) = *reinterpret_cast<const float4*>(img + buf * kDotImage + 16 * lane);
+    } else {
+      for (int k = lane; k < d; k += 64) ob[k] = *reinterpret_cast<const float*>(img + buf * kDotImage + 4 * k);
+    }
+    float* tri = ob + d;
+#pragma unroll
+    for (int v2 = 0; v2 < 16; v2++) {
+      const int i = 8 * (v2 >> 2) + 4 * h + (v2 & 3);
+      if (i < c && r < i) tri[i * (i - 1) / 2 + r] = acc[v2];
+    }
+    // this sample's image is overwritten by pieces issued in the NEXT iteration's MFMA loop: every ds_read of it has returned
+    // by then (their results fed the MFMAs above); the wave barrier keeps the compiler from moving code across the iteration
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // backward: one wave per sample; s_S[w] is the wave's symmetric 32 x 32 (stride 33) matrix G + G^T
 template <int VEC, bool ACCUM>
 __global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ og, int64_t ldg,
@@ -192,6 +282,21 @@ int ffh_dot_interaction_fwd(ffh_ctx* c, const float* z, int64_t ldz, float* out,
   const bool v4 = d % 4 == 0 && ldz % 4 == 0 && aligned16(z);
   const bool o4 = v4 && ldo % 4 == 0 && aligned16(out);
   const unsigned grid = ffh_grid(batch, 4, 4096);
+  static const bool no_lds = getenv("FFH_DOT_NO_LDS") && atoi(getenv("FFH_DOT_NO_LDS"));      // A/B switch
+  if (v4 && d == kDotD && !no_lds) {
+    // one 4-wave workgroup per CU (128 KB of LDS), every wave walks its samples with the next one streaming in
+    static const bool ok4 = hipFuncSetAttribute((const void*)dot_interaction_fwd_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kDotLds) == hipSuccess;
+    static const bool ok1 = hipFuncSetAttribute((const void*)dot_interaction_fwd_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kDotLds) == hipSuccess;
+    if (ok4 && ok1) {
+      unsigned g2 = (unsigned)c->num_cus;
+      if ((int64_t)g2 * 4 > batch) g2 = (unsigned)((batch + 3) / 4);
+      if (o4) hipLaunchKernelGGL((dot_interaction_fwd_lds_kernel<4>), dim3(g2), dim3(256), kDotLds, as_stream(s), z, ldz, out, ldo, batch, nrows);
+      else hipLaunchKernelGGL((dot_interaction_fwd_lds_kernel<1>), dim3(g2), dim3(256), kDotLds, as_stream(s), z, ldz, out, ldo, batch, nrows);
+      FFH_LAUNCH_CHECK(c, "dot_interaction_fwd (lds)");
+      return FFH_OK;
+    }
+    (void)hipGetLastError();
+  }
   if (o4) hipLaunchKernelGGL((dot_interaction_fwd_kernel<4, 4>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
   else if (v4) hipLaunchKernelGGL((dot_interaction_fwd_kernel<4, 1>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
   else hipLaunchKernelGGL((dot_interaction_fwd_kernel<1, 1>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out, ldo, batch, nrows, d);
