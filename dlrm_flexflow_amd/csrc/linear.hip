@@ -51,6 +51,8 @@ struct GemmArgs {
   // FFH_LINEAR_DX_MASK_BY_X: C = mask[m][n] > 0 ? v : 0 in the epilogue
   const float* mask;
   int64_t      ldmask;
+  // CMAP kernels (dX of the layer above a Concat, ffh_linear_bwd_set_dx_scatter): column n of C lives at colmap[n].base[m * colmap[n].ld]
+  const ffh_col_dest* colmap;
 };
 
 constexpr int kSplitGran = 32;   // split-K granularity; splits are multiples of 2*kSplitGran = 64 = the largest BK
@@ -83,7 +85,7 @@ __device__ __forceinline__ float4 load4_guard(const float* p, bool row_ok, int c
 //                 ways (intra-workgroup split-K), partial accumulators meet in LDS in a fixed order.
 //                 For the skinny DLRM layers (2048 x 256, 2048 x 64 ...) this gives 4x the waves of
 //                 a 64x64 tiling: a 32x32x2 MFMA chain over K = 512 alone is 16k cycles.
-template <int BM, int BN, int BK, bool AKC, bool BKC, bool SPLITW = false, bool FUSE_DY = false>
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool SPLITW = false, bool FUSE_DY = false, bool CMAP = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
   constexpr int PA = AKC ? 1 : 4, PB = BKC ? 1 : 4;
   constexpr int LA = BM + PA, LB = BN + PB;
@@ -389,11 +391,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
       const int n = n0 + wn0 + j * 32 + lr;
       if (n >= g.N) continue;
       const float bv = (g.epi == EPI_STORE && g.bias) ? g.bias[n] : 0.0f;
+      float* cbase = C + n;
+      int64_t cld = g.ldc;
+      if (CMAP) { const ffh_col_dest cd = g.colmap[n]; cbase = cd.base; cld = cd.ld; }
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= g.M) continue;
-        float* cp = C + (int64_t)m * g.ldc + n;
+        float* cp = cbase + (int64_t)m * cld;
         float v = acc[i][j][r];
         if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) v = 0.0f;
         if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
@@ -1345,7 +1350,7 @@ __global__ __launch_bounds__(256) void bmm_small_kernel(const GemmArgs g, const 
   }
 }
 
-template <bool AKC, bool BKC, bool FUSE_DY = false>
+template <bool AKC, bool BKC, bool FUSE_DY = false, bool CMAP = false>
 int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char* name) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || batch <= 0) return FFH_OK;
   if (batch > 1 && !FUSE_DY && g.epi != EPI_ATOMIC && !g.bias && !g.mask && g.act == FFH_AC_MODE_NONE &&
@@ -1375,6 +1380,7 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   else cfg = 2;
   static const int forced = getenv("FFH_GEMM_CFG") ? atoi(getenv("FFH_GEMM_CFG")) : -1;   // A/B switch (tools/gemm_tune.py)
   if (forced >= 0 && forced <= 5 && (forced <= 2 || cfg == 0)) cfg = forced;
+  if (CMAP) cfg = (cfg == 0 || cfg == 3 || cfg == 4 || cfg == 5) ? 0 : 1;     // the column-map epilogue exists for the two plain tile shapes
   const int BMv = cfg == 3 ? 256 : (cfg == 5 ? 128 : (cfg == 0 || cfg == 4 ? 128 : (cfg == 1 ? 64 : 32)));
   const int BNv = cfg == 3 ? 128 : (cfg == 5 ? 256 : BMv);
   const int gx = (g.N + BNv - 1) / BNv, gy = (g.M + BMv - 1) / BMv;
@@ -1402,8 +1408,8 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   if (cfg == 3) hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
   else if (cfg == 4) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 32, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
   else if (cfg == 5) hipLaunchKernelGGL((gemm_f32_kernel<128, 256, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
-  else if (cfg == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
-  else if (cfg == 1) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
+  else if (cfg == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 16, AKC, BKC, false, FUSE_DY, CMAP>), grid, dim3(256), 0, as_stream(s), g);
+  else if (cfg == 1) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, 32, AKC, BKC, false, FUSE_DY, CMAP>), grid, dim3(256), 0, as_stream(s), g);
   else hipLaunchKernelGGL((gemm_f32_kernel<32, 32, 64, AKC, BKC, true, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, name);
@@ -2191,11 +2197,23 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       if (rc < 0) return rc;
       if (rc == 1) return FFH_OK;
     }
+    // ffh_linear_bwd_set_dx_scatter: the data gradient goes where a Concat backward would copy it (the register-staged kernel's
+    // epilogue takes the column map too: no pack kernel on the critical stream in front of the all-to-all)
+    const bool scatter = c->scatter_map && c->scatter_ncols == in && g.epi == EPI_STORE && !c->deterministic;
+    if (scatter) g.colmap = (const ffh_col_dest*)c->scatter_map;
     if ((forked || !do_dw) && relu) {
       g.act_y = y; g.ld_act_y = ldy; g.fuse = 1;
-      rc = launch_gemm<true, false, true>(c, g, 1, s, "linear_bwd dx gemm (masking)");
+      rc = scatter ? launch_gemm<true, false, true, true>(c, g, 1, s, "linear_bwd dx gemm (masking, column map)")
+                   : launch_gemm<true, false, true>(c, g, 1, s, "linear_bwd dx gemm (masking)");
     } else {
-      rc = launch_gemm<true, false>(c, g, 1, s, "linear_bwd dx gemm");
+      rc = scatter ? launch_gemm<true, false, false, true>(c, g, 1, s, "linear_bwd dx gemm (column map)")
+                   : launch_gemm<true, false>(c, g, 1, s, "linear_bwd dx gemm");
+    }
+    if (rc == FFH_OK && scatter) {
+      c->scatter_used = 1;
+      if (c->scatter_event) {          // "gradients ready" behind the kernel that produced them
+        FFH_HIP_TRY(c, hipEventRecord((hipEvent_t)c->scatter_event, as_stream(s)));
+      }
     }
     if (rc) return rc;
   }

@@ -306,9 +306,10 @@ int ffh_second_stream_used(ffh_ctx* ctx, int clear);
  * own completion signal (hipExtLaunchKernelGGL's stop event) instead of sending a separate barrier packet down s. */
 int ffh_event_record_with_next_linear_bwd(ffh_ctx* ctx, ffh_event e);
 /* Storing a data gradient where a Concat backward would copy it afterwards.  The NEXT ffh_linear_bwd_ex on this ctx, if it is
- * called with FFH_LINEAR_DX_OVERWRITE for in_dim == ncols and runs as the one-launch LDS-DMA form, writes column n of dX to
+ * called with FFH_LINEAR_DX_OVERWRITE for in_dim == ncols and runs as the one-launch LDS-DMA form or as the register-staged
+ * fp32 data-gradient GEMM (not: skinny / pair launches, the bf16-pipe math modes, deterministic mode), writes column n of dX to
  * map[n].base[row * map[n].ld] instead of dx[row * lddx + n] (map: device memory, ncols entries, must stay valid until that
- * call's kernels have run).  `attach_if_used` (may be NULL) is then signalled by that launch's completion, like
+ * call's kernels have run).  `attach_if_used` (may be NULL) is then signalled behind that launch, like
  * ffh_event_record_with_next_linear_bwd; if the call cannot take the map it writes dx as always and records nothing.
  * ffh_linear_dx_scatter_used() says which of the two happened (it reports on the last such call). */
 typedef struct ffh_col_dest { float* base; int64_t ld; } ffh_col_dest;

@@ -4,6 +4,7 @@ import os
 import subprocess
 
 import numpy as np
+import torch
 import pytest
 
 from conftest import ROOT
@@ -263,3 +264,52 @@ def test_deterministic_mode_is_bit_reproducible(hip):
     for k in runs[0]:
         assert runs[0][k].tobytes() == runs[1][k].tobytes(), k
         np.testing.assert_allclose(runs[0][k], runs[2][k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("B,IN,OUT,act,fork", [(4096, 384, 256, "relu", True), (4096, 384, 256, "relu", False), (2048, 512, 512, "none", True),
+                                              (8192, 3456, 1024, "relu", True), (300, 48, 40, "none", False)])
+def test_dx_column_map_in_every_kernel_family(hip, B, IN, OUT, act, fork):
+    """ffh_linear_bwd_set_dx_scatter: column n of the data gradient lands at map[n].base[row * map[n].ld] -- where the Concat
+    backward below the layer would copy it.  Round 2: the register-staged dX GEMM (big layers) takes the map in its epilogue too,
+    not only the one-launch LDS-DMA form.  The scattered result must equal the plain call's dx (the map may route the call to
+    another tile shape, i.e. another order of the k sum: the usual 1e-5-of-term-mass bound, in practice the last bit) and
+    ffh_linear_dx_scatter_used() must say the map was taken."""
+    import ctypes
+    rng = np.random.default_rng(B + IN)
+    a = capi.AC_MODE_RELU if act == "relu" else capi.AC_MODE_NONE
+    x = torch.from_numpy(np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)).cuda()
+    y = torch.from_numpy(rng.uniform(-1, 1, (B, OUT)).astype(np.float32)).cuda()
+    dy0 = torch.from_numpy(rng.uniform(-1, 1, (B, OUT)).astype(np.float32)).cuda()
+    s2 = torch.cuda.Stream()
+
+    def run(colmap):
+        dy = dy0.clone(); dx = torch.full((B, IN), 3.0, device="cuda")
+        dw = torch.zeros(OUT, IN, device="cuda"); db = torch.zeros(OUT, device="cuda")
+        if colmap is not None:
+            hip.check(hip.lib.ffh_linear_bwd_set_dx_scatter(hip.ctx, ctypes.c_void_p(colmap.data_ptr()), IN, None), "set map")
+        hip.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy, OUT, w, dw, db, IN, OUT, B, a, capi.LINEAR_DX_OVERWRITE, None, s2.cuda_stream if fork else None)
+        torch.cuda.synchronize()
+        return dx, dw, int(hip.lib.ffh_linear_dx_scatter_used(hip.ctx))
+
+    dx_plain, dw_plain, used0 = run(None)
+    assert used0 == 0
+    # three destinations: a [B][w0] buffer of its own, the middle of a wider one, and one with a leading dimension beyond its width
+    w0, w1 = IN // 3, IN // 3
+    w2 = IN - w0 - w1
+    d0 = torch.full((B, w0), -7.0, device="cuda"); d1 = torch.full((B, w1 + 10), -7.0, device="cuda"); d2 = torch.full((B, w2 + 6), -7.0, device="cuda")
+    ent = np.zeros((IN, 2), np.int64)
+    for n in range(IN):
+        if n < w0: ent[n] = (d0.data_ptr() + 4 * n, w0)
+        elif n < w0 + w1: ent[n] = (d1.data_ptr() + 4 * (5 + n - w0), w1 + 10)
+        else: ent[n] = (d2.data_ptr() + 4 * (n - w0 - w1), w2 + 6)
+    cmap = torch.from_numpy(ent).cuda()
+    dx_s, dw_s, used1 = run(cmap)
+    assert used1 == 1
+    got = torch.cat([d0, d1[:, 5:5 + w1], d2[:, :w2]], 1)
+    dmass = (dy0.abs().double() @ w.abs().double()).cpu().numpy()
+    np.testing.assert_array_less(np.abs((got - dx_plain).cpu().numpy()), 1e-5 * dmass + 1e-7)
+    assert bool((dx_s == 3.0).all())                                         # the plain destination is not written
+    assert bool((d1[:, :5] == -7.0).all()) and bool((d1[:, 5 + w1:] == -7.0).all()) and bool((d2[:, w2:] == -7.0).all())
+    mass = (dy0.abs().double().T @ x.abs().double()).cpu().numpy()
+    np.testing.assert_array_less(np.abs((dw_s - dw_plain).cpu().numpy()), 2e-5 * mass + 1e-6)   # dW: split-K atomics, order differs run to run
