@@ -152,7 +152,10 @@ def hip_bf16(hip, oracle_bf16):
     (2048, 512, 256, capi.AC_MODE_RELU), (2048, 432, 512, capi.AC_MODE_RELU), (4096, 1024, 1024, capi.AC_MODE_RELU),
     (1024, 3456, 1024, capi.AC_MODE_RELU), (512, 479, 1024, capi.AC_MODE_RELU), (512, 857, 1024, capi.AC_MODE_NONE),
     (333, 130, 200, capi.AC_MODE_SIGMOID), (65, 128, 128, capi.AC_MODE_NONE), (1000, 257, 129, capi.AC_MODE_RELU),
-    (8192, 256, 128, capi.AC_MODE_RELU), (100, 2000, 1000, capi.AC_MODE_NONE)])
+    (8192, 256, 128, capi.AC_MODE_RELU), (100, 2000, 1000, capi.AC_MODE_NONE),
+    # outputs with >= 256 tiles of 256 x 256: the big-tile kernel (8 waves of 128 x 64), ragged on every edge; the second
+    # one also in dX (reduction depth >= 1024)
+    (16500, 200, 1000, capi.AC_MODE_RELU), (16500, 1000, 1030, capi.AC_MODE_RELU)])
 def test_linear_bf16_mode_hip_vs_oracle_same_mode(hip_bf16, oracle_bf16, B, IN, OUT, act):
     T = _gpu_helpers()
     rng = np.random.default_rng(IN * OUT + 1)
