@@ -5,7 +5,7 @@ import sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from dlrm_flexflow_amd import ffmodel
-w = bench.workload("kaggle", None, 1)
+w = bench.workload(sys.argv[1] if len(sys.argv) > 1 else "kaggle", bench.DEFAULT_BATCH[sys.argv[1] if len(sys.argv) > 1 else "kaggle"])
 app = ffmodel.DLRM(bench.flags_of(w, ["--device", "0"]))
 app.warmup()
 m = app.model
