@@ -1427,11 +1427,15 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
   const bool x3 = c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3;      // three bf16 planes per operand: fp32-accurate
   // 256 x 256 tiles (one 8-wave workgroup per CU, 128 x 64 per wave) where the output still fills the chip with them: half
   // the operand traffic per flop.  Measured at batch 32768: forward 3456 -> 1024 492 -> 353 us, 1024 -> 1024 162 -> 143;
-  // dX +3...6 % from a reduction depth of 1024 up, slower below; the split-K weight-gradient form is slower (-8 %): 128 x 128.
+  // dX +3...6 % from a reduction depth of 1024 up, slower below; the split-K weight-gradient form: see below.
   static const int tile_env = getenv("FFH_BF16_TILE") ? atoi(getenv("FFH_BF16_TILE")) : 0;
   const int64_t tiles_big = (int64_t)((g.N + 255) / 256) * ((g.M + 255) / 256);
   const bool big_form = (AKC && BKC) || (AKC && !BKC && g.K >= 1024);
   bool big = !x3 && big_form && g.M >= 256 && g.N >= 256 && tiles_big >= c->num_cus;
+  // the split-K weight-gradient form: big tiles where there are enough of them that a split can fill whole rounds of one
+  // workgroup per CU (3456 x 1024 at batch 32768: 56 tiles x 9 splits = 504; 747 -> 553 us); 16 tiles (1024 x 1024) lose 8 %
+  static const int dw_big = getenv("FFH_BF16_DW_BIG") ? atoi(getenv("FFH_BF16_DW_BIG")) : 1;     // A/B switch
+  if (dw_big && !x3 && !AKC && !BKC && g.epi == EPI_ATOMIC && !c->deterministic && tiles_big >= 32 && g.K >= 8192) big = true;
   if (tile_env == 128) big = false;
   if (tile_env == 256 && !x3 && g.M >= 256 && g.N >= 256) big = true;
   const int bm = big ? 256 : kBfBM, bn = big ? 256 : kBfBN;
@@ -1444,6 +1448,20 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     const int64_t tiles = (int64_t)gx * gy;
     int want = (int)(((big ? 1LL : 2LL) * c->num_cus + tiles - 1) / tiles);
     const int max_split = (g.K + 4 * kBfBK - 1) / (4 * kBfBK);     // at least four k-tiles per workgroup
+    // (for the 128 x 128 tile the same search makes a weight-gradient GEMM up to 30 % faster ALONE and the step no faster:
+    //  in the step the holes of an unbalanced launch are filled by the data-gradient GEMM on the other stream -- off by default)
+    static const int fill_small = getenv("FFH_BF16_FILL") ? atoi(getenv("FFH_BF16_FILL")) : 0;    // A/B switch
+    if (big || fill_small) {
+      // pick the split whose workgroup count fills whole rounds of resident workgroups best (one per CU for the big tile, two for 128 x 128)
+      const int64_t slots = (big ? 1LL : 2LL) * c->num_cus;
+      int best = want; double best_u = 0.0;
+      for (int w2 = want; w2 <= 2 * want + 2 && w2 <= max_split; w2++) {
+        const int64_t nb = tiles * w2;
+        const double u = (double)nb / (double)(((nb + slots - 1) / slots) * slots);
+        if (u > best_u + 1e-9) { best_u = u; best = w2; }
+      }
+      want = best;
+    }
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
     int kps = (g.K + want - 1) / want;

@@ -155,7 +155,9 @@ def hip_bf16(hip, oracle_bf16):
     (8192, 256, 128, capi.AC_MODE_RELU), (100, 2000, 1000, capi.AC_MODE_NONE),
     # outputs with >= 256 tiles of 256 x 256: the big-tile kernel (8 waves of 128 x 64), ragged on every edge; the second
     # one also in dX (reduction depth >= 1024)
-    (16500, 200, 1000, capi.AC_MODE_RELU), (16500, 1000, 1030, capi.AC_MODE_RELU)])
+    (16500, 200, 1000, capi.AC_MODE_RELU), (16500, 1000, 1030, capi.AC_MODE_RELU),
+    # ... and the split-K weight gradient on big tiles (>= 32 of them, batch >= 8192)
+    (8200, 1800, 1030, capi.AC_MODE_RELU)])
 def test_linear_bf16_mode_hip_vs_oracle_same_mode(hip_bf16, oracle_bf16, B, IN, OUT, act):
     T = _gpu_helpers()
     rng = np.random.default_rng(IN * OUT + 1)
