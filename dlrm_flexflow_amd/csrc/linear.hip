@@ -666,9 +666,12 @@ __device__ __forceinline__ void split_bf16x3(const float4 v, uint2& p1, uint2& p
   p3 = pack_bf16x4(residual_f32x4(r, p2));
 }
 
-template <bool AKC, bool BKC, bool MASK_A = false>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
-  constexpr int BM = 128, BN = 128, BK = kX3BK;
+template <bool AKC, bool BKC, bool MASK_A = false, int BM = 128, int BN = 128, int WM = 64>
+__global__ __launch_bounds__(BM / WM * BN) void gemm_bf16x3_kernel(const GemmArgs g) {
+  constexpr int BK = kX3BK, NT = BM / WM * BN;                  // one wave per WM x 64 of the tile
+  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;             // float4 per thread per k-tile
+  constexpr int TM = WM / 32;
+  constexpr int PLANE_A = BM * BK * 2, PLANE_B = BN * BK * 2;   // bytes of one bf16 plane of an operand image
   extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bx, by, bz;
@@ -694,15 +697,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
   const float* A = g.A;
   const float* B = g.B;
 
-  float4 ra0[4], rb0[4];
+  float4 ra0[NA], rb0[NB];
   const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
-  auto load_tile = [&](int kt, auto fast_tag, float4 (&ra)[4], float4 (&rb)[4]) {
+  auto load_tile = [&](int kt, auto fast_tag, float4 (&ra)[NA], float4 (&rb)[NB]) {
     constexpr bool FAST = decltype(fast_tag)::value;
     const int k0 = kb + kt * BK;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NA; i++) {
       if (AKC) {
-        const int k4 = tid & 7, row = (tid >> 3) + 32 * i;
+        const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i;
         const int m = m0 + row, k = k0 + 4 * k4;
         if (FAST) ra[i] = ld4u(A + (int64_t)m * g.sAm + k);
         else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, true);
@@ -714,113 +717,119 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
           ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
         }
       } else {
-        const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        const int m4 = tid % (BM / 4), kr = tid / (BM / 4) + (4 * NT / BM) * i;
         const int m = m0 + 4 * m4, k = k0 + kr;
         if (FAST) ra[i] = ld4u(A + (int64_t)k * g.sAk + m);
         else ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, true);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NB; i++) {
       if (BKC) {
-        const int k4 = tid & 7, row = (tid >> 3) + 32 * i;
+        const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i;
         const int n = n0 + row, k = k0 + 4 * k4;
         if (FAST) rb[i] = ld4u(B + (int64_t)n * g.sBn + k);
         else rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, true);
       } else {
-        const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;
+        const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;
         const int n = n0 + 4 * n4, k = k0 + kr;
         if (FAST) rb[i] = ld4u(B + (int64_t)k * g.sBk + n);
         else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, true);
       }
     }
   };
-  auto split_store = [&](const float4 (&ra)[4], const float4 (&rb)[4]) {
+  auto split_store = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
     unsigned char* as = x3_smem;
-    unsigned char* bs = x3_smem + 3 * kX3Plane;
+    unsigned char* bs = x3_smem + 3 * PLANE_A;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NA; i++) {
       uint2 p1, p2, p3;
       split_bf16x3(ra[i], p1, p2, p3);
       unsigned o;
-      if (AKC) { const int k4 = tid & 7, row = (tid >> 3) + 32 * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
-      else     { const int m4 = tid & 31, kr = (tid >> 5) + 8 * i;  o = bf_off_kr<128>(kr, m4 >> 1) + 8 * (m4 & 1); }
+      if (AKC) { const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
+      else     { const int m4 = tid % (BM / 4), kr = tid / (BM / 4) + (4 * NT / BM) * i;  o = bf_off_kr<BM>(kr, m4 >> 1) + 8 * (m4 & 1); }
       *reinterpret_cast<uint2*>(as + o) = p1;
-      *reinterpret_cast<uint2*>(as + kX3Plane + o) = p2;
-      *reinterpret_cast<uint2*>(as + 2 * kX3Plane + o) = p3;
+      *reinterpret_cast<uint2*>(as + PLANE_A + o) = p2;
+      *reinterpret_cast<uint2*>(as + 2 * PLANE_A + o) = p3;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NB; i++) {
       uint2 p1, p2, p3;
       split_bf16x3(rb[i], p1, p2, p3);
       unsigned o;
-      if (BKC) { const int k4 = tid & 7, row = (tid >> 3) + 32 * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
-      else     { const int n4 = tid & 31, kr = (tid >> 5) + 8 * i;  o = bf_off_kr<128>(kr, n4 >> 1) + 8 * (n4 & 1); }
+      if (BKC) { const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
+      else     { const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;  o = bf_off_kr<BN>(kr, n4 >> 1) + 8 * (n4 & 1); }
       *reinterpret_cast<uint2*>(bs + o) = p1;
-      *reinterpret_cast<uint2*>(bs + kX3Plane + o) = p2;
-      *reinterpret_cast<uint2*>(bs + 2 * kX3Plane + o) = p3;
+      *reinterpret_cast<uint2*>(bs + PLANE_B + o) = p2;
+      *reinterpret_cast<uint2*>(bs + 2 * PLANE_B + o) = p3;
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][2];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < TM; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave / (BN / 64)) * WM, wn0 = (wave % (BN / 64)) * 64;
   const int lr = lane & 31, lh = lane >> 5;
   const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-  auto frag = [&](const unsigned char* img, bool kc, int o, int s) -> bf16x8_t {
+  auto frag = [&](const unsigned char* img, bool kc, auto rowlen_tag, int o, int s) -> bf16x8_t {
+    constexpr int RL = decltype(rowlen_tag)::value;
     if (kc) return *reinterpret_cast<const bf16x8_t*>(img + x3_off_kc(o + lr, 2 * s + lh));
     typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
     const int ch = (o >> 3) + 2 * (tg & 1) + (tp >> 1);
     const int k0r = 16 * s + 8 * (tg >> 1) + tq;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<128>(k0r, ch) + 8 * (tp & 1)));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<128>(k0r + 4, ch) + 8 * (tp & 1)));
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<RL>(k0r, ch) + 8 * (tp & 1)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<RL>(k0r + 4, ch) + 8 * (tp & 1)));
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
   auto compute_tile = [&]() {
     const unsigned char* as = x3_smem;
-    const unsigned char* bs = x3_smem + 3 * kX3Plane;
+    const unsigned char* bs = x3_smem + 3 * PLANE_A;
 #pragma unroll
     for (int s = 0; s < BK / 16; s++) {
-      bf16x8_t a[2][3], b[2][3];
+      bf16x8_t b[2][3];
 #pragma unroll
-      for (int p = 0; p < 3; p++) {
+      for (int p = 0; p < 3; p++)
 #pragma unroll
-        for (int i = 0; i < 2; i++) a[i][p] = frag(as + p * kX3Plane, AKC, wm0 + 32 * i, s);
+        for (int j = 0; j < 2; j++) b[j][p] = frag(bs + p * PLANE_B, BKC, std::integral_constant<int, BN>{}, wn0 + 32 * j, s);
 #pragma unroll
-        for (int j = 0; j < 2; j++) b[j][p] = frag(bs + p * kX3Plane, BKC, wn0 + 32 * j, s);
+      for (int ih = 0; ih < TM; ih += 2) {                  // two row tiles at a time: 6 + 6 fragments live
+        bf16x8_t a[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+          for (int i = 0; i < 2; i++) a[i][p] = frag(as + p * PLANE_A, AKC, std::integral_constant<int, BM>{}, wm0 + 32 * (ih + i), s);
+        // the six products with i + j <= 4, small terms first
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[ih + i][j], 0, 0, 0);
+            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[ih + i][j], 0, 0, 0);
+            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[ih + i][j], 0, 0, 0);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[ih + i][j], 0, 0, 0);
+            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[ih + i][j], 0, 0, 0);
+          }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[ih + i][j], 0, 0, 0);
       }
-      // the six products with i + j <= 4, small terms first
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
-        }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
-        }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
     }
   };
 
   const int nfull = (a_in && b_in) ? (ke - kb) / BK : 0;
-  auto load_any = [&](int kt, float4 (&ra)[4], float4 (&rb)[4]) {
+  auto load_any = [&](int kt, float4 (&ra)[NA], float4 (&rb)[NB]) {
     if (kt >= nk) return;
     if (kt < nfull) load_tile(kt, std::true_type{}, ra, rb); else load_tile(kt, std::false_type{}, ra, rb);
   };
@@ -836,7 +845,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
 
   float* C = g.C;
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < TM; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int n = n0 + wn0 + j * 32 + lr;
@@ -1431,13 +1440,16 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
   static const int tile_env = getenv("FFH_BF16_TILE") ? atoi(getenv("FFH_BF16_TILE")) : 0;
   const int64_t tiles_big = (int64_t)((g.N + 255) / 256) * ((g.M + 255) / 256);
   const bool big_form = (AKC && BKC) || (AKC && !BKC && g.K >= 1024);
-  bool big = !x3 && big_form && g.M >= 256 && g.N >= 256 && tiles_big >= c->num_cus;
+  // the split mode takes the same tile (96 KB: three planes per operand): forward / dX +4 %, the weight gradient of the big
+  // layer 1,676 -> 1,241 us; whole split-mode step 6.9 -> 6.6-6.8 ms (FFH_X3_BIG: 0 never, 1 not for the weight gradient)
+  static const int x3_big = getenv("FFH_X3_BIG") ? atoi(getenv("FFH_X3_BIG")) : 2;             // A/B switch
+  bool big = (!x3 || x3_big) && big_form && g.M >= 256 && g.N >= 256 && tiles_big >= c->num_cus;
   // the split-K weight-gradient form: big tiles where there are enough of them that a split can fill whole rounds of one
   // workgroup per CU (3456 x 1024 at batch 32768: 56 tiles x 9 splits = 504; 747 -> 553 us); 16 tiles (1024 x 1024) lose 8 %
   static const int dw_big = getenv("FFH_BF16_DW_BIG") ? atoi(getenv("FFH_BF16_DW_BIG")) : 1;     // A/B switch
-  if (dw_big && !x3 && !AKC && !BKC && g.epi == EPI_ATOMIC && !c->deterministic && tiles_big >= 32 && g.K >= 8192) big = true;
+  if (dw_big && (!x3 || x3_big > 1) && !AKC && !BKC && g.epi == EPI_ATOMIC && !c->deterministic && tiles_big >= 32 && g.K >= 8192) big = true;
   if (tile_env == 128) big = false;
-  if (tile_env == 256 && !x3 && g.M >= 256 && g.N >= 256) big = true;
+  if (tile_env == 256 && g.M >= 256 && g.N >= 256) big = true;
   const int bm = big ? 256 : kBfBM, bn = big ? 256 : kBfBN;
   const int gx = (g.N + bn - 1) / bn, gy = (g.M + bm - 1) / bm;
   g.splitk = 1;
@@ -1472,6 +1484,16 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     gz = g.splitk;
   }
   if (gy > 65535 || gz > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm (bf16): grid too large");
+  if (x3 && big) {
+    auto kern3b = gemm_bf16x3_kernel<AKC, BKC, MASK_A, 256, 256, 128>;
+    constexpr int lds3b = 3 * (256 + 256) * kX3BK * 2;          // 96 KB: one 8-wave workgroup per CU
+    static const bool ok3b = glds_set_lds(kern3b, lds3b);
+    if (!ok3b) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16x3): cannot reserve 96 KB of LDS");
+    hipLaunchKernelGGL(kern3b, dim3(gx, gy, gz), dim3(512), lds3b, as_stream(s), g);
+    hipError_t e3b = hipGetLastError();
+    if (e3b != hipSuccess) return ffh_fail_hip(c, e3b, name);
+    return FFH_OK;
+  }
   if (x3) {
     auto kern3 = gemm_bf16x3_kernel<AKC, BKC, MASK_A>;
     static const bool ok3 = glds_set_lds(kern3, kX3Lds);

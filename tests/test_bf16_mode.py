@@ -278,7 +278,9 @@ def hip_x3(hip):
 @pytest.mark.parametrize("B,IN,OUT,act", [
     (2048, 512, 256, capi.AC_MODE_RELU), (2048, 432, 512, capi.AC_MODE_RELU), (4096, 1024, 1024, capi.AC_MODE_RELU),
     (1024, 3456, 1024, capi.AC_MODE_RELU), (512, 479, 1024, capi.AC_MODE_RELU), (333, 130, 200, capi.AC_MODE_SIGMOID),
-    (65, 128, 128, capi.AC_MODE_NONE), (1000, 257, 129, capi.AC_MODE_RELU), (100, 2000, 1000, capi.AC_MODE_NONE)])
+    (65, 128, 128, capi.AC_MODE_NONE), (1000, 257, 129, capi.AC_MODE_RELU), (100, 2000, 1000, capi.AC_MODE_NONE),
+    # the 256 x 256 tile: forward, deep-K dX, and the split-K weight gradient with >= 32 tiles; ragged on every edge
+    (16500, 200, 1000, capi.AC_MODE_RELU), (16500, 1000, 1030, capi.AC_MODE_RELU), (8200, 1800, 1030, capi.AC_MODE_RELU)])
 def test_linear_split_bf16x3_mode_meets_the_fp32_bound(hip_x3, oracle, B, IN, OUT, act):
     T = _gpu_helpers()
     rng = np.random.default_rng(IN * OUT + 5)
