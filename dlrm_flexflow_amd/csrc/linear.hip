@@ -17,68 +17,17 @@
 // Replaces cublasSgemm x2 + cudnnActivationForward [ref: src/ops/linear.cu:436-453],
 // reluBackward/sigmoid_backward + cublasSgemm x2 + cublasSgemv [ref: src/ops/linear.cu:624-659],
 // cublasSgemmStridedBatched [ref: src/ops/batch_matmul.cu:238-241,393-398].
-#include "ffh_common.h"
+#include "linear_gemm.h"
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: a launch that carries its own completion event
 
 #include <stdlib.h>
 #include <type_traits>
 
+using namespace ffh_gemm;
+
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-enum { EPI_STORE = 0, EPI_ADD = 1, EPI_ATOMIC = 2 };
-
-struct GemmArgs {
-  const float* A;
-  const float* B;
-  float*       C;
-  const float* bias;
-  int64_t sAm, sAk, sBn, sBk, ldc;
-  int64_t bsA, bsB, bsC;     // batch strides (grid.z = batch when splitk == 1)
-  int M, N, K;
-  int k_per_split;           // multiple of kSplitGran; grid.z = split when splitk > 1
-  int splitk;
-  int epi;
-  int act;
-  // dW form only (FUSE_DY): relu'(y) applied to the dy operand as it is loaded (and written back in
-  // place by the first column of workgroups), bias gradient = column sums of the same tiles
-  const float* act_y;
-  int64_t      ld_act_y;
-  float*       db;
-  int          fuse;         // bit0: relu mask from act_y, bit1: db += column sums
-  // FFH_LINEAR_DX_MASK_BY_X: C = mask[m][n] > 0 ? v : 0 in the epilogue
-  const float* mask;
-  int64_t      ldmask;
-  // CMAP kernels (dX of the layer above a Concat, ffh_linear_bwd_set_dx_scatter): column n of C lives at colmap[n].base[m * colmap[n].ld]
-  const ffh_col_dest* colmap;
-};
-
-constexpr int kSplitGran = 32;   // split-K granularity; splits are multiples of 2*kSplitGran = 64 = the largest BK
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == FFH_AC_MODE_RELU) return v > 0.0f ? v : 0.0f;
-  if (act == FFH_AC_MODE_SIGMOID) return 1.0f / (1.0f + expf(-v));
-  if (act == FFH_AC_MODE_GELU) {     // tanh form, forward only [ref: gelu_forward_kernel, src/runtime/cuda_helper.cu:81-90; src/ops/linear.cu:454-459]
-    constexpr float B = 0.7978845608028654f, C = 0.035677408136300125f;
-    return v * (0.5f + 0.5f * tanhf(v * (C * v * v + B)));
-  }
-  return v;
-}
-
-// Load 4 consecutive elements along the contiguous dimension (index c0..c0+3 < climit) of
-// row `r` (valid if r < rlimit).  p points at element (r, c0).
-__device__ __forceinline__ float4 load4_guard(const float* p, bool row_ok, int c0, int climit, bool vec_ok) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!row_ok) return v;
-  if (vec_ok && c0 + 3 < climit) return ld4u(p);
-  if (c0 + 0 < climit) v.x = p[0];
-  if (c0 + 1 < climit) v.y = p[1];
-  if (c0 + 2 < climit) v.z = p[2];
-  if (c0 + 3 < climit) v.w = p[3];
-  return v;
-}
 
 // SPLITW = false: 2x2 waves tile the BM x BN block, each wave owns (BM/2) x (BN/2) and the whole K.
 // SPLITW = true : BM = BN = 32; the four waves share ONE 32x32 tile and split every k-tile four
@@ -409,463 +358,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 }
 
 // =============================================================================================
-// Tensor-op math mode (ffh_ctx_set_math_mode(FFH_MATH_TENSOR_OP_BF16); the reference's
-// --allow-tensor-op-math-conversion -> cublasSetMathMode(CUBLAS_TENSOR_OP_MATH) [ref: src/runtime/model.cu:81-83]):
-// the same three GEMM forms with bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 16x the fp32 MFMA rate).
-// Activations, weights and gradients stay fp32 in HBM; a tile is rounded to bf16 (v_cvt_pk_bf16_f32, nearest even)
-// between its global load and its LDS image, so nothing outside this kernel knows about the mode.
-//   128 x 128 x 64 block tile, 4 waves (2 x 2), each 64 x 64 = 2 x 2 MFMA tiles; double-buffered LDS (64 KB: two
-//   workgroups per CU), one barrier per k-tile, global loads of tile t+1 in flight under the MFMAs of tile t.
-//   k-contiguous operand (x, w forward; dy in dX): image [row][64 bf16] = 128-byte rows, 16-byte chunks XOR-swizzled by
-//     (row >> 1) & 7 -> the fragment of lane (row r, half h) at k-step s is ONE conflict-free ds_read_b128 (chunk 2s + h);
-//   rows-are-k operand (w in dX; dy, x in dW): image [k][128 bf16] = 256-byte rows, stored as it arrives (one ds_write_b64
-//     per float4, coalesced), read TRANSPOSED by ds_read_b64_tr_b16: a 16-lane group fetches a 4 (k) x 16 (column) block and
-//     every lane receives the 4 k-values of its own column; two such reads make the 8-element MFMA fragment.  Chunk swizzle
-//     ch ^ (((k & 3) << 2) | ((k >> 2) & 3)) keeps both the stores and the transposed reads conflict-free.
-// With fp32 operands in memory the kernel is bound by the global -> LDS path (32 flop per staged byte), not by the matrix
-// pipe: ~0.8-1 PFLOP/s, i.e. 6-8x the fp32 mode.
-// =============================================================================================
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ uint2 pack_bf16x4(const float4 v) {
-  const bf16x2_t lo = {(__bf16)v.x, (__bf16)v.y}, hi = {(__bf16)v.z, (__bf16)v.w};
-  return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
-}
-
-constexpr int kBfBM = 128, kBfBN = 128, kBfBK = 64;
-constexpr int kBfImage = 128 * 64 * 2;                    // bytes of one 128-row operand image (either layout)
-constexpr int kBfLds = 2 * 2 * kBfImage;                  // two operands, two buffers
-constexpr int bf_lds_bytes(int bm, int bn) { return 2 * (bm + bn) * kBfBK * 2; }
-
-__device__ __forceinline__ unsigned bf_off_kc(int row, int chunk) { return (unsigned)(row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); }
-// rows-are-k image of an operand with ROWLEN (128 or 256) columns: 2 * ROWLEN bytes per k-row, the swizzle acts on the low four chunk bits
-template <int ROWLEN = 128>
-__device__ __forceinline__ unsigned bf_off_kr(int krow, int chunk) { return (unsigned)(krow * (2 * ROWLEN) + ((chunk ^ (((krow & 3) << 2) | ((krow >> 2) & 3))) << 4)); }
-
-// MASK_A: the A operand (k-contiguous dy of the dX form) is read through relu'(act_y) (FFH_LINEAR_ONLY_DX / forked dW)
-// BM x BN block tile, one wave per WM x 64 of it: 128 x 128 (4 waves of 64 x 64, two workgroups per CU) or, where the output
-// has enough tiles to fill the chip with them, 256 x 256 (8 waves of 128 x 64, 128 KB of LDS, one workgroup per CU): the fp32
-// operands cross the L2 -> CU path half as often, and that path is what bounds this kernel
-template <bool AKC, bool BKC, bool MASK_A = false, int BM = kBfBM, int BN = kBfBN, int WM = 64>
-__global__ __launch_bounds__(BM / WM * BN) void gemm_bf16_kernel(const GemmArgs g) {
-  constexpr int BK = kBfBK, NT = BM / WM * BN;                 // one wave per WM x 64 of the tile
-  constexpr int TM = WM / 32;
-  constexpr int NA = BM * 16 / NT, NB = BN * 16 / NT;          // float4 per thread per k-tile
-  constexpr int IMG_A = BM * BK * 2, IMG_B = BN * BK * 2;     // bytes of the operand images
-  static_assert(NT <= 1024 && NA >= 1 && NB >= 1, "tile");
-  extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bx, by, bz;
-  {
-    const unsigned nbx = gridDim.x, nby = gridDim.y, nbz = gridDim.z;
-    const unsigned total = nbx * nby * nbz;
-    const unsigned lin = (blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x;
-    const unsigned xcd = lin & 7u, loc = lin >> 3;
-    const unsigned q = total >> 3, rem = total & 7u;
-    const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
-    bx = (int)(nlin % nbx);
-    by = (int)((nlin / nbx) % nby);
-    bz = (int)(nlin / (nbx * nby));
-  }
-  const int m0 = by * BM, n0 = bx * BN;
-  int kb = 0, ke = g.K;
-  if (g.splitk > 1) {
-    kb = bz * g.k_per_split;
-    ke = kb + g.k_per_split < g.K ? kb + g.k_per_split : g.K;
-  }
-  if (kb >= ke) return;
-  const int nk = (ke - kb + BK - 1) / BK;
-  const float* A = g.A;
-  const float* B = g.B;
-
-  float4 ra[NA], rb[NB];
-  const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
-  auto load_tile = [&](int kt, auto fast_tag) {
-    constexpr bool FAST = decltype(fast_tag)::value;
-    const int k0 = kb + kt * BK;
-#pragma unroll
-    for (int i = 0; i < NA; i++) {
-      if (AKC) {
-        const int k4 = tid & 15, row = (tid >> 4) + (NT / 16) * i;
-        const int m = m0 + row, k = k0 + 4 * k4;
-        if (FAST) ra[i] = ld4u(A + (int64_t)m * g.sAm + k);
-        else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, true);
-        if (MASK_A) {
-          float4 yv;
-          if (FAST) yv = ld4u(g.act_y + (int64_t)m * g.ld_act_y + k);
-          else yv = load4_guard(g.act_y + (int64_t)m * g.ld_act_y + k, m < g.M, k, ke, true);
-          ra[i].x = yv.x > 0.0f ? ra[i].x : 0.0f; ra[i].y = yv.y > 0.0f ? ra[i].y : 0.0f;
-          ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
-        }
-      } else {
-        const int m4 = tid % (BM / 4), kr = tid / (BM / 4) + (4 * NT / BM) * i;
-        const int m = m0 + 4 * m4, k = k0 + kr;
-        if (FAST) ra[i] = ld4u(A + (int64_t)k * g.sAk + m);
-        else ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, true);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-      if (BKC) {
-        const int k4 = tid & 15, row = (tid >> 4) + (NT / 16) * i;
-        const int n = n0 + row, k = k0 + 4 * k4;
-        if (FAST) rb[i] = ld4u(B + (int64_t)n * g.sBn + k);
-        else rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, true);
-      } else {
-        const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;
-        const int n = n0 + 4 * n4, k = k0 + kr;
-        if (FAST) rb[i] = ld4u(B + (int64_t)k * g.sBk + n);
-        else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, true);
-      }
-    }
-  };
-  auto store_tile = [&](int buf) {
-    unsigned char* as = bf_smem + buf * (IMG_A + IMG_B);
-    unsigned char* bs = as + IMG_A;
-#pragma unroll
-    for (int i = 0; i < NA; i++) {
-      if (AKC) {
-        const int k4 = tid & 15, row = (tid >> 4) + (NT / 16) * i;
-        *reinterpret_cast<uint2*>(as + bf_off_kc(row, k4 >> 1) + 8 * (k4 & 1)) = pack_bf16x4(ra[i]);
-      } else {
-        const int m4 = tid % (BM / 4), kr = tid / (BM / 4) + (4 * NT / BM) * i;
-        *reinterpret_cast<uint2*>(as + bf_off_kr<BM>(kr, m4 >> 1) + 8 * (m4 & 1)) = pack_bf16x4(ra[i]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-      if (BKC) {
-        const int k4 = tid & 15, row = (tid >> 4) + (NT / 16) * i;
-        *reinterpret_cast<uint2*>(bs + bf_off_kc(row, k4 >> 1) + 8 * (k4 & 1)) = pack_bf16x4(rb[i]);
-      } else {
-        const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;
-        *reinterpret_cast<uint2*>(bs + bf_off_kr<BN>(kr, n4 >> 1) + 8 * (n4 & 1)) = pack_bf16x4(rb[i]);
-      }
-    }
-  };
-
-  f32x16 acc[TM][2];
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-  const int wm0 = (wave / (BN / 64)) * WM, wn0 = (wave % (BN / 64)) * 64;
-  const int lr = lane & 31, lh = lane >> 5;
-  // transposed-read lane roles: 16-lane group tg, row tq and column quad tp of the 4 x 16 block
-  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-
-  // fragment of the 32-row (or 32-column) tile starting at `o` of an image, k-step s (16 k)
-  auto frag = [&](const unsigned char* img, bool kc, auto rowlen_tag, int o, int s) -> bf16x8_t {
-    constexpr int RL = decltype(rowlen_tag)::value;
-    if (kc) return *reinterpret_cast<const bf16x8_t*>(img + bf_off_kc(o + lr, 2 * s + lh));
-    typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
-    const int ch = (o >> 3) + 2 * (tg & 1) + (tp >> 1);
-    const int k0r = 16 * s + 8 * (tg >> 1) + tq;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<RL>(k0r, ch) + 8 * (tp & 1)));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<RL>(k0r + 4, ch) + 8 * (tp & 1)));
-    typedef short s16x8_t __attribute__((ext_vector_type(8)));
-    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8_t, v);
-  };
-  auto compute_tile = [&](int buf) {
-    const unsigned char* as = bf_smem + buf * (IMG_A + IMG_B);
-    const unsigned char* bs = as + IMG_A;
-#pragma unroll
-    for (int s = 0; s < BK / 16; s++) {
-      bf16x8_t a[TM], b[2];
-#pragma unroll
-      for (int i = 0; i < TM; i++) a[i] = frag(as, AKC, std::integral_constant<int, BM>{}, wm0 + 32 * i, s);
-#pragma unroll
-      for (int j = 0; j < 2; j++) b[j] = frag(bs, BKC, std::integral_constant<int, BN>{}, wn0 + 32 * j, s);
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  // k-tiles fully inside the matrices take the unguarded loader (workgroup-uniform choice)
-  const int nfull = (a_in && b_in) ? (ke - kb) / BK : 0;
-  if (nfull > 0) load_tile(0, std::true_type{}); else load_tile(0, std::false_type{});
-  store_tile(0);
-  __syncthreads();
-  for (int t = 0; t < nk; t++) {
-    const int buf = t & 1;
-    if (t + 1 < nk) { if (t + 1 < nfull) load_tile(t + 1, std::true_type{}); else load_tile(t + 1, std::false_type{}); }
-    compute_tile(buf);
-    if (t + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
-  }
-
-  float* C = g.C;
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int n = n0 + wn0 + j * 32 + lr;
-      if (n >= g.N) continue;
-      const float bv = (g.epi == EPI_STORE && g.bias) ? g.bias[n] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= g.M) continue;
-        float* cp = C + (int64_t)m * g.ldc + n;
-        float v = acc[i][j][r];
-        if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) v = 0.0f;
-        if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
-        else if (g.epi == EPI_ADD) *cp = *cp + v;
-        else atomicAdd(cp, v);
-      }
-    }
-}
-
-// =============================================================================================
-// fp32 GEMM on the bf16 matrix pipe: FFH_MATH_FP32_SPLIT_BF16X3.  gfx950's fp32 MFMA runs at 1/16 of the bf16 rate, so an
-// fp32-ACCURATE product can be had faster from bf16 pieces: every operand element is split into three bfloat16 terms
-//     x = x1 + x2 + x3,   x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)      (both residuals are exact in fp32;
-//                                                                                       |x - x1 - x2 - x3| <= 2^-27 |x|)
-// and a*b is accumulated from the six products a_i b_j with i + j <= 4 -- each exact in fp32 (8 x 8 significant bits), summed
-// in fp32 by v_mfma_f32_32x32x16_bf16, small terms first; the three dropped products are <= 2^-26 |a b|, below fp32's own
-// rounding.  Six bf16 MFMAs of 32 cycles per 16 k against eight fp32 MFMAs of 64 cycles: 2.67x the fp32 pipe rate at the
-// same result to within the fp32 summation-order bound (the parity tests hold this mode to the SAME 1e-5-of-term-mass bound
-// as the exact-fp32 kernels, and compare both against float64).  Same tile / layouts as gemm_bf16_kernel with BK = 32 and
-// three planes per operand in a single 48 KB LDS buffer (two workgroups per CU); the split happens between the global load
-// and the LDS store.  Not the default: an opt-in math mode.
-// What bounds it (measured by ablation, 3456 -> 1024 at batch 32768, 1,212 us): not the 48 MFMAs per k-tile (59 % of the
-// SIMD cycles at the 1.9 GHz the chip holds under this load) but the staging path -- fp32 operands from L2 (7.2 GB per
-// launch: ~410 us by itself) and 48 KB of ds_write_b64 per k-tile (LDS stores run at ~85 B/clk/CU: ~260 us by itself); the
-// split's VALU work costs ~20 us once it is spelled as below.  A wave-specialised variant (four waves multiply, four load /
-// split / store into a second or third LDS buffer, three k-tiles of loads in flight) measured 186 / 165 / 174 TFLOP/s
-// (fwd / dX / dW) against 191 / 172 / 138 here, and the same 6.52 ms for the whole step: not kept.
-// =============================================================================================
-constexpr int kX3BK = 32;
-constexpr int kX3Plane = 128 * kX3BK * 2;               // bytes of one bf16 plane of one operand image
-constexpr int kX3Lds = 2 * 3 * kX3Plane;                // two operands x three planes, single buffer
-
-__device__ __forceinline__ unsigned x3_off_kc(int row, int chunk) { return (unsigned)(row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4)); }
-
-// The unpack and the subtraction are spelled as instructions: left to itself hipcc re-converts the low element
-// (v_cvt_pk_bf16_f32 + shift instead of a shift of the packed word: 80 conversions per tile where 48 are needed) and packs the
-// subtractions into v_pk_add_f32, which costs four times a v_sub_f32 in the shadow of an MFMA.
-__device__ __forceinline__ float bf16_lo_as_f32(const unsigned p) { unsigned r; asm("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(p)); return __uint_as_float(r); }
-__device__ __forceinline__ float bf16_hi_as_f32(const unsigned p) { unsigned r; asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(r) : "v"(p)); return __uint_as_float(r); }
-__device__ __forceinline__ float sub_f32(const float a, const float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float4 residual_f32x4(const float4 v, const uint2 p) {
-  return make_float4(sub_f32(v.x, bf16_lo_as_f32(p.x)), sub_f32(v.y, bf16_hi_as_f32(p.x)), sub_f32(v.z, bf16_lo_as_f32(p.y)), sub_f32(v.w, bf16_hi_as_f32(p.y)));
-}
-// x -> (x1, x2, x3): 22 VALU instructions per four elements.  (An infinite x gives x - x1 = NaN: such an operand turns its
-// outputs into NaN where fp32 arithmetic gives an infinity -- stated in ff_hip.h.)
-__device__ __forceinline__ void split_bf16x3(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
-  p1 = pack_bf16x4(v);
-  const float4 r = residual_f32x4(v, p1);
-  p2 = pack_bf16x4(r);
-  p3 = pack_bf16x4(residual_f32x4(r, p2));
-}
-
-template <bool AKC, bool BKC, bool MASK_A = false, int BM = 128, int BN = 128, int WM = 64>
-__global__ __launch_bounds__(BM / WM * BN) void gemm_bf16x3_kernel(const GemmArgs g) {
-  constexpr int BK = kX3BK, NT = BM / WM * BN;                  // one wave per WM x 64 of the tile
-  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;             // float4 per thread per k-tile
-  constexpr int TM = WM / 32;
-  constexpr int PLANE_A = BM * BK * 2, PLANE_B = BN * BK * 2;   // bytes of one bf16 plane of an operand image
-  extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int bx, by, bz;
-  {
-    const unsigned nbx = gridDim.x, nby = gridDim.y, nbz = gridDim.z;
-    const unsigned total = nbx * nby * nbz;
-    const unsigned lin = (blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x;
-    const unsigned xcd = lin & 7u, loc = lin >> 3;
-    const unsigned q = total >> 3, rem = total & 7u;
-    const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
-    bx = (int)(nlin % nbx);
-    by = (int)((nlin / nbx) % nby);
-    bz = (int)(nlin / (nbx * nby));
-  }
-  const int m0 = by * BM, n0 = bx * BN;
-  int kb = 0, ke = g.K;
-  if (g.splitk > 1) {
-    kb = bz * g.k_per_split;
-    ke = kb + g.k_per_split < g.K ? kb + g.k_per_split : g.K;
-  }
-  if (kb >= ke) return;
-  const int nk = (ke - kb + BK - 1) / BK;
-  const float* A = g.A;
-  const float* B = g.B;
-
-  float4 ra0[NA], rb0[NB];
-  const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
-  auto load_tile = [&](int kt, auto fast_tag, float4 (&ra)[NA], float4 (&rb)[NB]) {
-    constexpr bool FAST = decltype(fast_tag)::value;
-    const int k0 = kb + kt * BK;
-#pragma unroll
-    for (int i = 0; i < NA; i++) {
-      if (AKC) {
-        const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i;
-        const int m = m0 + row, k = k0 + 4 * k4;
-        if (FAST) ra[i] = ld4u(A + (int64_t)m * g.sAm + k);
-        else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, true);
-        if (MASK_A) {
-          float4 yv;
-          if (FAST) yv = ld4u(g.act_y + (int64_t)m * g.ld_act_y + k);
-          else yv = load4_guard(g.act_y + (int64_t)m * g.ld_act_y + k, m < g.M, k, ke, true);
-          ra[i].x = yv.x > 0.0f ? ra[i].x : 0.0f; ra[i].y = yv.y > 0.0f ? ra[i].y : 0.0f;
-          ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
-        }
-      } else {
-        const int m4 = tid % (BM / 4), kr = tid / (BM / 4) + (4 * NT / BM) * i;
-        const int m = m0 + 4 * m4, k = k0 + kr;
-        if (FAST) ra[i] = ld4u(A + (int64_t)k * g.sAk + m);
-        else ra[i] = load4_guard(A + (int64_t)k * g.sAk + m, k < ke, m, g.M, true);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-      if (BKC) {
-        const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i;
-        const int n = n0 + row, k = k0 + 4 * k4;
-        if (FAST) rb[i] = ld4u(B + (int64_t)n * g.sBn + k);
-        else rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, true);
-      } else {
-        const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;
-        const int n = n0 + 4 * n4, k = k0 + kr;
-        if (FAST) rb[i] = ld4u(B + (int64_t)k * g.sBk + n);
-        else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, true);
-      }
-    }
-  };
-  auto split_store = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
-    unsigned char* as = x3_smem;
-    unsigned char* bs = x3_smem + 3 * PLANE_A;
-#pragma unroll
-    for (int i = 0; i < NA; i++) {
-      uint2 p1, p2, p3;
-      split_bf16x3(ra[i], p1, p2, p3);
-      unsigned o;
-      if (AKC) { const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
-      else     { const int m4 = tid % (BM / 4), kr = tid / (BM / 4) + (4 * NT / BM) * i;  o = bf_off_kr<BM>(kr, m4 >> 1) + 8 * (m4 & 1); }
-      *reinterpret_cast<uint2*>(as + o) = p1;
-      *reinterpret_cast<uint2*>(as + PLANE_A + o) = p2;
-      *reinterpret_cast<uint2*>(as + 2 * PLANE_A + o) = p3;
-    }
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-      uint2 p1, p2, p3;
-      split_bf16x3(rb[i], p1, p2, p3);
-      unsigned o;
-      if (BKC) { const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i; o = x3_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
-      else     { const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;  o = bf_off_kr<BN>(kr, n4 >> 1) + 8 * (n4 & 1); }
-      *reinterpret_cast<uint2*>(bs + o) = p1;
-      *reinterpret_cast<uint2*>(bs + PLANE_B + o) = p2;
-      *reinterpret_cast<uint2*>(bs + 2 * PLANE_B + o) = p3;
-    }
-  };
-
-  f32x16 acc[TM][2];
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
-  const int wm0 = (wave / (BN / 64)) * WM, wn0 = (wave % (BN / 64)) * 64;
-  const int lr = lane & 31, lh = lane >> 5;
-  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-  auto frag = [&](const unsigned char* img, bool kc, auto rowlen_tag, int o, int s) -> bf16x8_t {
-    constexpr int RL = decltype(rowlen_tag)::value;
-    if (kc) return *reinterpret_cast<const bf16x8_t*>(img + x3_off_kc(o + lr, 2 * s + lh));
-    typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
-    const int ch = (o >> 3) + 2 * (tg & 1) + (tp >> 1);
-    const int k0r = 16 * s + 8 * (tg >> 1) + tq;
-    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<RL>(k0r, ch) + 8 * (tp & 1)));
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<RL>(k0r + 4, ch) + 8 * (tp & 1)));
-    typedef short s16x8_t __attribute__((ext_vector_type(8)));
-    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8_t, v);
-  };
-  auto compute_tile = [&]() {
-    const unsigned char* as = x3_smem;
-    const unsigned char* bs = x3_smem + 3 * PLANE_A;
-#pragma unroll
-    for (int s = 0; s < BK / 16; s++) {
-      bf16x8_t b[2][3];
-#pragma unroll
-      for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int j = 0; j < 2; j++) b[j][p] = frag(bs + p * PLANE_B, BKC, std::integral_constant<int, BN>{}, wn0 + 32 * j, s);
-#pragma unroll
-      for (int ih = 0; ih < TM; ih += 2) {                  // two row tiles at a time: 6 + 6 fragments live
-        bf16x8_t a[2][3];
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-#pragma unroll
-          for (int i = 0; i < 2; i++) a[i][p] = frag(as + p * PLANE_A, AKC, std::integral_constant<int, BM>{}, wm0 + 32 * (ih + i), s);
-        // the six products with i + j <= 4, small terms first
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) {
-            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[ih + i][j], 0, 0, 0);
-            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[ih + i][j], 0, 0, 0);
-            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[ih + i][j], 0, 0, 0);
-          }
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) {
-            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[ih + i][j], 0, 0, 0);
-            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[ih + i][j], 0, 0, 0);
-          }
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < 2; j++) acc[ih + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[ih + i][j], 0, 0, 0);
-      }
-    }
-  };
-
-  const int nfull = (a_in && b_in) ? (ke - kb) / BK : 0;
-  auto load_any = [&](int kt, float4 (&ra)[NA], float4 (&rb)[NB]) {
-    if (kt >= nk) return;
-    if (kt < nfull) load_tile(kt, std::true_type{}, ra, rb); else load_tile(kt, std::false_type{}, ra, rb);
-  };
-  load_any(0, ra0, rb0);
-  split_store(ra0, rb0);
-  __syncthreads();
-  for (int t = 0; t < nk; t++) {
-    load_any(t + 1, ra0, rb0);            // in flight under this tile's MFMAs (a second register set, two tiles ahead, was
-    compute_tile();                       //   measured: +2 % forward, -12 % dW -- its 194 VGPRs leave one workgroup per CU)
-    __syncthreads();                      // every wave has read this tile's fragments
-    if (t + 1 < nk) { split_store(ra0, rb0); __syncthreads(); }
-  }
-
-  float* C = g.C;
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int n = n0 + wn0 + j * 32 + lr;
-      if (n >= g.N) continue;
-      const float bv = (g.epi == EPI_STORE && g.bias) ? g.bias[n] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= g.M) continue;
-        float* cp = C + (int64_t)m * g.ldc + n;
-        float v = acc[i][j][r];
-        if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) v = 0.0f;
-        if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
-        else if (g.epi == EPI_ADD) *cp = *cp + v;
-        else atomicAdd(cp, v);
-      }
-    }
-}
-
-// =============================================================================================
 // LDS-DMA GEMM for the mid-size layers of the 2048-sample step (432x512, 512x256 ...): outputs of only
 // ~1 M elements, i.e. ONE 64x64 tile per CU.  What bounds such a launch is not the matrix pipe but how the
 // operand bytes get on chip next to it, so:
@@ -1163,11 +655,6 @@ bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p, double 
   return true;
 }
 
-template <typename K>
-bool glds_set_lds(K kern, int bytes) {
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return true;
-}
 
 // Returns 1 if the LDS-DMA kernel took the GEMM, 0 if the shape is not its business, < 0 on error.
 template <bool AKR, bool BKR>
@@ -1425,101 +912,6 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   return FFH_OK;
 }
 
-inline bool use_bf16(const ffh_ctx* c, int in, int out) {     // either bf16-pipe mode: same layers, same launch paths
-  return (c->math_mode == FFH_MATH_TENSOR_OP_BF16 || c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3) && in >= FFH_BF16_MIN_DIM && out >= FFH_BF16_MIN_DIM;
-}
-
-// bf16-operand form of launch_gemm (tensor-op math mode): 128 x 128 tiles; EPI_ATOMIC splits K over workgroups
-template <bool AKC, bool BKC, bool MASK_A = false>
-int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
-  if (g.M <= 0 || g.N <= 0 || g.K <= 0) return FFH_OK;
-  const bool x3 = c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3;      // three bf16 planes per operand: fp32-accurate
-  // 256 x 256 tiles (one 8-wave workgroup per CU, 128 x 64 per wave) where the output still fills the chip with them: half
-  // the operand traffic per flop.  Measured at batch 32768: forward 3456 -> 1024 492 -> 353 us, 1024 -> 1024 162 -> 143;
-  // dX +3...6 % from a reduction depth of 1024 up, slower below; the split-K weight-gradient form: see below.
-  static const int tile_env = getenv("FFH_BF16_TILE") ? atoi(getenv("FFH_BF16_TILE")) : 0;
-  const int64_t tiles_big = (int64_t)((g.N + 255) / 256) * ((g.M + 255) / 256);
-  const bool big_form = (AKC && BKC) || (AKC && !BKC && g.K >= 1024);
-  // the split mode takes the same tile (96 KB: three planes per operand): forward / dX +4 %, the weight gradient of the big
-  // layer 1,676 -> 1,241 us; whole split-mode step 6.9 -> 6.6-6.8 ms (FFH_X3_BIG: 0 never, 1 not for the weight gradient)
-  static const int x3_big = getenv("FFH_X3_BIG") ? atoi(getenv("FFH_X3_BIG")) : 2;             // A/B switch
-  bool big = (!x3 || x3_big) && big_form && g.M >= 256 && g.N >= 256 && tiles_big >= c->num_cus;
-  // the split-K weight-gradient form: big tiles where there are enough of them that a split can fill whole rounds of one
-  // workgroup per CU (3456 x 1024 at batch 32768: 56 tiles x 9 splits = 504; 747 -> 553 us); 16 tiles (1024 x 1024) lose 8 %
-  static const int dw_big = getenv("FFH_BF16_DW_BIG") ? atoi(getenv("FFH_BF16_DW_BIG")) : 1;     // A/B switch
-  if (dw_big && (!x3 || x3_big > 1) && !AKC && !BKC && g.epi == EPI_ATOMIC && !c->deterministic && tiles_big >= 32 && g.K >= 8192) big = true;
-  if (tile_env == 128) big = false;
-  if (tile_env == 256 && g.M >= 256 && g.N >= 256) big = true;
-  const int bm = big ? 256 : kBfBM, bn = big ? 256 : kBfBN;
-  const int gx = (g.N + bn - 1) / bn, gy = (g.M + bm - 1) / bm;
-  g.splitk = 1;
-  g.k_per_split = g.K;
-  int gz = 1;
-  if (g.epi == EPI_ATOMIC && c->deterministic) g.epi = EPI_ADD;
-  if (g.epi == EPI_ATOMIC) {
-    const int64_t tiles = (int64_t)gx * gy;
-    int want = (int)(((big ? 1LL : 2LL) * c->num_cus + tiles - 1) / tiles);
-    const int max_split = (g.K + 4 * kBfBK - 1) / (4 * kBfBK);     // at least four k-tiles per workgroup
-    // (for the 128 x 128 tile the same search makes a weight-gradient GEMM up to 30 % faster ALONE and the step no faster:
-    //  in the step the holes of an unbalanced launch are filled by the data-gradient GEMM on the other stream -- off by default)
-    static const int fill_small = getenv("FFH_BF16_FILL") ? atoi(getenv("FFH_BF16_FILL")) : 0;    // A/B switch
-    if (big || fill_small) {
-      // pick the split whose workgroup count fills whole rounds of resident workgroups best (one per CU for the big tile, two for 128 x 128)
-      const int64_t slots = (big ? 1LL : 2LL) * c->num_cus;
-      int best = want; double best_u = 0.0;
-      for (int w2 = want; w2 <= 2 * want + 2 && w2 <= max_split; w2++) {
-        const int64_t nb = tiles * w2;
-        const double u = (double)nb / (double)(((nb + slots - 1) / slots) * slots);
-        if (u > best_u + 1e-9) { best_u = u; best = w2; }
-      }
-      want = best;
-    }
-    if (want > max_split) want = max_split;
-    if (want < 1) want = 1;
-    int kps = (g.K + want - 1) / want;
-    kps = (kps + kBfBK - 1) / kBfBK * kBfBK;
-    g.k_per_split = kps;
-    g.splitk = (g.K + kps - 1) / kps;
-    if (g.splitk <= 1) g.splitk = 2;             // keeps blockIdx.z meaning "split" (the second split is empty)
-    gz = g.splitk;
-  }
-  if (gy > 65535 || gz > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm (bf16): grid too large");
-  if (x3 && big) {
-    auto kern3b = gemm_bf16x3_kernel<AKC, BKC, MASK_A, 256, 256, 128>;
-    constexpr int lds3b = 3 * (256 + 256) * kX3BK * 2;          // 96 KB: one 8-wave workgroup per CU
-    static const bool ok3b = glds_set_lds(kern3b, lds3b);
-    if (!ok3b) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16x3): cannot reserve 96 KB of LDS");
-    hipLaunchKernelGGL(kern3b, dim3(gx, gy, gz), dim3(512), lds3b, as_stream(s), g);
-    hipError_t e3b = hipGetLastError();
-    if (e3b != hipSuccess) return ffh_fail_hip(c, e3b, name);
-    return FFH_OK;
-  }
-  if (x3) {
-    auto kern3 = gemm_bf16x3_kernel<AKC, BKC, MASK_A>;
-    static const bool ok3 = glds_set_lds(kern3, kX3Lds);
-    if (!ok3) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16x3): cannot reserve 48 KB of LDS");
-    hipLaunchKernelGGL(kern3, dim3(gx, gy, gz), dim3(256), kX3Lds, as_stream(s), g);
-    hipError_t e3 = hipGetLastError();
-    if (e3 != hipSuccess) return ffh_fail_hip(c, e3, name);
-    return FFH_OK;
-  }
-  if (big) {
-    auto kernw = gemm_bf16_kernel<AKC, BKC, MASK_A, 256, 256, 128>;
-    static const bool okw = glds_set_lds(kernw, bf_lds_bytes(256, 256));
-    if (!okw) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16): cannot reserve 128 KB of LDS");
-    hipLaunchKernelGGL(kernw, dim3(gx, gy, gz), dim3(512), bf_lds_bytes(256, 256), as_stream(s), g);
-    hipError_t ew = hipGetLastError();
-    if (ew != hipSuccess) return ffh_fail_hip(c, ew, name);
-    return FFH_OK;
-  }
-  auto kern = gemm_bf16_kernel<AKC, BKC, MASK_A>;
-  static const bool ok = glds_set_lds(kern, kBfLds);
-  if (!ok) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16): cannot reserve 64 KB of LDS");
-  hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), kBfLds, as_stream(s), g);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return ffh_fail_hip(c, e, name);
-  return FFH_OK;
-}
 
 // =============================================================================================
 // Linear with a handful of outputs (the click-probability layer of the DLRM top MLP: out = 1).  GEMV-shaped and
@@ -2015,7 +1407,7 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   g.C = y; g.ldc = ldy; g.bias = bias;
   g.M = (int)batch; g.N = out; g.K = in;
   g.epi = EPI_STORE; g.act = act;
-  if (use_bf16(c, in, out)) return launch_gemm_bf16<true, true>(c, g, s, "linear_fwd gemm (bf16)");
+  if (use_bf16(c, in, out)) return launch_gemm_bf16_form(c, g, BF16_FORM_FWD, s, "linear_fwd gemm (bf16)");
   {
     GldsArgs d{};
     d.A = x; d.lda = ldx; d.B = w; d.ldb = in; d.C = y; d.ldc = ldy; d.bias = bias;
@@ -2130,7 +1522,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       gw.C = dw; gw.ldc = in;
       gw.M = out; gw.N = in; gw.K = (int)batch;
       gw.epi = EPI_ATOMIC; gw.act = FFH_AC_MODE_NONE;
-      const int rc = launch_gemm_bf16<false, false>(c, gw, sw_, "linear_bwd dw gemm (bf16)");
+      const int rc = launch_gemm_bf16_form(c, gw, BF16_FORM_DW, sw_, "linear_bwd dw gemm (bf16)");
       if (rc) return rc;
     }
     if (dx && do_dx) {
@@ -2145,9 +1537,9 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       int rc;
       if ((forked_ || !do_dw) && relu_) {          // dy is (being) masked by someone else: read it through relu'(y)
         gx.act_y = y; gx.ld_act_y = ldy;
-        rc = launch_gemm_bf16<true, false, true>(c, gx, s, "linear_bwd dx gemm (bf16, masking)");
+        rc = launch_gemm_bf16_form(c, gx, BF16_FORM_DX_MASK, s, "linear_bwd dx gemm (bf16, masking)");
       } else {
-        rc = launch_gemm_bf16<true, false>(c, gx, s, "linear_bwd dx gemm (bf16)");
+        rc = launch_gemm_bf16_form(c, gx, BF16_FORM_DX, s, "linear_bwd dx gemm (bf16)");
       }
       if (rc) return rc;
     }
