@@ -57,8 +57,10 @@ def test_new_batch_every_step_is_ordered_behind_the_table_update(hip, tmp_path, 
             dg, dc = g1 - res["hip"][0][k], c1 - res["cpu"][0][k]
             scale = np.abs(dc).max()
             assert scale > 0
-            # same rows touched by the same amounts (tolerance: fp32 differences of nearly equal numbers)
-            assert np.abs(dg - dc).max() <= 2e-3 * scale, (k, float(np.abs(dg - dc).max()), float(scale))
+            # same rows touched by the same amounts.  Tolerance: fp32 differences of nearly equal numbers, and seven steps of
+            # weight gradients summed by fp32 atomics in a different order every run (seen: up to a few 1e-3 of the largest
+            # delta); a stale or half-overwritten id buffer moves whole rows, i.e. errors of the order of `scale` itself
+            assert np.abs(dg - dc).max() <= 2e-2 * scale, (k, float(np.abs(dg - dc).max()), float(scale))
 
 
 def test_graph_replay_uses_this_steps_gradients_kaggle_shape(hip):
@@ -86,7 +88,7 @@ def test_graph_replay_uses_this_steps_gradients_kaggle_shape(hip):
         if k.startswith("Embedding"):
             dg, de = res[True][1][k] - res[True][0][k], res[False][1][k] - res[False][0][k]
             scale = np.abs(de).max()
-            assert np.abs(dg - de).max() <= 5e-3 * scale, (k, float(np.abs(dg - de).max()), float(scale))
+            assert np.abs(dg - de).max() <= 2e-2 * scale, (k, float(np.abs(dg - de).max()), float(scale))
             n_tab += 1
     assert n_tab == 26
 
