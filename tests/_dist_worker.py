@@ -35,8 +35,9 @@ def main():
             for k, v in rec.items():
                 out[f"s{step}/{k}"] = v
         m.close()
-    elif mode == "hdf5":
-        app = ffmodel.DLRM(["--backend", H.oracle_backend()] + H.HDF5_ARGS + ["--dataset", os.path.join(outdir, "day.h5")], comm=comm.struct)
+    elif mode in ("hdf5", "hdf5_replicated"):
+        rep = ["--replicate-embedding-rows", "60"] if mode == "hdf5_replicated" else []      # tables of 50 and 7 rows data-parallel, the 300-row one owned
+        app = ffmodel.DLRM(["--backend", H.oracle_backend()] + H.HDF5_ARGS + rep + ["--dataset", os.path.join(outdir, "day.h5")], comm=comm.struct)
         app.warmup()
         app.train_steps(7, trace=False)          # 1 + 7 steps over 6 batches: wraps around once
         app.model.sync()

@@ -632,3 +632,29 @@ def test_profiling_flag_prints_per_op_times(oracle):
     assert "forward time" not in plain.stdout
     mse = lambda txt: [l for l in txt.splitlines() if "mean_squared_error" in l][-1]
     assert mse(r.stderr) == mse(plain.stderr)
+
+
+def test_two_rank_hdf5_dataset_with_data_parallel_tables(tmp_path):
+    """The file loader next to --replicate-embedding-rows: every rank holds the ids of a replicated table for the whole batch and
+    gathers its own half; a new batch every step (the replicated gradient is computed on the compute stream from that step's
+    ids).  Trajectory equals the single-rank run; both ranks end with the same copy of the two replicated tables."""
+    h5, exp = H.make_criteo_like_hdf5(str(tmp_path))
+    _run_ranks(2, tmp_path, "hdf5_replicated")
+    app = ffmodel.DLRM(["--backend", H.oracle_backend()] + H.HDF5_ARGS + ["--dataset", h5])
+    app.warmup(); app.train_steps(7, trace=False); app.model.sync()
+    ref = {"w_bot": app.model.parameter(0, 0).get_weights(), "w_top": app.model.parameter(app.model.num_layers - 1, 0).get_weights()}
+    for t in range(3):
+        ref[f"emb{t}"] = app.model.parameter(2 + t, 0).get_weights()
+    app.close()
+    holders = {0: [], 1: [], 2: []}
+    for r in range(2):
+        z = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        assert np.array_equal(z["dense"], exp["X_int"][16 + 8 * r:16 + 8 * (r + 1)])
+        for t in range(3):
+            if f"emb{t}" in z.files:
+                holders[t].append(r)
+                assert np.array_equal(z[f"sparse{t}"].reshape(-1), exp["X_cat"][16:32, t])       # ids of the whole batch
+                np.testing.assert_allclose(z[f"emb{t}"], ref[f"emb{t}"], rtol=1e-5, atol=1e-6, err_msg=f"rank {r} table {t}")
+        np.testing.assert_allclose(z["w_top"], ref["w_top"], rtol=1e-5, atol=1e-6)
+        assert int(z["alltoall_calls"]) == 2 * 8 and int(z["allreduce_calls"]) == 8     # table 2 still crosses the all-to-all
+    assert holders[0] == [0, 1] and holders[1] == [0, 1] and len(holders[2]) == 1
