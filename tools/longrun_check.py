@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from dlrm_flexflow_amd import ffmodel
 w = bench.workload(sys.argv[1] if len(sys.argv) > 1 else "kaggle", bench.DEFAULT_BATCH[sys.argv[1] if len(sys.argv) > 1 else "kaggle"])
-app = ffmodel.DLRM(bench.flags_of(w, ["--device", "0"]))
+app = ffmodel.DLRM(bench.flags_of(w, ["--device", "0"] + sys.argv[2:]))
 app.warmup()
 m = app.model
 for k in range(6):
