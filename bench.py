@@ -473,6 +473,14 @@ def main():
     if world > 1 or args.force_exchange:
         out["config"]["ranks_observed"] = dist.get_world_size()
         out["config"]["collective_calls_rank0"] = calls
+        # what one step moves over xGMI from / to rank 0 (payload, not counting RCCL's own protocol)
+        def mlp_params(spec, first_in=None):
+            dims = [int(v) for v in spec.split("-")]
+            return sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
+        a2a = owned * B * D * 4 * (world - 1) // world if table_wise else None     # column- / row-wise layouts: not itemised here
+        dense = mlp_params(w["bot"]) + mlp_params(w["top"]) + sum(rows_of[t] for t in replicated) * D
+        out["config"]["collective_payload_bytes_per_step_rank0"] = {"alltoall_forward_sent": a2a, "alltoall_backward_sent": a2a,
+                                                                    "allreduce_buffer": 4 * dense}
     if args.force_exchange:
         out["config"]["parallelism"] = f"1 rank, exchange path forced: {layout} + all-reduce; {collectives}"
     out["kernels"] = {}
