@@ -26,6 +26,14 @@
 
 using namespace ffh_gemm;
 
+// The plain forward instantiation of the 128 x 128 x 16 kernel is compiled for four workgroups per CU (128 registers, 8 bytes of
+// scratch) instead of the three its natural 164 registers allow: +1 % on the big layers' forward (1,737 -> 1,720 us), +0.35 %
+// on the Terabyte step, three interleaved pairs.  The masking / weight-gradient forms lose as much under the same limit and
+// keep theirs.  (Fewer than three workgroups per CU costs 6 % per workgroup: DESIGN 3.3.)
+#ifndef FFH_FWD_OCC4
+#define FFH_FWD_OCC4 1
+#endif
+
 namespace {
 
 
@@ -35,7 +43,8 @@ namespace {
 //                 For the skinny DLRM layers (2048 x 256, 2048 x 64 ...) this gives 4x the waves of
 //                 a 64x64 tiling: a 32x32x2 MFMA chain over K = 512 alone is 16k cycles.
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool SPLITW = false, bool FUSE_DY = false, bool CMAP = false>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, (FFH_FWD_OCC4 && BM == 128 && BN == 128 && BK == 16 && AKC && BKC && !SPLITW && !FUSE_DY && !CMAP) ? 4 : 1)
+void gemm_f32_kernel(const GemmArgs g) {
   constexpr int PA = AKC ? 1 : 4, PB = BKC ? 1 : 4;
   constexpr int LA = BM + PA, LB = BN + PB;
   constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 staging slots per thread
