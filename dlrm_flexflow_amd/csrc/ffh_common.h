@@ -24,8 +24,17 @@ struct ffh_ctx {
   int         deterministic;   // ffh_ctx_set_deterministic(): no fp atomics in weight / bias gradients
   int         math_mode; // ffh_ctx_set_math_mode(): FFH_MATH_DEFAULT | FFH_MATH_TENSOR_OP_BF16
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
+  char        route[256]; // ffh_linear_last_route(): kernel families of the latest ffh_linear_* call
   char        err[512];
 };
+
+// ffh_linear_last_route bookkeeping: every ffh_linear_* entry clears the note, every GEMM launch site appends a token
+static inline void ffh_route_clear(ffh_ctx* c) { if (c) c->route[0] = 0; }
+static inline void ffh_route_add(ffh_ctx* c, const char* token) {
+  if (!c) return;
+  const size_t n = strlen(c->route);
+  snprintf(c->route + n, sizeof c->route - n, "%s%s", n ? ";" : "", token);
+}
 
 static inline int ffh_fail(ffh_ctx* c, int code, const char* msg) {
   if (c) snprintf(c->err, sizeof c->err, "%s", msg);

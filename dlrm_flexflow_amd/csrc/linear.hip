@@ -685,6 +685,7 @@ int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const
 #undef FFH_GLDS_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+  { char tok[96]; snprintf(tok, sizeof tok, "%s|glds_%dx64_s%d|splitk=%d", name, p.bm, two ? 2 : 3, g.splitk); ffh_route_add(c, tok); }
   return 1;
 }
 
@@ -730,6 +731,7 @@ int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
 #undef FFH_DUAL
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, "linear_bwd dx+dw (lds-dma, one launch)");
+  { char tok[96]; snprintf(tok, sizeof tok, "linear_bwd dx+dw|glds_dual_%dx64_s%d|splitk=%d", px.bm, two ? 2 : 3, dwg.splitk); ffh_route_add(c, tok); }
   if (scatter) c->scatter_used = 1;         // only once the launch that scatters is really in the stream
   if (ev_after) {
     e = hipEventRecord(ev_after, as_stream(s));
@@ -918,6 +920,7 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   else hipLaunchKernelGGL((gemm_f32_kernel<32, 32, 64, AKC, BKC, true, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+  { char tok[96]; snprintf(tok, sizeof tok, "%s|f32_%dx%d_cfg%d|splitk=%d", name, BMv, BNv, cfg, g.splitk); ffh_route_add(c, tok); }
   return FFH_OK;
 }
 
@@ -1396,11 +1399,13 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   FFH_REQUIRE(c, batch == 0 || (x && y && w), "linear_fwd: null pointer");
   FFH_REQUIRE(c, batch < (1LL << 31), "linear_fwd: batch too large");
   if (!act_ok_fwd(act)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_fwd: activation not supported (NONE, RELU, SIGMOID, GELU)");
+  ffh_route_clear(c);
   if (batch == 0) return FFH_OK;
   if (out <= kSkinnyMaxOut) {
     hipLaunchKernelGGL(linear_skinny_fwd_kernel, dim3(ffh_grid(batch, 4, 2048)), dim3(256), 0, as_stream(s), x, ldx, y, ldy, w, bias, in, out,
                        batch, act);
     FFH_LAUNCH_CHECK(c, "linear_skinny_fwd_kernel");
+    ffh_route_add(c, "linear_fwd|skinny");
     return FFH_OK;
   }
   static const int no_thin = getenv("FFH_NO_THIN") ? atoi(getenv("FFH_NO_THIN")) : 0;   // A/B switch (tools/ab.sh)
@@ -1408,6 +1413,7 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
     hipLaunchKernelGGL(linear_thin_fwd_kernel, dim3((unsigned)((batch + 31) / 32), (unsigned)((out + 255) / 256)), dim3(512), 0, as_stream(s), x, ldx, y, ldy,
                        w, bias, in, out, batch, act);
     FFH_LAUNCH_CHECK(c, "linear_thin_fwd_kernel");
+    ffh_route_add(c, "linear_fwd|thin");
     return FFH_OK;
   }
   GemmArgs g{};
@@ -1492,6 +1498,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     else FFH_SKINNY(1, 16);
 #undef FFH_SKINNY
     FFH_LAUNCH_CHECK(c, "linear_skinny_bwd_kernel");
+    ffh_route_add(c, "linear_bwd|skinny");
     return FFH_OK;
   }
   if (label) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: not a one-launch layer (out_dim <= 4, in_dim <= 1024, aligned)");
@@ -1668,6 +1675,7 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
                       float* dy, int64_t lddy, const float* w, float* dw, float* db,
                       int in, int out, int64_t batch, int act, int flags, ffh_stream s, ffh_stream s_dw) {
   if (c) c->scatter_used = 0;
+  ffh_route_clear(c);
   const int rc = linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, s_dw, nullptr, 0.0f, nullptr, 0);
   if (c) { c->scatter_map = nullptr; c->scatter_event = nullptr; }       // one call only, taken or not
   if (c && c->attach_event) {        // no launch could carry it: the ordinary record behind everything this call put on s
@@ -1699,6 +1707,7 @@ int ffh_linear_bwd_mse(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64
   if (flags & (FFH_LINEAR_ONLY_DX | FFH_LINEAR_ONLY_DW | FFH_LINEAR_DY_PREMASKED)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: split / premasked forms");
   if (ldy != out || lddy != out) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: y and dy must be contiguous [batch][out_dim]");
   if (batch == 0) return FFH_OK;
+  ffh_route_clear(c);
   return linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, nullptr, label, scale, perf, metrics_flags);
 }
 

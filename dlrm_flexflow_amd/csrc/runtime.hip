@@ -4,6 +4,7 @@
 // [ref: examples/cpp/DLRM/dlrm.cc:174-181]) is exposed here as plain HIP objects.
 #include "ffh_common.h"
 
+#include <mutex>
 #include <new>
 
 extern "C" {
@@ -29,6 +30,23 @@ int ffh_ctx_create(ffh_ctx** out, int device) {
   return FFH_OK;
 }
 
+// ffh_ctx_default: one library-owned ctx per device, for static call sites that get no handle
+int ffh_ctx_default(ffh_ctx** out) {
+  static std::mutex mu;
+  static ffh_ctx* per_device[64];
+  if (!out) return FFH_ERR_BAD_ARG;
+  *out = nullptr;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return FFH_ERR_HIP; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (!per_device[dev]) {
+    const int rc = ffh_ctx_create(&per_device[dev], dev);
+    if (rc != FFH_OK) return rc;
+  }
+  *out = per_device[dev];
+  return FFH_OK;
+}
+
 int ffh_ctx_destroy(ffh_ctx* c) {
   if (c && c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c && c->zeros) (void)hipFree(c->zeros);
@@ -37,6 +55,7 @@ int ffh_ctx_destroy(ffh_ctx* c) {
 }
 
 const char* ffh_last_error_string(const ffh_ctx* c) { return c ? c->err : "null ctx"; }
+const char* ffh_linear_last_route(const ffh_ctx* c) { return c ? c->route : ""; }
 
 int ffh_device_query(ffh_ctx* c, ffh_device_info* info) {
   if (!c || !info) return FFH_ERR_BAD_ARG;

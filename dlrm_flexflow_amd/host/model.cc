@@ -1793,7 +1793,9 @@ void FFModel::forward(int _seq_length) {
     // The side stream already runs behind everything it depends on from earlier steps (the table update is on it);
     // what it must additionally see is a batch that was copied in on `stream`.  No new batch (the reference reuses
     // the warm-up batch for random input), no event: each record / wait is a barrier packet on the critical stream.
-    fork_recorded = inputs_dirty || capturing_trace >= 0 || use_workers();
+    // Exception: data-parallel (replicated) tables live in the dense parameter slab, which the optimizer of the step before
+    // wrote on `stream` (all-reduce + SGD / Adam in update()): their gather must always be ordered behind it.
+    fork_recorded = inputs_dirty || capturing_trace >= 0 || use_workers() || repl_workspace != nullptr;
     if (fork_recorded) check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
     inputs_dirty = false;
     // start the gather right now unless a host-side collective would stall THIS thread's launches

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 4   /* 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 5   /* 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -121,6 +121,13 @@ int         ffh_ctx_create(ffh_ctx** out, int device);
 int         ffh_ctx_destroy(ffh_ctx* ctx);
 const char* ffh_last_error_string(const ffh_ctx* ctx);
 int         ffh_device_query(ffh_ctx* ctx, ffh_device_info* info);
+/* The library-owned ctx of the calling thread's CURRENT device (hipGetDevice), created on first use, one per device and
+ * process, never destroyed by the caller.  For the reference's static kernels that receive NO handle or OpMeta:
+ * Embedding::forward_kernel / backward_kernel [ref: include/model.h:1169-1186] and Concat::forward_kernel /
+ * backward_kernel [ref: include/model.h:1771-1784] are static members without a meta argument (Linear and BatchMatmul carry
+ * a `*Meta`, :1011-1027, :1098-1118), so their replacement bodies cannot reach FFHandler; they call this instead
+ * (INTEGRATION.md section 2).  It has no workspace attached unless the caller attaches one. */
+int         ffh_ctx_default(ffh_ctx** out);
 /* attach caller-owned scratch; replaces FFHandler.workSpace/workSpaceSize */
 int         ffh_ctx_set_workspace(ffh_ctx* ctx, void* ws, size_t bytes);
 /* Math mode of the handle: cublasSetMathMode(handle.blas, CUBLAS_TENSOR_OP_MATH) behind --allow-tensor-op-math-conversion
@@ -205,7 +212,11 @@ int ffh_gen_bernoulli(ffh_ctx* ctx, float* ptr, int64_t count, uint64_t seed, in
  * aggr: FFH_AGGR_MODE_SUM, or FFH_AGGR_MODE_AVG (true mean: sum * (1/in_dim); the
  * reference's AVG divides inside the j loop, a bug not reproduced -- SURVEY 8a-1).
  * Row ids must satisfy 0 <= idx < num_entries (CPU reference asserts it,
- * [ref: src/ops/embedding.cc:71-73]); out-of-range ids are not checked on the device. */
+ * [ref: src/ops/embedding.cc:71-73]); out-of-range ids are not checked on the device.
+ * The reference's static signature carries no row count (its GPU kernel never reads one, [ref: src/ops/embedding.cu:166-190]):
+ * a caller that does not know it passes FFH_NUM_ENTRIES_UNKNOWN to ffh_embedding_fwd / ffh_embedding_bwd_dense, which use
+ * num_entries for argument validation only (the fused update does need the real count: it sizes the radix sort). */
+#define FFH_NUM_ENTRIES_UNKNOWN ((int64_t)1 << 40)
 int ffh_embedding_fwd(ffh_ctx* ctx, const int64_t* idx, float* out, const float* weight,
                       int in_dim, int out_dim, int64_t batch, int64_t num_entries,
                       int64_t out_ld, int aggr, ffh_stream s);
@@ -258,6 +269,10 @@ int ffh_embedding_localize_rows(ffh_ctx* ctx, const int64_t* idx, int64_t* local
 int ffh_linear_fwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy,
                    const float* w, const float* bias,
                    int in_dim, int out_dim, int64_t batch, int activation, ffh_stream s);
+/* Which kernel families the most recent ffh_linear_* call on this ctx launched: ';'-separated tokens "<gemm>:<family>[:detail]"
+ * with <gemm> in {fwd, dx, dw, bwd} (e.g. "dx:f32_128x128x16;dw:glds_64x64:splitk=8").  Diagnostic (no reference
+ * counterpart): lets a test assert that a shape really took the route it is meant to cover.  The oracle returns "oracle". */
+const char* ffh_linear_last_route(const ffh_ctx* ctx);
 /* Linear::backward_kernel [ref: include/model.h:1018-1027, src/ops/linear.cu:610-660]
  * in place: dy = dy * act'(y)   (relu: y>0 ? dy : 0 [ref: src/runtime/cuda_helper.cu:71-78];
  *                                sigmoid: dy*y*(1-y) [ref: src/ops/linear.cu:600-607])
@@ -480,7 +495,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
 /* X-macro list of every exported symbol (used by the dlopen loader of the C++
  * FFModel shim and by tests/test_abi_symbols.py). */
 #define FFH_API_LIST(X) \
-  X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) \
+  X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) X(ffh_ctx_default) \
   X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) \
   X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
   X(ffh_stream_create) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
@@ -492,7 +507,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

@@ -69,7 +69,15 @@ int ffh_ctx_create(ffh_ctx** out, int device) {
   *out = c;
   return FFH_OK;
 }
+int ffh_ctx_default(ffh_ctx** out) {          /* one library-owned ctx (the "device" is the host) */
+  static ffh_ctx* def;
+  if (!out) return FFH_ERR_BAD_ARG;
+  if (!def) { const int rc = ffh_ctx_create(&def, 0); if (rc != FFH_OK) return rc; }
+  *out = def;
+  return FFH_OK;
+}
 int ffh_ctx_destroy(ffh_ctx* c) { free(c); return FFH_OK; }
+const char* ffh_linear_last_route(const ffh_ctx* c) { (void)c; return "oracle"; }
 const char* ffh_last_error_string(const ffh_ctx* c) { return c ? c->err : "null ctx"; }
 int ffh_device_query(ffh_ctx* c, ffh_device_info* info) {
   if (!c || !info) return FFH_ERR_BAD_ARG;

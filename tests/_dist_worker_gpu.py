@@ -28,13 +28,20 @@ def main():
     if direct:
         comm = RcclComm(comm)
     out = {}
-    if len(sys.argv) > 3 and sys.argv[3] == "kaggle":
+    if len(sys.argv) > 3 and sys.argv[3].startswith("kaggle"):
         # the Criteo-Kaggle shape at 2048 samples per rank through the DLRM application object (driver flags)
+        # kaggle-repl[-noov]: tables of <= 8192 rows data-parallel; six steady-state steps on the resident batch (the inputs are
+        # never rewritten, so no new-batch event orders the side-stream gather behind the slab optimizer of the step before)
         from dlrm_flexflow_amd import ffmodel
         world = dist.get_world_size()
-        app = ffmodel.DLRM(H.KAGGLE_ARGS(2048 * world) + ["--device", "0", "--force-exchange"], comm=comm.struct)
+        extra, steps = [], 3
+        if sys.argv[3].startswith("kaggle-repl"):
+            extra, steps = ["--replicate-embedding-rows", "8192"], 6
+            if sys.argv[3].endswith("noov"):
+                extra.append("--no-overlap")
+        app = ffmodel.DLRM(H.KAGGLE_ARGS(2048 * world) + ["--device", "0", "--force-exchange"] + extra, comm=comm.struct)
         app.warmup()
-        app.train_steps(3, trace=False)
+        app.train_steps(steps, trace=False)
         app.model.sync()
         m = app.model
         out["pred"] = m.layer_output(m.num_layers - 1).get()

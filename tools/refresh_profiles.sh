@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the judged artefacts under profiles/ on one GPU box.  Outputs land in gpurun_out/refresh/ with their final
-# names (r02_*); copy them into profiles/ afterwards.   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh'
+# names (r03_*); copy them into profiles/ afterwards.   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh'
 R=$(pwd); O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $R
-P=r02
+P=${P:-r03}
 line() { grep '^{' | tail -1; }
 
 # 1. the default command, unprofiled: headline + roofline + kernels (bf16 mode, Kaggle secondary) + cpu_baseline
@@ -47,7 +47,8 @@ done
 # 6. GEMM microbenchmarks: fp32 kernels next to hipBLASLt (torch.mm) in one process; fp32 vs tensor-op (bf16) mode; the lab
 python3 tools/gemm_big.py -1 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_vs_hipblaslt.txt
 python3 tools/gemm_bf16_bench.py 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_bf16_mode.txt
-[ -x tools/lab/gemm_big_lab ] && timeout 300 tools/lab/gemm_big_lab 32768 1024 3456 > $O/${P}_lab_gemm_big.txt 2>&1
+# the lab binary is built here from its source (never committed)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_big_lab.hip -lrocblas -o tools/lab/gemm_big_lab 2> $O/lab_build.err && timeout 300 tools/lab/gemm_big_lab 32768 1024 3456 > $O/${P}_lab_gemm_big.txt 2>&1
 python3 tools/microbench.py emb > $O/${P}_microbench_embedding.txt 2>&1
 # SQ counters of the split-bf16x3 forward GEMM alone (MFMA busy cycles against GRBM_GUI_ACTIVE: what bounds that kernel)
 bash tools/pmc_x3.sh 2 > $O/pmc_x3.log 2>&1; cp gpurun_out/pmc_x3/summary.json $O/${P}_pmc_split_bf16x3_gemm.json
