@@ -42,9 +42,29 @@ namespace {
 //                 ways (intra-workgroup split-K), partial accumulators meet in LDS in a fixed order.
 //                 For the skinny DLRM layers (2048 x 256, 2048 x 64 ...) this gives 4x the waves of
 //                 a 64x64 tiling: a 32x32x2 MFMA chain over K = 512 alone is 16k cycles.
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool SPLITW, bool FUSE_DY, bool CMAP>
+__device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, const unsigned lin, const unsigned nbx, const unsigned nby, const unsigned nbz);
+
+// One workgroup per tile (3-D grid), or -- g.tnx != 0 -- a persistent 1-D grid whose workgroups walk the tile space with
+// stride gridDim.x: the hardware dispatcher hands out tiles of a multi-round launch unevenly over the CUs (a launch of 2048
+// equal tiles at three resident workgroups per CU ends with some CUs a whole tile behind); a grid of exactly
+// (resident workgroups per CU) x (CUs) workgroups, each with the same number of tiles, does not.  gridDim.x is a multiple of 8
+// in that mode, so a workgroup's tiles stay in its XCD's contiguous range of the tile space.
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool SPLITW = false, bool FUSE_DY = false, bool CMAP = false>
 __global__ __launch_bounds__(256, (FFH_FWD_OCC4 && BM == 128 && BN == 128 && BK == 16 && AKC && BKC && !SPLITW && !FUSE_DY && !CMAP) ? 4 : 1)
 void gemm_f32_kernel(const GemmArgs g) {
+  const bool pers = g.tnx != 0;
+  const unsigned nbx = pers ? g.tnx : gridDim.x, nby = pers ? g.tny : gridDim.y, nbz = pers ? g.tnz : gridDim.z;
+  const unsigned total = nbx * nby * nbz;
+  const unsigned stride = pers ? gridDim.x : total;
+  for (unsigned lin = pers ? blockIdx.x : (blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x; lin < total; lin += stride) {
+    gemm_f32_tile<BM, BN, BK, AKC, BKC, SPLITW, FUSE_DY, CMAP>(g, lin, nbx, nby, nbz);
+    if (lin + stride < total) __syncthreads();   // the epilogue's LDS exchanges (bias sums, split-wave reduction) end before the next tile stages
+  }
+}
+
+template <int BM, int BN, int BK, bool AKC, bool BKC, bool SPLITW, bool FUSE_DY, bool CMAP>
+__device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, const unsigned lin, const unsigned nbx, const unsigned nby, const unsigned nbz) {
   constexpr int PA = AKC ? 1 : 4, PB = BKC ? 1 : 4;
   constexpr int LA = BM + PA, LB = BN + PB;
   constexpr int NA = BM * BK / 1024, NB = BN * BK / 1024;   // float4 staging slots per thread
@@ -62,9 +82,7 @@ void gemm_f32_kernel(const GemmArgs g) {
   // the small shared operand is fetched by all eight.
   int bx, by, bz;
   {
-    const unsigned nbx = gridDim.x, nby = gridDim.y, nbz = gridDim.z;
     const unsigned total = nbx * nby * nbz;
-    const unsigned lin = (blockIdx.z * nby + blockIdx.y) * nbx + blockIdx.x;
     const unsigned xcd = lin & 7u, loc = lin >> 3;
     const unsigned q = total >> 3, rem = total & 7u;
     const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
@@ -912,6 +930,16 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   }
   if (gy > 65535 || gz > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm: grid too large");
   dim3 grid(gx, gy, gz);
+  g.tnx = g.tny = g.tnz = 0;
+  {
+    // persistent form (see gemm_f32_kernel): launches of more tiles than the chip holds at once
+    static const int persist = getenv("FFH_GEMM_PERSIST") ? atoi(getenv("FFH_GEMM_PERSIST")) : 0;   // A/B switch: resident workgroups per CU, 0 = off
+    const int64_t total = (int64_t)gx * gy * gz;
+    if (persist > 0 && total > (int64_t)persist * c->num_cus && total < (1LL << 31)) {
+      g.tnx = (unsigned)gx; g.tny = (unsigned)gy; g.tnz = (unsigned)gz;
+      grid = dim3((unsigned)(persist * c->num_cus), 1, 1);
+    }
+  }
   if (cfg == 3) hipLaunchKernelGGL((gemm_f32_kernel<256, 128, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
   else if (cfg == 4) hipLaunchKernelGGL((gemm_f32_kernel<128, 128, 32, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);
   else if (cfg == 5) hipLaunchKernelGGL((gemm_f32_kernel<128, 256, 16, AKC, BKC, false, FUSE_DY>), grid, dim3(256), 0, as_stream(s), g);

@@ -34,6 +34,9 @@ struct GemmArgs {
   int64_t      ldmask;
   // CMAP kernels (dX of the layer above a Concat, ffh_linear_bwd_set_dx_scatter): column n of C lives at colmap[n].base[m * colmap[n].ld]
   const ffh_col_dest* colmap;
+  // persistent launch: the (x, y, z) tile space; the launch is then a 1-D grid of fewer workgroups, each walking tiles
+  // blockIdx.x, blockIdx.x + gridDim.x, ...  (tnx == 0: one workgroup per tile, tile space = the 3-D grid)
+  unsigned tnx, tny, tnz;
 };
 
 constexpr int kSplitGran = 32;   // split-K granularity; splits are multiples of 2*kSplitGran = 64 = the largest BK
