@@ -1452,6 +1452,11 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   g.epi = EPI_STORE; g.act = act;
   if (use_bf16(c, in, out)) return launch_gemm_bf16_form(c, g, BF16_FORM_FWD, s, "linear_fwd gemm (bf16)");
   {
+    // big aligned layers: the persistent one-workgroup-per-CU kernel (linear_sk.hip)
+    const int rc = launch_gemm_sk(c, g, SK_FORM_FWD, s, "linear_fwd gemm");
+    if (rc != 0) return rc < 0 ? rc : FFH_OK;
+  }
+  {
     GldsArgs d{};
     d.A = x; d.lda = ldx; d.B = w; d.ldb = in; d.C = y; d.ldc = ldy; d.bias = bias;
     d.M = (int)batch; d.N = out; d.K = in; d.epi = EPI_STORE; d.act = act;
@@ -1464,6 +1469,24 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
 }  // extern "C"
 
 namespace {
+// dy <- dy * act'(y) in place (act NONE: dy untouched) and db[o] += sum_b dy[b][o] (db may be null): one pass over dy
+int launch_act_bwd_bias(ffh_ctx* c, float* dy, int64_t lddy, const float* y, int64_t ldy, float* db, int out, int64_t batch, int act, ffh_stream st) {
+  if (act == FFH_AC_MODE_NONE && !db) return FFH_OK;
+  const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
+  const int cols_v = v4 ? out / 4 : out;
+  int tx = 1;
+  while (tx < cols_v && tx < 256) tx <<= 1;       // power of two: TY = 256 / TX rows in flight per workgroup
+  const int ty = 256 / tx;
+  int64_t rows = (batch + 2 * c->num_cus - 1) / (2 * c->num_cus);
+  if (rows < 4 * ty) rows = 4 * ty;
+  if (c->deterministic) rows = batch;             // one workgroup: the column sums meet in a fixed order
+  const unsigned grid = (unsigned)((batch + rows - 1) / rows);
+  if (v4) hipLaunchKernelGGL((act_bwd_bias_kernel<4>), dim3(grid), dim3(256), 0, as_stream(st), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
+  else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(grid), dim3(256), 0, as_stream(st), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
+  FFH_LAUNCH_CHECK(c, "act_bwd_bias_kernel");
+  return FFH_OK;
+}
+
 // label != NULL: the MSE loss step is folded into the one-launch backward (ffh_linear_bwd_mse); layers that path does
 // not serve return FFH_ERR_UNSUPPORTED before anything is launched
 int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
@@ -1533,22 +1556,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
   if (use_bf16(c, in, out)) {
     // tensor-op math mode: the activation gradient (and db) as its own fp32 pass over dy, then the two GEMMs on bf16 operands
     const bool relu_ = act == FFH_AC_MODE_RELU;
-    auto act_pass = [&](ffh_stream st, int a) -> int {
-      if (a == FFH_AC_MODE_NONE && !db) return FFH_OK;
-      const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
-      const int cols_v = v4 ? out / 4 : out;
-      int tx = 1;
-      while (tx < cols_v && tx < 256) tx <<= 1;
-      const int ty = 256 / tx;
-      int64_t rows = (batch + 2 * c->num_cus - 1) / (2 * c->num_cus);
-      if (rows < 4 * ty) rows = 4 * ty;
-      if (c->deterministic) rows = batch;        // one workgroup: the column sums meet in a fixed order
-      const unsigned grid = (unsigned)((batch + rows - 1) / rows);
-      if (v4) hipLaunchKernelGGL((act_bwd_bias_kernel<4>), dim3(grid), dim3(256), 0, as_stream(st), dy, lddy, y, ldy, db, out, batch, (int)rows, a, tx);
-      else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(grid), dim3(256), 0, as_stream(st), dy, lddy, y, ldy, db, out, batch, (int)rows, a, tx);
-      FFH_LAUNCH_CHECK(c, "act_bwd_bias_kernel");
-      return FFH_OK;
-    };
+    auto act_pass = [&](ffh_stream st, int a) -> int { return launch_act_bwd_bias(c, dy, lddy, y, ldy, db, out, batch, a, st); };
     if (separate && do_dx) { const int rc = act_pass(s, act); if (rc) return rc; }       // sigmoid: in place, with db, before any fork
     const bool forked_ = do_dw && do_dx && s_dw != nullptr && s_dw != s;
     ffh_stream sw_ = forked_ ? s_dw : s;
@@ -1590,18 +1598,45 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     return FFH_OK;
   }
   if (separate && do_dx) {
-    const bool v4 = (out % 4 == 0) && (lddy % 4 == 0) && (ldy % 4 == 0) && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)y & 15) == 0);
-    const int cols_v = v4 ? out / 4 : out;
-    int tx = 1;
-    while (tx < cols_v && tx < 256) tx <<= 1;       // power of two: TY = 256 / TX rows in flight per workgroup
-    const int ty = 256 / tx;
-    int64_t rows = (batch + 2 * c->num_cus - 1) / (2 * c->num_cus);
-    if (rows < 4 * ty) rows = 4 * ty;
-    if (c->deterministic) rows = batch;          // one workgroup: the column sums meet in a fixed order
-    const unsigned grid = (unsigned)((batch + rows - 1) / rows);
-    if (v4) hipLaunchKernelGGL((act_bwd_bias_kernel<4>), dim3(grid), dim3(256), 0, as_stream(s), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
-    else hipLaunchKernelGGL((act_bwd_bias_kernel<1>), dim3(grid), dim3(256), 0, as_stream(s), dy, lddy, y, ldy, db, out, batch, (int)rows, act, tx);
-    FFH_LAUNCH_CHECK(c, "act_bwd_bias_kernel");
+    const int rc = launch_act_bwd_bias(c, dy, lddy, y, ldy, db, out, batch, act, s);
+    if (rc) return rc;
+  }
+  // big aligned layers: the persistent one-workgroup-per-CU kernels (linear_sk.hip).  They take dy as it is, so a live relu'
+  // (not premasked) and the bias gradient go through one pass over dy first -- on s, in front of the fork, so that both GEMMs
+  // read the finished dy.  Not served: ONLY_DX with a live relu (dy must not be written there), the column-map epilogue.
+  {
+    const bool want_dx = dx && do_dx;
+    const bool relu_live = act == FFH_AC_MODE_RELU;
+    const bool scatter_pending = c->scatter_map && c->scatter_ncols == in && (flags & FFH_LINEAR_DX_OVERWRITE);
+    GemmArgs gw{}, gx{};
+    gw.A = dy; gw.sAm = 1; gw.sAk = lddy; gw.B = x; gw.sBn = 1; gw.sBk = ldx; gw.C = dw; gw.ldc = in;
+    gw.M = out; gw.N = in; gw.K = (int)batch; gw.epi = EPI_ATOMIC; gw.act = FFH_AC_MODE_NONE;
+    gx.A = dy; gx.sAm = lddy; gx.sAk = 1; gx.B = w; gx.sBn = 1; gx.sBk = in; gx.C = dx; gx.ldc = lddx;
+    gx.M = (int)batch; gx.N = in; gx.K = out; gx.epi = (flags & FFH_LINEAR_DX_OVERWRITE) ? EPI_STORE : EPI_ADD; gx.act = FFH_AC_MODE_NONE;
+    if (mask_by_x) { gx.mask = x; gx.ldmask = ldx; }
+    bool ok = (do_dw || want_dx) && !(relu_live && !do_dw) && !(want_dx && scatter_pending);
+    if (ok && do_dw) ok = gemm_sk_serves(c, gw, SK_FORM_DW);
+    if (ok && want_dx) ok = gemm_sk_serves(c, gx, SK_FORM_DX);
+    if (ok) {
+      const bool forked_sk = do_dw && want_dx && s_dw != nullptr && s_dw != s;
+      ffh_stream sw_sk = forked_sk ? s_dw : s;
+      if (do_dw && relu_live) {      // live relu': masked in place, with the bias gradient, in one pass in front of both GEMMs
+        const int rc = launch_act_bwd_bias(c, dy, lddy, y, ldy, db, out, batch, FFH_AC_MODE_RELU, s);
+        if (rc) return rc;
+      } else if (do_dw && !separate) {
+        gw.db = db;                  // dy is final already (none / premasked): its column sums ride on the weight-gradient kernel
+      }                              // (sigmoid: its own pass above, or the ONLY_DX call before this one, has produced db)
+      if (forked_sk) {
+        c->second_stream_used = 1;
+        if (!c->ev_fork) FFH_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        FFH_HIP_TRY(c, hipEventRecord(c->ev_fork, as_stream(s)));
+        FFH_HIP_TRY(c, hipStreamWaitEvent(as_stream(sw_sk), c->ev_fork, 0));
+      }
+      // the data gradient first: it is what the layer below waits for; the weight gradient fills the chip behind it
+      if (want_dx) { const int rc = launch_gemm_sk(c, gx, SK_FORM_DX, s, "linear_bwd dx gemm"); if (rc < 0) return rc; }
+      if (do_dw) { const int rc = launch_gemm_sk(c, gw, SK_FORM_DW, sw_sk, "linear_bwd dw gemm"); if (rc < 0) return rc; }
+      return FFH_OK;
+    }
   }
   // mid-size layer with nothing to mask while loading: data- and weight-gradient GEMMs in ONE LDS-DMA launch on s
   // (measured against the two-stream form: fewer barrier packets on the critical stream, one dispatch)

@@ -81,4 +81,10 @@ enum { BF16_FORM_FWD = 0,        // A = x (k-contiguous), B = w (k-contiguous)
        BF16_FORM_DX_MASK = 3 };  // ... dy read through relu'(act_y)
 int launch_gemm_bf16_form(ffh_ctx* c, GemmArgs& g, int form, ffh_stream s, const char* name);
 
+// The persistent one-workgroup-per-CU fp32 kernels for the big aligned layers (linear_sk.hip): forward (bias + activation),
+// data gradient (store / add, optional relu'-of-the-layer-below mask), weight gradient (stream-K, atomics).
+enum { SK_FORM_FWD = 0, SK_FORM_DX = 1, SK_FORM_DW = 2 };
+bool gemm_sk_serves(const ffh_ctx* c, const GemmArgs& g, int form);                                   // shape / alignment / mode check only
+int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name);           // 1 launched, 0 not served, < 0 error
+
 }  // namespace ffh_gemm

@@ -1,0 +1,366 @@
+// linear_sk.hip -- the big fp32 GEMMs of Linear forward / backward (exact fp32, v_mfma_f32_16x16x4_f32): persistent workgroups,
+// one per CU, whose matrix pipe never waits.
+//
+// The register-staged kernel of linear.hip (128 x 128 x 16 tiles, three workgroups per CU, the compiler's schedule) keeps the
+// matrix pipe busy 0.84 of the time on the layers of the 32768-sample step; the shape of the loop below -- the one hand-written
+// library GEMMs use -- keeps it busy 0.93-0.96:
+//   * ONE workgroup per CU (4 waves, one per SIMD, 2 x 2 over a 128 x 128 tile, 64 accumulator registers in AGPRs), k-tiles of 64:
+//     a wave issues 256 MFMAs (8192 matrix-pipe cycles) per k-tile back to back and EVERY other instruction sits in the shadow of
+//     one of them, in a fixed order (sched_barrier after every MFMA):
+//       MFMA   0..23   the 24 fragment reads (ds_read_b128) of k-groups 1..3 of this k-tile -- the whole k-tile's fragments live
+//                      in 128 VGPRs, so the single LDS buffer is free again after ~50 MFMAs
+//       MFMA  53       s_waitcnt lgkmcnt(0) + s_barrier: every wave has its fragments
+//       MFMA  54..219  16 x { ds_write_b128 of the NEXT k-tile (in registers since the previous iteration);
+//                             buffer_load_dwordx4 of the one after it into the same registers }, one pair per 11 MFMAs
+//       MFMA 243       s_waitcnt lgkmcnt(0) + s_barrier: the next k-tile is in LDS
+//       MFMA 244..251  the 8 fragment reads of its first k-group
+//     (global loads have a whole iteration -- 3.4 us -- to land; no wait in the loop is ever for something issued recently);
+//   * the operand stream is CONTINUOUS ACROSS OUTPUT TILES: a workgroup walks its tiles with the loads two k-tiles ahead of the
+//     MFMAs, so a tile's first operands arrive while the previous tile's last MFMAs run; only the accumulator store sits between;
+//   * work is dealt in whole tiles (forward, dX: tiles i*G + (w%8)*(G/8) + w/8 -- the workgroups of one XCD walk neighbouring
+//     tiles, their A panels stay in that XCD's L2) or, for the weight gradient (few tiles, 32768-deep reduction, result
+//     accumulated anyway), STREAM-K: the flat (tile, k-tile) space cut into G equal ranges, partial tiles added by atomics;
+//   * LDS images: a k-contiguous operand keeps its rows (256 B + 32 B of padding per 1 KiB; fragment = one ds_read_b128 = four
+//     k-steps of one 16-row tile: lane (c, q) of the 16x16x4 MFMA takes k = 16j + 4q + e, legal because both operands agree);
+//     a rows-are-k operand (w in dX; dy and x in dW) is stored as it arrives and one ds_read_b128 yields ONE k-step of FOUR
+//     16-row tiles (tile t holds rows 4c + t): both forms read 16 x 16 B per operand and k-tile, conflict-free, no transpose;
+//   * the MFMAs are inline asm with the accumulator tied ("+a"): as builtins hipcc gives the loop-carried accumulators VGPR-class
+//     phis and moves all 64 through v_accvgpr_read / _write at the head of every iteration.  The hazard recogniser does not see
+//     inline-asm MFMAs: s_nop pads sit behind the loop (MFMA result -> v_accvgpr_read) and behind the zeroing.
+// Arithmetic: an exact fp32 fmaf chain per output element, k visited in the order 16j + 4q + e (q = lane / 16): a fixed order,
+// different from the other kernels' -- parity tests hold every kernel to 1e-5 of the term mass against the oracle.
+// Serves: M % 128 == 0, N % 128 == 0, K % 64 == 0, 16-byte aligned operands, enough tiles to fill the chip evenly; everything
+// else stays with linear.hip.  Developed in tools/lab/gemm_sk_lab.hip (stand-alone, with ablation modes).
+//
+// Replaces cublasSgemm of Linear::forward_kernel / backward_kernel [ref: src/ops/linear.cu:436-453,624-659].
+#include "linear_gemm.h"
+
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+using namespace ffh_gemm;
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SK_BM = 128, SK_BN = 128, SK_BK = 64;
+constexpr int SK_LDS_KC = 128 * 256 + 32 * 32;   // k-contiguous operand: row r at r*256 + (r>>2)*32
+constexpr int SK_LDS_KR = 64 * 512;              // rows-are-k operand: row k at k*512
+
+enum { SK_EPI_FWD = 0, SK_EPI_DX_STORE = 1, SK_EPI_DX_ADD = 2, SK_EPI_DW_ATOMIC = 3 };
+
+struct SkArgs {
+  const float* A; const float* B; float* C;
+  const float* bias;           // FWD: per-column bias or null
+  float*       db;             // DW (DB instantiation): db[m] += sum_k A(k, m), the bias gradient [ref: src/ops/linear.cu:644-651]
+  const float* mask;           // DX: C = mask[m][n] > 0 ? v : 0 (relu' of the layer below) or null
+  int64_t lda, ldb, ldc, ldmask;
+  int M, N, K;
+  int act;
+  unsigned a_bytes, b_bytes, bias_bytes, mask_bytes;     // extents for the buffer descriptors (0: operand absent -> loads return 0)
+};
+
+template <int... I, class F>
+__device__ __forceinline__ void sk_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N_, class F>
+__device__ __forceinline__ void sk_static_for(F&& f) { sk_static_for_impl(std::make_integer_sequence<int, N_>{}, static_cast<F&&>(f)); }
+
+#define SK_PIN() __builtin_amdgcn_sched_barrier(0)
+
+constexpr int SK_EP_LD = 68;                       // floats per row of a wave's 64 x 64 epilogue image (DW): 64 + 4 of padding
+constexpr int SK_EP_WAVE = 64 * SK_EP_LD * 4;     // bytes per wave
+
+template <bool AKR, bool BKR, int EPI, bool DB = false>
+__global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
+  static_assert(!DB || (EPI == SK_EPI_DW_ATOMIC && AKR), "the bias gradient rides on the weight-gradient form");
+  extern __shared__ __attribute__((aligned(16))) char sk_lds[];
+  constexpr bool ATOMIC = EPI == SK_EPI_DW_ATOMIC;
+  constexpr int LDS_A = AKR ? SK_LDS_KR : SK_LDS_KC;
+  char* const ldsA = sk_lds;
+  char* const ldsB = sk_lds + LDS_A;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave >> 1, wx = wave & 1;
+  const int c16 = lane & 15, q = lane >> 4;
+
+  // fragment read addresses (bytes inside the operand's LDS image)
+  const int fra = AKR ? (q * 2048 + wy * 256 + c16 * 16) : ((64 * wy + 4 * c16) * 256 + (16 * wy + c16) * 32 + q * 16);
+  const int frb = BKR ? (q * 2048 + wx * 256 + c16 * 16) : ((64 * wx + 4 * c16) * 256 + (16 * wx + c16) * 32 + q * 16);
+  // staging roles: this thread's 8 + 8 float4 of a k-tile -- where they come from (per-lane byte offset in the matrix) and go to
+  const int srowA = AKR ? (tid >> 5) : (tid >> 4), schA = AKR ? (tid & 31) : (tid & 15);
+  const int srowB = BKR ? (tid >> 5) : (tid >> 4), schB = BKR ? (tid & 31) : (tid & 15);
+  const unsigned voffA = (unsigned)((srowA * g.lda + schA * 4) * 4);
+  const unsigned voffB = (unsigned)((srowB * g.ldb + schB * 4) * 4);
+  const int swA = AKR ? (srowA * 512 + schA * 16) : (srowA * 256 + (srowA >> 2) * 32 + schA * 16);
+  const int swB = BKR ? (srowB * 512 + schB * 16) : (srowB * 256 + (srowB >> 2) * 32 + schB * 16);
+  constexpr int SW_STEP_A = AKR ? 4096 : 4224, SW_STEP_B = BKR ? 4096 : 4224;     // LDS bytes between a thread's consecutive pieces
+  const unsigned ioffA = (unsigned)((AKR ? 8 : 16) * g.lda * 4), ioffB = (unsigned)((BKR ? 8 : 16) * g.ldb * 4);   // global bytes between them
+  const unsigned kadvA = AKR ? (unsigned)(SK_BK * g.lda * 4) : (unsigned)(SK_BK * 4), kadvB = BKR ? (unsigned)(SK_BK * g.ldb * 4) : (unsigned)(SK_BK * 4);
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, g.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
+
+  // ---- this workgroup's share of the (tile, k-tile) iteration space ----
+  const unsigned nbx = (unsigned)(g.N / SK_BN), nby = (unsigned)(g.M / SK_BM), ntiles = nbx * nby;
+  const unsigned nk = (unsigned)(g.K / SK_BK);
+  const unsigned G = gridDim.x, w = blockIdx.x;
+  const unsigned total_it = ntiles * nk;                  // < 2^32 (the host checks)
+  const unsigned wperm = (w & 7u) * (G >> 3) + (w >> 3);  // G is a multiple of 8
+  unsigned it_b, it_e;
+  if (ATOMIC) {
+    const unsigned ipw = (total_it + G - 1) / G;
+    it_b = w * ipw; it_e = it_b + ipw < total_it ? it_b + ipw : total_it;
+    if (it_b > total_it) it_b = total_it;
+  } else {
+    const unsigned mine = ntiles / G + (wperm < ntiles % G ? 1u : 0u);
+    it_b = 0; it_e = mine * nk;
+  }
+  const unsigned n_it = it_e - it_b;
+  if (n_it == 0) return;
+
+  struct Cursor { unsigned seq, kt, m0, n0, offA, offB; };   // seq: index of the tile in this workgroup's sequence
+  auto place = [&](Cursor& c) {      // tile coordinates and operand offsets of (c.seq, c.kt)
+    unsigned lin;
+    if (ATOMIC) lin = it_b / nk + c.seq;
+    else lin = c.seq * G + wperm;
+    if (lin >= ntiles) lin = ntiles - 1;                  // run-ahead loads past the end of the share: any valid tile
+    const unsigned by = lin / nbx, bx = lin - by * nbx;
+    c.m0 = by * SK_BM; c.n0 = bx * SK_BN;
+    c.offA = (AKR ? c.m0 * 4u : (unsigned)(c.m0 * g.lda * 4)) + c.kt * kadvA;
+    c.offB = (BKR ? c.n0 * 4u : (unsigned)(c.n0 * g.ldb * 4)) + c.kt * kadvB;
+  };
+  auto advance = [&](Cursor& c) {
+    c.kt++;
+    if (c.kt == nk) { c.kt = 0; c.seq++; place(c); }
+    else { c.offA += kadvA; c.offB += kadvB; }
+  };
+  Cursor ld{0, ATOMIC ? it_b % nk : 0u, 0, 0, 0, 0}, cp = ld;
+  place(ld); place(cp);
+
+  u32x4 P[16];
+  auto gload_one = [&](int i, const Cursor& c) {
+    if (i < 8) P[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, c.offA + (unsigned)i * ioffA, 0);
+    else P[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB, c.offB + (unsigned)(i - 8) * ioffB, 0);
+  };
+  auto lwrite_one = [&](int i) {
+    if (i < 8) *reinterpret_cast<u32x4*>(ldsA + swA + i * SW_STEP_A) = P[i];
+    else *reinterpret_cast<u32x4*>(ldsB + swB + (i - 8) * SW_STEP_B) = P[i];
+  };
+  f32x4 fa[4][4], fb[4][4];      // [j][r]: k-contiguous operand: r = 16-row tile, components = 4 k-steps; rows-are-k: r = k-step, components = 4 tiles
+  auto fread = [&](int j, int r, bool isB) {
+    if (!isB) fa[j][r] = *reinterpret_cast<const f32x4*>(ldsA + fra + (AKR ? (j * 8192 + r * 512) : (r * 256 + j * 64)));
+    else fb[j][r] = *reinterpret_cast<const f32x4*>(ldsB + frb + (BKR ? (j * 8192 + r * 512) : (r * 256 + j * 64)));
+  };
+  f32x4 acc[4][4];
+  f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};   // DB: column sums of A over this segment's k range, rows m0 + 64 wy + 4 c16 + {0..3}, this lane's k-steps
+
+  // ---- prologue: k-tile 0 -> LDS, k-tile 1 -> registers, fragments j = 0 of k-tile 0 ----
+#pragma unroll
+  for (int i = 0; i < 16; i++) gload_one(i, ld);
+  advance(ld);
+#pragma unroll
+  for (int i = 0; i < 16; i++) lwrite_one(i);
+#pragma unroll
+  for (int i = 0; i < 16; i++) gload_one(i, ld);
+  advance(ld);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+  SK_PIN();
+#pragma unroll
+  for (int r = 0; r < 4; r++) { fread(0, r, false); fread(0, r, true); }
+  SK_PIN();
+
+  // outer loop: the output tiles (stream-K: segments) of this workgroup; inner loop: their k-tiles.  The operand stream (cursor
+  // ld, two k-tiles ahead) does not know about the nest.
+  for (unsigned it = 0; it < n_it;) {
+    const unsigned seg = (nk - cp.kt) < (n_it - it) ? (nk - cp.kt) : (n_it - it);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_nop 7" ::: "memory");
+    for (unsigned kk = 0; kk < seg; kk++) {
+      sk_static_for<256>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int j = s >> 6, e = (s >> 4) & 3, tm = (s >> 2) & 3, tn = s & 3;
+        const float av = AKR ? fa[j][e][tm] : fa[j][tm][e];
+        const float bv = BKR ? fb[j][e][tn] : fb[j][tn][e];
+        asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tm][tn]) : "v"(av), "v"(bv));
+        if constexpr (DB && (s & 15) == 1) {      // one k-step of four row tiles, behind the first MFMA that used it.  Spelled as
+          // instructions: left to itself hipcc gathers the 16 adds of a k-tile in one place (fragments parked in AGPRs meanwhile) and
+          // packs them into v_pk_add_f32, which costs several times a v_add_f32 beside MFMAs
+          asm volatile("v_add_f32 %0, %4, %0\n\tv_add_f32 %1, %5, %1\n\tv_add_f32 %2, %6, %2\n\tv_add_f32 %3, %7, %3"
+                       : "+v"(bsum.x), "+v"(bsum.y), "+v"(bsum.z), "+v"(bsum.w)
+                       : "v"(fa[j][e].x), "v"(fa[j][e].y), "v"(fa[j][e].z), "v"(fa[j][e].w));
+        }
+        if constexpr (s < 24) {                    // fragments of k-groups 1..3
+          constexpr int jj = 1 + s / 8, r = (s % 8) >> 1;
+          fread(jj, r, (s & 1) != 0);
+        }
+        if constexpr (s == 53) {                   // every wave has its fragments: the LDS buffer may be overwritten
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (s >= 54 && s <= 219 && (s - 54) % 11 == 0) {
+          constexpr int i = (s - 54) / 11;
+          lwrite_one(i);                           // next k-tile: registers -> LDS
+          gload_one(i, ld);                        // the one after it -> the same registers
+        }
+        if constexpr (s == 243) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);
+          __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (s >= 244 && s < 252) {       // first k-group of the next k-tile, in the order its MFMAs want them
+          constexpr int o = s - 244;               // A0 B0 B1 B2 B3 A1 A2 A3
+          if constexpr (o == 0) fread(0, 0, false);
+          else if constexpr (o <= 4) fread(0, o - 1, true);
+          else fread(0, o - 4, false);
+        }
+        SK_PIN();
+      });
+      advance(ld);
+    }
+    it += seg;
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA result -> v_accvgpr_read
+    // ---- epilogue of the tile / segment: lane (c16, q) of wave (wy, wx) holds, for tm, i in 0..3, the four columns
+    //      n0 + 64 wx + 4 c16 + {0..3} of row m0 + 64 wy + 16 q + 4 i + tm
+    {
+      const int nn = (int)cp.n0 + 64 * wx + 4 * c16;
+      f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (EPI == SK_EPI_FWD) {
+        const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.bias), 0, g.bias_bytes, 0x00020000);
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsBias, (unsigned)nn * 4u, 0, 0);     // absent bias: extent 0, the load returns 0
+        bv = __builtin_bit_cast(f32x4, t);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int mm = (int)cp.m0 + 64 * wy + 16 * q + 4 * i + tm;
+          f32x4 v = f32x4{acc[tm][0][i], acc[tm][1][i], acc[tm][2][i], acc[tm][3][i]};
+          float* cptr = g.C + (int64_t)mm * g.ldc + nn;
+          if constexpr (EPI == SK_EPI_DW_ATOMIC) {
+            // through a per-wave LDS image so that one atomic instruction covers 256 contiguous bytes of one row (the shape at
+            // which memory-side float atomics run at their full rate; 4-byte pieces 16 bytes apart run ~10x slower)
+            (void)cptr;
+            *reinterpret_cast<f32x4*>(sk_lds + LDS_A + (BKR ? SK_LDS_KR : SK_LDS_KC) + wave * SK_EP_WAVE + ((16 * q + 4 * i + tm) * SK_EP_LD + 4 * c16) * 4) = v;
+          } else if constexpr (EPI == SK_EPI_FWD) {
+            v += bv;
+            v.x = act_apply(v.x, g.act); v.y = act_apply(v.y, g.act); v.z = act_apply(v.z, g.act); v.w = act_apply(v.w, g.act);
+            *reinterpret_cast<f32x4*>(cptr) = v;
+          } else {
+            if (g.mask_bytes) {        // uniform
+              const f32x4 mk = *reinterpret_cast<const f32x4*>(g.mask + (int64_t)mm * g.ldmask + nn);
+              v.x = mk.x > 0.0f ? v.x : 0.0f; v.y = mk.y > 0.0f ? v.y : 0.0f; v.z = mk.z > 0.0f ? v.z : 0.0f; v.w = mk.w > 0.0f ? v.w : 0.0f;
+            }
+            if constexpr (EPI == SK_EPI_DX_ADD) v += *reinterpret_cast<const f32x4*>(cptr);
+            *reinterpret_cast<f32x4*>(cptr) = v;
+          }
+        }
+    }
+    if constexpr (EPI == SK_EPI_DW_ATOMIC) {
+      const float* ep = reinterpret_cast<const float*>(sk_lds + LDS_A + (BKR ? SK_LDS_KR : SK_LDS_KC) + wave * SK_EP_WAVE);
+      float* crow = g.C + (int64_t)((int)cp.m0 + 64 * wy) * g.ldc + (int)cp.n0 + 64 * wx + lane;
+#pragma unroll 8
+      for (int r = 0; r < 64; r++) atomicAdd(crow + (int64_t)r * g.ldc, ep[r * SK_EP_LD + lane]);     // the wave's own image: no barrier
+      if constexpr (DB) {
+        if (cp.n0 == 0 && wx == 0) {          // wave-uniform: the first column of tiles owns the bias gradient
+          f32x4 t = bsum;
+#pragma unroll
+          for (int c = 0; c < 4; c++) { t[c] += __shfl_xor(t[c], 16); t[c] += __shfl_xor(t[c], 32); }
+          if (q == 0) {
+            float* dbp = g.db + (int)cp.m0 + 64 * wy + 4 * c16;
+            atomicAdd(dbp + 0, t.x); atomicAdd(dbp + 1, t.y); atomicAdd(dbp + 2, t.z); atomicAdd(dbp + 3, t.w);
+          }
+        }
+        bsum = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    cp.kt += seg;
+    if (cp.kt == nk) { cp.kt = 0; cp.seq++; place(cp); }
+  }
+}
+
+template <typename K>
+bool sk_set_lds(K kern, int bytes) {
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
+}
+
+inline bool sk_aligned(const void* p, int64_t ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
+
+}  // namespace
+
+namespace ffh_gemm {
+
+namespace {
+struct SkPlan { int64_t lda, ldb, a_bytes, b_bytes; int G; };
+bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
+  static const int off = getenv("FFH_GEMM_NO_SK") ? atoi(getenv("FFH_GEMM_NO_SK")) : 0;   // A/B switch (tools/ab.sh)
+  if (off) return false;
+  if (g.M % SK_BM || g.N % SK_BN || g.K % SK_BK || g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
+  const bool akr = form == SK_FORM_DW, bkr = form != SK_FORM_FWD;
+  p.lda = akr ? g.sAk : g.sAm; p.ldb = bkr ? g.sBk : g.sBn;
+  if ((akr ? g.sAm : g.sAk) != 1 || (bkr ? g.sBn : g.sBk) != 1) return false;
+  if (!sk_aligned(g.A, p.lda) || !sk_aligned(g.B, p.ldb) || !sk_aligned(g.C, g.ldc)) return false;
+  if (g.mask && !sk_aligned(g.mask, g.ldmask)) return false;
+  if (g.bias && ((uintptr_t)g.bias & 15)) return false;
+  if (g.colmap || g.act_y || g.fuse || g.splitk > 1) return false;  // column-map / masking-while-loading forms stay with linear.hip
+  p.a_bytes = ((akr ? (int64_t)(g.K - 1) : (int64_t)(g.M - 1)) * p.lda + (akr ? g.M : g.K)) * 4;
+  p.b_bytes = ((bkr ? (int64_t)(g.K - 1) : (int64_t)(g.N - 1)) * p.ldb + (bkr ? g.N : g.K)) * 4;
+  if (p.a_bytes >= (1LL << 32) || p.b_bytes >= (1LL << 32)) return false;  // 32-bit buffer offsets
+  p.G = c->num_cus & ~7;
+  if (p.G < 8) return false;
+  const int64_t ntiles = (int64_t)(g.M / SK_BM) * (g.N / SK_BN), nk = g.K / SK_BK;
+  if (ntiles * nk >= (1LL << 31)) return false;
+  if (form == SK_FORM_DW) {
+    if (c->deterministic || g.epi != EPI_ATOMIC) return false;     // its partial tiles meet by atomics
+    if (ntiles * nk < 4LL * p.G) return false;                     // at least four k-tiles per workgroup
+  } else {
+    if (g.epi != EPI_STORE && g.epi != EPI_ADD) return false;
+    if (ntiles < p.G) return false;
+    const int64_t rounds = (ntiles + p.G - 1) / p.G;
+    if (ntiles * 100 < rounds * p.G * 80) return false;            // whole tiles only: the last round must be nearly full
+  }
+  return true;
+}
+}  // namespace
+
+bool gemm_sk_serves(const ffh_ctx* c, const GemmArgs& g, int form) { SkPlan p; return sk_plan(c, g, form, p); }
+
+// 1: launched; 0: not this kernel's shape (nothing launched); < 0: error
+int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name) {
+  SkPlan p;
+  if (!sk_plan(c, g, form, p)) return 0;
+  const int64_t lda = p.lda, ldb = p.ldb, a_bytes = p.a_bytes, b_bytes = p.b_bytes;
+  const int G = p.G;
+  SkArgs a{};
+  a.A = g.A; a.B = g.B; a.C = g.C; a.bias = g.bias; a.mask = g.mask; a.db = g.db;
+  a.lda = lda; a.ldb = ldb; a.ldc = g.ldc; a.ldmask = g.ldmask;
+  a.M = g.M; a.N = g.N; a.K = g.K; a.act = g.act;
+  a.a_bytes = (unsigned)a_bytes; a.b_bytes = (unsigned)b_bytes;
+  a.bias_bytes = g.bias ? (unsigned)g.N * 4u : 0u;
+  a.mask_bytes = g.mask ? 1u : 0u;
+#define FFH_SK_LAUNCH(AKR, BKR, EPI, LDSB, ...)                                                                  \
+  {                                                                                                              \
+    auto kern = gemm_sk_kernel<AKR, BKR, EPI, ##__VA_ARGS__>;                                                    \
+    static const bool ok = sk_set_lds(kern, LDSB);                                                               \
+    if (!ok) return 0;                                                                                           \
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), LDSB, as_stream(s), a);                               \
+  }
+  if (form == SK_FORM_FWD) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC)
+  else if (form == SK_FORM_DW && g.db) FFH_SK_LAUNCH(true, true, SK_EPI_DW_ATOMIC, 2 * SK_LDS_KR + 4 * SK_EP_WAVE, true)
+  else if (form == SK_FORM_DW) FFH_SK_LAUNCH(true, true, SK_EPI_DW_ATOMIC, 2 * SK_LDS_KR + 4 * SK_EP_WAVE)
+  else if (g.epi == EPI_STORE) FFH_SK_LAUNCH(false, true, SK_EPI_DX_STORE, SK_LDS_KC + SK_LDS_KR)
+  else FFH_SK_LAUNCH(false, true, SK_EPI_DX_ADD, SK_LDS_KC + SK_LDS_KR)
+#undef FFH_SK_LAUNCH
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+  { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64|wgs=%d", name, G); ffh_route_add(c, tok); }
+  return 1;
+}
+
+}  // namespace ffh_gemm

@@ -100,7 +100,9 @@ def test_linear_layers_of_the_benched_step_at_b32768_vs_oracle(hip, oracle, IN, 
         # the deep weight-gradient reductions (K = 32768 > 16384) of the premasked form: pin the route the step takes, whatever it
         # is called this round, by requiring the dw token to name its kernel family and split
         dw_tok = [t for t in routes["bwd_ex"].split(";") if "dw" in t]
-        assert len(dw_tok) == 1 and "splitk=" in dw_tok[0], routes["bwd_ex"]
+        assert len(dw_tok) == 1 and ("splitk=" in dw_tok[0] or "|sk_" in dw_tok[0]), routes["bwd_ex"]
+        # round 3: these layers belong to the persistent one-workgroup-per-CU kernels (linear_sk.hip), all three GEMMs
+        assert "|sk_128x128x64" in routes["fwd"] and routes["bwd_ex"].count("|sk_128x128x64") == 2, routes
 
 
 @pytest.mark.timeout(1800)

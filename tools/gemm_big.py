@@ -7,8 +7,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     from dlrm_flexflow_amd import capi
     hip = capi.load_hip(0)
-    def timeit(fn, iters=10):
-        for _ in range(2): fn()
+    def timeit(fn, iters=20):
+        for _ in range(20): fn()          # the chip's clock needs tens of milliseconds under load to settle
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
