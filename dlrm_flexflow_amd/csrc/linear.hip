@@ -1017,6 +1017,45 @@ __global__ __launch_bounds__(512) void linear_thin_fwd_kernel(const float* __res
   }
 }
 
+// The same layer as an HBM-write-bound stream (the 13 -> 512 layer at 32768 samples writes 67 MB and reads 1.7 MB): a wave owns
+// a ROW and 256 consecutive columns -- lane l the four columns 4l .. 4l+3, so a row segment leaves as ONE 1-KiB store
+// instruction; the <= 16 inputs of the row are wave-uniform (scalar loads), the lane's 4 x in weights stay in registers for
+// all of the workgroup's rows.  52 FMAs per 16 bytes written: the VALU work is a tenth of the store time.  Each output is
+// the ascending-k fmaf chain from 0, then + bias, then the activation -- the oracle's order, bit for bit.
+constexpr int kThinRowsPerWg = 128;
+__global__ __launch_bounds__(256) void linear_thin_fwd_rows_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+                                                                   const float* __restrict__ w, const float* __restrict__ bias, int in, int out,
+                                                                   int64_t batch, int act) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = (blockIdx.y * 64 + lane) * 4;
+  const bool live = n0 < out;                    // out % 4 == 0 (host check)
+  float wr[16][4];
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) wr[k][j] = (live && k < in) ? w[(int64_t)(n0 + j) * in + k] : 0.0f;
+  float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live && bias) bs = *reinterpret_cast<const float4*>(bias + n0);
+  const int64_t r_end = ((int64_t)blockIdx.x + 1) * kThinRowsPerWg < batch ? ((int64_t)blockIdx.x + 1) * kThinRowsPerWg : batch;
+  for (int64_t r = (int64_t)blockIdx.x * kThinRowsPerWg + wave; r < r_end; r += 4) {
+    const float* xr = x + r * ldx;               // wave-uniform address: scalar loads
+    float xs[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) xs[k] = k < in ? xr[k] : 0.0f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k < in) {
+        a0 = __fmaf_rn(xs[k], wr[k][0], a0); a1 = __fmaf_rn(xs[k], wr[k][1], a1);
+        a2 = __fmaf_rn(xs[k], wr[k][2], a2); a3 = __fmaf_rn(xs[k], wr[k][3], a3);
+      }
+    }
+    if (bias) { a0 = a0 + bs.x; a1 = a1 + bs.y; a2 = a2 + bs.z; a3 = a3 + bs.w; }
+    if (live) *reinterpret_cast<float4*>(y + r * ldy + n0) = make_float4(act_apply(a0, act), act_apply(a1, act), act_apply(a2, act), act_apply(a3, act));
+  }
+}
+
 struct SkinnyBwdArgs {
   const float* x;  float* dx;  const float* y;  float* dy;  const float* w;  float* dw;  float* db;
   int64_t ldx, lddx, ldy, lddy, batch;
@@ -1437,6 +1476,13 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
     return FFH_OK;
   }
   static const int no_thin = getenv("FFH_NO_THIN") ? atoi(getenv("FFH_NO_THIN")) : 0;   // A/B switch (tools/ab.sh)
+  if (!no_thin && in <= 16 && out >= 64 && out % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)y | (uintptr_t)(bias ? bias : w)) & 15) == 0 && batch >= 1024) {
+    hipLaunchKernelGGL(linear_thin_fwd_rows_kernel, dim3((unsigned)((batch + kThinRowsPerWg - 1) / kThinRowsPerWg), (unsigned)((out + 255) / 256)), dim3(256), 0,
+                       as_stream(s), x, ldx, y, ldy, w, bias, in, out, batch, act);
+    FFH_LAUNCH_CHECK(c, "linear_thin_fwd_rows_kernel");
+    ffh_route_add(c, "linear_fwd|thin_rows");
+    return FFH_OK;
+  }
   if (!no_thin && in <= 16 && out >= 64) {
     hipLaunchKernelGGL(linear_thin_fwd_kernel, dim3((unsigned)((batch + 31) / 32), (unsigned)((out + 255) / 256)), dim3(512), 0, as_stream(s), x, ldx, y, ldy,
                        w, bias, in, out, batch, act);
@@ -1531,7 +1577,10 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     }
     // dW / db are accumulated with one atomic per weight per workgroup: adds to ONE address serialise (~0.1 us each), so
     // the number of workgroups is kept near 32 -- and every wave then keeps 16 / NC rows in flight to cover the latency
-    const int64_t nblk = batch >= 8192 ? 64 : 32;                       // large batches: HBM traffic outweighs the longer atomic chains
+    static const int nblk_env = getenv("FFH_SKINNY_NBLK") ? atoi(getenv("FFH_SKINNY_NBLK")) : 0;   // A/B switch
+    // large batches: HBM traffic outweighs the longer atomic chains -- at 32768 samples the x / dX traffic (67 MB for the 256 -> 1
+    // layer) needs every CU's load queue, and the 256 per-workgroup atomics per weight are ~3 us spread over the launch
+    const int64_t nblk = nblk_env > 0 ? nblk_env : (batch >= 16384 ? 256 : (batch >= 8192 ? 64 : 32));
     int64_t rpb = (batch + nblk - 1) / nblk;
     rpb = (rpb + 15) / 16 * 16;
     if (rpb > 1024) rpb = 1024;

@@ -5,6 +5,7 @@
 #include "ffh_common.h"
 
 #include <mutex>
+#include <stdlib.h>
 #include <new>
 
 extern "C" {
@@ -109,6 +110,17 @@ int ffh_memcpy_d2d(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) 
 int ffh_stream_create(ffh_ctx* c, ffh_stream* s) {
   if (!s) return FFH_ERR_BAD_ARG;
   hipStream_t st;
+  // A/B switch (tools/ab.sh): FFH_STREAM_PRIOS="p0,p1,p2" gives the n-th stream this process creates HIP priority pn
+  static int created = 0;
+  const char* pr = getenv("FFH_STREAM_PRIOS");
+  if (pr) {
+    int idx = created++, prio = 0;
+    const char* p = pr;
+    for (int i = 0; i <= idx && p && *p; i++) { prio = atoi(p); p = strchr(p, ','); if (p) p++; else if (i < idx) { prio = 0; break; } }
+    FFH_HIP_TRY(c, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
+    *s = (ffh_stream)st;
+    return FFH_OK;
+  }
   FFH_HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   *s = (ffh_stream)st;
   return FFH_OK;

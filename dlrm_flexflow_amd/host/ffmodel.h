@@ -513,6 +513,10 @@ class FFModel {
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
   std::vector<Initializer*> owned_initializers;
   int grad_attach_layer;        // the Linear whose backward completes the embedding output gradients (-1: none / not attachable)
+  int z_reader_layer;           // the lowest-index Linear that reads a Concat output the tables are gathered into (-1: unknown): behind ITS
+                                // backward no forked weight-gradient GEMM reads that buffer any more, so the next gather may overwrite it
+  ffh_event ev_z_free;          // recorded on dw_stream behind that layer's backward
+  mutable bool z_free_recorded;
   mutable bool grad_ready_attached;
 
   // slabs

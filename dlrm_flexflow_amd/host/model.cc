@@ -3,6 +3,7 @@
 #include "ffmodel.h"
 
 #include <algorithm>
+#include <set>
 #include <cassert>
 #include <chrono>
 #include <cmath>
@@ -437,6 +438,8 @@ FFModel::FFModel(FFConfig& _config)
   check(api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw_done), "event create");
+  check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_z_free), "event create");
+  z_reader_layer = -1; z_free_recorded = false;
   dw_worker = side_worker = nullptr;
   if (config.async_launch && (std::string(api->ffh_backend_name()).rfind("hip", 0) == 0 || getenv("FFM_FORCE_ASYNC_LAUNCH"))) {
     // asynchronous devices only: on the CPU oracle a "launch" is the computation itself
@@ -476,6 +479,7 @@ FFModel::~FFModel() {
   api->ffh_event_destroy(ctx, ev_fork); api->ffh_event_destroy(ctx, ev_join);
   api->ffh_event_destroy(ctx, ev_grad_ready); api->ffh_event_destroy(ctx, ev_update_done);
   api->ffh_event_destroy(ctx, ev_dw_done);
+  api->ffh_event_destroy(ctx, ev_z_free);
   api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream);
   api->ffh_ctx_destroy(ctx);
   for (Op* op : layers) delete op;
@@ -1530,6 +1534,27 @@ void FFModel::allocate() {
     if (l < layers.size() && layers[l]->op_type == OP_LINEAR && l == (size_t)embeddings.back()->layer_index + 2) grad_attach_layer = (int)l;
   }
 
+  // ---- 4c'. the last forked weight-gradient GEMM that reads the buffer the tables are gathered into ----------
+  // The next step's gather (side stream) overwrites embedding outputs that alias a Concat output; the Linear layers consuming
+  // that output read it as the x operand of their weight-gradient GEMMs on dw_stream.  In backward order the lowest-index such
+  // layer comes last: behind its backward the gather may go, without waiting for the bottom MLP's weight gradients.
+  z_reader_layer = -1;
+  if (!embeddings.empty() && !exchange) {
+    std::set<const TensorImpl*> zs;
+    bool known = true;
+    for (const Embedding* e : embeddings) {
+      auto it = alias_of.find(e->outputs[0].impl);
+      if (it == alias_of.end()) { known = false; break; }     // a table with storage of its own: some other op reads it -- keep the full join
+      zs.insert(it->second.first->outputs[0].impl);
+    }
+    if (known) {
+      for (size_t l = 0; l < layers.size(); l++) {
+        if (layers[l]->op_type != OP_LINEAR) continue;
+        if (zs.count(layers[l]->inputs[0].impl)) { z_reader_layer = (int)l; break; }
+      }
+    }
+  }
+
   // ---- 4d. exchange mode: the feature Concat's backward folded into the layer above it ----------
   // There the embedding gradients have to reach the all-to-all send buffer, which Concat::backward does with a pack
   // kernel on the critical stream.  The Linear that consumes the Concat can store each column of its data gradient where
@@ -1940,6 +1965,13 @@ void FFModel::backward(int _seq_length) {
     check(api->ffh_mse_bwd_metrics(ctx, fin.impl->grad, (const float*)fin.impl->ptr, (const float*)label_tensor.impl->ptr, d_perf,
                                    local_rows(fin, this), fin.adim[0], scale, metrics_flags, stream), "metrics + loss backward");
   grad_ready_attached = false;
+  z_free_recorded = false;
+  auto mark_z_free = [&](int l) {     // behind the last reader of the gather's destination among the forked weight-gradient GEMMs
+    if (l == z_reader_layer && dw_forked && !dw_worker && capturing_trace < 0) {
+      check(api->ffh_event_record(ctx, ev_z_free, dw_stream), "z free");
+      z_free_recorded = true;
+    }
+  };
   for (int l = first; l >= 0; l--) {
     if (l == grad_attach_layer) {
       check(api->ffh_event_record_with_next_linear_bwd(ctx, ev_grad_ready), "attach event");
@@ -1950,6 +1982,7 @@ void FFModel::backward(int _seq_length) {
       const bool attach = l == scatter_attach_layer;
       check(api->ffh_linear_bwd_set_dx_scatter(ctx, up->dx_map, up->in_channels, attach ? ev_grad_ready : nullptr), "dx scatter");
       up->backward(*this);
+      mark_z_free(l);
       if (api->ffh_linear_dx_scatter_used(ctx)) {
         up->dx_map_concat->bwd_done = true;                    // its pack kernel is not needed this step
         if (attach) grad_ready_attached = true;
@@ -1972,6 +2005,7 @@ void FFModel::backward(int _seq_length) {
       up->pair_lower = nullptr;                                // not a shape the pair launch serves: the ordinary calls from now on
     }
     layers[l]->backward(*this);
+    mark_z_free(l);
   }
   if (emb_update_pending) {
     // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
@@ -1996,7 +2030,7 @@ void FFModel::update() {
     // the next gather (side stream) overwrites embedding outputs that alias the Concat output -- the x operand of the first
     // top-MLP layer, which a forked dW GEMM may still be reading: write-after-read across streams
     if (config.overlap_embedding && !embeddings.empty() && !use_workers())
-      check(api->ffh_stream_wait_event(ctx, side_stream, ev_dw_done), "join dw (embedding stream)");
+      check(api->ffh_stream_wait_event(ctx, side_stream, z_free_recorded ? ev_z_free : ev_dw_done), "join dw (embedding stream)");
     dw_forked = false;
   }
   // data-parallel MLP gradients: ONE bucket [ref: one ncclAllReduce per tensor, src/runtime/optimizer_kernel.cu:170-171].
