@@ -94,6 +94,28 @@ def pmc_traffic(key):
     return json.load(open(files[-1])).get(key) or {}, os.path.relpath(files[-1], ROOT)
 
 
+def traffic_file_is_current(src):
+    """The committed PMC file names the kernels it measured; if one of them no longer exists in libffhip.so the kernels have
+    changed since and the `traffic` figure is stale."""
+    if not src:
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, src)))
+        names = set()
+        for blk in d.values():
+            for k in (blk.get("per_kernel") or {}):
+                names.add(k.split("<")[0].strip())
+        blob = open(os.path.join(ROOT, "dlrm_flexflow_amd", "csrc", "libffhip.so"), "rb").read()
+        missing = sorted(n for n in names if n.encode() not in blob)
+        if missing:
+            print(f"bench: WARNING: {src} names kernels that are not in libffhip.so any more ({', '.join(missing)}): roofline.traffic is stale, "
+                  "re-run tools/pmc_traffic.sh", file=sys.stderr, flush=True)
+        return not missing
+    except Exception as e:  # noqa: BLE001
+        print("bench: could not check", src, e, file=sys.stderr)
+        return None
+
+
 def mlp_flops_per_sample(w):
     bot = [int(x) for x in w["bot"].split("-")]
     top = [int(x) for x in w["top"].split("-")]
@@ -141,6 +163,39 @@ def cpu_baseline_leg(name, budget_s, out):
     print("CPU_LEG " + json.dumps({"steps": n, "seconds": dt, "threads": threads, "batch": w["B"]}), file=out, flush=True)
 
 
+def reference_lookup(budget_s=6.0):
+    """The reference's ONLY CPU arithmetic for this path -- EmbeddingLookup_int64_t_float_float__avx2_fma
+    [ref: src/ops/embedding.cc:23-342, caller forward_task_cpu :377-415], compiled from the reference's own source into
+    oracle/_ref/libref_embedding.so (oracle/Makefile) -- timed as the reference runs it: one thread, bags of one id, emb_dim
+    128, uniform ids over a table far larger than the caches.  None when the library is not on this box."""
+    import ctypes as C
+    import numpy as np
+    lib_path = os.path.join(ROOT, "oracle", "_ref", "libref_embedding.so")
+    if not os.path.exists(lib_path):
+        return None
+    fn = getattr(C.CDLL(lib_path), "_Z45EmbeddingLookup_int64_t_float_float__avx2_fmaiiiiPKfPKlPKiS0_bPf")
+    fn.restype = None
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_bool, C.c_void_p]
+    D, R, B = 128, 4_000_000, 32768                      # 2.05 GB table, one bench batch of one table per call
+    rng = np.random.default_rng(0)
+    w = np.empty((R, D), np.float32); w[:] = 0.5
+    idx = rng.integers(0, R, B).astype(np.int64)
+    lengths = np.ones(B, np.int32)
+    out = np.empty((B, D), np.float32)
+    call = lambda: fn(D, B, B, R, w.ctypes.data, idx.ctypes.data, lengths.ctypes.data, None, False, out.ctypes.data)
+    call()                                               # warm (page-in of the table)
+    sets = [rng.integers(0, R, B).astype(np.int64) for _ in range(8)]
+    t = 0.0; calls = 0
+    while t < budget_s:
+        idx = sets[calls % 8]
+        t1 = time.perf_counter(); call(); t += time.perf_counter() - t1; calls += 1
+    nbytes = B * (8 + 4 * D + 4 * D)                      # the same per-lookup bytes the GPU roofline bills (SURVEY 8d)
+    return {"kind": "reference", "function": "EmbeddingLookup_int64_t_float_float__avx2_fma (oracle/_ref/libref_embedding.so, compiled from "
+            "/root/reference/src/ops/embedding.cc:17-374 by oracle/Makefile)", "cores": 1,
+            "lookups_per_s": round(calls * B / t, 1), "GB/s": round(calls * nbytes / t / 1e9, 3), "unit": "lookups/s",
+            "sample": f"{calls} calls of {B} single-id bags, emb_dim {D}, uniform ids over a {R}-row table ({R * D * 4 / 1e9:.2f} GB), {t:.1f} s, 1 thread"}
+
+
 def cpu_baseline(args, budget_s=24.0):
     """The same DLRM application with the CPU oracle as its kernel library, timed on the host: one thread (the reference's
     CPU embedding loop is serial), a quarter of the hardware threads and all of them; `value` is the fastest."""
@@ -164,13 +219,17 @@ def cpu_baseline(args, budget_s=24.0):
                       f"{b['seconds']:.1f} s" + (f", rows per table capped at {CPU_ROW_CAP} (host-side table init; favours the CPU's caches)" if capped else "") +
                       "; oracle/ffh_oracle.c (OpenMP over the batch) behind the same C++ FFModel host code",
             "host_cpus": ncpu,
-            "by_threads": {str(t): legs[t]["value"] for t in sorted(legs)}}
+            "by_threads": {str(t): legs[t]["value"] for t in sorted(legs)},
+            "reference_lookup": reference_lookup()}
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # N > 1 without a launcher: start the ranks ourselves, before anything initialises a GPU
 # ------------------------------------------------------------------------------------------------------------------
 def spawn_ranks(n: int) -> int:
+    """Starts the n ranks (nothing here touches a GPU), relays rank 0's single JSON line, and makes every rank's stderr visible in
+    this process's stderr with a "[rank r]" tag in front of each line -- a failure on rank 5 of 8 is then readable in the driver's log."""
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -180,30 +239,46 @@ def spawn_ranks(n: int) -> int:
                    MASTER_PORT=str(port), FFM_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    import threading
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
     buf = []
-    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)   # rank 0 prints the one JSON line
-    reader.start()
+    tails = [[] for _ in range(n)]
+
+    def relay(r, pipe):
+        for line in pipe:
+            tails[r].append(line)
+            del tails[r][:-40]
+            sys.stderr.write(f"[rank {r}] {line}")
+            sys.stderr.flush()
+
+    threads = [threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)]   # rank 0 prints the one JSON line
+    threads += [threading.Thread(target=relay, args=(r, p.stderr), daemon=True) for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
     deadline = time.time() + float(os.environ.get("FFM_SPAWN_TIMEOUT", "1500"))
     while True:
         rcs = [p.poll() for p in procs]
         if all(rc is not None for rc in rcs):
             break
         if any(rc not in (None, 0) for rc in rcs) or time.time() > deadline:
+            first_bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
             time.sleep(2.0)                  # let the failing rank's peers print what they have
             for p in procs:
                 if p.poll() is None:
                     p.kill()                 # exactly the children started above, by handle
             rcs = [p.wait() for p in procs]
+            if first_bad:
+                sys.stderr.write(f"bench.py: rank(s) {first_bad} failed first; the others were ended by the launcher\n")
             break
         time.sleep(0.05)
-    reader.join(timeout=10)
+    for t in threads:
+        t.join(timeout=10)
     out0 = buf[0] if buf else ""
     bad = [i for i, rc in enumerate(rcs) if rc != 0]
     line = [l for l in out0.splitlines() if l.startswith("{")]
     if bad or not line:
         sys.stderr.write(f"bench.py: rank(s) {bad} failed (exit codes {rcs}); rank 0 printed {len(line)} JSON line(s)\n")
+        for r in bad:
+            sys.stderr.write(f"---- last lines of rank {r} ----\n" + "".join(f"[rank {r}] {l}" for l in tails[r][-15:]))
         return 1
     print(line[-1], flush=True)
     return 0
@@ -226,10 +301,16 @@ def largest_linear(w, B, t_fwd, t_bwd, bf16):
                     "note": "dX and dW GEMMs of the layer (dW on its own stream where the layer is large enough), interval on the model's stream incl. the join"}}
 
 
-def hbm_block(kernel, nbytes, sec, traffic=None, src=None, note=None):
+def hbm_block(kernel, nbytes, sec, traffic=None, src=None, note=None, in_step_sec=None):
     d = {"kernel": kernel, "bound": "hbm", "achieved": round(nbytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src if traffic else None,
-         "us_per_launch": round(sec * 1e6, 2), "algorithmic_bytes_per_launch": nbytes}
+         "us_per_launch": round(sec * 1e6, 2), "algorithmic_bytes_per_launch": nbytes,
+         "probe": "back-to-back launches on the model's stream, HIP events; the launches rotate over 4 id sets drawn with their own seeds (a launch "
+                  "never finds the previous launch's rows in the 256 MiB Infinity Cache)"}
+    if in_step_sec:
+        d["us_per_launch_in_step"] = round(in_step_sec * 1e6, 2)     # events around the same launch inside real steps: it shares the chip there
+    if traffic:
+        d["traffic_source_current"] = traffic_file_is_current(src)
     if traffic:
         d["achieved_from_traffic"] = round(traffic / sec / 1e9, 1)     # HBM GB/s priced on the PMC bytes instead of the formula
         d["traffic_over_algorithmic"] = round(traffic / nbytes, 3)
@@ -258,12 +339,19 @@ def bf16_mode_block(ffmodel, w, local_rank, B, split=False):
     flops = mlp_flops_per_sample(w) * B
     blk = largest_linear(w, B, t_f, t_b, not split)
     if split:
-        blk["dtype"] = "f32 result from three bf16 terms per operand (six v_mfma_f32_32x32x16_bf16 products per k-step, fp32 accumulate)"
-        blk["note"] = "achieved / frac are fp32-equivalent flops (2*B*in*out) against the fp32 MFMA peak: above 1.0 means faster than any exact-fp32 MFMA kernel can be"
+        # the GEMMs run on the bf16 matrix pipe: six bf16 MFMAs per fp32-equivalent product, so the pipe's ceiling for this mode is
+        # BF16_PEAK / 6 fp32-equivalent TFLOP/s (not the fp32 MFMA peak: priced on that the fraction would exceed 1)
+        peak6 = BF16_PEAK_TFLOPS / 6.0
+        blk["dtype"] = "fp32 via 3x bf16 split: three bf16 terms per operand, six v_mfma_f32_32x32x16_bf16 products per k-step, fp32 accumulate"
+        blk["peak"] = round(peak6, 1)
+        for leg in ("fwd", "bwd"):
+            blk[leg]["frac"] = round(blk[leg]["achieved"] / peak6, 3)
+            blk[leg]["x_fp32_mfma_peak"] = round(blk[leg]["achieved"] / F32_PEAK_TFLOPS, 3)
+        blk["note"] = "achieved = fp32-equivalent flops (2*B*in*out); peak = bf16 MFMA peak / 6 (six bf16 products per fp32-accurate product); x_fp32_mfma_peak = the same rate over the 157.3 TFLOP/s fp32 MFMA peak"
         return {"flag": "--fp32-split-bf16x3 (ffh_ctx_set_math_mode(FFH_MATH_FP32_SPLIT_BF16X3)); opt-in, not the headline",
                 "parity": "same 1e-5-of-term-mass bound as the exact-fp32 kernels against the fp32 oracle; error against float64 within 4x theirs (tests/test_bf16_mode.py)",
                 "samples_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mlp_tflops_over_whole_step_fp32_equivalent": round(flops / dt / 1e12, 1),
-                "frac_of_fp32_mfma_peak": round(flops / dt / 1e12 / F32_PEAK_TFLOPS, 3), "linear_largest_layer": blk}
+                "x_fp32_mfma_peak_over_whole_step": round(flops / dt / 1e12 / F32_PEAK_TFLOPS, 3), "linear_largest_layer": blk}
     return {"flag": "--allow-tensor-op-math-conversion (ffh_ctx_set_math_mode(FFH_MATH_TENSOR_OP_BF16))",
             "dtype": "bf16 GEMM operands rounded from fp32 in the kernel, fp32 accumulate, fp32 master weights and activations in HBM",
             "samples_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mlp_tflops_over_whole_step": round(flops / dt / 1e12, 1),
@@ -334,6 +422,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FFM_TEST_FAIL_RANK") == str(rank) and args.functional_test_backend:      # tests/test_launchers.py: a rank that dies on purpose
+        raise SystemExit(f"rank {rank}: failing on purpose (FFM_TEST_FAIL_RANK)")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus {args.gpus}` (it starts its own ranks) or\n"
                          f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
@@ -436,6 +526,8 @@ def main():
     n_g = 200 if B * owned <= 65536 else 40
     t_fwd = app.time_kernel(8, n_g) * 1e-3 if (rank == 0 and table_wise and owned) else None           # gather kernel alone (no exchange)
     t_bwd = app.time_kernel(9, max(10, n_g // 2)) * 1e-3 if (rank == 0 and table_wise and owned) else None   # fused update kernels alone
+    t_fwd_in = app.time_kernel(10, 10 if B > 4096 else 50) * 1e-3 if (t_fwd and not trace and not ftest) else None      # the same kernels inside real eager steps
+    t_bwd_in = app.time_kernel(11, 10 if B > 4096 else 50) * 1e-3 if (t_bwd and not trace and not ftest) else None
     t_step_dev = app.time_kernel(2 if trace else 4, 20 if B > 4096 else 100) * 1e-3 if solo else None
     t_lin_fwd = app.time_kernel(6, 20 if B > 4096 else 200) * 1e-3 if solo else None      # largest Linear layer alone: forward, backward (dX + dW)
     t_lin_bwd = app.time_kernel(7, 20 if B > 4096 else 100) * 1e-3 if solo else None
@@ -490,12 +582,12 @@ def main():
         fwd_bytes = owned * B * (8 + 4 * D + 4 * D)            # indices + gathered rows + output write
         bwd_bytes = owned * B * (8 + 4 * D + 2 * 4 * D)        #            indices + out-grad read + row read-modify-write
         out["roofline"] = hbm_block("emb_fwd_kernel (embedding gather + bag-sum, this rank's tables in one launch)", fwd_bytes, t_fwd,
-                                    pmc.get("gather_bytes_per_launch"), src)
+                                    pmc.get("gather_bytes_per_launch"), src, in_step_sec=t_fwd_in)
         out["roofline"]["bytes_per_sample"] = fwd_bytes // B
         out["roofline"]["tables_in_launch"] = owned
         out["kernels"]["embedding_bwd_sgd_fused"] = hbm_block(
             "radix_hist/radix_scatter (LDS-histogram LSD radix sort of the ids) + emb_sgd_reduce (segmented sum + W -= lr*sum) + emb_sgd_fold; "
-            "batch x bag <= 2048 per table: emb_sgd_small_kernel, one launch", bwd_bytes, t_bwd, pmc.get("update_bytes_per_call"), src)
+            "batch x bag <= 2048 per table: emb_sgd_small_kernel, one launch", bwd_bytes, t_bwd, pmc.get("update_bytes_per_call"), src, in_step_sec=t_bwd_in)
     if solo:
         flops = mlp_flops_per_sample(w) * B
         peak = BF16_PEAK_TFLOPS if bf16 else F32_PEAK_TFLOPS
@@ -517,8 +609,9 @@ def main():
                 out["kernels"]["kaggle_secondary"] = kaggle_secondary(ffmodel, local_rank)
             except Exception as e:  # noqa: BLE001
                 out["kernels"]["kaggle_secondary"] = {"error": repr(e)}
-        if not args.no_cpu_baseline and not ftest:
-            out["cpu_baseline"] = cpu_baseline(args)
+    if not args.no_cpu_baseline and not ftest:
+        # host only, rank 0: the full three-leg sample at N = 1, a shorter one on the N > 1 lines (the driver runs N = 1, 2, 4, 8 back to back)
+        out["cpu_baseline"] = cpu_baseline(args, budget_s=24.0 if world == 1 else 9.0)
     print(json.dumps(out), file=json_out, flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -502,7 +502,14 @@ class FFModel {
   void embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx = nullptr) const;   // on_ctx: the issuing thread's ctx
   void replicated_embedding_grads() const;                     // dense gradient of the data-parallel tables into the slab (compute stream)
   void embedding_group_update(ffh_stream s, ffh_ctx* on_ctx = nullptr) const;
-  void embedding_kernels_only(bool fwd, ffh_stream s) const;                      // this rank's gather / fused update kernels, no exchange
+  // this rank's gather / fused update kernels, no exchange.  idx_override (bench probes): one id buffer per owned shard, in shard
+  // order, used instead of the model's own -- back-to-back probe launches rotate over several id sets so that no launch finds the
+  // rows of the launch before in the 256 MiB Infinity Cache
+  void embedding_kernels_only(bool fwd, ffh_stream s, const std::vector<const int64_t*>* idx_override = nullptr) const;
+  // bench probes: events around the side-stream gather / update of a REAL step (what the kernels take while they share the chip)
+  mutable bool probe_events_on = false;
+  mutable ffh_event probe_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gather begin / end, update begin / end
+  void probe_record(int which, ffh_stream s, ffh_ctx* cx) const;
   bool fused_embedding_update() const;
   void issue_embedding_forward_on_side_stream() const;
   void join_embedding_forward() const;

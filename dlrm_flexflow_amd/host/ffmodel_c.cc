@@ -144,6 +144,45 @@ float flexflow_dlrm_time_kernel(flexflow_dlrm_t h, int which, int iters) {
   FFModel* ff = app->ff;
   if (!app->warmed_up) app->warmup();
   ff->sync();
+  if (which == 10 || which == 11) {
+    // in-step probes: `iters` real eager steps with events around the side-stream gather (10) / table update (11); the average
+    // of the event intervals = what those kernels take while they share the chip with the MLP kernels of the same step
+    if (ff->embeddings.empty() || !ff->config.overlap_embedding) return 0.0f;
+    ff->probe_events_on = true;
+    double sum = 0.0; int n = 0;
+    for (int i = 0; i < iters + 1; i++) {
+      app->train_steps(1, false);
+      ff->sync();
+      const int a = which == 10 ? 0 : 2;
+      if (i == 0 || !ff->probe_ev[a] || !ff->probe_ev[a + 1]) continue;     // first step: warm
+      float ms = 0.f;
+      if (ff->api->ffh_event_elapsed_ms(ff->ctx, ff->probe_ev[a], ff->probe_ev[a + 1], &ms) == 0) { sum += ms; n++; }
+    }
+    ff->probe_events_on = false;
+    return n ? (float)(sum / n) : 0.0f;
+  }
+  // gather / update probes (8, 9): back-to-back launches rotate over kProbeSets id sets drawn with their own seeds, so that a
+  // launch never finds the rows of the one before in the Infinity Cache (26 x 32768 rows x 512 B = 436 MB per set > 256 MiB)
+  constexpr int kProbeSets = 4;
+  std::vector<std::vector<const int64_t*>> probe_ids;
+  std::vector<void*> probe_bufs;
+  if (which == 8 || which == 9) {
+    const int L = ff->embeddings.empty() ? 1 : ff->embeddings[0]->inputs[0].adim[0];
+    for (int set = 0; set < kProbeSets; set++) {
+      std::vector<const int64_t*> ptrs;
+      for (const FFModel::EmbShard& sh : ff->shards) {
+        if (sh.owner != ff->rank) continue;
+        const int64_t n = (int64_t)ff->config.batchSize * L;
+        void* buf = nullptr;
+        ff->check(ff->api->ffh_malloc(ff->ctx, &buf, (size_t)n * sizeof(int64_t)), "probe ids");
+        ff->check(ff->api->ffh_gen_indices(ff->ctx, (int64_t*)buf, n, 0x9e3779b97f4a7c15ull * (uint64_t)(set + 1) + (uint64_t)ptrs.size(), 0, sh.e->num_entries, ff->stream), "probe ids");
+        probe_bufs.push_back(buf);
+        ptrs.push_back((const int64_t*)buf);
+      }
+      probe_ids.push_back(ptrs);
+    }
+  }
+  int probe_turn = 0;
   ffh_event e0, e1;
   ff->check(ff->api->ffh_event_create(ff->ctx, &e0), "event");
   ff->check(ff->api->ffh_event_create(ff->ctx, &e1), "event");
@@ -158,8 +197,8 @@ float flexflow_dlrm_time_kernel(flexflow_dlrm_t h, int which, int iters) {
         if (which == 6) big->forward(*ff); else big->backward(*ff);
         continue;
       }
-      if (which == 8) ff->embedding_kernels_only(true, ff->stream);          // gather kernels of this rank's shards, no exchange
-      else if (which == 9) ff->embedding_kernels_only(false, ff->stream);    // fused update kernels alone
+      if (which == 8) ff->embedding_kernels_only(true, ff->stream, &probe_ids[probe_turn++ % kProbeSets]);          // gather kernels of this rank's shards, no exchange
+      else if (which == 9) ff->embedding_kernels_only(false, ff->stream, &probe_ids[probe_turn++ % kProbeSets]);    // fused update kernels alone
       else if (which == 0) ff->embedding_group_forward(ff->stream);
       else if (which == 1) ff->embedding_group_update(ff->stream);
       else if (which == 3) {   // launch floor: a trivial dependent kernel (MSE gradient of the batch)
@@ -197,6 +236,7 @@ float flexflow_dlrm_time_kernel(flexflow_dlrm_t h, int which, int iters) {
   ff->check(ff->api->ffh_event_elapsed_ms(ff->ctx, e0, e1, &ms), "event");
   ff->api->ffh_event_destroy(ff->ctx, e0);
   ff->api->ffh_event_destroy(ff->ctx, e1);
+  for (void* b : probe_bufs) ff->api->ffh_free(ff->ctx, b);
   return ms / (float)iters;
 }
 

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -109,6 +110,8 @@ int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv)
     unsigned sum = 0;
     for (int i = 0; i < 128; i++) sum += id[i];
     printf("[launcher] rank %d of %d: rendezvous ok (id checksum %u)\n", rank, world, sum);
+    fflush(stdout);
+    if (getenv("FFM_LAUNCH_TEST_HANG")) for (;;) pause();      // tests: a rank that never ends by itself (the parent must end it)
     return 0;
   }
   ffcomm comm;
@@ -136,6 +139,16 @@ int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv)
 }
 
 }  // namespace
+
+// the parent's signal handler: forwards SIGTERM / SIGINT to the ranks it started (async-signal-safe: kill only)
+static const pid_t* volatile g_pids = nullptr;
+static volatile size_t g_npids = 0;
+static volatile sig_atomic_t g_signalled = 0;
+static void forward_signal(int sig) {
+  g_signalled = 1;
+  const pid_t* p = g_pids;
+  for (size_t i = 0; p && i < g_npids; i++) kill(p[i], sig);
+}
 
 int dlrm_launch(int argc, char** argv) {
   const char* er = getenv("FFM_LAUNCH_RANK");
@@ -176,10 +189,35 @@ int dlrm_launch(int argc, char** argv) {
   int failed = (int)pids.size() != n;
   size_t left = pids.size();
   std::vector<bool> done(pids.size(), false);
+  // a termination signal to the launcher goes on to the ranks it started (they would be orphaned on the GPUs otherwise)
+  g_pids = pids.data(); g_npids = pids.size();
+  struct sigaction sa;
+  memset(&sa, 0, sizeof sa);
+  sa.sa_handler = forward_signal;
+  sigaction(SIGTERM, &sa, nullptr);
+  sigaction(SIGINT, &sa, nullptr);
+  if (failed)        // a fork failed after some ranks had started: they would wait for a world that never completes
+    for (pid_t q : pids) kill(q, SIGTERM);
+  std::chrono::steady_clock::time_point term_at{};
+  bool terminating = failed != 0;
+  if (terminating) term_at = std::chrono::steady_clock::now();
   while (left > 0) {
     int st = 0;
-    const pid_t p = wait(&st);
-    if (p < 0) break;
+    const pid_t p = waitpid(-1, &st, terminating ? WNOHANG : 0);
+    if (p == 0) {      // asked the ranks to end: give them a grace period, then SIGKILL what is left
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - term_at).count() > 10.0)
+        for (size_t j = 0; j < pids.size(); j++)
+          if (!done[j]) kill(pids[j], SIGKILL);
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+      continue;
+    }
+    if (p < 0) {
+      if (errno == EINTR) {                      // our own handler ran: the signal has been forwarded
+        if (g_signalled && !terminating) { terminating = true; failed = 1; term_at = std::chrono::steady_clock::now(); }
+        continue;
+      }
+      break;
+    }
     for (size_t i = 0; i < pids.size(); i++) {
       if (pids[i] != p || done[i]) continue;
       done[i] = true; left--;
@@ -190,10 +228,12 @@ int dlrm_launch(int argc, char** argv) {
           failed = 1;
           for (size_t j = 0; j < pids.size(); j++)
             if (!done[j]) kill(pids[j], SIGTERM);      // the ranks this process started, by pid: peers of a dead rank would wait for ever
+          terminating = true; term_at = std::chrono::steady_clock::now();
         }
       }
     }
   }
+  g_pids = nullptr; g_npids = 0;
   unlink((std::string(dir) + "/rccl_unique_id").c_str());
   unlink((std::string(dir) + "/rccl_unique_id.tmp").c_str());
   rmdir(dir);

@@ -480,6 +480,7 @@ FFModel::~FFModel() {
   api->ffh_event_destroy(ctx, ev_grad_ready); api->ffh_event_destroy(ctx, ev_update_done);
   api->ffh_event_destroy(ctx, ev_dw_done);
   api->ffh_event_destroy(ctx, ev_z_free);
+  for (ffh_event& e : probe_ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
   api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream);
   api->ffh_ctx_destroy(ctx);
   for (Op* op : layers) delete op;
@@ -1666,16 +1667,19 @@ void FFModel::print_layers(int id) {
 // =============================================================================================
 // launches one batched kernel per distinct shard width (all table-wise tables share one; column blocks of
 // giant tables another); FWD: gather, else fused backward + SGD
-static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s, ffh_ctx* cx) {
+static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s, ffh_ctx* cx, const std::vector<const int64_t*>* idx_override = nullptr) {
   const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(ff->optimizer);
   const int L = ff->embeddings[0]->inputs[0].adim[0];
   const int aggr = (int)ff->embeddings[0]->aggr;
   std::map<int, std::vector<ffh_emb_table>> by_cols;
+  size_t owned_i = 0;
   for (const FFModel::EmbShard& sh : ff->shards) {
     if (sh.owner != ff->rank) continue;
     const Embedding* e = sh.e;
     ffh_emb_table t;
     t.idx = (const int64_t*)e->inputs[0].impl->ptr;
+    if (idx_override && owned_i < idx_override->size()) t.idx = (*idx_override)[owned_i];
+    owned_i++;
     t.weight = (float*)e->weights[0].impl->ptr;      // column-sharded: the local [R][cols] slice
     t.num_entries = e->num_entries;
     if (!ff->exchange) {
@@ -1700,9 +1704,15 @@ static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s, ffh_c
 
 // the batched gather (fwd) or fused update kernels of this rank's shards alone, no exchange: what bench.py times as the
 // roofline kernels of a multi-rank job
-void FFModel::embedding_kernels_only(bool fwd, ffh_stream s) const {
+void FFModel::embedding_kernels_only(bool fwd, ffh_stream s, const std::vector<const int64_t*>* idx_override) const {
   if (embeddings.empty()) return;
-  launch_shard_groups(this, fwd, s, ctx);
+  launch_shard_groups(this, fwd, s, ctx, idx_override);
+}
+
+void FFModel::probe_record(int which, ffh_stream s, ffh_ctx* cx) const {
+  if (!probe_events_on) return;
+  if (!probe_ev[which]) check(api->ffh_event_create(ctx, &probe_ev[which]), "probe event");
+  check(api->ffh_event_record(cx, probe_ev[which], s), "probe event");
 }
 
 void FFModel::embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx) const {
@@ -1872,7 +1882,9 @@ void FFModel::issue_embedding_forward_on_side_stream() const {
     });
   } else {
     if (fork_recorded) check(api->ffh_stream_wait_event(ctx, side_stream, ev_fork), "fork");
+    probe_record(0, side_stream, ctx);
     embedding_group_forward(side_stream);
+    probe_record(1, side_stream, ctx);
     check(api->ffh_event_record(ctx, ev_join, side_stream), "join");
   }
   emb_forward_issued = true;
@@ -1895,7 +1907,9 @@ void FFModel::issue_embedding_update_on_side_stream() const {
     });
   } else {
     check(api->ffh_stream_wait_event(ctx, side_stream, ev_grad_ready), "event");
+    probe_record(2, side_stream, ctx);
     embedding_group_update(side_stream);
+    probe_record(3, side_stream, ctx);
     check(api->ffh_event_record(ctx, ev_update_done, side_stream), "event");
   }
 }

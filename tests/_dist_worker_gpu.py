@@ -34,9 +34,9 @@ def main():
         # never rewritten, so no new-batch event orders the side-stream gather behind the slab optimizer of the step before)
         from dlrm_flexflow_amd import ffmodel
         world = dist.get_world_size()
-        extra, steps = [], 3
+        extra, steps = list(sys.argv[4:]), 3            # further driver flags (math modes ...)
         if sys.argv[3].startswith("kaggle-repl"):
-            extra, steps = ["--replicate-embedding-rows", "8192"], 6
+            extra, steps = extra + ["--replicate-embedding-rows", "8192"], 6
             if sys.argv[3].endswith("noov"):
                 extra.append("--no-overlap")
         app = ffmodel.DLRM(H.KAGGLE_ARGS(2048 * world) + ["--device", "0", "--force-exchange"] + extra, comm=comm.struct)

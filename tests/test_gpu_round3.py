@@ -225,3 +225,31 @@ def test_graph_replay_race_regression_bit_exact(hip):
         app.close()
     for k in res[0]:
         assert res[0][k].tobytes() == res[1][k].tobytes(), k
+
+
+@pytest.mark.parametrize("flag", ["--allow-tensor-op-math-conversion", "--fp32-split-bf16x3"])
+def test_exchange_path_in_the_bf16_pipe_math_modes(hip, tmp_path, flag):
+    """Round-2 advisor finding: in both bf16-pipe math modes the backward returns before the dX column-map path, so in the exchange
+    configuration the model must fall back to the Concat pack kernel (ffh_linear_dx_scatter_used() == 0) with the event ordering that
+    goes with it.  One RCCL rank with the exchange path forced (all-to-all each way + all-reduce really enqueued), Kaggle shape, in
+    each mode, against the plain single-GPU run in the same mode: same kernels up to the pack / unpack copies, so the same numbers
+    to the fp32 summation-order bound."""
+    import os, subprocess
+    from conftest import ROOT
+    worker = os.path.join(ROOT, "tests", "_dist_worker_gpu.py")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200))
+    r = subprocess.run(["python", worker, str(tmp_path), "direct", "kaggle", flag], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    z = np.load(os.path.join(tmp_path, "rank0.npz"))
+    assert int(z["alltoall_calls"]) >= 2 * 4 and int(z["allreduce_calls"]) >= 4
+    app = ffmodel.DLRM(H.KAGGLE_ARGS(2048, HIP) + [flag])
+    app.warmup(); app.train_steps(3, trace=False); app.model.sync()
+    m = app.model
+    np.testing.assert_allclose(z["pred"], m.layer_output(m.num_layers - 1).get(), rtol=2e-5, atol=2e-6)
+    for l in range(m.num_layers):
+        if not m.layer_num_weights(l):
+            continue
+        w = m.parameter(l, 0).get_weights()
+        exp = w if w.size <= 1 << 16 else np.array([w.astype(np.float64).sum(), np.abs(w).astype(np.float64).sum(), float(w[:64].astype(np.float64).sum())])
+        np.testing.assert_allclose(z[f"p{l}"], exp, rtol=2e-5, atol=2e-6, err_msg=f"layer {l} {m.layer_name(l)}")
+    app.close()

@@ -69,6 +69,31 @@ def test_dlrm_binary_starts_its_own_ranks_dry():
         assert f"rank {k} of 3" in got[k]
 
 
+def test_dlrm_binary_forwards_sigterm_to_its_ranks():
+    """Round-2 advisor finding: SIGTERM / SIGINT to the launcher alone used to orphan the ranks.  Three ranks that never end by
+    themselves (dry run + FFM_LAUNCH_TEST_HANG); SIGTERM to the parent ends all of them, the parent returns non-zero and removes
+    its rendezvous directory."""
+    import signal, time, psutil, glob
+    before = set(glob.glob("/tmp/ffm_launch_*"))
+    env = dict(os.environ, FFM_LAUNCH_DRYRUN="1", FFM_LAUNCH_TEST_HANG="1")
+    p = subprocess.Popen([EXE, "-ll:gpu", "3", *SMALL], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    deadline = time.time() + 30
+    kids = []
+    while time.time() < deadline:
+        kids = psutil.Process(p.pid).children()
+        if len(kids) == 3:
+            break
+        time.sleep(0.05)
+    assert len(kids) == 3
+    time.sleep(0.5)
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=30)
+    assert p.returncode != 0
+    gone, alive = psutil.wait_procs(kids, timeout=10)
+    assert not alive, alive
+    assert set(glob.glob("/tmp/ffm_launch_*")) <= before
+
+
 def test_dlrm_binary_reports_a_failing_rank():
     """A rank that cannot come up (no GPU here / no such device) makes the parent end the others and return non-zero."""
     import torch
@@ -148,6 +173,20 @@ def test_bench_two_ranks_functional_on_cpu(oracle, scaling):
     assert c["alltoall"] == 2 * (1 + 1 + 3) and c["allreduce"] == 1 + 1 + 3        # the driver's warm-up + W + K steps
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["tables_in_launch"] == 4      # rank 0 owns tables 0, 2, 4, 6 of 8
     assert d["value"] > 0 and "cpu_baseline" not in d
+    pay = d["config"]["collective_payload_bytes_per_step_rank0"]
+    B, D = d["config"]["global_batch"], 16
+    assert pay["alltoall_forward_sent"] == pay["alltoall_backward_sent"] == 4 * B * D * 4 // 2 and pay["allreduce_buffer"] > 0
+
+
+def test_bench_failing_rank_is_named_in_the_parents_output(oracle):
+    """First-contact readiness for N > 1: when a rank other than 0 dies, the launcher's own stderr carries that rank's output with a
+    [rank r] tag, names the rank that failed first, ends the others and exits non-zero without a JSON line."""
+    env = dict(_bench_env(), FFM_TEST_FAIL_RANK="1", FFM_SPAWN_TIMEOUT="120")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                        "--functional-test-backend", oracle.ORACLE_LIB], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "[rank 1] rank 1: failing on purpose" in r.stderr and "rank(s) [1] failed first" in r.stderr
 
 
 def test_bench_as_a_rank_under_torchrun_functional_on_cpu(oracle):
