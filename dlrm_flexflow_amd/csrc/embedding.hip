@@ -24,6 +24,7 @@ constexpr int kMaxChunks = 4;   // row chunks per lane: D <= 4*64*4 = 1024 (vect
 
 struct EmbArgs {
   ffh_emb_table t[FFH_MAX_TABLES];
+  unsigned short* out16[FFH_MAX_TABLES];   // forward, tensor-op mode: bf16 twin of t[i].io (same leading dimension) or null
   int64_t batch;
   int     ntables;
   int     L;
@@ -39,6 +40,7 @@ template <int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void emb_fwd_kernel(const EmbArgs a) {
   using vec_t = typename std::conditional<VEC == 4, float4, float>::type;
   const ffh_emb_table tb = a.t[blockIdx.y];
+  unsigned short* const o16 = a.out16[blockIdx.y];
   const int D = a.D, L = a.L;
   const int nvec = D / VEC;                       // vectors per row
   const int lpr = nvec < 64 ? nvec : 64;          // lanes per row
@@ -88,6 +90,11 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(const EmbArgs a) {
 #pragma unroll
           for (int v = 0; v < VEC; v++) f[v] = avg ? acc[u][v] * inv : acc[u][v];
           reinterpret_cast<vec_t*>(tb.io + b * tb.ld)[c] = o;
+          if (VEC == 4 && o16) {      // the twin the first top-MLP GEMM reads its operand from (ffh_ctx_bf16_mirror_set)
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            const bf2 lo = {(__bf16)f[0], (__bf16)f[1]}, hi = {(__bf16)f[2], (__bf16)f[3]};
+            reinterpret_cast<uint2*>(o16 + b * tb.ld)[c] = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+          }
         }
       }
     }
@@ -817,7 +824,11 @@ int ffh_embedding_fwd_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int
   if ((nvec + 63) / 64 > kMaxChunks * 64) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "embedding_fwd: out_dim too large");
   EmbArgs a;
   memset(&a, 0, sizeof a);
-  for (int i = 0; i < nt; i++) a.t[i] = tables[i];
+  for (int i = 0; i < nt; i++) {
+    a.t[i] = tables[i];
+    // tensor-op mode with a registered twin of the destination: the gather writes the bf16 roundings beside the fp32 rows
+    a.out16[i] = (v4 && tables[i].ld % 4 == 0) ? ffh_mirror_of(c, tables[i].io, (size_t)((batch - 1) * tables[i].ld + D) * 4) : nullptr;
+  }
   a.batch = batch; a.ntables = nt; a.L = L; a.D = D; a.aggr = aggr;
   const int lpr = nvec < 64 ? nvec : 64;
   const int rpw = 64 / lpr;

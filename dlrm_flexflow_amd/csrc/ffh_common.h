@@ -10,6 +10,8 @@
 #include "../../include/ff_hip.h"
 #include "../../include/ffh_rng.h"
 
+struct ffh_mirror_region { const char* base; size_t bytes; char* twin; };   // ffh_ctx_bf16_mirror_set
+
 struct ffh_ctx {
   int         device;
   void*       ws;        // caller-attached scratch (FFHandler.workSpace analogue)
@@ -24,6 +26,8 @@ struct ffh_ctx {
   int         deterministic;   // ffh_ctx_set_deterministic(): no fp atomics in weight / bias gradients
   int         math_mode; // ffh_ctx_set_math_mode(): FFH_MATH_DEFAULT | FFH_MATH_TENSOR_OP_BF16
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
+  ffh_mirror_region mirrors[32];   // bf16 twins of fp32 buffers (tensor-op mode)
+  int         nmirrors;
   char        route[256]; // ffh_linear_last_route(): kernel families of the latest ffh_linear_* call
   char        err[512];
 };
@@ -65,6 +69,17 @@ static inline int ffh_fail_hip(ffh_ctx* c, hipError_t e, const char* what) {
   } while (0)
 
 static inline hipStream_t as_stream(ffh_stream s) { return (hipStream_t)s; }
+
+// the bf16 twin of the fp32 element at p when [p, p + span_bytes) lies inside a registered region and the tensor-op mode is on
+static inline unsigned short* ffh_mirror_of(const ffh_ctx* c, const void* p, size_t span_bytes) {
+  if (!c || !p || c->math_mode != FFH_MATH_TENSOR_OP_BF16) return nullptr;
+  const char* q = (const char*)p;
+  for (int i = 0; i < c->nmirrors; i++) {
+    const ffh_mirror_region& r = c->mirrors[i];
+    if (q >= r.base && q + span_bytes <= r.base + r.bytes) return (unsigned short*)(r.twin + (q - r.base) / 2);
+  }
+  return nullptr;
+}
 
 // grid sizing for memory-bound grid-stride kernels: enough workgroups to fill
 // 256 CUs x 8 blocks, capped (cdna guide, Guideline 11)

@@ -1623,6 +1623,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       gw.C = dw; gw.ldc = in;
       gw.M = out; gw.N = in; gw.K = (int)batch;
       gw.epi = EPI_ATOMIC; gw.act = FFH_AC_MODE_NONE;
+      gw.a_not_twinned = act != FFH_AC_MODE_NONE;       // a live activation gradient rewrote dy in place: its bf16 twin is stale
       const int rc = launch_gemm_bf16_form(c, gw, BF16_FORM_DW, sw_, "linear_bwd dw gemm (bf16)");
       if (rc) return rc;
     }
@@ -1634,6 +1635,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       gx.M = (int)batch; gx.N = in; gx.K = out;
       gx.epi = (flags & FFH_LINEAR_DX_OVERWRITE) ? EPI_STORE : EPI_ADD;
       gx.act = FFH_AC_MODE_NONE;
+      gx.a_not_twinned = act != FFH_AC_MODE_NONE;
       if (mask_by_x) { gx.mask = x; gx.ldmask = ldx; }
       int rc;
       if ((forked_ || !do_dw) && relu_) {          // dy is (being) masked by someone else: read it through relu'(y)

@@ -49,11 +49,14 @@ __device__ __forceinline__ unsigned bf_off_kr(int krow, int chunk) { return (uns
 // BM x BN block tile, one wave per WM x 64 of it: 128 x 128 (4 waves of 64 x 64, two workgroups per CU) or, where the output
 // has enough tiles to fill the chip with them, 256 x 256 (8 waves of 128 x 64, 128 KB of LDS, one workgroup per CU): the fp32
 // operands cross the L2 -> CU path half as often, and that path is what bounds this kernel
-template <bool AKC, bool BKC, bool MASK_A = false, int BM = kBfBM, int BN = kBfBN, int WM = 64>
+// SRC16: both operands come from their bf16 twins (ffh_ctx_bf16_mirror_set; K a multiple of 64, M, N and the strides multiples
+// of 8): a thread moves 16-byte chunks of 8 elements global -> LDS with no conversion and half the bytes
+template <bool AKC, bool BKC, bool MASK_A = false, int BM = kBfBM, int BN = kBfBN, int WM = 64, bool SRC16 = false>
 __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16_kernel(const GemmArgs g) {
+  static_assert(!(SRC16 && MASK_A), "the masking loader reads fp32 operands");
   constexpr int BK = kBfBK, NT = BM / WM * BN;                 // one wave per WM x 64 of the tile
   constexpr int TM = WM / 32;
-  constexpr int NA = BM * 16 / NT, NB = BN * 16 / NT;          // float4 per thread per k-tile
+  constexpr int NA = SRC16 ? BM * 8 / NT : BM * 16 / NT, NB = SRC16 ? BN * 8 / NT : BN * 16 / NT;   // 16-byte pieces per thread per k-tile
   constexpr int IMG_A = BM * BK * 2, IMG_B = BN * BK * 2;     // bytes of the operand images
   static_assert(NT <= 1024 && NA >= 1 && NB >= 1, "tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char bf_smem[];
@@ -82,10 +85,26 @@ __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16_kernel(const GemmArgs 
   const float* B = g.B;
 
   float4 ra[NA], rb[NB];
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  u32x4_t pa[NA], pb[NB];          // SRC16: 16-byte pieces of the twins, moved as they are
   const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
-  auto load_tile = [&](int kt, auto fast_tag) {
+  auto load_tile = [&](int kt, auto fast_tag) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_tag)::value;
     const int k0 = kb + kt * BK;
+    if constexpr (SRC16) {      // 8 bf16 per piece; a k-contiguous row is 8 pieces, a k-row of the other form BM / 8 (BN / 8)
+#pragma unroll
+      // rows / columns of an edge tile beyond the matrix are clamped to its last row / last 8 columns (M, N multiples of 8): valid
+      // addresses, values the epilogue never stores
+      for (int i = 0; i < NA; i++) {
+        if (AKC) { const int ch = tid & 7, row = (tid >> 3) + (NT / 8) * i; const int m = m0 + row < g.M ? m0 + row : g.M - 1; pa[i] = *reinterpret_cast<const u32x4_t*>(g.A16 + (int64_t)m * g.sAm + k0 + 8 * ch); }
+        else { const int ch = tid % (BM / 8), kr = tid / (BM / 8) + (8 * NT / BM) * i; const int m = m0 + 8 * ch < g.M ? m0 + 8 * ch : g.M - 8; pa[i] = *reinterpret_cast<const u32x4_t*>(g.A16 + (int64_t)(k0 + kr) * g.sAk + m); }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        if (BKC) { const int ch = tid & 7, row = (tid >> 3) + (NT / 8) * i; const int n = n0 + row < g.N ? n0 + row : g.N - 1; pb[i] = *reinterpret_cast<const u32x4_t*>(g.B16 + (int64_t)n * g.sBn + k0 + 8 * ch); }
+        else { const int ch = tid % (BN / 8), kr = tid / (BN / 8) + (8 * NT / BN) * i; const int n = n0 + 8 * ch < g.N ? n0 + 8 * ch : g.N - 8; pb[i] = *reinterpret_cast<const u32x4_t*>(g.B16 + (int64_t)(k0 + kr) * g.sBk + n); }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NA; i++) {
       if (AKC) {
@@ -121,10 +140,23 @@ __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16_kernel(const GemmArgs 
         else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, true);
       }
     }
+    }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf) __attribute__((always_inline)) {
     unsigned char* as = bf_smem + buf * (IMG_A + IMG_B);
     unsigned char* bs = as + IMG_A;
+    if constexpr (SRC16) {      // the same images, one whole 16-byte chunk per store
+#pragma unroll
+      for (int i = 0; i < NA; i++) {
+        if (AKC) { const int ch = tid & 7, row = (tid >> 3) + (NT / 8) * i; *reinterpret_cast<u32x4_t*>(as + bf_off_kc(row, ch)) = pa[i]; }
+        else { const int ch = tid % (BM / 8), kr = tid / (BM / 8) + (8 * NT / BM) * i; *reinterpret_cast<u32x4_t*>(as + bf_off_kr<BM>(kr, ch)) = pa[i]; }
+      }
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        if (BKC) { const int ch = tid & 7, row = (tid >> 3) + (NT / 8) * i; *reinterpret_cast<u32x4_t*>(bs + bf_off_kc(row, ch)) = pb[i]; }
+        else { const int ch = tid % (BN / 8), kr = tid / (BN / 8) + (8 * NT / BN) * i; *reinterpret_cast<u32x4_t*>(bs + bf_off_kr<BN>(kr, ch)) = pb[i]; }
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < NA; i++) {
       if (AKC) {
@@ -144,6 +176,7 @@ __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16_kernel(const GemmArgs 
         const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;
         *reinterpret_cast<uint2*>(bs + bf_off_kr<BN>(kr, n4 >> 1) + 8 * (n4 & 1)) = pack_bf16x4(rb[i]);
       }
+    }
     }
   };
 
@@ -172,7 +205,7 @@ __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16_kernel(const GemmArgs 
     const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
   };
-  auto compute_tile = [&](int buf) {
+  auto compute_tile = [&](int buf) __attribute__((always_inline)) {
     const unsigned char* as = bf_smem + buf * (IMG_A + IMG_B);
     const unsigned char* bs = as + IMG_A;
 #pragma unroll
@@ -217,9 +250,11 @@ __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16_kernel(const GemmArgs 
         float* cp = C + (int64_t)m * g.ldc + n;
         float v = acc[i][j][r];
         if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n] > 0.0f)) v = 0.0f;
-        if (g.epi == EPI_STORE) *cp = act_apply(v + bv, g.act);
-        else if (g.epi == EPI_ADD) *cp = *cp + v;
-        else atomicAdd(cp, v);
+        if (g.epi == EPI_STORE) v = act_apply(v + bv, g.act);
+        else if (g.epi == EPI_ADD) v = *cp + v;
+        if (g.epi == EPI_ATOMIC) { atomicAdd(cp, v); continue; }
+        *cp = v;
+        if (g.C16) { const __bf16 t = (__bf16)v; g.C16[(int64_t)m * g.ldc + n] = __builtin_bit_cast(unsigned short, t); }   // the twin of C
       }
     }
 }
@@ -540,7 +575,45 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     if (e3 != hipSuccess) return ffh_fail_hip(c, e3, name);
     return FFH_OK;
   }
-  if (big) {
+  // bf16 twins (ffh_ctx_bf16_mirror_set): the output's twin is written whenever one is registered; the operands come from
+  // their twins when both have one and the problem is whole tiles of this launch
+  g.A16 = g.B16 = nullptr; g.C16 = nullptr;
+  if (!x3) {
+    const bool akc = AKC, bkc = BKC;
+    const int64_t lda = akc ? g.sAm : g.sAk, ldb = bkc ? g.sBn : g.sBk;
+    const size_t a_span = (size_t)(((akc ? g.M : g.K) - 1) * lda + (akc ? g.K : g.M)) * 4, b_span = (size_t)(((bkc ? g.N : g.K) - 1) * ldb + (bkc ? g.K : g.N)) * 4;
+    if (g.epi != EPI_ATOMIC) g.C16 = ffh_mirror_of(c, g.C, (size_t)((int64_t)(g.M - 1) * g.ldc + g.N) * 4);
+    static const int no_src16 = getenv("FFH_BF16_NO_TWINS") ? atoi(getenv("FFH_BF16_NO_TWINS")) : 0;      // A/B switch
+    if (!MASK_A && !no_src16 && !g.a_not_twinned && g.M % 8 == 0 && g.N % 8 == 0 && g.M >= 8 && g.N >= 8 && g.K % kBfBK == 0 && g.k_per_split % kBfBK == 0 && lda % 8 == 0 && ldb % 8 == 0) {
+      const unsigned short* a16 = ffh_mirror_of(c, g.A, a_span);
+      const unsigned short* b16 = ffh_mirror_of(c, g.B, b_span);
+      if (a16 && b16 && (((uintptr_t)a16 | (uintptr_t)b16) & 15) == 0) { g.A16 = a16; g.B16 = b16; }
+    }
+  }
+  if constexpr (!MASK_A) {
+    if (g.A16 && big) {
+      auto kernw = gemm_bf16_kernel<AKC, BKC, false, 256, 256, 128, true>;
+      static const bool okw = glds_set_lds(kernw, bf_lds_bytes(256, 256));
+      if (!okw) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16): cannot reserve 128 KB of LDS");
+      hipLaunchKernelGGL(kernw, dim3(gx, gy, gz), dim3(512), bf_lds_bytes(256, 256), as_stream(s), g);
+      hipError_t ew = hipGetLastError();
+      if (ew != hipSuccess) return ffh_fail_hip(c, ew, name);
+      { char tok[96]; snprintf(tok, sizeof tok, "%s|bf16_256x256_twins|splitk=%d", name, g.splitk); ffh_route_add(c, tok); }
+      return FFH_OK;
+    }
+    if (g.A16) {
+      auto kern = gemm_bf16_kernel<AKC, BKC, false, kBfBM, kBfBN, 64, true>;
+      static const bool ok = glds_set_lds(kern, kBfLds);
+      if (!ok) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16): cannot reserve 64 KB of LDS");
+      hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(256), kBfLds, as_stream(s), g);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+      { char tok[96]; snprintf(tok, sizeof tok, "%s|bf16_128x128_twins|splitk=%d", name, g.splitk); ffh_route_add(c, tok); }
+      return FFH_OK;
+    }
+  }
+  { char tok[96]; snprintf(tok, sizeof tok, "%s|bf16%s_%s|splitk=%d", name, x3 ? "x3" : "", big ? "256x256" : "128x128", g.splitk); ffh_route_add(c, tok); }
+  if (big && !x3) {
     auto kernw = gemm_bf16_kernel<AKC, BKC, MASK_A, 256, 256, 128>;
     static const bool okw = glds_set_lds(kernw, bf_lds_bytes(256, 256));
     if (!okw) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16): cannot reserve 128 KB of LDS");

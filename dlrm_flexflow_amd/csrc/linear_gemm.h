@@ -34,6 +34,12 @@ struct GemmArgs {
   int64_t      ldmask;
   // CMAP kernels (dX of the layer above a Concat, ffh_linear_bwd_set_dx_scatter): column n of C lives at colmap[n].base[m * colmap[n].ld]
   const ffh_col_dest* colmap;
+  // tensor-op mode with bf16 twins (ffh_ctx_bf16_mirror_set): the operands' twins (same element strides; both or neither) and
+  // the twin the epilogue writes beside C (or null)
+  const unsigned short* A16;
+  const unsigned short* B16;
+  unsigned short*       C16;
+  int                   a_not_twinned;   // the caller changed A in place without its twin (live activation gradient): do not read A's twin
   // persistent launch: the (x, y, z) tile space; the launch is then a 1-D grid of fewer workgroups, each walking tiles
   // blockIdx.x, blockIdx.x + gridDim.x, ...  (tnx == 0: one workgroup per tile, tile space = the 3-D grid)
   unsigned tnx, tny, tnz;

@@ -86,6 +86,44 @@ int ffh_ctx_set_math_mode(ffh_ctx* c, int mode) {
   return FFH_OK;
 }
 
+int ffh_ctx_bf16_mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* twin) {
+  if (!c || !base || bytes == 0 || ((uintptr_t)base & 15) || ((uintptr_t)twin & 15)) return FFH_ERR_BAD_ARG;
+  int at = -1;
+  for (int i = 0; i < c->nmirrors; i++) if (c->mirrors[i].base == (const char*)base) at = i;
+  if (!twin) {
+    if (at >= 0) { c->mirrors[at] = c->mirrors[c->nmirrors - 1]; c->nmirrors--; }
+    return FFH_OK;
+  }
+  if (at < 0) {
+    if (c->nmirrors >= 32) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "bf16_mirror_set: more than 32 regions");
+    at = c->nmirrors++;
+  }
+  c->mirrors[at].base = (const char*)base; c->mirrors[at].bytes = bytes; c->mirrors[at].twin = (char*)twin;
+  return FFH_OK;
+}
+
+__global__ __launch_bounds__(256) void convert_bf16_kernel(unsigned short* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n && (((uintptr_t)(src + i)) & 15) == 0 && (((uintptr_t)(dst + i)) & 7) == 0) {
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+      const bf2 lo = {(__bf16)v.x, (__bf16)v.y}, hi = {(__bf16)v.z, (__bf16)v.w};
+      *reinterpret_cast<uint2*>(dst + i) = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+    } else {
+      for (int k = 0; k < 4 && i + k < n; k++) { const __bf16 b = (__bf16)src[i + k]; dst[i + k] = __builtin_bit_cast(unsigned short, b); }
+    }
+  }
+}
+
+int ffh_convert_f32_to_bf16(ffh_ctx* c, void* dst, const float* src, int64_t n, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && ((dst && src) || n == 0), "convert_f32_to_bf16: bad args");
+  if (n == 0) return FFH_OK;
+  hipLaunchKernelGGL(convert_bf16_kernel, dim3(ffh_grid((n + 3) / 4, 256)), dim3(256), 0, as_stream(s), (unsigned short*)dst, src, n);
+  FFH_LAUNCH_CHECK(c, "convert_bf16_kernel");
+  return FFH_OK;
+}
+
 int ffh_ctx_set_deterministic(ffh_ctx* c, int on) {
   if (!c) return FFH_ERR_BAD_ARG;
   c->deterministic = on ? 1 : 0;

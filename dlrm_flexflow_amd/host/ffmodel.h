@@ -520,6 +520,11 @@ class FFModel {
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
   std::vector<Initializer*> owned_initializers;
   int grad_attach_layer;        // the Linear whose backward completes the embedding output gradients (-1: none / not attachable)
+  // tensor-op math mode: bfloat16 twins of the weight slab, of activations and of activation gradients whose every writer
+  // keeps a twin current (ffh_ctx_bf16_mirror_set): the bf16-pipe GEMMs then read 2-byte operands instead of rounding 4-byte ones
+  void* w_twin = nullptr; void* act_twin = nullptr; void* grad_twin = nullptr;
+  mutable bool w_twin_dirty = false;      // a host write / initializer touched the weights: reconvert before the next forward
+  int n_twin_regions = 0;
   int z_reader_layer;           // the lowest-index Linear that reads a Concat output the tables are gathered into (-1: unknown): behind ITS
                                 // backward no forked weight-gradient GEMM reads that buffer any more, so the next gather may overwrite it
   ffh_event ev_z_free;          // recorded on dw_stream behind that layer's backward

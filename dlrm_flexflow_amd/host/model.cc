@@ -241,6 +241,8 @@ bool Tensor::set_tensor(const FFModel* model, const std::vector<int>& dims, cons
                                                cols_ * sizeof(T), model->stream), "set_tensor");
   }
   model->check(model->api->ffh_stream_sync(model->ctx, model->stream), "set_tensor sync");
+  if (model->w_twin && (const char*)impl->ptr >= (const char*)model->mlp_weights && (const char*)impl->ptr < (const char*)(model->mlp_weights + model->mlp_count))
+    model->w_twin_dirty = true;       // tensor-op mode: the weights' bf16 twin is reconverted before the next forward
   return true;
 }
 
@@ -468,6 +470,7 @@ FFModel::~FFModel() {
     if (t->ptr && !t->alias && t->bytes) api->ffh_free(ctx, t->ptr);
     delete t;
   }
+  for (void* p : {w_twin, act_twin, grad_twin}) if (p) api->ffh_free(ctx, p);
   for (void* p : {(void*)mlp_weights, (void*)mlp_grads, (void*)act_slab, (void*)act_grad_slab, workspace, repl_workspace, (void*)d_perf, (void*)xsend,
                   (void*)xrecv, (void*)gsend, (void*)grecv})
     if (p) api->ffh_free(ctx, p);
@@ -1649,6 +1652,62 @@ void FFModel::allocate() {
   check(api->ffh_zero(ctx, d_perf, sizeof(ffh_perf_metrics), stream), "zero");
   check(api->ffh_zero(ctx, act_slab, std::max<size_t>(act_bytes, 256), stream), "zero");
   check(api->ffh_zero(ctx, act_grad_slab, std::max<size_t>(act_grad_bytes, 256), stream), "zero");
+
+  // ---- 7. tensor-op math mode: bf16 twins ---------------------------------------------------------
+  // [ref: --allow-tensor-op-math-conversion, src/runtime/model.cu:81-83]  The library rounds GEMM operands to bfloat16 in that
+  // mode; a buffer whose EVERY writer keeps a bf16 twin current can be read at half the bytes (include/ff_hip.h,
+  // ffh_ctx_bf16_mirror_set: validity is this layer's contract).  Twin-writers: a Linear with in, out >= FFH_BF16_MIN_DIM
+  // (forward: its output; backward: its input gradient, when it is that gradient's only producer), the gather (embedding
+  // outputs of a width divisible by 4), the slab optimizer (weights).  Registered:
+  //   * the weight slab (reconverted here whenever the host or an initializer wrote weights);
+  //   * the output of such a Linear with storage of its own; a Concat output all of whose inputs are written in place by
+  //     tables and such Linears;
+  //   * the gradient buffer of a tensor whose single consumer is such a Linear storing (not accumulating) its data gradient.
+  n_twin_regions = 0;
+  if (config.allow_tensor_op_math_conversion && !getenv("FFM_NO_BF16_TWINS") && mlp_count > 0) {
+    const size_t ab = std::max<size_t>(act_bytes, 256);
+    act_twin = dmalloc(ab / 2 + 256); grad_twin = dmalloc(ab / 2 + 256); w_twin = dmalloc((size_t)mlp_count * 2 + 256);
+    check(api->ffh_zero(ctx, act_twin, ab / 2 + 256, stream), "zero"); check(api->ffh_zero(ctx, grad_twin, ab / 2 + 256, stream), "zero");
+    check(api->ffh_zero(ctx, w_twin, (size_t)mlp_count * 2 + 256, stream), "zero");
+    auto reg = [&](const void* base, size_t bytes, void* twin) {
+      if (bytes == 0 || n_twin_regions >= 30) return;
+      check(api->ffh_ctx_bf16_mirror_set(ctx, base, bytes, twin), "bf16 twin");
+      if (dw_worker) check(api->ffh_ctx_bf16_mirror_set(dw_worker->ctx(), base, bytes, twin), "bf16 twin");
+      if (side_worker) check(api->ffh_ctx_bf16_mirror_set(side_worker->ctx(), base, bytes, twin), "bf16 twin");
+      n_twin_regions++;
+    };
+    reg(mlp_weights, (size_t)mlp_count * 4, w_twin);
+    w_twin_dirty = true;
+    auto twin_linear = [&](const Op* op) {
+      const Linear* l = op && op->op_type == OP_LINEAR ? static_cast<const Linear*>(op) : nullptr;
+      return l && l->in_channels >= FFH_BF16_MIN_DIM && l->out_channels >= FFH_BF16_MIN_DIM;
+    };
+    auto in_slab = [&](const void* q) { return (const char*)q >= act_slab && (const char*)q < act_slab + act_bytes; };
+    for (Op* op : layers) {
+      TensorImpl* im = op->outputs[0].impl;
+      if (!im || !im->ptr || alias_of.count(im) || !in_slab(im->ptr) || !im->pieces.empty()) continue;
+      bool act_ok = false;
+      if (twin_linear(op)) act_ok = true;
+      else if (Concat* c = dynamic_cast<Concat*>(op)) {
+        act_ok = !exchange && c->numInputs > 0;
+        for (int i = 0; i < c->numInputs && act_ok; i++) {
+          const Tensor& in = c->inputs[i];
+          auto it = alias_of.find(in.impl);
+          if (it == alias_of.end() || it->second.first != c || !in.owner_op) { act_ok = false; break; }
+          if (in.owner_op->op_type == OP_EMBEDDING) act_ok = static_cast<const Embedding*>(in.owner_op)->out_channels % 4 == 0 && !static_cast<const Embedding*>(in.owner_op)->replicated;
+          else act_ok = twin_linear(in.owner_op);
+        }
+      }
+      if (act_ok) reg(im->ptr, im->bytes, (char*)act_twin + ((const char*)im->ptr - act_slab) / 2);
+      // the gradient of this tensor: one consumer, a twin-writing Linear that stores its data gradient
+      const Linear* only = nullptr; int ncons = 0;
+      for (Op* q : layers)
+        for (int i = 0; i < q->numInputs; i++)
+          if (q->inputs[i].impl == im) { ncons++; only = q->op_type == OP_LINEAR ? static_cast<const Linear*>(q) : nullptr; }
+      if (ncons == 1 && only && twin_linear(only) && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange)
+        reg(im->grad, im->bytes, (char*)grad_twin + ((const char*)im->grad - act_grad_slab) / 2);
+    }
+  }
   check(api->ffh_stream_sync(ctx, stream), "allocate sync");
 }
 
@@ -1822,6 +1881,10 @@ void FFModel::reset_metrics() {
 void FFModel::forward(int _seq_length) {
   if (replaying_trace >= 0) return;
   seq_length = _seq_length;
+  if (w_twin && w_twin_dirty) {      // tensor-op mode: the weights' bf16 twin after a host write / (re)initialisation
+    check(api->ffh_convert_f32_to_bf16(ctx, w_twin, mlp_weights, (int64_t)mlp_count, stream), "weight twin");
+    w_twin_dirty = false;
+  }
   emb_forward_issued = emb_forward_joined = false;
   // gather (+ all-to-all) go to the side stream beside the bottom MLP: the fork point is here (inputs ready)
   if (config.overlap_embedding && !embeddings.empty()) {

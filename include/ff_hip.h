@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 5   /* 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 6   /* 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -154,6 +154,23 @@ int         ffh_ctx_set_workspace(ffh_ctx* ctx, void* ws, size_t bytes);
 #define FFH_MATH_FP32_SPLIT_BF16X3 2
 #define FFH_BF16_MIN_DIM 128
 int         ffh_ctx_set_math_mode(ffh_ctx* ctx, int mode);
+/* bf16 MIRRORS for the tensor-op mode (no reference counterpart; the reference reaches its tensor cores through cuBLAS, which
+ * converts internally).  In FFH_MATH_TENSOR_OP_BF16 the GEMM operands are rounded to bfloat16 anyway; with fp32 operands in HBM
+ * the kernel is bound by bringing 4-byte elements on chip to use 2 of their bytes.  A caller may therefore give an fp32 buffer a
+ * bfloat16 twin of the same element layout (same leading dimensions, 2 bytes per element):
+ *   ffh_ctx_bf16_mirror_set(ctx, fp32_base, fp32_bytes, bf16_base)   registers [fp32_base, fp32_base + fp32_bytes) -> bf16_base
+ *                                                                    (bf16_base NULL: removes the registration); <= 32 regions
+ * From then on, in tensor-op mode only,
+ *   producers that write fp32 values into a registered region also write their bf16 roundings (nearest even) into the twin:
+ *     ffh_linear_fwd (y), ffh_linear_bwd / _ex (dx), when they run on the bf16 pipe (in_dim, out_dim >= FFH_BF16_MIN_DIM);
+ *     ffh_embedding_fwd / _multi (out); ffh_sgd_update / _ex and ffh_adam_update (w); ffh_convert_f32_to_bf16 (explicit);
+ *   the bf16-pipe GEMMs take an operand from its twin when BOTH operands of the GEMM lie in registered regions.
+ * The twin of an element is by construction the value the kernel would have rounded it to, so results are bit-identical with and
+ * without mirrors.  VALIDITY IS THE CALLER'S CONTRACT: register a region only if every writer of it is in the list above (or
+ * refresh it with ffh_convert_f32_to_bf16); the library does not track who else writes the fp32 buffer.  A backward call that
+ * applies a live activation derivative to dy in place (RELU / SIGMOID without FFH_LINEAR_DY_PREMASKED) does not read dy's twin. */
+int         ffh_ctx_bf16_mirror_set(ffh_ctx* ctx, const void* fp32_base, size_t fp32_bytes, void* bf16_base);
+int         ffh_convert_f32_to_bf16(ffh_ctx* ctx, void* dst_bf16, const float* src, int64_t count, ffh_stream s);
 /* on != 0: every weight / bias gradient is produced WITHOUT floating-point atomics -- no split-K over workgroups (one
  * workgroup owns an output element and adds its k-ordered sum once), no per-workgroup partials meeting in one address;
  * the one-launch skinny / pair / dX+dW forms that rely on such atomics report FFH_ERR_UNSUPPORTED or are bypassed.  Results
@@ -496,7 +513,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
  * FFModel shim and by tests/test_abi_symbols.py). */
 #define FFH_API_LIST(X) \
   X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) X(ffh_ctx_default) \
-  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) \
+  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) X(ffh_ctx_bf16_mirror_set) X(ffh_convert_f32_to_bf16) \
   X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
   X(ffh_stream_create) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
   X(ffh_event_create) X(ffh_event_create_sync) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \

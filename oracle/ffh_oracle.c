@@ -77,6 +77,9 @@ int ffh_ctx_default(ffh_ctx** out) {          /* one library-owned ctx (the "dev
   return FFH_OK;
 }
 int ffh_ctx_destroy(ffh_ctx* c) { free(c); return FFH_OK; }
+/* bf16 twins are a bandwidth optimisation of the HIP library (the twin of x is bf16_round(x), which this oracle computes at
+ * the point of use): registrations are accepted and ignored; the explicit conversion is the rounding itself */
+int ffh_ctx_bf16_mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* twin) { (void)twin; return (c && base && bytes) ? FFH_OK : FFH_ERR_BAD_ARG; }
 const char* ffh_linear_last_route(const ffh_ctx* c) { (void)c; return "oracle"; }
 const char* ffh_last_error_string(const ffh_ctx* c) { return c ? c->err : "null ctx"; }
 int ffh_device_query(ffh_ctx* c, ffh_device_info* info) {
@@ -109,6 +112,13 @@ static inline float bf16_round(float v) {
   u &= 0xffff0000u;
   memcpy(&v, &u, 4);
   return v;
+}
+int ffh_convert_f32_to_bf16(ffh_ctx* c, void* dst, const float* src, int64_t n, ffh_stream s) {
+  (void)s;
+  if (!c || n < 0 || ((!dst || !src) && n)) return FFH_ERR_BAD_ARG;
+  uint16_t* d = (uint16_t*)dst;
+  for (int64_t i = 0; i < n; i++) { const float r = bf16_round(src[i]); uint32_t u; memcpy(&u, &r, 4); d[i] = (uint16_t)(u >> 16); }
+  return FFH_OK;
 }
 static inline int use_bf16(const ffh_ctx* c, int in, int out) {
   return c && c->math_mode == FFH_MATH_TENSOR_OP_BF16 && in >= FFH_BF16_MIN_DIM && out >= FFH_BF16_MIN_DIM;

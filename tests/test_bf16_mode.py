@@ -341,3 +341,91 @@ def test_dlrm_step_split_bf16x3_mode_matches_the_fp32_oracle_backend(hip, oracle
         app.close()
     for k in out["hip"]:
         np.testing.assert_allclose(out["hip"][k], out["cpu"][k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16 twins (ffh_ctx_bf16_mirror_set, ABI 6): in tensor-op mode a registered fp32 buffer has a bfloat16 twin that its writers
+# keep current and the bf16-pipe GEMMs read instead.  The twin of x is the value the kernel rounds x to anyway, so every result
+# must be BIT-identical with and without twins (fp32 outputs) -- only the weight gradient's atomic order may differ.
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,IN,OUT", [(4096, 1024, 1024), (2048, 512, 256), (8192, 3456, 1024), (4160, 3456, 1000), (576, 1024, 136)])
+def test_bf16_twins_give_the_same_bits_as_in_kernel_rounding(hip_bf16, B, IN, OUT):
+    import torch
+    hip = hip_bf16
+    dev = "cuda:0"
+    rng = np.random.default_rng(B + OUT)
+    x = torch.from_numpy(np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)).to(dev)
+    b = torch.from_numpy(rng.uniform(-1, 1, OUT).astype(np.float32)).to(dev)
+    gy = torch.from_numpy(rng.uniform(-1, 1, (B, OUT)).astype(np.float32)).to(dev)
+    route = lambda: hip.lib.ffh_linear_last_route(hip.ctx).decode()
+
+    def run(with_twins):
+        y = torch.full((B, OUT), 3.0, device=dev); dx = torch.full((B, IN), 9.0, device=dev)
+        dw = torch.zeros(OUT, IN, device=dev); db = torch.zeros(OUT, device=dev); dy = gy.clone()
+        tw = {}
+        if with_twins:
+            for name, t in (("x", x), ("w", w), ("y", y), ("dy", dy), ("dx", dx)):
+                tw[name] = torch.zeros(t.shape, dtype=torch.bfloat16, device=dev)
+                assert hip.lib.ffh_ctx_bf16_mirror_set(hip.ctx, t.data_ptr(), t.numel() * 4, tw[name].data_ptr()) == 0
+            hip.call("ffh_convert_f32_to_bf16", tw["x"], x, x.numel(), None)       # the producers of x, w, dy in a model
+            hip.call("ffh_convert_f32_to_bf16", tw["w"], w, w.numel(), None)
+            hip.call("ffh_convert_f32_to_bf16", tw["dy"], dy, dy.numel(), None)
+        hip.call("ffh_linear_fwd", x, IN, y, OUT, w, b, IN, OUT, B, capi.AC_MODE_RELU, None)
+        r_f = route()
+        flags = capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DY_PREMASKED | capi.LINEAR_DX_MASK_BY_X
+        hip.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy, OUT, w, dw, db, IN, OUT, B, capi.AC_MODE_RELU, flags, None, None)
+        r_b = route()
+        torch.cuda.synchronize()
+        if with_twins:
+            for t in (x, w, y, dy, dx):
+                assert hip.lib.ffh_ctx_bf16_mirror_set(hip.ctx, t.data_ptr(), t.numel() * 4, None) == 0
+        return y, dx, dw, db, tw, r_f, r_b
+
+    y0, dx0, dw0, db0, _, rf0, rb0 = run(False)
+    y1, dx1, dw1, db1, tw, rf1, rb1 = run(True)
+    # twins serve a GEMM whose reduction depth is a multiple of 64 (forward: IN, dX: OUT, dW: the batch); edge tiles in M / N are fine
+    want = (IN % 64 == 0, OUT % 64 == 0, B % 64 == 0)
+    tok = {t.split(" gemm")[0].split("linear_bwd ")[-1]: t for t in rb1.split(";")}
+    assert "twins" not in rf0 + rb0, (rf0, rb0)
+    assert ("twins" in rf1) == want[0] and ("twins" in tok["dx"]) == want[1] and ("twins" in tok["dw"]) == want[2], (rf1, rb1)
+    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)                       # same operands, same order: same bits
+    assert torch.equal(tw["y"], y1.to(torch.bfloat16)) and torch.equal(tw["dx"], dx1.to(torch.bfloat16))   # nearest-even, as torch rounds
+    assert torch.equal(tw["x"], x.to(torch.bfloat16))
+    mass = (gy.abs().double().T @ x.abs().double()).cpu().numpy()
+    np.testing.assert_array_less(np.abs((dw1 - dw0).cpu().numpy()), 2e-5 * mass + 1e-6)      # split-K atomics: order differs run to run
+    np.testing.assert_array_less(np.abs((db1 - db0).cpu().numpy()), 2e-5 * gy.abs().double().sum(0).cpu().numpy() + 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_dlrm_step_bf16_mode_twins_on_equals_twins_off(hip, monkeypatch):
+    """Whole model in tensor-op mode at the Terabyte widths (top 3456-1024-1024-512-256-1: every big layer reads twins, the gather
+    writes the twin of the Concat output, the optimizer the weights' twin), batch 4096, rows capped: three steps with the twins
+    against the same run with FFM_NO_BF16_TWINS=1 (operands rounded inside the kernels).  Identical arithmetic; the only
+    freedom is the atomic order of the weight gradients."""
+    import dlrm_helpers as H
+    from dlrm_flexflow_amd import ffmodel
+    rows = "-".join(str(min(r, 50000)) for r in [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155, 4, 976, 14,
+                                                 39979771, 25641295, 39664984, 585935, 12972, 108, 36])
+    args = ["--backend", capi.HIP_LIB_PATH, "-b", "4096", "--arch-sparse-feature-size", "128", "--arch-embedding-size", rows, "--arch-mlp-bot", "13-512-256-128",
+            "--arch-mlp-top", "3456-1024-1024-512-256-1", "--data-size", "4096", "--allow-tensor-op-math-conversion"]
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("FFM_NO_BF16_TWINS", "1")
+        else:
+            monkeypatch.delenv("FFM_NO_BF16_TWINS", raising=False)
+        app = ffmodel.DLRM(args)
+        app.warmup(); app.train_steps(3, trace=False); app.model.sync()
+        m = app.model
+        o = {f"{m.layer_name(l)}/{i}": m.parameter(l, i).get_weights() for l in range(m.num_layers) for i in range(m.layer_num_weights(l))}
+        o["pred"] = m.layer_output(m.num_layers - 1).get()
+        out.append(o)
+        app.close()
+    for k in out[0]:
+        g, e = out[0][k].astype(np.float64), out[1][k].astype(np.float64)
+        tight = np.abs(g - e) <= 2e-5 * np.abs(e) + 2e-6
+        assert tight.mean() >= 0.99, (k, float(tight.mean()))                  # a one-ulp dW difference can cross a bf16 rounding boundary downstream
+        np.testing.assert_allclose(g, e, rtol=2e-3, atol=2e-4, err_msg=k)
