@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random-shape check of ffh_linear_fwd / ffh_linear_bwd_ex on the GPU against the CPU oracle (test infrastructure):
-shapes drawn so that every kernel family of linear.hip is hit (LDS-DMA single / paired launches, register-staged tiles,
-skinny outputs), ragged sizes, strides, all flag combinations.  Usage: tools/fuzz_linear.py [cases] [seed] [math_mode]
+shapes drawn so that every kernel family of linear.hip / linear_sk.hip is hit (LDS-DMA single / paired launches, register-staged
+tiles, skinny outputs, the persistent stream-K kernels), ragged sizes, strides, all flag combinations; tolerance 1e-5 of the term
+mass (FUZZ_TOL overrides).  Usage: tools/fuzz_linear.py [cases] [seed] [math_mode]
 math_mode 1 (tensor-op bf16 operands): both sides run in that mode; 2 (fp32-accurate bf16x3 split): the GPU runs in it, the
 oracle computes in fp32 -- same tolerance either way."""
 import os, sys
@@ -15,24 +16,27 @@ hip = capi.load_hip(0)
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 math_mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+TOL = float(os.environ.get("FUZZ_TOL", "1e-5"))     # north_star: 1e-5 of the term mass
 assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, math_mode) == 0
 assert oracle.lib().lib.ffh_ctx_set_math_mode(oracle.lib().ctx, math_mode) == 0
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 def close(got, exp, mass, what):
-    tol = 2e-5 * mass + 1e-6
+    tol = TOL * mass + 1e-6
     bad = np.abs(got.astype(np.float64) - exp) > tol
     assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} off, worst {np.abs(got - exp).max():.3e} vs tol {tol.max():.3e}"
 worst = 0
 for case in range(ncases):
-    kind = rng.integers(0, 4)
+    kind = rng.integers(0, 5)
     if kind == 0:      # LDS-DMA territory, multiples of 4
         B = int(rng.integers(64, 3000)); IN = 4 * int(rng.integers(16, 200)); OUT = 4 * int(rng.integers(16, 200))
     elif kind == 1:    # anything goes (unaligned -> register-staged kernels)
         B = int(rng.integers(1, 600)); IN = int(rng.integers(1, 300)); OUT = int(rng.integers(5, 300))
     elif kind == 2:    # skinny outputs
         B = int(rng.integers(1, 5000)); OUT = int(rng.integers(1, 17)); IN = 4 * int(rng.integers(1, 256 if OUT <= 4 else 65))
-    else:              # wide and deep
+    elif kind == 3:    # wide and deep
         B = int(rng.integers(512, 4097)); IN = 4 * int(rng.integers(64, 300)); OUT = 4 * int(rng.integers(64, 300))
+    else:              # whole 128 x 128 x 64 tiles, enough of them: the persistent one-workgroup-per-CU kernels (linear_sk.hip)
+        B = 128 * int(rng.choice([32, 64, 96, 128])); IN = 128 * int(rng.integers(1, 9)); OUT = 128 * int(rng.integers(1, 9))
     if math_mode and kind != 2 and rng.integers(0, 4):   # mostly layers the bf16-pipe modes serve (both dims >= 128), any alignment
         IN = max(IN, 128) + int(rng.integers(0, 4)) * (kind == 1); OUT = max(OUT, 128) + int(rng.integers(0, 4)) * (kind == 1)
     act = int(rng.choice([capi.AC_MODE_NONE, capi.AC_MODE_RELU, capi.AC_MODE_SIGMOID]))
