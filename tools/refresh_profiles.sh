@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the judged artefacts under profiles/ on one GPU box.  Outputs land in gpurun_out/refresh/ with their final
-# names (r03_*); copy them into profiles/ afterwards.   gpurun --timeout 3000 -- 'bash tools/refresh_profiles.sh'
+# names (r03_*); copy them into profiles/ afterwards.   gpurun --timeout 3300 -- 'bash tools/refresh_profiles.sh'
 R=$(pwd); O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $R
 P=${P:-r03}
@@ -14,14 +14,15 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- p
 S=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp $S $O/${P}_bench_terabyte_kernel_stats.csv
 T=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python3 tools/trace_summary.py $T > $O/${P}_bench_terabyte_step_timeline.txt
-for k in emb_fwd_kernel emb_sgd_reduce_kernel radix_scatter_kernel "gemm_f32_kernel<128, 128, 16, true, true" "gemm_f32_kernel<128, 128, 16, true, false, false, false" "gemm_f32_kernel<128, 128, 16, false, false, false, true"; do
+for k in emb_fwd_kernel emb_sgd_reduce_kernel radix_scatter_kernel "gemm_sk_kernel<false, false, 0" "gemm_sk_kernel<false, true, 1" "gemm_sk_kernel<true, true, 3, true"; do
   python3 tools/kernel_avg.py $T "$k"
 done > $O/${P}_bench_terabyte_probe_averages.txt
 find $O/prof -name "*.csv" -size +10M -delete
 
 # 3. HBM traffic of the embedding kernels (two counter-only passes) and SQ counters of the step's kernels
 bash tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1; cp gpurun_out/pmc_traffic/pmc_traffic.json $O/${P}_pmc_traffic.json
-bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.json $O/${P}_pmc_sq_counters.json
+bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.json $O/${P}_pmc_sq_counters_step.json
+bash tools/pmc_gemm.sh > $O/pmc_gemm.log 2>&1; cp gpurun_out/pmc_gemm/summary.json $O/${P}_pmc_sq_counters.json
 
 # 4. the other workloads (one GPU)
 python3 bench.py --no-cpu-baseline --no-secondary --shim-flags=--allow-tensor-op-math-conversion 2>/dev/null | line > $O/${P}_bench_terabyte_bf16_mode.json
@@ -50,6 +51,10 @@ python3 tools/gemm_bf16_bench.py 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_mic
 # the lab binary is built here from its source (never committed)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_big_lab.hip -lrocblas -o tools/lab/gemm_big_lab 2> $O/lab_build.err && timeout 300 tools/lab/gemm_big_lab 32768 1024 3456 > $O/${P}_lab_gemm_big.txt 2>&1
 python3 tools/microbench.py emb > $O/${P}_microbench_embedding.txt 2>&1
+# the stand-alone lab of the persistent fp32 GEMM (built here from its source), with its ablation modes
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_sk_lab.hip -o tools/lab/gemm_sk_lab 2>> $O/lab_build.err && { timeout 120 tools/lab/gemm_sk_lab 32768 1024 1024 1 256 1; timeout 120 tools/lab/gemm_sk_lab 32768 3456 1024 1 256 0; } > $O/${P}_lab_gemm_sk.txt 2>&1
+# tensor-op mode: one big layer with and without bf16 twins
+{ python3 tools/bf16_twin_probe.py 32768x3456x1024; python3 tools/bf16_twin_probe.py 32768x1024x1024; } 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_bf16_twins.txt
 # SQ counters of the split-bf16x3 forward GEMM alone (MFMA busy cycles against GRBM_GUI_ACTIVE: what bounds that kernel)
 bash tools/pmc_x3.sh 2 > $O/pmc_x3.log 2>&1; cp gpurun_out/pmc_x3/summary.json $O/${P}_pmc_split_bf16x3_gemm.json
 
