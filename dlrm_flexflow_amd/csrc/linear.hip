@@ -1476,7 +1476,10 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
     return FFH_OK;
   }
   static const int no_thin = getenv("FFH_NO_THIN") ? atoi(getenv("FFH_NO_THIN")) : 0;   // A/B switch (tools/ab.sh)
-  if (!no_thin && in <= 16 && out >= 64 && out % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)y | (uintptr_t)(bias ? bias : w)) & 15) == 0 && batch >= 1024) {
+  // (rows kernel from 8192 samples up: it keeps 128 rows per workgroup to amortise its weight registers, so a 2048-sample launch
+  //  would be 32 workgroups -- the MFMA form below is the faster one there: Kaggle step 208 vs 185 us)
+  static const int thin_rows_min = getenv("FFH_THIN_ROWS_MIN_BATCH") ? atoi(getenv("FFH_THIN_ROWS_MIN_BATCH")) : 8192;   // A/B switch
+  if (!no_thin && in <= 16 && out >= 64 && out % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)y | (uintptr_t)(bias ? bias : w)) & 15) == 0 && batch >= thin_rows_min) {
     hipLaunchKernelGGL(linear_thin_fwd_rows_kernel, dim3((unsigned)((batch + kThinRowsPerWg - 1) / kThinRowsPerWg), (unsigned)((out + 255) / 256)), dim3(256), 0,
                        as_stream(s), x, ldx, y, ldy, w, bias, in, out, batch, act);
     FFH_LAUNCH_CHECK(c, "linear_thin_fwd_rows_kernel");

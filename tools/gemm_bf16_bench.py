@@ -6,7 +6,7 @@ import torch
 from dlrm_flexflow_amd import capi
 hip = capi.load_hip(0)
 def timeit(fn, iters=10):
-    for _ in range(2): fn()
+    for _ in range(20): fn()      # the clock needs tens of milliseconds of load to settle
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
