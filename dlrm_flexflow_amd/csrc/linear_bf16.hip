@@ -591,6 +591,11 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     }
   }
   if constexpr (!MASK_A) {
+    if (g.A16) {      // big outputs: the LDS-DMA kernel (linear_bf16_dma.hip)
+      const int rc = launch_gemm_bf16_dma(c, g, AKC && BKC ? BF16_FORM_FWD : (AKC ? BF16_FORM_DX : BF16_FORM_DW), s, name);
+      if (rc < 0) return rc;
+      if (rc > 0) return FFH_OK;
+    }
     if (g.A16 && big) {
       auto kernw = gemm_bf16_kernel<AKC, BKC, false, 256, 256, 128, true>;
       static const bool okw = glds_set_lds(kernw, bf_lds_bytes(256, 256));

@@ -86,6 +86,9 @@ enum { BF16_FORM_FWD = 0,        // A = x (k-contiguous), B = w (k-contiguous)
        BF16_FORM_DX = 2,         // A = dy (k-contiguous), B = w (rows-are-k)
        BF16_FORM_DX_MASK = 3 };  // ... dy read through relu'(act_y)
 int launch_gemm_bf16_form(ffh_ctx* c, GemmArgs& g, int form, ffh_stream s, const char* name);
+// Tensor-op mode, operands with bf16 twins, outputs of at least one 256 x 256 tile per CU (linear_bf16_dma.hip): LDS-DMA operand
+// path, two wave groups alternating on the matrix pipe.  g.A16 / g.B16 / g.C16 as launch_gemm_bf16_form found them.
+int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name);     // 1 launched, 0 not served, < 0 error
 
 // The persistent one-workgroup-per-CU fp32 kernels for the big aligned layers (linear_sk.hip): forward (bias + activation),
 // data gradient (store / add, optional relu'-of-the-layer-below mask), weight gradient (stream-K, atomics).

@@ -349,7 +349,7 @@ def test_dlrm_step_split_bf16x3_mode_matches_the_fp32_oracle_backend(hip, oracle
 # must be BIT-identical with and without twins (fp32 outputs) -- only the weight gradient's atomic order may differ.
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,IN,OUT", [(4096, 1024, 1024), (2048, 512, 256), (8192, 3456, 1024), (4160, 3456, 1000), (576, 1024, 136)])
+@pytest.mark.parametrize("B,IN,OUT", [(4096, 1024, 1024), (2048, 512, 256), (8192, 3456, 1024), (4160, 3456, 1000), (576, 1024, 136), (16640, 1024, 1096)])
 def test_bf16_twins_give_the_same_bits_as_in_kernel_rounding(hip_bf16, B, IN, OUT):
     import torch
     hip = hip_bf16
@@ -390,12 +390,77 @@ def test_bf16_twins_give_the_same_bits_as_in_kernel_rounding(hip_bf16, B, IN, OU
     tok = {t.split(" gemm")[0].split("linear_bwd ")[-1]: t for t in rb1.split(";")}
     assert "twins" not in rf0 + rb0, (rf0, rb0)
     assert ("twins" in rf1) == want[0] and ("twins" in tok["dx"]) == want[1] and ("twins" in tok["dw"]) == want[2], (rf1, rb1)
-    assert torch.equal(y0, y1) and torch.equal(dx0, dx1)                       # same operands, same order: same bits
+    # same operands; the same kernel structure gives the same bits, the LDS-DMA kernel (outputs of >= one 256 x 256 tile per CU)
+    # sums in its own order: 1e-5 of the term mass
+    ymass = (x.abs().double() @ w.abs().double().T + b.abs().double()).cpu().numpy()
+    dxmass = (gy.abs().double() @ w.abs().double()).cpu().numpy()
+    if "bf16_dma" in rf1: np.testing.assert_array_less(np.abs((y1 - y0).cpu().numpy()), 1e-5 * ymass + 1e-6)
+    else: assert torch.equal(y0, y1)
+    if "bf16_dma" in tok["dx"]: np.testing.assert_array_less(np.abs((dx1 - dx0).cpu().numpy()), 1e-5 * dxmass + 1e-6)
+    else: assert torch.equal(dx0, dx1)
     assert torch.equal(tw["y"], y1.to(torch.bfloat16)) and torch.equal(tw["dx"], dx1.to(torch.bfloat16))   # nearest-even, as torch rounds
     assert torch.equal(tw["x"], x.to(torch.bfloat16))
     mass = (gy.abs().double().T @ x.abs().double()).cpu().numpy()
     np.testing.assert_array_less(np.abs((dw1 - dw0).cpu().numpy()), 2e-5 * mass + 1e-6)      # split-K atomics: order differs run to run
     np.testing.assert_array_less(np.abs((db1 - db0).cpu().numpy()), 2e-5 * gy.abs().double().sum(0).cpu().numpy() + 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("B,IN,OUT", [(32768, 3456, 1024), (32768, 1024, 1024), (32768, 1024, 512), (16704, 1088, 1344)])
+def test_bf16_dma_kernel_layers_of_the_benched_step_vs_emulation(hip_bf16, B, IN, OUT):
+    """The LDS-DMA kernel (csrc/linear_bf16_dma.hip) on the layers it serves in the benched step (batch 32768, twins registered as
+    the model registers them) and on a ragged shape (edge tiles in rows and columns, partial last round): forward with bias +
+    relu, then the model's backward form (premasked dy, dX stored and masked by relu'(x), weight gradient on its own stream)
+    against float64 sums over the bf16-rounded operands (the numpy restatement the oracle's tensor-op mode is pinned to in
+    test_oracle_bf16_mode_matches_numpy_emulation) at 1e-5 of the term mass; the twins of y and dX are the nearest-even
+    roundings of the fp32 results; the route names the kernel for all three GEMMs."""
+    import torch
+    hip = hip_bf16
+    dev = "cuda:0"
+    rng = np.random.default_rng(B + IN + OUT)
+    x = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    xb, wb = bf16_round(x).astype(np.float64), bf16_round(w).astype(np.float64)
+    y_e = np.maximum(xb @ wb.T + b, 0)
+    dy_e = np.where(y_e.astype(np.float32) > 0, gy, 0).astype(np.float32)      # premasked by the layer above
+    dB = bf16_round(dy_e).astype(np.float64)
+    dw_e, db_e = dB.T @ xb, dy_e.astype(np.float64).sum(0)
+    dx_e = np.where(x > 0, dB @ wb, 0)
+    ax, aw, ad = np.abs(x).astype(np.float32), np.abs(w).astype(np.float32), np.abs(dy_e)
+    xd, wd, bd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
+    y = torch.full((B, OUT), 3.0, device=dev); dx = torch.full((B, IN), 9.0, device=dev)
+    dw = torch.zeros(OUT, IN, device=dev); db = torch.zeros(OUT, device=dev); dy = torch.from_numpy(dy_e).to(dev)
+    tw = {}
+    for name, t in (("x", xd), ("w", wd), ("y", y), ("dy", dy), ("dx", dx)):
+        tw[name] = torch.zeros(t.shape, dtype=torch.bfloat16, device=dev)
+        assert hip.lib.ffh_ctx_bf16_mirror_set(hip.ctx, t.data_ptr(), t.numel() * 4, tw[name].data_ptr()) == 0
+    try:
+        for name, t in (("x", xd), ("w", wd), ("dy", dy)):
+            hip.call("ffh_convert_f32_to_bf16", tw[name], t, t.numel(), None)
+        hip.call("ffh_linear_fwd", xd, IN, y, OUT, wd, bd, IN, OUT, B, capi.AC_MODE_RELU, None)
+        r_f = hip.lib.ffh_linear_last_route(hip.ctx).decode()
+        flags = capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DY_PREMASKED | capi.LINEAR_DX_MASK_BY_X
+        s2 = torch.cuda.Stream()
+        hip.call("ffh_linear_bwd_ex", xd, IN, dx, IN, y, OUT, dy, OUT, wd, dw, db, IN, OUT, B, capi.AC_MODE_RELU, flags, None, s2.cuda_stream)
+        r_b = hip.lib.ffh_linear_last_route(hip.ctx).decode()
+        torch.cuda.synchronize()
+    finally:
+        for t in (xd, wd, y, dy, dx):
+            assert hip.lib.ffh_ctx_bf16_mirror_set(hip.ctx, t.data_ptr(), t.numel() * 4, None) == 0
+    print("routes:", r_f, "|", r_b)
+    assert "bf16_dma_256x256_twins" in r_f and r_b.count("bf16_dma_256x256_twins") == 2, (r_f, r_b)
+    def close(got, exp, mass, what):
+        bad = np.abs(got.astype(np.float64) - exp) > 1e-5 * mass + 1e-6
+        assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} off, worst {np.abs(got - exp).max():.3e}"
+    yh = y.cpu().numpy()
+    close(yh, y_e, (ax @ aw.T).astype(np.float64) + np.abs(b), "y")
+    close(dx.cpu().numpy(), dx_e, (ad @ aw).astype(np.float64), "dx")
+    close(dw.cpu().numpy(), dw_e, (ad.T @ ax).astype(np.float64), "dw")
+    close(db.cpu().numpy(), db_e, ad.astype(np.float64).sum(0), "db")
+    assert torch.equal(tw["y"], y.to(torch.bfloat16)) and torch.equal(tw["dx"], dx.to(torch.bfloat16))
 
 
 @pytest.mark.gpu
