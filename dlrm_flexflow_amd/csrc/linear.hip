@@ -1619,7 +1619,10 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       FFH_HIP_TRY(c, hipStreamWaitEvent(as_stream(sw_), c->ev_fork, 0));
     }
     if (do_dw) {
-      if (!separate) { const int rc = act_pass(sw_, act); if (rc) return rc; }          // relu: mask written back in place (idempotent); db
+      // no activation gradient to apply (premasked dy / no activation): the pass would only sum db -- the LDS-DMA weight-gradient
+      // kernel does that itself from the fp32 dy where it serves the layer
+      const bool db_only = !separate && act == FFH_AC_MODE_NONE && db != nullptr;
+      if (!separate && !db_only) { const int rc = act_pass(sw_, act); if (rc) return rc; }          // relu: mask written back in place (idempotent); db
       GemmArgs gw{};
       gw.A = dy; gw.sAm = 1; gw.sAk = lddy;
       gw.B = x; gw.sBn = 1; gw.sBk = ldx;
@@ -1627,8 +1630,10 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       gw.M = out; gw.N = in; gw.K = (int)batch;
       gw.epi = EPI_ATOMIC; gw.act = FFH_AC_MODE_NONE;
       gw.a_not_twinned = act != FFH_AC_MODE_NONE;       // a live activation gradient rewrote dy in place: its bf16 twin is stale
+      if (db_only) gw.db = db;
       const int rc = launch_gemm_bf16_form(c, gw, BF16_FORM_DW, sw_, "linear_bwd dw gemm (bf16)");
       if (rc) return rc;
+      if (db_only && !gw.db_done) { const int rc2 = act_pass(sw_, act); if (rc2) return rc2; }
     }
     if (dx && do_dx) {
       GemmArgs gx{};

@@ -594,7 +594,7 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     if (g.A16) {      // big outputs: the LDS-DMA kernel (linear_bf16_dma.hip)
       const int rc = launch_gemm_bf16_dma(c, g, AKC && BKC ? BF16_FORM_FWD : (AKC ? BF16_FORM_DX : BF16_FORM_DW), s, name);
       if (rc < 0) return rc;
-      if (rc > 0) return FFH_OK;
+      if (rc > 0) { if (g.db && !AKC && !BKC) g.db_done = 1; return FFH_OK; }
     }
     if (g.A16 && big) {
       auto kernw = gemm_bf16_kernel<AKC, BKC, false, 256, 256, 128, true>;

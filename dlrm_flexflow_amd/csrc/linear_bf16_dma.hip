@@ -60,6 +60,9 @@ struct DmaArgs {
   float* C; unsigned short* C16;
   const float* bias;           // FWD: per-column bias or null
   const float* mask;           // DX: C = mask[m][n] > 0 ? v : 0 (relu' of the layer below) or null
+  const float* Af32;           // DW with db: the fp32 matrix behind A (same strides)
+  float*       db;             // DW: db[m] += sum_k A(k, m) over this workgroup's share of its k-slice, from the fp32 values
+                               //     [ref: src/ops/linear.cu:644-651], or null
   int64_t lda, ldb, ldc, ldmask;
   int M, N, K;
   int act;                     // FWD
@@ -172,6 +175,34 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma_kernel(const DmaArgs g) 
 
   // ---- prologue: k-tile 0 and the first two units of k-tile 1 ----
   stage(DM_BLO, 0); stage(DM_ALO, 0); stage(DM_BHI, 0); stage(DM_AHI, 0); stage(DM_BLO, 1); stage(DM_ALO, 1);
+  if constexpr (EPI == DM_EPI_DW) {
+    if (g.db) {
+      // bias gradient = column sums of the fp32 dy (the bf16 twin would not do: the oracle sums fp32 values).  The k-tiles of this
+      // k-slice are dealt round-robin to the tile columns, so every (k-tile, 256 rows of A^T) block is summed by exactly one
+      // workgroup: 64 x 256 floats per block, 8 row groups x 64 column quads, then across the row groups through LDS.  While the
+      // prologue's DMA pieces are in flight.
+      const int cg = tid & 63, rg = tid >> 6;
+      const int col = m0 + 4 * cg;
+      f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (col < g.M)
+        for (int t = kt0 + (int)bx; t < kt1; t += (int)nbx) {
+          const float* p = g.Af32 + ((int64_t)t * DM_BK + rg * 8) * g.lda + col;
+#pragma unroll
+          for (int r = 0; r < 8; r++) sum += *reinterpret_cast<const f32x4*>(p + (int64_t)r * g.lda);
+        }
+      f32x4* red = reinterpret_cast<f32x4*>(dm_lds + 2 * DM_BUF);
+      red[rg * 64 + cg] = sum;
+      __syncthreads();
+      if (tid < 256) {
+        const float* rf = reinterpret_cast<const float*>(red);
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; r++) v += rf[r * 256 + tid];
+        if (m0 + tid < g.M) atomicAdd(g.db + m0 + tid, v);
+      }
+      __syncthreads();
+    }
+  }
   DM_WAIT_VM(8);          // B-lo(0), A-lo(0) have landed
   DM_BARRIER();
   DM_FENCE();
@@ -312,6 +343,7 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
   if ((((uintptr_t)g.A16 | (uintptr_t)g.B16 | (uintptr_t)g.C) & 15) || ((uintptr_t)g.C16 & 7)) return 0;
   if (g.bias && ((uintptr_t)g.bias & 15)) return 0;
   if (g.mask && ((((uintptr_t)g.mask) & 15) || g.ldmask % 4)) return 0;
+  if (form == BF16_FORM_DW && g.db && ((((uintptr_t)g.A) & 15) || g.M % 4)) return 0;
   const int64_t a_bytes = ((akr ? (int64_t)(g.K - 1) : (int64_t)(g.M - 1)) * lda + (akr ? g.M : g.K)) * 2;
   const int64_t b_bytes = ((bkr ? (int64_t)(g.K - 1) : (int64_t)(g.N - 1)) * ldb + (bkr ? g.N : g.K)) * 2;
   if (a_bytes >= (1LL << 31) || b_bytes >= (1LL << 31)) return 0;              // 32-bit buffer offsets, with room for the run-ahead
@@ -339,6 +371,7 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
   DmaArgs a{};
   a.A = g.A16; a.B = g.B16; a.C = g.C; a.C16 = form == BF16_FORM_DW ? nullptr : g.C16;
   a.bias = form == BF16_FORM_FWD ? g.bias : nullptr; a.mask = form == BF16_FORM_DX ? g.mask : nullptr;
+  a.Af32 = g.A; a.db = form == BF16_FORM_DW ? g.db : nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = g.ldc; a.ldmask = g.ldmask;
   a.M = g.M; a.N = g.N; a.K = g.K; a.act = g.act; a.add = g.epi == EPI_ADD; a.splitk = splitk;
   a.a_bytes = (unsigned)a_bytes; a.b_bytes = (unsigned)b_bytes;

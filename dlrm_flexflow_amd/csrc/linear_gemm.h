@@ -40,6 +40,7 @@ struct GemmArgs {
   const unsigned short* B16;
   unsigned short*       C16;
   int                   a_not_twinned;   // the caller changed A in place without its twin (live activation gradient): do not read A's twin
+  int                   db_done;         // out: the bf16-pipe weight-gradient launch also produced db (asked for by db != null, fuse == 0)
   // persistent launch: the (x, y, z) tile space; the launch is then a 1-D grid of fewer workgroups, each walking tiles
   // blockIdx.x, blockIdx.x + gridDim.x, ...  (tnx == 0: one workgroup per tile, tile space = the 3-D grid)
   unsigned tnx, tny, tnz;
