@@ -1065,6 +1065,7 @@ struct SkinnyBwdArgs {
   int do_db, do_dw, do_dx, dx_overwrite, mask_by_x;
   // MSE loss step folded in (ffh_linear_bwd_mse): dy is not read but made here from y and label; metrics as metrics_kernel
   const float* label;  float loss_scale;  ffh_perf_metrics* perf;  int metrics_flags;
+  unsigned short* dx16;       // tensor-op mode: the bf16 twin of dx (ffh_ctx_bf16_mirror_set), written beside it, or null
 };
 
 // NC: 16-byte column chunks per lane (in <= 256 * NC), NO: output slots kept in registers (out <= NO),
@@ -1205,6 +1206,11 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
           float4* p = reinterpret_cast<float4*>(a.dx + (b0 + r) * a.lddx) + ch;
           if (!a.dx_overwrite) { const float4 q = *p; v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
           *p = v;
+          if (a.dx16) {
+            typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+            const bf16x4_t t = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+            *reinterpret_cast<bf16x4_t*>(a.dx16 + (b0 + r) * a.lddx + 4 * ch) = t;
+          }
         }
       }
     }
@@ -1573,6 +1579,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     a.do_dw = do_dw; a.do_dx = do_dx && dx != nullptr;
     a.dx_overwrite = (flags & FFH_LINEAR_DX_OVERWRITE) ? 1 : 0;
     a.mask_by_x = mask_by_x ? 1 : 0;
+    a.dx16 = a.do_dx ? ffh_mirror_of(c, dx, (size_t)((batch - 1) * lddx + in) * 4) : nullptr;      // tensor-op mode: the twin of dx, for the layer below
     if (label) {
       if (only_dx || only_dw || premasked || out > kSkinnyMaxOut) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: not a whole one-launch layer");
       a.label = label; a.loss_scale = loss_scale; a.perf = perf; a.metrics_flags = metrics_flags;

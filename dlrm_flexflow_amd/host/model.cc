@@ -1704,7 +1704,12 @@ void FFModel::allocate() {
       for (Op* q : layers)
         for (int i = 0; i < q->numInputs; i++)
           if (q->inputs[i].impl == im) { ncons++; only = q->op_type == OP_LINEAR ? static_cast<const Linear*>(q) : nullptr; }
-      if (ncons == 1 && only && twin_linear(only) && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange)
+      // (... or the one-launch backward of a layer with <= 4 outputs, which writes the twin of its data gradient too: the
+      //  256 -> 1 layer on top of the Terabyte MLP, whose input gradient is the 512 -> 256 layer's dy)
+      auto skinny_twin = [&](const Linear* l) {
+        return l && l->out_channels <= 4 && l->in_channels >= FFH_BF16_MIN_DIM && l->in_channels <= 1024 && l->in_channels % 4 == 0 && !config.deterministic;
+      };
+      if (ncons == 1 && only && (twin_linear(only) || skinny_twin(only)) && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange)
         reg(im->grad, im->bytes, (char*)grad_twin + ((const char*)im->grad - act_grad_slab) / 2);
     }
   }

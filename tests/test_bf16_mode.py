@@ -464,6 +464,47 @@ def test_bf16_dma_kernel_layers_of_the_benched_step_vs_emulation(hip_bf16, B, IN
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("IN,OUT,label", [(256, 1, True), (256, 1, False), (512, 4, False)])
+def test_one_launch_backward_of_a_skinny_layer_writes_the_twin_of_its_data_gradient(hip_bf16, oracle, IN, OUT, label):
+    """The 256 -> 1 layer on top of the Terabyte MLP stays fp32 in tensor-op mode (out < 128), but its input gradient is the
+    dy of the 512 -> 256 layer below, which reads bf16: the one-launch backward (with and without the loss step folded in)
+    writes the registered twin of dX beside dX -- the nearest-even rounding of exactly the fp32 values it stores, which
+    themselves equal the oracle's."""
+    import torch
+    hip = hip_bf16
+    dev = "cuda:0"
+    B = 4100
+    rng = np.random.default_rng(IN + OUT)
+    x = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    y = oracle.linear_fwd(x, w, None, capi.AC_MODE_SIGMOID if label else capi.AC_MODE_NONE)
+    gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
+    lab = rng.integers(0, 2, (B, OUT)).astype(np.float32)
+    xd, wd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(y).to(dev)
+    dx = torch.full((B, IN), 9.0, device=dev); dw = torch.zeros(OUT, IN, device=dev); db = torch.zeros(OUT, device=dev)
+    dy = torch.from_numpy(gy).to(dev)
+    tw = torch.zeros(B, IN, dtype=torch.bfloat16, device=dev)
+    assert hip.lib.ffh_ctx_bf16_mirror_set(hip.ctx, dx.data_ptr(), dx.numel() * 4, tw.data_ptr()) == 0
+    flags = capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DX_MASK_BY_X
+    try:
+        if label:
+            perf = torch.zeros(64, dtype=torch.uint8, device=dev)
+            hip.call("ffh_linear_bwd_mse", xd, IN, dx, IN, yd, OUT, dy, OUT, wd, dw, db, IN, OUT, B, capi.AC_MODE_SIGMOID, flags,
+                     torch.from_numpy(lab).to(dev), 1.0 / B, perf, 0, None)
+        else:
+            hip.call("ffh_linear_bwd_ex", xd, IN, dx, IN, yd, OUT, dy, OUT, wd, dw, db, IN, OUT, B, capi.AC_MODE_NONE, flags, None, None)
+        assert "skinny" in hip.lib.ffh_linear_last_route(hip.ctx).decode()
+        torch.cuda.synchronize()
+    finally:
+        assert hip.lib.ffh_ctx_bf16_mirror_set(hip.ctx, dx.data_ptr(), dx.numel() * 4, None) == 0
+    assert torch.equal(tw, dx.to(torch.bfloat16))
+    if not label:
+        dx_e = oracle.linear_bwd_ex(x, y, gy, w, capi.AC_MODE_NONE, flags, dx0=None)[0]
+        mass = np.abs(gy).astype(np.float64) @ np.abs(w).astype(np.float64)
+        assert np.all(np.abs(dx.cpu().numpy().astype(np.float64) - dx_e) <= 1e-5 * mass + 1e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_dlrm_step_bf16_mode_twins_on_equals_twins_off(hip, monkeypatch):
     """Whole model in tensor-op mode at the Terabyte widths (top 3456-1024-1024-512-256-1: every big layer reads twins, the gather
