@@ -24,9 +24,11 @@
 //         fragment is two ds_read_b64_tr_b16 (4 k x 16 columns each, transposed on the way out).
 //   * Rows / columns beyond the matrix: the buffer descriptor ends with the operand, so loads past it return 0 and touch
 //     nothing; columns past N of a rows-are-k operand read the next row's values into accumulators nobody stores.
-//   * Epilogue through a per-wave LDS block (16 rows x 32 columns), so that a store covers 8 rows x 128 contiguous bytes and an
-//     atomic instruction 2 rows x 128: bias + activation (forward), relu'(x) mask and store / add (dX), atomics onto the
-//     k-slices' common tile (dW); the fp32 result and, where the output has a twin, its bf16 rounding.
+//   * Epilogue through LDS (all of it is free by then: 20 KB per wave, half of the wave's accumulators at a time), so that a store
+//     covers 8 rows x 128 contiguous bytes and an atomic instruction 2 rows x 128: bias + activation (forward), relu'(x) mask
+//     and store / add (dX), atomics onto the k-slices' common tile (dW); the fp32 result and, where the output has a twin, its
+//     bf16 rounding.  (A first version went block by block through 4 KB per wave -- 32 dependent LDS round trips and 32
+//     dependent bias loads: 13 us per tile where this one takes ~6.)
 // The main loop runs at ~1.4 PFLOP/s (32768 x 3456 x 1024); what a launch adds to that is its output traffic (fp32 + bf16:
 // 6 bytes per element at the HBM write rate), which this structure does not overlap with the MFMAs.  Developed in
 // tools/lab/gemm_bf16_lab.hip (stand-alone, with ablation modes).
@@ -47,10 +49,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DM_BM = 256, DM_BN = 256, DM_BK = 64;
 constexpr int DM_UNIT = 16384, DM_BUF = 4 * DM_UNIT;
-constexpr int DM_LDS = 2 * DM_BUF + 8 * 4096;          // two buffers + a 4 KB epilogue block per wave = 160 KB
+constexpr int DM_LDS = 2 * DM_BUF + 32768;             // two buffers + 32 KB (bias-gradient reduction); the epilogue reuses all 160 KB
 constexpr int DM_ALO = 0, DM_AHI = 1, DM_BLO = 2, DM_BHI = 3;
 
 enum { DM_EPI_FWD = 0, DM_EPI_DX = 1, DM_EPI_DW = 2 };
@@ -60,6 +63,8 @@ struct DmaArgs {
   float* C; unsigned short* C16;
   const float* bias;           // FWD: per-column bias or null
   const float* mask;           // DX: C = mask[m][n] > 0 ? v : 0 (relu' of the layer below) or null
+  const unsigned short* mask16;   // ... the bf16 twin of mask, read instead where there is one (half the bytes; same sign as the
+                               //     fp32 value except 0 < x < 2^-134, which rounds to +0: stated in ff_hip.h)
   const float* Af32;           // DW with db: the fp32 matrix behind A (same strides)
   float*       db;             // DW: db[m] += sum_k A(k, m) over this workgroup's share of its k-slice, from the fp32 values
                                //     [ref: src/ops/linear.cu:644-651], or null
@@ -173,6 +178,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma_kernel(const DmaArgs g) 
     __builtin_amdgcn_s_setprio(0);
   };
 
+  f32x4 bias_r[4];          // FWD: the bias of this lane's four column quads
+#pragma unroll
+  for (int tn = 0; tn < 4; tn++) {
+    bias_r[tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == DM_EPI_FWD) {
+      const int cc = n0 + (tn >> 1) * 128 + wc * 32 + (tn & 1) * 16 + 4 * q;
+      if (g.bias && cc < g.N) bias_r[tn] = *reinterpret_cast<const f32x4*>(g.bias + cc);
+    }
+  }
+
   // ---- prologue: k-tile 0 and the first two units of k-tile 1 ----
   stage(DM_BLO, 0); stage(DM_ALO, 0); stage(DM_BHI, 0); stage(DM_AHI, 0); stage(DM_BLO, 1); stage(DM_ALO, 1);
   if constexpr (EPI == DM_EPI_DW) {
@@ -269,47 +284,79 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma_kernel(const DmaArgs g) 
   }
   if (grp == 0) DM_BARRIER();
   DM_WAIT_VM(0);
+  DM_BARRIER();           // every wave is past its last fragment read and its last DMA piece has landed: all of LDS is free
 
-  // ---- epilogue: lane (c, q) holds C[row(tm) + c][col(tn) + 4 q + {0..3}]; two neighbouring fragments (32 columns) go through
-  //      the wave's own LDS block (rows padded to 144 B) and leave as whole 128-byte lines ----
-  char* blk = dm_lds + 2 * DM_BUF + wave * 4096;
+  // ---- epilogue: lane (c, q) holds C[row(tm) + c][col(tn) + 4 q + {0..3}].  Half of the wave's accumulators at a time (64 rows
+  //      x 64 columns) goes through the wave's own 20 KB of LDS -- 16 writes, then rows back out: a store covers 8 rows x 128
+  //      contiguous bytes (whole lines), an atomic instruction 2 rows x 128 (4-byte pieces 16 bytes apart run ~10x slower at
+  //      the memory-side adders).  Rows padded to 272 B: conflict-free writes.
+  constexpr int EP_LD = 272;
+  char* blk = dm_lds + wave * 20480;
 #pragma unroll
-  for (int tm = 0; tm < 8; tm++)
+  for (int half = 0; half < 2; half++) {
+    const int rowb = m0 + half * 128 + grp * 64;          // tile row of the block's first row
+    // the relu' mask of the rows this lane will store (dX; from the twin of x where it has one), fetched ahead of
+    // the LDS round trip: rows p = 0..3 before the writes, p = 4..7 behind them
+    f32x4 mkA[8], mkB[8];
+    s16x4 mhA[8], mhB[8];
+    auto mask_load = [&](f32x4 (&mk)[8], s16x4 (&mh)[8], const int p0) {
+      if constexpr (EPI == DM_EPI_DX) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int row0 = m0 + (tm >= 4 ? 128 : 0) + grp * 64 + (tm & 3) * 16;
-      const int col0 = n0 + h * 128 + wc * 32;
+        for (int e = 0; e < 8; e++) {
+          const int p = p0 + (e >> 1), h = e & 1;
+          const int row = rowb + p * 8 + (lane >> 3), col = n0 + h * 128 + wc * 32 + (lane & 7) * 4;
+          const bool in = row < g.M && col < g.N;
+          mk[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (g.mask16) {
+            mh[e] = in ? *reinterpret_cast<const s16x4*>(g.mask16 + (int64_t)row * g.ldmask + col) : s16x4{0, 0, 0, 0};
+          } else if (g.mask) {
+            if (in) mk[e] = *reinterpret_cast<const f32x4*>(g.mask + (int64_t)row * g.ldmask + col);
+          }
+        }
+      }
+    };
+    mask_load(mkA, mhA, 0);
 #pragma unroll
-      for (int t2 = 0; t2 < 2; t2++) {
-        f32x4 v = acc[tm][2 * h + t2];
+    for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+      for (int tn = 0; tn < 4; tn++) {
+        f32x4 v = acc[4 * half + tm][tn];
         if constexpr (EPI == DM_EPI_FWD) {
-          const int cc = col0 + t2 * 16 + 4 * q;
-          if (g.bias && cc < g.N) v += *reinterpret_cast<const f32x4*>(g.bias + cc);
+          v += bias_r[tn];
           v.x = act_apply(v.x, g.act); v.y = act_apply(v.y, g.act); v.z = act_apply(v.z, g.act); v.w = act_apply(v.w, g.act);
         }
-        *reinterpret_cast<f32x4*>(blk + c * 144 + (t2 * 16 + 4 * q) * 4) = v;
+        *reinterpret_cast<f32x4*>(blk + (tm * 16 + c) * EP_LD + ((tn >> 1) * 32 + (tn & 1) * 16 + 4 * q) * 4) = v;
       }
-      // the wave's own block: no barrier, the compiler orders the LDS accesses
-      if constexpr (EPI == DM_EPI_DW) {
-        const int rr = lane >> 5, rc = lane & 31;
-        const int col = col0 + rc;
+    // the wave's own block: no barrier, LDS operations of one wave execute in order
+    if constexpr (EPI == DM_EPI_DW) {
+      const int rr = lane >> 5, rc = lane & 31;
 #pragma unroll
-        for (int p = 0; p < 8; p++) {
-          const float v = *reinterpret_cast<const float*>(blk + (2 * p + rr) * 144 + rc * 4);
-          const int row = row0 + 2 * p + rr;
+      for (int h = 0; h < 2; h++) {
+        const int col = n0 + h * 128 + wc * 32 + rc;
+#pragma unroll 8
+        for (int p = 0; p < 32; p++) {
+          const float v = *reinterpret_cast<const float*>(blk + (2 * p + rr) * EP_LD + (h * 32 + rc) * 4);
+          const int row = rowb + 2 * p + rr;
           if (row < g.M && col < g.N) atomicAdd(g.C + (int64_t)row * g.ldc + col, v);
         }
-      } else {
-        const int rr = lane >> 3, rc = lane & 7;
+      }
+    } else {
+      const int rr = lane >> 3, rc = lane & 7;
+      mask_load(mkB, mhB, 4);
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(blk + (p * 8 + rr) * 144 + rc * 16);
-          const int row = row0 + p * 8 + rr, col = col0 + rc * 4;
+      for (int p = 0; p < 8; p++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(blk + (p * 8 + rr) * EP_LD + (h * 32 + rc * 4) * 4);
+          const int row = rowb + p * 8 + rr, col = n0 + h * 128 + wc * 32 + rc * 4;
           if (row < g.M && col < g.N) {
             float* cp = g.C + (int64_t)row * g.ldc + col;
             if constexpr (EPI == DM_EPI_DX) {
-              if (g.mask) {
-                const f32x4 mk = *reinterpret_cast<const f32x4*>(g.mask + (int64_t)row * g.ldmask + col);
+              const f32x4 mk = p < 4 ? mkA[(p & 3) * 2 + h] : mkB[(p & 3) * 2 + h];
+              if (g.mask16) {        // a bf16 is > 0 iff its sign bit is clear and the rest is not zero: a signed 16-bit compare
+                const s16x4 mh = p < 4 ? mhA[(p & 3) * 2 + h] : mhB[(p & 3) * 2 + h];
+                v.x = mh[0] > 0 ? v.x : 0.f; v.y = mh[1] > 0 ? v.y : 0.f; v.z = mh[2] > 0 ? v.z : 0.f; v.w = mh[3] > 0 ? v.w : 0.f;
+              } else if (g.mask) {
                 v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
               }
               if (g.add) v += *reinterpret_cast<const f32x4*>(cp);
@@ -321,8 +368,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma_kernel(const DmaArgs g) 
             }
           }
         }
-      }
     }
+  }
 }
 
 }  // namespace
@@ -372,6 +419,9 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
   a.A = g.A16; a.B = g.B16; a.C = g.C; a.C16 = form == BF16_FORM_DW ? nullptr : g.C16;
   a.bias = form == BF16_FORM_FWD ? g.bias : nullptr; a.mask = form == BF16_FORM_DX ? g.mask : nullptr;
   a.Af32 = g.A; a.db = form == BF16_FORM_DW ? g.db : nullptr;
+  static const int mask_fp32 = getenv("FFH_BF16_MASK_FP32") ? atoi(getenv("FFH_BF16_MASK_FP32")) : 0;      // A/B switch
+  a.mask16 = (a.mask && !mask_fp32) ? ffh_mirror_of(c, g.mask, (size_t)((int64_t)(g.M - 1) * g.ldmask + g.N) * 4) : nullptr;
+  if (a.mask16 && ((uintptr_t)a.mask16 & 7)) a.mask16 = nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = g.ldc; a.ldmask = g.ldmask;
   a.M = g.M; a.N = g.N; a.K = g.K; a.act = g.act; a.add = g.epi == EPI_ADD; a.splitk = splitk;
   a.a_bytes = (unsigned)a_bytes; a.b_bytes = (unsigned)b_bytes;

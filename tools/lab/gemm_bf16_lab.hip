@@ -48,7 +48,7 @@ struct Args {
   const uint16_t* A; const uint16_t* B; float* C; uint16_t* C16; const float* bias; const float* mask; int64_t ldmask;
   int M, N, K;
   int64_t lda, ldb, ldc;
-  int relu, atomic, splitk;
+  int relu, atomic, splitk, eflags;     // eflags (experiments): 1 no fp32 store, 2 no bf16 store, 4 nontemporal stores
   unsigned a_bytes, b_bytes;
 };
 
@@ -292,7 +292,18 @@ __global__ __launch_bounds__(512, 1) void gemm16(const Args g) {
         for (int p = 0; p < 2; p++) {
           const f32x4 vv = *reinterpret_cast<const f32x4*>(blk + (p * 8 + rr) * 144 + rc * 16);
           const int row = row0 + p * 8 + rr, col = col0 + rc * 4;
-          if (row < g.M && col < g.N) {
+          if (row < g.M && col < g.N && g.eflags) {     // experiment variants of the store pair
+            f32x4 v = vv;
+            float* cp = g.C + (int64_t)row * g.ldc + col;
+            const bf16x4 t = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+            if (g.eflags & 4) {
+              if (!(g.eflags & 1)) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(cp));
+              if (!(g.eflags & 2) && g.C16) __builtin_nontemporal_store(t, reinterpret_cast<bf16x4*>(g.C16 + (int64_t)row * g.ldc + col));
+            } else {
+              if (!(g.eflags & 1)) *reinterpret_cast<f32x4*>(cp) = v;
+              if (!(g.eflags & 2) && g.C16) *reinterpret_cast<bf16x4*>(g.C16 + (int64_t)row * g.ldc + col) = t;
+            }
+          } else if (row < g.M && col < g.N) {
             f32x4 v = vv;
             if (g.mask) {
               const f32x4 mk = *reinterpret_cast<const f32x4*>(g.mask + (int64_t)row * g.ldmask + col);
@@ -379,6 +390,17 @@ int main(int argc, char** argv) {
   Args a{}; a.A = x; a.B = wt; a.C = y; a.C16 = y16; a.bias = bias; a.M = Bt; a.N = OUT; a.K = IN; a.lda = IN; a.ldb = IN; a.ldc = OUT; a.relu = 1; a.splitk = 1;
   a.a_bytes = (unsigned)(hx.size() * 2); a.b_bytes = (unsigned)(hw.size() * 2);
   report("fwd  (kc,kc) fp32 + bf16 outputs", time_it([&] { hipLaunchKernelGGL(k0, dim3(tiles(a.M, a.N)), dim3(512), 2 * BUF + 32768, 0, a); }, 30));
+  if (diag == 2) {
+    auto kd = gemm16<false, false, 0, 1>; CK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 32768));
+    auto k4 = gemm16<false, false, 4, 0>; CK(hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 32768));
+    report("no stores at all", time_it([&] { hipLaunchKernelGGL(k4, dim3(tiles(a.M, a.N)), dim3(512), 2 * BUF + 32768, 0, a); }, 30));
+    for (int ef : {0, 1, 2, 3, 4, 5, 6}) {
+      Args ae = a; ae.eflags = ef;
+      char nm[64]; snprintf(nm, sizeof nm, "via LDS, eflags %d", ef);
+      report(nm, time_it([&] { hipLaunchKernelGGL(kd, dim3(tiles(a.M, a.N)), dim3(512), 2 * BUF + 32768, 0, ae); }, 30));
+    }
+    return 0;
+  }
   if (diag) {
 #define DIAGRUN(D, NAME) { auto kd = gemm16<false, false, D>; CK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + 32768)); \
       report("fwd  " NAME, time_it([&] { hipLaunchKernelGGL(kd, dim3(tiles(a.M, a.N)), dim3(512), 2 * BUF + 32768, 0, a); }, 30)); }
