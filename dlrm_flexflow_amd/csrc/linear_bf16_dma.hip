@@ -400,15 +400,21 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
   if (form == BF16_FORM_DW) {
     if (g.epi != EPI_ATOMIC || c->deterministic) return 0;       // the k-slices of a tile meet by atomics
     if (tiles < 8) return 0;                                     // tiny outputs: the atomic traffic of ~256 / tiles slices outweighs the tile
-    // the split whose workgroup count fills whole rounds of one workgroup per CU best (fewest slices among the near-best)
-    double bu = 0.0;
+    // the split with the least estimated time: rounds of one workgroup per CU x k-tiles per slice (~1 us each at the main
+    // loop's rate) + the slices' atomic traffic at the memory-side adders' ~1.3 TB/s (every slice adds a whole tile).  At batch
+    // 32768: 3456 x 1024 -> 4 slices (224 workgroups, one round), 1024 x 1024 -> 16, 1024 x 512 -> 16
+    static const int split_env = getenv("FFH_BF16_DMA_SPLIT") ? atoi(getenv("FFH_BF16_DMA_SPLIT")) : 0;     // A/B switch
+    const double tile_bytes = (double)DM_BM * DM_BN * 4;
+    double best = 1e30;
     for (int sp = 1; sp <= 64 && sp * 4 <= nk; sp++) {
       const int64_t nb = tiles * sp;
-      if (nb < c->num_cus) continue;
-      const double u = (double)nb / (double)(((nb + c->num_cus - 1) / c->num_cus) * c->num_cus);
-      if (u > bu + 0.02) { bu = u; splitk = sp; }
+      if (nb * 2 < c->num_cus) continue;
+      const double rounds = (double)((nb + c->num_cus - 1) / c->num_cus);
+      const double t = rounds * (double)((nk + sp - 1) / sp) * 1.0 + (double)nb * tile_bytes / 1.3e6;
+      if (t < best) { best = t; splitk = sp; }
     }
-    if (bu == 0.0) return 0;
+    if (best == 1e30) return 0;
+    if (split_env > 0 && split_env * 4 <= nk) splitk = split_env;
   } else {
     if (g.epi != EPI_STORE && g.epi != EPI_ADD) return 0;
     if (form == BF16_FORM_FWD && g.epi != EPI_STORE) return 0;

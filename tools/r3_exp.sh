@@ -1,39 +1,5 @@
-timeout 600 python - <<'PY'
-import sys, numpy as np, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
-from dlrm_flexflow_amd import capi
-hip = capi.load_hip(0)
-assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, 1) == 0
-B, IN, OUT = 16384, 1024, 1024
-dev = "cuda:0"
-rng = np.random.default_rng(1)
-x = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)
-w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
-gy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
-xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
-y = (xd @ wd.T).relu()
-res = {}
-import os
-for name in ("m16", "m32"):
-    dx = torch.full((B, IN), 9.0, device=dev); dw = torch.zeros(OUT, IN, device=dev); db = torch.zeros(OUT, device=dev); dy = torch.from_numpy(gy).to(dev)
-    tw = {}
-    regs = (("x", xd), ("w", wd), ("dy", dy), ("dx", dx)) if name == "m16" else (("w", wd), ("dy", dy), ("dx", dx))
-    for n_, t in regs:
-        tw[n_] = torch.zeros(t.shape, dtype=torch.bfloat16, device=dev)
-        assert hip.lib.ffh_ctx_bf16_mirror_set(hip.ctx, t.data_ptr(), t.numel() * 4, tw[n_].data_ptr()) == 0
-        if n_ != "dx": hip.call("ffh_convert_f32_to_bf16", tw[n_], t, t.numel(), None)
-    flags = capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DY_PREMASKED | capi.LINEAR_DX_MASK_BY_X | capi.LINEAR_ONLY_DX
-    hip.call("ffh_linear_bwd_ex", xd, IN, dx, IN, y, OUT, dy, OUT, wd, dw, db, IN, OUT, B, capi.AC_MODE_RELU, flags, None, None)
-    print(name, hip.lib.ffh_linear_last_route(hip.ctx).decode())
-    torch.cuda.synchronize()
-    for n_, t in regs: hip.lib.ffh_ctx_bf16_mirror_set(hip.ctx, t.data_ptr(), t.numel() * 4, None)
-    res[name] = dx.cpu().numpy()
-d = res["m16"] != res["m32"]
-print("mismatch", d.sum(), "of", d.size)
-r, c = np.nonzero(d)
-print("rows", np.unique(r)[:40], "cols", np.unique(c)[:64])
-print("row%64 hist", np.bincount(r % 64, minlength=64))
-print("col%64 hist", np.bincount(c % 64, minlength=64))
-for k in range(0, min(len(r), 5)):
-    i = (r[k], c[k]); print(i, res["m16"][i], res["m32"][i], x[i], x[i[0], max(i[1]-4,0):i[1]+5])
-PY
+for shape in 32768x3456x1024 32768x1024x1024 32768x1024x512; do
+  for sp in 0 3 4 5 6 7 9 12 16 24 32; do
+    echo -n "$shape split $sp: "; FFH_BF16_DMA_SPLIT=$sp timeout 120 python tools/bf16_twin_probe.py $shape 2>/dev/null | grep "operand twins" | sed 's/.*dW/dW/'
+  done
+done
