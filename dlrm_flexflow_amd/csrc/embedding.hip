@@ -543,12 +543,21 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
     const int64_t B = ratio > 0 ? b / ratio : 0;
     int64_t bend = ratio > 0 ? (B + 1) * (int64_t)ratio : (int64_t)nin;
     if (bend > nin) bend = nin;
-    // length of the walk (same for every column chunk)
+    // length of the walk (same for every column chunk): the lanes of the group look at lpr candidate blocks at once -- one
+    // parallel load and a ballot instead of up to `ratio` dependent loads (which were most of this kernel's time on the
+    // tables whose rows are hit thousands of times)
     int64_t b2 = b + 1;
-    while (b2 < bend) {
-      const uint2 m2 = meta[2 * b2];
-      if (m2.x != kMetaCont || m2.y != m.y) break;
-      b2++;
+    {
+      const uint64_t gmask = (lpr == 64 ? ~0ull : ((1ull << lpr) - 1ull)) << (rsub * lpr);
+      for (int64_t base = b + 1; base < bend; base += lpr) {
+        const int64_t idx = base + c0;
+        bool ok = false;
+        if (idx < bend) { const uint2 m2 = meta[2 * idx]; ok = m2.x == kMetaCont && m2.y == m.y; }
+        const uint64_t stop = ~(uint64_t)__ballot(ok) & gmask;          // lanes of this group whose block ends the run (or lies past bend)
+        if (stop) { b2 = base + (__ffsll((unsigned long long)stop) - 1 - rsub * lpr); break; }
+        b2 = base + lpr;
+      }
+      if (b2 > bend) b2 = bend;
     }
     bool cont_after = false;
     if (b2 == bend && bend < nin) { const uint2 m3 = meta[2 * bend]; cont_after = (m3.x == kMetaCont && m3.y == m.y); }

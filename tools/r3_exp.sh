@@ -1,5 +1,2 @@
-for shape in 32768x3456x1024 32768x1024x1024 32768x1024x512; do
-  for sp in 0 3 4 5 6 7 9 12 16 24 32; do
-    echo -n "$shape split $sp: "; FFH_BF16_DMA_SPLIT=$sp timeout 120 python tools/bf16_twin_probe.py $shape 2>/dev/null | grep "operand twins" | sed 's/.*dW/dW/'
-  done
-done
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -m gpu -k "emb or sgd or fused" 2>&1 | tail -3
+timeout 300 python tools/microbench.py emb 2>&1 | tail -15
