@@ -1709,7 +1709,12 @@ void FFModel::allocate() {
       auto skinny_twin = [&](const Linear* l) {
         return l && l->out_channels <= 4 && l->in_channels >= FFH_BF16_MIN_DIM && l->in_channels <= 1024 && l->in_channels % 4 == 0 && !config.deterministic;
       };
-      if (ncons == 1 && only && (twin_linear(only) || skinny_twin(only)) && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange)
+      // ... and only where somebody reads that twin: the producer of the tensor is a twin-reading Linear whose dy arrives final
+      // (premasked by the consumer's dX epilogue, or no activation).  The Concat output's gradient (3456 columns at the Terabyte
+      // shape, of which the bottom MLP reads 128 through a live relu') has no such reader: 226 MB per step not written
+      const Linear* prod = op->op_type == OP_LINEAR ? static_cast<const Linear*>(op) : nullptr;
+      const bool twin_read = prod && twin_linear(prod) && (prod->dy_premasked || prod->activation == AC_MODE_NONE);
+      if (ncons == 1 && twin_read && only && (twin_linear(only) || skinny_twin(only)) && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange)
         reg(im->grad, im->bytes, (char*)grad_twin + ((const char*)im->grad - act_grad_slab) / 2);
     }
   }
