@@ -104,6 +104,8 @@ _SIGS = {
     "ffh_embedding_bwd_dense": (I, [P, P, P, P, I, I, L, L, L, I, P]),
     "ffh_embedding_bwd_sgd_fused": (I, [P, P, P, P, I, I, L, L, L, I, F, P]),
     "ffh_embedding_bwd_sgd_fused_multi": (I, [P, C.POINTER(EmbTable), I, I, I, L, I, F, P]),
+    "ffh_embedding_bwd_sort_multi": (I, [P, C.POINTER(EmbTable), I, I, I, L, P]),
+    "ffh_embedding_bwd_sgd_apply_multi": (I, [P, C.POINTER(EmbTable), I, I, I, L, I, F, P]),
     "ffh_embedding_bwd_workspace_bytes": (SZ, [I, I, I, L]),
     "ffh_embedding_localize_rows": (I, [P, P, P, L, L, L, P]),
     "ffh_linear_fwd": (I, [P, P, L, P, L, P, P, I, I, L, I, P]),

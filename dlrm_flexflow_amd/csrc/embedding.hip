@@ -886,8 +886,12 @@ size_t ffh_embedding_bwd_workspace_bytes(int nt, int L, int D, int64_t batch) {
   return bwd_layout(nt, L, D, batch).total;
 }
 
-int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch,
-                                      int aggr, float lr, ffh_stream s) {
+// The fused update in two phases: the stable sort of (row id, position) needs the indices only, so a caller that knows them
+// early (the DLRM step: at the gather) can run it off the critical path (ffh_embedding_bwd_sort_multi) and do the part that
+// needs the output gradients -- segmented reduce, folds, the SGD step -- when they exist (ffh_embedding_bwd_sgd_apply_multi).
+// Same launches in the same order on the same workspace: the fused entry is both phases back to back.
+static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch,
+                          int aggr, float lr, ffh_stream s, const bool do_sort, const bool do_apply) {
   int rc = validate_tables(c, tables, nt, L, D, batch, aggr, "embedding_bwd_sgd_fused");
   if (rc) return rc;
   if (nt == 0 || batch == 0) return FFH_OK;
@@ -905,7 +909,8 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
   if (!aligned16(ws)) return ffh_fail(c, FFH_ERR_WORKSPACE, "embedding_bwd_sgd_fused: workspace must be 16-byte aligned");
 
   if (N <= kSmallMax) {
-    // small-batch path: one launch, one workgroup per table (see emb_sgd_small_kernel)
+    // small-batch path: one launch, one workgroup per table (see emb_sgd_small_kernel): the sort lives inside it
+    if (!do_apply) return FFH_OK;
     int bits_s = 1;
     while (bits_s < 32 && ((maxR - 1) >> bits_s) != 0) bits_s++;
     const int passes_s = (bits_s + kMaxRadixBits - 1) / kMaxRadixBits;
@@ -955,7 +960,7 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
   uint32_t* pbuf[2] = {(uint32_t*)(ws + lay.pos_a), (uint32_t*)(ws + lay.pos_b)};
   dim3 sgrid((unsigned)lay.nblk, (unsigned)nt);
   const int E = sort_per_thread(nt, N);
-  for (int p = 0; p < passes; p++) {
+  for (int p = 0; p < passes && do_sort; p++) {
     sa.shift = p * rb;
     sa.pass = p;
     // pass p reads buffer p%2 (pass 0: the int64 ids) and writes buffer (p+1)%2
@@ -972,6 +977,7 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
 #undef FFH_SORT_PASS
   }
   FFH_LAUNCH_CHECK(c, "radix sort");
+  if (!do_apply) return FFH_OK;
 
   for (int i = 0; i < nt; i++) ra.t[i] = tables[i];
   ra.keys[0] = kbuf[0]; ra.keys[1] = kbuf[1];
@@ -1009,6 +1015,20 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, i
   }
   FFH_LAUNCH_CHECK(c, "emb_sgd_reduce/fold");
   return FFH_OK;
+}
+
+int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch,
+                                      int aggr, float lr, ffh_stream s) {
+  return emb_bwd_phases(c, tables, nt, L, D, batch, aggr, lr, s, true, true);
+}
+
+int ffh_embedding_bwd_sort_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch, ffh_stream s) {
+  return emb_bwd_phases(c, tables, nt, L, D, batch, FFH_AGGR_MODE_SUM, 0.0f, s, true, false);
+}
+
+int ffh_embedding_bwd_sgd_apply_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch,
+                                      int aggr, float lr, ffh_stream s) {
+  return emb_bwd_phases(c, tables, nt, L, D, batch, aggr, lr, s, false, true);
 }
 
 int ffh_embedding_bwd_sgd_fused(ffh_ctx* c, const int64_t* idx, const float* g, float* weight, int L, int D, int64_t batch,

@@ -105,6 +105,7 @@ class FFConfig {
   bool deterministic;          // --deterministic: weight / bias gradients without fp atomics (ffh_ctx_set_deterministic): bit-identical runs
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
+  bool early_sort;             // the index-only sort of the fused table update runs behind the gather (ffh_embedding_bwd_sort_multi), off the backward's critical path (A/B: --no-early-sort)
   bool dx_scatter;             // exchange mode: the layer above the feature Concat writes its dX into the send buffer itself (A/B: --no-dx-scatter)
   bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)
   bool attach_events;          // hang ev_grad_ready on the producing kernel's completion instead of a record packet (A/B: --no-attach-event)
@@ -517,6 +518,8 @@ class FFModel {
   void order_input_writes_behind_update() const;
   void profiled(const Op* op, bool fwd, const std::function<void()>& fn) const;   // --profiling: one op between two events
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
+  bool early_sort_possible() const;      // one launch group, nothing else on the workspace between a step's gather and its update
+  mutable bool emb_sorted_early;         // this step's sort was issued behind the gather: the update is the apply phase only
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
   std::vector<Initializer*> owned_initializers;
   int grad_attach_layer;        // the Linear whose backward completes the embedding output gradients (-1: none / not attachable)

@@ -133,6 +133,7 @@ FFConfig::FFConfig() {
   attach_events = true;
   fuse_pair = true;
   dx_scatter = true;
+  early_sort = true;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
   deterministic = false;
@@ -191,6 +192,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-attach-event")) { attach_events = false; continue; }
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
+    if (is("--no-early-sort")) { early_sort = false; continue; }
   }
 }
 
@@ -414,7 +416,7 @@ FFModel::FFModel(FFConfig& _config)
     : op_global_guid(100), config(profiling_schedule(_config)), optimizer(nullptr), loss_type(LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE),
       metrics_flags(0), seq_length(-1), api(nullptr), ctx(nullptr), stream(nullptr), side_stream(nullptr),
       ev_fork(nullptr), ev_join(nullptr), ev_grad_ready(nullptr), ev_update_done(nullptr), compiled(false),
-      emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
+      emb_forward_issued(false), emb_forward_joined(false), emb_update_pending(false), emb_sorted_early(false), mlp_weights(nullptr), mlp_grads(nullptr), mlp_count(0),
       act_slab(nullptr), act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), repl_workspace(nullptr), repl_workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1), inputs_dirty(true), fork_recorded(false) {
   seed_counter = 0;
@@ -1736,7 +1738,9 @@ void FFModel::print_layers(int id) {
 // =============================================================================================
 // launches one batched kernel per distinct shard width (all table-wise tables share one; column blocks of
 // giant tables another); FWD: gather, else fused backward + SGD
-static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s, ffh_ctx* cx, const std::vector<const int64_t*>* idx_override = nullptr) {
+enum ShardLaunch { kGather, kFusedUpdate, kSortOnly, kApplyOnly };
+static void launch_shard_groups(const FFModel* ff, ShardLaunch what, ffh_stream s, ffh_ctx* cx, const std::vector<const int64_t*>* idx_override = nullptr) {
+  const bool fwd = what == kGather;
   const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(ff->optimizer);
   const int L = ff->embeddings[0]->inputs[0].adim[0];
   const int aggr = (int)ff->embeddings[0]->aggr;
@@ -1764,9 +1768,15 @@ static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s, ffh_c
     std::vector<ffh_emb_table>& tabs = kv.second;
     for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
       const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
-      if (fwd) ff->check(ff->api->ffh_embedding_fwd_multi(cx, tabs.data() + b, n, L, kv.first, ff->config.batchSize, aggr, s), "embedding_fwd_multi");
-      else ff->check(ff->api->ffh_embedding_bwd_sgd_fused_multi(cx, tabs.data() + b, n, L, kv.first, ff->config.batchSize, aggr, (float)sgd->lr, s),
-                     "embedding_bwd_sgd_fused_multi");
+      const int64_t B = ff->config.batchSize;
+      switch (what) {
+        case kGather: ff->check(ff->api->ffh_embedding_fwd_multi(cx, tabs.data() + b, n, L, kv.first, B, aggr, s), "embedding_fwd_multi"); break;
+        case kFusedUpdate: ff->check(ff->api->ffh_embedding_bwd_sgd_fused_multi(cx, tabs.data() + b, n, L, kv.first, B, aggr, (float)sgd->lr, s),
+                                     "embedding_bwd_sgd_fused_multi"); break;
+        case kSortOnly: ff->check(ff->api->ffh_embedding_bwd_sort_multi(cx, tabs.data() + b, n, L, kv.first, B, s), "embedding_bwd_sort_multi"); break;
+        case kApplyOnly: ff->check(ff->api->ffh_embedding_bwd_sgd_apply_multi(cx, tabs.data() + b, n, L, kv.first, B, aggr, (float)sgd->lr, s),
+                                   "embedding_bwd_sgd_apply_multi"); break;
+      }
     }
   }
 }
@@ -1775,7 +1785,27 @@ static void launch_shard_groups(const FFModel* ff, bool fwd, ffh_stream s, ffh_c
 // roofline kernels of a multi-rank job
 void FFModel::embedding_kernels_only(bool fwd, ffh_stream s, const std::vector<const int64_t*>* idx_override) const {
   if (embeddings.empty()) return;
-  launch_shard_groups(this, fwd, s, ctx, idx_override);
+  launch_shard_groups(this, fwd ? kGather : kFusedUpdate, s, ctx, idx_override);
+}
+
+// The sort of the fused update reads only the sparse ids, which are final when the gather starts: issued behind the gather on
+// the side stream it runs beside the top MLP's forward instead of between the gradients and the next gather (what Legion's
+// region dependences would give an index-only task).  The sorted list waits in the ctx workspace, so this is only done when
+// nothing else writes the workspace between a step's gather and its update: one launch group (one shard width, <=
+// FFH_MAX_TABLES shards), no row-wise sharded table (its own fused call), launches issued inline.
+bool FFModel::early_sort_possible() const {
+  if (!config.early_sort || !config.overlap_embedding || !fused_embedding_update() || config.profiling) return false;
+  if (config.computationMode != COMP_MODE_TRAINING || use_workers()) return false;
+  int n = 0, cols = -1;
+  for (const EmbShard& sh : shards) {
+    if (sh.owner != rank) continue;
+    if (cols >= 0 && sh.cols != cols) return false;
+    cols = sh.cols;
+    n++;
+  }
+  for (const Embedding* e : embeddings)
+    if (e->row_sharded) return false;
+  return n > 0 && n <= FFH_MAX_TABLES;
 }
 
 void FFModel::probe_record(int which, ffh_stream s, ffh_ctx* cx) const {
@@ -1786,7 +1816,7 @@ void FFModel::probe_record(int which, ffh_stream s, ffh_ctx* cx) const {
 
 void FFModel::embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx) const {
   if (embeddings.empty()) return;
-  launch_shard_groups(this, true, s, on_ctx ? on_ctx : ctx);
+  launch_shard_groups(this, kGather, s, on_ctx ? on_ctx : ctx);
   if (exchange) {
     // each owner gathered its tables / column blocks for the global batch; rows go to the rank that owns the sample
     if (!shards.empty() && config.comm.alltoall_f32(config.comm.user, xsend, fwd_send_counts.data(), xrecv, fwd_recv_counts.data(), s) != 0)
@@ -1863,7 +1893,8 @@ void FFModel::embedding_group_update(ffh_stream s, ffh_ctx* on_ctx) const {
     if (!shards.empty() && config.comm.alltoall_f32(config.comm.user, gsend, fwd_recv_counts.data(), grecv, fwd_send_counts.data(), s) != 0)
       die("alltoall (embedding backward) failed");
   }
-  launch_shard_groups(this, false, s, on_ctx ? on_ctx : ctx);
+  launch_shard_groups(this, emb_sorted_early ? kApplyOnly : kFusedUpdate, s, on_ctx ? on_ctx : ctx);
+  emb_sorted_early = false;
   // row-wise sharded tables: every rank needs the gradient rows of the global batch; the fused update then touches the
   // rows held here, and whatever the other ranks' rows piled onto the zero row is wiped
   ffh_ctx* cx = on_ctx ? on_ctx : ctx;
@@ -1959,6 +1990,10 @@ void FFModel::issue_embedding_forward_on_side_stream() const {
     embedding_group_forward(side_stream);
     probe_record(1, side_stream, ctx);
     check(api->ffh_event_record(ctx, ev_join, side_stream), "join");
+    if (early_sort_possible()) {        // behind the join: nothing waits for it until this step's update
+      launch_shard_groups(this, kSortOnly, side_stream, ctx);
+      emb_sorted_early = true;
+    }
   }
   emb_forward_issued = true;
   emb_forward_joined = false;

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 6   /* 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 7   /* 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -267,6 +267,17 @@ int ffh_embedding_bwd_sgd_fused(ffh_ctx* ctx, const int64_t* idx, const float* o
 int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int ntables,
                                       int in_dim, int out_dim, int64_t batch, int aggr, float lr, ffh_stream s);
 size_t ffh_embedding_bwd_workspace_bytes(int ntables, int in_dim, int out_dim, int64_t batch);
+/* The same update in two calls (ABI 7): the stable sort by (row, position) reads only the indices, so a caller that has them
+ * before the output gradients exist (a training step: from the gather on) can run it early --
+ *   ffh_embedding_bwd_sort_multi      the index-only part, into the ctx workspace (tables[].io / .ld are not read);
+ *   ffh_embedding_bwd_sgd_apply_multi the rest (segmented sums, folds, w = fmaf(-lr, sum, w)), on the SAME tables / indices /
+ *                                     batch, with nothing else using the workspace in between and ordered behind the sort by
+ *                                     the caller's streams / events.
+ * sort + apply launch what ffh_embedding_bwd_sgd_fused_multi launches, in the same order: the same bits. */
+int ffh_embedding_bwd_sort_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int ntables,
+                                 int in_dim, int out_dim, int64_t batch, ffh_stream s);
+int ffh_embedding_bwd_sgd_apply_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int ntables,
+                                      int in_dim, int out_dim, int64_t batch, int aggr, float lr, ffh_stream s);
 
 /* Row-wise sharded table (no reference counterpart: the reference splits an embedding on the sample dim only,
  * [ref: src/ops/embedding.cu:84-85]).  A rank holds rows [row_begin, row_begin + rows_local) followed by ONE extra
@@ -522,7 +533,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_fill_f32) X(ffh_zero) X(ffh_init_uniform) \
   X(ffh_gen_indices) X(ffh_gen_uniform01) X(ffh_gen_bernoulli) \
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
-  X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) \
+  X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) X(ffh_embedding_bwd_sort_multi) X(ffh_embedding_bwd_sgd_apply_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
   X(ffh_linear_fwd) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \

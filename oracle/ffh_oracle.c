@@ -352,6 +352,18 @@ int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* t, int nt
   }
   return FFH_OK;
 }
+
+/* the two-call form (include/ff_hip.h, ABI 7): the index-only phase has nothing to precompute here -- the restatement sorts
+ * inside the update -- so the sort call only validates and the apply call is the whole update */
+int ffh_embedding_bwd_sort_multi(ffh_ctx* c, const ffh_emb_table* t, int nt, int L, int D, int64_t B, ffh_stream s) {
+  (void)s;
+  if (nt < 0 || nt > FFH_MAX_TABLES || (nt > 0 && !t) || L <= 0 || D <= 0 || B < 0) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_sort_multi: bad args");
+  return FFH_OK;
+}
+
+int ffh_embedding_bwd_sgd_apply_multi(ffh_ctx* c, const ffh_emb_table* t, int nt, int L, int D, int64_t B, int aggr, float lr, ffh_stream s) {
+  return ffh_embedding_bwd_sgd_fused_multi(c, t, nt, L, D, B, aggr, lr, s);
+}
 /* row-wise sharded table (this build's extension; include/ff_hip.h): ids of rows held elsewhere -> the zero row */
 int ffh_embedding_localize_rows(ffh_ctx* c, const int64_t* idx, int64_t* local, int64_t n, int64_t row_begin, int64_t rows_local, ffh_stream s) {
   (void)s;
