@@ -144,6 +144,8 @@ struct SortArgs {
   int       bits;
   int       pass;
   uint8_t   npass[FFH_MAX_TABLES];      // digits table t really has; later passes would be the identity and are skipped
+  uint32_t* clear[2];                   // [nt][nclear[i]] dwords the pass-0 histogram kernel zeroes for the apply phase
+  int       nclear[2];                  //   (level-1 meta slots, arrival counters)
 };
 
 template <bool FIRST>
@@ -159,6 +161,13 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const SortArgs
   constexpr int kSortPerThread = E;
   __shared__ uint32_t s_hist[kMaxRadix];
   const int t = blockIdx.y, blk = blockIdx.x;
+  if (FIRST) {     // every table has a pass 0: the apply phase finds its level-1 slots empty and its arrival counters at zero
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      uint32_t* z = a.clear[r] + (int64_t)t * a.nclear[r];
+      for (int i = blk * kSortThreads + threadIdx.x; i < a.nclear[r]; i += gridDim.x * kSortThreads) z[i] = 0u;
+    }
+  }
   if (a.pass >= a.npass[t]) return;
   const int radix = 1 << a.bits;
   const uint32_t mask = radix - 1;
@@ -343,7 +352,9 @@ struct RedArgs {
   int       D;
   int       avg;
   float     lr;
-  uint2*    meta1;          // level-1 slots [nt][2*nchunks1]: cleared here (grid-stride) for the folds that follow
+  float*    partial1;       // level-1 partial rows [nt][2*nchunks1][D]
+  uint2*    meta1;          // level-1 slots [nt][2*nchunks1] (cleared by the sort phase)
+  uint32_t* arrive;         // [nt][nchunks1 + 1] (cleared by the sort phase): tiles done per 1024-block, then 1024-blocks folded
   int       nchunks1;
 };
 
@@ -361,6 +372,54 @@ __device__ __forceinline__ void load_grad(float (&dst)[VEC], const float* rowp, 
   }
 }
 
+// Partial rows and slot records that one workgroup writes and ANOTHER reads inside the same launch (the folds in the tail of
+// emb_sgd_reduce_kernel).  The eight XCDs' L2s are not coherent with each other for ordinary accesses inside a kernel, and an
+// agent-scope fence pays for that with a write-back of the whole L2 (measured: 4x on the kernel, the L2 is full of the table
+// rows just written).  Instead these few accesses are agent-scope relaxed atomics -- `sc1` stores (written through) and `sc1`
+// loads (served behind the L2) -- ordered by completion: the writer waits for its stores (vmcnt) before it counts itself in, the
+// reader loads after it has seen the count.  AGENT = false: the one-workgroup small-batch kernel, ordinary accesses.
+__device__ __forceinline__ void xwg_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <bool AGENT>
+__device__ __forceinline__ void xwg_store2(uint2* p, uint2 v) {
+  if (AGENT) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool AGENT>
+__device__ __forceinline__ uint2 xwg_load2(const uint2* p) {
+  if (!AGENT) return *p;
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+template <int VEC, bool AGENT>
+__device__ __forceinline__ void xwg_store_row(float* rowp, int c, const float (&v)[VEC]) {
+  if (VEC == 4) {
+    if (AGENT) {
+      xwg_store2<true>(reinterpret_cast<uint2*>(rowp) + 2 * c, make_uint2(__float_as_uint(v[0]), __float_as_uint(v[1])));
+      xwg_store2<true>(reinterpret_cast<uint2*>(rowp) + 2 * c + 1, make_uint2(__float_as_uint(v[2]), __float_as_uint(v[3])));
+    } else {
+      reinterpret_cast<float4*>(rowp)[c] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else {
+    if (AGENT) __hip_atomic_store(rowp + c, v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else rowp[c] = v[0];
+  }
+}
+template <int VEC, bool AGENT>
+__device__ __forceinline__ void xwg_load_row(float (&dst)[VEC], const float* rowp, int c) {
+  if (VEC == 4) {
+    if (AGENT) {
+      const uint2 lo = xwg_load2<true>(reinterpret_cast<const uint2*>(rowp) + 2 * c), hi = xwg_load2<true>(reinterpret_cast<const uint2*>(rowp) + 2 * c + 1);
+      dst[0] = __uint_as_float(lo.x); dst[1] = __uint_as_float(lo.y); dst[2] = __uint_as_float(hi.x); dst[3] = __uint_as_float(hi.y);
+    } else {
+      const float4 v = reinterpret_cast<const float4*>(rowp)[c];
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+  } else {
+    dst[0] = AGENT ? __hip_atomic_load(rowp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : rowp[c];
+  }
+}
+
+constexpr int kFoldStage = 1024;     // slot records of one fold staged in LDS (a 1024-block has 64; a table's 1024-blocks: 2 N / 1024)
 struct RedShared {
   uint32_t key[kRedTile + 2];     // [0] = key before the tile, [1+i], [1+n] = key after
   uint32_t pos[kRedTile];
@@ -370,7 +429,7 @@ struct RedShared {
 };
 
 // one tile of one table; `partial_t` / `meta_t` are the table's level-0 slot arrays
-template <int VEC>
+template <int VEC, bool AGENT>
 __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const uint32_t* keys, const uint32_t* posg,
                                                  float* partial_t, uint2* meta_t, int64_t N, int nchunks, int tile, int tile_index,
                                                  int L, int D_, bool avg_, float lr_, RedShared& sh, const int tid = threadIdx.x) {
@@ -386,7 +445,8 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
 
   for (int i = tid; i < n; i += kRedThreads) {
     s_key[1 + i] = keys[tile0 + i];
-    s_pos[i] = posg[tile0 + i];
+    const uint32_t p = posg[tile0 + i];
+    s_pos[i] = a.L == 1 ? p : p / (uint32_t)a.L;      // the sample (gradient row) of the entry
   }
   if (tid == 0) {
     s_key[0] = (tile0 > 0 && tile0 < N) ? keys[tile0 - 1] : 0xFFFFFFFFu;   // no valid key equals it when tile0 == 0 (checked below)
@@ -438,6 +498,9 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
   const float Lf = (float)a.L;
   const bool avg = a.avg != 0;
 
+  // (Several sub-runs per lane-group in flight at once were tried -- 2 and 4, with and without the registers capped for eight
+  //  waves per SIMD -- and changed nothing: with every tile resident the kernel runs at the rate the memory system takes random
+  //  512-B reads and read-modify-writes, ~5 TB/s of real traffic, not at a latency chain's.)
   if (rsub < rpw) {
     for (int k = gid; k < S; k += groups) {
       const int s = s_start[k], e = s_start[k + 1];
@@ -445,28 +508,28 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
       const bool head = (s_key[s] != key) || (s == 0 && at_table_start);
       const bool tail = (s_key[1 + e] != key) || (tile0 + e >= N);
       const int64_t chunk = (tile0 + s) / FFH_EMB_CHUNK;
-      const int slot_local = (int)(chunk - tile0 / FFH_EMB_CHUNK) * 2 + ((s % FFH_EMB_CHUNK) ? 1 : 0);
+      const int odd = (s % FFH_EMB_CHUNK) ? 1 : 0;
       const bool single = head && tail;
-      if (!single && c0 == 0) s_meta[slot_local] = make_uint2(head ? kMetaFirst : kMetaCont, key);
+      if (!single && c0 == 0) s_meta[(int)(chunk - tile0 / FFH_EMB_CHUNK) * 2 + odd] = make_uint2(head ? kMetaFirst : kMetaCont, key);
       float* wrow = tb.weight + (int64_t)key * D;
-      float* prow = partial_t + (chunk * 2 + ((s % FFH_EMB_CHUNK) ? 1 : 0)) * D;
+      float* prow = partial_t + (chunk * 2 + odd) * D;
       for (int c = c0; c < nvec; c += lpr) {
         float acc[VEC];
-        load_grad<VEC>(acc, tb.io + (int64_t)(s_pos[s] / a.L) * tb.ld, c, Lf, avg);
+        load_grad<VEC>(acc, tb.io + (int64_t)s_pos[s] * tb.ld, c, Lf, avg);
         int q = s + 1;
         // four independent row loads in flight, summed in order
         for (; q + 4 <= e; q += 4) {
           float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-          load_grad<VEC>(v0, tb.io + (int64_t)(s_pos[q] / a.L) * tb.ld, c, Lf, avg);
-          load_grad<VEC>(v1, tb.io + (int64_t)(s_pos[q + 1] / a.L) * tb.ld, c, Lf, avg);
-          load_grad<VEC>(v2, tb.io + (int64_t)(s_pos[q + 2] / a.L) * tb.ld, c, Lf, avg);
-          load_grad<VEC>(v3, tb.io + (int64_t)(s_pos[q + 3] / a.L) * tb.ld, c, Lf, avg);
+          load_grad<VEC>(v0, tb.io + (int64_t)s_pos[q] * tb.ld, c, Lf, avg);
+          load_grad<VEC>(v1, tb.io + (int64_t)s_pos[q + 1] * tb.ld, c, Lf, avg);
+          load_grad<VEC>(v2, tb.io + (int64_t)s_pos[q + 2] * tb.ld, c, Lf, avg);
+          load_grad<VEC>(v3, tb.io + (int64_t)s_pos[q + 3] * tb.ld, c, Lf, avg);
 #pragma unroll
           for (int v = 0; v < VEC; v++) acc[v] = (((acc[v] + v0[v]) + v1[v]) + v2[v]) + v3[v];
         }
         for (; q < e; q++) {
           float v0[VEC];
-          load_grad<VEC>(v0, tb.io + (int64_t)(s_pos[q] / a.L) * tb.ld, c, Lf, avg);
+          load_grad<VEC>(v0, tb.io + (int64_t)s_pos[q] * tb.ld, c, Lf, avg);
 #pragma unroll
           for (int v = 0; v < VEC; v++) acc[v] = acc[v] + v0[v];
         }
@@ -480,8 +543,7 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
             wrow[c] = __fmaf_rn(-a.lr, acc[0], wrow[c]);
           }
         } else {
-          if (VEC == 4) reinterpret_cast<float4*>(prow)[c] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-          else prow[c] = acc[0];
+          xwg_store_row<VEC, AGENT>(prow, c, acc);
         }
       }
     }
@@ -489,21 +551,8 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
   __syncthreads();
   if (tid < metas) {
     const int64_t slot = (tile0 / FFH_EMB_CHUNK) * 2 + tid;
-    if (slot < 2 * (int64_t)a.nchunks) meta_t[slot] = s_meta[tid];
+    if (slot < 2 * (int64_t)a.nchunks) xwg_store2<AGENT>(meta_t + slot, s_meta[tid]);
   }
-}
-
-template <int VEC>
-__global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedArgs a) {
-  __shared__ RedShared sh;
-  const int tix = blockIdx.y;
-  if (a.nchunks1 > 1) {      // the level-1 slots of this table start empty (saves the memset launch in front of the folds)
-    uint2* m1 = a.meta1 + (int64_t)tix * 2 * a.nchunks1;
-    for (int i = blockIdx.x * kRedThreads + threadIdx.x; i < 2 * a.nchunks1; i += gridDim.x * kRedThreads) m1[i] = make_uint2(kMetaNone, 0);
-  }
-  reduce_tile_body<VEC>(a.t[tix], a.keys[a.parity[tix]] + (int64_t)tix * a.N, a.pos[a.parity[tix]] + (int64_t)tix * a.N,
-                        a.partial + (int64_t)tix * 2 * a.nchunks * a.D, a.meta + (int64_t)tix * 2 * a.nchunks, a.N, a.nchunks, a.tile,
-                        (int)blockIdx.x, a.L, a.D, a.avg != 0, a.lr, sh);
 }
 
 // step 3: fold.  A row whose run crosses block boundaries left one partial per block at level k (slot 2b:
@@ -512,20 +561,21 @@ __global__ __launch_bounds__(kRedThreads) void emb_sgd_reduce_kernel(const RedAr
 // stopping at the boundary of the enclosing level-(k+1) block (`ratio` level-k blocks; 0 = no boundary,
 // last level).  A run that is now complete is applied to the table; otherwise its level-(k+1) partial
 // is written with the same two-slots-per-block convention.  Chains are <= ratio steps long.
-struct FoldArgs {
-  ffh_emb_table t[FFH_MAX_TABLES];
-  const float* pin;   // [nt][2*nin][D]
-  const uint2* min;   // [nt][2*nin]
-  float*       pout;  // [nt][2*nout][D]
-  uint2*       mout;  // [nt][2*nout]   (pre-zeroed = kMetaNone)
-  int nin, nout, ratio, D;
-  float lr;
-};
-
-// one table; the lane-groups numbered group0, group0+ngroups, ... share the slots
-template <int VEC>
+// one table; the lane-groups numbered group0, group0+ngroups, ... share the slots [slot_lo, slot_hi).
+// `keys` (the table's sorted ids; level-0 input only, ratio > 0): whether a run goes on past the end of its level-(k+1) block is
+// read off the sorted list instead of the next block's first slot -- the workgroup that folds one block (the last of the
+// block's reduce tiles to finish, see emb_sgd_reduce_kernel) then needs nothing another block's tiles write.
+template <int VEC, bool AGENT>
 __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const float* part, const uint2* meta, float* pout_t, uint2* mout_t,
-                                                int nin, int ratio, int D, float lr, int64_t group0, int64_t ngroups) {
+                                                int nin, int ratio, int D, float lr, int64_t slot_lo, int64_t slot_hi,
+                                                int64_t group0, int64_t ngroups, const uint32_t* keys = nullptr,
+                                                const uint2* staged = nullptr, int64_t staged_lo = 0, int staged_n = 0) {
+  // `staged`: an LDS copy of meta[staged_lo, staged_lo + staged_n) the caller fetched with one parallel load (the in-kernel folds:
+  // a dependent memory round trip per slot and lane-group would otherwise be most of the fold)
+  auto slot_meta = [&](int64_t sl) -> uint2 {
+    if (staged && sl >= staged_lo && sl < staged_lo + staged_n) return staged[sl - staged_lo];
+    return xwg_load2<AGENT>(meta + sl);
+  };
   const int nvec = D / VEC;
   const int lpr = nvec < 64 ? nvec : 64;
   const int rpw = 64 / lpr;
@@ -533,9 +583,8 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
   const int rsub = lane / lpr;
   const int c0 = lane - rsub * lpr;
   if (rsub >= rpw) return;
-  const int64_t nslots = 2 * (int64_t)nin;
-  for (int64_t slot = group0; slot < nslots; slot += ngroups) {
-    const uint2 m = meta[slot];
+  for (int64_t slot = slot_lo + group0; slot < slot_hi; slot += ngroups) {
+    const uint2 m = slot_meta(slot);
     if (m.x == kMetaNone) continue;
     const int64_t b = slot >> 1;
     const bool at_block_start = ratio > 0 && (b % ratio == 0) && ((slot & 1) == 0);
@@ -552,7 +601,7 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
       for (int64_t base = b + 1; base < bend; base += lpr) {
         const int64_t idx = base + c0;
         bool ok = false;
-        if (idx < bend) { const uint2 m2 = meta[2 * idx]; ok = m2.x == kMetaCont && m2.y == m.y; }
+        if (idx < bend) { const uint2 m2 = slot_meta(2 * idx); ok = m2.x == kMetaCont && m2.y == m.y; }
         const uint64_t stop = ~(uint64_t)__ballot(ok) & gmask;          // lanes of this group whose block ends the run (or lies past bend)
         if (stop) { b2 = base + (__ffsll((unsigned long long)stop) - 1 - rsub * lpr); break; }
         b2 = base + lpr;
@@ -560,29 +609,34 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
       if (b2 > bend) b2 = bend;
     }
     bool cont_after = false;
-    if (b2 == bend && bend < nin) { const uint2 m3 = meta[2 * bend]; cont_after = (m3.x == kMetaCont && m3.y == m.y); }
+    if (b2 == bend && bend < nin) {
+      // the run reached the end of the block: it continues iff the entry behind the block carries the same id (sorted list);
+      // equivalently the next block's first slot is a continuation of this id
+      if (keys) cont_after = keys[bend * FFH_EMB_CHUNK] == m.y;
+      else { const uint2 m3 = slot_meta(2 * bend); cont_after = (m3.x == kMetaCont && m3.y == m.y); }
+    }
     const bool head = m.x == kMetaFirst;
     const bool complete = head && !cont_after;
     const int64_t oslot = 2 * B + (at_block_start ? 0 : 1);
-    if (!complete && c0 == 0) mout_t[oslot] = make_uint2(head ? kMetaFirst : kMetaCont, m.y);
+    if (!complete && c0 == 0) xwg_store2<AGENT>(mout_t + oslot, make_uint2(head ? kMetaFirst : kMetaCont, m.y));
     float* wrow = tb.weight + (int64_t)m.y * D;
     float* orow = pout_t + oslot * D;
     for (int c = c0; c < nvec; c += lpr) {
       float acc[VEC];
-      load_grad<VEC>(acc, part + slot * D, c, 1.0f, false);
+      xwg_load_row<VEC, AGENT>(acc, part + slot * D, c);
       int64_t q = b + 1;
       for (; q + 4 <= b2; q += 4) {   // four partial rows in flight, added in order
         float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
-        load_grad<VEC>(v0, part + 2 * q * D, c, 1.0f, false);
-        load_grad<VEC>(v1, part + 2 * (q + 1) * D, c, 1.0f, false);
-        load_grad<VEC>(v2, part + 2 * (q + 2) * D, c, 1.0f, false);
-        load_grad<VEC>(v3, part + 2 * (q + 3) * D, c, 1.0f, false);
+        xwg_load_row<VEC, AGENT>(v0, part + 2 * q * D, c);
+        xwg_load_row<VEC, AGENT>(v1, part + 2 * (q + 1) * D, c);
+        xwg_load_row<VEC, AGENT>(v2, part + 2 * (q + 2) * D, c);
+        xwg_load_row<VEC, AGENT>(v3, part + 2 * (q + 3) * D, c);
 #pragma unroll
         for (int v = 0; v < VEC; v++) acc[v] = (((acc[v] + v0[v]) + v1[v]) + v2[v]) + v3[v];
       }
       for (; q < b2; q++) {
         float v0[VEC];
-        load_grad<VEC>(v0, part + 2 * q * D, c, 1.0f, false);
+        xwg_load_row<VEC, AGENT>(v0, part + 2 * q * D, c);
 #pragma unroll
         for (int v = 0; v < VEC; v++) acc[v] = acc[v] + v0[v];
       }
@@ -596,24 +650,81 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
           wrow[c] = __fmaf_rn(-lr, acc[0], wrow[c]);
         }
       } else {
-        if (VEC == 4) reinterpret_cast<float4*>(orow)[c] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        else orow[c] = acc[0];
+        xwg_store_row<VEC, AGENT>(orow, c, acc);
       }
     }
   }
 }
 
+// step 2 + 3 in one launch.  The folds (step 3, below) used to be two more launches; now the LAST tile of a 1024-block to finish
+// folds that block's 32-block partials (release fence + arrival counter + acquire fence: the classic last-arriver reduction),
+// and the last 1024-block of a table to be folded folds the table's 1024-block partials.  Who folds is decided by timing, what is
+// added to what is not: the same additions in the same order as the separate launches.
 template <int VEC>
-__global__ __launch_bounds__(256) void emb_sgd_fold_kernel(const FoldArgs a) {
+__global__ __launch_bounds__(kRedThreads, 8) void emb_sgd_reduce_kernel(const RedArgs a) {
+  __shared__ RedShared sh;
+  __shared__ int s_last;
+  __shared__ uint2 s_fmeta[kFoldStage];
   const int tix = blockIdx.y;
+  const ffh_emb_table& tb = a.t[tix];
+  const uint32_t* keys = a.keys[a.parity[tix]] + (int64_t)tix * a.N;
+  float* p0 = a.partial + (int64_t)tix * 2 * a.nchunks * a.D;
+  uint2* m0 = a.meta + (int64_t)tix * 2 * a.nchunks;
+  reduce_tile_body<VEC, true>(tb, keys, a.pos[a.parity[tix]] + (int64_t)tix * a.N, p0, m0, a.N, a.nchunks, a.tile,
+                        (int)blockIdx.x, a.L, a.D, a.avg != 0, a.lr, sh);
+
   const int nvec = a.D / VEC;
   const int lpr = nvec < 64 ? nvec : 64;
   const int rpw = 64 / lpr;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t group0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * rpw + lane / lpr;
-  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x >> 6) * rpw;
-  fold_table_body<VEC>(a.t[tix], a.pin + (int64_t)tix * 2 * a.nin * a.D, a.min + (int64_t)tix * 2 * a.nin,
-                       a.pout + (int64_t)tix * 2 * a.nout * a.D, a.mout + (int64_t)tix * 2 * a.nout, a.nin, a.ratio, a.D, a.lr, group0, ngroups);
+  const int64_t group0 = (int64_t)wave * rpw + lane / lpr;
+  const int64_t ngroups = (int64_t)(kRedThreads / 64) * rpw;
+  uint32_t* arrive = a.arrive + (int64_t)tix * (a.nchunks1 + 1);
+  float* p1 = a.partial1 + (int64_t)tix * 2 * a.nchunks1 * a.D;
+  uint2* m1 = a.meta1 + (int64_t)tix * 2 * a.nchunks1;
+  constexpr int kRatio = FFH_EMB_CHUNK1 / FFH_EMB_CHUNK;
+
+  // this tile's partials and slots are out (written through, completed), then count it in
+  const int64_t tile0 = (int64_t)blockIdx.x * a.tile;
+  const int64_t B1 = tile0 / FFH_EMB_CHUNK1;
+  const int64_t blk_end = (B1 + 1) * FFH_EMB_CHUNK1 < a.N ? (B1 + 1) * FFH_EMB_CHUNK1 : a.N;
+  const uint32_t tiles_in_block = (uint32_t)((blk_end - B1 * FFH_EMB_CHUNK1 + a.tile - 1) / a.tile);
+  xwg_stores_done();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&arrive[B1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles_in_block - 1u;
+  __syncthreads();
+  if (!s_last) return;
+  // the slot records the fold walks over, fetched by the whole workgroup at once; nothing to fold (the usual case on the big
+  // tables, whose rows are hit once): no walk at all
+  auto stage = [&](const uint2* m, int64_t lo, int64_t hi) -> bool {
+    const int n = (int)(hi - lo < kFoldStage ? hi - lo : kFoldStage);
+    bool any = false;
+    for (int i = threadIdx.x; i < n; i += kRedThreads) {
+      const uint2 v = xwg_load2<true>(m + lo + i);
+      s_fmeta[i] = v;
+      any |= v.x != kMetaNone;
+    }
+    for (int64_t i = lo + kFoldStage + threadIdx.x; i < hi; i += kRedThreads) any |= xwg_load2<true>(m + i).x != kMetaNone;   // (beyond the stage: N > 512 K)
+    return __syncthreads_or(any);
+  };
+  if (a.nchunks1 > 1) {
+    const int64_t lo = 2 * B1 * kRatio;
+    const int64_t hi = lo + 2 * kRatio < 2 * (int64_t)a.nchunks ? lo + 2 * kRatio : 2 * (int64_t)a.nchunks;
+    if (stage(m0, lo, hi))
+      fold_table_body<VEC, true>(tb, p0, m0, p1, m1, a.nchunks, kRatio, a.D, a.lr, lo, hi, group0, ngroups, keys, s_fmeta, lo, (int)(hi - lo));
+    xwg_stores_done();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&arrive[a.nchunks1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)a.nchunks1 - 1u;
+    __syncthreads();
+    if (!s_last) return;
+    const int64_t hi1 = 2 * (int64_t)a.nchunks1;
+    if (stage(m1, 0, hi1))
+      fold_table_body<VEC, true>(tb, p1, m1, p1, m1, a.nchunks1, 0, a.D, a.lr, 0, hi1, group0, ngroups, nullptr, s_fmeta, 0, (int)(hi1 < kFoldStage ? hi1 : kFoldStage));
+  } else {
+    const int64_t hi0 = 2 * (int64_t)a.nchunks;
+    if (stage(m0, 0, hi0))
+      fold_table_body<VEC, true>(tb, p0, m0, p1, m1, a.nchunks, 0, a.D, a.lr, 0, hi0, group0, ngroups, nullptr, s_fmeta, 0, (int)hi0);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -721,7 +832,7 @@ __global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const Smal
   const int team = threadIdx.x / kRedThreads, ttid = threadIdx.x % kRedThreads;
   const int ntiles = (int)((N + a.tile - 1) / a.tile);
   for (int t0 = 0; t0 < ntiles; t0 += kSmallRedParts) {
-    reduce_tile_body<VEC>(tb, keys, posg, p0, m0, N, a.nch0, a.tile, t0 + team, a.L, a.D, a.avg != 0, a.lr, sm.red[team], ttid);
+    reduce_tile_body<VEC, false>(tb, keys, posg, p0, m0, N, a.nch0, a.tile, t0 + team, a.L, a.D, a.avg != 0, a.lr, sm.red[team], ttid);
     __syncthreads();
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -735,13 +846,13 @@ __global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const Smal
   const int64_t ngroups = (int64_t)NW * rpw;
   float* p1 = a.partial1 + (int64_t)tix * 2 * a.nch1 * a.D;
   if (a.nch1 > 1) {
-    fold_table_body<VEC>(tb, p0, m0, p1, m1, a.nch0, FFH_EMB_CHUNK1 / FFH_EMB_CHUNK, a.D, a.lr, group0, ngroups);
+    fold_table_body<VEC, false>(tb, p0, m0, p1, m1, a.nch0, FFH_EMB_CHUNK1 / FFH_EMB_CHUNK, a.D, a.lr, 0, 2 * (int64_t)a.nch0, group0, ngroups);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    fold_table_body<VEC>(tb, p1, m1, p1, m1, a.nch1, 0, a.D, a.lr, group0, ngroups);
+    fold_table_body<VEC, false>(tb, p1, m1, p1, m1, a.nch1, 0, a.D, a.lr, 0, 2 * (int64_t)a.nch1, group0, ngroups);
   } else {
-    fold_table_body<VEC>(tb, p0, m0, p1, m1, a.nch0, 0, a.D, a.lr, group0, ngroups);
+    fold_table_body<VEC, false>(tb, p0, m0, p1, m1, a.nch0, 0, a.D, a.lr, 0, 2 * (int64_t)a.nch0, group0, ngroups);
   }
 }
 
@@ -750,7 +861,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct BwdLayout {
-  size_t keys_a, pos_a, keys_b, pos_b, hist, partial, meta, partial1, meta1, total;
+  size_t keys_a, pos_a, keys_b, pos_b, hist, partial, meta, partial1, meta1, arrive, total;
   int nblk, nchunks, nchunks1;
 };
 
@@ -788,6 +899,7 @@ inline BwdLayout bwd_layout(int nt, int L, int D, int64_t batch) {
   l.nchunks1 = (int)((N + FFH_EMB_CHUNK1 - 1) / FFH_EMB_CHUNK1);
   l.partial1 = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks1 * (size_t)D * sizeof(float), 256);
   l.meta1 = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks1 * sizeof(uint2), 256);
+  l.arrive = o; o += align_up((size_t)nt * ((size_t)l.nchunks1 + 1) * sizeof(uint32_t), 256);
   l.total = o;
   return l;
 }
@@ -956,6 +1068,8 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
   }
   sa.hist = (uint32_t*)(ws + lay.hist);
   sa.N = N; sa.nblk = lay.nblk; sa.bits = rb;
+  sa.clear[0] = (uint32_t*)(ws + lay.meta1); sa.nclear[0] = 4 * lay.nchunks1;     // uint2 slots, two per 1024-block
+  sa.clear[1] = (uint32_t*)(ws + lay.arrive); sa.nclear[1] = lay.nchunks1 + 1;
   uint32_t* kbuf[2] = {(uint32_t*)(ws + lay.keys_a), (uint32_t*)(ws + lay.keys_b)};
   uint32_t* pbuf[2] = {(uint32_t*)(ws + lay.pos_a), (uint32_t*)(ws + lay.pos_b)};
   dim3 sgrid((unsigned)lay.nblk, (unsigned)nt);
@@ -988,31 +1102,13 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
   ra.N = N; ra.nchunks = lay.nchunks; ra.L = L; ra.D = D;
   ra.avg = aggr == FFH_AGGR_MODE_AVG ? 1 : 0;
   ra.lr = lr;
+  ra.partial1 = (float*)(ws + lay.partial1);
   ra.meta1 = (uint2*)(ws + lay.meta1); ra.nchunks1 = lay.nchunks1;
+  ra.arrive = (uint32_t*)(ws + lay.arrive);
+  // segmented sums + both folds (32-block partials -> 1024-block partials -> row totals) + the SGD step: one launch
   dim3 rgrid((unsigned)((N + ra.tile - 1) / ra.tile), (unsigned)nt);
-  const int lpr = nvec < 64 ? nvec : 64;
   if (v4) hipLaunchKernelGGL((emb_sgd_reduce_kernel<4>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
   else hipLaunchKernelGGL((emb_sgd_reduce_kernel<1>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
-  // folds: 32-block partials -> 1024-block partials -> row totals (the second level only exists for N > 1024)
-  FoldArgs fa;
-  memset(&fa, 0, sizeof fa);
-  for (int i = 0; i < nt; i++) fa.t[i] = tables[i];
-  fa.D = D; fa.lr = lr;
-  const int groups_per_block = 4 * (64 / lpr);
-  auto launch_fold = [&](const float* pin, const uint2* min, int nin, float* pout, uint2* mout, int nout, int ratio) {
-    fa.pin = pin; fa.min = min; fa.nin = nin; fa.pout = pout; fa.mout = mout; fa.nout = nout; fa.ratio = ratio;
-    dim3 fgrid((unsigned)ffh_grid(2LL * nin, groups_per_block, 1024), (unsigned)nt);
-    if (v4) hipLaunchKernelGGL((emb_sgd_fold_kernel<4>), fgrid, dim3(256), 0, as_stream(s), fa);
-    else hipLaunchKernelGGL((emb_sgd_fold_kernel<1>), fgrid, dim3(256), 0, as_stream(s), fa);
-  };
-  float* p1 = (float*)(ws + lay.partial1);
-  uint2* m1 = (uint2*)(ws + lay.meta1);
-  if (lay.nchunks1 > 1) {
-    launch_fold(ra.partial, ra.meta, lay.nchunks, p1, m1, lay.nchunks1, FFH_EMB_CHUNK1 / FFH_EMB_CHUNK);
-    launch_fold(p1, m1, lay.nchunks1, p1, m1, 1, 0);
-  } else {
-    launch_fold(ra.partial, ra.meta, lay.nchunks, p1, m1, 1, 0);
-  }
   FFH_LAUNCH_CHECK(c, "emb_sgd_reduce/fold");
   return FFH_OK;
 }
