@@ -586,8 +586,13 @@ def main():
         out["roofline"]["bytes_per_sample"] = fwd_bytes // B
         out["roofline"]["tables_in_launch"] = owned
         out["kernels"]["embedding_bwd_sgd_fused"] = hbm_block(
-            "radix_hist/radix_scatter (LDS-histogram LSD radix sort of the ids) + emb_sgd_reduce (segmented sum + W -= lr*sum) + emb_sgd_fold; "
-            "batch x bag <= 2048 per table: emb_sgd_small_kernel, one launch", bwd_bytes, t_bwd, pmc.get("update_bytes_per_call"), src, in_step_sec=t_bwd_in)
+            "radix_hist/radix_scatter (LDS-histogram LSD radix sort of the ids) + emb_sgd_reduce (segmented sums, both folds by the last tile "
+            "to arrive, W -= lr*sum); batch x bag <= 2048 per table: emb_sgd_small_kernel, one launch", bwd_bytes, t_bwd,
+            pmc.get("update_bytes_per_call"), src, in_step_sec=t_bwd_in)
+        if "--no-early-sort" not in args.shim_flags.split():
+            out["kernels"]["embedding_bwd_sgd_fused"]["in_step_covers"] = (
+                "the apply phase only (ffh_embedding_bwd_sgd_apply_multi): inside a step the index-only sort is issued behind the gather "
+                "(ffh_embedding_bwd_sort_multi, --no-early-sort turns that off); us_per_launch above is the whole update, sort included")
     if solo:
         flops = mlp_flops_per_sample(w) * B
         peak = BF16_PEAK_TFLOPS if bf16 else F32_PEAK_TFLOPS

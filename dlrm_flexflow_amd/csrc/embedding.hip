@@ -133,10 +133,8 @@ constexpr int kMaxRadix = 1 << kMaxRadixBits;
 
 struct SortArgs {
   const int64_t* idx[FFH_MAX_TABLES];   // pass 0 source
-  uint32_t* keys_src;                   // [nt][N]
-  uint32_t* pos_src;
-  uint32_t* keys_dst;
-  uint32_t* pos_dst;
+  const uint2* src;                     // [nt][N] {row id, position}: ONE 8-byte element per entry -- a pass scatters one store per
+  uint2*    dst;                        //   entry instead of two 4-byte ones into two arrays (the scattered stores are most of a pass)
   uint32_t* hist;                       // [nt][nblk][radix]
   int64_t   N;                          // entries per table (batch * L)
   int       nblk;
@@ -151,7 +149,7 @@ struct SortArgs {
 template <bool FIRST>
 __device__ __forceinline__ uint32_t sort_load_key(const SortArgs& a, int t, int64_t i) {
   if (FIRST) return (uint32_t)a.idx[t][i];
-  return a.keys_src[(int64_t)t * a.N + i];
+  return a.src[(int64_t)t * a.N + i].x;
 }
 
 // histogram of the current digit per 2048-entry tile (LDS-staged bucketing)
@@ -237,10 +235,12 @@ __device__ __forceinline__ void sort_scan_offsets(const uint32_t (&all_d)[QN], c
 
 // stable ranking of a wave's E x 64 entries, 64 at a time: the lanes holding the same digit find each other with
 // `bits` ballots (a match-any), the rank inside the group is a popcount of the lower lanes, and the group's
-// lowest lane advances the wave's running offset in LDS.  kd / pd may point to LDS or to global memory.
-template <int E>
+// lowest lane advances the wave's running offset in LDS.  `out.put(dest, key, pos)` stores an entry (SortOutGlobal / SortOutLds).
+struct SortOutGlobal { uint2* kp; __device__ __forceinline__ void put(uint32_t d, uint32_t k, uint32_t p) const { kp[d] = make_uint2(k, p); } };
+struct SortOutLds { uint32_t* k; uint32_t* p; __device__ __forceinline__ void put(uint32_t d, uint32_t key, uint32_t pos) const { k[d] = key; p[d] = pos; } };
+template <int E, class Out>
 __device__ __forceinline__ void sort_rank_and_scatter(const uint32_t (&key)[E], const uint32_t (&pos)[E], const bool (&valid)[E],
-                                                      int shift, int bits, uint32_t mask, uint32_t* wave_off, uint32_t* kd, uint32_t* pd) {
+                                                      int shift, int bits, uint32_t mask, uint32_t* wave_off, const Out out) {
   const int lane = threadIdx.x & 63;
   volatile uint32_t* my_off = wave_off;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -257,8 +257,7 @@ __device__ __forceinline__ void sort_rank_and_scatter(const uint32_t (&key)[E], 
       const uint32_t base = my_off[d];
       const uint32_t rank = __popcll(peers & lt_mask);
       const uint32_t dest = base + rank;
-      kd[dest] = key[e];
-      pd[dest] = pos[e];
+      out.put(dest, key[e], pos[e]);
       if (rank == 0) my_off[d] = base + __popcll(peers);
     }
     __builtin_amdgcn_wave_barrier();
@@ -292,8 +291,13 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
   for (int e = 0; e < kSortPerThread; e++) {
     const int64_t i = tile0 + wave * (kSortTile / 4) + e * 64 + lane;
     valid[e] = i < a.N;
-    key[e] = valid[e] ? sort_load_key<FIRST>(a, t, i) : 0u;
-    pos[e] = valid[e] ? (FIRST ? (uint32_t)i : a.pos_src[(int64_t)t * a.N + i]) : 0u;
+    if (FIRST) {
+      key[e] = valid[e] ? (uint32_t)a.idx[t][i] : 0u;
+      pos[e] = (uint32_t)i;
+    } else {
+      const uint2 kp = valid[e] ? a.src[(int64_t)t * a.N + i] : make_uint2(0u, 0u);
+      key[e] = kp.x; pos[e] = kp.y;
+    }
     if (valid[e]) atomicAdd(&s_off[wave][(key[e] >> a.shift) & mask], 1u);
   }
   __syncthreads();
@@ -324,8 +328,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
     }
   }
   sort_scan_offsets<4, 2>(all_d, before_d, radix, s_off, s_scan, s_wsum);
-  sort_rank_and_scatter<kSortPerThread>(key, pos, valid, a.shift, a.bits, mask, s_off[wave], a.keys_dst + (int64_t)t * a.N,
-                                        a.pos_dst + (int64_t)t * a.N);
+  sort_rank_and_scatter<kSortPerThread>(key, pos, valid, a.shift, a.bits, mask, s_off[wave], SortOutGlobal{a.dst + (int64_t)t * a.N});
 }
 
 // ---------------------------------------------------------------------------
@@ -340,8 +343,7 @@ enum : uint32_t { kMetaNone = 0, kMetaFirst = 1, kMetaCont = 2 };
 
 struct RedArgs {
   ffh_emb_table t[FFH_MAX_TABLES];
-  const uint32_t* keys[2];  // sorted [nt][N]: table t ends in buffer parity[t]
-  const uint32_t* pos[2];
+  const uint2* kp[2];       // sorted {row id, position} [nt][N]: table t ends in buffer parity[t]
   uint8_t   parity[FFH_MAX_TABLES];
   int       tile;           // sorted entries per workgroup: multiple of FFH_EMB_CHUNK, <= kRedTile
   float*    partial;        // level-0 partial rows [nt][2*nchunks][D] (2 slots per FFH_EMB_CHUNK block)
@@ -430,7 +432,7 @@ struct RedShared {
 
 // one tile of one table; `partial_t` / `meta_t` are the table's level-0 slot arrays
 template <int VEC, bool AGENT>
-__device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const uint32_t* keys, const uint32_t* posg,
+__device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const uint2* kp,
                                                  float* partial_t, uint2* meta_t, int64_t N, int nchunks, int tile, int tile_index,
                                                  int L, int D_, bool avg_, float lr_, RedShared& sh, const int tid = threadIdx.x) {
   uint32_t* s_key = sh.key;
@@ -444,13 +446,13 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
   const int lane = tid & 63, wave = tid >> 6;
 
   for (int i = tid; i < n; i += kRedThreads) {
-    s_key[1 + i] = keys[tile0 + i];
-    const uint32_t p = posg[tile0 + i];
-    s_pos[i] = a.L == 1 ? p : p / (uint32_t)a.L;      // the sample (gradient row) of the entry
+    const uint2 e = kp[tile0 + i];
+    s_key[1 + i] = e.x;
+    s_pos[i] = a.L == 1 ? e.y : e.y / (uint32_t)a.L;      // the sample (gradient row) of the entry
   }
   if (tid == 0) {
-    s_key[0] = (tile0 > 0 && tile0 < N) ? keys[tile0 - 1] : 0xFFFFFFFFu;   // no valid key equals it when tile0 == 0 (checked below)
-    s_key[1 + n] = (tile0 + n < N) ? keys[tile0 + n] : 0xFFFFFFFFu;
+    s_key[0] = (tile0 > 0 && tile0 < N) ? kp[tile0 - 1].x : 0xFFFFFFFFu;   // no valid key equals it when tile0 == 0 (checked below)
+    s_key[1 + n] = (tile0 + n < N) ? kp[tile0 + n].x : 0xFFFFFFFFu;
   }
   const int metas = 2 * (tile / FFH_EMB_CHUNK);
   if (tid < metas) s_meta[tid] = make_uint2(kMetaNone, 0);
@@ -568,7 +570,7 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
 template <int VEC, bool AGENT>
 __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const float* part, const uint2* meta, float* pout_t, uint2* mout_t,
                                                 int nin, int ratio, int D, float lr, int64_t slot_lo, int64_t slot_hi,
-                                                int64_t group0, int64_t ngroups, const uint32_t* keys = nullptr,
+                                                int64_t group0, int64_t ngroups, const uint2* keys = nullptr,
                                                 const uint2* staged = nullptr, int64_t staged_lo = 0, int staged_n = 0) {
   // `staged`: an LDS copy of meta[staged_lo, staged_lo + staged_n) the caller fetched with one parallel load (the in-kernel folds:
   // a dependent memory round trip per slot and lane-group would otherwise be most of the fold)
@@ -612,7 +614,7 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
     if (b2 == bend && bend < nin) {
       // the run reached the end of the block: it continues iff the entry behind the block carries the same id (sorted list);
       // equivalently the next block's first slot is a continuation of this id
-      if (keys) cont_after = keys[bend * FFH_EMB_CHUNK] == m.y;
+      if (keys) cont_after = keys[bend * FFH_EMB_CHUNK].x == m.y;
       else { const uint2 m3 = slot_meta(2 * bend); cont_after = (m3.x == kMetaCont && m3.y == m.y); }
     }
     const bool head = m.x == kMetaFirst;
@@ -667,10 +669,10 @@ __global__ __launch_bounds__(kRedThreads, 8) void emb_sgd_reduce_kernel(const Re
   __shared__ uint2 s_fmeta[kFoldStage];
   const int tix = blockIdx.y;
   const ffh_emb_table& tb = a.t[tix];
-  const uint32_t* keys = a.keys[a.parity[tix]] + (int64_t)tix * a.N;
+  const uint2* keys = a.kp[a.parity[tix]] + (int64_t)tix * a.N;
   float* p0 = a.partial + (int64_t)tix * 2 * a.nchunks * a.D;
   uint2* m0 = a.meta + (int64_t)tix * 2 * a.nchunks;
-  reduce_tile_body<VEC, true>(tb, keys, a.pos[a.parity[tix]] + (int64_t)tix * a.N, p0, m0, a.N, a.nchunks, a.tile,
+  reduce_tile_body<VEC, true>(tb, keys, p0, m0, a.N, a.nchunks, a.tile,
                         (int)blockIdx.x, a.L, a.D, a.avg != 0, a.lr, sh);
 
   const int nvec = a.D / VEC;
@@ -737,8 +739,7 @@ constexpr int kSmallMax = 2048;
 struct SmallArgs {
   ffh_emb_table t[FFH_MAX_TABLES];
   uint8_t   npass[FFH_MAX_TABLES];
-  uint32_t* keys;      // [nt][N] sorted row ids   (workspace)
-  uint32_t* pos;       // [nt][N] their positions
+  uint2*    kp;        // [nt][N] sorted {row id, position}   (workspace)
   float*    partial0;  uint2* meta0;   // level-0 slots [nt][2*nch0]
   float*    partial1;  uint2* meta1;   // level-1 slots [nt][2*nch1]
   int64_t   N;
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const Smal
       all_d[0] = t;
     }
     sort_scan_offsets<NW, 1>(all_d, before_d, radix, s_off, sm.sort.scan, sm.sort.wsum);
-    sort_rank_and_scatter<E>(key, pos, valid, shift, a.rb, mask, s_off[wave], s_k, s_p);
+    sort_rank_and_scatter<E>(key, pos, valid, shift, a.rb, mask, s_off[wave], SortOutLds{s_k, s_p});
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < E; e++) {
@@ -813,12 +814,11 @@ __global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const Smal
     }
     __syncthreads();
   }
-  uint32_t* keys = a.keys + (int64_t)tix * N;
-  uint32_t* posg = a.pos + (int64_t)tix * N;
+  uint2* keys = a.kp + (int64_t)tix * N;
 #pragma unroll
   for (int e = 0; e < E; e++) {
     const int i = wave * (kSmallMax / NW) + e * 64 + lane;
-    if (valid[e]) { keys[i] = key[e]; posg[i] = pos[e]; }
+    if (valid[e]) keys[i] = make_uint2(key[e], pos[e]);
   }
   uint2* m1 = a.meta1 + (int64_t)tix * 2 * a.nch1;
   for (int i = threadIdx.x; i < 2 * a.nch1; i += kSmallThreads) m1[i] = make_uint2(kMetaNone, 0);
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const Smal
   const int team = threadIdx.x / kRedThreads, ttid = threadIdx.x % kRedThreads;
   const int ntiles = (int)((N + a.tile - 1) / a.tile);
   for (int t0 = 0; t0 < ntiles; t0 += kSmallRedParts) {
-    reduce_tile_body<VEC, false>(tb, keys, posg, p0, m0, N, a.nch0, a.tile, t0 + team, a.L, a.D, a.avg != 0, a.lr, sm.red[team], ttid);
+    reduce_tile_body<VEC, false>(tb, keys, p0, m0, N, a.nch0, a.tile, t0 + team, a.L, a.D, a.avg != 0, a.lr, sm.red[team], ttid);
     __syncthreads();
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -861,7 +861,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct BwdLayout {
-  size_t keys_a, pos_a, keys_b, pos_b, hist, partial, meta, partial1, meta1, arrive, total;
+  size_t kp_a, kp_b, hist, partial, meta, partial1, meta1, arrive, total;
   int nblk, nchunks, nchunks1;
 };
 
@@ -887,12 +887,10 @@ inline BwdLayout bwd_layout(int nt, int L, int D, int64_t batch) {
   const int sort_tile = kSortThreads * sort_per_thread(nt, N);
   l.nblk = (int)((N + sort_tile - 1) / sort_tile);
   l.nchunks = (int)((N + FFH_EMB_CHUNK - 1) / FFH_EMB_CHUNK);
-  const size_t arr = align_up((size_t)nt * (size_t)N * sizeof(uint32_t), 256);
+  const size_t arr = align_up((size_t)nt * (size_t)N * sizeof(uint2), 256);
   size_t o = 0;
-  l.keys_a = o; o += arr;
-  l.pos_a = o; o += arr;
-  l.keys_b = o; o += arr;
-  l.pos_b = o; o += arr;
+  l.kp_a = o; o += arr;
+  l.kp_b = o; o += arr;
   l.hist = o; o += align_up((size_t)nt * (size_t)l.nblk * kMaxRadix * sizeof(uint32_t), 256);
   l.partial = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks * (size_t)D * sizeof(float), 256);
   l.meta = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks * sizeof(uint2), 256);
@@ -1035,7 +1033,7 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
       while (tb < 32 && ((tables[i].num_entries - 1) >> tb) != 0) tb++;
       sm.npass[i] = (uint8_t)((tb + rb_s - 1) / rb_s);
     }
-    sm.keys = (uint32_t*)(ws + lay.keys_a); sm.pos = (uint32_t*)(ws + lay.pos_a);
+    sm.kp = (uint2*)(ws + lay.kp_a);
     sm.partial0 = (float*)(ws + lay.partial); sm.meta0 = (uint2*)(ws + lay.meta);
     sm.partial1 = (float*)(ws + lay.partial1); sm.meta1 = (uint2*)(ws + lay.meta1);
     sm.N = N; sm.nch0 = lay.nchunks; sm.nch1 = lay.nchunks1; sm.rb = rb_s; sm.L = L; sm.D = D;
@@ -1070,16 +1068,15 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
   sa.N = N; sa.nblk = lay.nblk; sa.bits = rb;
   sa.clear[0] = (uint32_t*)(ws + lay.meta1); sa.nclear[0] = 4 * lay.nchunks1;     // uint2 slots, two per 1024-block
   sa.clear[1] = (uint32_t*)(ws + lay.arrive); sa.nclear[1] = lay.nchunks1 + 1;
-  uint32_t* kbuf[2] = {(uint32_t*)(ws + lay.keys_a), (uint32_t*)(ws + lay.keys_b)};
-  uint32_t* pbuf[2] = {(uint32_t*)(ws + lay.pos_a), (uint32_t*)(ws + lay.pos_b)};
+  uint2* kbuf[2] = {(uint2*)(ws + lay.kp_a), (uint2*)(ws + lay.kp_b)};
   dim3 sgrid((unsigned)lay.nblk, (unsigned)nt);
   const int E = sort_per_thread(nt, N);
   for (int p = 0; p < passes && do_sort; p++) {
     sa.shift = p * rb;
     sa.pass = p;
     // pass p reads buffer p%2 (pass 0: the int64 ids) and writes buffer (p+1)%2
-    sa.keys_src = kbuf[p & 1]; sa.pos_src = pbuf[p & 1];
-    sa.keys_dst = kbuf[(p + 1) & 1]; sa.pos_dst = pbuf[(p + 1) & 1];
+    sa.src = kbuf[p & 1];
+    sa.dst = kbuf[(p + 1) & 1];
 #define FFH_SORT_PASS(FIRSTV, EV)                                                                              \
     hipLaunchKernelGGL((radix_hist_kernel<FIRSTV, EV>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);      \
     hipLaunchKernelGGL((radix_scatter_kernel<FIRSTV, EV>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
@@ -1094,8 +1091,7 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
   if (!do_apply) return FFH_OK;
 
   for (int i = 0; i < nt; i++) ra.t[i] = tables[i];
-  ra.keys[0] = kbuf[0]; ra.keys[1] = kbuf[1];
-  ra.pos[0] = pbuf[0]; ra.pos[1] = pbuf[1];
+  ra.kp[0] = kbuf[0]; ra.kp[1] = kbuf[1];
   ra.tile = reduce_tile(nt, N);
   ra.partial = (float*)(ws + lay.partial);
   ra.meta = (uint2*)(ws + lay.meta);
