@@ -353,10 +353,10 @@ def bf16_mode_block(ffmodel, w, local_rank, B, split=False):
                 "samples_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mlp_tflops_over_whole_step_fp32_equivalent": round(flops / dt / 1e12, 1),
                 "x_fp32_mfma_peak_over_whole_step": round(flops / dt / 1e12 / F32_PEAK_TFLOPS, 3), "linear_largest_layer": blk}
     return {"flag": "--allow-tensor-op-math-conversion (ffh_ctx_set_math_mode(FFH_MATH_TENSOR_OP_BF16))",
-            "dtype": "bf16 GEMM operands rounded from fp32 in the kernel, fp32 accumulate, fp32 master weights and activations in HBM",
+            "dtype": "bf16 GEMM operands, fp32 accumulate; fp32 master weights / activations / gradients in HBM with bfloat16 twins kept by their producers (ffh_ctx_bf16_mirror_set), which the big layers' LDS-DMA GEMMs read",
             "samples_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 4), "mlp_tflops_over_whole_step": round(flops / dt / 1e12, 1),
             "linear_largest_layer": blk,
-            "note": "operands stay fp32 in memory, so the kernel is bound by the global->LDS staging path (32 flop per staged byte), not by the bf16 matrix pipe"}
+            "note": "results are fp32 sums of products of bf16-rounded operands, held to the oracle run in the same mode and to a stated 2^-8 bound against the exact mode (tests/test_bf16_mode.py); layers below the twin size round their 4-byte operands between the global load and the LDS store"}
 
 
 def kaggle_secondary(ffmodel, local_rank):

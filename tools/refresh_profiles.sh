@@ -6,6 +6,10 @@ cd /tmp && export TMPDIR=/tmp; cd $R
 P=${P:-r03}
 line() { grep '^{' | tail -1; }
 
+# 0. HBM traffic of the embedding kernels first (two counter-only passes): the bench lines below quote it, and warn when the file on
+#    disk names kernels the library no longer has
+bash tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1; cp gpurun_out/pmc_traffic/pmc_traffic.json $O/${P}_pmc_traffic.json; cp $O/${P}_pmc_traffic.json profiles/${P}_pmc_traffic.json
+
 # 1. the default command, unprofiled: headline + roofline + kernels (bf16 mode, Kaggle secondary) + cpu_baseline
 python3 bench.py 2> $O/bench_default.err | line > $O/${P}_bench_terabyte.json
 
@@ -19,8 +23,7 @@ for k in emb_fwd_kernel emb_sgd_reduce_kernel radix_scatter_kernel "gemm_sk_kern
 done > $O/${P}_bench_terabyte_probe_averages.txt
 find $O/prof -name "*.csv" -size +10M -delete
 
-# 3. HBM traffic of the embedding kernels (two counter-only passes) and SQ counters of the step's kernels
-bash tools/pmc_traffic.sh > $O/pmc_traffic.log 2>&1; cp gpurun_out/pmc_traffic/pmc_traffic.json $O/${P}_pmc_traffic.json
+# 3. SQ counters of the step's kernels
 bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.json $O/${P}_pmc_sq_counters_step.json
 bash tools/pmc_gemm.sh > $O/pmc_gemm.log 2>&1; cp gpurun_out/pmc_gemm/summary.json $O/${P}_pmc_sq_counters.json
 
