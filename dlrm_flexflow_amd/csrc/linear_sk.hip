@@ -70,8 +70,13 @@ __device__ __forceinline__ void sk_static_for(F&& f) { sk_static_for_impl(std::m
 
 #define SK_PIN() __builtin_amdgcn_sched_barrier(0)
 
-constexpr int SK_EP_LD = 68;                       // floats per row of a wave's 64 x 64 epilogue image (DW): 64 + 4 of padding
-constexpr int SK_EP_WAVE = 64 * SK_EP_LD * 4;     // bytes per wave
+constexpr int SK_EP_LD = 68;                       // floats per row of a wave's epilogue image (DW): 64 + 4 of padding
+constexpr int SK_EP_ROWS = 16;                     // rows of the wave's 64 x 64 result that pass through the image at a time (the rows the lanes of
+                                                   // one q hold): 4 rounds.  With all 64 rows at once the kernel held 135 KB of LDS and the 33-37 KB
+                                                   // workgroups of the small layers' GEMMs could not start beside it (at 4096 samples the bottom MLP's
+                                                   // backward waited ~200 us of a 1.2 ms step for the big weight-gradient GEMM's workgroups to leave);
+                                                   // a segment ends once or twice per workgroup, so the rounds cost nothing
+constexpr int SK_EP_WAVE = SK_EP_ROWS * SK_EP_LD * 4;     // bytes per wave
 
 template <bool AKR, bool BKR, int EPI, bool DB = false>
 __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
@@ -245,8 +250,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
           if constexpr (EPI == SK_EPI_DW_ATOMIC) {
             // through a per-wave LDS image so that one atomic instruction covers 256 contiguous bytes of one row (the shape at
             // which memory-side float atomics run at their full rate; 4-byte pieces 16 bytes apart run ~10x slower)
-            (void)cptr;
-            *reinterpret_cast<f32x4*>(sk_lds + LDS_A + (BKR ? SK_LDS_KR : SK_LDS_KC) + wave * SK_EP_WAVE + ((16 * q + 4 * i + tm) * SK_EP_LD + 4 * c16) * 4) = v;
+            (void)cptr; (void)v;          // below: 16 rows at a time
           } else if constexpr (EPI == SK_EPI_FWD) {
             v += bv;
             v.x = act_apply(v.x, g.act); v.y = act_apply(v.y, g.act); v.z = act_apply(v.z, g.act); v.w = act_apply(v.w, g.act);
@@ -262,10 +266,23 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
         }
     }
     if constexpr (EPI == SK_EPI_DW_ATOMIC) {
-      const float* ep = reinterpret_cast<const float*>(sk_lds + LDS_A + (BKR ? SK_LDS_KR : SK_LDS_KC) + wave * SK_EP_WAVE);
+      // through a per-wave LDS image so that one atomic instruction covers 256 contiguous bytes of one row
+      float* const ep = reinterpret_cast<float*>(sk_lds + LDS_A + (BKR ? SK_LDS_KR : SK_LDS_KC) + wave * SK_EP_WAVE);
       float* crow = g.C + (int64_t)((int)cp.m0 + 64 * wy) * g.ldc + (int)cp.n0 + 64 * wx + lane;
-#pragma unroll 8
-      for (int r = 0; r < 64; r++) atomicAdd(crow + (int64_t)r * g.ldc, ep[r * SK_EP_LD + lane]);     // the wave's own image: no barrier
+#pragma unroll
+      for (int p = 0; p < 4; p++) {            // rows 16 p .. 16 p + 15 of the wave's result are held by the lanes with q == p
+        if (q == p) {
+#pragma unroll
+          for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              *reinterpret_cast<f32x4*>(ep + (4 * i + tm) * SK_EP_LD + 4 * c16) = f32x4{acc[tm][0][i], acc[tm][1][i], acc[tm][2][i], acc[tm][3][i]};
+        }
+        __builtin_amdgcn_wave_barrier();       // the wave's own image: no workgroup barrier (a wave's ds operations complete in order)
+#pragma unroll
+        for (int r = 0; r < 16; r++) atomicAdd(crow + (int64_t)(16 * p + r) * g.ldc, ep[r * SK_EP_LD + lane]);
+        __builtin_amdgcn_wave_barrier();
+      }
       if constexpr (DB) {
         if (cp.n0 == 0 && wx == 0) {          // wave-uniform: the first column of tiles owns the bias gradient
           f32x4 t = bsum;
