@@ -60,6 +60,33 @@ def test_sort_then_apply_equals_fused_and_oracle(hip, oracle, B, L, D, rows):
         assert out[1][t].tobytes() == exp.tobytes(), f"table {t}: differs from the oracle"
 
 
+@pytest.mark.parametrize("B,L,D,rows", [
+    (262144, 4, 4, (3, 70000)),        # 1 M lookups per table: 1024 blocks of 1024 -> 2048 level-1 slots, twice what the fold stages in LDS
+    (40000, 16, 8, (1,)),              # every lookup on one row: one run through all 625 blocks
+])
+def test_folds_inside_the_reduce_launch_beyond_the_staged_slots(hip, oracle, B, L, D, rows):
+    """The folds run in the tail of the reduce launch, by whichever tile / 1024-block arrives last, from slot records staged in LDS
+    (1024 at a time); a table with more 1024-block slots than that reads the rest straight from memory.  Bit for bit against the
+    oracle's canonical order [include/ff_hip.h, ffh_embedding_bwd_sgd_fused], SUM and AVG."""
+    rng = np.random.default_rng(B + L)
+    T = len(rows)
+    ws = torch.empty(hip.lib.ffh_embedding_bwd_workspace_bytes(T, L, D, B) + 256, dtype=torch.uint8, device=DEV)
+    hip.set_workspace(ws, ws.numel())
+    Wn = [rng.uniform(-1, 1, (r, D)).astype(np.float32) for r in rows]
+    In = [rng.integers(0, r, (B, L)) for r in rows]
+    Gn = [rng.uniform(-1, 1, (B, D)).astype(np.float32) for _ in rows]
+    I = [torch.from_numpy(i).to(DEV) for i in In]
+    G = [torch.from_numpy(g).to(DEV) for g in Gn]
+    for aggr in (capi.AGGR_MODE_SUM, capi.AGGR_MODE_AVG):
+        W = [torch.from_numpy(w).to(DEV) for w in Wn]
+        arr = _tables(hip, I, W, G, rows)
+        hip.check(hip.lib.ffh_embedding_bwd_sgd_fused_multi(hip.ctx, arr, T, L, D, B, aggr, 1e-3, None), "fused")
+        torch.cuda.synchronize()
+        for t in range(T):
+            exp = oracle.embedding_bwd_sgd_fused(In[t], Gn[t], Wn[t], 1e-3, aggr=aggr)
+            assert W[t].cpu().numpy().tobytes() == exp.tobytes(), f"table {t}, aggr {aggr}: differs from the oracle"
+
+
 def test_sort_call_validates_like_the_fused_call(hip):
     B, D = 4096, 16
     I = [torch.zeros(B, 1, dtype=torch.int64, device=DEV)]
