@@ -428,6 +428,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus {args.gpus}` (it starts its own ranks) or\n"
                          f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
                          f"--master-port 29511 bench.py --gpus {args.gpus} --steps {args.steps} --warmup {args.warmup}")
+    # multi-process GPU work on this pool needs dmabuf IPC (hipIpcGetMemHandle fails under the legacy mode): spawn_ranks() sets it for its
+    # children, a torchrun launch inherits the shell's -- make sure it is there before anything initialises the GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     if args.dry_run:                   # launcher test (CPU): the ranks meet over gloo, rank 0 reports what it saw
