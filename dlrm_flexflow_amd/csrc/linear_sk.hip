@@ -318,6 +318,18 @@ struct SkPlan { int64_t lda, ldb, a_bytes, b_bytes; int G; };
 bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
   static const int off = getenv("FFH_GEMM_NO_SK") ? atoi(getenv("FFH_GEMM_NO_SK")) : 0;   // A/B switch (tools/ab.sh)
   if (off) return false;
+  {
+    // The backward GEMMs of a layer with fewer than 256 x 256 weights stay with the register-staged kernels: their workgroups
+    // (33-37 KB of LDS, 100-160 registers) fit on a CU beside a persistent one, a second persistent workgroup does not (registers).  In
+    // the DLRM step that layer is the bottom MLP's last one, whose backward is launched while the first top layer's stream-K weight
+    // gradient holds a workgroup on every CU: as a persistent kernel it waited ~1.7 ms for CUs and the rest of the bottom MLP's
+    // backward behind it (Terabyte step 8.07-8.10 -> 8.01-8.03 ms; at 140 K the two 512 x 256 layers move too: 8.13-8.15).
+    // FFH_SK_MIN_WEIGHTS / _BWD: A/B switches (all forms / the two backward forms).
+    static const int64_t min_w = getenv("FFH_SK_MIN_WEIGHTS") ? atoll(getenv("FFH_SK_MIN_WEIGHTS")) : 0;
+    static const int64_t min_wb = getenv("FFH_SK_MIN_WEIGHTS_BWD") ? atoll(getenv("FFH_SK_MIN_WEIGHTS_BWD")) : 65536;
+    const int64_t nw = form == SK_FORM_DW ? (int64_t)g.M * g.N : (int64_t)g.N * g.K;
+    if (nw < min_w || (form != SK_FORM_FWD && nw < min_wb)) return false;
+  }
   if (g.M % SK_BM || g.N % SK_BN || g.K % SK_BK || g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
   const bool akr = form == SK_FORM_DW, bkr = form != SK_FORM_FWD;
   p.lda = akr ? g.sAk : g.sAm; p.ldb = bkr ? g.sBk : g.sBn;
