@@ -65,10 +65,14 @@ def emb(hip):
         ba = hip.emb_tables([(I[t], W[t], G[:, t * D:], rows[t], ld) for t in range(T)])
         tf = timeit(lambda: hip.check(hip.lib.ffh_embedding_fwd_multi(hip.ctx, fa, T, 1, D, B, capi.AGGR_MODE_SUM, None), "f"))
         tb = timeit(lambda: hip.check(hip.lib.ffh_embedding_bwd_sgd_fused_multi(hip.ctx, ba, T, 1, D, B, capi.AGGR_MODE_SUM, 1e-6, None), "b"))
+        # the index-only phase alone (ffh_embedding_bwd_sort_multi): what a training step issues behind the gather, off its critical path;
+        # the rest of the fused call is the apply phase (segmented sums + folds + SGD step, one launch above 2048 lookups per table)
+        ts = timeit(lambda: hip.check(hip.lib.ffh_embedding_bwd_sort_multi(hip.ctx, ba, T, 1, D, B, None), "s"))
         bf = T * B * (8 + 4 * D + 4 * D)
         bb = T * B * (8 + 4 * D + 2 * 4 * D)
+        ta = max(tb - ts, 1e-9)
         print(f"{name:24s} fwd {tf*1e6:9.1f} us  {bf/tf/1e9:8.1f} GB/s ({bf/tf/PEAK_HBM*100:5.1f}% of 8 TB/s) | "
-              f"fused bwd+sgd {tb*1e6:9.1f} us  {bb/tb/1e9:8.1f} GB/s ({bb/tb/PEAK_HBM*100:5.1f}%)", flush=True)
+              f"fused bwd+sgd {tb*1e6:9.1f} us  {bb/tb/1e9:8.1f} GB/s ({bb/tb/PEAK_HBM*100:5.1f}%) = sort {ts*1e6:6.1f} us + apply {ta*1e6:6.1f} us", flush=True)
         del W, I, Z, G, ws
         torch.cuda.empty_cache()
 
