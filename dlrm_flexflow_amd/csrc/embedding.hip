@@ -658,10 +658,14 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
   }
 }
 
-// step 2 + 3 in one launch.  The folds (step 3, below) used to be two more launches; now the LAST tile of a 1024-block to finish
-// folds that block's 32-block partials (release fence + arrival counter + acquire fence: the classic last-arriver reduction),
-// and the last 1024-block of a table to be folded folds the table's 1024-block partials.  Who folds is decided by timing, what is
-// added to what is not: the same additions in the same order as the separate launches.
+// step 2 + 3 in one launch.  The folds (step 3, above) used to be two more launches; now the LAST tile of a 1024-block to finish
+// folds that block's 32-block partials (the classic last-arriver reduction: an arrival counter per block, with write-through
+// stores / sc1 loads of the few cross-workgroup values in place of fences, see xwg_*), and the last 1024-block of a table to be
+// folded folds the table's 1024-block partials.  Who folds is decided by timing, what is added to what is not: the same additions
+// in the same order as the separate launches.
+// Compiled for 8 waves per SIMD (64 VGPRs; the few spills sit in the fold path): a tile's time is a chain of dependent row round
+// trips, so every tile of the launch should be resident at once -- at 74 registers 1,536 of the 26-table shape's 1,664 tiles are,
+// and the launch takes 336 instead of 230 us.
 template <int VEC>
 __global__ __launch_bounds__(kRedThreads, 8) void emb_sgd_reduce_kernel(const RedArgs a) {
   __shared__ RedShared sh;
