@@ -240,6 +240,21 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
         const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsBias, (unsigned)nn * 4u, 0, 0);     // absent bias: extent 0, the load returns 0
         bv = __builtin_bit_cast(f32x4, t);
       }
+      // dX: the relu' mask (x of this layer) and, in the accumulating form, C's previous content are fetched for all 16 row groups
+      // BEFORE the first store: left inside the loop below each load sat behind the store in front of it (the compiler cannot tell
+      // the two apart, and s_waitcnt vmcnt(0) counts stores too) -- sixteen dependent round trips per tile on a SIMD whose only wave
+      // this is
+      f32x4 mk[4][4], cold[4][4];
+      if constexpr (EPI == SK_EPI_DX_STORE || EPI == SK_EPI_DX_ADD) {
+#pragma unroll
+        for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int mm = (int)cp.m0 + 64 * wy + 16 * q + 4 * i + tm;
+            if (g.mask_bytes) mk[tm][i] = *reinterpret_cast<const f32x4*>(g.mask + (int64_t)mm * g.ldmask + nn);      // uniform
+            if constexpr (EPI == SK_EPI_DX_ADD) cold[tm][i] = *reinterpret_cast<const f32x4*>(g.C + (int64_t)mm * g.ldc + nn);
+          }
+      }
 #pragma unroll
       for (int tm = 0; tm < 4; tm++)
 #pragma unroll
@@ -257,10 +272,10 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
             *reinterpret_cast<f32x4*>(cptr) = v;
           } else {
             if (g.mask_bytes) {        // uniform
-              const f32x4 mk = *reinterpret_cast<const f32x4*>(g.mask + (int64_t)mm * g.ldmask + nn);
-              v.x = mk.x > 0.0f ? v.x : 0.0f; v.y = mk.y > 0.0f ? v.y : 0.0f; v.z = mk.z > 0.0f ? v.z : 0.0f; v.w = mk.w > 0.0f ? v.w : 0.0f;
+              const f32x4 m4 = mk[tm][i];
+              v.x = m4.x > 0.0f ? v.x : 0.0f; v.y = m4.y > 0.0f ? v.y : 0.0f; v.z = m4.z > 0.0f ? v.z : 0.0f; v.w = m4.w > 0.0f ? v.w : 0.0f;
             }
-            if constexpr (EPI == SK_EPI_DX_ADD) v += *reinterpret_cast<const f32x4*>(cptr);
+            if constexpr (EPI == SK_EPI_DX_ADD) v += cold[tm][i];
             *reinterpret_cast<f32x4*>(cptr) = v;
           }
         }
