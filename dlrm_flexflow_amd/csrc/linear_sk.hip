@@ -234,6 +234,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
     //      n0 + 64 wx + 4 c16 + {0..3} of row m0 + 64 wy + 16 q + 4 i + tm
     {
       const int nn = (int)cp.n0 + 64 * wx + 4 * c16;
+      const bool relu_fast = g.act == FFH_AC_MODE_RELU, none_fast = g.act == FFH_AC_MODE_NONE;      // uniform
+      (void)relu_fast; (void)none_fast;
       f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (EPI == SK_EPI_FWD) {
         const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.bias), 0, g.bias_bytes, 0x00020000);
@@ -268,7 +270,10 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
             (void)cptr; (void)v;          // below: 16 rows at a time
           } else if constexpr (EPI == SK_EPI_FWD) {
             v += bv;
-            v.x = act_apply(v.x, g.act); v.y = act_apply(v.y, g.act); v.z = act_apply(v.z, g.act); v.w = act_apply(v.w, g.act);
+            // ReLU / none without act_apply's chain of (uniform) branches per element: 64 elements x 3 branches per lane and tile were
+            // ~2 us of every tile with nothing else to run on the SIMD; same values (v > 0 ? v : 0)
+            if (relu_fast) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f; }
+            else if (!none_fast) { v.x = act_apply(v.x, g.act); v.y = act_apply(v.y, g.act); v.z = act_apply(v.z, g.act); v.w = act_apply(v.w, g.act); }
             *reinterpret_cast<f32x4*>(cptr) = v;
           } else {
             if (g.mask_bytes) {        // uniform
