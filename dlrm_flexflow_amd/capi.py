@@ -44,6 +44,20 @@ class EmbTable(C.Structure):
     _fields_ = [("idx", P), ("weight", P), ("io", P), ("num_entries", L), ("ld", L)]
 
 
+class EmbState(C.Structure):
+    """struct ffh_emb_state: per-table optimizer state of the sparse (touched-rows) optimizers"""
+    _fields_ = [("s0", P), ("s1", P)]
+
+
+class SparseOpt(C.Structure):
+    """struct ffh_sparse_opt"""
+    _fields_ = [("kind", C.c_int32), ("lr", F), ("weight_decay", F), ("momentum", F), ("nesterov", C.c_int32),
+                ("beta1", F), ("beta2", F), ("epsilon", F)]
+
+
+SPARSE_OPT_SGD, SPARSE_OPT_SGD_MOMENTUM, SPARSE_OPT_ADAM = 0, 1, 2
+
+
 class PerfMetrics(C.Structure):
     """struct ffh_perf_metrics"""
     _fields_ = [("train_all", C.c_int32), ("train_correct", C.c_int32), ("cce_loss", F),
@@ -106,6 +120,8 @@ _SIGS = {
     "ffh_embedding_bwd_sgd_fused_multi": (I, [P, C.POINTER(EmbTable), I, I, I, L, I, F, P]),
     "ffh_embedding_bwd_sort_multi": (I, [P, C.POINTER(EmbTable), I, I, I, L, P]),
     "ffh_embedding_bwd_sgd_apply_multi": (I, [P, C.POINTER(EmbTable), I, I, I, L, I, F, P]),
+    "ffh_embedding_bwd_opt_fused_multi": (I, [P, C.POINTER(EmbTable), C.POINTER(EmbState), I, I, I, L, I, C.POINTER(SparseOpt), P]),
+    "ffh_embedding_bwd_opt_apply_multi": (I, [P, C.POINTER(EmbTable), C.POINTER(EmbState), I, I, I, L, I, C.POINTER(SparseOpt), P]),
     "ffh_embedding_bwd_workspace_bytes": (SZ, [I, I, I, L]),
     "ffh_embedding_localize_rows": (I, [P, P, P, L, L, L, P]),
     "ffh_linear_fwd": (I, [P, P, L, P, L, P, P, I, I, L, I, P]),
@@ -233,6 +249,15 @@ class FFHLib:
         arr = (EmbTable * len(entries))()
         for k, (idx, w, io, r, ld) in enumerate(entries):
             arr[k] = EmbTable(ptr(idx), ptr(w), ptr(io), int(r), int(ld))
+        return arr
+
+    @staticmethod
+    def emb_states(entries) -> "C.Array":
+        """entries: iterable of (s0, s1) buffers (None where the optimizer kind has no such state)."""
+        entries = list(entries)
+        arr = (EmbState * len(entries))()
+        for k, (s0, s1) in enumerate(entries):
+            arr[k] = EmbState(ptr(s0), ptr(s1))
         return arr
 
     def transpose(self, name: str, dst, src, in_dims, perm, stream=None):

@@ -26,6 +26,7 @@ struct ConcatArgs {
 // interaction) is still moved 16 bytes at a time.
 template <bool BWD, int VEC>
 __global__ __launch_bounds__(256) void concat_kernel(const ConcatArgs a) {
+  ffh_kernel_prio();
   const int p = blockIdx.y;
   float* part = a.part[p];
   const int64_t w = a.blk[p], ld = a.ld[p], off = a.off[p];
@@ -102,6 +103,7 @@ int concat_impl(ffh_ctx* c, float* big, int64_t out_blk, float* const* parts, co
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mse_bwd_kernel(float* __restrict__ lg, const float* __restrict__ logit,
                                                       const float* __restrict__ label, int64_t n, float scale) {
+  ffh_kernel_prio();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float d = logit[i] - label[i];
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void mse_bwd_kernel(float* __restrict__ lg, co
 __global__ __launch_bounds__(256) void metrics_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
                                                       ffh_perf_metrics* __restrict__ perf, int64_t ns, int nc, int flags,
                                                       float* __restrict__ lg, float scale) {
+  ffh_kernel_prio();
   __shared__ float s_f[3][4];
   __shared__ int   s_i[2][4];
   float mse_s = 0.f, rmse_s = 0.f, mae_s = 0.f;
@@ -183,6 +186,7 @@ struct TransposeArgs {
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void transpose_generic_kernel(float* __restrict__ dst, const float* __restrict__ src, const TransposeArgs a) {
+  ffh_kernel_prio();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < a.vol; o += stride) {
     int64_t t = o, ii = 0;
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(256) void transpose_generic_kernel(float* __restric
 // src [batch][R][C] -> dst [batch][C][R];  BWD: dst [batch][R][C] += src [batch][C][R]^T (same tile walk, roles swapped)
 template <bool ACC>
 __global__ __launch_bounds__(256) void transpose_last2_kernel(float* __restrict__ dst, const float* __restrict__ src, int R, int C) {
+  ffh_kernel_prio();
   __shared__ float tile[32][33];
   const int64_t b = blockIdx.z;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -263,6 +268,7 @@ int transpose_launch(ffh_ctx* c, float* dst, const float* src, int nd, const int
 template <int VEC>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ v,
                                                   int64_t n, float lr, float wd, float mom, int nesterov, int zero_grad) {
+  ffh_kernel_prio();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t nv = n / VEC;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
@@ -301,6 +307,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* 
 template <int VEC>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float alpha_t, float b1, float b2, float wd, float eps, int zero_grad) {
+  ffh_kernel_prio();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t nv = n / VEC;
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
@@ -345,6 +352,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float*
 }
 
 __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ d, const float* __restrict__ src, int64_t n, float scale) {
+  ffh_kernel_prio();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = __fmaf_rn(src[i], scale, d[i]);
 }
@@ -358,6 +366,7 @@ namespace {
 constexpr int kTrilMaxN = 64;
 template <bool BWD>
 __global__ __launch_bounds__(256) void tril_kernel(float* __restrict__ tri, int64_t tri_ld, float* __restrict__ full, int64_t batch, int n) {
+  ffh_kernel_prio();
   __shared__ uint16_t tab[kTrilMaxN * (kTrilMaxN - 1) / 2];
   const int P = n * (n - 1) / 2;
   for (int p = threadIdx.x; p < P; p += 256) {

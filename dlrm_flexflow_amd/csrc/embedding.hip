@@ -38,6 +38,7 @@ struct EmbArgs {
 // VEC = floats per lane per access (4: 16-B accesses; 1: any D / alignment)
 template <int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void emb_fwd_kernel(const EmbArgs a) {
+  ffh_kernel_prio();
   using vec_t = typename std::conditional<VEC == 4, float4, float>::type;
   const ffh_emb_table tb = a.t[blockIdx.y];
   unsigned short* const o16 = a.out16[blockIdx.y];
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(const EmbArgs a) {
 __global__ __launch_bounds__(256) void emb_bwd_dense_kernel(const int64_t* __restrict__ idx, const float* __restrict__ g,
                                                             float* __restrict__ wg, int L, int D, int64_t batch,
                                                             int64_t gld, int avg) {
+  ffh_kernel_prio();
   const int64_t total = batch * D;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -155,6 +157,7 @@ __device__ __forceinline__ uint32_t sort_load_key(const SortArgs& a, int t, int6
 // histogram of the current digit per 2048-entry tile (LDS-staged bucketing)
 template <bool FIRST, int E>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const SortArgs a) {
+  ffh_kernel_prio();
   constexpr int kSortTile = kSortThreads * E;
   constexpr int kSortPerThread = E;
   __shared__ uint32_t s_hist[kMaxRadix];
@@ -270,6 +273,7 @@ __device__ __forceinline__ void sort_rank_and_scatter(const uint32_t (&key)[E], 
 // advances the wave's running offset in LDS.
 template <bool FIRST, int E>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortArgs a) {
+  ffh_kernel_prio();
   constexpr int kSortTile = kSortThreads * E;
   constexpr int kSortPerThread = E;
   if (a.pass >= a.npass[blockIdx.y]) return;
@@ -341,6 +345,71 @@ static_assert(kRedTile % FFH_EMB_CHUNK == 0, "tile must hold whole chunks");
 
 enum : uint32_t { kMetaNone = 0, kMetaFirst = 1, kMetaCont = 2 };
 
+// What happens to a touched row once its gradient sum is complete (ffh_sparse_opt, include/ff_hip.h).  OPT is a template parameter
+// of the kernels: 0 = plain SGD (the fused update of SURVEY 8a-4, unchanged instructions), 1 = sgd_update with weight decay /
+// momentum / nesterov, 2 = adam_update -- the element arithmetic of sgd_kernel / adam_kernel (elementwise.hip), statement by
+// statement, so a row hit by one gradient row ends up with the bits the dense optimizer gives that row.
+struct OptP { float lr, wd, mom, b1, b2, eps, omb1, omb2; int nesterov; };
+
+template <int VEC, int OPT>
+__device__ __forceinline__ void apply_row(const OptP& o, float* wrow, float* s0row, float* s1row, int c, const float (&acc)[VEC]) {
+  if (OPT == 0) {
+    if (VEC == 4) {
+      float4 w = reinterpret_cast<float4*>(wrow)[c];
+      w.x = __fmaf_rn(-o.lr, acc[0], w.x); w.y = __fmaf_rn(-o.lr, acc[1], w.y);
+      w.z = __fmaf_rn(-o.lr, acc[2], w.z); w.w = __fmaf_rn(-o.lr, acc[3], w.w);
+      reinterpret_cast<float4*>(wrow)[c] = w;
+    } else {
+      wrow[c] = __fmaf_rn(-o.lr, acc[0], wrow[c]);
+    }
+    return;
+  }
+  float wv[VEC], av[VEC], bv[VEC];
+  const bool has0 = OPT == 2 || o.mom > 0.f;
+  if (VEC == 4) {
+    const float4 w = reinterpret_cast<const float4*>(wrow)[c];
+    wv[0] = w.x; wv[1] = w.y; wv[2] = w.z; wv[3] = w.w;
+    if (has0) { const float4 a = reinterpret_cast<const float4*>(s0row)[c]; av[0] = a.x; av[1] = a.y; av[2] = a.z; av[3] = a.w; }
+    if (OPT == 2) { const float4 b = reinterpret_cast<const float4*>(s1row)[c]; bv[0] = b.x; bv[1] = b.y; bv[2] = b.z; bv[3] = b.w; }
+  } else {
+    wv[0] = wrow[c];
+    if (has0) av[0] = s0row[c];
+    if (OPT == 2) bv[0] = s1row[c];
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; k++) {
+    if (OPT == 1) {            // sgd_update [ref: src/runtime/optimizer_kernel.cu:23-41], as sgd_kernel spells it
+      float gt = __fmaf_rn(o.wd, wv[k], acc[k]);
+      if (o.mom > 0.f) {
+        av[k] = __fmaf_rn(av[k], o.mom, gt);
+        gt = o.nesterov ? __fmaf_rn(o.mom, av[k], gt) : av[k];
+      }
+      wv[k] = __fmaf_rn(-o.lr, gt, wv[k]);
+    } else {                   // adam_update [ref: src/runtime/optimizer_kernel.cu:206-226], as adam_kernel spells it (lr = alpha_t)
+#pragma clang fp contract(off)
+      const float gt = fmaf(o.wd, wv[k], acc[k]);
+      const float t1 = o.omb1 * gt;
+      av[k] = fmaf(o.b1, av[k], t1);
+      const float t2 = o.omb2 * gt;
+      const float t3 = t2 * gt;
+      bv[k] = fmaf(o.b2, bv[k], t3);
+      const float num = o.lr * av[k];
+      const float den = sqrtf(bv[k]) + o.eps;
+      const float step = num / den;
+      wv[k] = wv[k] - step;
+    }
+  }
+  if (VEC == 4) {
+    reinterpret_cast<float4*>(wrow)[c] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+    if (has0) reinterpret_cast<float4*>(s0row)[c] = make_float4(av[0], av[1], av[2], av[3]);
+    if (OPT == 2) reinterpret_cast<float4*>(s1row)[c] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+  } else {
+    wrow[c] = wv[0];
+    if (has0) s0row[c] = av[0];
+    if (OPT == 2) s1row[c] = bv[0];
+  }
+}
+
 struct RedArgs {
   ffh_emb_table t[FFH_MAX_TABLES];
   const uint2* kp[2];       // sorted {row id, position} [nt][N]: table t ends in buffer parity[t]
@@ -353,11 +422,13 @@ struct RedArgs {
   int       L;
   int       D;
   int       avg;
-  float     lr;
   float*    partial1;       // level-1 partial rows [nt][2*nchunks1][D]
   uint2*    meta1;          // level-1 slots [nt][2*nchunks1] (cleared by the sort phase)
   uint32_t* arrive;         // [nt][nchunks1 + 1] (cleared by the sort phase): tiles done per 1024-block, then 1024-blocks folded
   int       nchunks1;
+  OptP      op;             // the row rule's parameters (op.lr = the plain update's lr)
+  float*    s0[FFH_MAX_TABLES];   // OPT 1: momentum buffer V; OPT 2: first moment M -- [num_entries][D] like the table, or null
+  float*    s1[FFH_MAX_TABLES];   // OPT 2: second moment V
 };
 
 template <int VEC>
@@ -431,16 +502,16 @@ struct RedShared {
 };
 
 // one tile of one table; `partial_t` / `meta_t` are the table's level-0 slot arrays
-template <int VEC, bool AGENT>
+template <int VEC, bool AGENT, int OPT>
 __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const uint2* kp,
                                                  float* partial_t, uint2* meta_t, int64_t N, int nchunks, int tile, int tile_index,
-                                                 int L, int D_, bool avg_, float lr_, RedShared& sh, const int tid = threadIdx.x) {
+                                                 int L, int D_, bool avg_, const OptP& op, float* st0, float* st1, RedShared& sh, const int tid = threadIdx.x) {
   uint32_t* s_key = sh.key;
   uint32_t* s_pos = sh.pos;
   uint16_t* s_start = sh.start;
   uint32_t* s_cnt = sh.cnt;
   uint2* s_meta = sh.meta;
-  struct { int64_t N; int nchunks, L, D, avg; float lr; } a = {N, nchunks, L, D_, avg_ ? 1 : 0, lr_};
+  struct { int64_t N; int nchunks, L, D, avg; } a = {N, nchunks, L, D_, avg_ ? 1 : 0};
   const int64_t tile0 = (int64_t)tile_index * tile;
   const int n = tile0 >= N ? 0 : (int)((N - tile0) < tile ? (N - tile0) : tile);   // a tile past the end still walks the barriers
   const int lane = tid & 63, wave = tid >> 6;
@@ -536,14 +607,7 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
           for (int v = 0; v < VEC; v++) acc[v] = acc[v] + v0[v];
         }
         if (single) {
-          if (VEC == 4) {
-            float4 w = reinterpret_cast<float4*>(wrow)[c];
-            w.x = __fmaf_rn(-a.lr, acc[0], w.x); w.y = __fmaf_rn(-a.lr, acc[1], w.y);
-            w.z = __fmaf_rn(-a.lr, acc[2], w.z); w.w = __fmaf_rn(-a.lr, acc[3], w.w);
-            reinterpret_cast<float4*>(wrow)[c] = w;
-          } else {
-            wrow[c] = __fmaf_rn(-a.lr, acc[0], wrow[c]);
-          }
+          apply_row<VEC, OPT>(op, wrow, OPT ? st0 + (int64_t)key * D : nullptr, OPT == 2 ? st1 + (int64_t)key * D : nullptr, c, acc);
         } else {
           xwg_store_row<VEC, AGENT>(prow, c, acc);
         }
@@ -567,9 +631,9 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
 // `keys` (the table's sorted ids; level-0 input only, ratio > 0): whether a run goes on past the end of its level-(k+1) block is
 // read off the sorted list instead of the next block's first slot -- the workgroup that folds one block (the last of the
 // block's reduce tiles to finish, see emb_sgd_reduce_kernel) then needs nothing another block's tiles write.
-template <int VEC, bool AGENT>
+template <int VEC, bool AGENT, int OPT>
 __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const float* part, const uint2* meta, float* pout_t, uint2* mout_t,
-                                                int nin, int ratio, int D, float lr, int64_t slot_lo, int64_t slot_hi,
+                                                int nin, int ratio, int D, const OptP& op, float* st0, float* st1, int64_t slot_lo, int64_t slot_hi,
                                                 int64_t group0, int64_t ngroups, const uint2* keys = nullptr,
                                                 const uint2* staged = nullptr, int64_t staged_lo = 0, int staged_n = 0) {
   // `staged`: an LDS copy of meta[staged_lo, staged_lo + staged_n) the caller fetched with one parallel load (the in-kernel folds:
@@ -643,14 +707,7 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
         for (int v = 0; v < VEC; v++) acc[v] = acc[v] + v0[v];
       }
       if (complete) {
-        if (VEC == 4) {
-          float4 w = reinterpret_cast<float4*>(wrow)[c];
-          w.x = __fmaf_rn(-lr, acc[0], w.x); w.y = __fmaf_rn(-lr, acc[1], w.y);
-          w.z = __fmaf_rn(-lr, acc[2], w.z); w.w = __fmaf_rn(-lr, acc[3], w.w);
-          reinterpret_cast<float4*>(wrow)[c] = w;
-        } else {
-          wrow[c] = __fmaf_rn(-lr, acc[0], wrow[c]);
-        }
+        apply_row<VEC, OPT>(op, wrow, OPT ? st0 + (int64_t)m.y * D : nullptr, OPT == 2 ? st1 + (int64_t)m.y * D : nullptr, c, acc);
       } else {
         xwg_store_row<VEC, AGENT>(orow, c, acc);
       }
@@ -666,8 +723,11 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
 // Compiled for 8 waves per SIMD (64 VGPRs; the few spills sit in the fold path): a tile's time is a chain of dependent row round
 // trips, so every tile of the launch should be resident at once -- at 74 registers 1,536 of the 26-table shape's 1,664 tiles are,
 // and the launch takes 336 instead of 230 us.
-template <int VEC>
-__global__ __launch_bounds__(kRedThreads, 8) void emb_sgd_reduce_kernel(const RedArgs a) {
+// OPT != 0 (momentum / weight-decay SGD, Adam on the touched rows): the row rule holds up to three more rows' worth of registers;
+// those instantiations are compiled for 4 waves per SIMD instead of spilling.
+template <int VEC, int OPT>
+__global__ __launch_bounds__(kRedThreads, OPT == 0 ? 8 : 4) void emb_sgd_reduce_kernel(const RedArgs a) {
+  ffh_kernel_prio();
   __shared__ RedShared sh;
   __shared__ int s_last;
   __shared__ uint2 s_fmeta[kFoldStage];
@@ -676,8 +736,10 @@ __global__ __launch_bounds__(kRedThreads, 8) void emb_sgd_reduce_kernel(const Re
   const uint2* keys = a.kp[a.parity[tix]] + (int64_t)tix * a.N;
   float* p0 = a.partial + (int64_t)tix * 2 * a.nchunks * a.D;
   uint2* m0 = a.meta + (int64_t)tix * 2 * a.nchunks;
-  reduce_tile_body<VEC, true>(tb, keys, p0, m0, a.N, a.nchunks, a.tile,
-                        (int)blockIdx.x, a.L, a.D, a.avg != 0, a.lr, sh);
+  float* const st0 = a.s0[tix];
+  float* const st1 = a.s1[tix];
+  reduce_tile_body<VEC, true, OPT>(tb, keys, p0, m0, a.N, a.nchunks, a.tile,
+                        (int)blockIdx.x, a.L, a.D, a.avg != 0, a.op, st0, st1, sh);
 
   const int nvec = a.D / VEC;
   const int lpr = nvec < 64 ? nvec : 64;
@@ -717,7 +779,7 @@ __global__ __launch_bounds__(kRedThreads, 8) void emb_sgd_reduce_kernel(const Re
     const int64_t lo = 2 * B1 * kRatio;
     const int64_t hi = lo + 2 * kRatio < 2 * (int64_t)a.nchunks ? lo + 2 * kRatio : 2 * (int64_t)a.nchunks;
     if (stage(m0, lo, hi))
-      fold_table_body<VEC, true>(tb, p0, m0, p1, m1, a.nchunks, kRatio, a.D, a.lr, lo, hi, group0, ngroups, keys, s_fmeta, lo, (int)(hi - lo));
+      fold_table_body<VEC, true, OPT>(tb, p0, m0, p1, m1, a.nchunks, kRatio, a.D, a.op, st0, st1, lo, hi, group0, ngroups, keys, s_fmeta, lo, (int)(hi - lo));
     xwg_stores_done();
     __syncthreads();
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&arrive[a.nchunks1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)a.nchunks1 - 1u;
@@ -725,11 +787,11 @@ __global__ __launch_bounds__(kRedThreads, 8) void emb_sgd_reduce_kernel(const Re
     if (!s_last) return;
     const int64_t hi1 = 2 * (int64_t)a.nchunks1;
     if (stage(m1, 0, hi1))
-      fold_table_body<VEC, true>(tb, p1, m1, p1, m1, a.nchunks1, 0, a.D, a.lr, 0, hi1, group0, ngroups, nullptr, s_fmeta, 0, (int)(hi1 < kFoldStage ? hi1 : kFoldStage));
+      fold_table_body<VEC, true, OPT>(tb, p1, m1, p1, m1, a.nchunks1, 0, a.D, a.op, st0, st1, 0, hi1, group0, ngroups, nullptr, s_fmeta, 0, (int)(hi1 < kFoldStage ? hi1 : kFoldStage));
   } else {
     const int64_t hi0 = 2 * (int64_t)a.nchunks;
     if (stage(m0, 0, hi0))
-      fold_table_body<VEC, true>(tb, p0, m0, p1, m1, a.nchunks, 0, a.D, a.lr, 0, hi0, group0, ngroups, nullptr, s_fmeta, 0, (int)hi0);
+      fold_table_body<VEC, true, OPT>(tb, p0, m0, p1, m1, a.nchunks, 0, a.D, a.op, st0, st1, 0, hi0, group0, ngroups, nullptr, s_fmeta, 0, (int)hi0);
   }
 }
 
@@ -749,7 +811,9 @@ struct SmallArgs {
   int64_t   N;
   int nch0, nch1, rb, L, D, avg;
   int tile;            // sorted entries per reduce team (multiple of FFH_EMB_CHUNK, <= kRedTile)
-  float lr;
+  OptP op;
+  float* s0[FFH_MAX_TABLES];
+  float* s1[FFH_MAX_TABLES];
 };
 
 constexpr int kSmallWaves = 8;                        // threads per table = 64 x this: sort ranks kSmallMax / threads entries per thread, reduce = teams of 256
@@ -767,8 +831,9 @@ union SmallShared {                                    // the sort arrays are de
   RedShared red[kSmallRedParts];
 };
 
-template <int VEC>
+template <int VEC, int OPT>
 __global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const SmallArgs a) {
+  ffh_kernel_prio();
   constexpr int NW = kSmallWaves;
   constexpr int E = kSmallMax / kSmallThreads;         // 2 entries per thread, wave w owns [128 w, 128 w + 128)
   __shared__ SmallShared sm;
@@ -777,6 +842,8 @@ __global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const Smal
   uint32_t (*s_off)[kMaxRadix] = sm.sort.off;
   const int tix = blockIdx.x;
   const ffh_emb_table tb = a.t[tix];
+  float* const st0 = a.s0[tix];
+  float* const st1 = a.s1[tix];
   const int64_t N = a.N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int radix = 1 << a.rb;
@@ -836,7 +903,7 @@ __global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const Smal
   const int team = threadIdx.x / kRedThreads, ttid = threadIdx.x % kRedThreads;
   const int ntiles = (int)((N + a.tile - 1) / a.tile);
   for (int t0 = 0; t0 < ntiles; t0 += kSmallRedParts) {
-    reduce_tile_body<VEC, false>(tb, keys, p0, m0, N, a.nch0, a.tile, t0 + team, a.L, a.D, a.avg != 0, a.lr, sm.red[team], ttid);
+    reduce_tile_body<VEC, false, OPT>(tb, keys, p0, m0, N, a.nch0, a.tile, t0 + team, a.L, a.D, a.avg != 0, a.op, st0, st1, sm.red[team], ttid);
     __syncthreads();
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -850,13 +917,13 @@ __global__ __launch_bounds__(kSmallThreads) void emb_sgd_small_kernel(const Smal
   const int64_t ngroups = (int64_t)NW * rpw;
   float* p1 = a.partial1 + (int64_t)tix * 2 * a.nch1 * a.D;
   if (a.nch1 > 1) {
-    fold_table_body<VEC, false>(tb, p0, m0, p1, m1, a.nch0, FFH_EMB_CHUNK1 / FFH_EMB_CHUNK, a.D, a.lr, 0, 2 * (int64_t)a.nch0, group0, ngroups);
+    fold_table_body<VEC, false, OPT>(tb, p0, m0, p1, m1, a.nch0, FFH_EMB_CHUNK1 / FFH_EMB_CHUNK, a.D, a.op, st0, st1, 0, 2 * (int64_t)a.nch0, group0, ngroups);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    fold_table_body<VEC, false>(tb, p1, m1, p1, m1, a.nch1, 0, a.D, a.lr, 0, 2 * (int64_t)a.nch1, group0, ngroups);
+    fold_table_body<VEC, false, OPT>(tb, p1, m1, p1, m1, a.nch1, 0, a.D, a.op, st0, st1, 0, 2 * (int64_t)a.nch1, group0, ngroups);
   } else {
-    fold_table_body<VEC, false>(tb, p0, m0, p1, m1, a.nch0, 0, a.D, a.lr, 0, 2 * (int64_t)a.nch0, group0, ngroups);
+    fold_table_body<VEC, false, OPT>(tb, p0, m0, p1, m1, a.nch0, 0, a.D, a.op, st0, st1, 0, 2 * (int64_t)a.nch0, group0, ngroups);
   }
 }
 
@@ -930,6 +997,7 @@ bool can_vec4(const ffh_emb_table* t, int nt, int D) {
 // row-wise sharded table: global id -> local id, rows held elsewhere -> the zero row behind the local slice
 __global__ __launch_bounds__(256) void emb_localize_kernel(const int64_t* __restrict__ idx, int64_t* __restrict__ local, int64_t n,
                                                            int64_t row_begin, int64_t rows_local) {
+  ffh_kernel_prio();
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t r = idx[i] - row_begin;
     local[i] = (r >= 0 && r < rows_local) ? r : rows_local;
@@ -1004,23 +1072,60 @@ size_t ffh_embedding_bwd_workspace_bytes(int nt, int L, int D, int64_t batch) {
 // early (the DLRM step: at the gather) can run it off the critical path (ffh_embedding_bwd_sort_multi) and do the part that
 // needs the output gradients -- segmented reduce, folds, the SGD step -- when they exist (ffh_embedding_bwd_sgd_apply_multi).
 // Same launches in the same order on the same workspace: the fused entry is both phases back to back.
+// `opt` / `states`: the row rule (ffh_sparse_opt) and the per-table optimizer state it updates; null opt = plain SGD with `lr`
 static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch,
-                          int aggr, float lr, ffh_stream s, const bool do_sort, const bool do_apply) {
+                          int aggr, float lr, ffh_stream s, const bool do_sort, const bool do_apply,
+                          const ffh_sparse_opt* opt = nullptr, const ffh_emb_state* states = nullptr) {
   int rc = validate_tables(c, tables, nt, L, D, batch, aggr, "embedding_bwd_sgd_fused");
   if (rc) return rc;
+  OptP op{};
+  op.lr = lr;
+  int kind = FFH_SPARSE_OPT_SGD;
+  if (opt && do_apply) {
+    kind = opt->kind;
+    if (kind != FFH_SPARSE_OPT_SGD && kind != FFH_SPARSE_OPT_SGD_MOMENTUM && kind != FFH_SPARSE_OPT_ADAM)
+      return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt: unknown ffh_sparse_opt.kind");
+    op.lr = opt->lr; op.wd = opt->weight_decay; op.mom = opt->momentum; op.nesterov = opt->nesterov ? 1 : 0;
+    op.b1 = opt->beta1; op.b2 = opt->beta2; op.eps = opt->epsilon; op.omb1 = 1.0f - opt->beta1; op.omb2 = 1.0f - opt->beta2;
+    if (kind == FFH_SPARSE_OPT_SGD && (op.wd != 0.0f || op.mom != 0.0f)) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt: FFH_SPARSE_OPT_SGD takes no weight decay / momentum (use FFH_SPARSE_OPT_SGD_MOMENTUM)");
+    const bool need0 = kind == FFH_SPARSE_OPT_ADAM || (kind == FFH_SPARSE_OPT_SGD_MOMENTUM && op.mom > 0.0f);
+    for (int i = 0; i < nt && batch > 0; i++) {
+      if (need0 && (!states || !states[i].s0)) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt: optimizer state (s0) missing");
+      if (kind == FFH_SPARSE_OPT_ADAM && !states[i].s1) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt: optimizer state (s1) missing");
+    }
+  }
   if (nt == 0 || batch == 0) return FFH_OK;
   const int64_t N = batch * L;
   if (N >= (1LL << 31)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "embedding_bwd_sgd_fused: batch*in_dim >= 2^31");
   int64_t maxR = 1;
   for (int i = 0; i < nt; i++) maxR = tables[i].num_entries > maxR ? tables[i].num_entries : maxR;
   if (maxR > (1LL << 32)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "embedding_bwd_sgd_fused: num_entries > 2^32");
-  const bool v4 = can_vec4(tables, nt, D);
+  bool v4 = can_vec4(tables, nt, D);
+  for (int i = 0; i < nt && v4 && kind != FFH_SPARSE_OPT_SGD; i++)
+    v4 = (!states[i].s0 || aligned16(states[i].s0)) && (!states[i].s1 || aligned16(states[i].s1));
   const int nvec = v4 ? D / 4 : D;
   if ((nvec + 63) / 64 > kMaxChunks * 64) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "embedding_bwd_sgd_fused: out_dim too large");
   const BwdLayout lay = bwd_layout(nt, L, D, batch);
   if (!c->ws || c->ws_bytes < lay.total) return ffh_fail(c, FFH_ERR_WORKSPACE, "embedding_bwd_sgd_fused: workspace too small (ffh_embedding_bwd_workspace_bytes)");
   char* ws = (char*)c->ws;
   if (!aligned16(ws)) return ffh_fail(c, FFH_ERR_WORKSPACE, "embedding_bwd_sgd_fused: workspace must be 16-byte aligned");
+  // The apply phase CONSUMES what the sort phase left in the workspace: besides the sorted list, the arrival counters and level-1
+  // slots that only the sort's first histogram pass clears -- a second apply on the same sort would find them used (no workgroup
+  // would be "last", rows whose runs cross tiles would silently miss their update).  The two-call form is therefore one-shot: the
+  // sort notes (workspace, shape) in the ctx, the apply requires and clears that note; the fused call needs no note but spoils one
+  // that sits on the workspace it overwrites.
+  const int64_t sig[4] = {nt, L, D, batch};
+  if (do_sort && do_apply) {
+    if (c->emb_sorted_ws == c->ws) c->emb_sorted_ws = nullptr;
+  } else if (do_sort) {
+    c->emb_sorted_ws = c->ws;
+    memcpy(c->emb_sorted_sig, sig, sizeof sig);
+  } else {
+    if (c->emb_sorted_ws != c->ws || memcmp(c->emb_sorted_sig, sig, sizeof sig) != 0)
+      return ffh_fail(c, FFH_ERR_WORKSPACE, "embedding_bwd_sgd_apply_multi: no fresh ffh_embedding_bwd_sort_multi of the same tables / batch on this ctx's "
+                                           "workspace (the apply phase consumes the sort: one apply per sort)");
+    c->emb_sorted_ws = nullptr;
+  }
 
   if (N <= kSmallMax) {
     // small-batch path: one launch, one workgroup per table (see emb_sgd_small_kernel): the sort lives inside it
@@ -1041,12 +1146,16 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
     sm.partial0 = (float*)(ws + lay.partial); sm.meta0 = (uint2*)(ws + lay.meta);
     sm.partial1 = (float*)(ws + lay.partial1); sm.meta1 = (uint2*)(ws + lay.meta1);
     sm.N = N; sm.nch0 = lay.nchunks; sm.nch1 = lay.nchunks1; sm.rb = rb_s; sm.L = L; sm.D = D;
-    sm.avg = aggr == FFH_AGGR_MODE_AVG ? 1 : 0; sm.lr = lr;
+    sm.avg = aggr == FFH_AGGR_MODE_AVG ? 1 : 0; sm.op = op;
+    for (int i = 0; i < nt && kind != FFH_SPARSE_OPT_SGD; i++) { sm.s0[i] = states[i].s0; sm.s1[i] = states[i].s1; }
     int tile = (int)((N + kSmallRedParts - 1) / kSmallRedParts);          // one tile per 256-thread team
     tile = (tile + FFH_EMB_CHUNK - 1) / FFH_EMB_CHUNK * FFH_EMB_CHUNK;
     sm.tile = tile < FFH_EMB_CHUNK ? FFH_EMB_CHUNK : tile;
-    if (v4) hipLaunchKernelGGL((emb_sgd_small_kernel<4>), dim3(nt), dim3(kSmallThreads), 0, as_stream(s), sm);
-    else hipLaunchKernelGGL((emb_sgd_small_kernel<1>), dim3(nt), dim3(kSmallThreads), 0, as_stream(s), sm);
+#define FFH_SMALL(OPTV)                                                                                               \
+    { if (v4) hipLaunchKernelGGL((emb_sgd_small_kernel<4, OPTV>), dim3(nt), dim3(kSmallThreads), 0, as_stream(s), sm);  \
+      else hipLaunchKernelGGL((emb_sgd_small_kernel<1, OPTV>), dim3(nt), dim3(kSmallThreads), 0, as_stream(s), sm); }
+    if (kind == FFH_SPARSE_OPT_SGD) FFH_SMALL(0) else if (kind == FFH_SPARSE_OPT_SGD_MOMENTUM) FFH_SMALL(1) else FFH_SMALL(2)
+#undef FFH_SMALL
     FFH_LAUNCH_CHECK(c, "emb_sgd_small_kernel");
     return FFH_OK;
   }
@@ -1101,14 +1210,18 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
   ra.meta = (uint2*)(ws + lay.meta);
   ra.N = N; ra.nchunks = lay.nchunks; ra.L = L; ra.D = D;
   ra.avg = aggr == FFH_AGGR_MODE_AVG ? 1 : 0;
-  ra.lr = lr;
+  ra.op = op;
+  for (int i = 0; i < nt && kind != FFH_SPARSE_OPT_SGD; i++) { ra.s0[i] = states[i].s0; ra.s1[i] = states[i].s1; }
   ra.partial1 = (float*)(ws + lay.partial1);
   ra.meta1 = (uint2*)(ws + lay.meta1); ra.nchunks1 = lay.nchunks1;
   ra.arrive = (uint32_t*)(ws + lay.arrive);
   // segmented sums + both folds (32-block partials -> 1024-block partials -> row totals) + the SGD step: one launch
   dim3 rgrid((unsigned)((N + ra.tile - 1) / ra.tile), (unsigned)nt);
-  if (v4) hipLaunchKernelGGL((emb_sgd_reduce_kernel<4>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
-  else hipLaunchKernelGGL((emb_sgd_reduce_kernel<1>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);
+#define FFH_RED(OPTV)                                                                                                 \
+  { if (v4) hipLaunchKernelGGL((emb_sgd_reduce_kernel<4, OPTV>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);        \
+    else hipLaunchKernelGGL((emb_sgd_reduce_kernel<1, OPTV>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra); }
+  if (kind == FFH_SPARSE_OPT_SGD) FFH_RED(0) else if (kind == FFH_SPARSE_OPT_SGD_MOMENTUM) FFH_RED(1) else FFH_RED(2)
+#undef FFH_RED
   FFH_LAUNCH_CHECK(c, "emb_sgd_reduce/fold");
   return FFH_OK;
 }
@@ -1125,6 +1238,18 @@ int ffh_embedding_bwd_sort_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt
 int ffh_embedding_bwd_sgd_apply_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L, int D, int64_t batch,
                                       int aggr, float lr, ffh_stream s) {
   return emb_bwd_phases(c, tables, nt, L, D, batch, aggr, lr, s, false, true);
+}
+
+int ffh_embedding_bwd_opt_fused_multi(ffh_ctx* c, const ffh_emb_table* tables, const ffh_emb_state* states, int nt, int L, int D, int64_t batch,
+                                      int aggr, const ffh_sparse_opt* opt, ffh_stream s) {
+  if (!opt) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt_fused_multi: null ffh_sparse_opt");
+  return emb_bwd_phases(c, tables, nt, L, D, batch, aggr, opt->lr, s, true, true, opt, states);
+}
+
+int ffh_embedding_bwd_opt_apply_multi(ffh_ctx* c, const ffh_emb_table* tables, const ffh_emb_state* states, int nt, int L, int D, int64_t batch,
+                                      int aggr, const ffh_sparse_opt* opt, ffh_stream s) {
+  if (!opt) return ffh_fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt_apply_multi: null ffh_sparse_opt");
+  return emb_bwd_phases(c, tables, nt, L, D, batch, aggr, opt->lr, s, false, true, opt, states);
 }
 
 int ffh_embedding_bwd_sgd_fused(ffh_ctx* c, const int64_t* idx, const float* g, float* weight, int L, int D, int64_t batch,

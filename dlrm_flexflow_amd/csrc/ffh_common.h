@@ -28,6 +28,8 @@ struct ffh_ctx {
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
   ffh_mirror_region mirrors[32];   // bf16 twins of fp32 buffers (tensor-op mode)
   int         nmirrors;
+  const void* emb_sorted_ws;     // ffh_embedding_bwd_sort_multi left a sorted list (and cleared fold counters) in THIS workspace ...
+  int64_t     emb_sorted_sig[4]; // ... for this (ntables, in_dim, out_dim, batch): ffh_embedding_bwd_sgd_apply_multi consumes it, once
   char        route[256]; // ffh_linear_last_route(): kernel families of the latest ffh_linear_* call
   char        err[512];
 };
@@ -93,6 +95,21 @@ static inline unsigned ffh_grid(int64_t work_items, int per_block, unsigned cap 
 constexpr int kWave = 64;
 
 #ifdef __HIPCC__
+// Wave priority of every kernel except the persistent GEMMs (linear_sk.hip).  A persistent workgroup keeps one wave per SIMD that
+// issues MFMAs back to back for hundreds of microseconds; the instruction arbiter serves the oldest ready wave of a SIMD first, so a
+// short kernel whose workgroups share those CUs got an issue slot only while the GEMM wave sat at a barrier -- the bottom MLP's
+// 0.27-GFLOP data-gradient GEMM took 210 us beside the first top layer's weight gradient at 4096 samples (alone: 8 us), and the
+// whole chain behind it waited.  s_setprio raises these waves above the GEMM's (priority 0): they run when they are ready, the GEMM
+// fills every other cycle.  FFH_PRIO = 0 compiles it out (A/B builds).
+#ifndef FFH_PRIO
+#define FFH_PRIO 3
+#endif
+__device__ __forceinline__ void ffh_kernel_prio() {
+#if FFH_PRIO > 0
+  __builtin_amdgcn_s_setprio(FFH_PRIO);
+#endif
+}
+
 // 16-byte global access at 4-byte alignment: gfx950 (unaligned-access mode, the amdhsa default) serves a dwordx4 load /
 // store at any dword address, so leading dimensions that are not multiples of 4 floats keep the wide accesses
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));

@@ -50,6 +50,7 @@ __device__ __forceinline__ void load_row_piece(float (&v)[16], const float* row,
 template <int VEC, int OV>
 __global__ __launch_bounds__(256) void dot_interaction_fwd_kernel(const float* __restrict__ z, int64_t ldz, float* __restrict__ out, int64_t ldo,
                                                                   int64_t batch, int c, int d) {
+  ffh_kernel_prio();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -109,6 +110,7 @@ constexpr int kDotLds = 4 * 2 * kDotImage;               // 4 waves x 2 buffers 
 template <int OV>
 __global__ __launch_bounds__(256) void dot_interaction_fwd_lds_kernel(const float* __restrict__ z, int64_t ldz, float* __restrict__ out, int64_t ldo,
                                                                       int64_t batch, int c) {
+  ffh_kernel_prio();
   extern __shared__ __attribute__((aligned(16))) unsigned char dot_smem[];
   constexpr int d = kDotD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_lds_kernel(const floa
 template <int VEC, bool ACCUM>
 __global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ og, int64_t ldg,
                                                                   float* __restrict__ zg, int64_t ldzg, int64_t batch, int c, int d) {
+  ffh_kernel_prio();
   __shared__ float s_S[4][32 * 33];
   __shared__ uint16_t s_pair[kMaxC * (kMaxC - 1) / 2];     // p -> i * 33 + j
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -53,6 +53,7 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, const unsigned 
 template <int BM, int BN, int BK, bool AKC, bool BKC, bool SPLITW = false, bool FUSE_DY = false, bool CMAP = false>
 __global__ __launch_bounds__(256, (FFH_FWD_OCC4 && BM == 128 && BN == 128 && BK == 16 && AKC && BKC && !SPLITW && !FUSE_DY && !CMAP) ? 4 : 1)
 void gemm_f32_kernel(const GemmArgs g) {
+  ffh_kernel_prio();
   const bool pers = g.tnx != 0;
   const unsigned nbx = pers ? g.tnx : gridDim.x, nby = pers ? g.tny : gridDim.y, nbz = pers ? g.tnz : gridDim.z;
   const unsigned total = nbx * nby * nbz;
@@ -617,6 +618,7 @@ __device__ __forceinline__ void glds_body(const GldsArgs& g, const unsigned lin,
 
 template <bool AKR, bool BKR, int BM, int NSTAGE = kGldsStages>
 __global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_kernel(const GldsArgs g) {
+  ffh_kernel_prio();
   glds_body<AKR, BKR, BM, NSTAGE>(g, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, gridDim.z);
 }
 
@@ -628,6 +630,7 @@ struct GldsDims { unsigned nbx, nby, nbz; };
 template <int BM_DX, int NSTAGE = kGldsStages>
 __global__ __launch_bounds__(kGldsWaves * 64) void gemm_glds_bwd_kernel(const GldsArgs dxg, const GldsDims dxd, const unsigned na8,
                                                                         const GldsArgs dwg, const GldsDims dwd) {
+  ffh_kernel_prio();
   if (blockIdx.x < na8) glds_body<false, true, BM_DX, NSTAGE>(dxg, blockIdx.x, dxd.nbx, dxd.nby, dxd.nbz);
   else glds_body<true, true, 64, NSTAGE>(dwg, blockIdx.x - na8, dwd.nbx, dwd.nby, dwd.nbz);
 }
@@ -768,6 +771,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void act_bwd_bias_kernel(float* __restrict__ dy, int64_t lddy, const float* __restrict__ y, int64_t ldy,
                                                            float* __restrict__ db, int out, int64_t batch, int rows_per_block, int act,
                                                            int tx_count) {
+  ffh_kernel_prio();
   __shared__ float s_red[256 * VEC];
   const int TX = tx_count, TY = 256 / tx_count;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -850,6 +854,7 @@ __global__ __launch_bounds__(256) void act_bwd_bias_kernel(float* __restrict__ d
 // round trip, and a 64x64 workgroup tile would be 80 % padding.  Lane (row r, half h) of v_mfma_f32_32x32x2_f32
 // loads A(m0 + r, k + h) and B(n0 + r, k + h); eight k-steps of loads are issued before their MFMAs.
 __global__ __launch_bounds__(256) void bmm_small_kernel(const GemmArgs g, const int tiles_m, const int tiles_n, const int64_t ntiles) {
+  ffh_kernel_prio();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -978,6 +983,7 @@ constexpr int kSkinnyMaxIn = 1024;      // backward: a thread keeps <= 4 columns
 __global__ __launch_bounds__(256) void linear_skinny_fwd_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
                                                                 const float* __restrict__ w, const float* __restrict__ bias, int in, int out,
                                                                 int64_t batch, int act) {
+  ffh_kernel_prio();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < batch; b += (int64_t)gridDim.x * 4) {
     float acc[kSkinnyMaxOut] = {0.f, 0.f, 0.f, 0.f};
@@ -1003,6 +1009,7 @@ __global__ __launch_bounds__(256) void linear_skinny_fwd_kernel(const float* __r
 __global__ __launch_bounds__(512) void linear_thin_fwd_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
                                                               const float* __restrict__ w, const float* __restrict__ bias, int in, int out,
                                                               int64_t batch, int act) {
+  ffh_kernel_prio();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int64_t b0 = (int64_t)blockIdx.x * 32;
@@ -1040,6 +1047,7 @@ constexpr int kThinRowsPerWg = 128;
 __global__ __launch_bounds__(256) void linear_thin_fwd_rows_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
                                                                    const float* __restrict__ w, const float* __restrict__ bias, int in, int out,
                                                                    int64_t batch, int act) {
+  ffh_kernel_prio();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n0 = (blockIdx.y * 64 + lane) * 4;
@@ -1109,6 +1117,7 @@ struct SkinnyBwdArgs {
 // (lane = rsub * (64 / RPW) + chunk) instead of leaving three quarters of the wave idle on the 64-wide layer
 template <int NC, int NO, int RPW = 1>
 __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdArgs a) {
+  ffh_kernel_prio();
   static_assert(RPW == 1 || NC == 1, "row packing is for rows narrower than a wave");
   constexpr int LPR = 64 / RPW;
   extern __shared__ float s_dz[];                       // [rows_per_block][out], then the cross-wave dW reduction
@@ -1307,6 +1316,7 @@ struct PairBwdArgs {
 };
 
 __global__ __launch_bounds__(512) void linear_pair_bwd_kernel(const PairBwdArgs a) {
+  ffh_kernel_prio();
   __shared__ float s_gu[32][17];                         // dy_u tile after its activation gradient
   __shared__ float s_gl[32][65];                         // g_l tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1412,6 +1422,7 @@ struct PairFwdArgs {
 };
 
 __global__ __launch_bounds__(512) void linear_pair_fwd_kernel(const PairFwdArgs a) {
+  ffh_kernel_prio();
   __shared__ float s_red[8 * 16 * 64];                   // [wave][reg][lane]: the k-slices of the first product
   __shared__ float s_yl[32][65];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -53,6 +53,7 @@ __device__ __forceinline__ unsigned bf_off_kr(int krow, int chunk) { return (uns
 // of 8): a thread moves 16-byte chunks of 8 elements global -> LDS with no conversion and half the bytes
 template <bool AKC, bool BKC, bool MASK_A = false, int BM = kBfBM, int BN = kBfBN, int WM = 64, bool SRC16 = false>
 __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16_kernel(const GemmArgs g) {
+  ffh_kernel_prio();
   static_assert(!(SRC16 && MASK_A), "the masking loader reads fp32 operands");
   constexpr int BK = kBfBK, NT = BM / WM * BN;                 // one wave per WM x 64 of the tile
   constexpr int TM = WM / 32;
@@ -304,6 +305,7 @@ __device__ __forceinline__ void split_bf16x3(const float4 v, uint2& p1, uint2& p
 
 template <bool AKC, bool BKC, bool MASK_A = false, int BM = 128, int BN = 128, int WM = 64>
 __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16x3_kernel(const GemmArgs g) {
+  ffh_kernel_prio();
   constexpr int BK = kX3BK, NT = BM / WM * BN;                  // one wave per WM x 64 of the tile
   constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;             // float4 per thread per k-tile
   constexpr int TM = WM / 32;

@@ -393,11 +393,16 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   a.a_bytes = (unsigned)a_bytes; a.b_bytes = (unsigned)b_bytes;
   a.bias_bytes = g.bias ? (unsigned)g.N * 4u : 0u;
   a.mask_bytes = g.mask ? 1u : 0u;
+  // The kernels need more than 64 KB of dynamic LDS; hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of the
+  // function, and one process may hold a ctx per device (ffh_ctx_default): set once per (kernel, device).  A launch that still
+  // fails (attribute refused, no such resources) is not an error of the call: 0 = "not served", linear.hip's kernels take the layer.
 #define FFH_SK_LAUNCH(AKR, BKR, EPI, LDSB, ...)                                                                  \
   {                                                                                                              \
     auto kern = gemm_sk_kernel<AKR, BKR, EPI, ##__VA_ARGS__>;                                                    \
-    static const bool ok = sk_set_lds(kern, LDSB);                                                               \
-    if (!ok) return 0;                                                                                           \
+    static signed char ok[64];      /* 0: not tried on this device, 1: set, -1: refused */                      \
+    const int dev = c->device & 63;                                                                              \
+    if (ok[dev] == 0) ok[dev] = sk_set_lds(kern, LDSB) ? 1 : -1;                                                 \
+    if (ok[dev] < 0) return 0;                                                                                   \
     hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), LDSB, as_stream(s), a);                               \
   }
   if (form == SK_FORM_FWD) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC)
@@ -406,8 +411,7 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   else if (g.epi == EPI_STORE) FFH_SK_LAUNCH(false, true, SK_EPI_DX_STORE, SK_LDS_KC + SK_LDS_KR)
   else FFH_SK_LAUNCH(false, true, SK_EPI_DX_ADD, SK_LDS_KC + SK_LDS_KR)
 #undef FFH_SK_LAUNCH
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+  if (hipGetLastError() != hipSuccess) return 0;        // launch refused: nothing was enqueued, the caller falls through to linear.hip
   { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64|wgs=%d", name, G); ffh_route_add(c, tok); }
   return 1;
 }

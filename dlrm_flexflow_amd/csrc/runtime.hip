@@ -103,6 +103,7 @@ int ffh_ctx_bf16_mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* tw
 }
 
 __global__ __launch_bounds__(256) void convert_bf16_kernel(unsigned short* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  ffh_kernel_prio();
   const int64_t stride = (int64_t)gridDim.x * 256 * 4;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
     if (i + 3 < n && (((uintptr_t)(src + i)) & 15) == 0 && (((uintptr_t)(dst + i)) & 7) == 0) {

@@ -25,7 +25,7 @@ void print_vector(const std::string& name, const std::vector<int>& v) {
 
 DLRMConfig::DLRMConfig(void)
     : sparse_feature_size(2), sigmoid_bot(-1), sigmoid_top(-1), embedding_bag_size(1), loss_threshold(0.0f),
-      arch_interaction_op("cat"), dataset_path(""), data_size(-1), zipf_alpha(0.0) {
+      arch_interaction_op("cat"), dataset_path(""), data_size(-1), optimizer("sgd"), zipf_alpha(0.0) {
   embedding_size.push_back(4);
   mlp_bot.push_back(4); mlp_bot.push_back(2);
   mlp_top.push_back(8); mlp_top.push_back(2);
@@ -50,6 +50,7 @@ void parse_input_args(char** argv, int argc, DLRMConfig& config) {
     if (!strcmp(argv[i], "--sigmoid-top")) { config.sigmoid_top = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "--sigmoid-bot")) { config.sigmoid_bot = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "--arch-interaction-op")) { config.arch_interaction_op = std::string(argv[++i]); continue; }
+    if (!strcmp(argv[i], "--optimizer") && i + 1 < argc) { config.optimizer = std::string(argv[++i]); continue; }
     if (!strcmp(argv[i], "--dataset")) { config.dataset_path = std::string(argv[++i]); continue; }
     if (!strcmp(argv[i], "--data-size")) { config.data_size = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "--zipf-alpha")) { config.zipf_alpha = atof(argv[++i]); continue; }   // not a reference flag
@@ -314,8 +315,13 @@ DLRMApp::DLRMApp(int argc, char** argv, const ffcomm* comm) : ff(nullptr), loade
     fprintf(stderr, "FATAL: --loss-threshold clamp is not implemented (the reference asserts here, dlrm.cc:125-128)\n");
     abort();
   }
-  // Use SGD Optimizer
-  optimizer = new SGDOptimizer(ff, 0.01f);
+  // Use SGD Optimizer [ref: examples/cpp/DLRM/dlrm.cc:130: SGDOptimizer(&ff, 0.01f), the reference driver's only choice].
+  // --optimizer (this build): the other optimizers of the reference's library behind the same driver -- "sgd-momentum" =
+  // SGDOptimizer(lr 0.01, momentum 0.9), "adam" = AdamOptimizer with its defaults [ref: include/optimizer.h:40-42,62-85]
+  if (dlrm.optimizer == "sgd") optimizer = new SGDOptimizer(ff, 0.01f);
+  else if (dlrm.optimizer == "sgd-momentum") optimizer = new SGDOptimizer(ff, 0.01f, 0.9f);
+  else if (dlrm.optimizer == "adam") optimizer = new AdamOptimizer(ff);
+  else { fprintf(stderr, "FATAL: --optimizer %s: 'sgd', 'sgd-momentum' or 'adam'\n", dlrm.optimizer.c_str()); abort(); }
   std::vector<MetricsType> metrics;
   metrics.push_back(METRICS_ACCURACY);
   metrics.push_back(METRICS_MEAN_SQUARED_ERROR);

@@ -17,6 +17,7 @@ struct DLRMConfig {
   std::vector<int> embedding_size, mlp_bot, mlp_top;
   std::string arch_interaction_op, dataset_path;
   int data_size;
+  std::string optimizer;   // --optimizer sgd (default, the reference driver's) | sgd-momentum | adam (not a reference flag)
   double zipf_alpha;   // > 0: synthetic ids follow a power law instead of the reference's uniform draw (not a reference flag)
 };
 

@@ -105,6 +105,8 @@ class FFConfig {
   bool deterministic;          // --deterministic: weight / bias gradients without fp atomics (ffh_ctx_set_deterministic): bit-identical runs
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
+  bool sparse_embedding_optimizer;   // --sparse-embedding-optimizer: momentum / weight-decay SGD and Adam update the rows a batch touched, with per-row state, on the
+                               // sorted segments of the fused update (ffh_sparse_opt: lazy semantics, a stated divergence) instead of the reference's dense sweep
   bool early_sort;             // the index-only sort of the fused table update runs behind the gather (ffh_embedding_bwd_sort_multi), off the backward's critical path (A/B: --no-early-sort)
   bool dx_scatter;             // exchange mode: the layer above the feature Concat writes its dX into the send buffer itself (A/B: --no-dx-scatter)
   bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)
@@ -327,6 +329,7 @@ class Embedding : public Op {
   // MLP all-reduce bucket and the slab SGD / Adam launch cover them.  --replicate-embedding-rows N or a strategy file.
   bool replicated;
   void set_replicated(const FFModel& model, bool on);
+  float* opt_state[2] = {nullptr, nullptr};   // --sparse-embedding-optimizer: per-row state of this rank's slice (SGD momentum: V; Adam: M, V)
   bool held_here(int rank) const { return owner_rank == rank || column_sharded || row_sharded || replicated; }
 };
 
@@ -511,7 +514,10 @@ class FFModel {
   mutable bool probe_events_on = false;
   mutable ffh_event probe_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gather begin / end, update begin / end
   void probe_record(int which, ffh_stream s, ffh_ctx* cx) const;
-  bool fused_embedding_update() const;
+  bool fused_embedding_update() const;        // the tables are updated on the sorted segments (plain SGD, or any optimizer with --sparse-embedding-optimizer)
+  bool sparse_rule(ffh_sparse_opt& rule) const;   // the row rule in force; false: plain SGD
+  mutable bool opt_next_done = false;          // Optimizer::next() has run for the step in flight (update() does it; backward() clears it)
+  void embedding_dense_update() const;         // the reference's dense path on the holders of each table (any optimizer, any placement)
   void issue_embedding_forward_on_side_stream() const;
   void join_embedding_forward() const;
   void issue_embedding_update_on_side_stream() const;
@@ -526,7 +532,9 @@ class FFModel {
   // tensor-op math mode: bfloat16 twins of the weight slab, of activations and of activation gradients whose every writer
   // keeps a twin current (ffh_ctx_bf16_mirror_set): the bf16-pipe GEMMs then read 2-byte operands instead of rounding 4-byte ones
   void* w_twin = nullptr; void* act_twin = nullptr; void* grad_twin = nullptr;
-  mutable bool w_twin_dirty = false;      // a host write / initializer touched the weights: reconvert before the next forward
+  mutable bool w_twin_dirty = false;      // a host write / initializer touched the weights: reconvert before the next step
+  void refresh_weight_twin() const;
+  void note_weight_write(const void* p) const;
   int n_twin_regions = 0;
   int z_reader_layer;           // the lowest-index Linear that reads a Concat output the tables are gathered into (-1: unknown): behind ITS
                                 // backward no forked weight-gradient GEMM reads that buffer any more, so the next gather may overwrite it

@@ -75,6 +75,7 @@ int launcher_barrier(void*) {
 
 int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv) {
   const bool dry = getenv("FFM_LAUNCH_DRYRUN") != nullptr;     // tests: process management + rendezvous without a GPU
+  if (dry && getenv("FFM_LAUNCH_TEST_IGNORE_TERM")) signal(SIGTERM, SIG_IGN);   // tests: a rank that does not listen (SIGKILL after the grace period)
   unsigned char id[128];
   memset(id, 0, sizeof id);
   const char* rccl = getenv("FFM_RCCL_LIB");
@@ -111,7 +112,9 @@ int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv)
     for (int i = 0; i < 128; i++) sum += id[i];
     printf("[launcher] rank %d of %d: rendezvous ok (id checksum %u)\n", rank, world, sum);
     fflush(stdout);
-    if (getenv("FFM_LAUNCH_TEST_HANG")) for (;;) pause();      // tests: a rank that never ends by itself (the parent must end it)
+    if (getenv("FFM_LAUNCH_TEST_HANG")) {                      // tests: a rank that never ends by itself (the parent must end it)
+      for (;;) pause();
+    }
     return 0;
   }
   ffcomm comm;
@@ -140,15 +143,10 @@ int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv)
 
 }  // namespace
 
-// the parent's signal handler: forwards SIGTERM / SIGINT to the ranks it started (async-signal-safe: kill only)
-static const pid_t* volatile g_pids = nullptr;
-static volatile size_t g_npids = 0;
+// the parent's signal handler only notes the signal (async-signal-safe by construction); the wait loop below forwards it to the
+// ranks that are still running -- by the pids this process forked and has not reaped yet, so a reused pid is never signalled
 static volatile sig_atomic_t g_signalled = 0;
-static void forward_signal(int sig) {
-  g_signalled = 1;
-  const pid_t* p = g_pids;
-  for (size_t i = 0; p && i < g_npids; i++) kill(p[i], sig);
-}
+static void note_signal(int sig) { g_signalled = sig; }
 
 int dlrm_launch(int argc, char** argv) {
   const char* er = getenv("FFM_LAUNCH_RANK");
@@ -171,11 +169,26 @@ int dlrm_launch(int argc, char** argv) {
   const ssize_t k = readlink("/proc/self/exe", exe, sizeof exe - 1);
   if (k <= 0) { perror("dlrm: /proc/self/exe"); return 2; }
   exe[k] = 0;
+  // SIGTERM / SIGINT stay blocked while the ranks are being started and the handlers are in place BEFORE the first fork: a signal
+  // that arrives early is delivered when the loop below unblocks it and is then forwarded like any other (it used to kill the
+  // parent and orphan the ranks on their GPUs).  The children restore the default disposition and the mask before they exec.
+  sigset_t block, old;
+  sigemptyset(&block); sigaddset(&block, SIGTERM); sigaddset(&block, SIGINT);
+  sigprocmask(SIG_BLOCK, &block, &old);
+  struct sigaction sa, old_term, old_int;
+  memset(&sa, 0, sizeof sa);
+  sa.sa_handler = note_signal;
+  sigaction(SIGTERM, &sa, &old_term);
+  sigaction(SIGINT, &sa, &old_int);
+  if (getenv("FFM_LAUNCH_TEST_SIGNAL_SELF_EARLY")) raise(SIGTERM);     // tests: a signal that arrives before the first fork (stays pending until the mask is restored)
   std::vector<pid_t> pids;
   for (int r = 0; r < n; r++) {
     const pid_t pid = fork();
     if (pid < 0) { perror("dlrm: fork"); break; }
     if (pid == 0) {
+      sigaction(SIGTERM, &old_term, nullptr);
+      sigaction(SIGINT, &old_int, nullptr);
+      sigprocmask(SIG_SETMASK, &old, nullptr);
       setenv("FFM_LAUNCH_RANK", std::to_string(r).c_str(), 1);
       setenv("FFM_LAUNCH_WORLD", std::to_string(n).c_str(), 1);
       setenv("FFM_LAUNCH_RDV", dir, 1);
@@ -186,36 +199,36 @@ int dlrm_launch(int argc, char** argv) {
     }
     pids.push_back(pid);
   }
+  sigprocmask(SIG_SETMASK, &old, nullptr);
   int failed = (int)pids.size() != n;
   size_t left = pids.size();
   std::vector<bool> done(pids.size(), false);
-  // a termination signal to the launcher goes on to the ranks it started (they would be orphaned on the GPUs otherwise)
-  g_pids = pids.data(); g_npids = pids.size();
-  struct sigaction sa;
-  memset(&sa, 0, sizeof sa);
-  sa.sa_handler = forward_signal;
-  sigaction(SIGTERM, &sa, nullptr);
-  sigaction(SIGINT, &sa, nullptr);
-  if (failed)        // a fork failed after some ranks had started: they would wait for a world that never completes
-    for (pid_t q : pids) kill(q, SIGTERM);
+  auto signal_running = [&](int sig) {
+    for (size_t j = 0; j < pids.size(); j++)
+      if (!done[j]) kill(pids[j], sig);            // never a pid that has been reaped (it may belong to somebody else by now)
+  };
   std::chrono::steady_clock::time_point term_at{};
-  bool terminating = failed != 0;
-  if (terminating) term_at = std::chrono::steady_clock::now();
+  bool terminating = false, killed = false;
+  const double grace_s = getenv("FFM_LAUNCH_GRACE_S") ? atof(getenv("FFM_LAUNCH_GRACE_S")) : 10.0;
+  auto begin_termination = [&](int sig) {
+    if (terminating) return;
+    terminating = true; failed = 1; term_at = std::chrono::steady_clock::now();
+    signal_running(sig);
+  };
+  if (failed) begin_termination(SIGTERM);      // a fork failed after some ranks had started: they would wait for a world that never completes
   while (left > 0) {
-    int st = 0;
-    const pid_t p = waitpid(-1, &st, terminating ? WNOHANG : 0);
-    if (p == 0) {      // asked the ranks to end: give them a grace period, then SIGKILL what is left
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - term_at).count() > 10.0)
-        for (size_t j = 0; j < pids.size(); j++)
-          if (!done[j]) kill(pids[j], SIGKILL);
-      std::this_thread::sleep_for(std::chrono::milliseconds(20));
-      continue;
+    // the flag is looked at on every turn, not only when waitpid was interrupted: a signal that lands between two waitpid calls
+    // starts the grace timer as well (a rank that ignores SIGTERM is SIGKILLed after 10 s either way)
+    if (g_signalled) begin_termination(g_signalled);
+    if (terminating && !killed && std::chrono::duration<double>(std::chrono::steady_clock::now() - term_at).count() > grace_s) {
+      signal_running(SIGKILL);
+      killed = true;
     }
+    int st = 0;
+    const pid_t p = waitpid(-1, &st, WNOHANG);
+    if (p == 0) { std::this_thread::sleep_for(std::chrono::milliseconds(10)); continue; }
     if (p < 0) {
-      if (errno == EINTR) {                      // our own handler ran: the signal has been forwarded
-        if (g_signalled && !terminating) { terminating = true; failed = 1; term_at = std::chrono::steady_clock::now(); }
-        continue;
-      }
+      if (errno == EINTR) continue;
       break;
     }
     for (size_t i = 0; i < pids.size(); i++) {
@@ -224,16 +237,12 @@ int dlrm_launch(int argc, char** argv) {
       const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
       if (rc != 0) {
         fprintf(stderr, "dlrm: rank %zu ended with %d\n", i, rc);
-        if (!failed) {
-          failed = 1;
-          for (size_t j = 0; j < pids.size(); j++)
-            if (!done[j]) kill(pids[j], SIGTERM);      // the ranks this process started, by pid: peers of a dead rank would wait for ever
-          terminating = true; term_at = std::chrono::steady_clock::now();
-        }
+        begin_termination(SIGTERM);              // peers of a dead rank would wait for ever
       }
     }
   }
-  g_pids = nullptr; g_npids = 0;
+  sigaction(SIGTERM, &old_term, nullptr);
+  sigaction(SIGINT, &old_int, nullptr);
   unlink((std::string(dir) + "/rccl_unique_id").c_str());
   unlink((std::string(dir) + "/rccl_unique_id.tmp").c_str());
   rmdir(dir);

@@ -134,6 +134,7 @@ FFConfig::FFConfig() {
   fuse_pair = true;
   dx_scatter = true;
   early_sort = true;
+  sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
   deterministic = false;
@@ -193,6 +194,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
     if (is("--no-early-sort")) { early_sort = false; continue; }
+    if (is("--sparse-embedding-optimizer")) { sparse_embedding_optimizer = true; continue; }
   }
 }
 
@@ -243,8 +245,7 @@ bool Tensor::set_tensor(const FFModel* model, const std::vector<int>& dims, cons
                                                cols_ * sizeof(T), model->stream), "set_tensor");
   }
   model->check(model->api->ffh_stream_sync(model->ctx, model->stream), "set_tensor sync");
-  if (model->w_twin && (const char*)impl->ptr >= (const char*)model->mlp_weights && (const char*)impl->ptr < (const char*)(model->mlp_weights + model->mlp_count))
-    model->w_twin_dirty = true;       // tensor-op mode: the weights' bf16 twin is reconverted before the next forward
+  model->note_weight_write(impl->ptr);       // tensor-op mode: the weights' bf16 twin is reconverted before the next step
   return true;
 }
 
@@ -302,14 +303,17 @@ template bool Parameter::get_weights<float>(const FFModel*, float*) const;
 // =============================================================================================
 void ZeroInitializer::init(const FFModel* ff, const Parameter* p) {
   ff->check(ff->api->ffh_zero(ff->ctx, p->impl->ptr, p->get_volume() * sizeof(float), ff->stream), "ZeroInitializer");
+  ff->note_weight_write(p->impl->ptr);
 }
 void ConstantInitializer::init(const FFModel* ff, const Parameter* p) {
   ff->check(ff->api->ffh_fill_f32(ff->ctx, (float*)p->impl->ptr, (int64_t)p->get_volume(), value, ff->stream), "ConstantInitializer");
+  ff->note_weight_write(p->impl->ptr);
 }
 void UniformInitializer::init(const FFModel* ff, const Parameter* p) {
   ff->check(ff->api->ffh_init_uniform(ff->ctx, (float*)p->impl->ptr, (int64_t)p->get_volume(),
                                       ff->config.seed * 0x9E3779B1ULL + (uint64_t)(uint32_t)seed, min_val, max_val, ff->stream),
             "UniformInitializer");
+  ff->note_weight_write(p->impl->ptr);
 }
 void NormInitializer::init(const FFModel* ff, const Parameter* p) {
   // Box-Muller on the host from the counter-based stream, then one upload (MLP tensors are small)
@@ -325,6 +329,7 @@ void NormInitializer::init(const FFModel* ff, const Parameter* p) {
   }
   ff->check(ff->api->ffh_memcpy_h2d(ff->ctx, p->impl->ptr, h.data(), n * sizeof(float), ff->stream), "NormInitializer");
   ff->check(ff->api->ffh_stream_sync(ff->ctx, ff->stream), "NormInitializer sync");
+  ff->note_weight_write(p->impl->ptr);
 }
 void GlorotUniform::init(const FFModel* ff, const Parameter* p) {
   // scale = sqrt(6 / (fan_in + fan_out)) [ref: src/runtime/initializer_kernel.cu:24-60]
@@ -333,6 +338,7 @@ void GlorotUniform::init(const FFModel* ff, const Parameter* p) {
   ff->check(ff->api->ffh_init_uniform(ff->ctx, (float*)p->impl->ptr, (int64_t)p->get_volume(),
                                       ff->config.seed * 0x9E3779B1ULL + (uint64_t)(uint32_t)seed, -scale, scale, ff->stream),
             "GlorotUniform");
+  ff->note_weight_write(p->impl->ptr);
 }
 
 // =============================================================================================
@@ -477,7 +483,7 @@ FFModel::~FFModel() {
                   (void*)xrecv, (void*)gsend, (void*)grecv})
     if (p) api->ffh_free(ctx, p);
   for (Embedding* e : embeddings)
-    for (void* p : {(void*)e->local_idx, (void*)e->partial, (void*)e->gfull})
+    for (void* p : {(void*)e->local_idx, (void*)e->partial, (void*)e->gfull, (void*)e->opt_state[0], (void*)e->opt_state[1]})
       if (p) api->ffh_free(ctx, p);
   for (Op* op : layers)
     if (op->op_type == OP_LINEAR && static_cast<Linear*>(op)->dx_map) api->ffh_free(ctx, static_cast<Linear*>(op)->dx_map);
@@ -786,13 +792,13 @@ void Embedding::backward(const FFModel& ff) {
     return;
   }
   // reference path: dense scatter-add into the full-table gradient [ref: src/ops/embedding.cu:308-320]
+  if (ff.exchange) return;      // multi-rank: the rows' gradients first go back to the owners -- embedding_dense_update(), from update()
   for (Embedding* e : ff.embeddings) {
     if (e->owner_rank != ff.rank || e->replicated) continue;
     const Tensor& in = e->inputs[0];
     const Tensor& out = e->outputs[0];
     const float* g = out.impl->grad;
     int64_t gld = out.impl->grad_ld, batch = ff.local_batch;
-    if (ff.exchange) die("dense embedding update is single-rank only");
     ff.check(ff.api->ffh_embedding_bwd_dense(ff.ctx, (const int64_t*)in.impl->ptr, g, e->weights[0].impl->grad, in.adim[0],
                                              e->out_channels, batch, e->num_entries, gld, (int)e->aggr, ff.stream), e->name);
   }
@@ -1154,8 +1160,34 @@ int FFModel::next_seed() {
 bool FFModel::fused_embedding_update() const {
   if (config.dense_embedding_update) return false;
   const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(optimizer);
-  // the fused sparse update equals the reference's dense sweep only for plain SGD
-  return sgd && sgd->momentum == 0.0 && sgd->weight_decay == 0.0;
+  // the fused sparse update equals the reference's dense sweep only for plain SGD ...
+  if (sgd && sgd->momentum == 0.0 && sgd->weight_decay == 0.0) return true;
+  // ... every other optimizer takes the reference's dense path (zero + scatter-add + whole-table sweep: reference semantics on
+  // every row) unless the user opts into the touched-rows rule (--sparse-embedding-optimizer; stated divergence: ffh_sparse_opt)
+  return config.sparse_embedding_optimizer && (sgd || dynamic_cast<const AdamOptimizer*>(optimizer));
+}
+
+// the row rule of the sorted-segments update for the optimizer in force; false: plain SGD (the lr-only entry points)
+bool FFModel::sparse_rule(ffh_sparse_opt& o) const {
+  memset(&o, 0, sizeof o);
+  if (const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(optimizer)) {
+    o.lr = (float)sgd->lr;
+    if (sgd->momentum == 0.0 && sgd->weight_decay == 0.0) { o.kind = FFH_SPARSE_OPT_SGD; return false; }
+    o.kind = FFH_SPARSE_OPT_SGD_MOMENTUM; o.weight_decay = (float)sgd->weight_decay; o.momentum = (float)sgd->momentum; o.nesterov = sgd->nesterov ? 1 : 0;
+    return true;
+  }
+  const AdamOptimizer* adam = dynamic_cast<const AdamOptimizer*>(optimizer);
+  if (!adam) die("sparse_rule: unknown optimizer");
+  // alpha_t of THIS step [ref: AdamOptimizer::next, src/runtime/optimizer.cc:248-254].  The reference advances it at the top of
+  // update(); the side-stream table update is issued from backward(), before that -- it looks one next() ahead then.
+  double alpha_t = adam->alpha_t;
+  if (!opt_next_done) {
+    const double b1 = adam->beta1_t * adam->beta1, b2 = adam->beta2_t * adam->beta2;
+    alpha_t = adam->alpha * sqrt(1 - b2) / (1 - b1);
+  }
+  o.kind = FFH_SPARSE_OPT_ADAM; o.lr = (float)alpha_t; o.weight_decay = (float)adam->weight_decay;
+  o.beta1 = (float)adam->beta1; o.beta2 = (float)adam->beta2; o.epsilon = (float)adam->epsilon;
+  return true;
 }
 
 // Placement from a strategy file [ref: FFModel::compile -> load_strategies_from_file, src/runtime/model.cc:1575-1577;
@@ -1267,12 +1299,11 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
   }
   if (exchange && config.enable_graph) config.enable_graph = false;   // collectives are host callbacks: not capturable
   if (dynamic_cast<AdamOptimizer*>(optimizer) && config.enable_graph) config.enable_graph = false;   // alpha_t is a new launch argument every step
-  // tables that one rank owns (or holds a slice of) are updated by the fused sparse kernel; only a purely data-parallel job --
-  // every table replicated, the reference's default placement -- can run any optimizer on several ranks
-  bool all_replicated = true;
-  for (const Embedding* e : embeddings) all_replicated = all_replicated && e->replicated;
-  if (exchange && !all_replicated && !fused_embedding_update())
-    die("multi-rank runs need the fused embedding update (plain SGD) unless every table is data-parallel (--replicate-embedding-rows)");
+  // Any optimizer x any placement (round 4).  Plain SGD: the fused sorted-segments update.  Momentum / weight-decay SGD, Adam:
+  // by default the reference's own path on the rank(s) that hold the table -- an owner-local dense gradient (zeroed, scatter-added
+  // from the rows the backward all-to-all returned, swept by sgd_update / adam_update with dense per-table state; sole owner: no
+  // all-reduce) -- or, with --sparse-embedding-optimizer, the touched-rows rule on the sorted segments with per-row state
+  // (ffh_sparse_opt).  Data-parallel (replicated) tables live in the dense slab and follow the MLP's optimizer launch either way.
   allocate();
   for (Op* op : layers) {
     if (Linear* li = dynamic_cast<Linear*>(op)) {
@@ -1284,6 +1315,20 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
   }
   compiled = true;
   optimizer->init();
+  {   // per-row optimizer state of the touched-rows rule: the shape of the local table (+ the zero row of a row block)
+    ffh_sparse_opt rule;
+    if (fused_embedding_update() && sparse_rule(rule)) {
+      const int nstate = rule.kind == FFH_SPARSE_OPT_ADAM ? 2 : (rule.momentum > 0.0f ? 1 : 0);
+      for (Embedding* e : embeddings) {
+        if (!e->held_here(rank) || e->replicated) continue;
+        const size_t bytes = e->weights[0].impl->bytes + (e->row_sharded ? (size_t)e->out_channels * 4 : 0);
+        for (int k = 0; k < nstate; k++) {
+          e->opt_state[k] = (float*)dmalloc(bytes);
+          check(api->ffh_zero(ctx, e->opt_state[k], bytes, stream), "sparse optimizer state");
+        }
+      }
+    }
+  }
   check(api->ffh_stream_sync(ctx, stream), "compile sync");
 }
 
@@ -1623,7 +1668,7 @@ void FFModel::allocate() {
       im->ptr = dmalloc(im->bytes + (e->row_sharded ? (size_t)e->out_channels * 4 : 0));   // row block: + the zero row
       if (e->row_sharded) check(api->ffh_zero(ctx, (char*)im->ptr + im->bytes, (size_t)e->out_channels * 4, stream), "zero row");
       if (!fused) {
-        im->grad = (float*)dmalloc(im->bytes);
+        im->grad = (float*)dmalloc(im->bytes + (e->row_sharded ? (size_t)e->out_channels * 4 : 0));   // row block: foreign ids pile onto the zero row
         im->grad_ld = im->ld;
       }
     }
@@ -1741,10 +1786,12 @@ void FFModel::print_layers(int id) {
 enum ShardLaunch { kGather, kFusedUpdate, kSortOnly, kApplyOnly };
 static void launch_shard_groups(const FFModel* ff, ShardLaunch what, ffh_stream s, ffh_ctx* cx, const std::vector<const int64_t*>* idx_override = nullptr) {
   const bool fwd = what == kGather;
-  const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(ff->optimizer);
+  ffh_sparse_opt rule;
+  const bool ruled = (what == kFusedUpdate || what == kApplyOnly) && ff->sparse_rule(rule);     // momentum / wd SGD, Adam on the touched rows
   const int L = ff->embeddings[0]->inputs[0].adim[0];
   const int aggr = (int)ff->embeddings[0]->aggr;
   std::map<int, std::vector<ffh_emb_table>> by_cols;
+  std::map<int, std::vector<ffh_emb_state>> st_by_cols;
   size_t owned_i = 0;
   for (const FFModel::EmbShard& sh : ff->shards) {
     if (sh.owner != ff->rank) continue;
@@ -1763,19 +1810,25 @@ static void launch_shard_groups(const FFModel* ff, ShardLaunch what, ffh_stream 
       t.ld = ff->rank_width[ff->rank];
     }
     by_cols[sh.cols].push_back(t);
+    st_by_cols[sh.cols].push_back(ffh_emb_state{e->opt_state[0], e->opt_state[1]});
   }
   for (auto& kv : by_cols) {
     std::vector<ffh_emb_table>& tabs = kv.second;
+    const std::vector<ffh_emb_state>& sts = st_by_cols[kv.first];
     for (size_t b = 0; b < tabs.size(); b += FFH_MAX_TABLES) {
       const int n = (int)std::min<size_t>(FFH_MAX_TABLES, tabs.size() - b);
       const int64_t B = ff->config.batchSize;
       switch (what) {
         case kGather: ff->check(ff->api->ffh_embedding_fwd_multi(cx, tabs.data() + b, n, L, kv.first, B, aggr, s), "embedding_fwd_multi"); break;
-        case kFusedUpdate: ff->check(ff->api->ffh_embedding_bwd_sgd_fused_multi(cx, tabs.data() + b, n, L, kv.first, B, aggr, (float)sgd->lr, s),
-                                     "embedding_bwd_sgd_fused_multi"); break;
+        case kFusedUpdate:
+          if (ruled) ff->check(ff->api->ffh_embedding_bwd_opt_fused_multi(cx, tabs.data() + b, sts.data() + b, n, L, kv.first, B, aggr, &rule, s), "embedding_bwd_opt_fused_multi");
+          else ff->check(ff->api->ffh_embedding_bwd_sgd_fused_multi(cx, tabs.data() + b, n, L, kv.first, B, aggr, rule.lr, s), "embedding_bwd_sgd_fused_multi");
+          break;
         case kSortOnly: ff->check(ff->api->ffh_embedding_bwd_sort_multi(cx, tabs.data() + b, n, L, kv.first, B, s), "embedding_bwd_sort_multi"); break;
-        case kApplyOnly: ff->check(ff->api->ffh_embedding_bwd_sgd_apply_multi(cx, tabs.data() + b, n, L, kv.first, B, aggr, (float)sgd->lr, s),
-                                   "embedding_bwd_sgd_apply_multi"); break;
+        case kApplyOnly:
+          if (ruled) ff->check(ff->api->ffh_embedding_bwd_opt_apply_multi(cx, tabs.data() + b, sts.data() + b, n, L, kv.first, B, aggr, &rule, s), "embedding_bwd_opt_apply_multi");
+          else ff->check(ff->api->ffh_embedding_bwd_sgd_apply_multi(cx, tabs.data() + b, n, L, kv.first, B, aggr, rule.lr, s), "embedding_bwd_sgd_apply_multi");
+          break;
       }
     }
   }
@@ -1784,7 +1837,7 @@ static void launch_shard_groups(const FFModel* ff, ShardLaunch what, ffh_stream 
 // the batched gather (fwd) or fused update kernels of this rank's shards alone, no exchange: what bench.py times as the
 // roofline kernels of a multi-rank job
 void FFModel::embedding_kernels_only(bool fwd, ffh_stream s, const std::vector<const int64_t*>* idx_override) const {
-  if (embeddings.empty()) return;
+  if (embeddings.empty() || (!fwd && !fused_embedding_update())) return;
   launch_shard_groups(this, fwd ? kGather : kFusedUpdate, s, ctx, idx_override);
 }
 
@@ -1898,17 +1951,53 @@ void FFModel::embedding_group_update(ffh_stream s, ffh_ctx* on_ctx) const {
   // row-wise sharded tables: every rank needs the gradient rows of the global batch; the fused update then touches the
   // rows held here, and whatever the other ranks' rows piled onto the zero row is wiped
   ffh_ctx* cx = on_ctx ? on_ctx : ctx;
-  const SGDOptimizer* sgd = dynamic_cast<const SGDOptimizer*>(optimizer);
+  ffh_sparse_opt rule;
+  const bool ruled = sparse_rule(rule);
   for (const Embedding* e : embeddings) {
     if (!e->row_sharded) continue;
     const int L = e->inputs[0].adim[0], D = e->out_channels;
     if (config.comm.allgather_f32(config.comm.user, e->outputs[0].impl->grad, e->gfull, local_batch * D, s) != 0)
       die("all-gather (row-sharded embedding backward) failed");
     float* w = (float*)e->weights[0].impl->ptr;
-    check(api->ffh_embedding_bwd_sgd_fused(cx, e->local_idx, e->gfull, w, L, D, config.batchSize, e->rows_local + 1, D, (int)e->aggr,
-                                           (float)sgd->lr, s), e->name);
-    check(api->ffh_zero(cx, w + e->rows_local * (int64_t)D, (size_t)D * 4, s), "zero row");
+    if (ruled) {
+      const ffh_emb_table t{e->local_idx, w, e->gfull, e->rows_local + 1, D};
+      const ffh_emb_state st{e->opt_state[0], e->opt_state[1]};
+      check(api->ffh_embedding_bwd_opt_fused_multi(cx, &t, &st, 1, L, D, config.batchSize, (int)e->aggr, &rule, s), e->name);
+    } else {
+      check(api->ffh_embedding_bwd_sgd_fused(cx, e->local_idx, e->gfull, w, L, D, config.batchSize, e->rows_local + 1, D, (int)e->aggr, rule.lr, s), e->name);
+    }
+    check(api->ffh_zero(cx, w + e->rows_local * (int64_t)D, (size_t)D * 4, s), "zero row");   // (its optimizer state is never read for a row of the block)
   }
+}
+
+// The reference's own table update on the rank(s) that hold a table, for optimizers the fused update does not cover (default for
+// momentum / weight-decay SGD and Adam): Op::zero_grad [ref: src/runtime/model.cc:466-490] (zero_gradients()), embed_backward
+// [ref: src/ops/embedding.cu:192-217] into the owner-local dense gradient, then the optimizer's dense sweep with its dense per-table
+// state [ref: src/runtime/optimizer.cc:93-189,256-330].  Multi-rank: the rows' gradients first travel back to the owners (the
+// transposed all-to-all / the all-gather of a row-sharded table); a table has ONE holder per element, so nothing is all-reduced.
+void FFModel::embedding_dense_update() const {
+  if (embeddings.empty()) return;
+  const int L = embeddings[0]->inputs[0].adim[0];
+  const int aggr = (int)embeddings[0]->aggr;
+  if (exchange) {
+    if (!shards.empty() && config.comm.alltoall_f32(config.comm.user, gsend, fwd_recv_counts.data(), grecv, fwd_send_counts.data(), stream) != 0)
+      die("alltoall (embedding backward) failed");
+    for (const EmbShard& sh : shards) {
+      if (sh.owner != rank) continue;
+      const Embedding* e = sh.e;
+      check(api->ffh_embedding_bwd_dense(ctx, (const int64_t*)e->inputs[0].impl->ptr, grecv + sh.off, e->weights[0].impl->grad, L, sh.cols,
+                                         config.batchSize, e->num_entries, rank_width[rank], aggr, stream), e->name);
+    }
+    for (const Embedding* e : embeddings) {
+      if (!e->row_sharded) continue;
+      const int D = e->out_channels;
+      if (config.comm.allgather_f32(config.comm.user, e->outputs[0].impl->grad, e->gfull, local_batch * D, stream) != 0)
+        die("all-gather (row-sharded embedding backward) failed");
+      check(api->ffh_embedding_bwd_dense(ctx, e->local_idx, e->gfull, e->weights[0].impl->grad, L, D, config.batchSize, e->rows_local + 1, D, aggr, stream), e->name);
+    }
+  }
+  for (Embedding* e : embeddings)
+    if (e->held_here(rank) && !e->replicated) optimizer->update(&e->weights[0]);
 }
 
 // =============================================================================================
@@ -1919,13 +2008,22 @@ void FFModel::reset_metrics() {
   check(api->ffh_zero(ctx, d_perf, sizeof(ffh_perf_metrics), stream), "reset_metrics");
 }
 
+// tensor-op mode: the weights' bf16 twin after a host write / (re)initialisation.  Called where a step STARTS -- from begin_trace()
+// ahead of a capture or a replay (a replayed forward() returns at once, and a conversion captured into the graph would run on
+// every replay) and from forward() for eager steps: the captured GEMMs of a replayed step never read a stale twin.
+void FFModel::refresh_weight_twin() const {
+  if (!w_twin || !w_twin_dirty) return;
+  check(api->ffh_convert_f32_to_bf16(ctx, w_twin, mlp_weights, (int64_t)mlp_count, stream), "weight twin");
+  w_twin_dirty = false;
+}
+void FFModel::note_weight_write(const void* p) const {
+  if (w_twin && (const char*)p >= (const char*)mlp_weights && (const char*)p < (const char*)(mlp_weights + mlp_count)) w_twin_dirty = true;
+}
+
 void FFModel::forward(int _seq_length) {
   if (replaying_trace >= 0) return;
   seq_length = _seq_length;
-  if (w_twin && w_twin_dirty) {      // tensor-op mode: the weights' bf16 twin after a host write / (re)initialisation
-    check(api->ffh_convert_f32_to_bf16(ctx, w_twin, mlp_weights, (int64_t)mlp_count, stream), "weight twin");
-    w_twin_dirty = false;
-  }
+  if (capturing_trace < 0) refresh_weight_twin();      // (a capture: begin_trace() did it on the stream, outside the graph)
   emb_forward_issued = emb_forward_joined = false;
   // gather (+ all-to-all) go to the side stream beside the bottom MLP: the fork point is here (inputs ready)
   if (config.overlap_embedding && !embeddings.empty()) {
@@ -1934,7 +2032,8 @@ void FFModel::forward(int _seq_length) {
     // the warm-up batch for random input), no event: each record / wait is a barrier packet on the critical stream.
     // Exception: data-parallel (replicated) tables live in the dense parameter slab, which the optimizer of the step before
     // wrote on `stream` (all-reduce + SGD / Adam in update()): their gather must always be ordered behind it.
-    fork_recorded = inputs_dirty || capturing_trace >= 0 || use_workers() || repl_workspace != nullptr;
+    // ... and so must the gather of EVERY table when the tables are updated by the dense path, which runs on `stream` in update().
+    fork_recorded = inputs_dirty || capturing_trace >= 0 || use_workers() || repl_workspace != nullptr || !fused_embedding_update();
     if (fork_recorded) check(api->ffh_event_record(ctx, ev_fork, stream), "fork");
     inputs_dirty = false;
     // start the gather right now unless a host-side collective would stall THIS thread's launches
@@ -2044,7 +2143,8 @@ void FFModel::zero_gradients() {
   }
   if (!fused_embedding_update())
     for (Embedding* e : embeddings)
-      if (e->owner_rank == rank) check(api->ffh_zero(ctx, e->weights[0].impl->grad, e->weights[0].impl->bytes, stream), "zero_gradients");
+      if (e->held_here(rank) && !e->replicated)
+        check(api->ffh_zero(ctx, e->weights[0].impl->grad, e->weights[0].impl->bytes + (e->row_sharded ? (size_t)e->out_channels * 4 : 0), stream), "zero_gradients");
 }
 
 void FFModel::compute_metrics() {
@@ -2064,6 +2164,7 @@ void FFModel::backward(int _seq_length) {
   const float scale = loss_type == LOSS_MEAN_SQUARED_ERROR_AVG_REDUCE ? 1.0f / (float)fin.adim[fin.numDim - 1] : 1.0f;
   if (fin.impl->grad_ld != fin.adim[0] || fin.impl->ld != fin.adim[0]) die("final layer output must be contiguous");
   dw_forked = false;
+  opt_next_done = false;
   // the click-probability layer (out = 1): loss step + metrics + the layer's whole backward in ONE launch; any other last
   // layer: the loss kernel, then the layer's own backward
   int first = (int)layers.size() - 1;
@@ -2139,6 +2240,7 @@ void FFModel::backward(int _seq_length) {
 void FFModel::update() {
   if (replaying_trace >= 0) return;
   optimizer->next();
+  opt_next_done = true;
   SGDOptimizer* sgd = dynamic_cast<SGDOptimizer*>(optimizer);
   AdamOptimizer* adam = dynamic_cast<AdamOptimizer*>(optimizer);
   if (!sgd && !adam) die("update(): unknown optimizer");
@@ -2186,13 +2288,13 @@ void FFModel::update() {
       embedding_group_update(stream);
     }
   } else {
-    for (Embedding* e : embeddings)
-      if (e->owner_rank == rank) optimizer->update(&e->weights[0]);
+    embedding_dense_update();
   }
 }
 
 void FFModel::begin_trace(int trace_id) {
   if (!config.enable_graph) return;
+  refresh_weight_twin();                  // ahead of the capture / the replay, on `stream`
   auto it = graphs.find(trace_id);
   if (it != graphs.end()) { replaying_trace = trace_id; return; }
   if (dw_worker) dw_worker->drain();      // stream capture is thread-local: everything is issued inline while capturing

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 7   /* 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 8   /* 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -273,11 +273,48 @@ size_t ffh_embedding_bwd_workspace_bytes(int ntables, int in_dim, int out_dim, i
  *   ffh_embedding_bwd_sgd_apply_multi the rest (segmented sums, folds, w = fmaf(-lr, sum, w)), on the SAME tables / indices /
  *                                     batch, with nothing else using the workspace in between and ordered behind the sort by
  *                                     the caller's streams / events.
- * sort + apply launch what ffh_embedding_bwd_sgd_fused_multi launches, in the same order: the same bits. */
+ * sort + apply launch what ffh_embedding_bwd_sgd_fused_multi launches, in the same order: the same bits.
+ * ONE-SHOT: the apply phase consumes the sort (the sorted list AND the fold counters / level-1 slots that only the sort clears).
+ * A ctx remembers (workspace, ntables, in_dim, out_dim, batch) of its latest sort; apply without such a note -- no sort, a second
+ * apply, another shape, another workspace attached, or a fused call on that workspace in between -- returns FFH_ERR_WORKSPACE and
+ * launches nothing.  (Both calls on the same ctx; a capture that records sort and apply replays them as a pair.) */
 int ffh_embedding_bwd_sort_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int ntables,
                                  int in_dim, int out_dim, int64_t batch, ffh_stream s);
 int ffh_embedding_bwd_sgd_apply_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int ntables,
                                       int in_dim, int out_dim, int64_t batch, int aggr, float lr, ffh_stream s);
+
+/* Any optimizer on the sorted segments (ABI 8; SURVEY 8f-4 "needs per-row state for the sparse variant").  The reference runs
+ * sgd_update / adam_update over EVERY element of a parameter [ref: src/runtime/optimizer_kernel.cu:23-41,206-226] -- for an embedding
+ * table a dense gradient plus three or five full-table sweeps per step.  These entry points apply the same element arithmetic
+ * (statement by statement that of ffh_sgd_update_ex / ffh_adam_update) to the rows a batch touched, with the row's gradient = its
+ * canonical sum (FFH_EMB_CHUNK order, as the fused update), and leave every other row AND its optimizer state untouched:
+ *   FFH_SPARSE_OPT_SGD           w = fmaf(-lr, g, w)                                   == ffh_embedding_bwd_sgd_fused_multi
+ *   FFH_SPARSE_OPT_SGD_MOMENTUM  gt = g + wd w; V = V mom + gt; gt = nesterov ? gt + mom V : V (mom > 0); w -= lr gt     state s0 = V
+ *   FFH_SPARSE_OPT_ADAM          gt = g + wd w; M = b1 M + (1-b1) gt; V = b2 V + (1-b2) gt gt; w -= lr M / (sqrt(V) + eps)
+ *                                (lr = alpha_t, advanced by the caller as for ffh_adam_update)                state s0 = M, s1 = V
+ * STATED DIVERGENCE from the reference's dense sweep ("lazy" semantics, those of torch.optim.SparseAdam / sparse SGD): a row the
+ * batch does not touch keeps w, M, V -- the dense sweep would decay its moments (and move w by the decayed momentum, and by
+ * wd w when weight_decay != 0) every step.  Equal to the dense sweep on every row of a step in which the state of the untouched
+ * rows is zero and weight_decay == 0 (e.g. the first step); on touched rows always, given the same row gradient.  A caller that
+ * needs the reference's semantics on every row uses ffh_embedding_bwd_dense + ffh_sgd_update / ffh_adam_update on a dense gradient.
+ * states[i].s0 / .s1: [num_entries][out_dim] fp32 like tables[i].weight (null where the kind has no such state).
+ * _fused_multi sorts and applies; _apply_multi is the second half of the two-call form behind ffh_embedding_bwd_sort_multi. */
+#define FFH_SPARSE_OPT_SGD          0
+#define FFH_SPARSE_OPT_SGD_MOMENTUM 1
+#define FFH_SPARSE_OPT_ADAM         2
+typedef struct ffh_sparse_opt {
+  int32_t kind;            /* FFH_SPARSE_OPT_*                          */
+  float   lr;              /* SGD: learning rate; Adam: alpha_t          */
+  float   weight_decay;
+  float   momentum;        /* FFH_SPARSE_OPT_SGD_MOMENTUM               */
+  int32_t nesterov;
+  float   beta1, beta2, epsilon;   /* FFH_SPARSE_OPT_ADAM               */
+} ffh_sparse_opt;
+typedef struct ffh_emb_state { float* s0; float* s1; } ffh_emb_state;
+int ffh_embedding_bwd_opt_fused_multi(ffh_ctx* ctx, const ffh_emb_table* tables, const ffh_emb_state* states, int ntables,
+                                      int in_dim, int out_dim, int64_t batch, int aggr, const ffh_sparse_opt* opt, ffh_stream s);
+int ffh_embedding_bwd_opt_apply_multi(ffh_ctx* ctx, const ffh_emb_table* tables, const ffh_emb_state* states, int ntables,
+                                      int in_dim, int out_dim, int64_t batch, int aggr, const ffh_sparse_opt* opt, ffh_stream s);
 
 /* Row-wise sharded table (no reference counterpart: the reference splits an embedding on the sample dim only,
  * [ref: src/ops/embedding.cu:84-85]).  A rank holds rows [row_begin, row_begin + rows_local) followed by ONE extra
@@ -533,7 +570,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_fill_f32) X(ffh_zero) X(ffh_init_uniform) \
   X(ffh_gen_indices) X(ffh_gen_uniform01) X(ffh_gen_bernoulli) \
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
-  X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) X(ffh_embedding_bwd_sort_multi) X(ffh_embedding_bwd_sgd_apply_multi) \
+  X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) X(ffh_embedding_bwd_sort_multi) X(ffh_embedding_bwd_sgd_apply_multi) X(ffh_embedding_bwd_opt_fused_multi) X(ffh_embedding_bwd_opt_apply_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
   X(ffh_linear_fwd) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \

@@ -286,9 +286,11 @@ static int rp_cmp(const void* a, const void* b) {
  * (W -= lr*0).  `W[i] -= lr*gt` is contracted to one FMA by nvcc's default -fmad=true, so
  * the update is restated as fmaf(-lr, sum, w).  The summation order is the canonical one
  * documented at ffh_embedding_bwd_sgd_fused in include/ff_hip.h. */
-int ffh_embedding_bwd_sgd_fused(ffh_ctx* c, const int64_t* idx, const float* g, float* w,
-                                int L, int D, int64_t B, int64_t R, int64_t gld, int aggr, float lr, ffh_stream s) {
-  (void)s;
+/* `opt` (may be NULL = plain SGD with lr): the rule applied to a touched row once its canonical gradient sum `tot` is complete
+ * (ffh_sparse_opt, include/ff_hip.h) -- the element statements of ffh_sgd_update_ex / ffh_adam_update below, on the touched rows
+ * only; s0 / s1 the per-row optimizer state. */
+static int emb_bwd_opt_one(ffh_ctx* c, const int64_t* idx, const float* g, float* w, float* s0, float* s1,
+                           int L, int D, int64_t B, int64_t R, int64_t gld, int aggr, float lr, const ffh_sparse_opt* opt) {
   if (L <= 0 || D <= 0 || B < 0 || gld < D) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_sgd_fused: bad dims");
   if (aggr != FFH_AGGR_MODE_SUM && aggr != FFH_AGGR_MODE_AVG) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_sgd_fused: aggr");
   const int64_t N = B * L;
@@ -337,11 +339,65 @@ int ffh_embedding_bwd_sgd_fused(ffh_ctx* c, const int64_t* idx, const float* g, 
       a1 = z1;
     }
     float* wr = w + row * (int64_t)D;
-    for (int d = 0; d < D; d++) wr[d] = fmaf(-lr, tot[d], wr[d]);
+    if (!opt || opt->kind == FFH_SPARSE_OPT_SGD) {
+      for (int d = 0; d < D; d++) wr[d] = fmaf(-lr, tot[d], wr[d]);
+    } else if (opt->kind == FFH_SPARSE_OPT_SGD_MOMENTUM) {      /* sgd_update [ref: src/runtime/optimizer_kernel.cu:23-41] on this row */
+      float* vr = s0 ? s0 + row * (int64_t)D : NULL;
+      for (int d = 0; d < D; d++) {
+        float gt = fmaf(opt->weight_decay, wr[d], tot[d]);
+        if (opt->momentum > 0.0f) {
+          vr[d] = fmaf(vr[d], opt->momentum, gt);
+          if (opt->nesterov) gt = fmaf(opt->momentum, vr[d], gt); else gt = vr[d];
+        }
+        wr[d] = fmaf(-opt->lr, gt, wr[d]);
+      }
+    } else {                                                     /* adam_update [ref: src/runtime/optimizer_kernel.cu:206-226] on this row */
+      float* mr = s0 + row * (int64_t)D;
+      float* vr = s1 + row * (int64_t)D;
+      const float omb1 = 1.0f - opt->beta1, omb2 = 1.0f - opt->beta2;
+      for (int d = 0; d < D; d++) {
+        const float gt = fmaf(opt->weight_decay, wr[d], tot[d]);
+        const float mt = fmaf(opt->beta1, mr[d], omb1 * gt);
+        const float vt = fmaf(opt->beta2, vr[d], (omb2 * gt) * gt);
+        mr[d] = mt;
+        vr[d] = vt;
+        wr[d] = wr[d] - (opt->lr * mt) / (sqrtf(vt) + opt->epsilon);
+      }
+    }
     i = e;
   }
   free(v); free(part); free(mid); free(tot);
   return FFH_OK;
+}
+
+int ffh_embedding_bwd_sgd_fused(ffh_ctx* c, const int64_t* idx, const float* g, float* w,
+                                int L, int D, int64_t B, int64_t R, int64_t gld, int aggr, float lr, ffh_stream s) {
+  (void)s;
+  return emb_bwd_opt_one(c, idx, g, w, NULL, NULL, L, D, B, R, gld, aggr, lr, NULL);
+}
+
+/* ABI 8: the sparse (touched-rows) optimizers -- see ffh_sparse_opt in include/ff_hip.h for the stated lazy semantics */
+int ffh_embedding_bwd_opt_fused_multi(ffh_ctx* c, const ffh_emb_table* t, const ffh_emb_state* st, int nt, int L, int D, int64_t B,
+                                      int aggr, const ffh_sparse_opt* opt, ffh_stream s) {
+  (void)s;
+  if (!opt) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt_fused_multi: null ffh_sparse_opt");
+  if (nt < 0 || nt > FFH_MAX_TABLES) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt_fused_multi: ntables");
+  if (opt->kind != FFH_SPARSE_OPT_SGD && opt->kind != FFH_SPARSE_OPT_SGD_MOMENTUM && opt->kind != FFH_SPARSE_OPT_ADAM)
+    return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt: unknown ffh_sparse_opt.kind");
+  if (opt->kind == FFH_SPARSE_OPT_SGD && (opt->weight_decay != 0.0f || opt->momentum != 0.0f))
+    return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt: FFH_SPARSE_OPT_SGD takes no weight decay / momentum");
+  const int need0 = opt->kind == FFH_SPARSE_OPT_ADAM || (opt->kind == FFH_SPARSE_OPT_SGD_MOMENTUM && opt->momentum > 0.0f);
+  for (int i = 0; i < nt; i++) {
+    if (B > 0 && need0 && (!st || !st[i].s0)) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt: optimizer state (s0) missing");
+    if (B > 0 && opt->kind == FFH_SPARSE_OPT_ADAM && !st[i].s1) return fail(c, FFH_ERR_BAD_ARG, "embedding_bwd_opt: optimizer state (s1) missing");
+    int rc = emb_bwd_opt_one(c, t[i].idx, t[i].io, t[i].weight, st ? st[i].s0 : NULL, st ? st[i].s1 : NULL, L, D, B, t[i].num_entries, t[i].ld, aggr, opt->lr, opt);
+    if (rc) return rc;
+  }
+  return FFH_OK;
+}
+int ffh_embedding_bwd_opt_apply_multi(ffh_ctx* c, const ffh_emb_table* t, const ffh_emb_state* st, int nt, int L, int D, int64_t B,
+                                      int aggr, const ffh_sparse_opt* opt, ffh_stream s) {
+  return ffh_embedding_bwd_opt_fused_multi(c, t, st, nt, L, D, B, aggr, opt, s);
 }
 
 int ffh_embedding_bwd_sgd_fused_multi(ffh_ctx* c, const ffh_emb_table* t, int nt, int L, int D, int64_t B, int aggr, float lr, ffh_stream s) {

@@ -80,6 +80,20 @@ def embedding_bwd_sgd_fused(idx, g, w, lr, aggr=capi.AGGR_MODE_SUM):
     return w
 
 
+def embedding_bwd_opt(idx, g, w, opt: "capi.SparseOpt", s0=None, s1=None, aggr=capi.AGGR_MODE_SUM):
+    """ffh_embedding_bwd_opt_fused_multi on one table: returns (w, s0, s1) after the touched-rows optimizer step."""
+    idx, g = _i64(idx), _f32(g)
+    w = _f32(w).copy()
+    s0 = None if s0 is None else _f32(s0).copy()
+    s1 = None if s1 is None else _f32(s1).copy()
+    B, Lb = idx.shape
+    R, D = w.shape
+    t = lib().emb_tables([(idx, w, g, R, g.shape[1])])
+    st = lib().emb_states([(s0, s1)])
+    lib().check(lib().lib.ffh_embedding_bwd_opt_fused_multi(lib().ctx, t, st, 1, Lb, D, B, aggr, C.byref(opt), None), "ffh_embedding_bwd_opt_fused_multi")
+    return w, s0, s1
+
+
 def linear_fwd(x, w, bias, act=capi.AC_MODE_NONE):
     x, w = _f32(x), _f32(w)
     B, IN = x.shape

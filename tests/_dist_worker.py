@@ -24,7 +24,20 @@ def main():
     rank = dist.get_rank()
     comm = TorchComm(on_gpu=False)
     out = {}
-    if mode in ("golden", "column", "strategy", "row", "replicated", "replicated_all", "replicated_adam"):
+    if mode.startswith("opt:"):
+        # any optimizer x any placement (round 4): "opt:<adam|mom>:<dense|sparse>:<table|column|row|mixed>"
+        _, okind, path, place = mode.split(":")
+        kw = dict(adam=H.ADAM_HP) if okind == "adam" else dict(sgd=H.MOM_HP)
+        m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True,
+                                   column_shard_rows=40 if place == "column" else 0, row_shard_rows=40 if place == "row" else 0,
+                                   replicate_rows=39 if place == "mixed" else 0,
+                                   extra_argv=["--sparse-embedding-optimizer"] if path == "sparse" else [], **kw)
+        recs = H.run_steps(m, h, 3)
+        for step, rec in enumerate(recs):
+            for k, v in rec.items():
+                out[f"s{step}/{k}"] = v
+        m.close()
+    elif mode in ("golden", "column", "strategy", "row", "replicated", "replicated_all", "replicated_adam"):
         extra = ["--import", os.path.join(outdir, "strategy.txt"), "--export", os.path.join(outdir, "export.txt")] if mode == "strategy" else []
         m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True,
                                    column_shard_rows=40 if mode == "column" else 0, row_shard_rows=40 if mode == "row" else 0, extra_argv=extra,

@@ -13,6 +13,10 @@ from conftest import golden
 from dlrm_flexflow_amd import capi, ffmodel
 
 
+ADAM_HP = dict(alpha=0.01, beta1=0.9, beta2=0.999, weight_decay=0.0, epsilon=1e-8)
+MOM_HP = dict(lr=0.05, momentum=0.9, nesterov=False, weight_decay=0.0)
+
+
 def oracle_backend():
     from oracle import oracle
     oracle.build()
@@ -20,7 +24,7 @@ def oracle_backend():
 
 
 def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dense_update=False, g=None, force_exchange=False,
-                      column_shard_rows=0, extra_argv=(), adam=None, row_shard_rows=0, replicate_rows=0):
+                      column_shard_rows=0, extra_argv=(), adam=None, row_shard_rows=0, replicate_rows=0, sgd=None):
     """Returns (model, handles) with weights and inputs of the golden fixture loaded.
     With `comm` (world_size > 1) each rank loads its batch slice / its tables."""
     g = g or golden("dlrm_step_torch")
@@ -49,6 +53,8 @@ def build_golden_dlrm(backend, comm=None, enable_graph=False, overlap=True, dens
         z = m.dense(z, top[i + 1], capi.AC_MODE_SIGMOID if i == len(top) - 2 else capi.AC_MODE_RELU)
     if adam is not None:
         m.set_adam_optimizer(**adam)
+    elif sgd is not None:
+        m.set_sgd_optimizer(**sgd)
     else:
         m.set_sgd_optimizer(lr=0.01)
     m.compile()
@@ -120,6 +126,67 @@ def check_against_golden(recs, h, rtol=1e-5, atol=1e-6):
             if k == "pred":
                 continue
             np.testing.assert_allclose(v, g[f"step{step}/{k}"], rtol=rtol, atol=atol, err_msg=f"{k} step {step}")
+
+
+def torch_optimizer_reference(g, steps, kind, lazy_tables, **hp):
+    """The golden DLRM in torch (autograd for the gradients) with the reference's optimizer statements applied by hand in fp32:
+    kind "adam" [ref: src/runtime/optimizer_kernel.cu:206-226, alpha_t optimizer.cc:248-254] or "sgd" (lr, momentum, nesterov,
+    weight_decay) [ref: optimizer_kernel.cu:23-41].  lazy_tables: the embedding tables follow the touched-rows rule
+    (--sparse-embedding-optimizer: rows a batch does not touch keep weight and state; the semantics of torch.optim.SparseAdam);
+    False: the reference's dense sweep over every row.  Returns per-step records like run_steps()."""
+    import torch
+    rows, bot, top = list(g["rows"]), list(g["bot"]), list(g["top"])
+    B = int(g["B"])
+    P = {}
+    for i in range(len(bot) - 1):
+        P[f"bot.{i}.weight"] = g[f"init/bot.{i}.weight"]; P[f"bot.{i}.bias"] = g[f"init/bot.{i}.bias"]
+    for i in range(len(top) - 1):
+        P[f"top.{i}.weight"] = g[f"init/top.{i}.weight"]; P[f"top.{i}.bias"] = g[f"init/top.{i}.bias"]
+    for t in range(len(rows)):
+        P[f"emb.{t}.weight"] = g[f"init/emb.{t}.weight"]
+    P = {k: torch.tensor(np.array(v, np.float32), requires_grad=True) for k, v in P.items()}
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    dense, label = torch.from_numpy(g["dense"]), torch.from_numpy(g["label"])
+    sparse = [torch.from_numpy(g[f"sparse{t}"]) for t in range(len(rows))]
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32)
+    b1t = b2t = 1.0
+    out = []
+    for _ in range(steps):
+        x = dense
+        for i in range(len(bot) - 1):
+            x = torch.relu(x @ P[f"bot.{i}.weight"].T + P[f"bot.{i}.bias"])
+        ly = [P[f"emb.{t}.weight"][s].sum(1) for t, s in enumerate(sparse)]
+        z = torch.cat([x] + ly, 1)
+        for i in range(len(top) - 1):
+            z = z @ P[f"top.{i}.weight"].T + P[f"top.{i}.bias"]
+            z = torch.sigmoid(z) if i == len(top) - 2 else torch.relu(z)
+        for v in P.values():
+            v.grad = None
+        (0.5 * ((z - label) ** 2).sum() / B).backward()
+        if kind == "adam":
+            b1t *= hp["beta1"]; b2t *= hp["beta2"]
+            alpha_t = hp["alpha"] * np.sqrt(1 - b2t) / (1 - b1t)
+        with torch.no_grad():
+            for k, w in P.items():
+                sel = slice(None)
+                if lazy_tables and k.startswith("emb"):
+                    sel = torch.unique(sparse[int(k.split(".")[1])].reshape(-1))
+                wd = f32(hp.get("weight_decay", 0.0))
+                gt = w.grad[sel] + wd * w[sel]
+                if kind == "adam":
+                    M[k][sel] = f32(hp["beta1"]) * M[k][sel] + (1 - f32(hp["beta1"])) * gt
+                    V[k][sel] = f32(hp["beta2"]) * V[k][sel] + (1 - f32(hp["beta2"])) * gt * gt
+                    w[sel] -= f32(alpha_t) * M[k][sel] / (torch.sqrt(V[k][sel]) + f32(hp["epsilon"]))
+                else:
+                    if hp.get("momentum", 0.0) > 0:
+                        V[k][sel] = V[k][sel] * f32(hp["momentum"]) + gt
+                        gt = gt + f32(hp["momentum"]) * V[k][sel] if hp.get("nesterov") else V[k][sel]
+                    w[sel] -= f32(hp["lr"]) * gt
+        rec = {"pred": z.detach().numpy().copy()}
+        rec.update({k: v.detach().numpy().copy() for k, v in P.items()})
+        out.append(rec)
+    return out
 
 
 def torch_adam_reference(g, steps, alpha=0.001, beta1=0.9, beta2=0.999, weight_decay=0.0, epsilon=1e-8):

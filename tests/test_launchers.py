@@ -94,6 +94,44 @@ def test_dlrm_binary_forwards_sigterm_to_its_ranks():
     assert set(glob.glob("/tmp/ffm_launch_*")) <= before
 
 
+def test_dlrm_binary_signal_before_the_first_fork_is_forwarded():
+    """Round-3 advisor finding (3): the handlers are installed, with SIGTERM / SIGINT blocked, BEFORE the first fork.  The parent
+    raises SIGTERM on itself there (test hook); it stays pending until the ranks exist, is then forwarded to them, and the parent
+    returns non-zero and cleans up instead of dying and leaving three hanging ranks behind."""
+    import glob
+    before = set(glob.glob("/tmp/ffm_launch_*"))
+    env = dict(os.environ, FFM_LAUNCH_DRYRUN="1", FFM_LAUNCH_TEST_HANG="1", FFM_LAUNCH_TEST_SIGNAL_SELF_EARLY="1", FFM_LAUNCH_GRACE_S="2.0")
+    r = subprocess.run([EXE, "-ll:gpu", "3", *SMALL], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode not in (0, -15), (r.returncode, r.stderr)      # the parent survived its own SIGTERM and reported failure
+    assert r.stderr.count("ended with 143") + r.stderr.count("ended with 137") == 3, r.stderr
+    assert set(glob.glob("/tmp/ffm_launch_*")) <= before
+
+
+def test_dlrm_binary_kills_a_rank_that_ignores_sigterm():
+    """Round-3 advisor findings (1), (2): the grace timer starts wherever the signal lands (the flag is read on every turn of the
+    wait loop), only ranks not yet reaped are signalled, and ranks that ignore SIGTERM are SIGKILLed after the grace period."""
+    import signal, time, psutil
+    env = dict(os.environ, FFM_LAUNCH_DRYRUN="1", FFM_LAUNCH_TEST_HANG="1", FFM_LAUNCH_TEST_IGNORE_TERM="1", FFM_LAUNCH_GRACE_S="1.0")
+    p = subprocess.Popen([EXE, "-ll:gpu", "3", *SMALL], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    deadline = time.time() + 30
+    kids = []
+    while time.time() < deadline:
+        kids = psutil.Process(p.pid).children()
+        if len(kids) == 3:
+            break
+        time.sleep(0.05)
+    assert len(kids) == 3
+    time.sleep(1.0)                            # the ranks are past their exec and ignore SIGTERM by now
+    t0 = time.time()
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=30)
+    assert p.returncode != 0
+    assert 0.9 < time.time() - t0 < 20
+    assert err.count("ended with 137") == 3, err      # 128 + SIGKILL
+    gone, alive = psutil.wait_procs(kids, timeout=10)
+    assert not alive, alive
+
+
 def test_dlrm_binary_reports_a_failing_rank():
     """A rank that cannot come up (no GPU here / no such device) makes the parent end the others and return non-zero."""
     import torch
