@@ -519,6 +519,7 @@ def main():
         elapsed = float(t.item())
 
     pm = app.model.perf_metrics()                  # loss over the K timed steps (before the kernel probes below touch the tables)
+    calls = dict(comm.calls) if comm is not None and hasattr(comm, "calls") else None     # collectives of warm-up + W + K steps (the probes below add theirs)
     # per-kernel device time, HIP events on the stream the kernels are launched on (the model's stream)
     T = len(w["rows"].split("-"))
     rows_of = [int(r) for r in w["rows"].split("-")]
@@ -529,13 +530,24 @@ def main():
     n_g = 200 if B * owned <= 65536 else 40
     t_fwd = app.time_kernel(8, n_g) * 1e-3 if (rank == 0 and table_wise and owned) else None           # gather kernel alone (no exchange)
     t_bwd = app.time_kernel(9, max(10, n_g // 2)) * 1e-3 if (rank == 0 and table_wise and owned) else None   # fused update kernels alone
-    t_fwd_in = app.time_kernel(10, 10 if B > 4096 else 50) * 1e-3 if (t_fwd and not trace and not ftest) else None      # the same kernels inside real eager steps
-    t_bwd_in = app.time_kernel(11, 10 if B > 4096 else 50) * 1e-3 if (t_bwd and not trace and not ftest) else None
+    # the same kernels and the collectives inside real eager steps, by events on the streams they are issued on.  COLLECTIVE: the
+    # steps run the exchange, so at N > 1 every rank walks them (round-3 advisor: rank 0 alone hung in the first all-to-all); the
+    # line reports rank 0's intervals and the maximum over the ranks
+    in_step = in_step_max = None
+    if not trace or not solo:
+        in_step = app.probe_step(10 if B > 4096 else 50)
+        in_step_max = dict(in_step)
+        if world > 1:
+            keys = sorted(in_step)
+            t = torch.tensor([in_step[k] for k in keys], dtype=torch.float64, device="cpu" if ftest else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            in_step_max = {k: float(v) for k, v in zip(keys, t.tolist())}
+    t_fwd_in = in_step["gather"] * 1e-3 if (in_step and t_fwd and in_step["gather"] > 0) else None
+    t_bwd_in = in_step["table_update"] * 1e-3 if (in_step and t_bwd and in_step["table_update"] > 0) else None
     t_step_dev = app.time_kernel(2 if trace else 4, 20 if B > 4096 else 100) * 1e-3 if solo else None
     t_lin_fwd = app.time_kernel(6, 20 if B > 4096 else 200) * 1e-3 if solo else None      # largest Linear layer alone: forward, backward (dX + dW)
     t_lin_bwd = app.time_kernel(7, 20 if B > 4096 else 100) * 1e-3 if solo else None
     uses_graph = app.model.uses_graph and trace
-    calls = dict(comm.calls) if comm is not None and hasattr(comm, "calls") else None
     app.close()
     if world > 1:
         barrier()                                  # the probes above are rank 0's: nobody tears the group down under them
@@ -576,6 +588,21 @@ def main():
         dense = mlp_params(w["bot"]) + mlp_params(w["top"]) + sum(rows_of[t] for t in replicated) * D
         out["config"]["collective_payload_bytes_per_step_rank0"] = {"alltoall_forward_sent": a2a, "alltoall_backward_sent": a2a,
                                                                     "allreduce_buffer": 4 * dense}
+        if in_step:
+            us = lambda d, k: round(d[k] * 1e3, 1)
+            # what the collectives cost inside the step, so that a scaling record explains its own efficiency: each collective's own
+            # interval on the stream it is issued on (side stream: both all-to-alls; compute stream: the all-reduce, which is therefore
+            # exposed in full) and `embedding_branch_wait_us` = how long the compute stream stood at the join in front of the first
+            # consumer of the embedding outputs -- the exposed part of [table update of the step before -> gather -> forward all-to-all]
+            out["collectives_in_step_us"] = {
+                "how": "HIP events around each call inside real eager steps, averaged; rank0 and max over ranks",
+                "rank0": {"alltoall_fwd_us": us(in_step, "alltoall_fwd"), "alltoall_bwd_us": us(in_step, "alltoall_bwd"), "allreduce_us": us(in_step, "allreduce"),
+                          "embedding_branch_wait_us": us(in_step, "join_wait"), "gather_plus_alltoall_fwd_us": us(in_step, "gather"),
+                          "alltoall_bwd_plus_table_update_us": us(in_step, "table_update")},
+                "max_over_ranks": {"alltoall_fwd_us": us(in_step_max, "alltoall_fwd"), "alltoall_bwd_us": us(in_step_max, "alltoall_bwd"), "allreduce_us": us(in_step_max, "allreduce"),
+                                   "embedding_branch_wait_us": us(in_step_max, "join_wait"), "gather_plus_alltoall_fwd_us": us(in_step_max, "gather"),
+                                   "alltoall_bwd_plus_table_update_us": us(in_step_max, "table_update")},
+                "exposed_on_the_compute_stream_us": round((in_step_max["allreduce"] + in_step_max["join_wait"]) * 1e3, 1)}
     if args.force_exchange:
         out["config"]["parallelism"] = f"1 rank, exchange path forced: {layout} + all-reduce; {collectives}"
     out["kernels"] = {}

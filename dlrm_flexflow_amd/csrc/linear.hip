@@ -1727,7 +1727,10 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     gx.A = dy; gx.sAm = lddy; gx.sAk = 1; gx.B = w; gx.sBn = 1; gx.sBk = in; gx.C = dx; gx.ldc = lddx;
     gx.M = (int)batch; gx.N = in; gx.K = out; gx.epi = (flags & FFH_LINEAR_DX_OVERWRITE) ? EPI_STORE : EPI_ADD; gx.act = FFH_AC_MODE_NONE;
     if (mask_by_x) { gx.mask = x; gx.ldmask = ldx; }
-    bool ok = (do_dw || want_dx) && !(relu_live && !do_dw) && !(want_dx && scatter_pending);
+    // ffh_linear_bwd_set_dx_scatter: the persistent data-gradient kernel takes the column map in its epilogue (SK_EPI_DX_CMAP)
+    const bool scatter_sk = want_dx && scatter_pending && !c->deterministic;
+    if (scatter_sk) gx.colmap = (const ffh_col_dest*)c->scatter_map;
+    bool ok = (do_dw || want_dx) && !(relu_live && !do_dw) && !(want_dx && scatter_pending && !scatter_sk);
     if (ok && do_dw) ok = gemm_sk_serves(c, gw, SK_FORM_DW);
     if (ok && want_dx) ok = gemm_sk_serves(c, gx, SK_FORM_DX);
     if (ok) {
@@ -1746,8 +1749,25 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
         FFH_HIP_TRY(c, hipStreamWaitEvent(as_stream(sw_sk), c->ev_fork, 0));
       }
       // the data gradient first: it is what the layer below waits for; the weight gradient fills the chip behind it
-      if (want_dx) { const int rc = launch_gemm_sk(c, gx, SK_FORM_DX, s, "linear_bwd dx gemm"); if (rc < 0) return rc; }
-      if (do_dw) { const int rc = launch_gemm_sk(c, gw, SK_FORM_DW, sw_sk, "linear_bwd dw gemm"); if (rc < 0) return rc; }
+      if (want_dx) {
+        const int rc = launch_gemm_sk(c, gx, SK_FORM_DX, s, "linear_bwd dx gemm");
+        if (rc < 0) return rc;
+        if (rc == 1 && scatter_sk) {
+          c->scatter_used = 1;
+          if (c->scatter_event) FFH_HIP_TRY(c, hipEventRecord((hipEvent_t)c->scatter_event, as_stream(s)));   // "gradients ready" behind the kernel that produced them
+        }
+        if (rc == 0) {     // (the launch was refused after the plan said yes: the register-staged kernel takes the data gradient, map included)
+          GemmArgs g2 = gx;
+          const int rc2 = scatter_sk ? launch_gemm<true, false, false, true>(c, g2, 1, s, "linear_bwd dx gemm (column map)") : launch_gemm<true, false>(c, g2, 1, s, "linear_bwd dx gemm");
+          if (rc2) return rc2;
+          if (scatter_sk) { c->scatter_used = 1; if (c->scatter_event) FFH_HIP_TRY(c, hipEventRecord((hipEvent_t)c->scatter_event, as_stream(s))); }
+        }
+      }
+      if (do_dw) {
+        const int rc = launch_gemm_sk(c, gw, SK_FORM_DW, sw_sk, "linear_bwd dw gemm");
+        if (rc < 0) return rc;
+        if (rc == 0) { GemmArgs g2 = gw; g2.act_y = y; g2.ld_act_y = ldy; g2.fuse = g2.db ? 2 : 0; const int rc2 = launch_gemm<false, false, true>(c, g2, 1, sw_sk, "linear_bwd dw gemm"); if (rc2) return rc2; }
+      }
       return FFH_OK;
     }
   }

@@ -50,13 +50,15 @@ constexpr int SK_BM = 128, SK_BN = 128, SK_BK = 64;
 constexpr int SK_LDS_KC = 128 * 256 + 32 * 32;   // k-contiguous operand: row r at r*256 + (r>>2)*32
 constexpr int SK_LDS_KR = 64 * 512;              // rows-are-k operand: row k at k*512
 
-enum { SK_EPI_FWD = 0, SK_EPI_DX_STORE = 1, SK_EPI_DX_ADD = 2, SK_EPI_DW_ATOMIC = 3 };
+enum { SK_EPI_FWD = 0, SK_EPI_DX_STORE = 1, SK_EPI_DX_ADD = 2, SK_EPI_DW_ATOMIC = 3, SK_EPI_DX_CMAP = 4 };
 
 struct SkArgs {
   const float* A; const float* B; float* C;
   const float* bias;           // FWD: per-column bias or null
   float*       db;             // DW (DB instantiation): db[m] += sum_k A(k, m), the bias gradient [ref: src/ops/linear.cu:644-651]
   const float* mask;           // DX: C = mask[m][n] > 0 ? v : 0 (relu' of the layer below) or null
+  const ffh_col_dest* colmap;  // DX_CMAP (ffh_linear_bwd_set_dx_scatter): column n of C lives at colmap[n].base[m * colmap[n].ld] -- the exchange
+                               // path's first top layer stores its data gradient into the bottom MLP's gradient and the all-to-all send buffer
   int64_t lda, ldb, ldc, ldmask;
   int M, N, K;
   int act;
@@ -246,6 +248,16 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
       // BEFORE the first store: left inside the loop below each load sat behind the store in front of it (the compiler cannot tell
       // the two apart, and s_waitcnt vmcnt(0) counts stores too) -- sixteen dependent round trips per tile on a SIMD whose only wave
       // this is
+      // DX_CMAP: where this lane's four columns go.  Destinations are runs of whole tensors (a table's slot in the send buffer, the
+      // bottom MLP's gradient), so four consecutive columns normally share one and the store stays 16 bytes wide; where a group
+      // straddles two destinations (or one is unaligned) its four columns are stored one by one
+      ffh_col_dest cd0{nullptr, 0}, cd1{nullptr, 0}, cd2{nullptr, 0}, cd3{nullptr, 0};
+      bool cvec = false;
+      if constexpr (EPI == SK_EPI_DX_CMAP) {
+        cd0 = g.colmap[nn]; cd3 = g.colmap[nn + 3];
+        cvec = cd3.base == cd0.base + 3 && cd3.ld == cd0.ld && ((((uintptr_t)cd0.base) | (uintptr_t)(cd0.ld * 4)) & 15) == 0;
+        if (!cvec) { cd1 = g.colmap[nn + 1]; cd2 = g.colmap[nn + 2]; }
+      }
       f32x4 mk[4][4], cold[4][4];
       if constexpr (EPI == SK_EPI_DX_STORE || EPI == SK_EPI_DX_ADD) {
 #pragma unroll
@@ -275,6 +287,13 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
             if (relu_fast) { v.x = v.x > 0.0f ? v.x : 0.0f; v.y = v.y > 0.0f ? v.y : 0.0f; v.z = v.z > 0.0f ? v.z : 0.0f; v.w = v.w > 0.0f ? v.w : 0.0f; }
             else if (!none_fast) { v.x = act_apply(v.x, g.act); v.y = act_apply(v.y, g.act); v.z = act_apply(v.z, g.act); v.w = act_apply(v.w, g.act); }
             *reinterpret_cast<f32x4*>(cptr) = v;
+          } else if constexpr (EPI == SK_EPI_DX_CMAP) {
+            if (cvec) {
+              *reinterpret_cast<f32x4*>(cd0.base + (int64_t)mm * cd0.ld) = v;
+            } else {
+              cd0.base[(int64_t)mm * cd0.ld] = v.x; cd1.base[(int64_t)mm * cd1.ld] = v.y;
+              cd2.base[(int64_t)mm * cd2.ld] = v.z; cd3.base[(int64_t)mm * cd3.ld] = v.w;
+            }
           } else {
             if (g.mask_bytes) {        // uniform
               const f32x4 m4 = mk[tm][i];
@@ -354,10 +373,11 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
   const bool akr = form == SK_FORM_DW, bkr = form != SK_FORM_FWD;
   p.lda = akr ? g.sAk : g.sAm; p.ldb = bkr ? g.sBk : g.sBn;
   if ((akr ? g.sAm : g.sAk) != 1 || (bkr ? g.sBn : g.sBk) != 1) return false;
-  if (!sk_aligned(g.A, p.lda) || !sk_aligned(g.B, p.ldb) || !sk_aligned(g.C, g.ldc)) return false;
+  if (!sk_aligned(g.A, p.lda) || !sk_aligned(g.B, p.ldb) || (!g.colmap && !sk_aligned(g.C, g.ldc))) return false;
   if (g.mask && !sk_aligned(g.mask, g.ldmask)) return false;
   if (g.bias && ((uintptr_t)g.bias & 15)) return false;
-  if (g.colmap || g.act_y || g.fuse || g.splitk > 1) return false;  // column-map / masking-while-loading forms stay with linear.hip
+  if (g.act_y || g.fuse || g.splitk > 1) return false;  // masking-while-loading forms stay with linear.hip
+  if (g.colmap && (form != SK_FORM_DX || g.epi != EPI_STORE || g.mask)) return false;     // the column map: plain stored data gradients only
   p.a_bytes = ((akr ? (int64_t)(g.K - 1) : (int64_t)(g.M - 1)) * p.lda + (akr ? g.M : g.K)) * 4;
   p.b_bytes = ((bkr ? (int64_t)(g.K - 1) : (int64_t)(g.N - 1)) * p.ldb + (bkr ? g.N : g.K)) * 4;
   if (p.a_bytes >= (1LL << 32) || p.b_bytes >= (1LL << 32)) return false;  // 32-bit buffer offsets
@@ -387,7 +407,7 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   const int64_t lda = p.lda, ldb = p.ldb, a_bytes = p.a_bytes, b_bytes = p.b_bytes;
   const int G = p.G;
   SkArgs a{};
-  a.A = g.A; a.B = g.B; a.C = g.C; a.bias = g.bias; a.mask = g.mask; a.db = g.db;
+  a.A = g.A; a.B = g.B; a.C = g.C; a.bias = g.bias; a.mask = g.mask; a.db = g.db; a.colmap = g.colmap;
   a.lda = lda; a.ldb = ldb; a.ldc = g.ldc; a.ldmask = g.ldmask;
   a.M = g.M; a.N = g.N; a.K = g.K; a.act = g.act;
   a.a_bytes = (unsigned)a_bytes; a.b_bytes = (unsigned)b_bytes;
@@ -408,11 +428,12 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   if (form == SK_FORM_FWD) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC)
   else if (form == SK_FORM_DW && g.db) FFH_SK_LAUNCH(true, true, SK_EPI_DW_ATOMIC, 2 * SK_LDS_KR + 4 * SK_EP_WAVE, true)
   else if (form == SK_FORM_DW) FFH_SK_LAUNCH(true, true, SK_EPI_DW_ATOMIC, 2 * SK_LDS_KR + 4 * SK_EP_WAVE)
+  else if (g.colmap) FFH_SK_LAUNCH(false, true, SK_EPI_DX_CMAP, SK_LDS_KC + SK_LDS_KR)
   else if (g.epi == EPI_STORE) FFH_SK_LAUNCH(false, true, SK_EPI_DX_STORE, SK_LDS_KC + SK_LDS_KR)
   else FFH_SK_LAUNCH(false, true, SK_EPI_DX_ADD, SK_LDS_KC + SK_LDS_KR)
 #undef FFH_SK_LAUNCH
   if (hipGetLastError() != hipSuccess) return 0;        // launch refused: nothing was enqueued, the caller falls through to linear.hip
-  { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64|wgs=%d", name, G); ffh_route_add(c, tok); }
+  { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64%s|wgs=%d", name, g.colmap ? "|colmap" : "", G); ffh_route_add(c, tok); }
   return 1;
 }
 

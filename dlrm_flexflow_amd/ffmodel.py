@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
         "flexflow_model_get_stream": (P, [H]), "flexflow_model_uses_graph": (I, [H]),
         "flexflow_tensor_get_num_dims": (I, [H]), "flexflow_tensor_get_dims": (None, [H, IP]),
         "flexflow_tensor_get_local_rows": (C.c_int64, [H]), "flexflow_tensor_is_local": (B, [H]),
+        "flexflow_tensor_get_device_ptr": (P, [H]), "flexflow_tensor_get_ld": (C.c_int64, [H]),
         "flexflow_tensor_set_float": (None, [H, H, IP, I, P]), "flexflow_tensor_set_int64": (None, [H, H, IP, I, P]),
         "flexflow_tensor_get_float": (None, [H, H, P]), "flexflow_tensor_get_int64": (None, [H, H, P]),
         "flexflow_tensor_get_grad_float": (None, [H, H, P]),
@@ -111,6 +112,7 @@ def lib() -> C.CDLL:
         "flexflow_dlrm_get_sparse_input": (H, [H, I]), "flexflow_dlrm_get_dense_input": (H, [H]),
         "flexflow_dlrm_warmup": (None, [H]), "flexflow_dlrm_train_steps": (None, [H, I, B]),
         "flexflow_dlrm_run_epochs": (D, [H]), "flexflow_dlrm_time_kernel": (F, [H, I, I]),
+        "flexflow_dlrm_probe_step": (None, [H, I, C.POINTER(F), I]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -144,6 +146,15 @@ class Tensor:
     @property
     def is_local(self) -> bool:
         return bool(lib().flexflow_tensor_is_local(self.h))
+
+    @property
+    def device_ptr(self) -> int:
+        """Address of element (0, 0) in the backend's memory (0: not held by this rank); tests / tools only."""
+        return lib().flexflow_tensor_get_device_ptr(self.h) or 0
+
+    @property
+    def ld(self) -> int:
+        return lib().flexflow_tensor_get_ld(self.h)
 
     def _local_shape(self):
         d = self.dims
@@ -334,6 +345,16 @@ class DLRM:
     def train_steps(self, n, trace=True): lib().flexflow_dlrm_train_steps(self.h, n, trace)
     def run_epochs(self) -> float: return lib().flexflow_dlrm_run_epochs(self.h)
     def time_kernel(self, which, iters) -> float: return lib().flexflow_dlrm_time_kernel(self.h, which, iters)
+
+    PROBE_PAIRS = ("gather", "table_update", "alltoall_fwd", "alltoall_bwd", "allreduce", "join_wait")
+
+    def probe_step(self, iters) -> dict:
+        """In-step event intervals (milliseconds, averaged over `iters` real eager steps): the side-stream gather (+ forward exchange)
+        and table update (+ backward exchange), each collective alone, and the compute stream's wait for the embedding branch -- the
+        exposed part of gather + exchange.  COLLECTIVE: with more than one rank every rank must call it."""
+        out = (C.c_float * len(self.PROBE_PAIRS))()
+        lib().flexflow_dlrm_probe_step(self.h, iters, out, len(self.PROBE_PAIRS))
+        return {k: float(out[i]) for i, k in enumerate(self.PROBE_PAIRS)}
 
     def close(self):
         if self.h is not None:

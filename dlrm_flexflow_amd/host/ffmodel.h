@@ -105,6 +105,7 @@ class FFConfig {
   bool deterministic;          // --deterministic: weight / bias gradients without fp atomics (ffh_ctx_set_deterministic): bit-identical runs
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
+  int  update_behind_bottom_bwd;     // 1 / 0: the side-stream table update is issued behind / beside the bottom MLP's backward; -1 (default): by model size
   bool sparse_embedding_optimizer;   // --sparse-embedding-optimizer: momentum / weight-decay SGD and Adam update the rows a batch touched, with per-row state, on the
                                // sorted segments of the fused update (ffh_sparse_opt: lazy semantics, a stated divergence) instead of the reference's dense sweep
   bool early_sort;             // the index-only sort of the fused table update runs behind the gather (ffh_embedding_bwd_sort_multi), off the backward's critical path (A/B: --no-early-sort)
@@ -512,7 +513,10 @@ class FFModel {
   void embedding_kernels_only(bool fwd, ffh_stream s, const std::vector<const int64_t*>* idx_override = nullptr) const;
   // bench probes: events around the side-stream gather / update of a REAL step (what the kernels take while they share the chip)
   mutable bool probe_events_on = false;
-  mutable ffh_event probe_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // gather begin / end, update begin / end
+  // pairs: 0/1 gather (+ forward exchange), 2/3 table update (+ backward exchange), 4/5 forward all-to-all, 6/7 backward all-to-all,
+  // 8/9 gradient all-reduce (compute stream), 10/11 the compute stream's wait for the gather / exchange branch (its exposed part)
+  static constexpr int kProbeEvents = 12;
+  mutable ffh_event probe_ev[kProbeEvents] = {};
   void probe_record(int which, ffh_stream s, ffh_ctx* cx) const;
   bool fused_embedding_update() const;        // the tables are updated on the sorted segments (plain SGD, or any optimizer with --sparse-embedding-optimizer)
   bool sparse_rule(ffh_sparse_opt& rule) const;   // the row rule in force; false: plain SGD
@@ -524,6 +528,7 @@ class FFModel {
   void order_input_writes_behind_update() const;
   void profiled(const Op* op, bool fwd, const std::function<void()>& fn) const;   // --profiling: one op between two events
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
+  bool update_behind_bottom_bwd() const;
   bool early_sort_possible() const;      // one launch group, nothing else on the workspace between a step's gather and its update
   mutable bool emb_sorted_early;         // this step's sort was issued behind the gather: the update is the apply phase only
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)

@@ -122,6 +122,8 @@ int flexflow_tensor_get_num_dims(flexflow_tensor_t t) { return T(t)->numDim; }
 void flexflow_tensor_get_dims(flexflow_tensor_t t, int* dims) { for (int i = 0; i < T(t)->numDim; i++) dims[i] = T(t)->adim[T(t)->numDim - 1 - i]; }
 int64_t flexflow_tensor_get_local_rows(flexflow_tensor_t t) { return T(t)->impl ? T(t)->impl->rows_local : 0; }
 bool flexflow_tensor_is_local(flexflow_tensor_t t) { return T(t)->impl && T(t)->impl->ptr != nullptr; }
+void* flexflow_tensor_get_device_ptr(flexflow_tensor_t t) { return T(t)->impl ? T(t)->impl->ptr : nullptr; }
+int64_t flexflow_tensor_get_ld(flexflow_tensor_t t) { return T(t)->impl ? T(t)->impl->ld : 0; }
 void flexflow_tensor_set_float(flexflow_tensor_t t, flexflow_model_t m, const int* dims, int nd, const float* d) { T(t)->set_tensor<float>(M(m), dims_vec(dims, nd), d); }
 void flexflow_tensor_set_int64(flexflow_tensor_t t, flexflow_model_t m, const int* dims, int nd, const int64_t* d) { T(t)->set_tensor<int64_t>(M(m), dims_vec(dims, nd), d); }
 void flexflow_tensor_get_float(flexflow_tensor_t t, flexflow_model_t m, float* d) { T(t)->get_tensor<float>(M(m), d); }
@@ -138,6 +140,34 @@ flexflow_tensor_t flexflow_dlrm_get_dense_input(flexflow_dlrm_t h) { return wrap
 void flexflow_dlrm_warmup(flexflow_dlrm_t h) { A(h)->warmup(); }
 void flexflow_dlrm_train_steps(flexflow_dlrm_t h, int n, bool trace) { A(h)->train_steps(n, trace); }
 double flexflow_dlrm_run_epochs(flexflow_dlrm_t h) { return A(h)->run_epochs(); }
+
+// `iters` real eager steps with events around the side-stream gather / table update, the three collectives and the compute stream's
+// wait for the embedding branch; out[k] = average milliseconds of pair k (FFModel::probe_ev: gather, update, forward all-to-all,
+// backward all-to-all, all-reduce, join wait), 0 where a pair was never recorded.  COLLECTIVE at world_size > 1: the steps issue the
+// exchange, so every rank must make this call (round-3 advisor: the probes of time_kernel(10 / 11) ran on rank 0 alone and hung).
+void flexflow_dlrm_probe_step(flexflow_dlrm_t h, int iters, float* out, int nout) {
+  DLRMApp* app = A(h);
+  FFModel* ff = app->ff;
+  for (int k = 0; k < nout; k++) out[k] = 0.0f;
+  if (!app->warmed_up) app->warmup();
+  ff->sync();
+  ff->probe_events_on = true;
+  const int npairs = FFModel::kProbeEvents / 2;
+  std::vector<double> sum(npairs, 0.0);
+  std::vector<int> cnt(npairs, 0);
+  for (int i = 0; i < iters + 1; i++) {
+    app->train_steps(1, false);
+    ff->sync();
+    if (i == 0) continue;                      // first step: warm
+    for (int k = 0; k < npairs; k++) {
+      if (!ff->probe_ev[2 * k] || !ff->probe_ev[2 * k + 1]) continue;
+      float ms = 0.f;
+      if (ff->api->ffh_event_elapsed_ms(ff->ctx, ff->probe_ev[2 * k], ff->probe_ev[2 * k + 1], &ms) == 0) { sum[k] += ms; cnt[k]++; }
+    }
+  }
+  ff->probe_events_on = false;
+  for (int k = 0; k < npairs && k < nout; k++) out[k] = cnt[k] ? (float)(sum[k] / cnt[k]) : 0.0f;
+}
 
 float flexflow_dlrm_time_kernel(flexflow_dlrm_t h, int which, int iters) {
   DLRMApp* app = A(h);

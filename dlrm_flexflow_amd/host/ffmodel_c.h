@@ -90,6 +90,9 @@ int  flexflow_tensor_get_num_dims(flexflow_tensor_t);
 void flexflow_tensor_get_dims(flexflow_tensor_t, int* dims);            /* natural order: dims[0] = batch */
 int64_t flexflow_tensor_get_local_rows(flexflow_tensor_t);
 bool flexflow_tensor_is_local(flexflow_tensor_t);                       /* false: table owned by another rank */
+void* flexflow_tensor_get_device_ptr(flexflow_tensor_t);                /* address of element (0, 0) in the backend's memory (tests / tools: on-device
+                                                                           comparisons of tables too large to copy out); NULL when not local */
+int64_t flexflow_tensor_get_ld(flexflow_tensor_t);                      /* elements between consecutive rows */
 void flexflow_tensor_set_float(flexflow_tensor_t, flexflow_model_t, const int* dims, int num_dims, const float* data);
 void flexflow_tensor_set_int64(flexflow_tensor_t, flexflow_model_t, const int* dims, int num_dims, const int64_t* data);
 void flexflow_tensor_get_float(flexflow_tensor_t, flexflow_model_t, float* data);
@@ -110,6 +113,7 @@ double flexflow_dlrm_run_epochs(flexflow_dlrm_t);
 /* average device time (ms) of `iters` back-to-back launches, HIP events on the launch stream:
  * which = 0 embedding gather (all owned tables, one launch), 1 fused embedding backward + SGD,
  *         2 whole training step (forward, zero_gradients, backward, update; traced if enabled) */
+void flexflow_dlrm_probe_step(flexflow_dlrm_t, int iters, float* out_ms, int nout);   /* in-step event intervals, see ffmodel_c.cc; collective at world_size > 1 */
 float flexflow_dlrm_time_kernel(flexflow_dlrm_t, int which, int iters);
 
 #ifdef __cplusplus

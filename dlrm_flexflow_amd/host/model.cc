@@ -134,6 +134,7 @@ FFConfig::FFConfig() {
   fuse_pair = true;
   dx_scatter = true;
   early_sort = true;
+  update_behind_bottom_bwd = -1;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
@@ -194,6 +195,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
     if (is("--no-early-sort")) { early_sort = false; continue; }
+    if (is("--update-behind-bottom-bwd")) { update_behind_bottom_bwd = 1; continue; }
+    if (is("--no-update-behind-bottom-bwd")) { update_behind_bottom_bwd = 0; continue; }
     if (is("--sparse-embedding-optimizer")) { sparse_embedding_optimizer = true; continue; }
   }
 }
@@ -783,7 +786,7 @@ void Embedding::backward(const FFModel& ff) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
       // backward(), after the host has enqueued the bottom-MLP backward it overlaps with
       if (!ff.grad_ready_attached) ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
-      if (ff.exchange && !ff.config.comm.nonblocking && !ff.use_workers()) {
+      if ((ff.exchange && !ff.config.comm.nonblocking && !ff.use_workers()) || ff.update_behind_bottom_bwd()) {
         ff.emb_update_pending = true;      // host-side collectives on this thread: issue after the bottom-MLP backward is enqueued
       } else {
         ff.issue_embedding_update_on_side_stream();
@@ -1861,6 +1864,20 @@ bool FFModel::early_sort_possible() const {
   return n > 0 && n <= FFH_MAX_TABLES;
 }
 
+// Big layers (the first top layer's weight gradient runs as a persistent one-workgroup-per-CU GEMM for hundreds of microseconds):
+// the table update's reduce launch is HBM-latency-bound and takes every register slot the persistent workgroups leave (3 waves per
+// SIMD on every CU) for ~200 us; the bottom MLP's backward -- a chain of small dependent GEMMs launched at the same moment on the
+// compute stream -- then gets a CU only when an update workgroup retires (its 0.27-GFLOP first kernel took 210 us at 4096 samples:
+// profiles/r04_*_timeline).  Issued behind that chain instead, the update still runs beside the same weight-gradient GEMM, and the
+// chain is out of the way when the GEMM ends.  Small models (Kaggle: the update is one 26-us launch that hides beside the bottom
+// MLP's backward) keep the early issue.  --update-behind-bottom-bwd / --no-update-behind-bottom-bwd force it.
+bool FFModel::update_behind_bottom_bwd() const {
+  if (config.update_behind_bottom_bwd >= 0) return config.update_behind_bottom_bwd != 0 && config.overlap_embedding && fused_embedding_update();
+  if (!config.overlap_embedding || !fused_embedding_update() || z_reader_layer < 0 || use_workers() || capturing_trace >= 0) return false;
+  const Linear* li = static_cast<const Linear*>(layers[z_reader_layer]);
+  return (double)li->in_channels * li->out_channels * (double)local_batch >= 2.0e9;
+}
+
 void FFModel::probe_record(int which, ffh_stream s, ffh_ctx* cx) const {
   if (!probe_events_on) return;
   if (!probe_ev[which]) check(api->ffh_event_create(ctx, &probe_ev[which]), "probe event");
@@ -1870,12 +1887,14 @@ void FFModel::probe_record(int which, ffh_stream s, ffh_ctx* cx) const {
 void FFModel::embedding_group_forward(ffh_stream s, ffh_ctx* on_ctx) const {
   if (embeddings.empty()) return;
   launch_shard_groups(this, kGather, s, on_ctx ? on_ctx : ctx);
+  ffh_ctx* cx = on_ctx ? on_ctx : ctx;
   if (exchange) {
     // each owner gathered its tables / column blocks for the global batch; rows go to the rank that owns the sample
+    probe_record(4, s, cx);
     if (!shards.empty() && config.comm.alltoall_f32(config.comm.user, xsend, fwd_send_counts.data(), xrecv, fwd_recv_counts.data(), s) != 0)
       die("alltoall (embedding forward) failed");
+    probe_record(5, s, cx);
   }
-  ffh_ctx* cx = on_ctx ? on_ctx : ctx;
   // data-parallel (replicated) tables: this rank's samples from this rank's copy, straight into the outputs; one launch
   {
     std::vector<ffh_emb_table> tabs;
@@ -1943,8 +1962,10 @@ void FFModel::embedding_group_update(ffh_stream s, ffh_ctx* on_ctx) const {
   if (embeddings.empty()) return;
   if (exchange) {
     // gradients of the rows go back to the owners (transposed exchange)
+    probe_record(6, s, on_ctx ? on_ctx : ctx);
     if (!shards.empty() && config.comm.alltoall_f32(config.comm.user, gsend, fwd_recv_counts.data(), grecv, fwd_send_counts.data(), s) != 0)
       die("alltoall (embedding backward) failed");
+    probe_record(7, s, on_ctx ? on_ctx : ctx);
   }
   launch_shard_groups(this, emb_sorted_early ? kApplyOnly : kFusedUpdate, s, on_ctx ? on_ctx : ctx);
   emb_sorted_early = false;
@@ -2100,7 +2121,9 @@ void FFModel::issue_embedding_forward_on_side_stream() const {
 
 void FFModel::join_embedding_forward() const {
   if (side_worker) side_worker->drain();   // the record of ev_join must have been issued before we wait on it
+  probe_record(10, stream, ctx);           // bench probes: what the compute stream waits here is the EXPOSED part of gather + exchange
   check(api->ffh_stream_wait_event(ctx, stream, ev_join), "join");
+  probe_record(11, stream, ctx);
   emb_forward_joined = true;
 }
 
@@ -2232,6 +2255,11 @@ void FFModel::backward(int _seq_length) {
   }
   if (emb_update_pending) {
     // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
+    if (update_behind_bottom_bwd()) {
+      // ... or rather BEHIND its data-gradient chain (see update_behind_bottom_bwd()): "gradients ready" becomes "the bottom MLP's
+      // backward kernels on the compute stream are through", one more event on a stream that waits for the big dW anyway
+      check(api->ffh_event_record(ctx, ev_grad_ready, stream), "event");
+    }
     issue_embedding_update_on_side_stream();
     emb_update_pending = false;
   }
@@ -2259,8 +2287,11 @@ void FFModel::update() {
   }
   // data-parallel MLP gradients: ONE bucket [ref: one ncclAllReduce per tensor, src/runtime/optimizer_kernel.cu:170-171].
   // No 1/world_size: the loss already divides by the global batch.
-  if (exchange && mlp_count)
+  if (exchange && mlp_count) {
+    probe_record(8, stream, ctx);
     if (config.comm.allreduce_sum_f32(config.comm.user, mlp_grads, (int64_t)mlp_count, stream) != 0) die("allreduce failed");
+    probe_record(9, stream, ctx);
+  }
   // one launch over the whole MLP slab; it also clears the gradients it consumed, so the next zero_gradients()
   // has nothing to sweep [ref: one update task per parameter, src/runtime/optimizer.cc:93-189,256-330]
   if (adam) {

@@ -57,6 +57,24 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if len(sys.argv) > 3 and sys.argv[3].startswith("opt:"):
+        # any optimizer x any placement on the HIP kernels: "opt:<adam|mom>:<dense|sparse>:<table|column|row|mixed>" (tests/test_gpu_round4.py)
+        _, okind, path, place = sys.argv[3].split(":")
+        kw = dict(adam=H.ADAM_HP) if okind == "adam" else dict(sgd=H.MOM_HP)
+        m, h = H.build_golden_dlrm(capi.HIP_LIB_PATH, comm=comm.struct, overlap=True, force_exchange=True,
+                                   column_shard_rows=40 if place == "column" else 0, row_shard_rows=40 if place == "row" else 0,
+                                   replicate_rows=39 if place == "mixed" else 0,
+                                   extra_argv=["--device", "0"] + (["--sparse-embedding-optimizer"] if path == "sparse" else []), **kw)
+        recs = H.run_steps(m, h, 3)
+        for step, rec in enumerate(recs):
+            for k, v in rec.items():
+                out[f"s{step}/{k}"] = v
+        out["allreduce_calls"] = np.array(comm.calls["allreduce"])
+        np.savez(os.path.join(outdir, f"rank{dist.get_rank()}.npz"), **out)
+        m.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     column = len(sys.argv) > 3 and sys.argv[3] == "column"     # the 50-row table of the golden model split column-wise over the ranks
     row = len(sys.argv) > 3 and sys.argv[3] == "row"           # ... row-wise: partial sums + reduce-scatter, all-gather backward
     strategy = len(sys.argv) > 3 and sys.argv[3] == "strategy" # table owners from <outdir>/strategy.txt (reference text format)

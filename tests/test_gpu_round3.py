@@ -105,34 +105,8 @@ def test_linear_layers_of_the_benched_step_at_b32768_vs_oracle(hip, oracle, IN, 
         assert "|sk_128x128x64" in routes["fwd"] and routes["bwd_ex"].count("|sk_128x128x64") == 2, routes
 
 
-@pytest.mark.timeout(1800)
-def test_bench_workload_whole_step_at_b32768_hip_vs_oracle(hip):
-    """ONE step of the workload bench.py times at N = 1 -- all 26 tables, emb_dim 128, bot 13-512-256-128, top
-    3456-1024-1024-512-256-1, batch 32768, eager launches on three streams -- HIP vs the same host code on the oracle.  Row
-    counts capped at 100,000 so that the oracle backend's tables fit the host (full-size tables: per-table property tests and
-    bench.py).  About 1 TFLOP of host loops per step."""
-    rows = "-".join(str(min(r, 100000)) for r in TERABYTE_ROWS)
-    args = ["-b", "32768", "--arch-sparse-feature-size", "128", "--arch-embedding-size", rows, "--arch-mlp-bot", "13-512-256-128",
-            "--arch-mlp-top", "3456-1024-1024-512-256-1", "--data-size", "32768"]
-    out = {}
-    for name, backend in (("hip", HIP), ("cpu", H.oracle_backend())):
-        app = ffmodel.DLRM(["--backend", backend] + args)
-        app.warmup()
-        app.train_steps(1, trace=False)
-        app.model.sync()
-        m = app.model
-        o = {}
-        for li in range(m.num_layers):
-            for wi in range(m.layer_num_weights(li)):
-                p = m.parameter(li, wi)
-                if p.is_local:
-                    o[f"{m.layer_name(li)}/{wi}"] = p.get_weights()
-        o["pred"] = m.layer_output(m.num_layers - 1).get()
-        out[name] = o
-        app.close()
-    assert out["hip"].keys() == out["cpu"].keys()
-    for k in out["hip"]:
-        np.testing.assert_allclose(out["hip"][k], out["cpu"][k], rtol=2e-5, atol=2e-6, err_msg=k)
+# (the one-step whole-model check of round 3 at this size lives on, tightened, in tests/test_gpu_round4.py:
+#  test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle -- three steps, weight DELTAS at 1e-5 of their term mass)
 
 
 def test_reference_harness_linear_20_5000_5000(hip):

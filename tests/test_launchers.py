@@ -211,6 +211,13 @@ def test_bench_two_ranks_functional_on_cpu(oracle, scaling):
     assert c["alltoall"] == 2 * (1 + 1 + 3) and c["allreduce"] == 1 + 1 + 3        # the driver's warm-up + W + K steps
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["tables_in_launch"] == 4      # rank 0 owns tables 0, 2, 4, 6 of 8
     assert d["value"] > 0 and "cpu_baseline" not in d
+    # round-3 advisor (high): the in-step probes run real steps, i.e. collectives -- every rank must walk them (rank 0 alone hung a
+    # real N > 1 run).  The functional run takes that branch now and reports the collectives' in-step intervals.
+    cis = d["collectives_in_step_us"]
+    for who in ("rank0", "max_over_ranks"):
+        assert set(cis[who]) == {"alltoall_fwd_us", "alltoall_bwd_us", "allreduce_us", "embedding_branch_wait_us", "gather_plus_alltoall_fwd_us", "alltoall_bwd_plus_table_update_us"}
+        assert cis[who]["alltoall_fwd_us"] >= 0 and cis[who]["allreduce_us"] >= 0
+    assert all(cis["max_over_ranks"][k] >= cis["rank0"][k] for k in cis["rank0"])
     pay = d["config"]["collective_payload_bytes_per_step_rank0"]
     B, D = d["config"]["global_batch"], 16
     assert pay["alltoall_forward_sent"] == pay["alltoall_backward_sent"] == 4 * B * D * 4 // 2 and pay["allreduce_buffer"] > 0
