@@ -28,6 +28,11 @@ struct ffh_ctx {
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
   ffh_mirror_region mirrors[32];   // bf16 twins of fp32 buffers (tensor-op mode)
   int         nmirrors;
+  // stream-K partial tiles of the persistent fp32 GEMMs (linear_sk.hip): per stream one set of num_cus slots of 128 x 128 floats +
+  // one flag per slot; the first set is allocated with the ctx, further ones when another stream first launches such a GEMM
+  struct { void* stream; float* slots; unsigned* flags; } sk_sets[4];
+  int         sk_nsets;
+  unsigned    sk_epoch;
   const void* emb_sorted_ws;     // ffh_embedding_bwd_sort_multi left a sorted list (and cleared fold counters) in THIS workspace ...
   int64_t     emb_sorted_sig[4]; // ... for this (ntables, in_dim, out_dim, batch): ffh_embedding_bwd_sgd_apply_multi consumes it, once
   char        route[256]; // ffh_linear_last_route(): kernel families of the latest ffh_linear_* call

@@ -63,6 +63,11 @@ struct SkArgs {
   int M, N, K;
   int act;
   unsigned a_bytes, b_bytes, bias_bytes, mask_bytes;     // extents for the buffer descriptors (0: operand absent -> loads return 0)
+  // SPLIT (stream-K forward / data gradient): partial tiles of the workgroups that continue a tile another one began -- slot r =
+  // range r's 128 x 128 accumulators in lane order -- and one flag per slot, set to `sk_epoch` when the slot is written
+  float*    sk_slots;
+  unsigned* sk_flags;
+  unsigned  sk_epoch;
 };
 
 template <int... I, class F>
@@ -80,11 +85,23 @@ constexpr int SK_EP_ROWS = 16;                     // rows of the wave's 64 x 64
                                                    // a segment ends once or twice per workgroup, so the rounds cost nothing
 constexpr int SK_EP_WAVE = SK_EP_ROWS * SK_EP_LD * 4;     // bytes per wave
 
-template <bool AKR, bool BKR, int EPI, bool DB = false>
+// SPLIT: stream-K for the forms whose output is stored, not accumulated (forward, data gradient).  Whole tiles only fill the chip
+// when their count is a multiple of the workgroup count: the 864 tiles of 3456 -> 1024's data gradient at 4096 samples are 3.4
+// rounds of 256 (a quarter of the last round's CUs idle: 114 instead of 135 TFLOP/s), the 128 tiles of 1024 -> 512 leave half the
+// chip empty.  As for the weight gradient the flat (tile, k-tile) space is cut into G equal ranges; a tile that straddles ranges is
+// finished by the workgroup that holds its HEAD (k = 0 ...): that range is the earlier one, its head is the LAST thing the
+// workgroup computes, while the ranges holding the rest of the tile compute it FIRST and leave their accumulators in a slot (lane
+// order: coalesced 8-byte agent-scope stores, then a flag) -- so the owner finds the partials waiting, adds them in k order (a
+// fixed order: same bits run to run) and runs the ordinary epilogue.  Owners wait only after all their own work, contributors
+// never wait: no cycle.  Cross-workgroup values travel as agent-scope relaxed atomics (sc1: written through / read behind the
+// per-XCD L2s), ordered by completion (vmcnt + barrier before the flag), as in embedding.hip's folds.
+template <bool AKR, bool BKR, int EPI, bool DB = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
   static_assert(!DB || (EPI == SK_EPI_DW_ATOMIC && AKR), "the bias gradient rides on the weight-gradient form");
+  static_assert(!SPLIT || EPI != SK_EPI_DW_ATOMIC, "the weight gradient meets by atomics");
   extern __shared__ __attribute__((aligned(16))) char sk_lds[];
   constexpr bool ATOMIC = EPI == SK_EPI_DW_ATOMIC;
+  constexpr bool STREAMK = ATOMIC || SPLIT;
   constexpr int LDS_A = AKR ? SK_LDS_KR : SK_LDS_KC;
   char* const ldsA = sk_lds;
   char* const ldsB = sk_lds + LDS_A;
@@ -117,9 +134,10 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
   const unsigned total_it = ntiles * nk;                  // < 2^32 (the host checks)
   const unsigned wperm = (w & 7u) * (G >> 3) + (w >> 3);  // G is a multiple of 8
   unsigned it_b, it_e;
-  if (ATOMIC) {
-    const unsigned ipw = (total_it + G - 1) / G;
-    it_b = w * ipw; it_e = it_b + ipw < total_it ? it_b + ipw : total_it;
+  const unsigned ipw = (total_it + G - 1) / G;
+  const unsigned rng = SPLIT ? wperm : w;                 // SPLIT: the ranges of one XCD's workgroups are neighbours (shared panels in its L2)
+  if (STREAMK) {
+    it_b = rng * ipw; it_e = it_b + ipw < total_it ? it_b + ipw : total_it;
     if (it_b > total_it) it_b = total_it;
   } else {
     const unsigned mine = ntiles / G + (wperm < ntiles % G ? 1u : 0u);
@@ -131,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
   struct Cursor { unsigned seq, kt, m0, n0, offA, offB; };   // seq: index of the tile in this workgroup's sequence
   auto place = [&](Cursor& c) {      // tile coordinates and operand offsets of (c.seq, c.kt)
     unsigned lin;
-    if (ATOMIC) lin = it_b / nk + c.seq;
+    if (STREAMK) lin = it_b / nk + c.seq;
     else lin = c.seq * G + wperm;
     if (lin >= ntiles) lin = ntiles - 1;                  // run-ahead loads past the end of the share: any valid tile
     const unsigned by = lin / nbx, bx = lin - by * nbx;
@@ -144,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
     if (c.kt == nk) { c.kt = 0; c.seq++; place(c); }
     else { c.offA += kadvA; c.offB += kadvB; }
   };
-  Cursor ld{0, ATOMIC ? it_b % nk : 0u, 0, 0, 0, 0}, cp = ld;
+  Cursor ld{0, STREAMK ? it_b % nk : 0u, 0, 0, 0, 0}, cp = ld;
   place(ld); place(cp);
 
   u32x4 P[16];
@@ -232,9 +250,53 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
     }
     it += seg;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // MFMA result -> v_accvgpr_read
+    bool store_tile = true;
+    if constexpr (SPLIT) {
+      const bool head = cp.kt == 0;
+      if (!(head && seg == nk)) {
+        typedef unsigned long long u64;
+        if (!head) {
+          // this range's first segment continues a tile: leave the accumulators for the workgroup that holds the tile's head
+          u64* slot = reinterpret_cast<u64*>(g.sk_slots + (size_t)rng * (SK_BM * SK_BN));
+#pragma unroll
+          for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+            for (int tn = 0; tn < 4; tn++) {
+              const f32x4 v = acc[tm][tn];
+              u64* q2 = slot + ((tm * 4 + tn) * 256 + tid) * 2;
+              __hip_atomic_store(q2, ((u64)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(q2 + 1, ((u64)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0) __hip_atomic_store(g.sk_flags + rng, g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          store_tile = false;
+        } else {
+          // the tile's head: add the partials of the following ranges, in k order, then the ordinary epilogue
+          unsigned rem = nk - seg, r2 = rng + 1;
+          while (rem) {
+            const unsigned b2 = r2 * ipw;
+            const unsigned e2 = b2 + ipw < total_it ? b2 + ipw : total_it;
+            const unsigned len = (e2 - b2) < rem ? (e2 - b2) : rem;
+            while (__hip_atomic_load(g.sk_flags + r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) __builtin_amdgcn_s_sleep(2);
+            const u64* slot = reinterpret_cast<const u64*>(g.sk_slots + (size_t)r2 * (SK_BM * SK_BN));
+#pragma unroll
+            for (int tm = 0; tm < 4; tm++)
+#pragma unroll
+              for (int tn = 0; tn < 4; tn++) {
+                const u64* q2 = slot + ((tm * 4 + tn) * 256 + tid) * 2;
+                const u64 lo = __hip_atomic_load(q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 hi = __hip_atomic_load(q2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                acc[tm][tn] += f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32))};
+              }
+            rem -= len; r2++;
+          }
+        }
+      }
+    }
     // ---- epilogue of the tile / segment: lane (c16, q) of wave (wy, wx) holds, for tm, i in 0..3, the four columns
     //      n0 + 64 wx + 4 c16 + {0..3} of row m0 + 64 wy + 16 q + 4 i + tm
-    {
+    if (store_tile) {
       const int nn = (int)cp.n0 + 64 * wx + 4 * c16;
       const bool relu_fast = g.act == FFH_AC_MODE_RELU, none_fast = g.act == FFH_AC_MODE_NONE;      // uniform
       (void)relu_fast; (void)none_fast;
@@ -353,7 +415,7 @@ inline bool sk_aligned(const void* p, int64_t ld) { return (((uintptr_t)p & 15) 
 namespace ffh_gemm {
 
 namespace {
-struct SkPlan { int64_t lda, ldb, a_bytes, b_bytes; int G; };
+struct SkPlan { int64_t lda, ldb, a_bytes, b_bytes; int G; bool split; };
 bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
   static const int off = getenv("FFH_GEMM_NO_SK") ? atoi(getenv("FFH_GEMM_NO_SK")) : 0;   // A/B switch (tools/ab.sh)
   if (off) return false;
@@ -390,10 +452,36 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
     if (ntiles * nk < 4LL * p.G) return false;                     // at least four k-tiles per workgroup
   } else {
     if (g.epi != EPI_STORE && g.epi != EPI_ADD) return false;
-    if (ntiles < p.G) return false;
+    // whole tiles when they fill whole rounds of workgroups (or nearly: a split costs a partial tile's round trip through memory);
+    // otherwise stream-K with the fix-up of the kernel's SPLIT form when every workgroup still gets >= 4 k-tiles
+    static const int no_split = getenv("FFH_SK_NO_SPLIT") ? atoi(getenv("FFH_SK_NO_SPLIT")) : 0;     // A/B switch (tools/ab.sh)
     const int64_t rounds = (ntiles + p.G - 1) / p.G;
-    if (ntiles * 100 < rounds * p.G * 80) return false;            // whole tiles only: the last round must be nearly full
+    const int64_t idle_it = (rounds * p.G - ntiles) * nk / p.G;      // k-tile iterations per workgroup the last round wastes
+    p.split = !no_split && !c->deterministic && idle_it >= 2 && ntiles * nk >= 4LL * p.G && g.epi == EPI_STORE;
+    if (!p.split) {
+      if (ntiles < p.G) return false;
+      if (ntiles * 100 < rounds * p.G * 80) return false;          // whole tiles only: the last round must be nearly full
+    }
   }
+  return true;
+}
+
+// the partial-tile slots of the SPLIT form for launches on stream s (ctx-owned scratch, like LinearMeta's ones vector
+// [ref: src/ops/linear.cu:986-994]: allocated when a stream first needs it, never during a capture)
+bool sk_slots_for(ffh_ctx* c, hipStream_t s, float** slots, unsigned** flags) {
+  for (int i = 0; i < c->sk_nsets; i++)
+    if (c->sk_sets[i].stream == (void*)s) { *slots = c->sk_sets[i].slots; *flags = c->sk_sets[i].flags; return true; }
+  if (c->sk_nsets >= 4) return false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (st != hipStreamCaptureStatusNone) return false;
+  float* sl = nullptr; unsigned* fl = nullptr;
+  const size_t G = (size_t)(c->num_cus & ~7);
+  if (hipMalloc((void**)&sl, G * SK_BM * SK_BN * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMalloc((void**)&fl, G * sizeof(unsigned)) != hipSuccess || hipMemset(fl, 0, G * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(sl); if (fl) (void)hipFree(fl); return false; }
+  c->sk_sets[c->sk_nsets] = {(void*)s, sl, fl};
+  c->sk_nsets++;
+  *slots = sl; *flags = fl;
   return true;
 }
 }  // namespace
@@ -402,8 +490,15 @@ bool gemm_sk_serves(const ffh_ctx* c, const GemmArgs& g, int form) { SkPlan p; r
 
 // 1: launched; 0: not this kernel's shape (nothing launched); < 0: error
 int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name) {
-  SkPlan p;
+  SkPlan p{};
   if (!sk_plan(c, g, form, p)) return 0;
+  float* slots = nullptr; unsigned* flags = nullptr;
+  if (p.split && !sk_slots_for(c, as_stream(s), &slots, &flags)) {
+    // no slots (a capture in flight, too many streams): the whole-tile form where it serves, else not this kernel's launch
+    p.split = false;
+    const int64_t ntiles = (int64_t)(g.M / SK_BM) * (g.N / SK_BN), rounds = (ntiles + p.G - 1) / p.G;
+    if (ntiles < p.G || ntiles * 100 < rounds * p.G * 80) return 0;
+  }
   const int64_t lda = p.lda, ldb = p.ldb, a_bytes = p.a_bytes, b_bytes = p.b_bytes;
   const int G = p.G;
   SkArgs a{};
@@ -413,6 +508,7 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   a.a_bytes = (unsigned)a_bytes; a.b_bytes = (unsigned)b_bytes;
   a.bias_bytes = g.bias ? (unsigned)g.N * 4u : 0u;
   a.mask_bytes = g.mask ? 1u : 0u;
+  if (p.split) { a.sk_slots = slots; a.sk_flags = flags; a.sk_epoch = ++c->sk_epoch; if (a.sk_epoch == 0) a.sk_epoch = ++c->sk_epoch; }
   // The kernels need more than 64 KB of dynamic LDS; hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of the
   // function, and one process may hold a ctx per device (ffh_ctx_default): set once per (kernel, device).  A launch that still
   // fails (attribute refused, no such resources) is not an error of the call: 0 = "not served", linear.hip's kernels take the layer.
@@ -425,7 +521,10 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
     if (ok[dev] < 0) return 0;                                                                                   \
     hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), LDSB, as_stream(s), a);                               \
   }
-  if (form == SK_FORM_FWD) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC)
+  if (form == SK_FORM_FWD && p.split) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC, false, true)
+  else if (form == SK_FORM_DX && p.split && g.colmap) FFH_SK_LAUNCH(false, true, SK_EPI_DX_CMAP, SK_LDS_KC + SK_LDS_KR, false, true)
+  else if (form == SK_FORM_DX && p.split) FFH_SK_LAUNCH(false, true, SK_EPI_DX_STORE, SK_LDS_KC + SK_LDS_KR, false, true)
+  else if (form == SK_FORM_FWD) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC)
   else if (form == SK_FORM_DW && g.db) FFH_SK_LAUNCH(true, true, SK_EPI_DW_ATOMIC, 2 * SK_LDS_KR + 4 * SK_EP_WAVE, true)
   else if (form == SK_FORM_DW) FFH_SK_LAUNCH(true, true, SK_EPI_DW_ATOMIC, 2 * SK_LDS_KR + 4 * SK_EP_WAVE)
   else if (g.colmap) FFH_SK_LAUNCH(false, true, SK_EPI_DX_CMAP, SK_LDS_KC + SK_LDS_KR)
@@ -433,7 +532,7 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   else FFH_SK_LAUNCH(false, true, SK_EPI_DX_ADD, SK_LDS_KC + SK_LDS_KR)
 #undef FFH_SK_LAUNCH
   if (hipGetLastError() != hipSuccess) return 0;        // launch refused: nothing was enqueued, the caller falls through to linear.hip
-  { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64%s|wgs=%d", name, g.colmap ? "|colmap" : "", G); ffh_route_add(c, tok); }
+  { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64%s%s|wgs=%d", name, g.colmap ? "|colmap" : "", p.split ? "|streamk" : "", G); ffh_route_add(c, tok); }
   return 1;
 }
 

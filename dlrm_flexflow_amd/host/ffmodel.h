@@ -105,7 +105,8 @@ class FFConfig {
   bool deterministic;          // --deterministic: weight / bias gradients without fp atomics (ffh_ctx_set_deterministic): bit-identical runs
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
-  int  update_behind_bottom_bwd;     // 1 / 0: the side-stream table update is issued behind / beside the bottom MLP's backward; -1 (default): by model size
+  int  defer_big_dw;                 // 1 / 0: the biggest layer's weight gradient is issued last / with its data gradient; -1 (default): by per-GPU batch
+  bool pad_linear_k;                 // (A/B: --no-pad-linear-k) zero-pad the input / kernel of a wide Linear whose in_dim is not a multiple of 64
   bool sparse_embedding_optimizer;   // --sparse-embedding-optimizer: momentum / weight-decay SGD and Adam update the rows a batch touched, with per-row state, on the
                                // sorted segments of the fused update (ffh_sparse_opt: lazy semantics, a stated divergence) instead of the reference's dense sweep
   bool early_sort;             // the index-only sort of the fused table update runs behind the gather (ffh_embedding_bwd_sort_multi), off the backward's critical path (A/B: --no-early-sort)
@@ -285,7 +286,10 @@ class Linear : public Op {
   void create_output_and_partition(FFModel& model) override;
   void forward(const FFModel&) override;
   void backward(const FFModel&) override;
+  void backward_part(const FFModel&, int part);   // 0: all; 1: data gradient only; 2: weight / bias gradient only, on the weight-gradient stream
   int in_channels, out_channels;
+  int in_padded;                // what the kernel library is told: in_channels, or that rounded up to 64 when the input tensor and the kernel were
+                                // given zero pad columns (FFModel::allocate step 4a: reduction depths the persistent GEMMs cannot take)
   ActiMode activation;
   bool use_bias;
   bool discard_input_grad;      // first layer on a model input: dX is never consumed
@@ -489,6 +493,8 @@ class FFModel {
   bool need_zero_gsend;        // some gradient in the exchange send buffer is accumulated rather than stored
   bool need_zero_act_grads;    // some activation gradient is accumulated by more than one producer
   mutable bool dw_forked;
+  mutable bool dw_stream_used_directly = false;   // a weight gradient was enqueued on dw_stream by this layer itself (deferred dW), not by the library's fork
+  int defer_big_dw_layer() const;
   mutable bool mlp_grads_clean;   // the optimizer kernel cleared the MLP gradient slab (FFH_OPT_ZERO_GRAD): zero_gradients() skips it
   LaunchWorker *dw_worker, *side_worker;   // NULL: launches are issued inline by the calling thread
   std::vector<ffh_event> layer_events;     // one per layer: "dY of this layer is ready"
@@ -528,7 +534,6 @@ class FFModel {
   void order_input_writes_behind_update() const;
   void profiled(const Op* op, bool fwd, const std::function<void()>& fn) const;   // --profiling: one op between two events
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
-  bool update_behind_bottom_bwd() const;
   bool early_sort_possible() const;      // one launch group, nothing else on the workspace between a step's gather and its update
   mutable bool emb_sorted_early;         // this step's sort was issued behind the gather: the update is the apply phase only
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)

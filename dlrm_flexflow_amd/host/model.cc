@@ -134,7 +134,8 @@ FFConfig::FFConfig() {
   fuse_pair = true;
   dx_scatter = true;
   early_sort = true;
-  update_behind_bottom_bwd = -1;
+  pad_linear_k = true;
+  defer_big_dw = -1;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
@@ -195,8 +196,9 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
     if (is("--no-early-sort")) { early_sort = false; continue; }
-    if (is("--update-behind-bottom-bwd")) { update_behind_bottom_bwd = 1; continue; }
-    if (is("--no-update-behind-bottom-bwd")) { update_behind_bottom_bwd = 0; continue; }
+    if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
+    if (is("--defer-big-dw")) { defer_big_dw = 1; continue; }
+    if (is("--no-defer-big-dw")) { defer_big_dw = 0; continue; }
     if (is("--sparse-embedding-optimizer")) { sparse_embedding_optimizer = true; continue; }
   }
 }
@@ -592,7 +594,7 @@ Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_
 // =============================================================================================
 Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activation, bool _use_bias, const Op* shared_op,
                Initializer* ki, Initializer* bi, const char* name)
-    : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), activation(_activation),
+    : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), in_padded(input.adim[0]), activation(_activation),
       use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), dx_map(nullptr), dx_map_concat(nullptr), pair_upper(nullptr), fwd_done_by_pair(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false),
       kernel_initializer(ki), bias_initializer(bi) {
   if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
@@ -630,9 +632,10 @@ void Linear::forward(const FFModel& ff) {
     if (rc != FFH_ERR_UNSUPPORTED) ff.check(rc, name);
     pair_upper = nullptr;                                          // not a shape the pair launch serves
   }
+  // (in_padded: the layer as the kernel library sees it -- see allocate(), step 4a; equal to in_channels unless the input was padded)
   ff.check(ff.api->ffh_linear_fwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, (float*)y.impl->ptr, y.impl->ld,
                                   (const float*)weights[0].impl->ptr, use_bias ? (const float*)weights[1].impl->ptr : nullptr,
-                                  in_channels, out_channels, b, (int)activation, ff.stream), name);
+                                  in_padded, out_channels, b, (int)activation, ff.stream), name);
 }
 int Linear::backward_pair(const FFModel& ff) {
   Linear* lo = pair_lower;
@@ -653,7 +656,12 @@ int Linear::backward_pair(const FFModel& ff) {
                                      FFH_LINEAR_ONLY_DW | FFH_LINEAR_DY_PREMASKED, ff.stream, nullptr), lo->name);
   return FFH_OK;
 }
-void Linear::backward(const FFModel& ff) {
+void Linear::backward(const FFModel& ff) { backward_part(ff, 0); }
+
+// part 0: the whole backward; 1: the data gradient only (FFH_LINEAR_ONLY_DX on the compute stream); 2: the weight / bias gradient
+// only (FFH_LINEAR_ONLY_DW on the weight-gradient stream, behind everything the compute stream holds at this point).  The two
+// halves are for FFModel::backward's deferred weight gradient (--defer-big-dw).
+void Linear::backward_part(const FFModel& ff, int part) {
   // [ref: src/ops/linear.cu:632-635: "only support relu and sigmoid for now" -- an assert there, a named error here]
   if (activation == AC_MODE_GELU) die("%s: GELU has no backward (forward / inference only, as in the reference)", name);
   const Tensor& x = inputs[0];
@@ -669,12 +677,27 @@ void Linear::backward(const FFModel& ff) {
   const float *xp = (const float*)x.impl->ptr, *yp = (const float*)y.impl->ptr, *wp = (const float*)weights[0].impl->ptr;
   float *dyp = y.impl->grad, *dwp = weights[0].impl->grad, *dbp = use_bias ? weights[1].impl->grad : nullptr;
   const int64_t ldx = x.impl->ld, lddx = x.impl->grad_ld, ldy = y.impl->ld, lddy = y.impl->grad_ld;
+  if (part == 1) {
+    ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
+                                       flags | FFH_LINEAR_ONLY_DX, ff.stream, nullptr), name);
+    return;
+  }
+  if (part == 2) {
+    ffh_event ev = ff.layer_events[layer_index];
+    ff.check(ff.api->ffh_event_record(ff.ctx, ev, ff.stream), "event");
+    ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.dw_stream, ev), "event");
+    ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, nullptr, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
+                                       flags | FFH_LINEAR_ONLY_DW, ff.dw_stream, nullptr), name);
+    ff.dw_forked = true;
+    ff.dw_stream_used_directly = true;
+    return;
+  }
   if (fork && ff.use_workers()) {
     // two host threads: this one keeps walking the dX chain, the dW GEMM is issued by the dw worker on its stream
     const KernelApi* api = ff.api;
     ffh_stream dws = ff.dw_stream;
     ffh_event ev = ff.layer_events[layer_index];
-    const int in = in_channels, out = out_channels, act = (int)activation;
+    const int in = in_padded, out = out_channels, act = (int)activation;
     const char* nm = name;
     auto dw_call = [=](ffh_ctx* wc) {
       int rc = api->ffh_stream_wait_event(wc, dws, ev);
@@ -688,7 +711,7 @@ void Linear::backward(const FFModel& ff) {
     ff.dw_forked = true;
     return;
   }
-  ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_channels, out_channels, b, (int)activation,
+  ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                      flags, ff.stream, fork ? ff.dw_stream : nullptr), name);
   if (fork) ff.dw_forked = true;
 }
@@ -786,7 +809,7 @@ void Embedding::backward(const FFModel& ff) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
       // backward(), after the host has enqueued the bottom-MLP backward it overlaps with
       if (!ff.grad_ready_attached) ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
-      if ((ff.exchange && !ff.config.comm.nonblocking && !ff.use_workers()) || ff.update_behind_bottom_bwd()) {
+      if (ff.exchange && !ff.config.comm.nonblocking && !ff.use_workers()) {
         ff.emb_update_pending = true;      // host-side collectives on this thread: issue after the bottom-MLP backward is enqueued
       } else {
         ff.issue_embedding_update_on_side_stream();
@@ -1092,7 +1115,7 @@ void SGDOptimizer::init(void) {
   if (momentum > 0.0) {
     for (const Parameter& p : model->parameters) {
       if (!p.impl->grad) continue;
-      const size_t bytes = p.get_volume() * sizeof(float);
+      const size_t bytes = p.impl->bytes;          // (rows x leading dimension: a padded Linear kernel keeps its pad columns)
       float* v = (float*)model->dmalloc(bytes);
       model->check(model->api->ffh_zero(model->ctx, v, bytes, model->stream), "momentum init");
       v_values[p.impl->ptr] = v;
@@ -1103,7 +1126,7 @@ void SGDOptimizer::next(void) {}
 void SGDOptimizer::update(const Parameter* p) {
   if (!p->impl->grad) return;   // embedding tables on the fused path have no dense gradient
   float* v = momentum > 0.0 ? v_values[p->impl->ptr] : nullptr;
-  model->check(model->api->ffh_sgd_update(model->ctx, (float*)p->impl->ptr, p->impl->grad, v, (int64_t)p->get_volume(), (float)lr,
+  model->check(model->api->ffh_sgd_update(model->ctx, (float*)p->impl->ptr, p->impl->grad, v, (int64_t)(p->impl->bytes / sizeof(float)), (float)lr,
                                           (float)weight_decay, (float)momentum, nesterov ? 1 : 0, model->stream), "sgd_update");
 }
 
@@ -1123,7 +1146,7 @@ void AdamOptimizer::init(void) {
   if (model->mlp_count) { mlp_m = zeros(model->mlp_count); mlp_v = zeros(model->mlp_count); }
   for (const Parameter& p : model->parameters) {
     if (in_dense_slab(p) || !p.impl->grad) continue;
-    mv_values[p.impl->ptr] = std::make_pair(zeros(p.get_volume()), zeros(p.get_volume()));
+    mv_values[p.impl->ptr] = std::make_pair(zeros(p.impl->bytes / sizeof(float)), zeros(p.impl->bytes / sizeof(float)));
   }
 }
 void AdamOptimizer::next(void) {
@@ -1143,7 +1166,7 @@ void AdamOptimizer::update(const Parameter* p) {
     if (it == mv_values.end()) die("AdamOptimizer::update: parameter without moments");
     m = it->second.first; v = it->second.second;
   }
-  model->check(model->api->ffh_adam_update(model->ctx, (float*)p->impl->ptr, p->impl->grad, m, v, (int64_t)p->get_volume(), (float)alpha_t,
+  model->check(model->api->ffh_adam_update(model->ctx, (float*)p->impl->ptr, p->impl->grad, m, v, (int64_t)(p->impl->bytes / sizeof(float)), (float)alpha_t,
                                            (float)beta1, (float)beta2, (float)weight_decay, (float)epsilon, 0, model->stream), "adam_update");
 }
 
@@ -1310,7 +1333,23 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
   allocate();
   for (Op* op : layers) {
     if (Linear* li = dynamic_cast<Linear*>(op)) {
-      li->kernel_initializer->init(this, &li->weights[0]);
+      if (li->in_padded != li->in_channels) {
+        // padded kernel: the initializer fills a contiguous [out][in] temporary exactly as it would fill the reference's tensor; the
+        // rows are then copied into the padded storage (whose pad columns stay zero)
+        Parameter tmp = li->weights[0];
+        TensorImpl ti = *li->weights[0].impl;
+        ti.ptr = dmalloc(tmp.get_volume() * sizeof(float)); ti.ld = li->in_channels; ti.grad = nullptr;
+        tmp.impl = &ti;
+        li->kernel_initializer->init(this, &tmp);
+        for (int r = 0; r < li->out_channels; r++)
+          check(api->ffh_memcpy_d2d(ctx, (float*)li->weights[0].impl->ptr + (size_t)r * li->in_padded, (const float*)ti.ptr + (size_t)r * li->in_channels,
+                                    (size_t)li->in_channels * sizeof(float), stream), "padded kernel init");
+        check(api->ffh_stream_sync(ctx, stream), "padded kernel init");
+        api->ffh_free(ctx, ti.ptr);
+        note_weight_write(li->weights[0].impl->ptr);
+      } else {
+        li->kernel_initializer->init(this, &li->weights[0]);
+      }
       if (li->use_bias) li->bias_initializer->init(this, &li->weights[1]);
     } else if (Embedding* e = dynamic_cast<Embedding*>(op)) {
       if (e->held_here(rank)) e->kernel_initializer->init(this, &e->weights[0]);
@@ -1429,6 +1468,29 @@ void FFModel::allocate() {
       off += in.adim[0];
     }
   }
+  // ---- 4a. reduction depths the persistent GEMMs cannot take (in % 64 != 0): pad the operand, not the kernel -------------
+  // MLPerf-DLRM's first top layer reads the dot interaction's 479 columns: K = 479 is not a multiple of the 64-deep k-tiles and
+  // rows of 479 floats start at odd dwords, so all three GEMMs of the layer fell back to the register-staged kernels (97 / 75 /
+  // 74 TFLOP/s where hipBLASLt does 118 / 118 / 113).  This layer owns both allocations: when the input tensor has storage of its
+  // own, one consumer, and a producer that writes with a leading dimension (the interaction, a Linear), the tensor and its
+  // gradient get ld = in rounded up to 64 with zero pad columns, and the kernel is stored [out][in_padded] with zero pads -- to the
+  // kernel library it is a 512-wide layer.  Same values: the pads add exact zeros at the END of every k sum (x_pad w_pad = 0);
+  // dW's pad columns are dy^T x_pad = 0, so the pads stay zero under SGD / momentum / weight decay / Adam; dX's pad columns are
+  // dy w_pad = 0 and nobody reads them.  The reference-visible shape stays [out][in] (get / set_weights copy rows).
+  std::map<TensorImpl*, int64_t> padded_ld;
+  for (Op* op : layers) {
+    Linear* li = dynamic_cast<Linear*>(op);
+    if (!li) continue;
+    li->in_padded = li->in_channels;
+    const Tensor& x = li->inputs[0];
+    if (!config.pad_linear_k || li->in_channels % 64 == 0 || li->in_channels < 256 || li->out_channels % 128 != 0) continue;
+    if (!x.owner_op || consumers[x.impl] != 1 || alias_of.count(x.impl) || !x.impl->pieces.empty()) continue;
+    if (x.owner_op->op_type != OP_DOT_INTERACTION && x.owner_op->op_type != OP_LINEAR) continue;
+    if (x.numDim != 2) continue;
+    li->in_padded = (li->in_channels + 63) / 64 * 64;
+    padded_ld[x.impl] = li->in_padded;
+  }
+  auto cols_of = [&](const Tensor& o) -> int64_t { auto it = padded_ld.find(o.impl); return it == padded_ld.end() ? (int64_t)o.adim[0] : it->second; };
   // sizes
   size_t act_bytes = 0;
   act_grad_bytes = 0;
@@ -1444,6 +1506,7 @@ void FFModel::allocate() {
     if (!x.owner_op || consumers[x.impl] != 1 || alias_of.count(x.impl) || alias_of.count(r->outputs[0].impl)) continue;
     if (exchange && x.owner_op->op_type == OP_EMBEDDING) continue;
     if (x.get_volume() != r->outputs[0].get_volume()) continue;
+    if (padded_ld.count(x.impl)) continue;          // padded rows are not one contiguous run
     r->is_view = true;
     views.push_back(r);
   }
@@ -1453,7 +1516,7 @@ void FFModel::allocate() {
     if (Reshape* r = dynamic_cast<Reshape*>(op)) if (r->is_view) continue;
     if (exchange && op->op_type == OP_EMBEDDING && !static_cast<Embedding*>(op)->row_sharded && !static_cast<Embedding*>(op)->replicated) continue;   // lives in xrecv / gsend
     const Tensor& o = op->outputs[0];
-    const size_t b = align_up((size_t)(o.rows() / world_size) * o.adim[0] * 4);
+    const size_t b = align_up((size_t)(o.rows() / world_size) * cols_of(o) * 4);
     act_bytes += b;
     act_grad_bytes += b;
     need.push_back(op);
@@ -1464,11 +1527,11 @@ void FFModel::allocate() {
   for (Op* op : need) {
     const Tensor& o = op->outputs[0];
     TensorImpl* im = o.impl;
-    const size_t raw = (size_t)(o.rows() / world_size) * o.adim[0] * 4;
+    const size_t raw = (size_t)(o.rows() / world_size) * cols_of(o) * 4;
     im->ptr = act_slab + off_a;
-    im->ld = o.adim[0];
+    im->ld = cols_of(o);
     im->grad = (float*)(act_grad_slab + off_a);
-    im->grad_ld = o.adim[0];
+    im->grad_ld = cols_of(o);
     im->bytes = raw;
     im->rows_local = o.rows() / world_size;
     im->alias = true;        // slab-owned: not freed individually
@@ -1644,9 +1707,15 @@ void FFModel::allocate() {
   }
 
   // ---- 5. parameters: one slab for every Linear tensor, tables on their own ---------------------
+  // (a Linear kernel whose input was padded in step 4a is [out][in_padded] here: pad columns zero, and kept zero by every optimizer --
+  //  their gradient is dy^T times the input's zero pad columns)
+  auto slab_elems = [&](const Parameter& p) -> size_t {
+    if (p.owner_op->op_type == OP_LINEAR && p.numDim == 2) return (size_t)p.adim[1] * (size_t)static_cast<const Linear*>(p.owner_op)->in_padded;
+    return p.get_volume();
+  };
   mlp_count = 0;
   for (Parameter& p : parameters)
-    if (in_dense_slab(p)) mlp_count += (p.get_volume() + 3) / 4 * 4;
+    if (in_dense_slab(p)) mlp_count += (slab_elems(p) + 3) / 4 * 4;
   mlp_weights = (float*)dmalloc(std::max<size_t>(mlp_count, 64) * 4);
   mlp_grads = (float*)dmalloc(std::max<size_t>(mlp_count, 64) * 4);
   check(api->ffh_zero(ctx, mlp_weights, std::max<size_t>(mlp_count, 64) * 4, stream), "zero");
@@ -1658,12 +1727,13 @@ void FFModel::allocate() {
     im->ld = p.adim[0];
     im->rows_local = (int64_t)(p.get_volume() / (size_t)p.adim[0]);
     if (in_dense_slab(p)) {
+      if (p.owner_op->op_type == OP_LINEAR && p.numDim == 2) im->ld = static_cast<const Linear*>(p.owner_op)->in_padded;
       im->ptr = mlp_weights + off_p;
       im->grad = mlp_grads + off_p;
       im->grad_ld = im->ld;
       im->alias = true;
-      im->bytes = p.get_volume() * 4;
-      off_p += (p.get_volume() + 3) / 4 * 4;
+      im->bytes = slab_elems(p) * 4;
+      off_p += (slab_elems(p) + 3) / 4 * 4;
     } else {
       Embedding* e = static_cast<Embedding*>(p.owner_op);
       if (!e->held_here(rank)) continue;   // sole owner (or one column / row block per rank): never replicated, never all-reduced
@@ -1864,18 +1934,20 @@ bool FFModel::early_sort_possible() const {
   return n > 0 && n <= FFH_MAX_TABLES;
 }
 
-// Big layers (the first top layer's weight gradient runs as a persistent one-workgroup-per-CU GEMM for hundreds of microseconds):
-// the table update's reduce launch is HBM-latency-bound and takes every register slot the persistent workgroups leave (3 waves per
-// SIMD on every CU) for ~200 us; the bottom MLP's backward -- a chain of small dependent GEMMs launched at the same moment on the
-// compute stream -- then gets a CU only when an update workgroup retires (its 0.27-GFLOP first kernel took 210 us at 4096 samples:
-// profiles/r04_*_timeline).  Issued behind that chain instead, the update still runs beside the same weight-gradient GEMM, and the
-// chain is out of the way when the GEMM ends.  Small models (Kaggle: the update is one 26-us launch that hides beside the bottom
-// MLP's backward) keep the early issue.  --update-behind-bottom-bwd / --no-update-behind-bottom-bwd force it.
-bool FFModel::update_behind_bottom_bwd() const {
-  if (config.update_behind_bottom_bwd >= 0) return config.update_behind_bottom_bwd != 0 && config.overlap_embedding && fused_embedding_update();
-  if (!config.overlap_embedding || !fused_embedding_update() || z_reader_layer < 0 || use_workers() || capturing_trace >= 0) return false;
-  const Linear* li = static_cast<const Linear*>(layers[z_reader_layer]);
-  return (double)li->in_channels * li->out_channels * (double)local_batch >= 2.0e9;
+// the layer whose weight gradient is issued last (-1: none): the Linear with the most multiply-adds, when its GEMMs are of the
+// persistent kind (>= 2e9 MACs) and the per-GPU batch is small (see FFModel::backward)
+int FFModel::defer_big_dw_layer() const {
+  if (config.defer_big_dw == 0 || !config.parallel_dw || config.profiling || use_workers() || config.deterministic) return -1;
+  int best = -1; double best_macs = 0.0;
+  for (size_t l = 0; l < layers.size(); l++) {
+    const Linear* li = layers[l]->op_type == OP_LINEAR ? static_cast<const Linear*>(layers[l]) : nullptr;
+    if (!li || li->discard_input_grad || li->activation == AC_MODE_SIGMOID || (li->activation == AC_MODE_RELU && !li->dy_premasked)) continue;
+    const double m = (double)li->in_channels * li->out_channels * (double)local_batch;
+    if (m > best_macs) { best_macs = m; best = (int)l; }
+  }
+  if (best < 0 || best == (int)layers.size() - 1 || best == grad_attach_layer) return -1;
+  if (config.defer_big_dw < 0 && (best_macs < 2.0e9 || local_batch > 8192)) return -1;      // auto
+  return best;
 }
 
 void FFModel::probe_record(int which, ffh_stream s, ffh_ctx* cx) const {
@@ -2218,6 +2290,15 @@ void FFModel::backward(int _seq_length) {
       z_free_recorded = true;
     }
   };
+  // --defer-big-dw: the biggest layer's weight-gradient GEMM (a persistent one-workgroup-per-CU launch of 200+ us that needs nothing
+  // the rest of the backward produces) is issued LAST.  Beside it every small kernel runs 5-10x slower than alone (measured: the
+  // bottom MLP's 0.27-GFLOP data gradient 80-210 us instead of 8, the table update 200 instead of 60 -- with or without wave /
+  // stream priorities, profiles/r04_*): the bottom MLP's backward chain and the table update, which both start when the layer's data
+  // gradient is done, then finish before the GEMM takes the chip instead of trailing it, and only the optimizer + bottom-MLP
+  // forward remain behind it.  Pays at small per-GPU batches (the 8-GPU job's 4096), costs at 32768 where the layer's two GEMMs
+  // overlap each other better than they run apart: on by batch size (defer_big_dw()).
+  const int defer_layer = defer_big_dw_layer();
+  Linear* deferred = nullptr;
   for (int l = first; l >= 0; l--) {
     if (l == grad_attach_layer) {
       check(api->ffh_event_record_with_next_linear_bwd(ctx, ev_grad_ready), "attach event");
@@ -2227,8 +2308,8 @@ void FFModel::backward(int _seq_length) {
     if (up && up->dx_map && !use_workers()) {
       const bool attach = l == scatter_attach_layer;
       check(api->ffh_linear_bwd_set_dx_scatter(ctx, up->dx_map, up->in_channels, attach ? ev_grad_ready : nullptr), "dx scatter");
-      up->backward(*this);
-      mark_z_free(l);
+      if (l == defer_layer) { up->backward_part(*this, 1); deferred = up; }
+      else { up->backward(*this); mark_z_free(l); }
       if (api->ffh_linear_dx_scatter_used(ctx)) {
         up->dx_map_concat->bwd_done = true;                    // its pack kernel is not needed this step
         if (attach) grad_ready_attached = true;
@@ -2250,16 +2331,16 @@ void FFModel::backward(int _seq_length) {
       if (prc != FFH_ERR_UNSUPPORTED) check(prc, up->name);
       up->pair_lower = nullptr;                                // not a shape the pair launch serves: the ordinary calls from now on
     }
+    if (l == defer_layer && up) { up->backward_part(*this, 1); deferred = up; continue; }
     layers[l]->backward(*this);
     mark_z_free(l);
   }
+  if (deferred) {
+    deferred->backward_part(*this, 2);
+    mark_z_free(deferred->layer_index);
+  }
   if (emb_update_pending) {
     // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
-    if (update_behind_bottom_bwd()) {
-      // ... or rather BEHIND its data-gradient chain (see update_behind_bottom_bwd()): "gradients ready" becomes "the bottom MLP's
-      // backward kernels on the compute stream are through", one more event on a stream that waits for the big dW anyway
-      check(api->ffh_event_record(ctx, ev_grad_ready, stream), "event");
-    }
     issue_embedding_update_on_side_stream();
     emb_update_pending = false;
   }
@@ -2274,7 +2355,8 @@ void FFModel::update() {
   if (!sgd && !adam) die("update(): unknown optimizer");
   // every rank must issue its collectives in the same order: the side thread's all-to-all (backward) first
   if (side_worker) side_worker->drain();
-  if (dw_forked && !dw_worker && !api->ffh_second_stream_used(ctx, 1)) dw_forked = false;   // the library kept everything on `stream`
+  if (dw_forked && !dw_worker && !api->ffh_second_stream_used(ctx, 1) && !dw_stream_used_directly) dw_forked = false;   // the library kept everything on `stream`
+  dw_stream_used_directly = false;
   if (dw_forked) {   // the weight-gradient GEMMs ran on their own stream: join before the gradients are consumed
     if (dw_worker) dw_worker->drain();
     check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");

@@ -281,23 +281,23 @@ def _weights(m):
 
 @pytest.mark.timeout(3000)
 def test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle(hip):
-    """THREE steps of the workload bench.py times at N = 1 (26 tables, emb_dim 128, bot 13-512-256-128, top 3456-1024-1024-512-256-1,
+    """FOUR steps (the driver's warm-up iteration + three) of the workload bench.py times at N = 1 (26 tables, emb_dim 128, bot 13-512-256-128, top 3456-1024-1024-512-256-1,
     batch 32768, eager launches on three streams, early sort: the next gather, the sort behind it and the update are all inside
     the window) on the HIP kernels against the same host code on the oracle, compared on the weight DELTAS: a weight is ~3e-2
     and one update ~1e-4, so round 3's rtol 2e-5 on the weights saw a gradient error only above ~0.5 % of the update.  Bound per
     element: 1e-5 of the update's term mass -- lr * sum over the steps of sum_b |dy[b][o]| |x[b][i]| for an MLP weight (taken as
-    3 x the last step's, computed in float64 from the oracle run's own activations and gradients), lr * sum_b |dy| for a bias, lr *
+    steps x the last step's, computed in float64 from the oracle run's own activations and gradients), lr * sum_b |dy| for a bias, lr *
     the summed |dZ| mass of the hits for a table row -- plus two ulps of the weight per step for the rounding of w itself.  Row
     counts capped at 100,000 (the oracle's tables must fit the host; full-size tables: the next test)."""
     rows = [min(r, 100000) for r in TERABYTE_ROWS]
-    steps, lr = 3, 0.01
+    steps, lr = 4, 0.01                        # the driver's warm-up iteration + three more
     runs = {}
     for name, backend in (("hip", HIP), ("cpu", H.oracle_backend())):
         app = ffmodel.DLRM(["--backend", backend] + TB_ARGS(rows))
-        app.warmup()
         m = app.model
-        w0 = _weights(m)
-        app.train_steps(steps, trace=False)
+        w0 = _weights(m)                      # before the driver's warm-up iteration (a full training step): the common starting point
+        app.warmup()
+        app.train_steps(steps - 1, trace=False)
         m.sync()
         rec = {"w0": w0, "w1": _weights(m), "pred": m.layer_output(m.num_layers - 1).get()}
         if name == "cpu":
@@ -413,3 +413,99 @@ def test_benched_step_overlapped_equals_serial_bit_for_bit_under_deterministic(h
     assert runs[0].keys() == runs[1].keys() and len(runs[0]) > 30
     for k in runs[0]:
         assert runs[0][k].tobytes() == runs[1][k].tobytes(), f"{k}: overlapped and serial runs differ under --deterministic"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the per-rank batch of the 8-GPU job (4096 samples) and the MLPerf batch (8192): stream-K with fix-up (linear_sk.hip SPLIT)
+# ---------------------------------------------------------------------------------------------------------------------
+def _close(got, exp, mass, what, tol=1e-5):
+    err = np.abs(got.astype(np.float64) - exp.astype(np.float64))
+    bad = err > tol * mass + 1e-6
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} beyond {tol} of the term mass, worst {err.max():.3e} (mass there {mass.flat[err.argmax()]:.3e})"
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("B,IN,OUT,expect", [
+    (4096, 3456, 1024, {"dx": "streamk"}),        # 864 data-gradient tiles on 256 workgroups: 3.4 rounds
+    (4096, 1024, 512, {"fwd": "streamk"}),        # 128 forward tiles: half a round
+    (4096, 1024, 1024, {}),                       # 256 tiles: whole tiles, one per workgroup
+    (8192, 512, 256, {"fwd": "streamk"}),         # MLPerf batch: 128 tiles of 8 k-tiles
+    (2560, 1024, 768, {"fwd": "streamk", "dx": "streamk"}),   # 120 / 160 tiles: ranges that end mid-tile everywhere, a short last range
+])
+def test_linear_layers_at_the_per_rank_batch_vs_oracle_with_routes(hip, oracle, B, IN, OUT, expect):
+    """Forward, plain backward and the model's backward form (premasked dy, relu'-by-x mask, stored dX, forked dW) of the layers of
+    the 4096-sample step against the oracle at 1e-5 of the term mass, with the route each call took: the uneven tile counts must
+    run as stream-K with fix-up ("streamk" in the route token), and twice in a row (the second launch finds the first one's flags:
+    the epoch must tell them apart)."""
+    act = capi.AC_MODE_RELU
+    rng = np.random.default_rng(IN + OUT + B)
+    x = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    gy = (rng.uniform(-1, 1, (B, OUT)) / B).astype(np.float32)
+    xd, wd, bd = (torch.from_numpy(a).to(DEV) for a in (x, w, b))
+    ax, aw = np.abs(x).astype(np.float64), np.abs(w).astype(np.float64)
+    routes = {}
+    y_e = oracle.linear_fwd(x, w, b, act)
+    for rep in range(2):
+        y = torch.full((B, OUT), 3.0, device=DEV)
+        hip.call("ffh_linear_fwd", xd, IN, y, OUT, wd, bd, IN, OUT, B, act, None)
+        routes["fwd"] = _route(hip)
+        _close(y.cpu().numpy(), y_e, ax @ aw.T + np.abs(b), f"{IN}->{OUT} y (launch {rep})")
+    yd = torch.from_numpy(y_e).to(DEV)
+    dx_e, dw_e, db_e, dy_e = oracle.linear_bwd(x, y_e, gy, w, act)
+    a = np.abs(dy_e).astype(np.float64)
+    m_dw, m_db, m_dx = a.T @ ax, a.sum(0), a @ aw
+    flags = capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DX_MASK_BY_X | capi.LINEAR_DY_PREMASKED
+    dx_e2, dw_e2, db_e2, _ = oracle.linear_bwd_ex(x, y_e, dy_e, w, act, flags, dx0=None)
+    s2 = torch.cuda.Stream()
+    for rep in range(2):
+        dy2 = torch.from_numpy(dy_e).to(DEV)
+        dx2 = torch.full((B, IN), 9.0, device=DEV); dw2 = torch.zeros(OUT, IN, device=DEV); db2 = torch.zeros(OUT, device=DEV)
+        hip.call("ffh_linear_bwd_ex", xd, IN, dx2, IN, yd, OUT, dy2, OUT, wd, dw2, db2, IN, OUT, B, act, flags, None, s2.cuda_stream)
+        routes["bwd_ex"] = _route(hip)
+        torch.cuda.synchronize()
+        _close(dw2.cpu().numpy(), dw_e2, m_dw, f"{IN}->{OUT} dw (model form, launch {rep})")
+        _close(db2.cpu().numpy(), db_e2, m_db, f"{IN}->{OUT} db (model form)")
+        _close(dx2.cpu().numpy(), dx_e2, m_dx, f"{IN}->{OUT} dx (model form, launch {rep})")
+    dy = torch.from_numpy(gy).to(DEV)
+    dx = torch.zeros(B, IN, device=DEV); dw = torch.zeros(OUT, IN, device=DEV); db = torch.zeros(OUT, device=DEV)
+    hip.call("ffh_linear_bwd", xd, IN, dx, IN, yd, OUT, dy, OUT, wd, dw, db, IN, OUT, B, act, None)
+    routes["bwd"] = _route(hip)
+    torch.cuda.synchronize()
+    _close(dw.cpu().numpy(), dw_e, m_dw, f"{IN}->{OUT} dw (plain)")
+    _close(dx.cpu().numpy(), dx_e, m_dx, f"{IN}->{OUT} dx (plain)")
+    print(f"routes {IN}->{OUT} @{B}:", routes)
+    tok = lambda r, which: [t for t in r.split(";") if which in t.split("|")[0]]
+    if "fwd" in expect:
+        assert "streamk" in routes["fwd"] and "|sk_128x128x64" in routes["fwd"], routes
+    else:
+        assert "streamk" not in routes["fwd"], routes
+    dx_tok = tok(routes["bwd_ex"], "dx")
+    assert len(dx_tok) == 1
+    assert ("streamk" in dx_tok[0]) == ("dx" in expect), routes
+
+
+@pytest.mark.timeout(1200)
+def test_mlperf_first_top_layer_padded_to_512_hip_vs_unpadded_oracle(hip):
+    """the 479-wide layer behind the dot interaction.  The shim pads the interaction output and the kernel to 512
+    columns of zeros (FFModel::allocate step 4a) so that the persistent GEMMs take the layer; two steps of an MLPerf-shaped model
+    (26 tables, emb_dim 128, bot 13-512-256-128, top 479-1024-1024-512-256-1, 4096 samples) on the HIP kernels with the padding
+    against the oracle backend WITHOUT it, parameters in the reference-visible shapes."""
+    args = ["-b", "4096", "--arch-sparse-feature-size", "128", "--arch-embedding-size", "-".join(["1000"] * 26), "--arch-mlp-bot", "13-512-256-128",
+            "--arch-mlp-top", "479-1024-1024-512-256-1", "--arch-interaction-op", "dot-tril", "--data-size", "4096"]
+    outs = []
+    for backend, flags in ((HIP, []), (H.oracle_backend(), ["--no-pad-linear-k"])):
+        app = ffmodel.DLRM(["--backend", backend] + args + flags)
+        app.warmup(); app.train_steps(2, trace=False); app.model.sync()
+        m = app.model
+        rec = {f"{m.layer_name(l)}/{i}": m.parameter(l, i).get_weights() for l in range(m.num_layers) for i in range(m.layer_num_weights(l))}
+        rec["pred"] = m.layer_output(m.num_layers - 1).get()
+        inter = [l for l in range(m.num_layers) if m.layer_name(l).startswith("DotInteraction")][0]
+        rec["ld"] = np.array(m.layer_output(inter).ld)
+        outs.append(rec)
+        app.close()
+    assert int(outs[0]["ld"]) == 512 and int(outs[1]["ld"]) == 479
+    for k in outs[0]:
+        if k != "ld":
+            np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=2e-5, atol=2e-6, err_msg=k)

@@ -185,3 +185,52 @@ def test_multi_rank_any_optimizer_any_placement_equals_one_rank(tmp_path, world,
     assert sorted(seen) == list(range(len(rows)))
     if place == "table":
         assert all(len(v) == 1 for v in seen.values())    # sole owner: nothing replicated, nothing all-reduced
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reduction depths that are not a multiple of 64 (MLPerf's 479-wide first top layer): padded operands, same values
+# ---------------------------------------------------------------------------------------------------------------------
+MLPERF_SMALL = ["-b", "64", "--arch-sparse-feature-size", "128", "--arch-embedding-size", "-".join(["100"] * 26), "--arch-mlp-bot", "13-64-128",
+                "--arch-mlp-top", "479-1024-64-1", "--arch-interaction-op", "dot-tril", "--data-size", "64"]
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_padded_reduction_depth_is_invisible(opt):
+    """FFModel::allocate step 4a gives the dot interaction's 479-column output (and its gradient) a leading dimension of 512 and
+    stores the 1024 x 479 kernel as 1024 x 512, pad columns zero, so that the persistent GEMMs serve the layer.  The pads add exact
+    zeros at the end of every k sum: three steps must leave the SAME BITS as --no-pad-linear-k in every parameter (returned in
+    the reference-visible [out][in] shape) and in the predictions -- under SGD and under Adam (whose moments of the pads stay 0)."""
+    from dlrm_flexflow_amd import ffmodel
+    outs = []
+    for flags in ([], ["--no-pad-linear-k"]):
+        app = ffmodel.DLRM(["--backend", H.oracle_backend(), "--optimizer", opt] + MLPERF_SMALL + flags)
+        app.warmup(); app.train_steps(3, trace=False); app.model.sync()
+        m = app.model
+        rec = {f"{m.layer_name(l)}/{i}": m.parameter(l, i).get_weights() for l in range(m.num_layers) for i in range(m.layer_num_weights(l))}
+        rec["pred"] = m.layer_output(m.num_layers - 1).get()
+        inter = [l for l in range(m.num_layers) if m.layer_name(l).startswith("DotInteraction")][0]
+        rec["interaction"] = m.layer_output(inter).get()
+        rec["interaction_grad"] = m.layer_output(inter).get_grad()
+        rec["ld"] = np.array(m.layer_output(inter).ld)
+        outs.append(rec)
+        app.close()
+    assert int(outs[0]["ld"]) == 512 and int(outs[1]["ld"]) == 479
+    first_top = [k for k in outs[0] if k.endswith("/0") and outs[0][k].shape == (1024, 479)]
+    assert len(first_top) == 1
+    for k in outs[0]:
+        if k != "ld":
+            assert outs[0][k].shape == outs[1][k].shape and outs[0][k].tobytes() == outs[1][k].tobytes(), k
+
+
+def test_deferred_big_weight_gradient_is_only_a_schedule():
+    """--defer-big-dw (the biggest layer's weight-gradient GEMM issued after the rest of the backward; default by per-GPU batch):
+    same arithmetic, another launch order -- on the sequential oracle backend the three-step trajectory keeps its bits, also
+    behind the exchange (one gloo-less rank, --force-exchange is covered by the GPU twin)."""
+    outs = []
+    for flags in (["--no-defer-big-dw"], ["--defer-big-dw"]):
+        m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=True, extra_argv=flags)
+        outs.append(H.run_steps(m, h, 3))
+        m.close()
+    for step in range(3):
+        for k in outs[0][step]:
+            assert outs[0][step][k].tobytes() == outs[1][step][k].tobytes(), (step, k)
