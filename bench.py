@@ -496,8 +496,8 @@ def main():
     # hipGraph replay (the reference's Legion trace) vs eager launches: keep whichever is faster on this box
     step_us = {}
     solo = world == 1 and not args.force_exchange
-    if not solo:
-        trace = False                              # collectives are host callbacks: not captured
+    if not solo and not ("--capture-exchange" in args.shim_flags.split() and collectives.startswith("RCCL called")):
+        trace = False                              # collectives served by host callbacks are not capturable; RcclComm's are, behind --capture-exchange
     if trace:
         # best of two short measurements each: one hiccup in either must not pick the slower mode for the whole timed region
         n_probe = 30 if w["B"] <= 4096 else 5

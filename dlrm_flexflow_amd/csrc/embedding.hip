@@ -1027,7 +1027,7 @@ int ffh_embedding_fwd_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int
   const int64_t rows_per_block = 4LL * rpw * U;
   // fill 256 CUs x 8 workgroups across all tables, grid-stride the rest
   int64_t gx = (batch + rows_per_block - 1) / rows_per_block;
-  static const int cap_env = getenv("FFH_EMB_FWD_CAP") ? atoi(getenv("FFH_EMB_FWD_CAP")) : 1024;   // A/B switch: workgroups over all tables
+  static const int cap_env = FFH_LAB_INT("FFH_EMB_FWD_CAP", 1024);   // A/B switch: workgroups over all tables
   const int64_t cap = cap_env / nt > 0 ? cap_env / nt : 1;
   if (gx > cap) gx = cap;
   dim3 grid((unsigned)gx, (unsigned)nt);

@@ -77,6 +77,20 @@ static inline int ffh_fail_hip(ffh_ctx* c, hipError_t e, const char* what) {
 
 static inline hipStream_t as_stream(ffh_stream s) { return (hipStream_t)s; }
 
+// A/B switches of the development builds.  The release library reads NO environment variable ("no global state" behind the
+// C-ABI): every switch below is its default, a compile-time constant.  tools/build_variant.sh <out.so> -DFFH_LAB builds a lab library
+// whose switches come from the environment (tools/ab.sh, tools/gemm_tune.py, tools/gemm_big.py: FFH_TOOLS_LIB=<out.so>).
+#ifdef FFH_LAB
+#include <stdlib.h>
+#define FFH_LAB_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define FFH_LAB_I64(name, dflt) (getenv(name) ? atoll(getenv(name)) : (dflt))
+#define FFH_LAB_F64(name, dflt) (getenv(name) ? atof(getenv(name)) : (dflt))
+#else
+#define FFH_LAB_INT(name, dflt) (dflt)
+#define FFH_LAB_I64(name, dflt) (dflt)
+#define FFH_LAB_F64(name, dflt) (dflt)
+#endif
+
 // the bf16 twin of the fp32 element at p when [p, p + span_bytes) lies inside a registered region and the tensor-op mode is on
 static inline unsigned short* ffh_mirror_of(const ffh_ctx* c, const void* p, size_t span_bytes) {
   if (!c || !p || c->math_mode != FFH_MATH_TENSOR_OP_BF16) return nullptr;

@@ -285,7 +285,7 @@ int ffh_dot_interaction_fwd(ffh_ctx* c, const float* z, int64_t ldz, float* out,
   const bool v4 = d % 4 == 0 && ldz % 4 == 0 && aligned16(z);
   const bool o4 = v4 && ldo % 4 == 0 && aligned16(out);
   const unsigned grid = ffh_grid(batch, 4, 4096);
-  static const bool no_lds = getenv("FFH_DOT_NO_LDS") && atoi(getenv("FFH_DOT_NO_LDS"));      // A/B switch
+  static const bool no_lds = FFH_LAB_INT("FFH_DOT_NO_LDS", 0) != 0;      // A/B switch
   if (v4 && d == kDotD && !no_lds) {
     // one 4-wave workgroup per CU (128 KB of LDS), every wave walks its samples with the next one streaming in
     static const bool ok4 = hipFuncSetAttribute((const void*)dot_interaction_fwd_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kDotLds) == hipSuccess;

@@ -642,15 +642,15 @@ struct GldsPlan { int bm; dim3 grid; int lds_bytes; };
 // Fills the plan (tile height, grid, split-K) if the LDS-DMA kernel should take this GEMM.
 template <bool AKR, bool BKR>
 bool plan_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, GldsPlan& p, double min_work = 1.5e8, int min_k = 128) {
-  static const int off = getenv("FFH_GEMM_NO_GLDS") ? atoi(getenv("FFH_GEMM_NO_GLDS")) : 0;   // A/B switch (tools/ab.sh)
+  static const int off = FFH_LAB_INT("FFH_GEMM_NO_GLDS", 0);   // A/B switch (tools/ab.sh)
   if (off || !c->zeros) return false;
   if (c->deterministic && atomic_splitk) return false;
   // weight-gradient GEMMs of the big-batch steps: above ~1e9 MACs the register-staged 128 x 128 split-K kernel wins (whole
   // Terabyte-shape step, interleaved A/B on one box: 1.27 vs 1.36 ms at 4096 samples, 2.48 vs 2.59 at 8192, 4.62 vs 4.78 at
   // 16384) -- except at 32768 samples, where this kernel's 16-wave workgroups share the chip better with the dX GEMM running
   // beside them on the other stream (9.11 vs 9.24-9.31 ms), so there it stays
-  static const double dw_max = getenv("FFH_GLDS_DW_MAX") ? atof(getenv("FFH_GLDS_DW_MAX")) : 1.0e9;   // A/B switches
-  static const int dw_kmax = getenv("FFH_GLDS_DW_KMAX") ? atoi(getenv("FFH_GLDS_DW_KMAX")) : 16384;
+  static const double dw_max = FFH_LAB_F64("FFH_GLDS_DW_MAX", 1.0e9);   // A/B switches
+  static const int dw_kmax = FFH_LAB_INT("FFH_GLDS_DW_KMAX", 16384);
   if (atomic_splitk && (double)g.M * g.N * g.K >= dw_max && g.K <= dw_kmax) return false;
   if (!glds_aligned(g.A, g.lda) || !glds_aligned(g.B, g.ldb)) return false;
   // whole 16-byte chunks only: the contiguous extent of each operand must be a multiple of 4 floats
@@ -712,7 +712,7 @@ int launch_glds(ffh_ctx* c, GldsArgs& g, bool atomic_splitk, ffh_stream s, const
 
 // dX and dW of one layer in ONE launch (gemm_glds_bwd_kernel); 1 = done, 0 = not applicable
 int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
-  static const int off = getenv("FFH_GLDS_NO_DUAL") ? atoi(getenv("FFH_GLDS_NO_DUAL")) : 0;   // A/B switch (tools/ab.sh)
+  static const int off = FFH_LAB_INT("FFH_GLDS_NO_DUAL", 0);   // A/B switch (tools/ab.sh)
   if (off || c->deterministic) return 0;
   GldsPlan px, pw;
   // (the 256x64 layer was tried as a pair too: no gain, so the work threshold of the single GEMMs stands; k >= 64 suffices)
@@ -736,7 +736,7 @@ int launch_glds_bwd(ffh_ctx* c, GldsArgs& dxg, GldsArgs& dwg, ffh_stream s) {
   hipEvent_t ev_after = nullptr;
   if (ev && cap != hipStreamCaptureStatusNone) { ev_after = ev; ev = nullptr; }
   // more workgroups than CUs: two stages (65 KB) so that two workgroups share a CU
-  static const int forced_stages = getenv("FFH_GLDS_BWD_STAGES") ? atoi(getenv("FFH_GLDS_BWD_STAGES")) : 0;   // A/B switch (tools/ab.sh)
+  static const int forced_stages = FFH_LAB_INT("FFH_GLDS_BWD_STAGES", 0);   // A/B switch (tools/ab.sh)
   const bool two = forced_stages ? forced_stages == 2 : (na8 + nb) > (unsigned)c->num_cus;
   const int lds2 = 2 * 128 * 256 + 1024;
 #define FFH_DUAL(BMV, NS, LDSV)                                                                                                   \
@@ -922,7 +922,7 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   } else if (tiles128 >= 2 * c->num_cus && g.M >= 128 && g.N >= 128) cfg = 0;
   else if (tiles64 >= 2 * c->num_cus || g.K < 64) cfg = 1;
   else cfg = 2;
-  static const int forced = getenv("FFH_GEMM_CFG") ? atoi(getenv("FFH_GEMM_CFG")) : -1;   // A/B switch (tools/gemm_tune.py)
+  static const int forced = FFH_LAB_INT("FFH_GEMM_CFG", -1);   // A/B switch (tools/gemm_tune.py)
   if (forced >= 0 && forced <= 5 && (forced <= 2 || cfg == 0)) cfg = forced;
   if (CMAP) cfg = (cfg == 0 || cfg == 3 || cfg == 4 || cfg == 5) ? 0 : 1;     // the column-map epilogue exists for the two plain tile shapes
   const int BMv = cfg == 3 ? 256 : (cfg == 5 ? 128 : (cfg == 0 || cfg == 4 ? 128 : (cfg == 1 ? 64 : 32)));
@@ -952,7 +952,7 @@ int launch_gemm(ffh_ctx* c, GemmArgs& g, int64_t batch, ffh_stream s, const char
   g.tnx = g.tny = g.tnz = 0;
   {
     // persistent form (see gemm_f32_kernel): launches of more tiles than the chip holds at once
-    static const int persist = getenv("FFH_GEMM_PERSIST") ? atoi(getenv("FFH_GEMM_PERSIST")) : 0;   // A/B switch: resident workgroups per CU, 0 = off
+    static const int persist = FFH_LAB_INT("FFH_GEMM_PERSIST", 0);   // A/B switch: resident workgroups per CU, 0 = off
     const int64_t total = (int64_t)gx * gy * gz;
     if (persist > 0 && total > (int64_t)persist * c->num_cus && total < (1LL << 31)) {
       g.tnx = (unsigned)gx; g.tny = (unsigned)gy; g.tnz = (unsigned)gz;
@@ -1528,10 +1528,10 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
     ffh_route_add(c, "linear_fwd|skinny");
     return FFH_OK;
   }
-  static const int no_thin = getenv("FFH_NO_THIN") ? atoi(getenv("FFH_NO_THIN")) : 0;   // A/B switch (tools/ab.sh)
+  static const int no_thin = FFH_LAB_INT("FFH_NO_THIN", 0);   // A/B switch (tools/ab.sh)
   // (rows kernel from 8192 samples up: it keeps 128 rows per workgroup to amortise its weight registers, so a 2048-sample launch
   //  would be 32 workgroups -- the MFMA form below is the faster one there: Kaggle step 208 vs 185 us)
-  static const int thin_rows_min = getenv("FFH_THIN_ROWS_MIN_BATCH") ? atoi(getenv("FFH_THIN_ROWS_MIN_BATCH")) : 8192;   // A/B switch
+  static const int thin_rows_min = FFH_LAB_INT("FFH_THIN_ROWS_MIN_BATCH", 8192);   // A/B switch
   if (!no_thin && in <= 16 && out >= 64 && out % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)y | (uintptr_t)(bias ? bias : w)) & 15) == 0 && batch >= thin_rows_min) {
     hipLaunchKernelGGL(linear_thin_fwd_rows_kernel, dim3((unsigned)((batch + kThinRowsPerWg - 1) / kThinRowsPerWg), (unsigned)((out + 255) / 256)), dim3(256), 0,
                        as_stream(s), x, ldx, y, ldy, w, bias, in, out, batch, act);
@@ -1609,7 +1609,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
   const bool do_dw = !(flags & FFH_LINEAR_ONLY_DX);
   const bool do_dx = !(flags & FFH_LINEAR_ONLY_DW);
   FFH_REQUIRE(c, do_dw || do_dx, "linear_bwd_ex: ONLY_DX and ONLY_DW are exclusive");
-  static const int no_skinny = getenv("FFH_NO_SKINNY") ? atoi(getenv("FFH_NO_SKINNY")) : 0;   // A/B switch (tools/ab.sh)
+  static const int no_skinny = FFH_LAB_INT("FFH_NO_SKINNY", 0);   // A/B switch (tools/ab.sh)
   const bool skinny_vec = !no_skinny && (in % 4 == 0) && glds_aligned(x, ldx) && (((uintptr_t)w & 15) == 0) && (!dx || glds_aligned(dx, lddx));
   // up to 4 outputs with in <= 1024, or up to 16 outputs with in <= 256 (the 64 -> 16 layer in front of the interaction):
   // whole backward in one launch
@@ -1634,7 +1634,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     }
     // dW / db are accumulated with one atomic per weight per workgroup: adds to ONE address serialise (~0.1 us each), so
     // the number of workgroups is kept near 32 -- and every wave then keeps 16 / NC rows in flight to cover the latency
-    static const int nblk_env = getenv("FFH_SKINNY_NBLK") ? atoi(getenv("FFH_SKINNY_NBLK")) : 0;   // A/B switch
+    static const int nblk_env = FFH_LAB_INT("FFH_SKINNY_NBLK", 0);   // A/B switch
     // large batches: HBM traffic outweighs the longer atomic chains -- at 32768 samples the x / dX traffic (67 MB for the 256 -> 1
     // layer) needs every CU's load queue, and the 256 per-workgroup atomics per weight are ~3 us spread over the launch
     const int64_t nblk = nblk_env > 0 ? nblk_env : (batch >= 16384 ? 256 : (batch >= 8192 ? 64 : 32));

@@ -511,16 +511,16 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
   // 256 x 256 tiles (one 8-wave workgroup per CU, 128 x 64 per wave) where the output still fills the chip with them: half
   // the operand traffic per flop.  Measured at batch 32768: forward 3456 -> 1024 492 -> 353 us, 1024 -> 1024 162 -> 143;
   // dX +3...6 % from a reduction depth of 1024 up, slower below; the split-K weight-gradient form: see below.
-  static const int tile_env = getenv("FFH_BF16_TILE") ? atoi(getenv("FFH_BF16_TILE")) : 0;
+  static const int tile_env = FFH_LAB_INT("FFH_BF16_TILE", 0);
   const int64_t tiles_big = (int64_t)((g.N + 255) / 256) * ((g.M + 255) / 256);
   const bool big_form = (AKC && BKC) || (AKC && !BKC && g.K >= 1024);
   // the split mode takes the same tile (96 KB: three planes per operand): forward / dX +4 %, the weight gradient of the big
   // layer 1,676 -> 1,241 us; whole split-mode step 6.9 -> 6.6-6.8 ms (FFH_X3_BIG: 0 never, 1 not for the weight gradient)
-  static const int x3_big = getenv("FFH_X3_BIG") ? atoi(getenv("FFH_X3_BIG")) : 2;             // A/B switch
+  static const int x3_big = FFH_LAB_INT("FFH_X3_BIG", 2);             // A/B switch
   bool big = (!x3 || x3_big) && big_form && g.M >= 256 && g.N >= 256 && tiles_big >= c->num_cus;
   // the split-K weight-gradient form: big tiles where there are enough of them that a split can fill whole rounds of one
   // workgroup per CU (3456 x 1024 at batch 32768: 56 tiles x 9 splits = 504; 747 -> 553 us); 16 tiles (1024 x 1024) lose 8 %
-  static const int dw_big = getenv("FFH_BF16_DW_BIG") ? atoi(getenv("FFH_BF16_DW_BIG")) : 1;     // A/B switch
+  static const int dw_big = FFH_LAB_INT("FFH_BF16_DW_BIG", 1);     // A/B switch
   if (dw_big && (!x3 || x3_big > 1) && !AKC && !BKC && g.epi == EPI_ATOMIC && !c->deterministic && tiles_big >= 32 && g.K >= 8192) big = true;
   if (tile_env == 128) big = false;
   if (tile_env == 256 && g.M >= 256 && g.N >= 256) big = true;
@@ -536,7 +536,7 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     const int max_split = (g.K + 4 * kBfBK - 1) / (4 * kBfBK);     // at least four k-tiles per workgroup
     // (for the 128 x 128 tile the same search makes a weight-gradient GEMM up to 30 % faster ALONE and the step no faster:
     //  in the step the holes of an unbalanced launch are filled by the data-gradient GEMM on the other stream -- off by default)
-    static const int fill_small = getenv("FFH_BF16_FILL") ? atoi(getenv("FFH_BF16_FILL")) : 0;    // A/B switch
+    static const int fill_small = FFH_LAB_INT("FFH_BF16_FILL", 0);    // A/B switch
     if (big || fill_small) {
       // pick the split whose workgroup count fills whole rounds of resident workgroups best (one per CU for the big tile, two for 128 x 128)
       const int64_t slots = (big ? 1LL : 2LL) * c->num_cus;
@@ -585,7 +585,7 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     const int64_t lda = akc ? g.sAm : g.sAk, ldb = bkc ? g.sBn : g.sBk;
     const size_t a_span = (size_t)(((akc ? g.M : g.K) - 1) * lda + (akc ? g.K : g.M)) * 4, b_span = (size_t)(((bkc ? g.N : g.K) - 1) * ldb + (bkc ? g.K : g.N)) * 4;
     if (g.epi != EPI_ATOMIC) g.C16 = ffh_mirror_of(c, g.C, (size_t)((int64_t)(g.M - 1) * g.ldc + g.N) * 4);
-    static const int no_src16 = getenv("FFH_BF16_NO_TWINS") ? atoi(getenv("FFH_BF16_NO_TWINS")) : 0;      // A/B switch
+    static const int no_src16 = FFH_LAB_INT("FFH_BF16_NO_TWINS", 0);      // A/B switch
     if (!MASK_A && !no_src16 && !g.a_not_twinned && g.M % 8 == 0 && g.N % 8 == 0 && g.M >= 8 && g.N >= 8 && g.K % kBfBK == 0 && g.k_per_split % kBfBK == 0 && lda % 8 == 0 && ldb % 8 == 0) {
       const unsigned short* a16 = ffh_mirror_of(c, g.A, a_span);
       const unsigned short* b16 = ffh_mirror_of(c, g.B, b_span);

@@ -378,7 +378,7 @@ namespace ffh_gemm {
 
 // 1: launched; 0: not this kernel's problem (nothing launched); < 0: error.  g.A16 / g.B16 (and g.C16) are set by the caller.
 int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name) {
-  static const int off = getenv("FFH_BF16_NO_DMA") ? atoi(getenv("FFH_BF16_NO_DMA")) : 0;     // A/B switch (tools/ab.sh)
+  static const int off = FFH_LAB_INT("FFH_BF16_NO_DMA", 0);     // A/B switch (tools/ab.sh)
   if (off || !g.A16 || !g.B16) return 0;
   if (form != BF16_FORM_FWD && form != BF16_FORM_DX && form != BF16_FORM_DW) return 0;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % DM_BK || g.N % 8) return 0;
@@ -403,7 +403,7 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
     // the split with the least estimated time: rounds of one workgroup per CU x k-tiles per slice (~1 us each at the main
     // loop's rate) + the slices' atomic traffic at the memory-side adders' ~1.3 TB/s (every slice adds a whole tile).  At batch
     // 32768: 3456 x 1024 -> 4 slices (224 workgroups, one round), 1024 x 1024 -> 16, 1024 x 512 -> 16
-    static const int split_env = getenv("FFH_BF16_DMA_SPLIT") ? atoi(getenv("FFH_BF16_DMA_SPLIT")) : 0;     // A/B switch
+    static const int split_env = FFH_LAB_INT("FFH_BF16_DMA_SPLIT", 0);     // A/B switch
     const double tile_bytes = (double)DM_BM * DM_BN * 4;
     double best = 1e30;
     for (int sp = 1; sp <= 64 && sp * 4 <= nk; sp++) {
@@ -425,7 +425,7 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
   a.A = g.A16; a.B = g.B16; a.C = g.C; a.C16 = form == BF16_FORM_DW ? nullptr : g.C16;
   a.bias = form == BF16_FORM_FWD ? g.bias : nullptr; a.mask = form == BF16_FORM_DX ? g.mask : nullptr;
   a.Af32 = g.A; a.db = form == BF16_FORM_DW ? g.db : nullptr;
-  static const int mask_fp32 = getenv("FFH_BF16_MASK_FP32") ? atoi(getenv("FFH_BF16_MASK_FP32")) : 0;      // A/B switch
+  static const int mask_fp32 = FFH_LAB_INT("FFH_BF16_MASK_FP32", 0);      // A/B switch
   a.mask16 = (a.mask && !mask_fp32) ? ffh_mirror_of(c, g.mask, (size_t)((int64_t)(g.M - 1) * g.ldmask + g.N) * 4) : nullptr;
   if (a.mask16 && ((uintptr_t)a.mask16 & 7)) a.mask16 = nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = g.ldc; a.ldmask = g.ldmask;

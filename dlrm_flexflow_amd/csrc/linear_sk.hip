@@ -417,7 +417,7 @@ namespace ffh_gemm {
 namespace {
 struct SkPlan { int64_t lda, ldb, a_bytes, b_bytes; int G; bool split; };
 bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
-  static const int off = getenv("FFH_GEMM_NO_SK") ? atoi(getenv("FFH_GEMM_NO_SK")) : 0;   // A/B switch (tools/ab.sh)
+  static const int off = FFH_LAB_INT("FFH_GEMM_NO_SK", 0);   // A/B switch (tools/ab.sh)
   if (off) return false;
   {
     // The backward GEMMs of a layer with fewer than 256 x 256 weights stay with the register-staged kernels: their workgroups
@@ -426,8 +426,8 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
     // gradient holds a workgroup on every CU: as a persistent kernel it waited ~1.7 ms for CUs and the rest of the bottom MLP's
     // backward behind it (Terabyte step 8.07-8.10 -> 8.01-8.03 ms; at 140 K the two 512 x 256 layers move too: 8.13-8.15).
     // FFH_SK_MIN_WEIGHTS / _BWD: A/B switches (all forms / the two backward forms).
-    static const int64_t min_w = getenv("FFH_SK_MIN_WEIGHTS") ? atoll(getenv("FFH_SK_MIN_WEIGHTS")) : 0;
-    static const int64_t min_wb = getenv("FFH_SK_MIN_WEIGHTS_BWD") ? atoll(getenv("FFH_SK_MIN_WEIGHTS_BWD")) : 65536;
+    static const int64_t min_w = FFH_LAB_I64("FFH_SK_MIN_WEIGHTS", 0);
+    static const int64_t min_wb = FFH_LAB_I64("FFH_SK_MIN_WEIGHTS_BWD", 65536);
     const int64_t nw = form == SK_FORM_DW ? (int64_t)g.M * g.N : (int64_t)g.N * g.K;
     if (nw < min_w || (form != SK_FORM_FWD && nw < min_wb)) return false;
   }
@@ -454,7 +454,7 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
     if (g.epi != EPI_STORE && g.epi != EPI_ADD) return false;
     // whole tiles when they fill whole rounds of workgroups (or nearly: a split costs a partial tile's round trip through memory);
     // otherwise stream-K with the fix-up of the kernel's SPLIT form when every workgroup still gets >= 4 k-tiles
-    static const int no_split = getenv("FFH_SK_NO_SPLIT") ? atoi(getenv("FFH_SK_NO_SPLIT")) : 0;     // A/B switch (tools/ab.sh)
+    static const int no_split = FFH_LAB_INT("FFH_SK_NO_SPLIT", 0);     // A/B switch (tools/ab.sh)
     const int64_t rounds = (ntiles + p.G - 1) / p.G;
     const int64_t idle_it = (rounds * p.G - ntiles) * nk / p.G;      // k-tile iterations per workgroup the last round wastes
     p.split = !no_split && !c->deterministic && idle_it >= 2 && ntiles * nk >= 4LL * p.G && g.epi == EPI_STORE;

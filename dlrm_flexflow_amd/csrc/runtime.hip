@@ -151,6 +151,7 @@ int ffh_stream_create(ffh_ctx* c, ffh_stream* s) {
   if (!s) return FFH_ERR_BAD_ARG;
   hipStream_t st;
   // A/B switch (tools/ab.sh): FFH_STREAM_PRIOS="p0,p1,p2" gives the n-th stream this process creates HIP priority pn
+#ifdef FFH_LAB
   static int created = 0;
   const char* pr = getenv("FFH_STREAM_PRIOS");
   if (pr) {
@@ -161,6 +162,7 @@ int ffh_stream_create(ffh_ctx* c, ffh_stream* s) {
     *s = (ffh_stream)st;
     return FFH_OK;
   }
+#endif
   FFH_HIP_TRY(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   *s = (ffh_stream)st;
   return FFH_OK;

@@ -6,8 +6,13 @@
 #include <map>
 #include <mutex>
 
+// FFH_BACKEND_LIB points the driver at another library exporting include/ff_hip.h (the CPU oracle in tests, an A/B build).  It is
+// the one environment variable this layer reads, so it is never silent: load_kernel_api() says on stderr which library an
+// override selected, and the driver names the kernel library on its THROUGHPUT line whenever it is not the product's own
+// (KernelApi::overridden).
+static bool g_env_override = false;
 std::string default_backend_path() {
-  if (const char* e = getenv("FFH_BACKEND_LIB")) return std::string(e);
+  if (const char* e = getenv("FFH_BACKEND_LIB")) { g_env_override = true; return std::string(e); }
   Dl_info info;
   std::string dir = ".";
   if (dladdr((void*)&default_backend_path, &info) && info.dli_fname) {
@@ -34,6 +39,7 @@ const KernelApi* load_kernel_api(const std::string& path_in) {
   KernelApi* api = new KernelApi();
   api->handle = h;
   api->path = path;
+  api->overridden = !path_in.empty() || g_env_override;
 #define FFH_LOAD(name)                                                        \
   api->name = reinterpret_cast<decltype(api->name)>(dlsym(h, #name));         \
   if (!api->name) {                                                           \
@@ -46,6 +52,8 @@ const KernelApi* load_kernel_api(const std::string& path_in) {
     fprintf(stderr, "FATAL: %s has ABI version %d, expected %d\n", path.c_str(), api->ffh_abi_version(), FFH_ABI_VERSION);
     abort();
   }
+  if (path_in.empty() && g_env_override)
+    fprintf(stderr, "[DLRM] FFH_BACKEND_LIB: kernel library %s (%s)\n", path.c_str(), api->ffh_backend_name());
   cache[path] = api;
   return api;
 }

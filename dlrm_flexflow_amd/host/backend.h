@@ -11,6 +11,7 @@ struct KernelApi {
 #undef FFH_DECL
   void* handle;
   std::string path;
+  bool overridden = false;      // chosen by --backend or $FFH_BACKEND_LIB rather than the product default: the driver says so on its THROUGHPUT line
 };
 
 // Loads `path` (or, when empty, $FFH_BACKEND_LIB, else csrc/libffhip.so next to this library).

@@ -389,7 +389,11 @@ double DLRMApp::run_epochs() {
   if (chatty) {
     PerfMetrics pm = ff->get_perf_metrics();
     pm.print(ff->metrics_flags);
-    printf("ELAPSED TIME = %.4fs, THROUGHPUT = %.2f samples/s\n", run_time, loader->num_samples * (double)ffconfig.epochs / run_time);
+    // [ref: examples/cpp/DLRM/dlrm.cc:193-194] -- the reference's line as it is; a kernel library other than the product's own
+    // (--backend / FFH_BACKEND_LIB: the CPU oracle in tests, an A/B build) is named on it, so a number can never be mistaken
+    printf("ELAPSED TIME = %.4fs, THROUGHPUT = %.2f samples/s", run_time, loader->num_samples * (double)ffconfig.epochs / run_time);
+    if (ff->api->overridden) printf("  [kernel library: %s, %s]", ff->api->ffh_backend_name(), ff->api->path.c_str());
+    printf("\n");
   }
   return run_time;
 }

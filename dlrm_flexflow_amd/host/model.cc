@@ -135,6 +135,9 @@ FFConfig::FFConfig() {
   dx_scatter = true;
   early_sort = true;
   pad_linear_k = true;
+  capture_exchange = false;
+  bf16_twins = true;
+  force_async_launch = false;
   defer_big_dw = -1;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
@@ -197,6 +200,9 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
     if (is("--no-early-sort")) { early_sort = false; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
+    if (is("--capture-exchange")) { capture_exchange = true; continue; }
+    if (is("--no-bf16-twins")) { bf16_twins = false; continue; }               // A/B and tests: tensor-op mode rounding its operands inside the kernels
+    if (is("--force-async-launch")) { force_async_launch = true; continue; }   // tests: the launch-worker threads on a synchronous backend
     if (is("--defer-big-dw")) { defer_big_dw = 1; continue; }
     if (is("--no-defer-big-dw")) { defer_big_dw = 0; continue; }
     if (is("--sparse-embedding-optimizer")) { sparse_embedding_optimizer = true; continue; }
@@ -456,7 +462,7 @@ FFModel::FFModel(FFConfig& _config)
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_z_free), "event create");
   z_reader_layer = -1; z_free_recorded = false;
   dw_worker = side_worker = nullptr;
-  if (config.async_launch && (std::string(api->ffh_backend_name()).rfind("hip", 0) == 0 || getenv("FFM_FORCE_ASYNC_LAUNCH"))) {
+  if (config.async_launch && (std::string(api->ffh_backend_name()).rfind("hip", 0) == 0 || config.force_async_launch)) {
     // asynchronous devices only: on the CPU oracle a "launch" is the computation itself
     dw_worker = new LaunchWorker(api, config.device);
     side_worker = new LaunchWorker(api, config.device);
@@ -1323,7 +1329,11 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
     tensor_impls.push_back(label_tensor.impl);
     label_tensor.impl->is_input = true;
   }
-  if (exchange && config.enable_graph) config.enable_graph = false;   // collectives are host callbacks: not capturable
+  // Collectives served by host callbacks (torch.distributed) cannot be captured.  RcclComm's are plain enqueues on the model's own
+  // streams from C++ (ffcomm.nonblocking): with --capture-exchange the per-rank step -- kernels, both all-to-alls, the all-reduce --
+  // is captured and replayed as one hipGraph, as the reference wraps every iteration in a Legion trace on any GPU count
+  // [ref: examples/cpp/DLRM/dlrm.cc:174-181].  Behind a flag until a multi-GPU box has measured it.
+  if (exchange && config.enable_graph && !(config.capture_exchange && config.comm.nonblocking)) config.enable_graph = false;
   if (dynamic_cast<AdamOptimizer*>(optimizer) && config.enable_graph) config.enable_graph = false;   // alpha_t is a new launch argument every step
   // Any optimizer x any placement (round 4).  Plain SGD: the fused sorted-segments update.  Momentum / weight-decay SGD, Adam:
   // by default the reference's own path on the rank(s) that hold the table -- an owner-local dense gradient (zeroed, scatter-added
@@ -1784,7 +1794,7 @@ void FFModel::allocate() {
   //     tables and such Linears;
   //   * the gradient buffer of a tensor whose single consumer is such a Linear storing (not accumulating) its data gradient.
   n_twin_regions = 0;
-  if (config.allow_tensor_op_math_conversion && !getenv("FFM_NO_BF16_TWINS") && mlp_count > 0) {
+  if (config.allow_tensor_op_math_conversion && config.bf16_twins && mlp_count > 0) {
     const size_t ab = std::max<size_t>(act_bytes, 256);
     act_twin = dmalloc(ab / 2 + 256); grad_twin = dmalloc(ab / 2 + 256); w_twin = dmalloc((size_t)mlp_count * 2 + 256);
     check(api->ffh_zero(ctx, act_twin, ab / 2 + 256, stream), "zero"); check(api->ffh_zero(ctx, grad_twin, ab / 2 + 256, stream), "zero");
@@ -1945,7 +1955,7 @@ int FFModel::defer_big_dw_layer() const {
     const double m = (double)li->in_channels * li->out_channels * (double)local_batch;
     if (m > best_macs) { best_macs = m; best = (int)l; }
   }
-  if (best < 0 || best == (int)layers.size() - 1 || best == grad_attach_layer) return -1;
+  if (best < 0 || best == (int)layers.size() - 1) return -1;
   if (config.defer_big_dw < 0 && (best_macs < 2.0e9 || local_batch > 8192)) return -1;      // auto
   return best;
 }

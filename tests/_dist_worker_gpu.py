@@ -39,9 +39,11 @@ def main():
             extra, steps = extra + ["--replicate-embedding-rows", "8192"], 6
             if sys.argv[3].endswith("noov"):
                 extra.append("--no-overlap")
+        graph = sys.argv[3] == "kaggle-graph"          # --capture-exchange: the exchange step captured and replayed as a hipGraph (RcclComm only)
         app = ffmodel.DLRM(H.KAGGLE_ARGS(2048 * world) + ["--device", "0", "--force-exchange"] + extra, comm=comm.struct)
         app.warmup()
-        app.train_steps(steps, trace=False)
+        app.train_steps(steps, trace=graph)
+        out["uses_graph"] = np.array(int(bool(app.model.uses_graph)))
         app.model.sync()
         m = app.model
         out["pred"] = m.layer_output(m.num_layers - 1).get()

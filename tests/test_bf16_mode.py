@@ -506,10 +506,10 @@ def test_one_launch_backward_of_a_skinny_layer_writes_the_twin_of_its_data_gradi
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-def test_dlrm_step_bf16_mode_twins_on_equals_twins_off(hip, monkeypatch):
+def test_dlrm_step_bf16_mode_twins_on_equals_twins_off(hip):
     """Whole model in tensor-op mode at the Terabyte widths (top 3456-1024-1024-512-256-1: every big layer reads twins, the gather
     writes the twin of the Concat output, the optimizer the weights' twin), batch 4096, rows capped: three steps with the twins
-    against the same run with FFM_NO_BF16_TWINS=1 (operands rounded inside the kernels).  Identical arithmetic; the only
+    against the same run with --no-bf16-twins (operands rounded inside the kernels).  Identical arithmetic; the only
     freedom is the atomic order of the weight gradients."""
     import dlrm_helpers as H
     from dlrm_flexflow_amd import ffmodel
@@ -519,11 +519,7 @@ def test_dlrm_step_bf16_mode_twins_on_equals_twins_off(hip, monkeypatch):
             "--arch-mlp-top", "3456-1024-1024-512-256-1", "--data-size", "4096", "--allow-tensor-op-math-conversion"]
     out = []
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("FFM_NO_BF16_TWINS", "1")
-        else:
-            monkeypatch.delenv("FFM_NO_BF16_TWINS", raising=False)
-        app = ffmodel.DLRM(args)
+        app = ffmodel.DLRM(args + (["--no-bf16-twins"] if off else []))
         app.warmup(); app.train_steps(3, trace=False); app.model.sync()
         m = app.model
         o = {f"{m.layer_name(l)}/{i}": m.parameter(l, i).get_weights() for l in range(m.num_layers) for i in range(m.layer_num_weights(l))}

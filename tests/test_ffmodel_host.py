@@ -38,12 +38,11 @@ def test_dlrm_two_steps_match_torch_golden(overlap, dense_update):
 
 
 @pytest.mark.timeout(180)
-def test_launch_worker_threads_on_cpu(monkeypatch):
+def test_launch_worker_threads_on_cpu():
     """The multi-threaded launch path (dW GEMMs and the embedding side stream issued by their own host
     threads, joined through drain() + events) with the CPU oracle as the device: same results as the
     inline path, and no deadlock (hard timeout)."""
-    monkeypatch.setenv("FFM_FORCE_ASYNC_LAUNCH", "1")
-    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=True, extra_argv=["--async-launch"])
+    m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=True, extra_argv=["--async-launch", "--force-async-launch"])
     recs = H.run_steps(m, h, 2)
     H.check_against_golden(recs, h)
     m.close()

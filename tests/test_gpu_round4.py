@@ -279,13 +279,31 @@ def _weights(m):
     return out
 
 
+def _delta_check(name, dh, dc, tol_mass, tol_ulp, worst):
+    """|delta_hip - delta_cpu| <= 1e-5 of the update's term mass (+ the rounding of w itself) on at least 99.9 % of a tensor's
+    elements, and within 5e-2 of the mass everywhere.  The second tier is for the ReLU's discontinuity, not for the kernels: a
+    sample whose pre-activation lies within one rounding error of zero gets its relu' mask 1 from one backend and 0 from the other,
+    which adds or drops ONE whole term of that output's weight-gradient row (1/16,000 of the row's mass at this batch: 6e-5) and one
+    whole term of the 1024-term sums behind a table row's gradient (1e-3) -- a few samples per layer and step (density of
+    pre-activations at zero x 1e-7 x 8 M elements)."""
+    err = np.abs(dh - dc)
+    tol = tol_mass + tol_ulp
+    bad = err > tol
+    worst[name] = (float(bad.mean()), float((err / tol).max()))
+    at = int((err / tol).argmax())
+    msg = (f"{name}: {int(bad.sum())} of {err.size} deltas beyond 1e-5 of the term mass; worst at flat index {at}: off by {err.flat[at]:.3e}, bound {tol.flat[at]:.3e} "
+           f"(delta hip {dh.flat[at]:.3e} cpu {dc.flat[at]:.3e})")
+    assert bad.mean() <= 1e-3, msg
+    assert np.all(err <= 5000 * tol_mass + tol_ulp), msg
+
+
 @pytest.mark.timeout(3000)
 def test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle(hip):
     """FOUR steps (the driver's warm-up iteration + three) of the workload bench.py times at N = 1 (26 tables, emb_dim 128, bot 13-512-256-128, top 3456-1024-1024-512-256-1,
     batch 32768, eager launches on three streams, early sort: the next gather, the sort behind it and the update are all inside
     the window) on the HIP kernels against the same host code on the oracle, compared on the weight DELTAS: a weight is ~3e-2
     and one update ~1e-4, so round 3's rtol 2e-5 on the weights saw a gradient error only above ~0.5 % of the update.  Bound per
-    element: 1e-5 of the update's term mass -- lr * sum over the steps of sum_b |dy[b][o]| |x[b][i]| for an MLP weight (taken as
+    element (two tiers, see _delta_check: the relu' mask is a discontinuity): 1e-5 of the update's term mass -- lr * sum over the steps of sum_b |dy[b][o]| |x[b][i]| for an MLP weight (taken as
     steps x the last step's, computed in float64 from the oracle run's own activations and gradients), lr * sum_b |dy| for a bias, lr *
     the summed |dZ| mass of the hits for a table row -- plus two ulps of the weight per step for the rounding of w itself.  Row
     counts capped at 100,000 (the oracle's tables must fit the host; full-size tables: the next test)."""
@@ -335,10 +353,7 @@ def test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle(hip):
             k = f"{nm}/{wi}"
             dh = h["w1"][k].astype(np.float64) - h["w0"][k].astype(np.float64)
             dc = c["w1"][k].astype(np.float64) - c["w0"][k].astype(np.float64)
-            tol = 1e-5 * lr * steps * mass.reshape(dh.shape) + steps * 2 * np.spacing(np.abs(c["w0"][k]).astype(np.float32)).astype(np.float64)
-            err = np.abs(dh - dc)
-            worst[k] = float((err / tol).max())
-            assert np.all(err <= tol), f"{k}: delta off by {err.max():.3e} where the bound is {tol.flat[err.argmax()]:.3e} (|delta| there {abs(dc.flat[err.argmax()]):.3e})"
+            _delta_check(k, dh, dc, 1e-5 * lr * steps * mass.reshape(dh.shape), steps * 2 * np.spacing(np.abs(c["w0"][k]).astype(np.float32)).astype(np.float64), worst)
             assert np.abs(dc).max() > 0
     # tables: a row's update is lr * the sum of its hits' gradient rows = rows of dZ = dy1 W1[:, table's columns]
     dy1, w1 = c["dy"][first_top], c["w0"][f"{first_top}/0"]
@@ -353,15 +368,12 @@ def test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle(hip):
         rowmass = torch.zeros(R, 128, dtype=torch.float64, device=DEV).index_add_(0, ids, dzmass[:, 128 * (t + 1):128 * (t + 2)]).cpu().numpy()
         dh = h["w1"][k].astype(np.float64) - h["w0"][k].astype(np.float64)
         dc = c["w1"][k].astype(np.float64) - c["w0"][k].astype(np.float64)
-        tol = 1e-5 * lr * steps * rowmass + steps * 2 * np.spacing(np.abs(c["w0"][k]).astype(np.float32)).astype(np.float64)
-        err = np.abs(dh - dc)
-        worst[k] = float((err / tol).max())
-        assert np.all(err <= tol), f"{k}: delta off by {err.max():.3e}, bound {tol.flat[err.argmax()]:.3e}"
+        _delta_check(k, dh, dc, 1e-5 * lr * steps * rowmass, steps * 2 * np.spacing(np.abs(c["w0"][k]).astype(np.float32)).astype(np.float64), worst)
         untouched = np.ones(R, bool); untouched[c["ids"][nm].reshape(-1)] = False
         assert not dh[untouched].any() and not dc[untouched].any()
         t += 1
     np.testing.assert_allclose(h["pred"], c["pred"], rtol=2e-5, atol=2e-6)
-    print("worst error / bound per tensor:", {k: round(v, 3) for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:8]})
+    print("fraction beyond 1e-5 of the mass, worst error / bound per tensor:", {k: (round(v[0], 6), round(v[1], 2)) for k, v in sorted(worst.items(), key=lambda kv: -kv[1][1])[:10]})
 
 
 def _digest_of_touched_rows(hip, app, steps_ids=None):
@@ -509,3 +521,23 @@ def test_mlperf_first_top_layer_padded_to_512_hip_vs_unpadded_oracle(hip):
     for k in outs[0]:
         if k != "ld":
             np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+def test_exchange_step_captured_as_a_graph_equals_eager_bit_for_bit(hip, tmp_path):
+    """with RcclComm the collectives are stream enqueues from C++, so the per-rank step of a multi-rank job --
+    kernels, both all-to-alls, the all-reduce, the side-stream branches -- can be captured and replayed as one hipGraph
+    (--capture-exchange), as the reference traces every iteration on any GPU count [ref: examples/cpp/DLRM/dlrm.cc:174-181].  One
+    forced RCCL rank, Kaggle shape, three steps under --deterministic: the replayed run must leave the bits of the eager one."""
+    worker = os.path.join(ROOT, "tests", "_dist_worker_gpu.py")
+    outs = []
+    for mode, flags in (("kaggle-graph", ["--capture-exchange", "--deterministic"]), ("kaggle", ["--deterministic", "--no-trace"])):
+        d = os.path.join(tmp_path, mode); os.makedirs(d)
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90))
+        r = subprocess.run(["python", worker, d, "direct", mode, *flags], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        outs.append(np.load(os.path.join(d, "rank0.npz")))
+    assert int(outs[0]["uses_graph"]) == 1 and int(outs[1]["uses_graph"]) == 0
+    assert int(outs[0]["alltoall_calls"]) < int(outs[1]["alltoall_calls"])      # replayed steps issue no host-side collective calls
+    for k in outs[1].files:
+        if k.startswith("p") or k == "pred":
+            assert outs[0][k].tobytes() == outs[1][k].tobytes(), k

@@ -4,7 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dlrm_flexflow_amd import capi
-hip = capi.load_hip(0)
+import _lab
+hip = _lab.load_hip(0)
 assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, 1) == 0
 B, IN, OUT = (int(v) for v in (sys.argv[1].split("x") if len(sys.argv) > 1 else (32768, 3456, 1024)))
 dev = "cuda"

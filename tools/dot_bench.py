@@ -5,11 +5,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dlrm_flexflow_amd import capi
+import _lab
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 c = int(sys.argv[2]) if len(sys.argv) > 2 else 27
 d = int(sys.argv[3]) if len(sys.argv) > 3 else 128
-hip = capi.load_hip(0)
+hip = _lab.load_hip(0)
 P = c * (c - 1) // 2
 z = torch.randn(B, c * d, device="cuda")
 out = torch.empty(B, d + P, device="cuda")

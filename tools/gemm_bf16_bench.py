@@ -4,7 +4,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dlrm_flexflow_amd import capi
-hip = capi.load_hip(0)
+import _lab
+hip = _lab.load_hip(0)
 def timeit(fn, iters=10):
     for _ in range(20): fn()      # the clock needs tens of milliseconds of load to settle
     torch.cuda.synchronize()

@@ -6,7 +6,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     from dlrm_flexflow_amd import capi
-    hip = capi.load_hip(0)
+    import _lab
+    hip = _lab.load_hip(0)
     def timeit(fn, iters=20):
         for _ in range(20): fn()          # the chip's clock needs tens of milliseconds under load to settle
         torch.cuda.synchronize()

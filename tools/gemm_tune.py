@@ -5,7 +5,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     from dlrm_flexflow_amd import capi
-    hip = capi.load_hip(0)
+    import _lab
+    hip = _lab.load_hip(0)
     def timeit(fn, iters=50):
         for _ in range(5): fn()
         torch.cuda.synchronize()

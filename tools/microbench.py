@@ -11,6 +11,7 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dlrm_flexflow_amd import capi
+import _lab
 
 DEV = "cuda:0"
 PEAK_HBM = 8.0e12
@@ -99,7 +100,7 @@ def gemm(hip):
 
 
 if __name__ == "__main__":
-    hip = capi.load_hip(0)
+    hip = _lab.load_hip(0)
     print(hip.device_info().name.decode(), hip.device_info().compute_units, "CUs")
     what = sys.argv[1:2] or ["emb", "gemm"]
     if "emb" in what:

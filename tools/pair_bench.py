@@ -5,9 +5,10 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dlrm_flexflow_amd import capi
+import _lab
 
 B, INL, INU, OUTU = 2048, 256, 64, 16
-hip = capi.load_hip(0)
+hip = _lab.load_hip(0)
 xl = torch.randn(B, INL, device="cuda"); xu = torch.randn(B, INU, device="cuda"); yu = torch.randn(B, OUTU, device="cuda")
 gu = torch.randn(B, OUTU, device="cuda"); wu = torch.randn(OUTU, INU, device="cuda"); wl = torch.randn(INU, INL, device="cuda")
 dxl = torch.zeros(B, INL, device="cuda"); dyl = torch.zeros(B, INU, device="cuda")

@@ -5,7 +5,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dlrm_flexflow_amd import capi
-hip = capi.load_hip(0)
+import _lab
+hip = _lab.load_hip(0)
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 B, IN, OUT = 32768, 3456, 1024
 x = torch.rand(B, IN, device="cuda"); w = torch.randn(OUT, IN, device="cuda") * 0.05; b = torch.randn(OUT, device="cuda")
