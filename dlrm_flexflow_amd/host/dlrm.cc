@@ -1,5 +1,9 @@
 // dlrm.cc -- DLRM application on the FFModel shim [ref: examples/cpp/DLRM/dlrm.cc].
 #include "dlrm.h"
+
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
 #include "hdf5_io.h"
 
 #include <chrono>
@@ -281,7 +285,21 @@ void DataLoader::next_batch(FFModel& ff) {
 }
 
 // =============================================================================================
+// --backtrace-on-crash (debugging aid): SIGSEGV / SIGBUS / SIGABRT print the native call stack of the faulting thread before the
+// process dies (glibc backtrace_symbols_fd: async-signal-safe enough for a last word; the GPU box has no core dumps to look at)
+static void crash_backtrace(int sig) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "\n[DLRM] fatal signal, native backtrace:\n";
+  if (write(2, msg, sizeof msg - 1) < 0) {}
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
 DLRMApp::DLRMApp(int argc, char** argv, const ffcomm* comm) : ff(nullptr), loader(nullptr), warmed_up(false) {
+  for (int i = 1; i < argc; i++)
+    if (!strcmp(argv[i], "--backtrace-on-crash")) { signal(SIGSEGV, crash_backtrace); signal(SIGBUS, crash_backtrace); signal(SIGABRT, crash_backtrace); }
   ffconfig.parse_args(argv, argc);
   if (comm) ffconfig.comm = *comm;
   parse_input_args(argv, argc, dlrm);

@@ -138,7 +138,7 @@ FFConfig::FFConfig() {
   capture_exchange = false;
   bf16_twins = true;
   force_async_launch = false;
-  defer_big_dw = -1;
+  defer_big_dw = 0;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
@@ -1944,10 +1944,9 @@ bool FFModel::early_sort_possible() const {
   return n > 0 && n <= FFH_MAX_TABLES;
 }
 
-// the layer whose weight gradient is issued last (-1: none): the Linear with the most multiply-adds, when its GEMMs are of the
-// persistent kind (>= 2e9 MACs) and the per-GPU batch is small (see FFModel::backward)
+// the layer whose weight gradient is issued last under --defer-big-dw (-1: none): the Linear with the most multiply-adds
 int FFModel::defer_big_dw_layer() const {
-  if (config.defer_big_dw == 0 || !config.parallel_dw || config.profiling || use_workers() || config.deterministic) return -1;
+  if (config.defer_big_dw <= 0 || !config.parallel_dw || config.profiling || use_workers() || config.deterministic) return -1;
   int best = -1; double best_macs = 0.0;
   for (size_t l = 0; l < layers.size(); l++) {
     const Linear* li = layers[l]->op_type == OP_LINEAR ? static_cast<const Linear*>(layers[l]) : nullptr;
@@ -1956,7 +1955,6 @@ int FFModel::defer_big_dw_layer() const {
     if (m > best_macs) { best_macs = m; best = (int)l; }
   }
   if (best < 0 || best == (int)layers.size() - 1) return -1;
-  if (config.defer_big_dw < 0 && (best_macs < 2.0e9 || local_batch > 8192)) return -1;      // auto
   return best;
 }
 
@@ -2300,13 +2298,11 @@ void FFModel::backward(int _seq_length) {
       z_free_recorded = true;
     }
   };
-  // --defer-big-dw: the biggest layer's weight-gradient GEMM (a persistent one-workgroup-per-CU launch of 200+ us that needs nothing
-  // the rest of the backward produces) is issued LAST.  Beside it every small kernel runs 5-10x slower than alone (measured: the
-  // bottom MLP's 0.27-GFLOP data gradient 80-210 us instead of 8, the table update 200 instead of 60 -- with or without wave /
-  // stream priorities, profiles/r04_*): the bottom MLP's backward chain and the table update, which both start when the layer's data
-  // gradient is done, then finish before the GEMM takes the chip instead of trailing it, and only the optimizer + bottom-MLP
-  // forward remain behind it.  Pays at small per-GPU batches (the 8-GPU job's 4096), costs at 32768 where the layer's two GEMMs
-  // overlap each other better than they run apart: on by batch size (defer_big_dw()).
+  // --defer-big-dw (A/B switch, off): the biggest layer's weight-gradient GEMM (a persistent one-workgroup-per-CU launch of 200+ us
+  // that needs nothing the rest of the backward produces) issued LAST, so that the bottom MLP's backward chain and the table update --
+  // which run 5-10x slower beside it than alone -- finish before it takes the chip.  Measured in round 4 and kept off: the layer's
+  // data- and weight-gradient GEMMs overlap each other better than they run apart -- 1.228 vs 1.190 ms at 4096 samples, 2.224 vs
+  // 2.155 at 8192, 8.02 vs 7.87 at 32768, MLPerf shape 1.337 vs 1.273.
   const int defer_layer = defer_big_dw_layer();
   Linear* deferred = nullptr;
   for (int l = first; l >= 0; l--) {
