@@ -220,6 +220,11 @@ def cpu_baseline(args, budget_s=24.0):
                       "; oracle/ffh_oracle.c (OpenMP over the batch) behind the same C++ FFModel host code",
             "host_cpus": ncpu,
             "by_threads": {str(t): legs[t]["value"] for t in sorted(legs)},
+            "scaling_note": "the port is the test oracle: clarity over speed.  Its GEMMs run one fp32 FMA chain per output element (the order the parity tests "
+                            "pin), OpenMP over the batch for forward / dX and over the output rows for dW, with no cache blocking -- every sample re-streams the "
+                            "layer's whole weight matrix (14 MB for 3456 x 1024), so beyond a few dozen threads the legs are bound by shared memory bandwidth and "
+                            "the all-threads leg can be SLOWER than the quarter leg; `value` is the fastest leg, `cores` its thread count.  The reference's own "
+                            "CPU arithmetic for this path is `reference_lookup` (one thread, as the reference runs it).",
             "reference_lookup": reference_lookup()}
 
 

@@ -137,9 +137,7 @@ struct SortArgs {
   const int64_t* idx[FFH_MAX_TABLES];   // pass 0 source
   const uint2* src;                     // [nt][N] {row id, position}: ONE 8-byte element per entry -- a pass scatters one store per
   uint2*    dst;                        //   entry instead of two 4-byte ones into two arrays (the scattered stores are most of a pass)
-  uint32_t* hist;                       // [nt][nblk][radix]: digit counts per tile of THIS pass
-  uint32_t* hist_next;                  // the same for the NEXT pass, accumulated by this pass's scatter (entries are counted where they land)
-  uint32_t* hist_zero;                  // the buffer the pass after that will accumulate into: cleared here
+  uint32_t* hist;                       // [nt][nblk][radix]
   int64_t   N;                          // entries per table (batch * L)
   int       nblk;
   int       shift;
@@ -174,10 +172,6 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const SortArgs
   if (a.pass >= a.npass[t]) return;
   const int radix = 1 << a.bits;
   const uint32_t mask = radix - 1;
-  if (a.hist_next) {                   // the scatter of this pass counts the next pass's digits into it
-    uint32_t* z = a.hist_next + ((int64_t)t * a.nblk + blk) * radix;
-    for (int d = threadIdx.x; d < radix; d += kSortThreads) z[d] = 0u;
-  }
   for (int d = threadIdx.x; d < radix; d += kSortThreads) s_hist[d] = 0;
   __syncthreads();
   const int64_t tile0 = (int64_t)blk * kSortTile;
@@ -246,17 +240,6 @@ __device__ __forceinline__ void sort_scan_offsets(const uint32_t (&all_d)[QN], c
 // `bits` ballots (a match-any), the rank inside the group is a popcount of the lower lanes, and the group's
 // lowest lane advances the wave's running offset in LDS.  `out.put(dest, key, pos)` stores an entry (SortOutGlobal / SortOutLds).
 struct SortOutGlobal { uint2* kp; __device__ __forceinline__ void put(uint32_t d, uint32_t k, uint32_t p) const { kp[d] = make_uint2(k, p); } };
-// ... and, while the destination and the key are in hand, the NEXT pass's histogram: the entry will be in tile d / tile of the
-// array the next pass reads, with digit (k >> next_shift) & mask there.  Counted in an LDS table [tiles][radix] per workgroup and
-// flushed as one global atomic per non-empty counter (tables with few distinct ids put thousands of entries on a handful of
-// counters: per-entry global atomics serialised on them -- measured in round 2); two launches per pass become one.
-struct SortOutGlobalCount {
-  uint2* kp; uint32_t* agg; uint32_t tile_shift; int next_shift; uint32_t mask; int radix_bits;
-  __device__ __forceinline__ void put(uint32_t d, uint32_t k, uint32_t p) const {
-    kp[d] = make_uint2(k, p);
-    atomicAdd(&agg[((d >> tile_shift) << radix_bits) + ((k >> next_shift) & mask)], 1u);
-  }
-};
 struct SortOutLds { uint32_t* k; uint32_t* p; __device__ __forceinline__ void put(uint32_t d, uint32_t key, uint32_t pos) const { k[d] = key; p[d] = pos; } };
 template <int E, class Out>
 __device__ __forceinline__ void sort_rank_and_scatter(const uint32_t (&key)[E], const uint32_t (&pos)[E], const bool (&valid)[E],
@@ -288,12 +271,11 @@ __device__ __forceinline__ void sort_rank_and_scatter(const uint32_t (&key)[E], 
 // time: the lanes holding the same digit find each other with `bits` ballots (a match-any),
 // the rank inside the group is a popcount of the lower lanes, and the group's lowest lane
 // advances the wave's running offset in LDS.
-template <bool FIRST, int E, bool NEXT>
+template <bool FIRST, int E>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortArgs a) {
   ffh_kernel_prio();
   constexpr int kSortTile = kSortThreads * E;
   constexpr int kSortPerThread = E;
-  extern __shared__ uint32_t s_agg[];                     // NEXT: [nblk][radix] counters of the next pass's histogram
   if (a.pass >= a.npass[blockIdx.y]) return;
   __shared__ uint32_t s_off[4][kMaxRadix];
   __shared__ uint32_t s_scan[kMaxRadix];
@@ -305,14 +287,6 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
   const int64_t tile0 = (int64_t)blk * kSortTile;
 
   for (int d = threadIdx.x; d < 4 * kMaxRadix; d += kSortThreads) (&s_off[0][0])[d] = 0;
-  const bool next = NEXT && a.pass + 1 < a.npass[t];      // this table has another pass: count its digits while scattering
-  if (NEXT) {
-    if (next) for (int d = threadIdx.x; d < a.nblk * radix; d += kSortThreads) s_agg[d] = 0;
-    if (a.hist_zero) {                                    // ... and clear the buffer the pass after that will count into
-      uint32_t* z = a.hist_zero + ((int64_t)t * a.nblk + blk) * radix;
-      for (int d = threadIdx.x; d < radix; d += kSortThreads) z[d] = 0u;
-    }
-  }
   __syncthreads();
 
   uint32_t key[kSortPerThread], pos[kSortPerThread];
@@ -358,19 +332,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
     }
   }
   sort_scan_offsets<4, 2>(all_d, before_d, radix, s_off, s_scan, s_wsum);
-  if (NEXT && next) {
-    constexpr uint32_t tile_shift = E == 1 ? 8 : (E == 2 ? 9 : (E == 4 ? 10 : 11));      // log2(kSortTile)
-    sort_rank_and_scatter<kSortPerThread>(key, pos, valid, a.shift, a.bits, mask, s_off[wave],
-                                          SortOutGlobalCount{a.dst + (int64_t)t * a.N, s_agg, tile_shift, a.shift + a.bits, mask, a.bits});
-    __syncthreads();
-    uint32_t* hn = a.hist_next + (int64_t)t * a.nblk * radix;
-    for (int d = threadIdx.x; d < a.nblk * radix; d += kSortThreads) {
-      const uint32_t v = s_agg[d];
-      if (v) atomicAdd(&hn[d], v);
-    }
-  } else {
-    sort_rank_and_scatter<kSortPerThread>(key, pos, valid, a.shift, a.bits, mask, s_off[wave], SortOutGlobal{a.dst + (int64_t)t * a.N});
-  }
+  sort_rank_and_scatter<kSortPerThread>(key, pos, valid, a.shift, a.bits, mask, s_off[wave], SortOutGlobal{a.dst + (int64_t)t * a.N});
 }
 
 // ---------------------------------------------------------------------------
@@ -1000,7 +962,7 @@ inline BwdLayout bwd_layout(int nt, int L, int D, int64_t batch) {
   size_t o = 0;
   l.kp_a = o; o += arr;
   l.kp_b = o; o += arr;
-  l.hist = o; o += 3 * align_up((size_t)nt * (size_t)l.nblk * kMaxRadix * sizeof(uint32_t), 256);     // three rotating [nt][nblk][radix] matrices
+  l.hist = o; o += align_up((size_t)nt * (size_t)l.nblk * kMaxRadix * sizeof(uint32_t), 256);
   l.partial = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks * (size_t)D * sizeof(float), 256);
   l.meta = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks * sizeof(uint2), 256);
   l.nchunks1 = (int)((N + FFH_EMB_CHUNK1 - 1) / FFH_EMB_CHUNK1);
@@ -1215,46 +1177,22 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
     sa.npass[i] = (uint8_t)np;
     ra.parity[i] = (uint8_t)(np & 1);
   }
+  sa.hist = (uint32_t*)(ws + lay.hist);
   sa.N = N; sa.nblk = lay.nblk; sa.bits = rb;
   sa.clear[0] = (uint32_t*)(ws + lay.meta1); sa.nclear[0] = 4 * lay.nchunks1;     // uint2 slots, two per 1024-block
   sa.clear[1] = (uint32_t*)(ws + lay.arrive); sa.nclear[1] = lay.nchunks1 + 1;
   uint2* kbuf[2] = {(uint2*)(ws + lay.kp_a), (uint2*)(ws + lay.kp_b)};
   dim3 sgrid((unsigned)lay.nblk, (unsigned)nt);
   const int E = sort_per_thread(nt, N);
-  // One histogram launch (pass 0), then ONE launch per pass: the scatter of pass p counts the digits of pass p + 1 where its
-  // entries land (LDS table per workgroup, one global atomic per non-empty counter) into the next of three rotating histogram
-  // matrices and clears the one after -- four dependent launches for a 26-bit id instead of six (same sorted list: bit-identical).
-  // The LDS table is [tiles][radix] counters: tile counts above 32 (only reachable past 2^19 lookups per table) keep two launches per pass.
-  const size_t hist_stride = align_up((size_t)nt * (size_t)lay.nblk * kMaxRadix * sizeof(uint32_t), 256);
-  auto hist_buf = [&](int k) { return (uint32_t*)(ws + lay.hist + (size_t)(k % 3) * hist_stride); };
-  const size_t agg_bytes = (size_t)lay.nblk * ((size_t)1 << rb) * sizeof(uint32_t);
-  const bool merged = agg_bytes <= 64 * 1024;
-  // (the table + the kernel's 10 KB of static LDS can pass the 64 KB a launch gets by default: the attribute is per kernel and device)
-  auto lds_ok = [&](const void* kern, signed char* state) -> bool {
-    if (agg_bytes <= 48 * 1024) return true;
-    signed char& st = state[c->device & 63];
-    if (st == 0) { st = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)agg_bytes) == hipSuccess ? 1 : -1; if (st < 0) (void)hipGetLastError(); }
-    return st > 0;
-  };
   for (int p = 0; p < passes && do_sort; p++) {
     sa.shift = p * rb;
     sa.pass = p;
     // pass p reads buffer p%2 (pass 0: the int64 ids) and writes buffer (p+1)%2
     sa.src = kbuf[p & 1];
     sa.dst = kbuf[(p + 1) & 1];
-    sa.hist = hist_buf(p);
-    const bool next = merged && p + 1 < passes;
-    sa.hist_next = next ? hist_buf(p + 1) : nullptr;
-    sa.hist_zero = (merged && p + 2 < passes) ? hist_buf(p + 2) : nullptr;
-    const bool need_hist = p == 0 || !merged;
-#define FFH_SORT_PASS(FIRSTV, EV)                                                                                         \
-    {                                                                                                                     \
-      static signed char attr_state[64];                                                                                  \
-      if (next && !lds_ok((const void*)radix_scatter_kernel<FIRSTV, EV, true>, attr_state)) return ffh_fail(c, FFH_ERR_HIP, "radix_scatter_kernel: dynamic LDS attribute refused"); \
-      if (need_hist) hipLaunchKernelGGL((radix_hist_kernel<FIRSTV, EV>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);   \
-      if (next) hipLaunchKernelGGL((radix_scatter_kernel<FIRSTV, EV, true>), sgrid, dim3(kSortThreads), agg_bytes, as_stream(s), sa); \
-      else hipLaunchKernelGGL((radix_scatter_kernel<FIRSTV, EV, false>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);   \
-    }
+#define FFH_SORT_PASS(FIRSTV, EV)                                                                              \
+    hipLaunchKernelGGL((radix_hist_kernel<FIRSTV, EV>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);      \
+    hipLaunchKernelGGL((radix_scatter_kernel<FIRSTV, EV>), sgrid, dim3(kSortThreads), 0, as_stream(s), sa);
     if (p == 0) {
       switch (E) { case 1: FFH_SORT_PASS(true, 1) break; case 2: FFH_SORT_PASS(true, 2) break; case 4: FFH_SORT_PASS(true, 4) break; default: FFH_SORT_PASS(true, 8) break; }
     } else {

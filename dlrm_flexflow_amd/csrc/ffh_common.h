@@ -114,14 +114,14 @@ static inline unsigned ffh_grid(int64_t work_items, int per_block, unsigned cap 
 constexpr int kWave = 64;
 
 #ifdef __HIPCC__
-// Wave priority of every kernel except the persistent GEMMs (linear_sk.hip).  A persistent workgroup keeps one wave per SIMD that
-// issues MFMAs back to back for hundreds of microseconds; the instruction arbiter serves the oldest ready wave of a SIMD first, so a
-// short kernel whose workgroups share those CUs got an issue slot only while the GEMM wave sat at a barrier -- the bottom MLP's
-// 0.27-GFLOP data-gradient GEMM took 210 us beside the first top layer's weight gradient at 4096 samples (alone: 8 us), and the
-// whole chain behind it waited.  s_setprio raises these waves above the GEMM's (priority 0): they run when they are ready, the GEMM
-// fills every other cycle.  FFH_PRIO = 0 compiles it out (A/B builds).
+// Wave priority of every kernel except the persistent GEMMs (linear_sk.hip) -- an A/B build switch, OFF in the product (FFH_PRIO 0).
+// Round 4 measured it: a persistent workgroup keeps one wave per SIMD issuing MFMAs back to back for hundreds of microseconds, and
+// short kernels that share those CUs run 5-10x slower than alone (the bottom MLP's 0.27-GFLOP data-gradient GEMM: 80-210 us beside
+// the first top layer's weight gradient at 4096 samples, 8 us alone).  Raising their waves' priority (s_setprio 3) shortened that
+// kernel to ~145 us and changed the step by nothing (1.199 -> 1.20-1.22 ms): the slow-down is not instruction arbitration alone.
+// tools/build_variant.sh <out.so> -DFFH_PRIO=3 builds the variant.
 #ifndef FFH_PRIO
-#define FFH_PRIO 3
+#define FFH_PRIO 0
 #endif
 __device__ __forceinline__ void ffh_kernel_prio() {
 #if FFH_PRIO > 0

@@ -105,6 +105,7 @@ class FFConfig {
   bool deterministic;          // --deterministic: weight / bias gradients without fp atomics (ffh_ctx_set_deterministic): bit-identical runs
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
+  bool two_dw_streams;               // (A/B: --one-dw-stream) the biggest layer's weight-gradient GEMM on a stream of its own
   int  defer_big_dw;                 // --defer-big-dw (A/B, default 0): the biggest layer's weight gradient is issued last instead of beside its data gradient
   bool bf16_twins, force_async_launch;   // --no-bf16-twins / --force-async-launch (A/B and test switches; they used to be environment variables)
   bool capture_exchange;             // --capture-exchange: world_size > 1 with collectives enqueued from C++ (RcclComm): the step is captured / replayed as a hipGraph
@@ -490,11 +491,14 @@ class FFModel {
   ffh_ctx* ctx;
   ffh_stream stream;           // main compute stream
   ffh_stream side_stream;      // embedding gather / exchange / sparse update
-  ffh_stream dw_stream;        // weight-gradient GEMMs (parallel_dw)
-  ffh_event ev_dw_done;
+  ffh_stream dw_stream;        // weight-gradient GEMMs (parallel_dw): the biggest layer's ...
+  ffh_stream dw_stream2;       // ... and everybody else's (A/B: --one-dw-stream)
+  ffh_event ev_dw_done, ev_dw2_done;
+  int big_dw_layer;            // the Linear with the most multiply-adds
   bool need_zero_gsend;        // some gradient in the exchange send buffer is accumulated rather than stored
   bool need_zero_act_grads;    // some activation gradient is accumulated by more than one producer
   mutable bool dw_forked;
+  mutable bool dw1_used = false, dw2_used = false;   // which weight-gradient stream(s) this step's forks were offered (joined in update())
   mutable bool dw_stream_used_directly = false;   // a weight gradient was enqueued on dw_stream by this layer itself (deferred dW), not by the library's fork
   int defer_big_dw_layer() const;
   mutable bool mlp_grads_clean;   // the optimizer kernel cleared the MLP gradient slab (FFH_OPT_ZERO_GRAD): zero_gradients() skips it

@@ -258,6 +258,7 @@ float flexflow_dlrm_time_kernel(flexflow_dlrm_t h, int which, int iters) {
     ff->check(ff->api->ffh_event_record(ff->ctx, ff->ev_dw_done, ff->dw_stream), "join dw");
     ff->check(ff->api->ffh_stream_wait_event(ff->ctx, ff->stream, ff->ev_dw_done), "join dw");
     ff->dw_forked = false;
+    ff->dw1_used = ff->dw2_used = false;
   }
   ff->check(ff->api->ffh_event_record(ff->ctx, e1, ff->stream), "event");
   ff->check(ff->api->ffh_event_sync(ff->ctx, e1), "event");

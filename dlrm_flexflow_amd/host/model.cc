@@ -139,6 +139,7 @@ FFConfig::FFConfig() {
   bf16_twins = true;
   force_async_launch = false;
   defer_big_dw = 0;
+  two_dw_streams = true;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
@@ -204,6 +205,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-bf16-twins")) { bf16_twins = false; continue; }               // A/B and tests: tensor-op mode rounding its operands inside the kernels
     if (is("--force-async-launch")) { force_async_launch = true; continue; }   // tests: the launch-worker threads on a synchronous backend
     if (is("--defer-big-dw")) { defer_big_dw = 1; continue; }
+    if (is("--one-dw-stream")) { two_dw_streams = false; continue; }
     if (is("--no-defer-big-dw")) { defer_big_dw = 0; continue; }
     if (is("--sparse-embedding-optimizer")) { sparse_embedding_optimizer = true; continue; }
   }
@@ -248,6 +250,7 @@ bool Tensor::set_tensor(const FFModel* model, const std::vector<int>& dims, cons
   if (model->side_worker) model->side_worker->drain();
   model->check(model->api->ffh_stream_sync(model->ctx, model->side_stream), "set_tensor sync");
   model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream), "set_tensor sync");
+  model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream2), "set_tensor sync");
   if (impl->ld == cols_) {
     model->check(model->api->ffh_memcpy_h2d(model->ctx, impl->ptr, data, vol * sizeof(T), model->stream), "set_tensor");
   } else {
@@ -271,6 +274,7 @@ bool copy_out(const FFModel* model, const Tensor& t, const void* base, int64_t l
   model->check(model->api->ffh_stream_sync(model->ctx, model->stream), "get_tensor sync");
   model->check(model->api->ffh_stream_sync(model->ctx, model->side_stream), "get_tensor sync");
   model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream), "get_tensor sync");
+  model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream2), "get_tensor sync");
   if (ld == cols_) {
     model->check(model->api->ffh_memcpy_d2h(model->ctx, data, base, (size_t)nrows * cols_ * sizeof(T), model->stream), "get_tensor");
   } else {
@@ -437,7 +441,7 @@ FFModel::FFModel(FFConfig& _config)
       act_slab(nullptr), act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), repl_workspace(nullptr), repl_workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1), inputs_dirty(true), fork_recorded(false) {
   seed_counter = 0;
-  dw_stream = nullptr; ev_dw_done = nullptr; need_zero_act_grads = true; need_zero_gsend = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
+  dw_stream = dw_stream2 = nullptr; ev_dw_done = ev_dw2_done = nullptr; big_dw_layer = -1; need_zero_act_grads = true; need_zero_gsend = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
   rank = config.comm.world_size > 1 ? config.comm.rank : 0;
   world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
   if (world_size == 1 && config.workersPerNode > 1)
@@ -458,6 +462,8 @@ FFModel::FFModel(FFConfig& _config)
   check(api->ffh_stream_create(ctx, &stream), "stream create");
   check(api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
+  check(api->ffh_stream_create(ctx, &dw_stream2), "stream create");
+  check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw2_done), "event create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw_done), "event create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_z_free), "event create");
   z_reader_layer = -1; z_free_recorded = false;
@@ -503,7 +509,8 @@ FFModel::~FFModel() {
   api->ffh_event_destroy(ctx, ev_dw_done);
   api->ffh_event_destroy(ctx, ev_z_free);
   for (ffh_event& e : probe_ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
-  api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream);
+  api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream); api->ffh_stream_destroy(ctx, dw_stream2);
+  api->ffh_event_destroy(ctx, ev_dw2_done);
   api->ffh_ctx_destroy(ctx);
   for (Op* op : layers) delete op;
   for (Initializer* i : owned_initializers) delete i;
@@ -695,6 +702,7 @@ void Linear::backward_part(const FFModel& ff, int part) {
     ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, nullptr, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                        flags | FFH_LINEAR_ONLY_DW, ff.dw_stream, nullptr), name);
     ff.dw_forked = true;
+    ff.dw1_used = true;
     ff.dw_stream_used_directly = true;
     return;
   }
@@ -717,9 +725,15 @@ void Linear::backward_part(const FFModel& ff, int part) {
     ff.dw_forked = true;
     return;
   }
+  // Two weight-gradient streams: the biggest layer's GEMM (the first top layer's: a persistent launch of hundreds of microseconds)
+  // has one to itself.  On a single stream the bottom MLP's weight gradients -- forked seconds of host time later, but needing only
+  // operands that exist long before the big GEMM ends -- queued BEHIND it and ran, with the optimizer and the next forward behind
+  // them, after it (4096 samples: ~80 of the 130 us between the end of that GEMM and the next top-MLP forward).
+  ffh_stream dws = layer_index == ff.big_dw_layer ? ff.dw_stream : ff.dw_stream2;
+  if (!ff.config.two_dw_streams) dws = ff.dw_stream;
   ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
-                                     flags, ff.stream, fork ? ff.dw_stream : nullptr), name);
-  if (fork) ff.dw_forked = true;
+                                     flags, ff.stream, fork ? dws : nullptr), name);
+  if (fork) { ff.dw_forked = true; (dws == ff.dw_stream ? ff.dw1_used : ff.dw2_used) = true; }
 }
 
 // =============================================================================================
@@ -1682,6 +1696,18 @@ void FFModel::allocate() {
     }
   }
 
+  // the Linear with the most multiply-adds: its weight-gradient GEMM gets dw_stream to itself (Linear::backward_part)
+  big_dw_layer = -1;
+  {
+    double best = 0.0;
+    for (size_t l = 0; l < layers.size(); l++) {
+      const Linear* li = layers[l]->op_type == OP_LINEAR ? static_cast<const Linear*>(layers[l]) : nullptr;
+      if (!li) continue;
+      const double m = (double)li->in_channels * li->out_channels;
+      if (m > best) { best = m; big_dw_layer = (int)l; }
+    }
+  }
+
   // ---- 4d. exchange mode: the feature Concat's backward folded into the layer above it ----------
   // There the embedding gradients have to reach the all-to-all send buffer, which Concat::backward does with a pack
   // kernel on the critical stream.  The Linear that consumes the Concat can store each column of its data gradient where
@@ -2294,7 +2320,7 @@ void FFModel::backward(int _seq_length) {
   z_free_recorded = false;
   auto mark_z_free = [&](int l) {     // behind the last reader of the gather's destination among the forked weight-gradient GEMMs
     if (l == z_reader_layer && dw_forked && !dw_worker && capturing_trace < 0) {
-      check(api->ffh_event_record(ctx, ev_z_free, dw_stream), "z free");
+      check(api->ffh_event_record(ctx, ev_z_free, (l == big_dw_layer || !config.two_dw_streams) ? dw_stream : dw_stream2), "z free");   // the stream that layer's dW is on
       z_free_recorded = true;
     }
   };
@@ -2361,16 +2387,28 @@ void FFModel::update() {
   if (!sgd && !adam) die("update(): unknown optimizer");
   // every rank must issue its collectives in the same order: the side thread's all-to-all (backward) first
   if (side_worker) side_worker->drain();
-  if (dw_forked && !dw_worker && !api->ffh_second_stream_used(ctx, 1) && !dw_stream_used_directly) dw_forked = false;   // the library kept everything on `stream`
+  if (dw_forked && !dw_worker && !api->ffh_second_stream_used(ctx, 1) && !dw_stream_used_directly) { dw_forked = false; dw1_used = dw2_used = false; }   // the library kept everything on `stream`
   dw_stream_used_directly = false;
   if (dw_forked) {   // the weight-gradient GEMMs ran on their own stream: join before the gradients are consumed
-    if (dw_worker) dw_worker->drain();
-    check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");
-    check(api->ffh_stream_wait_event(ctx, stream, ev_dw_done), "join dw");
+    if (dw_worker) { dw_worker->drain(); dw1_used = true; }
+    if (dw1_used) {
+      check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");
+      check(api->ffh_stream_wait_event(ctx, stream, ev_dw_done), "join dw");
+    }
+    if (dw2_used) {
+      check(api->ffh_event_record(ctx, ev_dw2_done, dw_stream2), "join dw");
+      check(api->ffh_stream_wait_event(ctx, stream, ev_dw2_done), "join dw");
+    }
     // the next gather (side stream) overwrites embedding outputs that alias the Concat output -- the x operand of the first
     // top-MLP layer, which a forked dW GEMM may still be reading: write-after-read across streams
-    if (config.overlap_embedding && !embeddings.empty() && !use_workers())
-      check(api->ffh_stream_wait_event(ctx, side_stream, z_free_recorded ? ev_z_free : ev_dw_done), "join dw (embedding stream)");
+    if (config.overlap_embedding && !embeddings.empty() && !use_workers()) {
+      if (z_free_recorded) check(api->ffh_stream_wait_event(ctx, side_stream, ev_z_free), "join dw (embedding stream)");
+      else {
+        if (dw1_used) check(api->ffh_stream_wait_event(ctx, side_stream, ev_dw_done), "join dw (embedding stream)");
+        if (dw2_used) check(api->ffh_stream_wait_event(ctx, side_stream, ev_dw2_done), "join dw (embedding stream)");
+      }
+    }
+    dw1_used = dw2_used = false;
     dw_forked = false;
   }
   // data-parallel MLP gradients: ONE bucket [ref: one ncclAllReduce per tensor, src/runtime/optimizer_kernel.cu:170-171].
@@ -2446,6 +2484,7 @@ void FFModel::sync() {
   check(api->ffh_stream_sync(ctx, stream), "sync");
   check(api->ffh_stream_sync(ctx, side_stream), "sync");
   check(api->ffh_stream_sync(ctx, dw_stream), "sync");
+  check(api->ffh_stream_sync(ctx, dw_stream2), "sync");
 }
 
 PerfMetrics FFModel::get_perf_metrics() {
