@@ -32,7 +32,6 @@ struct ffh_ctx {
   // one flag per slot; the first set is allocated with the ctx, further ones when another stream first launches such a GEMM
   struct { void* stream; float* slots; unsigned* flags; } sk_sets[4];
   int         sk_nsets;
-  unsigned    sk_epoch;
   const void* emb_sorted_ws;     // ffh_embedding_bwd_sort_multi left a sorted list (and cleared fold counters) in THIS workspace ...
   int64_t     emb_sorted_sig[4]; // ... for this (ntables, in_dim, out_dim, batch): ffh_embedding_bwd_sgd_apply_multi consumes it, once
   char        route[256]; // ffh_linear_last_route(): kernel families of the latest ffh_linear_* call

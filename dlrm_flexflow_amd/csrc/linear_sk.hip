@@ -64,10 +64,10 @@ struct SkArgs {
   int act;
   unsigned a_bytes, b_bytes, bias_bytes, mask_bytes;     // extents for the buffer descriptors (0: operand absent -> loads return 0)
   // SPLIT (stream-K forward / data gradient): partial tiles of the workgroups that continue a tile another one began -- slot r =
-  // range r's 128 x 128 accumulators in lane order -- and one flag per slot, set to `sk_epoch` when the slot is written
+  // range r's 128 x 128 accumulators in lane order -- and one flag per slot: 1 when the slot is written, cleared by the workgroup
+  // that consumed it (so a launch finds every flag 0, also when it is a node of a replayed hipGraph: no per-launch argument)
   float*    sk_slots;
   unsigned* sk_flags;
-  unsigned  sk_epoch;
 };
 
 template <int... I, class F>
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
             }
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
-          if (tid == 0) __hip_atomic_store(g.sk_flags + rng, g.sk_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (tid == 0) __hip_atomic_store(g.sk_flags + rng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           store_tile = false;
         } else {
           // the tile's head: add the partials of the following ranges, in k order, then the ordinary epilogue
@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
             const unsigned b2 = r2 * ipw;
             const unsigned e2 = b2 + ipw < total_it ? b2 + ipw : total_it;
             const unsigned len = (e2 - b2) < rem ? (e2 - b2) : rem;
-            while (__hip_atomic_load(g.sk_flags + r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.sk_epoch) __builtin_amdgcn_s_sleep(2);
+            while (__hip_atomic_load(g.sk_flags + r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
+            __syncthreads();            // every wave has seen the flag: clear it for the next launch on this stream (which starts behind this one)
+            if (tid == 0) __hip_atomic_store(g.sk_flags + r2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const u64* slot = reinterpret_cast<const u64*>(g.sk_slots + (size_t)r2 * (SK_BM * SK_BN));
 #pragma unroll
             for (int tm = 0; tm < 4; tm++)
@@ -508,7 +510,7 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   a.a_bytes = (unsigned)a_bytes; a.b_bytes = (unsigned)b_bytes;
   a.bias_bytes = g.bias ? (unsigned)g.N * 4u : 0u;
   a.mask_bytes = g.mask ? 1u : 0u;
-  if (p.split) { a.sk_slots = slots; a.sk_flags = flags; a.sk_epoch = ++c->sk_epoch; if (a.sk_epoch == 0) a.sk_epoch = ++c->sk_epoch; }
+  if (p.split) { a.sk_slots = slots; a.sk_flags = flags; }
   // The kernels need more than 64 KB of dynamic LDS; hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of the
   // function, and one process may hold a ctx per device (ffh_ctx_default): set once per (kernel, device).  A launch that still
   // fails (attribute refused, no such resources) is not an error of the call: 0 = "not served", linear.hip's kernels take the layer.

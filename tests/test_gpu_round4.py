@@ -553,3 +553,21 @@ def test_exchange_step_captured_as_a_graph_equals_eager_bit_for_bit(hip, tmp_pat
     for k in outs[1].files:
         if k.startswith("p") or k == "pred":
             assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+
+
+def test_stream_k_split_routes_under_graph_replay(hip):
+    """The SPLIT GEMMs' cross-workgroup flags carry no per-launch argument (the consumer clears them), so a captured step replays
+    correctly: the headline model at 4096 samples (3456->1024's dX and 1024->512's forward take the stream-K route there), four
+    steps replayed from a hipGraph against four eager steps."""
+    rows = [min(r, 2000) for r in TERABYTE_ROWS]
+    outs = []
+    for trace in (True, False):
+        app = ffmodel.DLRM(["--backend", HIP] + TB_ARGS(rows, 4096) + ([] if trace else ["--no-trace"]))
+        app.warmup(); app.train_steps(4, trace=trace); app.model.sync()
+        assert bool(app.model.uses_graph) == trace
+        rec = _weights(app.model)
+        rec["pred"] = app.model.layer_output(app.model.num_layers - 1).get()
+        outs.append(rec)
+        app.close()
+    for k in outs[0]:
+        np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=2e-5, atol=2e-6, err_msg=k)
