@@ -105,7 +105,8 @@ class FFConfig {
   bool deterministic;          // --deterministic: weight / bias gradients without fp atomics (ffh_ctx_set_deterministic): bit-identical runs
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
-  bool two_dw_streams;               // (A/B: --one-dw-stream) the biggest layer's weight-gradient GEMM on a stream of its own
+  int  big_dw_mode;                  // A/B: 0 the biggest layer's dW beside its dX (default), 1 forked behind its dX, 2 before its dX on the compute stream
+  bool two_dw_streams;               // (A/B: --two-dw-streams, off) the biggest layer's weight-gradient GEMM on a stream of its own
   int  defer_big_dw;                 // --defer-big-dw (A/B, default 0): the biggest layer's weight gradient is issued last instead of beside its data gradient
   bool bf16_twins, force_async_launch;   // --no-bf16-twins / --force-async-launch (A/B and test switches; they used to be environment variables)
   bool capture_exchange;             // --capture-exchange: world_size > 1 with collectives enqueued from C++ (RcclComm): the step is captured / replayed as a hipGraph

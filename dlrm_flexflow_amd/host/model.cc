@@ -139,7 +139,8 @@ FFConfig::FFConfig() {
   bf16_twins = true;
   force_async_launch = false;
   defer_big_dw = 0;
-  two_dw_streams = true;
+  two_dw_streams = false;      // measured in round 4: no gain (1.183-1.189 vs 1.184-1.188 ms at 4096 samples; MLPerf shape 1.29 vs 1.27: worse)
+  big_dw_mode = 0;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
@@ -206,6 +207,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--force-async-launch")) { force_async_launch = true; continue; }   // tests: the launch-worker threads on a synchronous backend
     if (is("--defer-big-dw")) { defer_big_dw = 1; continue; }
     if (is("--one-dw-stream")) { two_dw_streams = false; continue; }
+    if (is("--two-dw-streams")) { two_dw_streams = true; continue; }
+    if (is("--big-dw-mode")) { big_dw_mode = atoi(next()); continue; }
     if (is("--no-defer-big-dw")) { defer_big_dw = 0; continue; }
     if (is("--sparse-embedding-optimizer")) { sparse_embedding_optimizer = true; continue; }
   }
@@ -693,6 +696,11 @@ void Linear::backward_part(const FFModel& ff, int part) {
   if (part == 1) {
     ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                        flags | FFH_LINEAR_ONLY_DX, ff.stream, nullptr), name);
+    return;
+  }
+  if (part == 3) {      // the weight / bias gradient on the compute stream itself (A/B: --big-dw-mode 2)
+    ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, nullptr, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
+                                       flags | FFH_LINEAR_ONLY_DW, ff.stream, nullptr), name);
     return;
   }
   if (part == 2) {
@@ -2364,6 +2372,15 @@ void FFModel::backward(int _seq_length) {
       up->pair_lower = nullptr;                                // not a shape the pair launch serves: the ordinary calls from now on
     }
     if (l == defer_layer && up) { up->backward_part(*this, 1); deferred = up; continue; }
+    if (up && config.big_dw_mode && l == big_dw_layer && defer_layer < 0 && !up->discard_input_grad && !(up->activation == AC_MODE_RELU && !up->dy_premasked) &&
+        up->activation != AC_MODE_SIGMOID && !config.profiling && !use_workers() && !config.deterministic) {
+      // A/B (--big-dw-mode): 1 = the biggest layer's dW forked BEHIND its dX (the two persistent GEMMs do not share the chip);
+      //                      2 = dW first, then dX, both on the compute stream
+      if (config.big_dw_mode == 1) { up->backward_part(*this, 1); up->backward_part(*this, 2); }
+      else { up->backward_part(*this, 3); up->backward_part(*this, 1); }
+      mark_z_free(l);
+      continue;
+    }
     layers[l]->backward(*this);
     mark_z_free(l);
   }

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the judged artefacts under profiles/ on one GPU box.  Outputs land in gpurun_out/refresh/ with their final
-# names (r03_*); copy them into profiles/ afterwards.   gpurun --timeout 3300 -- 'bash tools/refresh_profiles.sh'
+# names (r04_*); copy them into profiles/ afterwards.   gpurun --timeout 3300 -- 'bash tools/refresh_profiles.sh'
 R=$(pwd); O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $R
-P=${P:-r03}
+P=${P:-r04}
 line() { grep '^{' | tail -1; }
 
 # 0. HBM traffic of the embedding kernels first (two counter-only passes): the bench lines below quote it, and warn when the file on
@@ -37,6 +37,14 @@ python3 bench.py --workload giant --steps 100 --warmup 10 --no-cpu-baseline --no
 python3 bench.py --force-exchange --steps 30 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | line > $O/${P}_bench_terabyte_exchange_1rank.json
 python3 bench.py --workload kaggle --force-exchange --steps 300 --warmup 30 --no-cpu-baseline --no-secondary 2>/dev/null | line > $O/${P}_bench_kaggle_exchange_1rank.json
 python3 bench.py --per-gpu-batch 4096 --steps 100 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | line > $O/${P}_bench_terabyte_b4096.json
+python3 bench.py --per-gpu-batch 4096 --steps 100 --warmup 10 --no-cpu-baseline --no-secondary --force-exchange 2>/dev/null | line > $O/${P}_bench_terabyte_b4096_exchange_1rank.json
+# ... and its kernel timelines (the per-rank step of the 8-GPU job), plain and exchange-forced
+for v in plain exchange; do
+  F=""; [ $v = exchange ] && F="--force-exchange"
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_b4096_$v -- python3 bench.py --per-gpu-batch 4096 --steps 30 --warmup 5 --no-cpu-baseline --no-secondary $F > /dev/null 2>&1
+  T=$(find $O/prof_b4096_$v -name "*kernel_trace.csv" | head -1); python3 tools/trace_summary.py $T > $O/${P}_terabyte_b4096_${v}_step_timeline.txt
+  find $O/prof_b4096_$v -name "*.csv" -size +10M -delete
+done
 
 # 5. hipGraph replay against eager launches, one step each
 for mode in graph eager; do
@@ -49,7 +57,7 @@ for mode in graph eager; do
 done
 
 # 6. GEMM microbenchmarks: fp32 kernels next to hipBLASLt (torch.mm) in one process; fp32 vs tensor-op (bf16) mode; the lab
-python3 tools/gemm_big.py -1 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_vs_hipblaslt.txt
+python3 tools/gemm_big.py -1 32768x3456x1024 32768x1024x1024 32768x1024x512 4096x3456x1024 4096x1024x1024 4096x1024x512 4096x512x256 8192x512x1024 8192x479x1024 8192x1024x1024 8192x1024x512 8192x512x256 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_vs_hipblaslt.txt
 python3 tools/gemm_bf16_bench.py 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_bf16_mode.txt
 # the lab binary is built here from its source (never committed)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_big_lab.hip -lrocblas -o tools/lab/gemm_big_lab 2> $O/lab_build.err && timeout 300 tools/lab/gemm_big_lab 32768 1024 3456 > $O/${P}_lab_gemm_big.txt 2>&1
