@@ -85,6 +85,7 @@ _SIGS = {
     "ffh_ctx_set_workspace": (I, [P, P, SZ]),
     "ffh_ctx_set_math_mode": (I, [P, I]),
     "ffh_ctx_set_deterministic": (I, [P, I]),
+    "ffh_ctx_set_dw_cu_reserve": (I, [P, I]),
     "ffh_ctx_bf16_mirror_set": (I, [P, P, SZ, P]),
     "ffh_convert_f32_to_bf16": (I, [P, P, P, L, P]),
     "ffh_malloc": (I, [P, C.POINTER(P), SZ]),

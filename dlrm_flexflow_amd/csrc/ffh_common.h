@@ -24,6 +24,7 @@ struct ffh_ctx {
   void*       scatter_event;        // hipEvent_t attached to the launch that takes the map (else dropped)
   void*       attach_event;         // ffh_event_record_with_next_linear_bwd(): hipEvent_t to signal behind the next backward's last kernel
   int         deterministic;   // ffh_ctx_set_deterministic(): no fp atomics in weight / bias gradients
+  int         dw_cu_reserve;   // ffh_ctx_set_dw_cu_reserve(): CUs the persistent weight-gradient GEMMs leave free
   int         math_mode; // ffh_ctx_set_math_mode(): FFH_MATH_DEFAULT | FFH_MATH_TENSOR_OP_BF16
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
   ffh_mirror_region mirrors[32];   // bf16 twins of fp32 buffers (tensor-op mode)

@@ -446,6 +446,7 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
   p.b_bytes = ((bkr ? (int64_t)(g.K - 1) : (int64_t)(g.N - 1)) * p.ldb + (bkr ? g.N : g.K)) * 4;
   if (p.a_bytes >= (1LL << 32) || p.b_bytes >= (1LL << 32)) return false;  // 32-bit buffer offsets
   p.G = c->num_cus & ~7;
+  if (form == SK_FORM_DW && c->dw_cu_reserve > 0 && p.G - c->dw_cu_reserve >= 64) p.G -= c->dw_cu_reserve;     // ffh_ctx_set_dw_cu_reserve
   if (p.G < 8) return false;
   const int64_t ntiles = (int64_t)(g.M / SK_BM) * (g.N / SK_BN), nk = g.K / SK_BK;
   if (ntiles * nk >= (1LL << 31)) return false;

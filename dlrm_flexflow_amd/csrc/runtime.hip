@@ -87,6 +87,12 @@ int ffh_ctx_set_math_mode(ffh_ctx* c, int mode) {
   return FFH_OK;
 }
 
+int ffh_ctx_set_dw_cu_reserve(ffh_ctx* c, int ncus) {
+  if (!c || ncus < 0 || ncus >= c->num_cus) return FFH_ERR_BAD_ARG;
+  c->dw_cu_reserve = ncus / 8 * 8;
+  return FFH_OK;
+}
+
 int ffh_ctx_bf16_mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* twin) {
   if (!c || !base || bytes == 0 || ((uintptr_t)base & 15) || ((uintptr_t)twin & 15)) return FFH_ERR_BAD_ARG;
   int at = -1;

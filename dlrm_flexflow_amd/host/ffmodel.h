@@ -105,6 +105,7 @@ class FFConfig {
   bool deterministic;          // --deterministic: weight / bias gradients without fp atomics (ffh_ctx_set_deterministic): bit-identical runs
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
+  int  dw_cu_reserve;                // --dw-cu-reserve N: CUs the biggest layer's persistent weight-gradient GEMM leaves free (-1: by per-GPU batch)
   int  big_dw_mode;                  // A/B: 0 the biggest layer's dW beside its dX (default), 1 forked behind its dX, 2 before its dX on the compute stream
   bool two_dw_streams;               // (A/B: --two-dw-streams, off) the biggest layer's weight-gradient GEMM on a stream of its own
   int  defer_big_dw;                 // --defer-big-dw (A/B, default 0): the biggest layer's weight gradient is issued last instead of beside its data gradient
@@ -502,6 +503,7 @@ class FFModel {
   mutable bool dw1_used = false, dw2_used = false;   // which weight-gradient stream(s) this step's forks were offered (joined in update())
   mutable bool dw_stream_used_directly = false;   // a weight gradient was enqueued on dw_stream by this layer itself (deferred dW), not by the library's fork
   int defer_big_dw_layer() const;
+  int dw_cu_reserve_for(int64_t batch) const;
   mutable bool mlp_grads_clean;   // the optimizer kernel cleared the MLP gradient slab (FFH_OPT_ZERO_GRAD): zero_gradients() skips it
   LaunchWorker *dw_worker, *side_worker;   // NULL: launches are issued inline by the calling thread
   std::vector<ffh_event> layer_events;     // one per layer: "dY of this layer is ready"

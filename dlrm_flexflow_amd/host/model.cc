@@ -141,6 +141,7 @@ FFConfig::FFConfig() {
   defer_big_dw = 0;
   two_dw_streams = false;      // measured in round 4: no gain (1.183-1.189 vs 1.184-1.188 ms at 4096 samples; MLPerf shape 1.29 vs 1.27: worse)
   big_dw_mode = 0;
+  dw_cu_reserve = -1;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
@@ -209,6 +210,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--one-dw-stream")) { two_dw_streams = false; continue; }
     if (is("--two-dw-streams")) { two_dw_streams = true; continue; }
     if (is("--big-dw-mode")) { big_dw_mode = atoi(next()); continue; }
+    if (is("--dw-cu-reserve")) { dw_cu_reserve = atoi(next()); continue; }
     if (is("--no-defer-big-dw")) { defer_big_dw = 0; continue; }
     if (is("--sparse-embedding-optimizer")) { sparse_embedding_optimizer = true; continue; }
   }
@@ -739,8 +741,14 @@ void Linear::backward_part(const FFModel& ff, int part) {
   // them, after it (4096 samples: ~80 of the 130 us between the end of that GEMM and the next top-MLP forward).
   ffh_stream dws = layer_index == ff.big_dw_layer ? ff.dw_stream : ff.dw_stream2;
   if (!ff.config.two_dw_streams) dws = ff.dw_stream;
+  // The biggest layer's weight-gradient GEMM leaves a few CUs without one of its persistent workgroups when the small dependent
+  // kernels that run beside it (the bottom MLP's backward chain, the table update, the next gather) are a large share of the step --
+  // small per-GPU batches; see ffh_ctx_set_dw_cu_reserve and FFConfig::dw_cu_reserve.
+  const int reserve = (fork && layer_index == ff.big_dw_layer) ? ff.dw_cu_reserve_for(b) : 0;
+  if (reserve > 0) ff.check(ff.api->ffh_ctx_set_dw_cu_reserve(ff.ctx, reserve), "dw cu reserve");
   ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                      flags, ff.stream, fork ? dws : nullptr), name);
+  if (reserve > 0) ff.check(ff.api->ffh_ctx_set_dw_cu_reserve(ff.ctx, 0), "dw cu reserve");
   if (fork) { ff.dw_forked = true; (dws == ff.dw_stream ? ff.dw1_used : ff.dw2_used) = true; }
 }
 
@@ -1356,6 +1364,11 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
   // is captured and replayed as one hipGraph, as the reference wraps every iteration in a Legion trace on any GPU count
   // [ref: examples/cpp/DLRM/dlrm.cc:174-181].  Behind a flag until a multi-GPU box has measured it.
   if (exchange && config.enable_graph && !(config.capture_exchange && config.comm.nonblocking)) config.enable_graph = false;
+  // Measured on ROCm 7.0 (the runtime torch bundles): hipStreamEndCapture recurses without end (174,586 frames of
+  // hip::Stream::EndCapture, profiles/r04_capture_exchange_endcapture_backtrace.txt) when RCCL's grouped send / recv were captured
+  // on a stream that itself joined the capture through an event -- the side stream of the overlapped gather.  With the collectives
+  // on the capturing stream itself the capture works, so a captured exchange step runs its embedding branch on the compute stream.
+  if (exchange && config.enable_graph && config.capture_exchange) config.overlap_embedding = false;
   if (dynamic_cast<AdamOptimizer*>(optimizer) && config.enable_graph) config.enable_graph = false;   // alpha_t is a new launch argument every step
   // Any optimizer x any placement (round 4).  Plain SGD: the fused sorted-segments update.  Momentum / weight-decay SGD, Adam:
   // by default the reference's own path on the rank(s) that hold the table -- an owner-local dense gradient (zeroed, scatter-added
@@ -1990,6 +2003,11 @@ int FFModel::defer_big_dw_layer() const {
   }
   if (best < 0 || best == (int)layers.size() - 1) return -1;
   return best;
+}
+
+int FFModel::dw_cu_reserve_for(int64_t batch) const {
+  if (config.dw_cu_reserve >= 0) return config.dw_cu_reserve;
+  return 0;       // (auto rule: set from measurements, FFConfig::dw_cu_reserve)
 }
 
 void FFModel::probe_record(int which, ffh_stream s, ffh_ctx* cx) const {

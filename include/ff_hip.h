@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 8   /* 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 9   /* 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -178,6 +178,13 @@ int         ffh_convert_f32_to_bf16(ffh_ctx* ctx, void* dst_bf16, const float* s
  * the speed: a debugging mode for diffing two runs, the GPU counterpart of comparing against the sequential oracle.
  * (The embedding kernels are deterministic in both modes: their order is part of the ABI, FFH_EMB_CHUNK.) */
 int         ffh_ctx_set_deterministic(ffh_ctx* ctx, int on);
+/* Persistent weight-gradient GEMMs (one workgroup per CU for hundreds of microseconds) launched after this call leave `ncus` CUs
+ * of the device without a workgroup (0: none, the default; rounded to a multiple of 8: one per XCD).  No reference counterpart -- a
+ * scheduling hint of the kind Legion's mapper gives the reference: kernels that run BESIDE such a GEMM on other streams (the bottom
+ * MLP's backward chain, the table update) are 5-10x slower on CUs they share with it than alone; a caller that knows such work is
+ * pending trades a few percent of the GEMM for it.  Results do not depend on it beyond the stream-K partition (the usual fp32
+ * summation-order bound).  Returns FFH_ERR_BAD_ARG for ncus < 0 or >= the device's CU count. */
+int         ffh_ctx_set_dw_cu_reserve(ffh_ctx* ctx, int ncus);
 
 /* memory / streams / events / graphs: what Legion+Realm provide to the
  * reference ops (regions, get_legion_stream [ref: src/runtime/cuda_helper.cu:5-31],
@@ -561,7 +568,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
  * FFModel shim and by tests/test_abi_symbols.py). */
 #define FFH_API_LIST(X) \
   X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) X(ffh_ctx_default) \
-  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) X(ffh_ctx_bf16_mirror_set) X(ffh_convert_f32_to_bf16) \
+  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) X(ffh_ctx_set_dw_cu_reserve) X(ffh_ctx_bf16_mirror_set) X(ffh_convert_f32_to_bf16) \
   X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
   X(ffh_stream_create) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
   X(ffh_event_create) X(ffh_event_create_sync) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \

@@ -539,7 +539,9 @@ def test_exchange_step_captured_as_a_graph_equals_eager_bit_for_bit(hip, tmp_pat
     """with RcclComm the collectives are stream enqueues from C++, so the per-rank step of a multi-rank job --
     kernels, both all-to-alls, the all-reduce, the side-stream branches -- can be captured and replayed as one hipGraph
     (--capture-exchange), as the reference traces every iteration on any GPU count [ref: examples/cpp/DLRM/dlrm.cc:174-181].  One
-    forced RCCL rank, Kaggle shape, three steps under --deterministic: the replayed run must leave the bits of the eager one."""
+    forced RCCL rank, Kaggle shape, three steps under --deterministic: the replayed run must leave the bits of the eager one.
+    (The captured step keeps its embedding branch on the compute stream: with RCCL captured on a stream that joined the capture by
+    an event, ROCm 7.0's hipStreamEndCapture recurses without end -- profiles/r04_capture_exchange_endcapture_backtrace.txt.)"""
     worker = os.path.join(ROOT, "tests", "_dist_worker_gpu.py")
     outs = []
     for mode, flags in (("kaggle-graph", ["--capture-exchange", "--deterministic"]), ("kaggle", ["--deterministic", "--no-trace"])):
