@@ -2005,9 +2005,11 @@ int FFModel::defer_big_dw_layer() const {
   return best;
 }
 
-int FFModel::dw_cu_reserve_for(int64_t batch) const {
-  if (config.dw_cu_reserve >= 0) return config.dw_cu_reserve;
-  return 0;       // (auto rule: set from measurements, FFConfig::dw_cu_reserve)
+// Measured in round 4 (profiles/r04_ab_schedule.txt): every CU taken from the GEMM costs more than the kernels beside it gain -- plain
+// step at 4096 samples 1.186 / 1.199 / 1.210 / 1.226 / 1.239 ms for 0 / 16 / 32 / 48 / 64 CUs, 32768 samples 7.87 / 8.00 / 8.08; only the
+// exchange-forced step (RCCL's copy kernels run beside that GEMM) gains 1 % at 32.  Default: none.
+int FFModel::dw_cu_reserve_for(int64_t) const {
+  return config.dw_cu_reserve > 0 ? config.dw_cu_reserve : 0;
 }
 
 void FFModel::probe_record(int which, ffh_stream s, ffh_ctx* cx) const {
