@@ -46,6 +46,14 @@ def test_hip_library_exports_every_symbol():
     assert 26 * 32768 * 16 <= n < 64 << 20
 
 
+def test_release_library_reads_no_environment_variable():
+    """A/B switches exist only in -DFFH_LAB builds (tools/build_variant.sh): the shipped kernel library and the host shim's way to
+    it import no getenv, so its behaviour is a function of the C-ABI arguments and the ctx setters alone."""
+    from dlrm_flexflow_amd import build
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", build.build_hip()], text=True)
+    assert not re.search(r"\b(secure_)?getenv\b", und), [l for l in und.splitlines() if "getenv" in l]
+
+
 def test_oracle_library_exports_every_symbol(oracle):
     exp = _exported(oracle.ORACLE_LIB)
     missing = [s for s in capi.header_symbols() if s not in exp]
