@@ -135,6 +135,8 @@ _SIGS = {
     "ffh_event_record_with_next_linear_bwd": (I, [P, P]),
     "ffh_linear_bwd_set_dx_scatter": (I, [P, P, I, P]),
     "ffh_linear_dx_scatter_used": (I, [P]),
+    "ffh_linear_bwd_set_dx_colsum": (I, [P, P, I]),
+    "ffh_linear_dx_colsum_used": (I, [P]),
     "ffh_mse_bwd_metrics": (I, [P, P, P, P, P, L, I, F, I, P]),
     "ffh_concat_fwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),
     "ffh_concat_bwd": (I, [P, P, L, C.POINTER(P), C.POINTER(L), C.POINTER(L), I, L, P]),

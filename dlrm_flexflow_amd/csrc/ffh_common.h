@@ -22,6 +22,8 @@ struct ffh_ctx {
   const void* scatter_map;          // ffh_linear_bwd_set_dx_scatter(): ffh_col_dest[scatter_ncols] in device memory, or NULL
   int         scatter_ncols, scatter_used;
   void*       scatter_event;        // hipEvent_t attached to the launch that takes the map (else dropped)
+  float*      colsum_dst;           // ffh_linear_bwd_set_dx_colsum(): pending for the next ffh_linear_bwd*, or NULL
+  int         colsum_ncols, colsum_used;
   void*       attach_event;         // ffh_event_record_with_next_linear_bwd(): hipEvent_t to signal behind the next backward's last kernel
   int         deterministic;   // ffh_ctx_set_deterministic(): no fp atomics in weight / bias gradients
   int         dw_cu_reserve;   // ffh_ctx_set_dw_cu_reserve(): CUs the persistent weight-gradient GEMMs leave free

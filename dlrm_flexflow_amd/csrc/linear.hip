@@ -1730,6 +1730,9 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     // ffh_linear_bwd_set_dx_scatter: the persistent data-gradient kernel takes the column map in its epilogue (SK_EPI_DX_CMAP)
     const bool scatter_sk = want_dx && scatter_pending && !c->deterministic;
     if (scatter_sk) gx.colmap = (const ffh_col_dest*)c->scatter_map;
+    // ffh_linear_bwd_set_dx_colsum: the lower layer's bias gradient from this kernel's store epilogue
+    const bool colsum_sk = want_dx && c->colsum_dst && c->colsum_ncols == in && gx.epi == EPI_STORE && !scatter_pending && !c->deterministic;
+    if (colsum_sk) gx.colsum = c->colsum_dst;
     bool ok = (do_dw || want_dx) && !(relu_live && !do_dw) && !(want_dx && scatter_pending && !scatter_sk);
     if (ok && do_dw) ok = gemm_sk_serves(c, gw, SK_FORM_DW);
     if (ok && want_dx) ok = gemm_sk_serves(c, gx, SK_FORM_DX);
@@ -1752,6 +1755,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       if (want_dx) {
         const int rc = launch_gemm_sk(c, gx, SK_FORM_DX, s, "linear_bwd dx gemm");
         if (rc < 0) return rc;
+        if (rc == 1 && colsum_sk) c->colsum_used = 1;
         if (rc == 1 && scatter_sk) {
           c->scatter_used = 1;
           if (c->scatter_event) FFH_HIP_TRY(c, hipEventRecord((hipEvent_t)c->scatter_event, as_stream(s)));   // "gradients ready" behind the kernel that produced them
@@ -1870,10 +1874,10 @@ extern "C" {
 int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
                       float* dy, int64_t lddy, const float* w, float* dw, float* db,
                       int in, int out, int64_t batch, int act, int flags, ffh_stream s, ffh_stream s_dw) {
-  if (c) c->scatter_used = 0;
+  if (c) { c->scatter_used = 0; c->colsum_used = 0; }
   ffh_route_clear(c);
   const int rc = linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, s_dw, nullptr, 0.0f, nullptr, 0);
-  if (c) { c->scatter_map = nullptr; c->scatter_event = nullptr; }       // one call only, taken or not
+  if (c) { c->scatter_map = nullptr; c->scatter_event = nullptr; c->colsum_dst = nullptr; }       // one call only, taken or not
   if (c && c->attach_event) {        // no launch could carry it: the ordinary record behind everything this call put on s
     hipEvent_t ev = (hipEvent_t)c->attach_event;
     c->attach_event = nullptr;
@@ -1888,6 +1892,13 @@ int ffh_linear_bwd_set_dx_scatter(ffh_ctx* c, const ffh_col_dest* map, int ncols
   return FFH_OK;
 }
 int ffh_linear_dx_scatter_used(ffh_ctx* c) { return c ? c->scatter_used : 0; }
+
+int ffh_linear_bwd_set_dx_colsum(ffh_ctx* c, float* colsum, int ncols) {
+  if (!c || !colsum || ncols <= 0) return FFH_ERR_BAD_ARG;
+  c->colsum_dst = colsum; c->colsum_ncols = ncols; c->colsum_used = 0;
+  return FFH_OK;
+}
+int ffh_linear_dx_colsum_used(ffh_ctx* c) { return c ? c->colsum_used : 0; }
 
 int ffh_event_record_with_next_linear_bwd(ffh_ctx* c, ffh_event e) {
   if (!c || !e) return FFH_ERR_BAD_ARG;
@@ -1904,7 +1915,10 @@ int ffh_linear_bwd_mse(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64
   if (ldy != out || lddy != out) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: y and dy must be contiguous [batch][out_dim]");
   if (batch == 0) return FFH_OK;
   ffh_route_clear(c);
-  return linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, nullptr, label, scale, perf, metrics_flags);
+  c->colsum_used = 0;
+  const int rc = linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, flags, s, nullptr, label, scale, perf, metrics_flags);
+  c->colsum_dst = nullptr;             // ffh_linear_bwd_set_dx_colsum: one call only, taken or not (this launch never takes it)
+  return rc;
 }
 
 int ffh_linear_pair_fwd(ffh_ctx* c, const float* x_l, int64_t ldx_l, const float* w_l, const float* b_l, int in_l, int act_l,

@@ -34,6 +34,8 @@ struct GemmArgs {
   int64_t      ldmask;
   // CMAP kernels (dX of the layer above a Concat, ffh_linear_bwd_set_dx_scatter): column n of C lives at colmap[n].base[m * colmap[n].ld]
   const ffh_col_dest* colmap;
+  // persistent dX kernel, plain store epilogue (ffh_linear_bwd_set_dx_colsum): colsum[n] += sum_m C[m][n] as stored, or null
+  float* colsum;
   // tensor-op mode with bf16 twins (ffh_ctx_bf16_mirror_set): the operands' twins (same element strides; both or neither) and
   // the twin the epilogue writes beside C (or null)
   const unsigned short* A16;

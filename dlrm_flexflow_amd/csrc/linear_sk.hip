@@ -59,6 +59,8 @@ struct SkArgs {
   const float* mask;           // DX: C = mask[m][n] > 0 ? v : 0 (relu' of the layer below) or null
   const ffh_col_dest* colmap;  // DX_CMAP (ffh_linear_bwd_set_dx_scatter): column n of C lives at colmap[n].base[m * colmap[n].ld] -- the exchange
                                // path's first top layer stores its data gradient into the bottom MLP's gradient and the all-to-all send buffer
+  float*       colsum;         // DX_STORE (ffh_linear_bwd_set_dx_colsum): colsum[n] += sum over the tile's rows of what is stored -- the bias
+                               // gradient of the layer below, whose dy this C is -- or null
   int64_t lda, ldb, ldc, ldmask;
   int M, N, K;
   int act;
@@ -323,6 +325,8 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
         if (!cvec) { cd1 = g.colmap[nn + 1]; cd2 = g.colmap[nn + 2]; }
       }
       f32x4 mk[4][4], cold[4][4];
+      f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};     // DX_STORE with g.colsum: this lane's four columns summed over its 16 rows
+      (void)csum;
       if constexpr (EPI == SK_EPI_DX_STORE || EPI == SK_EPI_DX_ADD) {
 #pragma unroll
         for (int tm = 0; tm < 4; tm++)
@@ -364,9 +368,18 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
               v.x = m4.x > 0.0f ? v.x : 0.0f; v.y = m4.y > 0.0f ? v.y : 0.0f; v.z = m4.z > 0.0f ? v.z : 0.0f; v.w = m4.w > 0.0f ? v.w : 0.0f;
             }
             if constexpr (EPI == SK_EPI_DX_ADD) v += cold[tm][i];
+            if constexpr (EPI == SK_EPI_DX_STORE) csum += v;
             *reinterpret_cast<f32x4*>(cptr) = v;
           }
         }
+      if constexpr (EPI == SK_EPI_DX_STORE) {
+        if (g.colsum) {            // uniform: the lane's 16 rows are summed above; the four lane groups hold rows 16 q ..: fold them, one atomic per column and wave
+          f32x4 t = csum;
+#pragma unroll
+          for (int cc = 0; cc < 4; cc++) { t[cc] += __shfl_xor(t[cc], 16); t[cc] += __shfl_xor(t[cc], 32); }
+          if (q == 0) { float* dp = g.colsum + nn; atomicAdd(dp + 0, t.x); atomicAdd(dp + 1, t.y); atomicAdd(dp + 2, t.z); atomicAdd(dp + 3, t.w); }
+        }
+      }
     }
     if constexpr (EPI == SK_EPI_DW_ATOMIC) {
       // through a per-wave LDS image so that one atomic instruction covers 256 contiguous bytes of one row
@@ -505,7 +518,7 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   const int64_t lda = p.lda, ldb = p.ldb, a_bytes = p.a_bytes, b_bytes = p.b_bytes;
   const int G = p.G;
   SkArgs a{};
-  a.A = g.A; a.B = g.B; a.C = g.C; a.bias = g.bias; a.mask = g.mask; a.db = g.db; a.colmap = g.colmap;
+  a.A = g.A; a.B = g.B; a.C = g.C; a.bias = g.bias; a.mask = g.mask; a.db = g.db; a.colmap = g.colmap; a.colsum = (form == SK_FORM_DX && g.epi == EPI_STORE && !g.colmap) ? g.colsum : nullptr;
   a.lda = lda; a.ldb = ldb; a.ldc = g.ldc; a.ldmask = g.ldmask;
   a.M = g.M; a.N = g.N; a.K = g.K; a.act = g.act;
   a.a_bytes = (unsigned)a_bytes; a.b_bytes = (unsigned)b_bytes;
@@ -535,7 +548,7 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   else FFH_SK_LAUNCH(false, true, SK_EPI_DX_ADD, SK_LDS_KC + SK_LDS_KR)
 #undef FFH_SK_LAUNCH
   if (hipGetLastError() != hipSuccess) return 0;        // launch refused: nothing was enqueued, the caller falls through to linear.hip
-  { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64%s%s|wgs=%d", name, g.colmap ? "|colmap" : "", p.split ? "|streamk" : "", G); ffh_route_add(c, tok); }
+  { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64%s%s%s|wgs=%d", name, g.colmap ? "|colmap" : "", p.split ? "|streamk" : "", a.colsum ? "|colsum" : "", G); ffh_route_add(c, tok); }
   return 1;
 }
 

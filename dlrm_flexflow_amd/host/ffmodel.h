@@ -115,6 +115,7 @@ class FFConfig {
   bool sparse_embedding_optimizer;   // --sparse-embedding-optimizer: momentum / weight-decay SGD and Adam update the rows a batch touched, with per-row state, on the
                                // sorted segments of the fused update (ffh_sparse_opt: lazy semantics, a stated divergence) instead of the reference's dense sweep
   bool early_sort;             // the index-only sort of the fused table update runs behind the gather (ffh_embedding_bwd_sort_multi), off the backward's critical path (A/B: --no-early-sort)
+  bool dx_colsum;              // a layer's bias gradient from the epilogue of the data-gradient kernel of the layer above (A/B: --no-dx-colsum)
   bool dx_scatter;             // exchange mode: the layer above the feature Concat writes its dX into the send buffer itself (A/B: --no-dx-scatter)
   bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)
   bool attach_events;          // hang ev_grad_ready on the producing kernel's completion instead of a record packet (A/B: --no-attach-event)
@@ -306,6 +307,9 @@ class Linear : public Op {
   Linear* pair_lower;           // the layer below, when its data gradient rides in this layer's backward launch (ffh_linear_pair_bwd)
   int backward_pair(const FFModel&);   // FFH_OK: this layer's backward and the lower layer's whole backward are enqueued
   bool dx_mask_by_x, dy_premasked;   // relu' of the layer below applied by this layer's dX epilogue / already applied by the layer above
+  Linear* colsum_lower;         // the Linear below whose FINAL dy is the dX this layer stores: its bias gradient can come out of this layer's
+                                // data-gradient kernel (ffh_linear_bwd_set_dx_colsum, ABI 10) instead of riding on its own weight-gradient GEMM
+  bool db_from_upper;           // set by the layer above for this backward(): the bias gradient is done, the call passes db = NULL
   Initializer *kernel_initializer, *bias_initializer;
 };
 

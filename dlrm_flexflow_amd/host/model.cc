@@ -133,6 +133,7 @@ FFConfig::FFConfig() {
   attach_events = true;
   fuse_pair = true;
   dx_scatter = true;
+  dx_colsum = true;
   early_sort = true;
   pad_linear_k = true;
   capture_exchange = false;
@@ -201,6 +202,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-attach-event")) { attach_events = false; continue; }
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
+    if (is("--no-dx-colsum")) { dx_colsum = false; continue; }
     if (is("--no-early-sort")) { early_sort = false; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
     if (is("--capture-exchange")) { capture_exchange = true; continue; }
@@ -613,7 +615,7 @@ Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_
 Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activation, bool _use_bias, const Op* shared_op,
                Initializer* ki, Initializer* bi, const char* name)
     : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), in_padded(input.adim[0]), activation(_activation),
-      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), dx_map(nullptr), dx_map_concat(nullptr), pair_upper(nullptr), fwd_done_by_pair(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false),
+      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), dx_map(nullptr), dx_map_concat(nullptr), pair_upper(nullptr), fwd_done_by_pair(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false), colsum_lower(nullptr), db_from_upper(false),
       kernel_initializer(ki), bias_initializer(bi) {
   if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
   if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
@@ -693,8 +695,17 @@ void Linear::backward_part(const FFModel& ff, int part) {
   const bool fork = ff.config.parallel_dw && macs >= 1.0e8;
   const int flags = (dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0) | (dx_mask_by_x ? FFH_LINEAR_DX_MASK_BY_X : 0) | (dy_premasked ? FFH_LINEAR_DY_PREMASKED : 0);
   const float *xp = (const float*)x.impl->ptr, *yp = (const float*)y.impl->ptr, *wp = (const float*)weights[0].impl->ptr;
-  float *dyp = y.impl->grad, *dwp = weights[0].impl->grad, *dbp = use_bias ? weights[1].impl->grad : nullptr;
+  float *dyp = y.impl->grad, *dwp = weights[0].impl->grad, *dbp = (use_bias && !db_from_upper) ? weights[1].impl->grad : nullptr;
   const int64_t ldx = x.impl->ld, lddx = x.impl->grad_ld, ldy = y.impl->ld, lddy = y.impl->grad_ld;
+  if (part != 1) db_from_upper = false;      // consumed by the call below that produces dW / db (part 1 is followed by a part 2 / 3 of this layer)
+  // the lower layer's bias gradient rides on this call's data-gradient kernel where the library takes it
+  struct ColsumScope {
+    const FFModel& ff; Linear* lo;
+    ColsumScope(const FFModel& f, Linear* l, bool produces_dx) : ff(f), lo(produces_dx ? l : nullptr) {
+      if (lo) ff.check(ff.api->ffh_linear_bwd_set_dx_colsum(ff.ctx, lo->weights[1].impl->grad, lo->out_channels), "dx colsum");
+    }
+    ~ColsumScope() { if (lo) lo->db_from_upper = ff.api->ffh_linear_dx_colsum_used(ff.ctx) != 0; }
+  } colsum_scope(ff, colsum_lower, dx != nullptr && (part == 0 || part == 1) && !ff.use_workers() && !ff.config.profiling);
   if (part == 1) {
     ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                        flags | FFH_LINEAR_ONLY_DX, ff.stream, nullptr), name);
@@ -1643,6 +1654,14 @@ void FFModel::allocate() {
         li->dx_mask_by_x = true;
         below->dy_premasked = true;
       }
+      // ... and where the gradient this layer stores is the lower layer's final dy (no activation, or the ReLU whose derivative this
+      // layer applies), the lower layer's bias gradient -- the column sums of that dy -- comes out of this layer's data-gradient
+      // kernel (ffh_linear_bwd_set_dx_colsum) when the persistent kernel runs it; the lower layer's weight-gradient GEMM then runs
+      // without the sums (6 % of it)
+      li->colsum_lower = nullptr;
+      if (config.dx_colsum && below && below->use_bias && li->dx_overwrite && !li->discard_input_grad && below->outputs[0].impl->pieces.empty() &&
+          ((below->activation == AC_MODE_RELU && li->dx_mask_by_x) || below->activation == AC_MODE_NONE) && li->in_padded == li->in_channels)
+        li->colsum_lower = below;
       // ... and two NARROW layers in a row (256 -> 64 -> 16 at the end of DLRM's bottom MLP): the upper layer's backward launch
       // also produces the lower layer's data gradient (ffh_linear_pair_bwd); shapes it does not serve fall back at run time
       li->pair_lower = nullptr;

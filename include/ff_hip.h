@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 9   /* 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 10   /* 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -402,6 +402,17 @@ int ffh_event_record_with_next_linear_bwd(ffh_ctx* ctx, ffh_event e);
 typedef struct ffh_col_dest { float* base; int64_t ld; } ffh_col_dest;
 int ffh_linear_bwd_set_dx_scatter(ffh_ctx* ctx, const ffh_col_dest* map, int ncols, ffh_event attach_if_used);
 int ffh_linear_dx_scatter_used(ffh_ctx* ctx);
+/* The bias gradient of the layer BELOW as a by-product of this layer's data gradient (ABI 10).  In a Linear -> Linear chain the dx a
+ * layer stores (FFH_LINEAR_DX_OVERWRITE; with FFH_LINEAR_DX_MASK_BY_X when the layer below ends in a ReLU) IS the lower layer's final dy,
+ * and that layer's db is the column sums of it [ref: the cublasSgemv over dy, src/ops/linear.cu:644-651].  Taken inside the lower
+ * layer's weight-gradient GEMM those sums cost it 6 % (every k-tile of dy is summed again in every tile column); taken where the tile
+ * of dx is complete and in registers -- the epilogue of this layer's data-gradient kernel -- they are 64 adds per tile.
+ * The NEXT ffh_linear_bwd / _ex on this ctx, if it stores its data gradient (DX_OVERWRITE, in_dim == ncols) through the persistent
+ * fp32 kernel with the plain store epilogue (not: column map pending, deterministic mode, other kernels), also does
+ * colsum[n] += sum over rows of dx[row][n] (after the mask).  One call only, taken or not; ffh_linear_dx_colsum_used() says whether the
+ * last such call took it -- then the caller passes db = NULL to the lower layer's call, else it passes db as always. */
+int ffh_linear_bwd_set_dx_colsum(ffh_ctx* ctx, float* colsum, int ncols);
+int ffh_linear_dx_colsum_used(ffh_ctx* ctx);
 int ffh_linear_bwd_ex(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,
                       const float* w, float* dw, float* db,
@@ -579,7 +590,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) X(ffh_embedding_bwd_sort_multi) X(ffh_embedding_bwd_sgd_apply_multi) X(ffh_embedding_bwd_opt_fused_multi) X(ffh_embedding_bwd_opt_apply_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_linear_bwd_set_dx_colsum) X(ffh_linear_dx_colsum_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

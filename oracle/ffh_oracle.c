@@ -46,6 +46,7 @@ struct ffh_ctx {
   size_t ws_bytes;
   char   err[256];
   const ffh_col_dest* scatter_map;   /* ffh_linear_bwd_set_dx_scatter: pending for the next ffh_linear_bwd_ex */
+  float* colsum_dst; int colsum_ncols, colsum_used;   /* ffh_linear_bwd_set_dx_colsum: pending for the next ffh_linear_bwd / _ex */
   int    scatter_ncols, scatter_used;
   int    math_mode;                  /* ffh_ctx_set_math_mode */
 };
@@ -586,6 +587,15 @@ int ffh_linear_bwd_set_dx_scatter(ffh_ctx* c, const ffh_col_dest* map, int ncols
 }
 int ffh_linear_dx_scatter_used(ffh_ctx* c) { return c ? c->scatter_used : 0; }
 
+/* the lower layer's bias gradient as the column sums of the data gradient the next call stores (include/ff_hip.h); on the host the
+ * request is always taken when the call qualifies (DX_OVERWRITE, in_dim == ncols, a data gradient is produced, no column map) */
+int ffh_linear_bwd_set_dx_colsum(ffh_ctx* c, float* colsum, int ncols) {
+  if (!c || !colsum || ncols <= 0) return FFH_ERR_BAD_ARG;
+  c->colsum_dst = colsum; c->colsum_ncols = ncols; c->colsum_used = 0;
+  return FFH_OK;
+}
+int ffh_linear_dx_colsum_used(ffh_ctx* c) { return c ? c->colsum_used : 0; }
+
 int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx,
                       const float* y, int64_t ldy, float* dy, int64_t lddy,
                       const float* w, float* dw, float* db, int in, int out, int64_t B, int act,
@@ -593,8 +603,18 @@ int ffh_linear_bwd_ex(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   (void)s; (void)s_dw;
   const ffh_col_dest* map = c ? c->scatter_map : NULL;
   const int take = map && c->scatter_ncols == in && (flags & FFH_LINEAR_DX_OVERWRITE) && !(flags & FFH_LINEAR_ONLY_DW) && dx;
-  if (c) { c->scatter_map = NULL; c->scatter_used = 0; }
+  float* colsum = c ? c->colsum_dst : NULL;
+  const int take_cs = colsum && c->colsum_ncols == in && (flags & FFH_LINEAR_DX_OVERWRITE) && !(flags & FFH_LINEAR_ONLY_DW) && dx && !take;
+  if (c) { c->scatter_map = NULL; c->scatter_used = 0; c->colsum_dst = NULL; c->colsum_used = 0; }
   const int rc = linear_bwd_ex_plain(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, B, act, flags);
+  if (rc == FFH_OK && take_cs) {       /* ascending chain over the rows, as the db of linear_bwd_parts */
+    for (int n = 0; n < in; n++) {
+      float acc = 0.0f;
+      for (int64_t b = 0; b < B; b++) acc = fmaf(dx[b * lddx + n], 1.0f, acc);
+      colsum[n] += acc;
+    }
+    c->colsum_used = 1;
+  }
   if (rc == FFH_OK && take) {
     for (int64_t b = 0; b < B; b++)
       for (int n = 0; n < in; n++) map[n].base[b * map[n].ld] = dx[b * lddx + n];

@@ -573,3 +573,54 @@ def test_stream_k_split_routes_under_graph_replay(hip):
         app.close()
     for k in outs[0]:
         np.testing.assert_allclose(outs[0][k], outs[1][k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("B,IN,OUT,served", [
+    (4096, 1024, 512, True),        # whole tiles on the persistent kernel
+    (4096, 3456, 1024, True),       # stream-K with fix-up: only the workgroup that completes a tile runs the epilogue
+    (2560, 1024, 768, True),        # ranges that end mid-tile everywhere
+    (512, 96, 64, False),           # not a shape of the persistent kernel: declined, colsum untouched
+])
+def test_lower_layers_bias_gradient_from_the_data_gradient_epilogue(hip, oracle, B, IN, OUT, served):
+    """ABI 10, ffh_linear_bwd_set_dx_colsum: the data gradient a layer stores (relu'-by-x mask applied) is the lower layer's final dy,
+    whose column sums are that layer's bias gradient [ref: src/ops/linear.cu:644-651].  The persistent data-gradient kernel adds them
+    to `colsum` from its store epilogue; checked against the oracle's twin and against the sums of the dx the same call stored, at
+    1e-5 of the term mass; one call only (the second call leaves colsum alone); a call the kernel does not serve says so."""
+    act = capi.AC_MODE_RELU
+    rng = np.random.default_rng(7 * IN + OUT + B)
+    x = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    y = np.maximum(rng.uniform(-1, 1, (B, OUT)), 0).astype(np.float32)
+    dy = (rng.uniform(-1, 1, (B, OUT)) * (y > 0) / B).astype(np.float32)          # premasked, as the model hands it down
+    flags = capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DX_MASK_BY_X | capi.LINEAR_DY_PREMASKED
+    xd, wd, yd = (torch.from_numpy(a).to(DEV) for a in (x, w, y))
+    res = {}
+    for name, be in (("hip", hip), ("oracle", oracle.lib())):
+        dev = name == "hip"
+        mk = (lambda a: torch.from_numpy(a).to(DEV)) if dev else (lambda a: a.copy())
+        host = (lambda a: a.cpu().numpy().copy()) if dev else (lambda a: a.copy())
+        dyt = mk(dy); dx = mk(np.full((B, IN), 9.0, np.float32)); dw = mk(np.zeros((OUT, IN), np.float32)); db = mk(np.zeros(OUT, np.float32))
+        cs = mk(np.full(IN, 0.5, np.float32))
+        xx, ww, yy = (xd, wd, yd) if dev else (x, w, y)
+        be.check(be.lib.ffh_linear_bwd_set_dx_colsum(be.ctx, capi.ptr(cs), IN), "set colsum")
+        be.call("ffh_linear_bwd_ex", xx, IN, dx, IN, yy, OUT, dyt, OUT, ww, dw, db, IN, OUT, B, act, flags, None, None)
+        used = be.lib.ffh_linear_dx_colsum_used(be.ctx)
+        route = be.lib.ffh_linear_last_route(be.ctx).decode() if dev else ""
+        if dev: torch.cuda.synchronize()
+        cs1 = host(cs); dx1 = host(dx)
+        be.call("ffh_linear_bwd_ex", xx, IN, dx, IN, yy, OUT, dyt, OUT, ww, dw, db, IN, OUT, B, act, flags, None, None)   # the request is gone
+        used2 = be.lib.ffh_linear_dx_colsum_used(be.ctx)
+        if dev: torch.cuda.synchronize()
+        res[name] = (used, used2, cs1, host(cs), dx1, route)
+    used, used2, cs1, cs2, dx1, route = res["hip"]
+    assert used2 == 0 and np.array_equal(cs1, cs2), "the request must be consumed by one call"
+    if not served:
+        assert used == 0 and np.all(cs1 == 0.5), (used, route)
+        return
+    assert used == 1 and "|colsum" in route and "|sk_128x128x64" in route, route
+    mass = (np.abs(dy).astype(np.float64) @ np.abs(w).astype(np.float64)).sum(0) + 0.5
+    want = 0.5 + dx1.astype(np.float64).sum(0)
+    assert np.max(np.abs(cs1 - want) / mass) < 1e-5, np.max(np.abs(cs1 - want) / mass)
+    o_used, o_used2, o_cs1, o_cs2, _, _ = res["oracle"]
+    assert o_used == 1 and o_used2 == 0 and np.array_equal(o_cs1, o_cs2)
+    assert np.max(np.abs(cs1 - o_cs1) / mass) < 1e-5

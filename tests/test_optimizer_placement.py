@@ -234,3 +234,36 @@ def test_deferred_big_weight_gradient_is_only_a_schedule():
     for step in range(3):
         for k in outs[0][step]:
             assert outs[0][step][k].tobytes() == outs[1][step][k].tobytes(), (step, k)
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_bias_gradient_from_the_upper_layers_data_gradient_is_only_a_placement(opt):
+    adam = H.ADAM_HP if opt == "adam" else None
+    """ABI 10 (ffh_linear_bwd_set_dx_colsum): in a Linear -> Linear chain the lower layer's bias gradient is taken as the column sums of
+    the data gradient the upper layer stores (its final dy), and the lower layer's call gets db = NULL.  On the oracle the sums are the
+    same ascending chain over the same values: three steps keep their bits against --no-dx-colsum in every parameter and in the
+    predictions, and the request is really taken (the flag is what differs, not a silent fallback)."""
+    outs = []
+    for flags in ([], ["--no-dx-colsum"]):
+        m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=True, extra_argv=flags, adam=adam)
+        outs.append(H.run_steps(m, h, 3))
+        m.close()
+    for step in range(3):
+        for k in outs[0][step]:
+            assert outs[0][step][k].tobytes() == outs[1][step][k].tobytes(), (step, k)
+    # the oracle takes the request whenever the call qualifies: the chain of the golden model has such calls
+    from oracle import oracle
+    be = oracle.lib()
+    B, IN, OUT = 8, 12, 4
+    x = np.ones((B, IN), np.float32); w = np.ones((OUT, IN), np.float32); y = np.ones((B, OUT), np.float32); dy = np.ones((B, OUT), np.float32)
+    dx = np.zeros((B, IN), np.float32); dw = np.zeros((OUT, IN), np.float32); db = np.zeros(OUT, np.float32); cs = np.zeros(IN, np.float32)
+    from dlrm_flexflow_amd import capi
+    assert be.lib.ffh_linear_bwd_set_dx_colsum(be.ctx, capi.ptr(cs), IN) == capi.FFH_OK
+    be.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy, OUT, w, dw, db, IN, OUT, B, capi.AC_MODE_NONE, capi.LINEAR_DX_OVERWRITE, None, None)
+    assert be.lib.ffh_linear_dx_colsum_used(be.ctx) == 1 and np.all(cs == B * OUT)
+    assert be.lib.ffh_linear_bwd_set_dx_colsum(be.ctx, None, IN) == -1
+    assert be.lib.ffh_linear_bwd_set_dx_colsum(be.ctx, capi.ptr(cs), 0) == -1
+    # without DX_OVERWRITE (an accumulated dx is not the lower layer's final dy) the request is dropped, not taken
+    assert be.lib.ffh_linear_bwd_set_dx_colsum(be.ctx, capi.ptr(cs), IN) == capi.FFH_OK
+    be.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy, OUT, w, dw, db, IN, OUT, B, capi.AC_MODE_NONE, 0, None, None)
+    assert be.lib.ffh_linear_dx_colsum_used(be.ctx) == 0 and np.all(cs == B * OUT)
