@@ -94,6 +94,7 @@ _SIGS = {
     "ffh_memcpy_d2h": (I, [P, P, P, SZ, P]),
     "ffh_memcpy_d2d": (I, [P, P, P, SZ, P]),
     "ffh_stream_create": (I, [P, C.POINTER(P)]),
+    "ffh_stream_create_with_priority": (I, [P, C.POINTER(P), I]),
     "ffh_stream_destroy": (I, [P, P]),
     "ffh_stream_sync": (I, [P, P]),
     "ffh_device_sync": (I, [P]),

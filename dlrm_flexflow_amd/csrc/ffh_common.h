@@ -116,14 +116,15 @@ static inline unsigned ffh_grid(int64_t work_items, int per_block, unsigned cap 
 constexpr int kWave = 64;
 
 #ifdef __HIPCC__
-// Wave priority of every kernel except the persistent GEMMs (linear_sk.hip) -- an A/B build switch, OFF in the product (FFH_PRIO 0).
-// Round 4 measured it: a persistent workgroup keeps one wave per SIMD issuing MFMAs back to back for hundreds of microseconds, and
-// short kernels that share those CUs run 5-10x slower than alone (the bottom MLP's 0.27-GFLOP data-gradient GEMM: 80-210 us beside
-// the first top layer's weight gradient at 4096 samples, 8 us alone).  Raising their waves' priority (s_setprio 3) shortened that
-// kernel to ~145 us and changed the step by nothing (1.199 -> 1.20-1.22 ms): the slow-down is not instruction arbitration alone.
-// tools/build_variant.sh <out.so> -DFFH_PRIO=3 builds the variant.
+// Wave priority of every kernel except the persistent GEMMs (linear_sk.hip): s_setprio 3 at kernel entry.  A persistent workgroup keeps
+// one wave per SIMD issuing MFMAs back to back for hundreds of microseconds; the waves of the short kernels that share those CUs (the
+// bottom MLP's backward, the table update, the gather) are the younger ones at the issue arbiter and run many times slower than alone.
+// Round 4 measured the priority twice: with the bias sums still inside the weight-gradient GEMMs it changed the step by nothing (4096
+// samples: the bottom MLP's first dX kernel 210 -> 145 us, step 1.199 -> 1.20-1.22 ms) and stayed off; once those GEMMs ran without the sums
+// (ABI 10) it paid a little (32768 samples 7.87 -> 7.83-7.85 ms, 4096: 1.190-1.195 -> 1.176-1.187, MLPerf shape level), and with
+// the embedding stream at a higher HIP priority 7.78-7.84 (profiles/r04_ab_schedule.txt).  -DFFH_PRIO=0 builds it out.
 #ifndef FFH_PRIO
-#define FFH_PRIO 0
+#define FFH_PRIO 3
 #endif
 __device__ __forceinline__ void ffh_kernel_prio() {
 #if FFH_PRIO > 0

@@ -173,6 +173,17 @@ int ffh_stream_create(ffh_ctx* c, ffh_stream* s) {
   *s = (ffh_stream)st;
   return FFH_OK;
 }
+int ffh_stream_create_with_priority(ffh_ctx* c, ffh_stream* s, int priority) {
+  if (!s) return FFH_ERR_BAD_ARG;
+  int lo = 0, hi = 0;                                     // numerically: hi <= lo, hi is the greatest priority
+  FFH_HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+  if (priority < hi) priority = hi;
+  if (priority > lo) priority = lo;
+  hipStream_t st;
+  FFH_HIP_TRY(c, hipStreamCreateWithPriority(&st, hipStreamNonBlocking, priority));
+  *s = (ffh_stream)st;
+  return FFH_OK;
+}
 int ffh_stream_destroy(ffh_ctx* c, ffh_stream s) { if (s) FFH_HIP_TRY(c, hipStreamDestroy(as_stream(s))); return FFH_OK; }
 int ffh_stream_sync(ffh_ctx* c, ffh_stream s) { FFH_HIP_TRY(c, hipStreamSynchronize(as_stream(s))); return FFH_OK; }
 int ffh_device_sync(ffh_ctx* c) { FFH_HIP_TRY(c, hipDeviceSynchronize()); return FFH_OK; }

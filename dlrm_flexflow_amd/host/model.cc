@@ -134,6 +134,7 @@ FFConfig::FFConfig() {
   fuse_pair = true;
   dx_scatter = true;
   dx_colsum = true;
+  stream_priorities = false;
   early_sort = true;
   pad_linear_k = true;
   capture_exchange = false;
@@ -203,6 +204,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
     if (is("--no-dx-colsum")) { dx_colsum = false; continue; }
+    if (is("--stream-priorities")) { stream_priorities = true; continue; }
+    if (is("--no-stream-priorities")) { stream_priorities = false; continue; }
     if (is("--no-early-sort")) { early_sort = false; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
     if (is("--capture-exchange")) { capture_exchange = true; continue; }
@@ -467,7 +470,11 @@ FFModel::FFModel(FFConfig& _config)
   else if (config.fp32_split_bf16x3) check(api->ffh_ctx_set_math_mode(ctx, FFH_MATH_FP32_SPLIT_BF16X3), "split-bf16x3 math mode");
   if (config.deterministic) { check(api->ffh_ctx_set_deterministic(ctx, 1), "deterministic mode"); config.async_launch = false; }
   check(api->ffh_stream_create(ctx, &stream), "stream create");
-  check(api->ffh_stream_create(ctx, &side_stream), "stream create");
+  // --stream-priorities (A/B, off): the embedding stream at a higher HIP priority (ABI 11).  Measured in round 4 (profiles/r04_ab_schedule.txt):
+  // level at 32768 samples (7.80-7.83 vs 7.82-7.84 ms), worse at 4096 (1.180-1.184 vs 1.173-1.178), 7 us better at the MLPerf shape --
+  // and never with the exchange on that stream: RCCL's send/recv kernels at the higher priority made the 1-rank exchange step
+  // 1.27 -> 1.99 ms (Terabyte shape, 4096 samples) and 0.195 -> 0.716 ms (Kaggle shape)
+  check((config.stream_priorities && !exchange) ? api->ffh_stream_create_with_priority(ctx, &side_stream, -1) : api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream2), "stream create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw2_done), "event create");

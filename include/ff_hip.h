@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 10   /* 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 11   /* 11: ffh_stream_create_with_priority; 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -195,6 +195,10 @@ int ffh_memcpy_h2d(ffh_ctx* ctx, void* dst, const void* src, size_t bytes, ffh_s
 int ffh_memcpy_d2h(ffh_ctx* ctx, void* dst, const void* src, size_t bytes, ffh_stream s);
 int ffh_memcpy_d2d(ffh_ctx* ctx, void* dst, const void* src, size_t bytes, ffh_stream s);
 int ffh_stream_create(ffh_ctx* ctx, ffh_stream* s);
+/* ABI 11: the same with a HIP stream priority (0 = default, negative = higher, positive = lower; clamped to the device's range) --
+ * what the Legion mapper's task priorities are to the reference.  Optional; the DLRM shim uses it behind --stream-priorities only
+ * (measured level on the single-GPU step, and harmful on a stream that carries RCCL's send/recv kernels). */
+int ffh_stream_create_with_priority(ffh_ctx* ctx, ffh_stream* s, int priority);
 int ffh_stream_destroy(ffh_ctx* ctx, ffh_stream s);
 int ffh_stream_sync(ffh_ctx* ctx, ffh_stream s);
 int ffh_device_sync(ffh_ctx* ctx);
@@ -581,7 +585,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) X(ffh_ctx_default) \
   X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) X(ffh_ctx_set_dw_cu_reserve) X(ffh_ctx_bf16_mirror_set) X(ffh_convert_f32_to_bf16) \
   X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
-  X(ffh_stream_create) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
+  X(ffh_stream_create) X(ffh_stream_create_with_priority) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
   X(ffh_event_create) X(ffh_event_create_sync) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \
   X(ffh_stream_wait_event) X(ffh_event_elapsed_ms) \
   X(ffh_graph_begin_capture) X(ffh_graph_end_capture) X(ffh_graph_launch) X(ffh_graph_destroy) \

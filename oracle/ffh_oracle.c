@@ -136,6 +136,7 @@ int ffh_memcpy_h2d(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) 
 int ffh_memcpy_d2h(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) { (void)c; (void)st; memcpy(d, s, n); return FFH_OK; }
 int ffh_memcpy_d2d(ffh_ctx* c, void* d, const void* s, size_t n, ffh_stream st) { (void)c; (void)st; memmove(d, s, n); return FFH_OK; }
 int ffh_stream_create(ffh_ctx* c, ffh_stream* s) { (void)c; if (s) *s = NULL; return FFH_OK; }
+int ffh_stream_create_with_priority(ffh_ctx* c, ffh_stream* s, int priority) { (void)c; (void)priority; if (!s) return FFH_ERR_BAD_ARG; *s = NULL; return FFH_OK; }
 int ffh_stream_destroy(ffh_ctx* c, ffh_stream s) { (void)c; (void)s; return FFH_OK; }
 int ffh_stream_sync(ffh_ctx* c, ffh_stream s) { (void)c; (void)s; return FFH_OK; }
 int ffh_device_sync(ffh_ctx* c) { (void)c; return FFH_OK; }
