@@ -33,4 +33,11 @@ for B, IN, OUT in shapes:
         out.append(f"dX act {nm} premasked overwrite: {t:7.1f} us {fl/t/1e6:6.1f} TF")
         t = timeit(lambda: hip.call("ffh_linear_fwd", x, IN, y, OUT, w, db, IN, OUT, B, act, None))
         out.append(f"fwd act {nm}: {t:7.1f} us {fl/t/1e6:6.1f} TF")
+    if os.environ.get("DW_CHECK"):
+        dw.zero_(); dy2 = dy.clone()
+        hip.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy2, OUT, w, dw, None, IN, OUT, B, capi.AC_MODE_NONE, capi.LINEAR_ONLY_DW, None, None)
+        hip.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy2, OUT, w, dw, None, IN, OUT, B, capi.AC_MODE_NONE, capi.LINEAR_ONLY_DW, None, None)   # accumulates: 2x
+        torch.cuda.synchronize()
+        ref = 2.0 * (dy.double().t() @ x.double()); mass = 2.0 * (dy.double().abs().t() @ x.double().abs()) + 1e-30
+        out.append(f"check (two accumulating launches, no db) worst |err| / term mass = {((dw.double() - ref).abs() / mass).max().item():.3e}  [{hip.lib.ffh_linear_last_route(hip.ctx).decode()}]")
     print(f"{B} x {IN} -> {OUT}"); [print("   ", o) for o in out]; sys.stdout.flush()
