@@ -465,15 +465,16 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
   if (ntiles * nk >= (1LL << 31)) return false;
   if (form == SK_FORM_DW) {
     if (c->deterministic || g.epi != EPI_ATOMIC) return false;     // its partial tiles meet by atomics
-    if (ntiles * nk < 4LL * p.G) return false;                     // at least four k-tiles per workgroup
+    if (ntiles * nk < 8LL * p.G) return false;                     // at least eight k-tiles per workgroup (with four the split-K kernels of linear.hip win:
+                                                                   // 8192 x 512 -> 256: 32.3 vs 37.0 us; with eight this one does: 4096 x 1024 -> 512: 48.7 vs 52.5)
   } else {
     if (g.epi != EPI_STORE && g.epi != EPI_ADD) return false;
     // whole tiles when they fill whole rounds of workgroups (or nearly: a split costs a partial tile's round trip through memory);
-    // otherwise stream-K with the fix-up of the kernel's SPLIT form when every workgroup still gets >= 4 k-tiles
+    // otherwise stream-K with the fix-up of the kernel's SPLIT form when every workgroup still gets >= 8 k-tiles
     static const int no_split = FFH_LAB_INT("FFH_SK_NO_SPLIT", 0);     // A/B switch (tools/ab.sh)
     const int64_t rounds = (ntiles + p.G - 1) / p.G;
     const int64_t idle_it = (rounds * p.G - ntiles) * nk / p.G;      // k-tile iterations per workgroup the last round wastes
-    p.split = !no_split && !c->deterministic && idle_it >= 2 && ntiles * nk >= 4LL * p.G && g.epi == EPI_STORE;
+    p.split = !no_split && !c->deterministic && idle_it >= 2 && ntiles * nk >= 8LL * p.G && g.epi == EPI_STORE;    // (four k-tiles per workgroup: 8192 x 512 -> 256 forward 33.3 us split, 27.8 on the LDS-DMA kernel)
     if (!p.split) {
       if (ntiles < p.G) return false;
       if (ntiles * 100 < rounds * p.G * 80) return false;          // whole tiles only: the last round must be nearly full

@@ -453,7 +453,8 @@ def _close(got, exp, mass, what, tol=1e-5):
     (4096, 3456, 1024, {"dx": "streamk"}),        # 864 data-gradient tiles on 256 workgroups: 3.4 rounds
     (4096, 1024, 512, {"fwd": "streamk"}),        # 128 forward tiles: half a round
     (4096, 1024, 1024, {}),                       # 256 tiles: whole tiles, one per workgroup
-    (8192, 512, 256, {"fwd": "streamk"}),         # MLPerf batch: 128 tiles of 8 k-tiles
+    (8192, 512, 256, {}),                         # MLPerf batch: 128 tiles of 8 k-tiles = 4 per workgroup: too few for the fix-up form, not split
+    (8192, 1024, 256, {"fwd": "streamk"}),        # 128 tiles of 16 k-tiles
     (2560, 1024, 768, {"fwd": "streamk", "dx": "streamk"}),   # 120 / 160 tiles: ranges that end mid-tile everywhere, a short last range
 ])
 def test_linear_layers_at_the_per_rank_batch_vs_oracle_with_routes(hip, oracle, B, IN, OUT, expect):
