@@ -538,15 +538,14 @@ def main():
     # the same kernels and the collectives inside real eager steps, by events on the streams they are issued on.  COLLECTIVE: the
     # steps run the exchange, so at N > 1 every rank walks them (round-3 advisor: rank 0 alone hung in the first all-to-all); the
     # line reports rank 0's intervals and the maximum over the ranks
-    in_step = in_step_max = None
-    if not trace or not solo:
-        in_step = app.probe_step(10 if B > 4096 else 50)
-        in_step_max = dict(in_step)
-        if world > 1:
-            keys = sorted(in_step)
-            t = torch.tensor([in_step[k] for k in keys], dtype=torch.float64, device="cpu" if ftest else "cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            in_step_max = {k: float(v) for k, v in zip(keys, t.tolist())}
+    # (also when the timed steps were replayed from a hipGraph: the probed steps are launched eagerly, the kernels are the same)
+    in_step = app.probe_step(10 if B > 4096 else 50)
+    in_step_max = dict(in_step)
+    if world > 1:
+        keys = sorted(in_step)
+        t = torch.tensor([in_step[k] for k in keys], dtype=torch.float64, device="cpu" if ftest else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        in_step_max = {k: float(v) for k, v in zip(keys, t.tolist())}
     t_fwd_in = in_step["gather"] * 1e-3 if (in_step and t_fwd and in_step["gather"] > 0) else None
     t_bwd_in = in_step["table_update"] * 1e-3 if (in_step and t_bwd and in_step["table_update"] > 0) else None
     t_step_dev = app.time_kernel(2 if trace else 4, 20 if B > 4096 else 100) * 1e-3 if solo else None

@@ -455,7 +455,7 @@ def _close(got, exp, mass, what, tol=1e-5):
     (4096, 1024, 1024, {}),                       # 256 tiles: whole tiles, one per workgroup
     (8192, 512, 256, {}),                         # MLPerf batch: 128 tiles of 8 k-tiles = 4 per workgroup: too few for the fix-up form, not split
     (8192, 1024, 256, {"fwd": "streamk"}),        # 128 tiles of 16 k-tiles
-    (2560, 1024, 768, {"fwd": "streamk", "dx": "streamk"}),   # 120 / 160 tiles: ranges that end mid-tile everywhere, a short last range
+    (2560, 1280, 768, {"fwd": "streamk", "dx": "streamk"}),   # 120 / 200 tiles of 20 / 12 k-tiles: ranges that end mid-tile everywhere, a short last range
 ])
 def test_linear_layers_at_the_per_rank_batch_vs_oracle_with_routes(hip, oracle, B, IN, OUT, expect):
     """Forward, plain backward and the model's backward form (premasked dy, relu'-by-x mask, stored dX, forked dW) of the layers of
@@ -579,7 +579,7 @@ def test_stream_k_split_routes_under_graph_replay(hip):
 @pytest.mark.parametrize("B,IN,OUT,served", [
     (4096, 1024, 512, True),        # whole tiles on the persistent kernel
     (4096, 3456, 1024, True),       # stream-K with fix-up: only the workgroup that completes a tile runs the epilogue
-    (2560, 1024, 768, True),        # ranges that end mid-tile everywhere
+    (2560, 1280, 768, True),        # ranges that end mid-tile everywhere
     (512, 96, 64, False),           # not a shape of the persistent kernel: declined, colsum untouched
 ])
 def test_lower_layers_bias_gradient_from_the_data_gradient_epilogue(hip, oracle, B, IN, OUT, served):
