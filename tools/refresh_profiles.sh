@@ -18,7 +18,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- p
 S=$(find $O/prof -name "*kernel_stats.csv" | head -1); cp $S $O/${P}_bench_terabyte_kernel_stats.csv
 T=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python3 tools/trace_summary.py $T > $O/${P}_bench_terabyte_step_timeline.txt
-for k in emb_fwd_kernel emb_sgd_reduce_kernel radix_scatter_kernel "gemm_sk_kernel<false, false, 0" "gemm_sk_kernel<false, true, 1" "gemm_sk_kernel<true, true, 3, true"; do
+for k in emb_fwd_kernel emb_sgd_reduce_kernel radix_scatter_kernel "gemm_sk_kernel<false, false, 0" "gemm_sk_kernel<false, true, 1" "gemm_sk_kernel<true, true, 3, true" "gemm_sk_kernel<true, true, 3, false"; do
   python3 tools/kernel_avg.py $T "$k"
 done > $O/${P}_bench_terabyte_probe_averages.txt
 find $O/prof -name "*.csv" -size +10M -delete
