@@ -75,3 +75,11 @@ def test_product_loader_rejects_the_oracle(oracle, monkeypatch):
     with pytest.raises(capi.FFHError):
         capi.load_hip()
     monkeypatch.setattr(capi, "_hip_singleton", None)
+
+
+def test_oracle_stream_with_priority_is_a_no_op(oracle):
+    """ABI 11 on the host twin: streams mean nothing there; the entry exists, checks its pointer and hands back the NULL stream."""
+    be = oracle.lib()
+    s = ctypes.c_void_p(1)
+    assert be.lib.ffh_stream_create_with_priority(be.ctx, ctypes.byref(s), -1) == 0 and not s.value
+    assert be.lib.ffh_stream_create_with_priority(be.ctx, None, 0) == -1

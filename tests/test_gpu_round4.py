@@ -625,3 +625,20 @@ def test_lower_layers_bias_gradient_from_the_data_gradient_epilogue(hip, oracle,
     o_used, o_used2, o_cs1, o_cs2, _, _ = res["oracle"]
     assert o_used == 1 and o_used2 == 0 and np.array_equal(o_cs1, o_cs2)
     assert np.max(np.abs(cs1 - o_cs1) / mass) < 1e-5
+
+
+def test_stream_with_priority_is_an_ordinary_stream(hip):
+    """ABI 11, ffh_stream_create_with_priority: priorities outside the device's range are clamped, the stream takes kernels and events
+    like any other, a NULL result pointer is a bad argument."""
+    C = capi.C
+    for prio in (-1, 0, 1, -100, 100):
+        s = C.c_void_p()
+        hip.check(hip.lib.ffh_stream_create_with_priority(hip.ctx, C.byref(s), prio), f"create with priority {prio}")
+        assert s.value
+        t = torch.full((1 << 16,), 3.0, device=DEV)
+        torch.cuda.synchronize()
+        hip.check(hip.lib.ffh_zero(hip.ctx, capi.ptr(t), t.numel() * 4, s), "zero on the stream")
+        hip.check(hip.lib.ffh_stream_sync(hip.ctx, s), "sync")
+        assert float(t.abs().sum()) == 0.0
+        hip.check(hip.lib.ffh_stream_destroy(hip.ctx, s), "destroy")
+    assert hip.lib.ffh_stream_create_with_priority(hip.ctx, None, 0) == -1
