@@ -271,6 +271,103 @@ __global__ __launch_bounds__(256) void dot_interaction_bwd_kernel(const float* _
   }
 }
 
+// Backward for the shape the models use (d = 128, 16-byte aligned rows), as straight-line code.  The general kernel above guards every
+// operand load (row < c, column < d) -- in the ISA each 16-byte load sits in its own branch with an s_waitcnt in front of the two or
+// four MFMAs that use it: sixteen dependent HBM round trips per 128 columns, 231 registers (two waves per SIMD), 0.51 of the HBM
+// rate.  Here rows past c read row c - 1 (their A columns are the zero padding of S, so what they hold does not matter), a pass's
+// sixteen operand loads are issued back to back -- the first pass's before the gradient's triangle is spread into S, the next
+// pass's before this pass's stores -- and NT = 2 tiles per pass keep the wave at half the registers.
+template <bool ACCUM, int NT>
+__global__ __launch_bounds__(256) void dot_interaction_bwd_d128_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ og, int64_t ldg,
+                                                                       float* __restrict__ zg, int64_t ldzg, int64_t batch, int c) {
+  ffh_kernel_prio();
+  static_assert(NT == 4 || NT == 2, "tiles per pass");
+  constexpr int d = 128, NPASS = d / (32 * NT);
+  typedef float vt __attribute__((ext_vector_type(NT)));
+  __shared__ float s_S[4][32 * 33];
+  __shared__ uint16_t s_pair[kMaxC * (kMaxC - 1) / 2];     // p -> i * 33 + j
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int P = c * (c - 1) / 2;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)p)) * 0.5f);
+    while (i * (i - 1) / 2 > p) i--;
+    while ((i + 1) * i / 2 <= p) i++;
+    s_pair[p] = (uint16_t)(i * 33 + (p - i * (i - 1) / 2));
+  }
+  float* S = s_S[wave];
+  for (int e = lane; e < 32 * 33; e += 64) S[e] = 0.0f;      // diagonal and padding stay zero for every sample
+  __syncthreads();
+  int krow[16];                                               // the operand rows of this lane, clamped
+#pragma unroll
+  for (int s = 0; s < 16; s++) { const int k = 16 * h + s; krow[s] = (k < c ? k : c - 1) * d; }
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t b = (int64_t)blockIdx.x * 4 + wave; b < batch; b += nwaves) {
+    const float* gb = og + b * ldg;
+    const float* zb = z + b * ldz;
+    float* zgb = zg + b * ldzg;
+    vt bv[16];
+    auto load_pass = [&](int pass) {
+      const float* zp = zb + pass * 32 * NT + NT * r;
+#pragma unroll
+      for (int s = 0; s < 16; s++) bv[s] = *reinterpret_cast<const vt*>(zp + krow[s]);
+    };
+    load_pass(0);
+    // the strict lower triangle of the gradient -> S = G + G^T (kMaxC (kMaxC - 1) / 2 = 496 entries: at most eight per lane)
+    float gq[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int p = lane + 64 * q; gq[q] = p < P ? gb[d + p] : 0.0f; }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int p = lane + 64 * q;
+      if (p < P) {
+        const int ij = s_pair[p], i = ij / 33, j = ij - i * 33;
+        S[ij] = gq[q];
+        S[j * 33 + i] = gq[q];
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0): the wave's own LDS writes have landed
+    // A operand: S[r][k], lane (r, h) supplies k = 16 h + s at step s
+    float a[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) a[s] = S[r * 33 + 16 * h + s];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < NPASS; pass++) {
+      const int col = pass * 32 * NT + NT * r;
+      f32x16 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 16; s++)
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv[s][t], acc[t], 0, 0, 0);
+      if (pass + 1 < NPASS) load_pass(pass + 1);              // under this pass's stores
+      // accumulator of tile t: lane holds column col + t, rows i = 8 (v / 4) + 4 h + v % 4
+      vt direct;                                              // direct path of the bottom-MLP output (row 0); the gradient's rows need no alignment
+#pragma unroll
+      for (int t = 0; t < NT; t++) direct[t] = h == 0 ? gb[col + t] : 0.0f;
+#pragma unroll
+      for (int v = 0; v < 16; v++) {
+        const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+        vt o;
+#pragma unroll
+        for (int t = 0; t < NT; t++) o[t] = acc[t][v];
+        if (v == 0 && h == 0) o += direct;                    // i == 0 <=> v == 0, h == 0
+        vt* dst = reinterpret_cast<vt*>(zgb + (int64_t)i * d + col);
+        if (i < c) {
+          if (ACCUM) o += *dst;
+          *dst = o;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();                           // S is rewritten for the next sample
+  }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
@@ -317,6 +414,16 @@ int ffh_dot_interaction_bwd(ffh_ctx* c, const float* z, int64_t ldz, const float
   const bool v4 = d % 4 == 0 && ldz % 4 == 0 && ldzg % 4 == 0 && aligned16(z) && aligned16(z_grad);
   const bool over = (flags & FFH_DOT_BWD_OVERWRITE) != 0;
   const unsigned grid = ffh_grid(batch, 4, 4096);
+  // the models' shape: the straight-line kernel (FFH_DOT_BWD_FAST: A/B in lab builds -- 0 off, 2 / 4 tiles per pass)
+  static const int fast = FFH_LAB_INT("FFH_DOT_BWD_FAST", 2);
+  if (fast && v4 && d == 128) {
+#define FFH_DOT_BWD_F(A, N) hipLaunchKernelGGL((dot_interaction_bwd_d128_kernel<A, N>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out_grad, ldg, z_grad, ldzg, batch, nrows)
+    if (fast == 4) { if (over) FFH_DOT_BWD_F(false, 4); else FFH_DOT_BWD_F(true, 4); }
+    else { if (over) FFH_DOT_BWD_F(false, 2); else FFH_DOT_BWD_F(true, 2); }
+#undef FFH_DOT_BWD_F
+    FFH_LAUNCH_CHECK(c, "dot_interaction_bwd (d128)");
+    return FFH_OK;
+  }
 #define FFH_DOT_BWD(V, A) hipLaunchKernelGGL((dot_interaction_bwd_kernel<V, A>), dim3(grid), dim3(256), 0, as_stream(s), z, ldz, out_grad, ldg, z_grad, ldzg, batch, nrows, d)
   if (v4) { if (over) FFH_DOT_BWD(4, false); else FFH_DOT_BWD(4, true); }
   else { if (over) FFH_DOT_BWD(1, false); else FFH_DOT_BWD(1, true); }
