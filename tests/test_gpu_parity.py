@@ -656,7 +656,8 @@ def test_tril_bit_exact(hip, oracle, B, n):
         hip.call("ffh_tril_fwd", out, P + 5, dev(z), B, 65, None)     # n > 64
 
 
-@pytest.mark.parametrize("B,c,d", [(1, 2, 1), (7, 4, 8), (2048, 27, 128), (130, 32, 36), (33, 9, 130), (64, 27, 16)])
+@pytest.mark.parametrize("B,c,d", [(1, 2, 1), (7, 4, 8), (2048, 27, 128), (130, 32, 36), (33, 9, 130), (64, 27, 16),
+                                   (5, 2, 128), (131, 32, 128), (9, 31, 128), (1030, 17, 128)])   # d = 128: the straight-line backward (round 4), smallest / largest c, odd batches
 def test_dot_interaction_vs_oracle(hip, oracle, B, c, d):
     """The fused pairwise-dot interaction (one wave per sample, Z Z^T on fp32 MFMA) against the oracle's plain loops:
     pass-through columns bit-exact, dot products within 1e-5 (the MFMA adds the k terms in another order); strided
