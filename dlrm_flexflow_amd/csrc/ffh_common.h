@@ -35,6 +35,10 @@ struct ffh_ctx {
   // one flag per slot; the first set is allocated with the ctx, further ones when another stream first launches such a GEMM
   struct { void* stream; float* slots; unsigned* flags; } sk_sets[4];
   int         sk_nsets;
+  // one-launch narrow-layer backward (linear_skinny_bwd_kernel): per stream, the workgroups' partial dW / db rows + an arrival counter
+  // (ctx-owned scratch, allocated when a stream first needs it, never during a capture)
+  struct { void* stream; float* ws; unsigned* cnt; } skinny_sets[4];
+  int         skinny_nsets;
   const void* emb_sorted_ws;     // ffh_embedding_bwd_sort_multi left a sorted list (and cleared fold counters) in THIS workspace ...
   int64_t     emb_sorted_sig[4]; // ... for this (ntables, in_dim, out_dim, batch): ffh_embedding_bwd_sgd_apply_multi consumes it, once
   char        route[256]; // ffh_linear_last_route(): kernel families of the latest ffh_linear_* call

@@ -1110,7 +1110,12 @@ struct SkinnyBwdArgs {
   // MSE loss step folded in (ffh_linear_bwd_mse): dy is not read but made here from y and label; metrics as metrics_kernel
   const float* label;  float loss_scale;  ffh_perf_metrics* perf;  int metrics_flags;
   unsigned short* dx16;       // tensor-op mode: the bf16 twin of dx (ffh_ctx_bf16_mirror_set), written beside it, or null
+  // dW / db without atomic chains: workgroup b leaves its partial row [out * in + out] at ws + b * ws_stride, the last one to arrive
+  // (ws_cnt) adds the rows up in block order and adds the total to dw / db.  Null: one atomic per weight per workgroup.
+  float* ws;  unsigned* ws_cnt;  int ws_stride;
 };
+constexpr int kSkinnyWsBlocks = 512;                       // workgroups the scratch holds
+constexpr int kSkinnyWsRow = 4160;                          // floats per partial row: out * in + out for out <= 4, in <= 1024 (4100) and out <= 16, in <= 256 (4112)
 
 // NC: 16-byte column chunks per lane (in <= 256 * NC), NO: output slots kept in registers (out <= NO),
 // RPW: rows per wave-instruction -- a row of in = 256 / RPW floats fills 64 / RPW lanes, so RPW rows go side by side
@@ -1193,7 +1198,8 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
   if (a.do_db && a.db && tid < a.out) {
     float sum = 0.f;
     for (int r = 0; r < rows; r++) sum += s_dz[r * a.out + tid];
-    atomicAdd(&a.db[tid], sum);
+    if (a.ws) __hip_atomic_store(a.ws + (int64_t)blockIdx.x * a.ws_stride + a.out * a.in + tid, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else atomicAdd(&a.db[tid], sum);
   }
   // 2. a wave takes rows wave, wave + 4, ...; a lane owns the 16-byte column chunks lane, lane + 64, ... of every row
   //    (in <= 1024: at most 4 chunks), so a row is one coalesced pass; four rows are in flight per wave
@@ -1282,11 +1288,88 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_kernel(const SkinnyBwdA
         if (o < a.out && ch < nch && rsub == 0) red[((int64_t)wave * a.out + o) * nch + ch] = dwacc[c][o];
       }
     __syncthreads();
+    typedef unsigned long long u64;
     for (int e = tid; e < a.out * nch; e += 256) {
       const float4 p0 = red[e], p1 = red[a.out * nch + e], p2 = red[2 * a.out * nch + e], p3 = red[3 * a.out * nch + e];
-      float* d = a.dw + (int64_t)e * 4;                 // e = o * nch + ch  ->  dw[o][4 ch]
-      atomicAdd(d + 0, (p0.x + p1.x) + (p2.x + p3.x)); atomicAdd(d + 1, (p0.y + p1.y) + (p2.y + p3.y));
-      atomicAdd(d + 2, (p0.z + p1.z) + (p2.z + p3.z)); atomicAdd(d + 3, (p0.w + p1.w) + (p2.w + p3.w));
+      const float4 s4 = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+      if (a.ws) {
+        u64* q = reinterpret_cast<u64*>(a.ws + (int64_t)blockIdx.x * a.ws_stride + (int64_t)e * 4);
+        __hip_atomic_store(q, ((u64)__float_as_uint(s4.y) << 32) | __float_as_uint(s4.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, ((u64)__float_as_uint(s4.w) << 32) | __float_as_uint(s4.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        float* d = a.dw + (int64_t)e * 4;                 // e = o * nch + ch  ->  dw[o][4 ch]
+        atomicAdd(d + 0, s4.x); atomicAdd(d + 1, s4.y); atomicAdd(d + 2, s4.z); atomicAdd(d + 3, s4.w);
+      }
+    }
+  }
+  if (a.ws && (a.do_dw || (a.do_db && a.db))) {
+    // The last workgroup to arrive adds the partial rows up -- in block order: the same bits run to run -- and adds the totals to dw /
+    // db.  With one atomic per weight per workgroup every weight was the end of a chain of gridDim.x serialised adds (~0.1 us each:
+    // 256 -> 1 at 32768 samples 33 us for dW + db in 256 workgroups, 58 in 512, while the dX stream alone wants 512: 13.9 us).
+    // Cross-workgroup values travel as agent-scope relaxed atomics ordered by completion (vmcnt + barrier before the counter), as in
+    // embedding.hip's folds; the counter is left at 0 for the next launch on this stream (also a replayed hipGraph node).
+    __shared__ unsigned s_prev;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_prev = __hip_atomic_fetch_add(a.ws_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_prev != gridDim.x - 1) return;
+    if (tid == 0) __hip_atomic_store(a.ws_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    typedef unsigned long long u64;
+    const int ng = a.do_dw ? a.out * nch : 0;            // float4 groups of dW
+    const int nb = (int)gridDim.x;
+    float4* comb = reinterpret_cast<float4*>(s_dz);      // [part][group] when several threads share a group (ng <= 128)
+    const int parts = ng > 0 && ng <= 128 ? 256 / ng : 1;      // threads per group (ng = 64 for 256 -> 1: 4)
+    const int gpi = parts > 1 ? ng : 256;                       // groups per sweep of the workgroup
+    __syncthreads();                                     // red[] is dead: s_dz is reused
+    for (int g0 = 0; g0 < ng; g0 += gpi) {
+      const int g = g0 + tid % gpi, part = tid / gpi;
+      const bool live = g < ng && part < parts;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) {
+        const u64* q = reinterpret_cast<const u64*>(a.ws + (int64_t)g * 4);
+        constexpr int UN = 8;
+        for (int b = part; b < nb; b += parts * UN) {
+          u64 lo[UN], hi[UN];
+#pragma unroll
+          for (int u = 0; u < UN; u++) {
+            const int bb = b + u * parts;
+            const u64* qq = q + (int64_t)(bb < nb ? bb : b) * (a.ws_stride / 2);
+            lo[u] = __hip_atomic_load(qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hi[u] = __hip_atomic_load(qq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int u = 0; u < UN; u++)
+            if (b + u * parts < nb) {
+              acc.x += __uint_as_float((unsigned)lo[u]); acc.y += __uint_as_float((unsigned)(lo[u] >> 32));
+              acc.z += __uint_as_float((unsigned)hi[u]); acc.w += __uint_as_float((unsigned)(hi[u] >> 32));
+            }
+        }
+      }
+      if (parts > 1) {
+        if (live) comb[part * gpi + (g - g0)] = acc;
+        __syncthreads();
+        if (live && part == 0)
+          for (int pp = 1; pp < parts; pp++) { const float4 o4 = comb[pp * gpi + (g - g0)]; acc.x += o4.x; acc.y += o4.y; acc.z += o4.z; acc.w += o4.w; }
+        __syncthreads();
+      }
+      if (live && part == 0) {
+        float4* d = reinterpret_cast<float4*>(a.dw + (int64_t)g * 4);
+        float4 o4 = *d; o4.x += acc.x; o4.y += acc.y; o4.z += acc.z; o4.w += acc.w; *d = o4;
+      }
+    }
+    if (a.do_db && a.db) {
+      __shared__ float s_dbw[4];
+      for (int o = 0; o < a.out; o++) {
+        float sum = 0.f;
+        for (int b = tid; b < nb; b += 256) sum += __hip_atomic_load(a.ws + (int64_t)b * a.ws_stride + a.out * a.in + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int dd = 32; dd > 0; dd >>= 1) sum += __shfl_down(sum, dd);
+        if (lane == 0) s_dbw[wave] = sum;
+        __syncthreads();
+        if (tid == 0) a.db[o] += (s_dbw[0] + s_dbw[1]) + (s_dbw[2] + s_dbw[3]);
+        __syncthreads();
+      }
     }
   }
 }
@@ -1589,6 +1672,26 @@ int launch_act_bwd_bias(ffh_ctx* c, float* dy, int64_t lddy, const float* y, int
   return FFH_OK;
 }
 
+// the partial-row scratch of linear_skinny_bwd_kernel for launches on stream s (allocated when a stream first needs it, never during
+// a capture; like linear_sk.hip's slots)
+bool skinny_ws_for(ffh_ctx* c, hipStream_t s, float** ws, unsigned** cnt) {
+  for (int i = 0; i < c->skinny_nsets; i++)
+    if (c->skinny_sets[i].stream == (void*)s) { *ws = c->skinny_sets[i].ws; *cnt = c->skinny_sets[i].cnt; return true; }
+  if (c->skinny_nsets >= 4) return false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (st != hipStreamCaptureStatusNone) return false;
+  float* w = nullptr; unsigned* k = nullptr;
+  if (hipMalloc(&w, (size_t)kSkinnyWsBlocks * kSkinnyWsRow * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  // (cleared ON the stream the launches go to: a null-stream hipMemset is not ordered against a non-blocking stream, and a launch that
+  //  finds the counter mid-way never sees its last workgroup)
+  if (hipMalloc(&k, 64) != hipSuccess || hipMemsetAsync(k, 0, 64, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w); if (k) (void)hipFree(k); return false; }
+  c->skinny_sets[c->skinny_nsets] = {(void*)s, w, k};
+  c->skinny_nsets++;
+  *ws = w; *cnt = k;
+  return true;
+}
+
 // label != NULL: the MSE loss step is folded into the one-launch backward (ffh_linear_bwd_mse); layers that path does
 // not serve return FFH_ERR_UNSUPPORTED before anything is launched
 int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const float* y, int64_t ldy,
@@ -1632,12 +1735,22 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
       a.label = label; a.loss_scale = loss_scale; a.perf = perf; a.metrics_flags = metrics_flags;
       a.write_back = 1;              // dy must end up holding what the loss step + the layer's in-place pass leave there
     }
-    // dW / db are accumulated with one atomic per weight per workgroup: adds to ONE address serialise (~0.1 us each), so
-    // the number of workgroups is kept near 32 -- and every wave then keeps 16 / NC rows in flight to cover the latency
+    // dW / db: the workgroups' partial rows meet in ctx-owned scratch and the last one to arrive adds them up (no atomic chains); then
+    // the number of workgroups follows what the x / dX stream wants.  Without scratch (a capture in flight before the stream's first
+    // eager call, more than four streams) they are accumulated with one atomic per weight per workgroup: adds to ONE address serialise
+    // (~0.1 us each), so the number of workgroups is kept near 32 -- and every wave then keeps 16 / NC rows in flight to cover the latency
+    float* sk_ws = nullptr; unsigned* sk_cnt = nullptr;
+    static const int no_ws = FFH_LAB_INT("FFH_SKINNY_NO_WS", 0);     // A/B switch
+    const int ws_stride = (out * in + out + 3) / 4 * 4;
+    // (from 16384 samples up, where the stream wants 256 workgroups and the chains are 256 long: 256 -> 1 at 32768 samples dW + db
+    //  33.4 -> 19.4 us alone.  Below that 32 - 64 workgroups and their short chains are faster than the last arriver's tail:
+    //  2048 x 64 -> 16: 11 vs 28 us, Kaggle-shape step 0.186 vs 0.190 ms.  FFH_SKINNY_WS_MIN_BATCH: A/B)
+    static const int64_t ws_min_batch = FFH_LAB_I64("FFH_SKINNY_WS_MIN_BATCH", 16384);
+    const bool want_ws = !no_ws && batch >= ws_min_batch && (a.do_dw || (a.do_db && db)) && ws_stride <= kSkinnyWsRow && skinny_ws_for(c, as_stream(s), &sk_ws, &sk_cnt);
     static const int nblk_env = FFH_LAB_INT("FFH_SKINNY_NBLK", 0);   // A/B switch
     // large batches: HBM traffic outweighs the longer atomic chains -- at 32768 samples the x / dX traffic (67 MB for the 256 -> 1
     // layer) needs every CU's load queue, and the 256 per-workgroup atomics per weight are ~3 us spread over the launch
-    const int64_t nblk = nblk_env > 0 ? nblk_env : (batch >= 16384 ? 256 : (batch >= 8192 ? 64 : 32));
+    const int64_t nblk = nblk_env > 0 ? nblk_env : (want_ws ? (batch >= 16384 ? 256 : 128) : (batch >= 16384 ? 256 : (batch >= 8192 ? 64 : 32)));
     int64_t rpb = (batch + nblk - 1) / nblk;
     rpb = (rpb + 15) / 16 * 16;
     if (rpb > 1024) rpb = 1024;
@@ -1646,6 +1759,10 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     size_t lds = (size_t)rpb * out * sizeof(float);
     const size_t red = (size_t)4 * out * in * sizeof(float);            // cross-wave dW reduction
     if (red > lds) lds = red;
+    if (want_ws && grid <= (unsigned)kSkinnyWsBlocks) {
+      a.ws = sk_ws; a.ws_cnt = sk_cnt; a.ws_stride = ws_stride;
+      if (lds < 4096) lds = 4096;                          // the last arriver's cross-thread combine
+    }
     const int nc = in <= 256 ? 1 : (in <= 512 ? 2 : 4);
 #define FFH_SKINNY(NCV, NOV) hipLaunchKernelGGL((linear_skinny_bwd_kernel<NCV, NOV>), dim3(grid), dim3(256), lds, as_stream(s), a)
     if (out == 1) { if (nc == 1) FFH_SKINNY(1, 1); else if (nc == 2) FFH_SKINNY(2, 1); else FFH_SKINNY(4, 1); }

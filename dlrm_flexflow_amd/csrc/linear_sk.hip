@@ -495,7 +495,8 @@ bool sk_slots_for(ffh_ctx* c, hipStream_t s, float** slots, unsigned** flags) {
   float* sl = nullptr; unsigned* fl = nullptr;
   const size_t G = (size_t)(c->num_cus & ~7);
   if (hipMalloc((void**)&sl, G * SK_BM * SK_BN * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (hipMalloc((void**)&fl, G * sizeof(unsigned)) != hipSuccess || hipMemset(fl, 0, G * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(sl); if (fl) (void)hipFree(fl); return false; }
+  // (flags cleared ON the stream the launches go to: a null-stream hipMemset is not ordered against a non-blocking stream)
+  if (hipMalloc((void**)&fl, G * sizeof(unsigned)) != hipSuccess || hipMemsetAsync(fl, 0, G * sizeof(unsigned), s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(sl); if (fl) (void)hipFree(fl); return false; }
   c->sk_sets[c->sk_nsets] = {(void*)s, sl, fl};
   c->sk_nsets++;
   *slots = sl; *flags = fl;

@@ -52,6 +52,7 @@ int ffh_ctx_destroy(ffh_ctx* c) {
   if (c && c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c && c->zeros) (void)hipFree(c->zeros);
   for (int i = 0; c && i < c->sk_nsets; i++) { if (c->sk_sets[i].slots) (void)hipFree(c->sk_sets[i].slots); if (c->sk_sets[i].flags) (void)hipFree(c->sk_sets[i].flags); }
+  for (int i = 0; c && i < c->skinny_nsets; i++) { if (c->skinny_sets[i].ws) (void)hipFree(c->skinny_sets[i].ws); if (c->skinny_sets[i].cnt) (void)hipFree(c->skinny_sets[i].cnt); }
   delete c;
   return FFH_OK;
 }

@@ -642,3 +642,28 @@ def test_stream_with_priority_is_an_ordinary_stream(hip):
         assert float(t.abs().sum()) == 0.0
         hip.check(hip.lib.ffh_stream_destroy(hip.ctx, s), "destroy")
     assert hip.lib.ffh_stream_create_with_priority(hip.ctx, None, 0) == -1
+
+
+@pytest.mark.parametrize("B,IN,OUT", [(32768, 256, 1), (20000, 256, 1), (16384, 64, 16), (17000, 1024, 3)])
+def test_narrow_layer_backward_with_partial_rows_and_last_arriver(hip, B, IN, OUT):
+    """Round 4: from 16384 samples up the one-launch narrow-layer backward (the click-probability layer) no longer ends every weight in
+    a chain of one atomic per workgroup: the workgroups leave partial dW / db rows in ctx-owned scratch and the last one to arrive adds
+    them up in block order.  dw, db (accumulated onto what the buffers held), dx against float64 at 1e-5 of the term mass; three
+    launches in a row (the arrival counter must be back at 0 each time); the same bits run to run (the block order is fixed)."""
+    g = torch.Generator(device="cpu"); g.manual_seed(B + IN + OUT)
+    x = torch.randn(B, IN, generator=g).to(DEV); w = (torch.randn(OUT, IN, generator=g) * 0.1).to(DEV)
+    y = torch.rand(B, OUT, generator=g).to(DEV); dy0 = torch.randn(B, OUT, generator=g).to(DEV)
+    d64, x64, w64 = dy0.double(), x.double(), w.double()
+    refs = {"dw": (0.5 + d64.t() @ x64, 0.5 + d64.abs().t() @ x64.abs()), "db": (0.25 + d64.sum(0), 0.25 + d64.abs().sum(0)),
+            "dx": (d64 @ w64, d64.abs() @ w64.abs() + 1e-30)}
+    seen = []
+    for rep in range(3):
+        dy = dy0.clone(); dx = torch.full((B, IN), 7.0, device=DEV); dw = torch.full((OUT, IN), 0.5, device=DEV); db = torch.full((OUT,), 0.25, device=DEV)
+        hip.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy, OUT, w, dw, db, IN, OUT, B, capi.AC_MODE_NONE, capi.LINEAR_DX_OVERWRITE, None, None)
+        assert "skinny" in _route(hip)
+        torch.cuda.synchronize()
+        for nm, got in (("dw", dw), ("db", db), ("dx", dx)):
+            ref, mass = refs[nm]
+            assert float(((got.double() - ref).abs() / mass).max()) < 1e-5, (nm, rep)
+        seen.append((dw.cpu().numpy().tobytes(), db.cpu().numpy().tobytes()))
+    assert seen[0] == seen[1] == seen[2], "partial rows are added in block order: no run-to-run differences"
