@@ -27,6 +27,7 @@ int ffh_ctx_create(ffh_ctx** out, int device) {
   if (hipGetDeviceProperties(&p, device) == hipSuccess) c->num_cus = p.multiProcessorCount;
   if (c->num_cus <= 0) c->num_cus = 256;
   if (hipMalloc((void**)&c->zeros, 256) != hipSuccess || hipMemset(c->zeros, 0, 256) != hipSuccess) { (void)hipGetLastError(); c->zeros = nullptr; }
+  else (void)hipStreamSynchronize(nullptr);      // the null-stream memset is not ordered against the non-blocking streams the callers create: wait for it once, here
   *out = c;
   return FFH_OK;
 }
