@@ -1614,7 +1614,11 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   static const int no_thin = FFH_LAB_INT("FFH_NO_THIN", 0);   // A/B switch (tools/ab.sh)
   // (rows kernel from 8192 samples up: it keeps 128 rows per workgroup to amortise its weight registers, so a 2048-sample launch
   //  would be 32 workgroups -- the MFMA form below is the faster one there: Kaggle step 208 vs 185 us)
-  static const int thin_rows_min = FFH_LAB_INT("FFH_THIN_ROWS_MIN_BATCH", 8192);   // A/B switch
+  // Round 4 re-measured the three forms of the 13 -> 512 layer alone (profiles/r04_ab_schedule.txt): at 32768 samples the rows kernel
+  // 31.8 us, the MFMA thin kernel 25.4, the ordinary GEMM path 23.4; at 8192: 23.9 / 9.5 / 14.0; at 4096: 7.7 / 7.5 / 8.2 -- the rows
+  // kernel is off (A/B: FFH_THIN_ROWS_MIN_BATCH), the thin kernel serves below 16384 samples (FFH_THIN_MAX_BATCH)
+  static const int64_t thin_rows_min = FFH_LAB_I64("FFH_THIN_ROWS_MIN_BATCH", (int64_t)1 << 40);   // A/B switch
+  static const int64_t thin_max = FFH_LAB_I64("FFH_THIN_MAX_BATCH", 16384);
   if (!no_thin && in <= 16 && out >= 64 && out % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)y | (uintptr_t)(bias ? bias : w)) & 15) == 0 && batch >= thin_rows_min) {
     hipLaunchKernelGGL(linear_thin_fwd_rows_kernel, dim3((unsigned)((batch + kThinRowsPerWg - 1) / kThinRowsPerWg), (unsigned)((out + 255) / 256)), dim3(256), 0,
                        as_stream(s), x, ldx, y, ldy, w, bias, in, out, batch, act);
@@ -1622,7 +1626,7 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
     ffh_route_add(c, "linear_fwd|thin_rows");
     return FFH_OK;
   }
-  if (!no_thin && in <= 16 && out >= 64) {
+  if (!no_thin && in <= 16 && out >= 64 && batch < thin_max) {
     hipLaunchKernelGGL(linear_thin_fwd_kernel, dim3((unsigned)((batch + 31) / 32), (unsigned)((out + 255) / 256)), dim3(512), 0, as_stream(s), x, ldx, y, ldy,
                        w, bias, in, out, batch, act);
     FFH_LAUNCH_CHECK(c, "linear_thin_fwd_kernel");
