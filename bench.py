@@ -623,10 +623,15 @@ def main():
             "radix_hist/radix_scatter (LDS-histogram LSD radix sort of the ids) + emb_sgd_reduce (segmented sums, both folds by the last tile "
             "to arrive, W -= lr*sum); batch x bag <= 2048 per table: emb_sgd_small_kernel, one launch", bwd_bytes, t_bwd,
             pmc.get("update_bytes_per_call"), src, in_step_sec=t_bwd_in)
-        if "--no-early-sort" not in args.shim_flags.split():
+        sf = args.shim_flags.split()
+        if "--early-sort" in sf or ("--no-early-sort" not in sf and (world > 1 or args.force_exchange or B // world < 8192)):
             out["kernels"]["embedding_bwd_sgd_fused"]["in_step_covers"] = (
                 "the apply phase only (ffh_embedding_bwd_sgd_apply_multi): inside a step the index-only sort is issued behind the gather "
                 "(ffh_embedding_bwd_sort_multi, --no-early-sort turns that off); us_per_launch above is the whole update, sort included")
+        else:
+            out["kernels"]["embedding_bwd_sgd_fused"]["in_step_covers"] = (
+                "the whole update, sort + apply (one GPU, >= 8192 samples: the early sort is off by shape -- beside the top MLP's first forward GEMM "
+                "it cost more than it saved; --early-sort forces it)")
     if solo:
         flops = mlp_flops_per_sample(w) * B
         peak = BF16_PEAK_TFLOPS if bf16 else F32_PEAK_TFLOPS

@@ -114,7 +114,8 @@ class FFConfig {
   bool pad_linear_k;                 // (A/B: --no-pad-linear-k) zero-pad the input / kernel of a wide Linear whose in_dim is not a multiple of 64
   bool sparse_embedding_optimizer;   // --sparse-embedding-optimizer: momentum / weight-decay SGD and Adam update the rows a batch touched, with per-row state, on the
                                // sorted segments of the fused update (ffh_sparse_opt: lazy semantics, a stated divergence) instead of the reference's dense sweep
-  bool early_sort;             // the index-only sort of the fused table update runs behind the gather (ffh_embedding_bwd_sort_multi), off the backward's critical path (A/B: --no-early-sort)
+  int early_sort;              // the index-only sort of the fused table update runs behind the gather (ffh_embedding_bwd_sort_multi), off the backward's critical path:
+                               // 1 / 0 (--early-sort / --no-early-sort), -1 = by shape (FFModel::early_sort_possible)
   bool stream_priorities;      // the embedding stream is created at a higher HIP priority (A/B: --stream-priorities; off; ignored with the exchange)
   bool dx_colsum;              // a layer's bias gradient from the epilogue of the data-gradient kernel of the layer above (A/B: --no-dx-colsum)
   bool dx_scatter;             // exchange mode: the layer above the feature Concat writes its dX into the send buffer itself (A/B: --no-dx-scatter)

@@ -135,7 +135,7 @@ FFConfig::FFConfig() {
   dx_scatter = true;
   dx_colsum = true;
   stream_priorities = false;
-  early_sort = true;
+  early_sort = -1;
   pad_linear_k = true;
   capture_exchange = false;
   bf16_twins = true;
@@ -206,7 +206,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-dx-colsum")) { dx_colsum = false; continue; }
     if (is("--stream-priorities")) { stream_priorities = true; continue; }
     if (is("--no-stream-priorities")) { stream_priorities = false; continue; }
-    if (is("--no-early-sort")) { early_sort = false; continue; }
+    if (is("--no-early-sort")) { early_sort = 0; continue; }
+    if (is("--early-sort")) { early_sort = 1; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
     if (is("--capture-exchange")) { capture_exchange = true; continue; }
     if (is("--no-bf16-twins")) { bf16_twins = false; continue; }               // A/B and tests: tensor-op mode rounding its operands inside the kernels
@@ -2005,6 +2006,11 @@ void FFModel::embedding_kernels_only(bool fwd, ffh_stream s, const std::vector<c
 bool FFModel::early_sort_possible() const {
   if (!config.early_sort || !config.overlap_embedding || !fused_embedding_update() || config.profiling) return false;
   if (config.computationMode != COMP_MODE_TRAINING || use_workers()) return false;
+  // by shape (round 4, profiles/r04_ab_schedule.txt): behind the exchange the whole update sits between the backward all-to-all and
+  // the next gather, so the sort leaves that chain; on one GPU it pays at small per-GPU batches (4096 samples: 1.178 vs 1.191 ms)
+  // and costs at large ones, where it runs beside the top MLP's first forward GEMM (32768: 7.76-7.79 vs 7.71-7.73; 8192, MLPerf
+  // shape: 1.236-1.239 vs 1.227-1.233)
+  if (config.early_sort < 0 && !exchange && local_batch >= 8192) return false;
   int n = 0, cols = -1;
   for (const EmbShard& sh : shards) {
     if (sh.owner != rank) continue;

@@ -120,7 +120,7 @@ def test_model_with_early_sort_trains_to_the_same_bits(hip, trace):
     args = ["--backend", HIP, "-b", "16384", "--arch-sparse-feature-size", "64", "--arch-embedding-size", "-".join(map(str, rows)),
             "--arch-mlp-bot", "13-32-64", "--arch-mlp-top", "384-64-1", "--deterministic"]
     res = []
-    for extra in ([], ["--no-early-sort"], ["--no-overlap"]):
+    for extra in (["--early-sort"], ["--no-early-sort"], ["--no-overlap"]):      # (by default the sort is early below 8192 samples per GPU only)
         app = ffmodel.DLRM(args + extra)
         app.warmup()
         app.train_steps(6, trace=trace)
