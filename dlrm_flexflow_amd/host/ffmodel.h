@@ -549,7 +549,8 @@ class FFModel {
   void order_input_writes_behind_update() const;
   void profiled(const Op* op, bool fwd, const std::function<void()>& fn) const;   // --profiling: one op between two events
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
-  bool early_sort_possible() const;      // one launch group, nothing else on the workspace between a step's gather and its update
+  static constexpr int early_sort_big_batch_mode = 0;   // one GPU, >= 8192 samples: 0 = the sort stays in front of the apply phase (see early_sort_possible)
+  bool early_sort_possible(int where) const;      // one launch group, nothing else on the workspace between a step's gather and its update
   mutable bool emb_sorted_early;         // this step's sort was issued behind the gather: the update is the apply phase only
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
   std::vector<Initializer*> owned_initializers;

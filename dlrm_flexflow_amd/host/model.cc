@@ -208,6 +208,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-stream-priorities")) { stream_priorities = false; continue; }
     if (is("--no-early-sort")) { early_sort = 0; continue; }
     if (is("--early-sort")) { early_sort = 1; continue; }
+    if (is("--sort-at-backward-start")) { early_sort = 2; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
     if (is("--capture-exchange")) { capture_exchange = true; continue; }
     if (is("--no-bf16-twins")) { bf16_twins = false; continue; }               // A/B and tests: tensor-op mode rounding its operands inside the kernels
@@ -2003,14 +2004,15 @@ void FFModel::embedding_kernels_only(bool fwd, ffh_stream s, const std::vector<c
 // region dependences would give an index-only task).  The sorted list waits in the ctx workspace, so this is only done when
 // nothing else writes the workspace between a step's gather and its update: one launch group (one shard width, <=
 // FFH_MAX_TABLES shards), no row-wise sharded table (its own fused call), launches issued inline.
-bool FFModel::early_sort_possible() const {
+bool FFModel::early_sort_possible(int where) const {
   if (!config.early_sort || !config.overlap_embedding || !fused_embedding_update() || config.profiling) return false;
   if (config.computationMode != COMP_MODE_TRAINING || use_workers()) return false;
   // by shape (round 4, profiles/r04_ab_schedule.txt): behind the exchange the whole update sits between the backward all-to-all and
   // the next gather, so the sort leaves that chain; on one GPU it pays at small per-GPU batches (4096 samples: 1.178 vs 1.191 ms)
   // and costs at large ones, where it runs beside the top MLP's first forward GEMM (32768: 7.76-7.79 vs 7.71-7.73; 8192, MLPerf
   // shape: 1.236-1.239 vs 1.227-1.233)
-  if (config.early_sort < 0 && !exchange && local_batch >= 8192) return false;
+  const int mode = config.early_sort > 0 ? config.early_sort : ((!exchange && local_batch >= 8192) ? early_sort_big_batch_mode : 1);
+  if (mode != where) return false;
   int n = 0, cols = -1;
   for (const EmbShard& sh : shards) {
     if (sh.owner != rank) continue;
@@ -2276,7 +2278,7 @@ void FFModel::issue_embedding_forward_on_side_stream() const {
     embedding_group_forward(side_stream);
     probe_record(1, side_stream, ctx);
     check(api->ffh_event_record(ctx, ev_join, side_stream), "join");
-    if (early_sort_possible()) {        // behind the join: nothing waits for it until this step's update
+    if (early_sort_possible(1)) {       // behind the join: nothing waits for it until this step's update
       launch_shard_groups(this, kSortOnly, side_stream, ctx);
       emb_sorted_early = true;
     }
@@ -2378,6 +2380,10 @@ void FFModel::backward(int _seq_length) {
                                    local_rows(fin, this), fin.adim[0], scale, metrics_flags, stream), "metrics + loss backward");
   grad_ready_attached = false;
   z_free_recorded = false;
+  if (!emb_sorted_early && early_sort_possible(2)) {      // (--sort-at-backward-start) the index-only sort beside the first backward GEMMs
+    launch_shard_groups(this, kSortOnly, side_stream, ctx);
+    emb_sorted_early = true;
+  }
   auto mark_z_free = [&](int l) {     // behind the last reader of the gather's destination among the forked weight-gradient GEMMs
     if (l == z_reader_layer && dw_forked && !dw_worker && capturing_trace < 0) {
       check(api->ffh_event_record(ctx, ev_z_free, (l == big_dw_layer || !config.two_dw_streams) ? dw_stream : dw_stream2), "z free");   // the stream that layer's dW is on
