@@ -1855,6 +1855,24 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     const bool colsum_sk = want_dx && c->colsum_dst && c->colsum_ncols == in && gx.epi == EPI_STORE && !scatter_pending && !c->deterministic;
     if (colsum_sk) gx.colsum = c->colsum_dst;
     bool ok = (do_dw || want_dx) && !(relu_live && !do_dw) && !(want_dx && scatter_pending && !scatter_sk);
+    // A layer whose data gradient is a shape of the persistent kernel while its weight gradient is not (few k-tiles per workgroup:
+    // 8192 x 512 -> 256) used to lose BOTH to the other kernels (dX 51 us in the MLPerf-shape step instead of 23).  With dy final
+    // (no live activation derivative) the call is the two split calls it stands for: ONLY_DX here, ONLY_DW through whatever serves it,
+    // forked to s_dw as the caller asked.
+    if (ok && do_dw && want_dx && !relu_live && !separate && !label && !scatter_pending && !gemm_sk_serves(c, gw, SK_FORM_DW) && gemm_sk_serves(c, gx, SK_FORM_DX)) {
+      const bool forked_split = s_dw != nullptr && s_dw != s;
+      if (forked_split) {
+        c->second_stream_used = 1;
+        if (!c->ev_fork) FFH_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        FFH_HIP_TRY(c, hipEventRecord(c->ev_fork, as_stream(s)));
+        FFH_HIP_TRY(c, hipStreamWaitEvent(as_stream(s_dw), c->ev_fork, 0));
+      }
+      const int f0 = flags & ~(FFH_LINEAR_ONLY_DX | FFH_LINEAR_ONLY_DW);
+      int rc = linear_bwd_impl(c, x, ldx, dx, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, f0 | FFH_LINEAR_ONLY_DX, s, nullptr, nullptr, 0.0f, nullptr, 0);
+      if (rc) return rc;
+      rc = linear_bwd_impl(c, x, ldx, nullptr, lddx, y, ldy, dy, lddy, w, dw, db, in, out, batch, act, f0 | FFH_LINEAR_ONLY_DW, forked_split ? s_dw : s, nullptr, nullptr, 0.0f, nullptr, 0);
+      return rc;
+    }
     if (ok && do_dw) ok = gemm_sk_serves(c, gw, SK_FORM_DW);
     if (ok && want_dx) ok = gemm_sk_serves(c, gx, SK_FORM_DX);
     if (ok) {

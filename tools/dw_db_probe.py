@@ -30,9 +30,9 @@ for B, IN, OUT in shapes:
                 route = hip.lib.ffh_linear_last_route(hip.ctx).decode()
                 out.append(f"dW act {nm}{fn} {dn}: {t:7.1f} us {fl/t/1e6:6.1f} TF [{route}]")
         t = timeit(lambda: hip.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy, OUT, w, dw, db, IN, OUT, B, act, capi.LINEAR_ONLY_DX | capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DY_PREMASKED, None, None))
-        out.append(f"dX act {nm} premasked overwrite: {t:7.1f} us {fl/t/1e6:6.1f} TF")
+        out.append(f"dX act {nm} premasked overwrite: {t:7.1f} us {fl/t/1e6:6.1f} TF [{hip.lib.ffh_linear_last_route(hip.ctx).decode()}]")
         t = timeit(lambda: hip.call("ffh_linear_fwd", x, IN, y, OUT, w, db, IN, OUT, B, act, None))
-        out.append(f"fwd act {nm}: {t:7.1f} us {fl/t/1e6:6.1f} TF")
+        out.append(f"fwd act {nm}: {t:7.1f} us {fl/t/1e6:6.1f} TF [{hip.lib.ffh_linear_last_route(hip.ctx).decode()}]")
     if os.environ.get("DW_CHECK"):
         dw.zero_(); dy2 = dy.clone()
         hip.call("ffh_linear_bwd_ex", x, IN, dx, IN, y, OUT, dy2, OUT, w, dw, None, IN, OUT, B, capi.AC_MODE_NONE, capi.LINEAR_ONLY_DW, None, None)
