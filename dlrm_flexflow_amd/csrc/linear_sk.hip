@@ -465,7 +465,8 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
   if (ntiles * nk >= (1LL << 31)) return false;
   if (form == SK_FORM_DW) {
     if (c->deterministic || g.epi != EPI_ATOMIC) return false;     // its partial tiles meet by atomics
-    if (ntiles * nk < 8LL * p.G) return false;                     // at least eight k-tiles per workgroup (with four the split-K kernels of linear.hip win:
+    static const int dw_min_it = FFH_LAB_INT("FFH_SK_DW_MIN_IT", 8);       // A/B switch
+    if (ntiles * nk < (int64_t)dw_min_it * p.G) return false;      // at least eight k-tiles per workgroup (with four the split-K kernels of linear.hip win:
                                                                    // 8192 x 512 -> 256: 32.3 vs 37.0 us; with eight this one does: 4096 x 1024 -> 512: 48.7 vs 52.5)
   } else {
     if (g.epi != EPI_STORE && g.epi != EPI_ADD) return false;
