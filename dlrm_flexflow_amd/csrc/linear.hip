@@ -1860,7 +1860,8 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     // (no live activation derivative) the call is the two split calls it stands for: ONLY_DX here, ONLY_DW through whatever serves it,
     // forked to s_dw as the caller asked.
     if (ok && do_dw && want_dx && !relu_live && !separate && !label && !scatter_pending && !gemm_sk_serves(c, gw, SK_FORM_DW) && gemm_sk_serves(c, gx, SK_FORM_DX)) {
-      const bool forked_split = s_dw != nullptr && s_dw != s;
+      static const int dw_on_s = FFH_LAB_INT("FFH_SPLIT_DW_ON_S", 0);      // A/B: the non-persistent dW behind the dX on s instead of beside persistent kernels on s_dw
+      const bool forked_split = s_dw != nullptr && s_dw != s && !dw_on_s;
       if (forked_split) {
         c->second_stream_used = 1;
         if (!c->ev_fork) FFH_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
