@@ -22,6 +22,7 @@ HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libffhip.so")
 HEADER_PATH = os.path.join(REPO_ROOT, "include", "ff_hip.h")
 
 FFH_OK = 0
+FFH_ERR_BAD_ARG, FFH_ERR_HIP, FFH_ERR_UNSUPPORTED, FFH_ERR_WORKSPACE, FFH_ERR_NOMEM = -1, -2, -3, -4, -5
 AC_MODE_NONE, AC_MODE_RELU, AC_MODE_SIGMOID, AC_MODE_TANH, AC_MODE_GELU = 10, 11, 12, 13, 14
 AGGR_MODE_NONE, AGGR_MODE_SUM, AGGR_MODE_AVG = 20, 21, 22
 MAX_TABLES = 64
@@ -63,6 +64,12 @@ class PerfMetrics(C.Structure):
     _fields_ = [("train_all", C.c_int32), ("train_correct", C.c_int32), ("cce_loss", F),
                 ("sparse_cce_loss", F), ("mse_loss", F), ("rmse_loss", F), ("mae_loss", F),
                 ("pad_", C.c_int32)]
+
+
+class ChainLayer(C.Structure):
+    """struct ffh_chain_layer"""
+    _fields_ = [("w", P), ("bias", P), ("y", P), ("dy", P), ("dw", P), ("db", P), ("ldy", L), ("lddy", L),
+                ("ldw", C.c_int32), ("in_dim", C.c_int32), ("out_dim", C.c_int32), ("activation", C.c_int32)]
 
 
 class DeviceInfo(C.Structure):
@@ -132,6 +139,8 @@ _SIGS = {
     "ffh_linear_bwd_mse": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, F, P, I, P]),
     "ffh_linear_pair_bwd": (I, [P, P, L, P, L, P, L, P, P, P, I, I, I, I, P, L, P, L, P, L, P, I, I, I, L, P]),
     "ffh_linear_pair_fwd": (I, [P, P, L, P, P, I, I, P, L, I, P, P, I, I, P, L, L, P]),
+    "ffh_mlp_chain_fwd": (I, [P, P, L, C.POINTER(ChainLayer), I, L, P]),
+    "ffh_mlp_chain_bwd": (I, [P, P, L, P, L, C.POINTER(ChainLayer), I, L, I, P]),
     "ffh_second_stream_used": (I, [P, I]),
     "ffh_event_record_with_next_linear_bwd": (I, [P, P]),
     "ffh_linear_bwd_set_dx_scatter": (I, [P, P, I, P]),
@@ -262,6 +271,17 @@ class FFHLib:
         arr = (EmbState * len(entries))()
         for k, (s0, s1) in enumerate(entries):
             arr[k] = EmbState(ptr(s0), ptr(s1))
+        return arr
+
+    @staticmethod
+    def chain_layers(entries) -> "C.Array":
+        """entries: iterable of dicts with w, bias, y, dy, dw, db, ldy, lddy, ldw, in_dim, out_dim, activation (missing: None / 0)."""
+        entries = list(entries)
+        arr = (ChainLayer * len(entries))()
+        for k, e in enumerate(entries):
+            arr[k] = ChainLayer(ptr(e.get("w")), ptr(e.get("bias")), ptr(e.get("y")), ptr(e.get("dy")), ptr(e.get("dw")), ptr(e.get("db")),
+                                int(e.get("ldy", e["out_dim"])), int(e.get("lddy", e["out_dim"])), int(e.get("ldw", e["in_dim"])),
+                                int(e["in_dim"]), int(e["out_dim"]), int(e["activation"]))
         return arr
 
     def transpose(self, name: str, dst, src, in_dims, perm, stream=None):

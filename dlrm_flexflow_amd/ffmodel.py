@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         "flexflow_model_get_layer_name": (C.c_char_p, [H, I]), "flexflow_model_get_layer_num_weights": (I, [H, I]),
         "flexflow_model_get_parameter": (H, [H, I, I]), "flexflow_model_get_layer_output": (H, [H, I]),
         "flexflow_model_get_stream": (P, [H]), "flexflow_model_uses_graph": (I, [H]),
+        "flexflow_model_get_counter": (C.c_int64, [H, C.c_char_p]),
         "flexflow_tensor_get_num_dims": (I, [H]), "flexflow_tensor_get_dims": (None, [H, IP]),
         "flexflow_tensor_get_local_rows": (C.c_int64, [H]), "flexflow_tensor_is_local": (B, [H]),
         "flexflow_tensor_get_device_ptr": (P, [H]), "flexflow_tensor_get_ld": (C.c_int64, [H]),
@@ -316,6 +317,7 @@ class FFModel:
     def stream(self) -> int: return lib().flexflow_model_get_stream(self.h) or 0
     @property
     def uses_graph(self) -> bool: return bool(lib().flexflow_model_uses_graph(self.h))
+    def counter(self, name: str) -> int: return int(lib().flexflow_model_get_counter(self.h, name.encode()))
 
     def perf_metrics(self) -> PerfMetrics:
         p = PerfMetrics()

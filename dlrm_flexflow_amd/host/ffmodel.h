@@ -120,6 +120,8 @@ class FFConfig {
   bool dx_colsum;              // a layer's bias gradient from the epilogue of the data-gradient kernel of the layer above (A/B: --no-dx-colsum)
   bool dx_scatter;             // exchange mode: the layer above the feature Concat writes its dX into the send buffer itself (A/B: --no-dx-scatter)
   bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)
+  bool mlp_chain;              // a run of narrow Linear layers (every width <= 512) as one launch forward, two backward (ffh_mlp_chain_fwd / _bwd; A/B: --no-mlp-chain)
+  int64_t mlp_chain_max_batch; // ... for at most this many samples per GPU (--mlp-chain-max-batch N)
   bool attach_events;          // hang ev_grad_ready on the producing kernel's completion instead of a record packet (A/B: --no-attach-event)
   bool timing_events;          // A/B: stream-ordering events created with timestamps, as before
   bool fuse_loss;              // loss step + metrics inside the last layer's one-launch backward (A/B: --no-fused-loss)
@@ -312,6 +314,10 @@ class Linear : public Op {
   Linear* colsum_lower;         // the Linear below whose FINAL dy is the dX this layer stores: its bias gradient can come out of this layer's
                                 // data-gradient kernel (ffh_linear_bwd_set_dx_colsum, ABI 10) instead of riding on its own weight-gradient GEMM
   bool db_from_upper;           // set by the layer above for this backward(): the bias gradient is done, the call passes db = NULL
+  std::vector<Linear*> chain_fwd;  // non-empty on the LOWEST layer of a chain of narrow layers: its members bottom -> top; forward() of that layer
+                                   // launches all of them (ffh_mlp_chain_fwd, ABI 12)
+  mutable bool fwd_done_by_chain;  // set by the chain's lowest layer for this forward()
+  std::vector<Linear*> chain_bwd;  // non-empty on the TOP layer of the chain FFModel::backward runs as one call (ffh_mlp_chain_bwd): members bottom -> top
   Initializer *kernel_initializer, *bias_initializer;
 };
 
@@ -509,6 +515,10 @@ class FFModel {
   mutable bool dw1_used = false, dw2_used = false;   // which weight-gradient stream(s) this step's forks were offered (joined in update())
   mutable bool dw_stream_used_directly = false;   // a weight gradient was enqueued on dw_stream by this layer itself (deferred dW), not by the library's fork
   int defer_big_dw_layer() const;
+  mutable int64_t n_chain_fwd_calls = 0, n_chain_bwd_calls = 0;   // successful ffh_mlp_chain_fwd / _bwd calls (tests: flexflow_model_get_counter)
+  bool mlp_chain_usable(int64_t rows) const;      // the chain launches are allowed in this mode / at this batch
+  int run_chain_fwd(const Linear* lowest) const;  // FFH_OK, or FFH_ERR_UNSUPPORTED with nothing launched
+  int run_chain_bwd(Linear* top);
   int dw_cu_reserve_for(int64_t batch) const;
   mutable bool mlp_grads_clean;   // the optimizer kernel cleared the MLP gradient slab (FFH_OPT_ZERO_GRAD): zero_gradients() skips it
   LaunchWorker *dw_worker, *side_worker;   // NULL: launches are issued inline by the calling thread

@@ -1,5 +1,6 @@
 // ffmodel_c.cc -- see ffmodel_c.h
 #include "ffmodel_c.h"
+#include <string>
 
 #include <chrono>
 
@@ -117,6 +118,12 @@ flexflow_tensor_t flexflow_model_get_parameter(flexflow_model_t m, int l, int i)
 flexflow_tensor_t flexflow_model_get_layer_output(flexflow_model_t m, int l) { return wrap(M(m)->layers.at(l)->outputs[0]); }
 void* flexflow_model_get_stream(flexflow_model_t m) { return M(m)->stream; }
 int flexflow_model_uses_graph(flexflow_model_t m) { return M(m)->config.enable_graph ? 1 : 0; }
+int64_t flexflow_model_get_counter(flexflow_model_t m, const char* name) {
+  const std::string n(name ? name : "");
+  if (n == "mlp_chain_fwd_calls") return M(m)->n_chain_fwd_calls;
+  if (n == "mlp_chain_bwd_calls") return M(m)->n_chain_bwd_calls;
+  return -1;
+}
 
 int flexflow_tensor_get_num_dims(flexflow_tensor_t t) { return T(t)->numDim; }
 void flexflow_tensor_get_dims(flexflow_tensor_t t, int* dims) { for (int i = 0; i < T(t)->numDim; i++) dims[i] = T(t)->adim[T(t)->numDim - 1 - i]; }

@@ -84,6 +84,7 @@ flexflow_tensor_t flexflow_model_get_parameter(flexflow_model_t, int layer, int 
 flexflow_tensor_t flexflow_model_get_layer_output(flexflow_model_t, int layer);
 void* flexflow_model_get_stream(flexflow_model_t);
 int  flexflow_model_uses_graph(flexflow_model_t);
+int64_t flexflow_model_get_counter(flexflow_model_t, const char* name);   /* diagnostics for tests: "mlp_chain_fwd_calls", "mlp_chain_bwd_calls"; -1: unknown */
 
 /* Tensor / Parameter host<->device [ref: flexflow_parameter_set_weights_float, python/flexflow_c.h:498-546] */
 int  flexflow_tensor_get_num_dims(flexflow_tensor_t);

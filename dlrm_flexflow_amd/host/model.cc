@@ -132,6 +132,8 @@ FFConfig::FFConfig() {
   timing_events = false;
   attach_events = true;
   fuse_pair = true;
+  mlp_chain = true;
+  mlp_chain_max_batch = 8192;
   dx_scatter = true;
   dx_colsum = true;
   stream_priorities = false;
@@ -202,6 +204,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--timing-events")) { timing_events = true; continue; }
     if (is("--no-attach-event")) { attach_events = false; continue; }
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
+    if (is("--no-mlp-chain")) { mlp_chain = false; continue; }
+    if (is("--mlp-chain-max-batch")) { mlp_chain_max_batch = atoll(next()); continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
     if (is("--no-dx-colsum")) { dx_colsum = false; continue; }
     if (is("--stream-priorities")) { stream_priorities = true; continue; }
@@ -440,7 +444,7 @@ void Op::print_layer(const FFModel&) const {
 static FFConfig& profiling_schedule(FFConfig& c) {
   if (c.profiling) {
     c.overlap_embedding = false; c.enable_graph = false; c.parallel_dw = false; c.async_launch = false;
-    c.fuse_pair = false; c.attach_events = false; c.dx_scatter = false; c.timing_events = true;
+    c.fuse_pair = false; c.mlp_chain = false; c.attach_events = false; c.dx_scatter = false; c.timing_events = true;
   }
   return c;
 }
@@ -624,7 +628,7 @@ Tensor FFModel::batch_matmul(const Tensor& A, const Tensor& B, int a_seq_length_
 Linear::Linear(FFModel& model, const Tensor& input, int out_dim, ActiMode _activation, bool _use_bias, const Op* shared_op,
                Initializer* ki, Initializer* bi, const char* name)
     : Op(model, OP_LINEAR, name, 1, &input), in_channels(input.adim[0]), out_channels(out_dim), in_padded(input.adim[0]), activation(_activation),
-      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), dx_map(nullptr), dx_map_concat(nullptr), pair_upper(nullptr), fwd_done_by_pair(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false), colsum_lower(nullptr), db_from_upper(false),
+      use_bias(_use_bias), discard_input_grad(input.owner_op == nullptr), dx_overwrite(false), dx_map(nullptr), dx_map_concat(nullptr), pair_upper(nullptr), fwd_done_by_pair(false), pair_lower(nullptr), dx_mask_by_x(false), dy_premasked(false), colsum_lower(nullptr), db_from_upper(false), fwd_done_by_chain(false),
       kernel_initializer(ki), bias_initializer(bi) {
   if (shared_op) die("%s: weight sharing is not supported on this path", this->name);
   if (input.data_type != DT_FLOAT) die("%s: input must be DT_FLOAT", this->name);
@@ -649,6 +653,13 @@ void Linear::forward(const FFModel& ff) {
   const Tensor& y = outputs[0];
   const int64_t b = local_rows(y, &ff);
   if (fwd_done_by_pair) { fwd_done_by_pair = false; return; }      // the layer below computed this output in its launch
+  if (fwd_done_by_chain) { fwd_done_by_chain = false; return; }    // ... or the lowest layer of its chain did
+  if (!chain_fwd.empty() && ff.mlp_chain_usable(b)) {
+    const int rc = ff.run_chain_fwd(this);
+    if (rc == FFH_OK) { for (size_t i = 1; i < chain_fwd.size(); i++) chain_fwd[i]->fwd_done_by_chain = true; return; }
+    if (rc != FFH_ERR_UNSUPPORTED) ff.check(rc, name);
+    chain_fwd.clear();                                             // not a chain the library serves: the per-layer calls from now on
+  }
   if (pair_upper) {
     Linear* up = pair_upper;
     const Tensor& yu = up->outputs[0];
@@ -770,6 +781,50 @@ void Linear::backward_part(const FFModel& ff, int part) {
                                      flags, ff.stream, fork ? dws : nullptr), name);
   if (reserve > 0) ff.check(ff.api->ffh_ctx_set_dw_cu_reserve(ff.ctx, 0), "dw cu reserve");
   if (fork) { ff.dw_forked = true; (dws == ff.dw_stream ? ff.dw1_used : ff.dw2_used) = true; }
+}
+
+// ---- chains of narrow Linear layers (ffh_mlp_chain_fwd / _bwd, ABI 12; built in FFModel::allocate step 4e) -------------------
+bool FFModel::mlp_chain_usable(int64_t rows) const {
+  return config.mlp_chain && !config.profiling && !use_workers() && !config.deterministic && !config.allow_tensor_op_math_conversion &&
+         !config.fp32_split_bf16x3 && rows <= config.mlp_chain_max_batch;
+}
+static void fill_chain(const std::vector<Linear*>& ch, ffh_chain_layer* out) {
+  for (size_t i = 0; i < ch.size(); i++) {
+    const Linear* li = ch[i];
+    ffh_chain_layer& d = out[i];
+    d.w = (const float*)li->weights[0].impl->ptr;
+    d.bias = li->use_bias ? (const float*)li->weights[1].impl->ptr : nullptr;
+    d.y = (float*)li->outputs[0].impl->ptr; d.ldy = li->outputs[0].impl->ld;
+    d.dy = li->outputs[0].impl->grad; d.lddy = li->outputs[0].impl->grad_ld;
+    d.dw = li->weights[0].impl->grad;
+    d.db = (li->use_bias && !li->db_from_upper) ? li->weights[1].impl->grad : nullptr;
+    d.ldw = (int)li->weights[0].impl->ld; d.in_dim = li->in_padded; d.out_dim = li->out_channels; d.activation = (int)li->activation;
+  }
+}
+int FFModel::run_chain_fwd(const Linear* lowest) const {
+  const std::vector<Linear*>& ch = lowest->chain_fwd;
+  ffh_chain_layer ls[FFH_CHAIN_MAX_LAYERS];
+  fill_chain(ch, ls);
+  const Tensor& x = lowest->inputs[0];
+  const int rc = api->ffh_mlp_chain_fwd(ctx, (const float*)x.impl->ptr, x.impl->ld, ls, (int)ch.size(), local_rows(lowest->outputs[0], this), stream);
+  if (rc == FFH_OK) n_chain_fwd_calls++;
+  return rc;
+}
+// The whole backward of the chain whose top layer is `top`: every member's dW / db, the data gradients between them and (unless it is
+// discarded) the chain input's.  A member that completes the embedding output gradients (grad_attach_layer) gets its event recorded
+// behind the call: the chain's weight-gradient kernel still reads the buffer the next gather overwrites.
+int FFModel::run_chain_bwd(Linear* top) {
+  const std::vector<Linear*>& ch = top->chain_bwd;
+  ffh_chain_layer ls[FFH_CHAIN_MAX_LAYERS];
+  fill_chain(ch, ls);
+  Linear* lo = ch.front();
+  const Tensor& x = lo->inputs[0];
+  const int flags = (top->dy_premasked ? FFH_LINEAR_DY_PREMASKED : 0) | (lo->dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0) |
+                    (lo->dx_mask_by_x ? FFH_LINEAR_DX_MASK_BY_X : 0);
+  const int rc = api->ffh_mlp_chain_bwd(ctx, (const float*)x.impl->ptr, x.impl->ld, lo->discard_input_grad ? nullptr : x.impl->grad, x.impl->grad_ld, ls,
+                                        (int)ch.size(), local_rows(top->outputs[0], this), flags, stream);
+  if (rc == FFH_OK) { n_chain_bwd_calls++; for (Linear* li : ch) li->db_from_upper = false; }
+  return rc;
 }
 
 // =============================================================================================
@@ -1791,6 +1846,51 @@ void FFModel::allocate() {
       scatter_attach_layer = li->layer_index;
   }
 
+  // ---- 4e. chains of narrow Linear layers ------------------------------------------------------------------------------
+  // A run of consecutive Linear layers, each the only reader of the one below, every width <= FFH_CHAIN_MAX_WIDTH (the bottom MLP
+  // 13-512-256-128; the Kaggle shape's 13-512-256-64-16 and 432-512-256-1): one launch forward (the lowest member's forward()), and for
+  // the backward one call on the top member (FFModel::backward) -- at 2048-8192 samples per GPU these layers are 5-30 us kernels that wait
+  // for each other, ~12 launches and ~100 us of the 1.18 ms per-rank step.  The backward chain leaves out the
+  // model's last layer (the loss step is folded into its own one-launch backward) and a lowest member whose data gradient goes through
+  // the exchange path's column map.
+  for (Op* op : layers)
+    if (Linear* li = dynamic_cast<Linear*>(op)) { li->chain_fwd.clear(); li->chain_bwd.clear(); li->fwd_done_by_chain = false; }
+  if (config.mlp_chain && !config.profiling && !config.async_launch && !config.deterministic && !config.allow_tensor_op_math_conversion && !config.fp32_split_bf16x3) {
+    auto member_ok = [&](const Linear* li) {
+      return li->in_channels <= FFH_CHAIN_MAX_WIDTH && li->out_channels <= FFH_CHAIN_MAX_WIDTH && li->in_padded == li->in_channels &&
+             li->inputs[0].impl->pieces.empty() && li->outputs[0].impl->pieces.empty() && li->inputs[0].impl->ptr && li->outputs[0].impl->ptr;
+    };
+    size_t l = 0;
+    while (l < layers.size()) {
+      Linear* a = layers[l]->op_type == OP_LINEAR ? static_cast<Linear*>(layers[l]) : nullptr;
+      if (!a || !member_ok(a)) { l++; continue; }
+      std::vector<Linear*> ch{a};
+      while (l + ch.size() < layers.size() && ch.size() < (size_t)FFH_CHAIN_MAX_LAYERS) {
+        Op* nx = layers[l + ch.size()];
+        Linear* b = nx->op_type == OP_LINEAR ? static_cast<Linear*>(nx) : nullptr;
+        Linear* lo = ch.back();
+        if (!b || !member_ok(b) || b->inputs[0].impl != lo->outputs[0].impl || consumers[lo->outputs[0].impl] != 1) break;
+        ch.push_back(b);
+      }
+      l += ch.size();
+      if (ch.size() < 2) continue;
+      a->chain_fwd = ch;
+      std::vector<Linear*> bw = ch;
+      if (bw.back() == layers.back()) bw.pop_back();
+      if (!bw.empty() && bw.front()->dx_map) bw.erase(bw.begin());
+      bool ok = bw.size() >= 2;
+      for (size_t i = 0; ok && i < bw.size(); i++) {
+        const ActiMode am = bw[i]->activation;
+        if (i + 1 < bw.size()) ok = (am == AC_MODE_NONE || am == AC_MODE_RELU) && bw[i + 1]->dx_overwrite && !bw[i + 1]->discard_input_grad;
+        else ok = am == AC_MODE_NONE || am == AC_MODE_RELU || am == AC_MODE_SIGMOID;
+      }
+      if (ok) bw.back()->chain_bwd = bw;
+      // (the two-narrow-layers launches of the same layers stand back: a member's forward / backward is the chain's)
+      for (Linear* m : ch) { m->pair_upper = nullptr; }
+      if (ok) for (Linear* m : bw) m->pair_lower = nullptr;
+    }
+  }
+
   // ---- 5. parameters: one slab for every Linear tensor, tables on their own ---------------------
   // (a Linear kernel whose input was padded in step 4a is [out][in_padded] here: pad columns zero, and kept zero by every optimizer --
   //  their gradient is dy^T times the input's zero pad columns)
@@ -2422,6 +2522,24 @@ void FFModel::backward(int _seq_length) {
         if (layers[l]->op_type == OP_EMBEDDING && fused_embedding_update()) embedding_group_update(stream);
       });
       continue;
+    }
+    if (up && !up->chain_bwd.empty() && mlp_chain_usable(local_rows(up->outputs[0], this))) {
+      // the chain this layer tops: one call for all its members (their indices are l - n + 1 .. l)
+      const int n = (int)up->chain_bwd.size();
+      const int crc = run_chain_bwd(up);
+      if (crc == FFH_OK) {
+        // a lower member completes the embedding output gradients: "gradients ready" behind the whole call (the chain's weight-gradient
+        // kernel still reads the buffer the next gather overwrites).  (l itself: attached above, recorded by the call.)
+        if (grad_attach_layer > l - n && grad_attach_layer < l && !grad_ready_attached) {
+          check(api->ffh_event_record(ctx, ev_grad_ready, stream), "event");
+          grad_ready_attached = true;
+        }
+        for (int k = 0; k < n; k++) mark_z_free(l - k);
+        l -= n - 1;
+        continue;
+      }
+      if (crc != FFH_ERR_UNSUPPORTED) check(crc, up->name);
+      up->chain_bwd.clear();                                   // not a chain the library serves: the per-layer calls from now on
     }
     if (up && up->pair_lower && !use_workers() && l != grad_attach_layer && l >= 1 && layers[l - 1] == up->pair_lower) {
       const int prc = up->backward_pair(*this);

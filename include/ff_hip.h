@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 11   /* 11: ffh_stream_create_with_priority; 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 12   /* 12: ffh_mlp_chain_fwd / _bwd (a chain of narrow Linear layers as three launches), ffh_ctx_reserve_scratch; 11: ffh_stream_create_with_priority; 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -511,6 +511,38 @@ int ffh_linear_pair_fwd(ffh_ctx* ctx, const float* x_l, int64_t ldx_l, const flo
                         float* y_l, int64_t ldy_l, int mid, const float* w_u, const float* b_u, int out_u, int act_u,
                         float* y_u, int64_t ldy_u, int64_t batch, ffh_stream s);
 
+/* A CHAIN of narrow Linear layers, x -> [L0] -> y0 -> [L1] -> ... -> y(n-1), every width <= FFH_CHAIN_MAX_WIDTH (DLRM's bottom MLP
+ * 13-512-256-128; the Kaggle shape's 13-512-256-64-16 and 432-512-256-1): what nlayers calls of Linear::forward_kernel /
+ * backward_kernel compute [ref: src/ops/linear.cu:425-465,610-660], as one launch forward and two launches backward -- the
+ * activations between the layers stay in LDS, the weights stream from L2 into MFMA operand registers (csrc/mlp_chain.hip).  The
+ * reference's precedent for several operators in one task is FusedOp [ref: src/ops/fused.cu:283-400].  Layer l: w [out][ldw],
+ * bias [out] or NULL, y [batch][ldy] its output, dy [batch][lddy] the gradient of the loss with respect to y, dw [out][ldw],
+ * db [out] or NULL (backward only: dy, dw, db may be NULL forward).
+ *   ffh_mlp_chain_fwd  ==  for l = 0 .. n-1: ffh_linear_fwd(x_l, ldx_l, y_l, ldy_l, w_l, bias_l, in_l, out_l, batch, act_l)
+ *                          with x_0 = x, x_l = y_(l-1); every y_l is written (the backward reads it).
+ *   ffh_mlp_chain_bwd  ==  for l = n-1 .. 0: ffh_linear_bwd_ex(x_l, ldx_l, dx_l, .., y_l, ldy_l, dy_l, lddy_l, w_l, dw_l, db_l, in_l, out_l,
+ *                          batch, act_l, flags_l, s, NULL) with dx_l = dy_(l-1) stored (FFH_LINEAR_DX_OVERWRITE | FFH_LINEAR_DX_MASK_BY_X
+ *                          where layer l-1 ends in a ReLU, and then FFH_LINEAR_DY_PREMASKED for layer l-1), dx_0 = dx (may be NULL: the
+ *                          gradient is discarded).  `flags`: FFH_LINEAR_DY_PREMASKED applies to the TOP layer's dy (else its activation
+ *                          derivative is applied to dy in place, as the reference leaves it), FFH_LINEAR_DX_OVERWRITE and
+ *                          FFH_LINEAR_DX_MASK_BY_X to dx.  dw / db accumulate into buffers the caller zeroed (atomics: not in
+ *                          deterministic mode).  An event attached with ffh_event_record_with_next_linear_bwd is recorded behind the
+ *                          data-gradient chain, in front of the weight gradients (dx and every dy are final there).
+ * Served: fp32 math mode; inner activations NONE / RELU (top layer also SIGMOID; forward also GELU); backward: rows of y, dy, dx and
+ * w 16-byte aligned and in_dim % 4 == 0 for every layer whose data gradient is produced.  Anything else returns FFH_ERR_UNSUPPORTED
+ * with nothing launched and the caller makes the per-layer calls. */
+#define FFH_CHAIN_MAX_LAYERS 8
+#define FFH_CHAIN_MAX_WIDTH  512
+typedef struct ffh_chain_layer {
+  const float* w; const float* bias;
+  float* y; float* dy; float* dw; float* db;
+  int64_t ldy, lddy;
+  int ldw, in_dim, out_dim, activation;
+} ffh_chain_layer;
+int ffh_mlp_chain_fwd(ffh_ctx* ctx, const float* x, int64_t ldx, const ffh_chain_layer* layers, int nlayers, int64_t batch, ffh_stream s);
+int ffh_mlp_chain_bwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* dx, int64_t lddx, const ffh_chain_layer* layers, int nlayers,
+                      int64_t batch, int flags, ffh_stream s);
+
 /* ------------------------------------------------------------------ */
 /* Strict lower triangle of the pairwise-dot matrix (MLPerf-DLRM's interaction keeps the 351 products
  * i > j of the 27 x 27 matrix; the reference has no operator for it -- its dot interaction is a TODO,
@@ -594,7 +626,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) X(ffh_embedding_bwd_sort_multi) X(ffh_embedding_bwd_sgd_apply_multi) X(ffh_embedding_bwd_opt_fused_multi) X(ffh_embedding_bwd_opt_apply_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_linear_bwd_set_dx_colsum) X(ffh_linear_dx_colsum_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_mlp_chain_fwd) X(ffh_mlp_chain_bwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_linear_bwd_set_dx_colsum) X(ffh_linear_dx_colsum_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

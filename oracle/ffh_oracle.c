@@ -683,6 +683,73 @@ int ffh_linear_pair_bwd(ffh_ctx* c, const float* x_u, int64_t ldx_u, const float
                            flags_l | FFH_LINEAR_ONLY_DX | FFH_LINEAR_DY_PREMASKED, s, s);
 }
 
+/* A chain of narrow Linear layers: the per-layer calls it stands for, in order (include/ff_hip.h).  The per-layer functions take
+ * w as [out][in] dense; a layer with ldw > in goes through a compact copy. */
+static int chain_check(ffh_ctx* c, const ffh_chain_layer* ls, int n, int64_t B, const char* who) {
+  (void)who;
+  if (!ls || n < 1 || n > FFH_CHAIN_MAX_LAYERS || B < 0) return fail(c, FFH_ERR_BAD_ARG, "mlp_chain: layer count / batch");
+  for (int l = 0; l < n; l++) {
+    if (ls[l].in_dim < 1 || ls[l].out_dim < 1 || ls[l].in_dim > FFH_CHAIN_MAX_WIDTH || ls[l].out_dim > FFH_CHAIN_MAX_WIDTH) return fail(c, FFH_ERR_BAD_ARG, "mlp_chain: layer width (1 .. 512)");
+    if (ls[l].ldw < ls[l].in_dim || ls[l].ldy < ls[l].out_dim || !ls[l].w || !ls[l].y) return fail(c, FFH_ERR_BAD_ARG, "mlp_chain: leading dimension / null pointer");
+    if (l > 0 && ls[l].in_dim != ls[l - 1].out_dim) return fail(c, FFH_ERR_BAD_ARG, "mlp_chain: widths do not chain");
+  }
+  return FFH_OK;
+}
+static float* chain_compact(const float* w, int out, int in, int ldw) {
+  float* t = (float*)malloc(sizeof(float) * (size_t)out * (size_t)in);
+  if (t) for (int o = 0; o < out; o++) memcpy(t + (size_t)o * in, w + (size_t)o * ldw, sizeof(float) * (size_t)in);
+  return t;
+}
+int ffh_mlp_chain_fwd(ffh_ctx* c, const float* x, int64_t ldx, const ffh_chain_layer* ls, int n, int64_t B, ffh_stream s) {
+  int rc = chain_check(c, ls, n, B, "fwd");
+  if (rc != FFH_OK) return rc;
+  if (c && c->math_mode != FFH_MATH_DEFAULT) return fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_fwd: fp32 math mode only");
+  for (int l = 0; l < n && rc == FFH_OK; l++) {
+    const ffh_chain_layer* L = &ls[l];
+    const float* xin = l == 0 ? x : ls[l - 1].y;
+    const int64_t ldi = l == 0 ? ldx : ls[l - 1].ldy;
+    float* wc = L->ldw != L->in_dim ? chain_compact(L->w, L->out_dim, L->in_dim, L->ldw) : NULL;
+    if (L->ldw != L->in_dim && !wc) return fail(c, FFH_ERR_NOMEM, "oom");
+    rc = ffh_linear_fwd(c, xin, ldi, L->y, L->ldy, wc ? wc : L->w, L->bias, L->in_dim, L->out_dim, B, L->activation, s);
+    free(wc);
+  }
+  return rc;
+}
+int ffh_mlp_chain_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t lddx, const ffh_chain_layer* ls, int n, int64_t B, int flags,
+                      ffh_stream s) {
+  int rc = chain_check(c, ls, n, B, "bwd");
+  if (rc != FFH_OK) return rc;
+  if (flags & ~(FFH_LINEAR_DX_OVERWRITE | FFH_LINEAR_DX_MASK_BY_X | FFH_LINEAR_DY_PREMASKED)) return fail(c, FFH_ERR_BAD_ARG, "mlp_chain_bwd: flags");
+  for (int l = 0; l < n; l++)
+    if (!ls[l].dy || !ls[l].dw || ls[l].lddy < ls[l].out_dim) return fail(c, FFH_ERR_BAD_ARG, "mlp_chain_bwd: null pointer / leading dimension");
+  if (c && c->math_mode != FFH_MATH_DEFAULT) return fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: fp32 math mode only");
+  for (int l = 0; l + 1 < n; l++)
+    if (ls[l].activation != FFH_AC_MODE_NONE && ls[l].activation != FFH_AC_MODE_RELU) return fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: inner layers NONE or RELU");
+  for (int l = n - 1; l >= 0 && rc == FFH_OK; l--) {
+    const ffh_chain_layer* L = &ls[l];
+    const float* xin = l == 0 ? x : ls[l - 1].y;
+    const int64_t ldi = l == 0 ? ldx : ls[l - 1].ldy;
+    float* dxl = l == 0 ? dx : ls[l - 1].dy;
+    const int64_t lddxl = l == 0 ? lddx : ls[l - 1].lddy;
+    int f = 0;
+    if (l == n - 1) f |= flags & FFH_LINEAR_DY_PREMASKED;
+    else if (L->activation == FFH_AC_MODE_RELU) f |= FFH_LINEAR_DY_PREMASKED;
+    if (l == 0) f |= flags & (FFH_LINEAR_DX_OVERWRITE | FFH_LINEAR_DX_MASK_BY_X);
+    else f |= FFH_LINEAR_DX_OVERWRITE | (ls[l - 1].activation == FFH_AC_MODE_RELU ? FFH_LINEAR_DX_MASK_BY_X : 0);
+    float *wc = NULL, *dwc = NULL;
+    if (L->ldw != L->in_dim) {
+      wc = chain_compact(L->w, L->out_dim, L->in_dim, L->ldw);
+      dwc = chain_compact(L->dw, L->out_dim, L->in_dim, L->ldw);
+      if (!wc || !dwc) { free(wc); free(dwc); return fail(c, FFH_ERR_NOMEM, "oom"); }
+    }
+    rc = ffh_linear_bwd_ex(c, xin, ldi, dxl, lddxl, L->y, L->ldy, L->dy, L->lddy, wc ? wc : L->w, dwc ? dwc : L->dw, L->db, L->in_dim, L->out_dim, B,
+                           L->activation, f, s, s);
+    if (dwc) for (int o = 0; o < L->out_dim; o++) memcpy(L->dw + (size_t)o * L->ldw, dwc + (size_t)o * L->in_dim, sizeof(float) * (size_t)L->in_dim);
+    free(wc); free(dwc);
+  }
+  return rc;
+}
+
 /* ------------------------------------------------------------------ */
 /* Concat                                                             */
 /* ------------------------------------------------------------------ */

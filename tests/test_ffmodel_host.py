@@ -551,7 +551,7 @@ def test_narrow_layer_pair_path_equals_plain_calls():
     """A bottom MLP ending 96 -> 64 -> 16 takes the ffh_linear_pair_bwd route of the host layer (upper backward + lower dX
     in one call, then the lower dW): on the oracle backend that is the same arithmetic as --no-fused-pair, bit for bit."""
     args = ["--backend", H.oracle_backend(), "-b", "48", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "30-11",
-            "--arch-mlp-bot", "13-96-64-16", "--arch-mlp-top", "48-24-1", "--data-size", "48"]
+            "--arch-mlp-bot", "13-96-64-16", "--arch-mlp-top", "48-24-1", "--data-size", "48", "--no-mlp-chain"]     # (the chain launches of round 5 would take these layers first)
     res = []
     for extra in ([], ["--no-fused-pair"]):
         app = ffmodel.DLRM(args + extra)
