@@ -93,6 +93,7 @@ _SIGS = {
     "ffh_ctx_set_math_mode": (I, [P, I]),
     "ffh_ctx_set_deterministic": (I, [P, I]),
     "ffh_ctx_set_dw_cu_reserve": (I, [P, I]),
+    "ffh_ctx_reserve_scratch": (I, [P, P]),
     "ffh_ctx_bf16_mirror_set": (I, [P, P, SZ, P]),
     "ffh_convert_f32_to_bf16": (I, [P, P, P, L, P]),
     "ffh_malloc": (I, [P, C.POINTER(P), SZ]),
@@ -223,6 +224,9 @@ class FFHLib:
             raise FFHError(f"ffh_ctx_create failed ({rc}) on {path}")
         self.ctx = ctx
         self._ws_keepalive = None
+        # tests and tools launch on the null stream: its scratch (stream-K slots ...) is reserved here, by the caller -- the library's
+        # compute entry points never allocate
+        self.check(self.lib.ffh_ctx_reserve_scratch(self.ctx, None), "ffh_ctx_reserve_scratch")
 
     # -- plumbing -----------------------------------------------------------
     def check(self, rc: int, what: str = ""):

@@ -31,14 +31,13 @@ struct ffh_ctx {
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
   ffh_mirror_region mirrors[32];   // bf16 twins of fp32 buffers (tensor-op mode)
   int         nmirrors;
-  // stream-K partial tiles of the persistent fp32 GEMMs (linear_sk.hip): per stream one set of num_cus slots of 128 x 128 floats +
-  // one flag per slot; the first set is allocated with the ctx, further ones when another stream first launches such a GEMM
-  struct { void* stream; float* slots; unsigned* flags; } sk_sets[4];
-  int         sk_nsets;
-  // one-launch narrow-layer backward (linear_skinny_bwd_kernel): per stream, the workgroups' partial dW / db rows + an arrival counter
-  // (ctx-owned scratch, allocated when a stream first needs it, never during a capture)
-  struct { void* stream; float* ws; unsigned* cnt; } skinny_sets[4];
-  int         skinny_nsets;
+  // ctx-owned scratch per stream, reserved by ffh_ctx_reserve_scratch(ctx, stream) and released by ffh_stream_destroy / ffh_ctx_destroy;
+  // no compute entry point allocates:
+  //   sk_slots / sk_cnt    stream-K partial tiles of the persistent fp32 GEMMs (linear_sk.hip): 2 x num_cus slots of 128 x 128 floats + one
+  //                        arrival counter per range
+  //   skinny_ws / _cnt     one-launch narrow-layer backward (linear_skinny_bwd_kernel): the workgroups' partial dW / db rows + an arrival counter
+  struct { void* stream; float* sk_slots; unsigned* sk_cnt; float* skinny_ws; unsigned* skinny_cnt; } scratch[FFH_MAX_SCRATCH_STREAMS];
+  int         nscratch;
   const void* emb_sorted_ws;     // ffh_embedding_bwd_sort_multi left a sorted list (and cleared fold counters) in THIS workspace ...
   int64_t     emb_sorted_sig[4]; // ... for this (ntables, in_dim, out_dim, batch): ffh_embedding_bwd_sgd_apply_multi consumes it, once
   char        route[256]; // ffh_linear_last_route(): kernel families of the latest ffh_linear_* call
@@ -81,6 +80,10 @@ static inline int ffh_fail_hip(ffh_ctx* c, hipError_t e, const char* what) {
     if (!(cond)) return ffh_fail((ctx), FFH_ERR_BAD_ARG, msg);  \
   } while (0)
 
+// sizes of the per-stream scratch sets (ffh_ctx_reserve_scratch, runtime.hip)
+constexpr int kSkinnyWsBlocks = 512;                       // workgroups the narrow-layer backward's scratch holds
+constexpr int kSkinnyWsRow = 4160;                          // floats per partial row: out * in + out for out <= 4, in <= 1024 (4100) and out <= 16, in <= 256 (4112)
+constexpr int kSkTileFloats = 128 * 128;                    // one stream-K slot (linear_sk.hip's tile)
 static inline hipStream_t as_stream(ffh_stream s) { return (hipStream_t)s; }
 
 // A/B switches of the development builds.  The release library reads NO environment variable ("no global state" behind the

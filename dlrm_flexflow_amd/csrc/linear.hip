@@ -1114,8 +1114,6 @@ struct SkinnyBwdArgs {
   // (ws_cnt) adds the rows up in block order and adds the total to dw / db.  Null: one atomic per weight per workgroup.
   float* ws;  unsigned* ws_cnt;  int ws_stride;
 };
-constexpr int kSkinnyWsBlocks = 512;                       // workgroups the scratch holds
-constexpr int kSkinnyWsRow = 4160;                          // floats per partial row: out * in + out for out <= 4, in <= 1024 (4100) and out <= 16, in <= 256 (4112)
 
 // NC: 16-byte column chunks per lane (in <= 256 * NC), NO: output slots kept in registers (out <= NO),
 // RPW: rows per wave-instruction -- a row of in = 256 / RPW floats fills 64 / RPW lanes, so RPW rows go side by side
@@ -1676,24 +1674,12 @@ int launch_act_bwd_bias(ffh_ctx* c, float* dy, int64_t lddy, const float* y, int
   return FFH_OK;
 }
 
-// the partial-row scratch of linear_skinny_bwd_kernel for launches on stream s (allocated when a stream first needs it, never during
-// a capture; like linear_sk.hip's slots)
+// the partial-row scratch of linear_skinny_bwd_kernel for launches on stream s: reserved by ffh_ctx_reserve_scratch(ctx, s) (runtime.hip);
+// a compute entry point never allocates.  No set for this stream: the atomic-chain form serves the layer.
 bool skinny_ws_for(ffh_ctx* c, hipStream_t s, float** ws, unsigned** cnt) {
-  for (int i = 0; i < c->skinny_nsets; i++)
-    if (c->skinny_sets[i].stream == (void*)s) { *ws = c->skinny_sets[i].ws; *cnt = c->skinny_sets[i].cnt; return true; }
-  if (c->skinny_nsets >= 4) return false;
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (st != hipStreamCaptureStatusNone) return false;
-  float* w = nullptr; unsigned* k = nullptr;
-  if (hipMalloc(&w, (size_t)kSkinnyWsBlocks * kSkinnyWsRow * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
-  // (cleared ON the stream the launches go to: a null-stream hipMemset is not ordered against a non-blocking stream, and a launch that
-  //  finds the counter mid-way never sees its last workgroup)
-  if (hipMalloc(&k, 64) != hipSuccess || hipMemsetAsync(k, 0, 64, s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w); if (k) (void)hipFree(k); return false; }
-  c->skinny_sets[c->skinny_nsets] = {(void*)s, w, k};
-  c->skinny_nsets++;
-  *ws = w; *cnt = k;
-  return true;
+  for (int i = 0; i < c->nscratch; i++)
+    if (c->scratch[i].stream == (void*)s && c->scratch[i].skinny_ws) { *ws = c->scratch[i].skinny_ws; *cnt = c->scratch[i].skinny_cnt; return true; }
+  return false;
 }
 
 // label != NULL: the MSE loss step is folded into the one-launch backward (ffh_linear_bwd_mse); layers that path does

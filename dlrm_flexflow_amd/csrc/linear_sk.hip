@@ -36,6 +36,7 @@
 #include "linear_gemm.h"
 
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -65,11 +66,13 @@ struct SkArgs {
   int M, N, K;
   int act;
   unsigned a_bytes, b_bytes, bias_bytes, mask_bytes;     // extents for the buffer descriptors (0: operand absent -> loads return 0)
-  // SPLIT (stream-K forward / data gradient): partial tiles of the workgroups that continue a tile another one began -- slot r =
-  // range r's 128 x 128 accumulators in lane order -- and one flag per slot: 1 when the slot is written, cleared by the workgroup
-  // that consumed it (so a launch finds every flag 0, also when it is a node of a replayed hipGraph: no per-launch argument)
+  // SPLIT (stream-K forward / data gradient): the partial tiles of a tile that straddles ranges -- slot 2r: range r's LEADING segment
+  // (it continues a tile an earlier range began), slot 2r + 1: its TRAILING segment (the head of a tile later ranges finish), 128 x 128
+  // accumulators in lane order -- and one arrival counter per range (the counter of the range holding the tile's head counts the
+  // tile's parts): the part that arrives last adds them up, and leaves the counter at 0 (so a launch finds every counter 0, also
+  // when it is a node of a replayed hipGraph: no per-launch argument)
   float*    sk_slots;
-  unsigned* sk_flags;
+  unsigned* sk_cnt;
 };
 
 template <int... I, class F>
@@ -90,13 +93,16 @@ constexpr int SK_EP_WAVE = SK_EP_ROWS * SK_EP_LD * 4;     // bytes per wave
 // SPLIT: stream-K for the forms whose output is stored, not accumulated (forward, data gradient).  Whole tiles only fill the chip
 // when their count is a multiple of the workgroup count: the 864 tiles of 3456 -> 1024's data gradient at 4096 samples are 3.4
 // rounds of 256 (a quarter of the last round's CUs idle: 114 instead of 135 TFLOP/s), the 128 tiles of 1024 -> 512 leave half the
-// chip empty.  As for the weight gradient the flat (tile, k-tile) space is cut into G equal ranges; a tile that straddles ranges is
-// finished by the workgroup that holds its HEAD (k = 0 ...): that range is the earlier one, its head is the LAST thing the
-// workgroup computes, while the ranges holding the rest of the tile compute it FIRST and leave their accumulators in a slot (lane
-// order: coalesced 8-byte agent-scope stores, then a flag) -- so the owner finds the partials waiting, adds them in k order (a
-// fixed order: same bits run to run) and runs the ordinary epilogue.  Owners wait only after all their own work, contributors
-// never wait: no cycle.  Cross-workgroup values travel as agent-scope relaxed atomics (sc1: written through / read behind the
-// per-XCD L2s), ordered by completion (vmcnt + barrier before the flag), as in embedding.hip's folds.
+// chip empty.  As for the weight gradient the flat (tile, k-tile) space is cut into G equal ranges; a tile that straddles ranges
+// is computed in parts, and NOBODY WAITS (round 5; round 4's owner spun on flags that later workgroups of the same launch set --
+// forward progress then hung on every contributor becoming resident while the owners held their CUs, which nothing guarantees
+// beside another persistent kernel or under a CU mask): every part leaves its accumulators in its slot (lane order: coalesced
+// 8-byte agent-scope stores), then one lane adds 1 to the tile's arrival counter; the part whose add returns parts - 1 arrived
+// last: it adds the parts up in k order -- a fixed order whoever is last: same bits run to run, so the form also runs in
+// deterministic mode -- and runs the ordinary epilogue.  A range computes its leading segment first and its trailing one (the head
+// of the next tile) last, so the head usually is the last to arrive and its own part never leaves its registers.  Cross-workgroup
+// values travel as agent-scope relaxed atomics (sc1: written through / read behind the per-XCD L2s), ordered by completion (vmcnt
+// + barrier before the counter add; the loads behind the returned add + a barrier), as in embedding.hip's folds.
 template <bool AKR, bool BKR, int EPI, bool DB = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
   static_assert(!DB || (EPI == SK_EPI_DW_ATOMIC && AKR), "the bias gradient rides on the weight-gradient form");
@@ -257,43 +263,46 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
       const bool head = cp.kt == 0;
       if (!(head && seg == nk)) {
         typedef unsigned long long u64;
-        if (!head) {
-          // this range's first segment continues a tile: leave the accumulators for the workgroup that holds the tile's head
-          u64* slot = reinterpret_cast<u64*>(g.sk_slots + (size_t)rng * (SK_BM * SK_BN));
+        const unsigned it0 = (it_b / nk + cp.seq) * nk;                  // the tile's first iteration in the flat space (place())
+        const unsigned r0 = it0 / ipw, r1 = (it0 + nk - 1) / ipw;        // the ranges it spans: part p is range r0 + p's share
+        const unsigned nparts = r1 - r0 + 1;
+        // 1. this part's accumulators -> its slot
+        u64* slot = reinterpret_cast<u64*>(g.sk_slots + (size_t)(head ? 2u * rng + 1u : 2u * rng) * (SK_BM * SK_BN));
 #pragma unroll
-          for (int tm = 0; tm < 4; tm++)
+        for (int tm = 0; tm < 4; tm++)
 #pragma unroll
-            for (int tn = 0; tn < 4; tn++) {
-              const f32x4 v = acc[tm][tn];
-              u64* q2 = slot + ((tm * 4 + tn) * 256 + tid) * 2;
-              __hip_atomic_store(q2, ((u64)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(q2 + 1, ((u64)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tid == 0) __hip_atomic_store(g.sk_flags + rng, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int tn = 0; tn < 4; tn++) {
+            const f32x4 v = acc[tm][tn];
+            u64* q2 = slot + ((tm * 4 + tn) * 256 + tid) * 2;
+            __hip_atomic_store(q2, ((u64)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q2 + 1, ((u64)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // 2. arrive; the value the add returns says whether every other part is in memory already
+        unsigned* const bc = reinterpret_cast<unsigned*>(sk_lds + LDS_A + (BKR ? SK_LDS_KR : SK_LDS_KC));      // one word behind the operand images
+        if (tid == 0) *bc = __hip_atomic_fetch_add(g.sk_cnt + r0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const bool last = *bc == nparts - 1;
+        __syncthreads();                      // (the word is free again)
+        if (!last) {
           store_tile = false;
         } else {
-          // the tile's head: add the partials of the following ranges, in k order, then the ordinary epilogue
-          unsigned rem = nk - seg, r2 = rng + 1;
-          while (rem) {
-            const unsigned b2 = r2 * ipw;
-            const unsigned e2 = b2 + ipw < total_it ? b2 + ipw : total_it;
-            const unsigned len = (e2 - b2) < rem ? (e2 - b2) : rem;
-            while (__hip_atomic_load(g.sk_flags + r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) __builtin_amdgcn_s_sleep(2);
-            __syncthreads();            // every wave has seen the flag: clear it for the next launch on this stream (which starts behind this one)
-            if (tid == 0) __hip_atomic_store(g.sk_flags + r2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const u64* slot = reinterpret_cast<const u64*>(g.sk_slots + (size_t)r2 * (SK_BM * SK_BN));
+          if (tid == 0) __hip_atomic_store(g.sk_cnt + r0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch on this stream
+          // 3. the parts in k order.  The head's own part is in its registers; any other last arriver reads every part, its own included
+          //    (the bits it stored), so that the order of the adds does not depend on who came last
+          for (unsigned p = head ? 1u : 0u; p < nparts; p++) {
+            const u64* sl = reinterpret_cast<const u64*>(g.sk_slots + (size_t)(p == 0 ? 2u * r0 + 1u : 2u * (r0 + p)) * (SK_BM * SK_BN));
 #pragma unroll
             for (int tm = 0; tm < 4; tm++)
 #pragma unroll
               for (int tn = 0; tn < 4; tn++) {
-                const u64* q2 = slot + ((tm * 4 + tn) * 256 + tid) * 2;
+                const u64* q2 = sl + ((tm * 4 + tn) * 256 + tid) * 2;
                 const u64 lo = __hip_atomic_load(q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const u64 hi = __hip_atomic_load(q2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                acc[tm][tn] += f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32))};
+                const f32x4 v = f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32))};
+                if (p == 0) acc[tm][tn] = v; else acc[tm][tn] += v;
               }
-            rem -= len; r2++;
           }
         }
       }
@@ -475,7 +484,7 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
     static const int no_split = FFH_LAB_INT("FFH_SK_NO_SPLIT", 0);     // A/B switch (tools/ab.sh)
     const int64_t rounds = (ntiles + p.G - 1) / p.G;
     const int64_t idle_it = (rounds * p.G - ntiles) * nk / p.G;      // k-tile iterations per workgroup the last round wastes
-    p.split = !no_split && !c->deterministic && idle_it >= 2 && ntiles * nk >= 8LL * p.G && g.epi == EPI_STORE;    // (four k-tiles per workgroup: 8192 x 512 -> 256 forward 33.3 us split, 27.8 on the LDS-DMA kernel)
+    p.split = !no_split && idle_it >= 2 && ntiles * nk >= 8LL * p.G && g.epi == EPI_STORE;    // (four k-tiles per workgroup: 8192 x 512 -> 256 forward 33.3 us split, 27.8 on the LDS-DMA kernel)
     if (!p.split) {
       if (ntiles < p.G) return false;
       if (ntiles * 100 < rounds * p.G * 80) return false;          // whole tiles only: the last round must be nearly full
@@ -484,24 +493,12 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
   return true;
 }
 
-// the partial-tile slots of the SPLIT form for launches on stream s (ctx-owned scratch, like LinearMeta's ones vector
-// [ref: src/ops/linear.cu:986-994]: allocated when a stream first needs it, never during a capture)
-bool sk_slots_for(ffh_ctx* c, hipStream_t s, float** slots, unsigned** flags) {
-  for (int i = 0; i < c->sk_nsets; i++)
-    if (c->sk_sets[i].stream == (void*)s) { *slots = c->sk_sets[i].slots; *flags = c->sk_sets[i].flags; return true; }
-  if (c->sk_nsets >= 4) return false;
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (st != hipStreamCaptureStatusNone) return false;
-  float* sl = nullptr; unsigned* fl = nullptr;
-  const size_t G = (size_t)(c->num_cus & ~7);
-  if (hipMalloc((void**)&sl, G * SK_BM * SK_BN * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
-  // (flags cleared ON the stream the launches go to: a null-stream hipMemset is not ordered against a non-blocking stream)
-  if (hipMalloc((void**)&fl, G * sizeof(unsigned)) != hipSuccess || hipMemsetAsync(fl, 0, G * sizeof(unsigned), s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(sl); if (fl) (void)hipFree(fl); return false; }
-  c->sk_sets[c->sk_nsets] = {(void*)s, sl, fl};
-  c->sk_nsets++;
-  *slots = sl; *flags = fl;
-  return true;
+// the partial-tile slots of the SPLIT form for launches on stream s: ctx-owned scratch reserved by ffh_ctx_reserve_scratch(ctx, s)
+// (runtime.hip) -- a compute entry point never allocates.  No set for this stream: the form is not offered.
+bool sk_slots_for(ffh_ctx* c, hipStream_t s, float** slots, unsigned** cnt) {
+  for (int i = 0; i < c->nscratch; i++)
+    if (c->scratch[i].stream == (void*)s && c->scratch[i].sk_slots) { *slots = c->scratch[i].sk_slots; *cnt = c->scratch[i].sk_cnt; return true; }
+  return false;
 }
 }  // namespace
 
@@ -513,7 +510,7 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   if (!sk_plan(c, g, form, p)) return 0;
   float* slots = nullptr; unsigned* flags = nullptr;
   if (p.split && !sk_slots_for(c, as_stream(s), &slots, &flags)) {
-    // no slots (a capture in flight, too many streams): the whole-tile form where it serves, else not this kernel's launch
+    // no scratch reserved for this stream (ffh_ctx_reserve_scratch): the whole-tile form where it serves, else not this kernel's launch
     p.split = false;
     const int64_t ntiles = (int64_t)(g.M / SK_BM) * (g.N / SK_BN), rounds = (ntiles + p.G - 1) / p.G;
     if (ntiles < p.G || ntiles * 100 < rounds * p.G * 80) return 0;
@@ -527,22 +524,23 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   a.a_bytes = (unsigned)a_bytes; a.b_bytes = (unsigned)b_bytes;
   a.bias_bytes = g.bias ? (unsigned)g.N * 4u : 0u;
   a.mask_bytes = g.mask ? 1u : 0u;
-  if (p.split) { a.sk_slots = slots; a.sk_flags = flags; }
+  if (p.split) { a.sk_slots = slots; a.sk_cnt = flags; }
   // The kernels need more than 64 KB of dynamic LDS; hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of the
   // function, and one process may hold a ctx per device (ffh_ctx_default): set once per (kernel, device).  A launch that still
   // fails (attribute refused, no such resources) is not an error of the call: 0 = "not served", linear.hip's kernels take the layer.
 #define FFH_SK_LAUNCH(AKR, BKR, EPI, LDSB, ...)                                                                  \
   {                                                                                                              \
     auto kern = gemm_sk_kernel<AKR, BKR, EPI, ##__VA_ARGS__>;                                                    \
-    static signed char ok[64];      /* 0: not tried on this device, 1: set, -1: refused */                      \
+    static std::atomic<signed char> ok[64];      /* 0: not tried on this device, 1: set, -1: refused */          \
     const int dev = c->device & 63;                                                                              \
-    if (ok[dev] == 0) ok[dev] = sk_set_lds(kern, LDSB) ? 1 : -1;                                                 \
-    if (ok[dev] < 0) return 0;                                                                                   \
+    if (ok[dev].load(std::memory_order_acquire) == 0) ok[dev].store(sk_set_lds(kern, LDSB) ? 1 : -1, std::memory_order_release); \
+    if (ok[dev].load(std::memory_order_acquire) < 0) return 0;                                                   \
     hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), LDSB, as_stream(s), a);                               \
   }
-  if (form == SK_FORM_FWD && p.split) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC, false, true)
-  else if (form == SK_FORM_DX && p.split && g.colmap) FFH_SK_LAUNCH(false, true, SK_EPI_DX_CMAP, SK_LDS_KC + SK_LDS_KR, false, true)
-  else if (form == SK_FORM_DX && p.split) FFH_SK_LAUNCH(false, true, SK_EPI_DX_STORE, SK_LDS_KC + SK_LDS_KR, false, true)
+  constexpr int BCW = 64;      // SPLIT: the arrival broadcast word behind the operand images
+  if (form == SK_FORM_FWD && p.split) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC + BCW, false, true)
+  else if (form == SK_FORM_DX && p.split && g.colmap) FFH_SK_LAUNCH(false, true, SK_EPI_DX_CMAP, SK_LDS_KC + SK_LDS_KR + BCW, false, true)
+  else if (form == SK_FORM_DX && p.split) FFH_SK_LAUNCH(false, true, SK_EPI_DX_STORE, SK_LDS_KC + SK_LDS_KR + BCW, false, true)
   else if (form == SK_FORM_FWD) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC)
   else if (form == SK_FORM_DW && g.db) FFH_SK_LAUNCH(true, true, SK_EPI_DW_ATOMIC, 2 * SK_LDS_KR + 4 * SK_EP_WAVE, true)
   else if (form == SK_FORM_DW) FFH_SK_LAUNCH(true, true, SK_EPI_DW_ATOMIC, 2 * SK_LDS_KR + 4 * SK_EP_WAVE)
@@ -550,7 +548,13 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   else if (g.epi == EPI_STORE) FFH_SK_LAUNCH(false, true, SK_EPI_DX_STORE, SK_LDS_KC + SK_LDS_KR)
   else FFH_SK_LAUNCH(false, true, SK_EPI_DX_ADD, SK_LDS_KC + SK_LDS_KR)
 #undef FFH_SK_LAUNCH
-  if (hipGetLastError() != hipSuccess) return 0;        // launch refused: nothing was enqueued, the caller falls through to linear.hip
+  {
+    // a launch the device refuses for its CONFIGURATION enqueued nothing: "not served", the caller falls through to linear.hip.  Anything
+    // else (a sticky fault of earlier work surfacing here) is the caller's to see
+    const hipError_t e = hipGetLastError();
+    if (e == hipErrorInvalidValue || e == hipErrorInvalidConfiguration || e == hipErrorLaunchOutOfResources || e == hipErrorSharedObjectInitFailed) return 0;
+    if (e != hipSuccess) return ffh_fail_hip(c, e, name);
+  }
   { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64%s%s%s|wgs=%d", name, g.colmap ? "|colmap" : "", p.split ? "|streamk" : "", a.colsum ? "|colsum" : "", G); ffh_route_add(c, tok); }
   return 1;
 }

@@ -48,6 +48,7 @@ struct ChLayer {
 struct ChainFwdArgs {
   const float* x; int64_t ldx; int64_t batch;
   int n; int buf1_off;     // floats: start of the second activation buffer
+  int stage_off;           // floats: start of the waves' weight images (behind the two activation buffers)
   int x_vec;
   ChLayer L[CH_MAXL];
 };
@@ -78,6 +79,7 @@ struct ChainDwArgs {
 };
 
 #define CH_PIN() __builtin_amdgcn_sched_barrier(0)
+#define CH_SGPR(x) asm volatile("" : "+s"(x))
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -173,6 +175,106 @@ __device__ __forceinline__ void ch_fwd_layer(const ChLayer& L, const float* in, 
   }
 }
 
+// forward, weights with 16-byte rows: the same arithmetic with w passing through a wave-private LDS image.  Straight from memory a
+// B fragment is 16 bytes from each of SIXTEEN rows of w per 16 lanes -- 64 separate requests per load instruction, which the
+// address path serves at a fraction of the rate of a contiguous one (the 512 -> 256 layer alone took 21 us at 4096 samples, 3.4 us of
+// MFMAs per wave).  Here a step = one 16-wide tile x one 64-deep k-block: four dwordx4 loads whose 16 lanes read 256 contiguous
+// bytes of one row, four ds_write_b128 into the wave's 16 x 64 image (row stride 72 floats: the fragment reads below touch sixteen
+// different bank groups), four ds_read_b128 = the fragments of the block's four k-groups.  The image is the wave's own: its DS
+// instructions execute in order, so the next step's writes cannot pass this step's reads -- one image, no barrier.  Ring of four
+// steps of loads in flight; the next step's image + fragments are issued in front of this step's MFMAs.
+constexpr int CH_STAGE_LD = 72;                         // floats per image row
+constexpr int CH_STAGE_FLOATS = 16 * CH_STAGE_LD;       // per wave
+template <int RT, int NT>
+__device__ __forceinline__ void ch_fwd_layer_staged(const ChLayer& L, const float* in, float* out, float* stage, const int wave, const int lane,
+                                                    const int c16, const int q) {
+  int K = L.in, N = L.out, ldw = L.ldw;
+  CH_SGPR(K); CH_SGPR(N); CH_SGPR(ldw);                  // in scalar registers NOW: left to itself the compiler re-reads them from the kernel
+                                                         // arguments inside the loop, behind an s_waitcnt lgkmcnt(0) that also drains the LDS queue
+  const int Sin = ch_stride(K), Sout = ch_stride(N);
+  const int ntiles = (N + 15) >> 4, tpw = (ntiles + 7) >> 3, kgs = (K + 15) >> 4, kbs = (K + 63) >> 6;
+  const int t0 = wave * tpw;
+  const int steps = kbs * NT;                            // step s: k-block s / NT, tile s % NT
+  constexpr int G = RT == 1 ? 4 : 2;                     // steps of loads in flight (registers: 16 per step)
+  constexpr int U = 4;                                   // unroll: a multiple of G, NT and 2, so that every register index is a constant
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.w), 0, L.w_bytes, 0x00020000);
+  const int lr = lane >> 4, lc = (lane & 15) * 4;        // load role: row 4i + lr of the tile, columns lc .. lc + 3 of the k-block
+  float* const wr = stage + lr * CH_STAGE_LD + lc;       // where piece i goes: + 4 i rows
+  const float* const rd = stage + c16 * CH_STAGE_LD + 4 * q;   // fragment of k-group j of the block: + 16 j
+  const float* const arow = in + c16 * Sin + 4 * q;
+  auto gload = [&](int s, int t, f32x4 (&P)[4]) {       // t = s % NT, passed as a constant
+    const int kb = s / NT, k = kb * 64 + lc;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int n = (t0 + t) * 16 + 4 * i + lr;
+      const bool ok = s < steps && t < tpw && n < N && k < K;
+      P[i] = bload4(rs, ok ? (unsigned)(n * ldw + k) * 4u : CH_OOB);
+    }
+  };
+  f32x4 acc[RT][NT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[rt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 P[G][4], F[2][4], A[RT][4];
+#pragma unroll
+  for (int g = 0; g < G; g++) gload(g, g % NT, P[g]);
+  auto stage_in = [&](f32x4 (&Pg)[4], f32x4 (&Fg)[4]) {      // registers -> image -> fragments
+#pragma unroll
+    for (int i = 0; i < 4; i++) *reinterpret_cast<f32x4*>(wr + 4 * i * CH_STAGE_LD) = Pg[i];
+#pragma unroll
+    for (int j = 0; j < 4; j++) Fg[j] = *reinterpret_cast<const f32x4*>(rd + 16 * j);
+  };
+  stage_in(P[0], F[0]);
+  gload(G, G % NT, P[0]);
+  CH_PIN();
+  for (int s0 = 0; s0 < steps; s0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int s = s0 + u;
+      const int t = u % NT;                              // (U is a multiple of NT)
+      const int kb = s / NT;
+      if (u % NT == 0) {                                 // a new k-block: its four A fragments per row tile
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (kb * 4 + j < kgs) A[rt][j] = *reinterpret_cast<const f32x4*>(arow + rt * 16 * Sin + (kb * 4 + j) * 16);     // uniform
+      }
+      // the next step's image and fragments, and the refill of its registers, in front of this step's MFMAs
+      stage_in(P[(u + 1) % G], F[(u + 1) & 1]);
+      gload(s + 1 + G, (u + 1 + G) % NT, P[(u + 1) % G]);
+      CH_PIN();
+      if (s < steps) {                                   // uniform
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (kb * 4 + j < kgs) {                        // uniform (the last block of a depth that is not a multiple of 64)
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+              for (int rt = 0; rt < RT; rt++) acc[rt][t] = mfma4(A[rt][j][e], F[u & 1][j][e], acc[rt][t]);
+          }
+      }
+      CH_PIN();
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    if (t < tpw && t0 + t < ntiles) {     // uniform
+      const int col = (t0 + t) * 16 + c16;
+      const float b = (L.bias && col < N) ? L.bias[col] : 0.0f;
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          float v = act_apply(acc[rt][t][i] + b, L.act);
+          if (col >= N) v = 0.0f;
+          out[(rt * 16 + 4 * q + i) * Sout + col] = v;
+        }
+    }
+  }
+}
+
 template <int RT>
 __global__ __launch_bounds__(CH_THREADS) void mlp_chain_fwd_kernel(const ChainFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float ch_lds[];
@@ -208,9 +310,10 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_fwd_kernel(const ChainFw
     float* out = (l & 1) ? buf0 : buf1;
     const int tpw = ((((L.out + 15) >> 4) + 7) >> 3);
     if (L.w_vec) {      // (uniform; the ragged form -- rows of w not 16-byte aligned, DLRM's 13-wide first layer -- loads dwords)
-      if (tpw <= 1) ch_fwd_layer<RT, 1, true>(L, in, out, wave, c16, q);
-      else if (tpw <= 2) ch_fwd_layer<RT, 2, true>(L, in, out, wave, c16, q);
-      else ch_fwd_layer<RT, 4, true>(L, in, out, wave, c16, q);
+      float* const stage = ch_lds + a.stage_off + wave * CH_STAGE_FLOATS;
+      if (tpw <= 1) ch_fwd_layer_staged<RT, 1>(L, in, out, stage, wave, lane, c16, q);
+      else if (tpw <= 2) ch_fwd_layer_staged<RT, 2>(L, in, out, stage, wave, lane, c16, q);
+      else ch_fwd_layer_staged<RT, 4>(L, in, out, stage, wave, lane, c16, q);
     } else {
       if (tpw <= 1) ch_fwd_layer<RT, 1, false>(L, in, out, wave, c16, q);
       else if (tpw <= 2) ch_fwd_layer<RT, 2, false>(L, in, out, wave, c16, q);
@@ -548,14 +651,17 @@ int ffh_mlp_chain_fwd(ffh_ctx* c, const float* x, int64_t ldx, const ffh_chain_l
   a.x = x; a.ldx = ldx; a.batch = batch; a.n = nlayers;
   a.x_vec = (al16(x) && (ldx & 3) == 0 && (layers[0].in_dim & 3) == 0) ? 1 : 0;
   for (int l = 0; l < nlayers; l++) fill_layer(a.L[l], layers[l]);
-  const int rt = batch >= 32LL * c->num_cus ? 2 : 1, R = 16 * rt;
   int w0 = 0, w1 = 0;     // widest block each buffer holds: position p (input of layer p; p = n: the last output) lives in buffer p & 1
   for (int p = 0; p <= nlayers; p++) {
     const int w = ch_stride(p == 0 ? layers[0].in_dim : layers[p - 1].out_dim);
     if (p & 1) { if (w > w1) w1 = w; } else { if (w > w0) w0 = w; }
   }
+  int rt = batch >= 32LL * c->num_cus ? 2 : 1;
+  if (rt == 2 && (32 * (w0 + w1) + 8 * CH_STAGE_FLOATS) * 4 > CH_LDS_MAX) rt = 1;      // (two 512-wide blocks of 32 rows do not fit beside the weight images)
+  const int R = 16 * rt;
   a.buf1_off = R * w0;
-  const int lds = R * (w0 + w1) * 4;
+  a.stage_off = R * (w0 + w1);
+  const int lds = (R * (w0 + w1) + 8 * CH_STAGE_FLOATS) * 4;
   if (lds > CH_LDS_MAX) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_fwd: LDS");
   const unsigned grid = (unsigned)((batch + R - 1) / R);
   static signed char ok1[64], ok2[64];
@@ -605,7 +711,13 @@ int ffh_mlp_chain_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
 
   // ---- 1. the data-gradient chain (nothing to do for a single layer whose input gradient is discarded and whose dy is final) ----
   const bool top_live = !premasked && top.activation != FFH_AC_MODE_NONE;
-  const int rt = batch >= 32LL * c->num_cus ? 2 : 1, R = 16 * rt;
+  int rt = batch >= 32LL * c->num_cus ? 2 : 1;
+  {
+    int v0 = 0, v1 = 0;
+    for (int j = 0; j < nlayers; j++) { const int w = ch_stride(layers[nlayers - 1 - j].out_dim); if (j & 1) { if (w > v1) v1 = w; } else { if (w > v0) v0 = w; } }
+    if (rt == 2 && 32 * (v0 + v1) * 4 > CH_LDS_MAX) rt = 1;
+  }
+  const int R = 16 * rt;
   if (nlayers > 1 || dx || top_live) {
     ChainDxArgs a{};
     a.dx = dx; a.lddx = lddx; a.batch = batch; a.n = nlayers;

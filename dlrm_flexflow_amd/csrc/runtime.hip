@@ -49,11 +49,52 @@ int ffh_ctx_default(ffh_ctx** out) {
   return FFH_OK;
 }
 
+static void ffh_scratch_free(ffh_ctx* c, int i) {
+  auto& t = c->scratch[i];
+  if (t.sk_slots) (void)hipFree(t.sk_slots);
+  if (t.sk_cnt) (void)hipFree(t.sk_cnt);
+  if (t.skinny_ws) (void)hipFree(t.skinny_ws);
+  if (t.skinny_cnt) (void)hipFree(t.skinny_cnt);
+  t = {};
+}
+
+// ffh_ctx_reserve_scratch (ABI 12): the per-stream scratch of the forms that meet through memory -- stream-K with fix-up (linear_sk.hip),
+// the narrow-layer backward's last-arriver sums (linear.hip).  The one place they are allocated: the compute entry points look a
+// stream's set up and run the other forms when there is none.  Like LinearMeta's ones vector [ref: src/ops/linear.cu:986-994], but
+// released (ffh_stream_destroy, ffh_ctx_destroy).  Idempotent; not during a stream capture (hipMalloc may synchronise).
+int ffh_ctx_reserve_scratch(ffh_ctx* c, ffh_stream st) {
+  if (!c) return FFH_ERR_BAD_ARG;
+  hipStream_t s = as_stream(st);
+  for (int i = 0; i < c->nscratch; i++)
+    if (c->scratch[i].stream == (void*)s) return FFH_OK;
+  if (c->nscratch >= FFH_MAX_SCRATCH_STREAMS) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "ctx_reserve_scratch: FFH_MAX_SCRATCH_STREAMS streams hold scratch already (destroy one)");
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+  if (cap != hipStreamCaptureStatusNone) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "ctx_reserve_scratch: the stream is being captured");
+  const size_t G = (size_t)(c->num_cus & ~7);
+  auto& t = c->scratch[c->nscratch];
+  t = {};
+  t.stream = (void*)s;
+  bool ok = hipMalloc((void**)&t.sk_slots, 2 * G * kSkTileFloats * sizeof(float)) == hipSuccess &&
+            hipMalloc((void**)&t.sk_cnt, (G + 16) * sizeof(unsigned)) == hipSuccess &&
+            hipMalloc((void**)&t.skinny_ws, (size_t)kSkinnyWsBlocks * kSkinnyWsRow * sizeof(float)) == hipSuccess &&
+            hipMalloc((void**)&t.skinny_cnt, 64) == hipSuccess;
+  // (counters cleared ON the stream the launches go to: a null-stream hipMemset is not ordered against a non-blocking stream, and a
+  //  launch that finds a counter mid-way never sees its last arriver)
+  ok = ok && hipMemsetAsync(t.sk_cnt, 0, (G + 16) * sizeof(unsigned), s) == hipSuccess && hipMemsetAsync(t.skinny_cnt, 0, 64, s) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    ffh_scratch_free(c, c->nscratch);
+    return ffh_fail(c, FFH_ERR_NOMEM, "ctx_reserve_scratch: out of device memory");
+  }
+  c->nscratch++;
+  return FFH_OK;
+}
+
 int ffh_ctx_destroy(ffh_ctx* c) {
   if (c && c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c && c->zeros) (void)hipFree(c->zeros);
-  for (int i = 0; c && i < c->sk_nsets; i++) { if (c->sk_sets[i].slots) (void)hipFree(c->sk_sets[i].slots); if (c->sk_sets[i].flags) (void)hipFree(c->sk_sets[i].flags); }
-  for (int i = 0; c && i < c->skinny_nsets; i++) { if (c->skinny_sets[i].ws) (void)hipFree(c->skinny_sets[i].ws); if (c->skinny_sets[i].cnt) (void)hipFree(c->skinny_sets[i].cnt); }
+  for (int i = 0; c && i < c->nscratch; i++) ffh_scratch_free(c, i);
   delete c;
   return FFH_OK;
 }
@@ -186,7 +227,21 @@ int ffh_stream_create_with_priority(ffh_ctx* c, ffh_stream* s, int priority) {
   *s = (ffh_stream)st;
   return FFH_OK;
 }
-int ffh_stream_destroy(ffh_ctx* c, ffh_stream s) { if (s) FFH_HIP_TRY(c, hipStreamDestroy(as_stream(s))); return FFH_OK; }
+int ffh_stream_destroy(ffh_ctx* c, ffh_stream s) {
+  if (!s) return FFH_OK;
+  // the stream's scratch goes with it (its kernels must have finished before the buffers are freed: hipFree waits for the device)
+  for (int i = 0; c && i < c->nscratch; i++)
+    if (c->scratch[i].stream == (void*)s) {
+      (void)hipStreamSynchronize(as_stream(s));
+      ffh_scratch_free(c, i);
+      c->scratch[i] = c->scratch[c->nscratch - 1];
+      c->scratch[c->nscratch - 1] = {};
+      c->nscratch--;
+      break;
+    }
+  FFH_HIP_TRY(c, hipStreamDestroy(as_stream(s)));
+  return FFH_OK;
+}
 int ffh_stream_sync(ffh_ctx* c, ffh_stream s) { FFH_HIP_TRY(c, hipStreamSynchronize(as_stream(s))); return FFH_OK; }
 int ffh_device_sync(ffh_ctx* c) { FFH_HIP_TRY(c, hipDeviceSynchronize()); return FFH_OK; }
 

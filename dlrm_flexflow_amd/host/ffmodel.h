@@ -122,6 +122,8 @@ class FFConfig {
   bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)
   bool mlp_chain;              // a run of narrow Linear layers (every width <= 512) as one launch forward, two backward (ffh_mlp_chain_fwd / _bwd; A/B: --no-mlp-chain)
   int64_t mlp_chain_max_batch; // ... for at most this many samples per GPU (--mlp-chain-max-batch N)
+  int64_t mlp_chain_fwd_min_batch;   // the forward chain from this many samples per GPU up (below, the per-layer kernels win: --mlp-chain-fwd-min-batch N)
+  int64_t mlp_chain_max_weights;     // chains of at most this many weights in all (every CU streams all of them from L2: --mlp-chain-max-weights N)
   bool attach_events;          // hang ev_grad_ready on the producing kernel's completion instead of a record packet (A/B: --no-attach-event)
   bool timing_events;          // A/B: stream-ordering events created with timestamps, as before
   bool fuse_loss;              // loss step + metrics inside the last layer's one-launch backward (A/B: --no-fused-loss)
@@ -516,7 +518,7 @@ class FFModel {
   mutable bool dw_stream_used_directly = false;   // a weight gradient was enqueued on dw_stream by this layer itself (deferred dW), not by the library's fork
   int defer_big_dw_layer() const;
   mutable int64_t n_chain_fwd_calls = 0, n_chain_bwd_calls = 0;   // successful ffh_mlp_chain_fwd / _bwd calls (tests: flexflow_model_get_counter)
-  bool mlp_chain_usable(int64_t rows) const;      // the chain launches are allowed in this mode / at this batch
+  bool mlp_chain_usable(int64_t rows, bool fwd) const;      // the chain launches are allowed in this mode / at this batch
   int run_chain_fwd(const Linear* lowest) const;  // FFH_OK, or FFH_ERR_UNSUPPORTED with nothing launched
   int run_chain_bwd(Linear* top);
   int dw_cu_reserve_for(int64_t batch) const;

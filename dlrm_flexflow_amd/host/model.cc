@@ -134,6 +134,12 @@ FFConfig::FFConfig() {
   fuse_pair = true;
   mlp_chain = true;
   mlp_chain_max_batch = 8192;
+  // measured (tools/chain_bench.py, profiles/r05_microbench_mlp_chain.txt): the backward chain beats the per-layer calls at every batch up
+  // to 8192 for the bottom MLPs (4096 samples: 46 vs 86 us); the forward chain only from 4096 samples up and with three layers or more
+  // (28 vs 31 us; at 2048: 28 vs 24); a chain whose weights are beyond ~200 K floats (the Kaggle top MLP: 352 K) loses to the
+  // per-layer GEMMs below 4096 samples -- every CU streams every weight from L2 for its 16 rows
+  mlp_chain_fwd_min_batch = 4096;
+  mlp_chain_max_weights = 200000;
   dx_scatter = true;
   dx_colsum = true;
   stream_priorities = false;
@@ -206,6 +212,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-mlp-chain")) { mlp_chain = false; continue; }
     if (is("--mlp-chain-max-batch")) { mlp_chain_max_batch = atoll(next()); continue; }
+    if (is("--mlp-chain-fwd-min-batch")) { mlp_chain_fwd_min_batch = atoll(next()); continue; }
+    if (is("--mlp-chain-max-weights")) { mlp_chain_max_weights = atoll(next()); continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
     if (is("--no-dx-colsum")) { dx_colsum = false; continue; }
     if (is("--stream-priorities")) { stream_priorities = true; continue; }
@@ -476,6 +484,9 @@ FFModel::FFModel(FFConfig& _config)
   else if (config.fp32_split_bf16x3) check(api->ffh_ctx_set_math_mode(ctx, FFH_MATH_FP32_SPLIT_BF16X3), "split-bf16x3 math mode");
   if (config.deterministic) { check(api->ffh_ctx_set_deterministic(ctx, 1), "deterministic mode"); config.async_launch = false; }
   check(api->ffh_stream_create(ctx, &stream), "stream create");
+  // the compute stream runs the Linear layers: the library's scratch for their stream-K / last-arriver forms is reserved here, once,
+  // outside any capture (ffh_ctx_reserve_scratch, ABI 12: compute entry points never allocate)
+  check(api->ffh_ctx_reserve_scratch(ctx, stream), "reserve scratch");
   // --stream-priorities (A/B, off): the embedding stream at a higher HIP priority (ABI 11).  Measured in round 4 (profiles/r04_ab_schedule.txt):
   // level at 32768 samples (7.80-7.83 vs 7.82-7.84 ms), worse at 4096 (1.180-1.184 vs 1.173-1.178), 7 us better at the MLPerf shape --
   // and never with the exchange on that stream: RCCL's send/recv kernels at the higher priority made the 1-rank exchange step
@@ -654,7 +665,7 @@ void Linear::forward(const FFModel& ff) {
   const int64_t b = local_rows(y, &ff);
   if (fwd_done_by_pair) { fwd_done_by_pair = false; return; }      // the layer below computed this output in its launch
   if (fwd_done_by_chain) { fwd_done_by_chain = false; return; }    // ... or the lowest layer of its chain did
-  if (!chain_fwd.empty() && ff.mlp_chain_usable(b)) {
+  if (!chain_fwd.empty() && ff.mlp_chain_usable(b, true)) {
     const int rc = ff.run_chain_fwd(this);
     if (rc == FFH_OK) { for (size_t i = 1; i < chain_fwd.size(); i++) chain_fwd[i]->fwd_done_by_chain = true; return; }
     if (rc != FFH_ERR_UNSUPPORTED) ff.check(rc, name);
@@ -784,9 +795,9 @@ void Linear::backward_part(const FFModel& ff, int part) {
 }
 
 // ---- chains of narrow Linear layers (ffh_mlp_chain_fwd / _bwd, ABI 12; built in FFModel::allocate step 4e) -------------------
-bool FFModel::mlp_chain_usable(int64_t rows) const {
+bool FFModel::mlp_chain_usable(int64_t rows, bool fwd) const {
   return config.mlp_chain && !config.profiling && !use_workers() && !config.deterministic && !config.allow_tensor_op_math_conversion &&
-         !config.fp32_split_bf16x3 && rows <= config.mlp_chain_max_batch;
+         !config.fp32_split_bf16x3 && rows <= config.mlp_chain_max_batch && (!fwd || rows >= config.mlp_chain_fwd_min_batch);
 }
 static void fill_chain(const std::vector<Linear*>& ch, ffh_chain_layer* out) {
   for (size_t i = 0; i < ch.size(); i++) {
@@ -1874,7 +1885,10 @@ void FFModel::allocate() {
       }
       l += ch.size();
       if (ch.size() < 2) continue;
-      a->chain_fwd = ch;
+      int64_t nweights = 0;
+      for (Linear* m : ch) nweights += (int64_t)m->in_channels * m->out_channels;
+      if (nweights > config.mlp_chain_max_weights) continue;
+      if (ch.size() >= 3) a->chain_fwd = ch;             // (two layers: one launch saved does not pay for the weights every CU streams)
       std::vector<Linear*> bw = ch;
       if (bw.back() == layers.back()) bw.pop_back();
       if (!bw.empty() && bw.front()->dx_map) bw.erase(bw.begin());
@@ -1886,7 +1900,7 @@ void FFModel::allocate() {
       }
       if (ok) bw.back()->chain_bwd = bw;
       // (the two-narrow-layers launches of the same layers stand back: a member's forward / backward is the chain's)
-      for (Linear* m : ch) { m->pair_upper = nullptr; }
+      if (!a->chain_fwd.empty()) for (Linear* m : ch) { m->pair_upper = nullptr; }
       if (ok) for (Linear* m : bw) m->pair_lower = nullptr;
     }
   }
@@ -2523,7 +2537,7 @@ void FFModel::backward(int _seq_length) {
       });
       continue;
     }
-    if (up && !up->chain_bwd.empty() && mlp_chain_usable(local_rows(up->outputs[0], this))) {
+    if (up && !up->chain_bwd.empty() && mlp_chain_usable(local_rows(up->outputs[0], this), false)) {
       // the chain this layer tops: one call for all its members (their indices are l - n + 1 .. l)
       const int n = (int)up->chain_bwd.size();
       const int crc = run_chain_bwd(up);

@@ -71,6 +71,7 @@ extern "C" {
 /* limits */
 #define FFH_MAX_TABLES        64   /* tables per batched embedding launch        */
 #define FFH_MAX_CONCAT_INPUTS 256  /* [ref: include/config.h:30-37 MAX_NUM_INPUTS] */
+#define FFH_MAX_SCRATCH_STREAMS 8  /* streams that may hold ctx-owned scratch at a time (ffh_ctx_reserve_scratch) */
 /* block lengths of the canonical (two-level) summation order of the fused
  * embedding backward + SGD (see ffh_embedding_bwd_sgd_fused) */
 #define FFH_EMB_CHUNK         32
@@ -185,6 +186,14 @@ int         ffh_ctx_set_deterministic(ffh_ctx* ctx, int on);
  * pending trades a few percent of the GEMM for it.  Results do not depend on it beyond the stream-K partition (the usual fp32
  * summation-order bound).  Returns FFH_ERR_BAD_ARG for ncus < 0 or >= the device's CU count. */
 int         ffh_ctx_set_dw_cu_reserve(ffh_ctx* ctx, int ncus);
+/* Scratch the library owns for launches on stream `s` (ABI 12): the partial-tile slots + arrival counters of the stream-K forms with
+ * fix-up (csrc/linear_sk.hip) and the partial rows of the narrow-layer backward (csrc/linear.hip) -- ~36 MB.  THE one place they are
+ * allocated: compute entry points never allocate (top of this file); a launch on a stream without scratch runs the other forms of the
+ * same layers (same results to the usual bound; ffh_linear_last_route shows it).  Call it once per stream that runs Linear layers,
+ * outside any capture; idempotent.  Released by ffh_stream_destroy(s) / ffh_ctx_destroy; at most FFH_MAX_SCRATCH_STREAMS streams hold
+ * scratch at a time.  The reference's counterpart is the ones vector LinearMeta allocates per op and never frees
+ * [ref: src/ops/linear.cu:986-994]. */
+int         ffh_ctx_reserve_scratch(ffh_ctx* ctx, ffh_stream s);
 
 /* memory / streams / events / graphs: what Legion+Realm provide to the
  * reference ops (regions, get_legion_stream [ref: src/runtime/cuda_helper.cu:5-31],
@@ -615,7 +624,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
  * FFModel shim and by tests/test_abi_symbols.py). */
 #define FFH_API_LIST(X) \
   X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) X(ffh_ctx_default) \
-  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) X(ffh_ctx_set_dw_cu_reserve) X(ffh_ctx_bf16_mirror_set) X(ffh_convert_f32_to_bf16) \
+  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) X(ffh_ctx_set_dw_cu_reserve) X(ffh_ctx_reserve_scratch) X(ffh_ctx_bf16_mirror_set) X(ffh_convert_f32_to_bf16) \
   X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
   X(ffh_stream_create) X(ffh_stream_create_with_priority) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
   X(ffh_event_create) X(ffh_event_create_sync) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \

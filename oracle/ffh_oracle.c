@@ -104,6 +104,8 @@ int ffh_ctx_set_math_mode(ffh_ctx* c, int mode) {
 }
 /* the oracle's sums are sequential: it is deterministic in either mode */
 int ffh_ctx_set_deterministic(ffh_ctx* c, int on) { (void)on; return c ? FFH_OK : FFH_ERR_BAD_ARG; }
+/* the oracle needs no scratch */
+int ffh_ctx_reserve_scratch(ffh_ctx* c, ffh_stream s) { (void)s; return c ? FFH_OK : FFH_ERR_BAD_ARG; }
 int ffh_ctx_set_dw_cu_reserve(ffh_ctx* c, int ncus) { return (c && ncus >= 0) ? FFH_OK : FFH_ERR_BAD_ARG; }   /* a scheduling hint: nothing to do on the host */
 /* float -> bfloat16 (round to nearest even, NaN kept) -> float: what v_cvt_pk_bf16_f32 leaves in the MFMA operand */
 static inline float bf16_round(float v) {

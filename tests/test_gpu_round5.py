@@ -168,3 +168,90 @@ def test_mlp_chain_refuses_what_it_does_not_serve(hip):
         assert hip.lib.ffh_mlp_chain_bwd(hip.ctx, capi.ptr(x), 64, None, 64, hip.chain_layers([mk(64, 32), mk(32, 16)]), 2, B, 0, None) == capi.FFH_ERR_UNSUPPORTED
     finally:
         hip.check(hip.lib.ffh_ctx_set_deterministic(hip.ctx, 0), "deterministic")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# stream-K with fix-up without waiting (round-4 advisor: the tile owner used to spin on flags later workgroups of the launch set)
+def _mk_stream(hip):
+    import ctypes
+    s = ctypes.c_void_p()
+    hip.check(hip.lib.ffh_stream_create(hip.ctx, ctypes.byref(s)), "stream")
+    hip.check(hip.lib.ffh_ctx_reserve_scratch(hip.ctx, s), "scratch")
+    return s
+
+
+@pytest.mark.timeout(900)
+def test_stream_k_fixup_beside_other_persistent_kernels_is_bit_reproducible(hip, oracle):
+    """The SPLIT form of the persistent GEMM (forward of 1024 -> 512 and data gradient of 3456 -> 1024 at 4096 samples) launched on two
+    streams at once, beside a persistent weight-gradient GEMM on a third: no part of a tile waits for another (the part that arrives
+    last adds them up), so nothing can hang whatever is resident; the parts are added in k order whoever is last, so every launch on
+    every stream leaves the same bits -- also in deterministic mode, which now takes this form -- and they match the oracle."""
+    B = 4096
+    rng = np.random.default_rng(5)
+    dev = lambda a: torch.from_numpy(a).to(DEV)
+    x1 = np.maximum(rng.uniform(-1, 1, (B, 1024)), 0).astype(np.float32); w1 = (rng.uniform(-1, 1, (512, 1024)) / 32).astype(np.float32)
+    b1 = rng.uniform(-1, 1, 512).astype(np.float32)
+    dy2 = (rng.uniform(-1, 1, (B, 1024)) / B).astype(np.float32); w2 = (rng.uniform(-1, 1, (1024, 3456)) / 59).astype(np.float32)
+    y_e = oracle.linear_fwd(x1, w1, b1, RELU)
+    m_y = np.abs(x1).astype(np.float64) @ np.abs(w1).astype(np.float64).T + np.abs(b1)
+    dx_e = dy2.astype(np.float64) @ w2.astype(np.float64)
+    m_dx = np.abs(dy2).astype(np.float64) @ np.abs(w2).astype(np.float64)
+    x1d, w1d, b1d, dy2d, w2d = dev(x1), dev(w1), dev(b1), dev(dy2), dev(w2)
+    x2 = torch.zeros(B, 3456, device=DEV); y2 = torch.zeros(B, 1024, device=DEV); dw2 = torch.zeros(1024, 3456, device=DEV)
+    # the neighbour: a long persistent weight-gradient GEMM (32768-deep) on its own stream
+    Bn = 32768
+    xn = torch.rand(Bn, 1024, device=DEV); yn = torch.rand(Bn, 1024, device=DEV); dyn = torch.rand(Bn, 1024, device=DEV) / Bn
+    wn = torch.rand(1024, 1024, device=DEV); dwn = torch.zeros(1024, 1024, device=DEV)
+    s = [_mk_stream(hip) for _ in range(3)]
+    flags_dx = capi.LINEAR_ONLY_DX | capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DY_PREMASKED
+    first = {}
+    try:
+        for det in (0, 1):
+            hip.check(hip.lib.ffh_ctx_set_deterministic(hip.ctx, det), "deterministic")
+            for rep in range(6):
+                ys = [torch.full((B, 512), 3.0, device=DEV) for _ in range(2)]
+                dxs = [torch.full((B, 3456), 3.0, device=DEV) for _ in range(2)]
+                torch.cuda.synchronize()
+                if not det:
+                    hip.call("ffh_linear_bwd_ex", xn, 1024, None, 1024, yn, 1024, dyn, 1024, wn, dwn, None, 1024, 1024, Bn, NONE,
+                             capi.LINEAR_ONLY_DW | capi.LINEAR_DY_PREMASKED, s[2].value, None)
+                for k in range(2):
+                    hip.call("ffh_linear_fwd", x1d, 1024, ys[k], 512, w1d, b1d, 1024, 512, B, RELU, s[k].value)
+                    r_f = _route(hip)
+                    hip.call("ffh_linear_bwd_ex", x2, 3456, dxs[k], 3456, y2, 1024, dy2d, 1024, w2d, dw2, None, 3456, 1024, B, NONE, flags_dx, s[k].value, None)
+                    r_x = _route(hip)
+                    assert "streamk" in r_f and "streamk" in r_x, (det, r_f, r_x)
+                for st in s:
+                    hip.check(hip.lib.ffh_stream_sync(hip.ctx, st), "sync")
+                for k in range(2):
+                    yk, dxk = ys[k].cpu().numpy(), dxs[k].cpu().numpy()
+                    if not first:
+                        _close(yk, y_e, m_y, "1024->512 forward (stream-K)")
+                        _close(dxk, dx_e, m_dx, "3456->1024 dX (stream-K)")
+                        first["y"], first["dx"] = yk, dxk
+                    assert yk.tobytes() == first["y"].tobytes(), f"forward differs (deterministic={det}, launch {rep}, stream {k})"
+                    assert dxk.tobytes() == first["dx"].tobytes(), f"dX differs (deterministic={det}, launch {rep}, stream {k})"
+    finally:
+        hip.check(hip.lib.ffh_ctx_set_deterministic(hip.ctx, 0), "deterministic")
+        for st in s:
+            hip.check(hip.lib.ffh_stream_destroy(hip.ctx, st), "destroy")
+
+
+def test_scratch_is_reserved_explicitly_and_leaves_with_its_stream(hip):
+    """ABI 12: no compute entry point allocates.  A stream without reserved scratch gets the whole-tile / other forms (never
+    'streamk'); ffh_ctx_reserve_scratch turns the form on; ffh_stream_destroy releases the set, so a long-lived ctx can take more than
+    FFH_MAX_SCRATCH_STREAMS streams over its life."""
+    import ctypes
+    B = 4096
+    x = torch.rand(B, 1024, device=DEV); w = torch.rand(512, 1024, device=DEV); y = torch.zeros(B, 512, device=DEV)
+    for i in range(12):
+        s = ctypes.c_void_p()
+        hip.check(hip.lib.ffh_stream_create(hip.ctx, ctypes.byref(s)), "stream")
+        hip.call("ffh_linear_fwd", x, 1024, y, 512, w, None, 1024, 512, B, RELU, s.value)
+        assert "streamk" not in _route(hip), _route(hip)
+        hip.check(hip.lib.ffh_ctx_reserve_scratch(hip.ctx, s), "scratch")
+        hip.check(hip.lib.ffh_ctx_reserve_scratch(hip.ctx, s), "scratch (again)")
+        hip.call("ffh_linear_fwd", x, 1024, y, 512, w, None, 1024, 512, B, RELU, s.value)
+        assert "streamk" in _route(hip), _route(hip)
+        hip.check(hip.lib.ffh_stream_sync(hip.ctx, s), "sync")
+        hip.check(hip.lib.ffh_stream_destroy(hip.ctx, s), "destroy")

@@ -71,13 +71,13 @@ def _run(args, steps=3, trace=False):
 
 
 @pytest.mark.parametrize("bot,top,inter,expect", [
-    ("13-96-64-16", "48-24-1", "cat", (2, 1)),          # bottom chain (3 layers) + top chain: forward 48-24-1; its backward leaves one layer below the loss layer: no chain
+    ("13-96-64-16", "48-24-1", "cat", (1, 1)),          # bottom chain (3 layers); the top's two layers stay per-layer forward, and its backward leaves one layer below the loss layer
     ("13-64-32-16", "48-40-24-1", "cat", (2, 2)),       # top chain backward = 48-40-24 (the click layer stays with the fused loss launch)
-    ("13-600-16", "48-24-1", "cat", (1, 0)),            # a 600-wide layer: no bottom chain
+    ("13-600-16", "48-40-24-1", "cat", (1, 1)),         # a 600-wide layer: no bottom chain
 ])
 def test_host_layer_runs_narrow_mlps_as_chains_same_bits_as_per_layer(bot, top, inter, expect):
     args = ["--backend", H.oracle_backend(), "-b", "48", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "30-11",
-            "--arch-mlp-bot", bot, "--arch-mlp-top", top, "--data-size", "48", "--arch-interaction-op", inter]
+            "--arch-mlp-bot", bot, "--arch-mlp-top", top, "--data-size", "48", "--arch-interaction-op", inter, "--mlp-chain-fwd-min-batch", "1"]
     steps = 3
     a, ca = _run(args, steps)
     b, cb = _run(args + ["--no-mlp-chain"], steps)
@@ -91,9 +91,11 @@ def test_host_layer_runs_narrow_mlps_as_chains_same_bits_as_per_layer(bot, top, 
 
 def test_chains_stand_back_where_they_are_not_served():
     base = ["--backend", H.oracle_backend(), "-b", "48", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "30-11",
-            "--arch-mlp-bot", "13-96-64-16", "--arch-mlp-top", "48-24-1", "--data-size", "48"]
-    for extra in (["--deterministic"], ["--profiling"], ["--mlp-chain-max-batch", "32"], ["--allow-tensor-op-math-conversion"]):
+            "--arch-mlp-bot", "13-96-64-16", "--arch-mlp-top", "48-24-1", "--data-size", "48", "--mlp-chain-fwd-min-batch", "1"]
+    for extra in (["--deterministic"], ["--profiling"], ["--mlp-chain-max-batch", "32"], ["--allow-tensor-op-math-conversion"], ["--mlp-chain-max-weights", "100"]):
         _, c = _run(base + extra, 1)
         assert c == (0, 0), (extra, c)
     _, c = _run(base, 2, trace=True)          # under begin_trace / end_trace as well (the oracle backend runs traces eagerly)
     assert c[0] > 0 and c[1] > 0
+    _, c = _run(base[:-2], 1)                 # the forward chain waits for 4096 samples per GPU by default; the backward chain does not
+    assert c[0] == 0 and c[1] > 0, c

@@ -29,11 +29,18 @@ def timeit(fn, iters=50, warm=5):
 
 def main():
     hip = _lab.load_hip(0)
-    batches = [int(a) for a in sys.argv[1:]] or [2048, 4096, 8192, 32768]
+    batches = [int(a) for a in sys.argv[1:] if a.isdigit()] or [2048, 4096, 8192, 32768]
+    single = "--single" in sys.argv       # every layer of the bottom MLP as a chain of its own (where does the chain's time go?)
+    only = [a[7:] for a in sys.argv[1:] if a.startswith("--only=")]
     chains = [("bottom 13-512-256-128", (13, 512, 256, 128), (RELU, RELU, RELU), False),
               ("kaggle bottom 13-512-256-64-16", (13, 512, 256, 64, 16), (RELU,) * 4, False),
               ("kaggle top 432-512-256 (+ dx)", (432, 512, 256), (RELU, RELU), True),
               ("kaggle top fwd 432-512-256-1", (432, 512, 256, 1), (RELU, RELU, SIG), True)]
+    if single:
+        chains = [("13-512", (13, 512), (RELU,), False), ("512-256", (512, 256), (RELU,), True), ("256-128", (256, 128), (RELU,), True),
+                  ("512-256-128", (512, 256, 128), (RELU, RELU), True), ("432-512", (432, 512), (RELU,), True), ("64-16", (64, 16), (RELU,), True)]
+    if only:
+        chains = [c for c in chains if any(o.replace("_", " ") in c[0] for o in only)]
     s2 = torch.cuda.Stream()
     for B in batches:
         for name, widths, acts, want_dx in chains:

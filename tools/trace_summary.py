@@ -8,7 +8,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # backward that now carries the loss step (linear_skinny_bwd_kernel<*, 1> / <*, 4> right after a skinny forward)
 idx = [i for i, r in enumerate(rows) if "metrics_kernel" in r["Kernel_Name"]]
 if len(idx) < 25:
-    idx = [i for i, r in enumerate(rows) if i > 0 and "linear_skinny_bwd_kernel" in r["Kernel_Name"] and "linear_skinny_fwd_kernel" in rows[i - 1]["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if i > 0 and "linear_skinny_bwd_kernel" in r["Kernel_Name"] and ("linear_skinny_fwd_kernel" in rows[i - 1]["Kernel_Name"] or "mlp_chain_fwd_kernel" in rows[i - 1]["Kernel_Name"])]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -20
 a, b = idx[which], idx[which + 1]
 # a step spans from the first kernel after previous step's last kernel ... approximate: window between consecutive mse kernels
