@@ -133,11 +133,14 @@ FFConfig::FFConfig() {
   attach_events = true;
   fuse_pair = true;
   mlp_chain = true;
-  mlp_chain_max_batch = 8192;
-  // measured (tools/chain_bench.py, profiles/r05_microbench_mlp_chain.txt): the backward chain beats the per-layer calls at every batch up
-  // to 8192 for the bottom MLPs (4096 samples: 46 vs 86 us); the forward chain only from 4096 samples up and with three layers or more
-  // (28 vs 31 us; at 2048: 28 vs 24); a chain whose weights are beyond ~200 K floats (the Kaggle top MLP: 352 K) loses to the
-  // per-layer GEMMs below 4096 samples -- every CU streams every weight from L2 for its 16 rows
+  mlp_chain_max_batch = 4096;
+  // measured on whole steps (profiles/r05_ab_chain.txt) and alone (tools/chain_bench.py, profiles/r05_microbench_mlp_chain.txt): the
+  // backward chain of the bottom MLPs beats the per-layer calls up to 4096 samples per GPU (alone 46 vs 86 us at 4096, 37 vs 74 at the
+  // Kaggle shape; steps 1.163 vs 1.188 ms and 0.170 vs 0.187); at 8192 it is faster alone (72 vs 116) but the step is slower (MLPerf
+  // shape 1.225 vs 1.200 ms: the per-layer weight gradients ran beside the data gradients on their own stream).  The forward chain
+  // is level with the per-layer kernels from 4096 samples (28 vs 31 us alone, the step unchanged) and slower below (28 vs 24 at
+  // 2048); a chain beyond ~200 K weights (the Kaggle top MLP: 352 K) loses below 4096 samples -- every CU streams every weight from
+  // L2 for its 16 rows, which bounds these kernels
   mlp_chain_fwd_min_batch = 4096;
   mlp_chain_max_weights = 200000;
   dx_scatter = true;
@@ -1899,9 +1902,8 @@ void FFModel::allocate() {
         else ok = am == AC_MODE_NONE || am == AC_MODE_RELU || am == AC_MODE_SIGMOID;
       }
       if (ok) bw.back()->chain_bwd = bw;
-      // (the two-narrow-layers launches of the same layers stand back: a member's forward / backward is the chain's)
-      if (!a->chain_fwd.empty()) for (Linear* m : ch) { m->pair_upper = nullptr; }
-      if (ok) for (Linear* m : bw) m->pair_lower = nullptr;
+      // (the two-narrow-layers launches of the same layers keep their pointers: where a chain call is not usable -- the batch -- they
+      //  serve as before; where it is, the chain's lowest / top member is reached first and marks the others done)
     }
   }
 
