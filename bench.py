@@ -408,6 +408,7 @@ def main():
     ap.add_argument("--leg-budget", type=float, default=7.0, help=argparse.SUPPRESS)
     ap.add_argument("--replicate-embedding-rows", type=int, default=0, help="N > 1: tables with at most this many rows are data-parallel (a copy on every "
                     "rank, dense gradient in the MLP's all-reduce bucket) instead of table-wise in the all-to-all; 0 (default): every table table-wise")
+    ap.add_argument("--allreduce-own-channel", action="store_true", help="a second RCCL communicator (ncclCommSplit) for the MLP-gradient buckets (N > 1; unmeasured: no multi-GPU box)")
     ap.add_argument("--shim-flags", default="", help="extra FFConfig flags for A/B runs, e.g. '--serial-dw --no-overlap'")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: ranks rendezvous over gloo and report, no GPU
     ap.add_argument("--functional-test-backend", default="", help=argparse.SUPPRESS)   # tests only: walk this file's whole rank path on the
@@ -470,7 +471,7 @@ def main():
         collectives = "torch.distributed (RCCL) callbacks" if not ftest else "torch.distributed (gloo) callbacks: FUNCTIONAL TEST, not a measurement"
         if not ftest and not args.torch_collectives and not os.environ.get("FFM_NO_DIRECT_RCCL"):
             try:
-                comm = RcclComm(comm)       # the same callbacks served by RCCL from the C++ host layer, no Python per collective
+                comm = RcclComm(comm, own_bucket_channel=args.allreduce_own_channel)       # the same callbacks served by RCCL from the C++ host layer, no Python per collective
                 collectives = "RCCL called from the C++ host layer"
             except Exception as e:  # noqa: BLE001  every rank raises together (comm.py): fall back to the torch callbacks
                 if rank == 0:
@@ -595,8 +596,7 @@ def main():
         if in_step:
             us = lambda d, k: round(d[k] * 1e3, 1)
             # what the collectives cost inside the step, so that a scaling record explains its own efficiency: each collective's own
-            # interval on the stream it is issued on (side stream: both all-to-alls; compute stream: the all-reduce, which is therefore
-            # exposed in full) and `embedding_branch_wait_us` = how long the compute stream stood at the join in front of the first
+            # interval on the stream it is issued on (side stream: both all-to-alls) and `embedding_branch_wait_us` = how long the compute stream stood at the join in front of the first
             # consumer of the embedding outputs -- the exposed part of [table update of the step before -> gather -> forward all-to-all]
             out["collectives_in_step_us"] = {
                 "how": "HIP events around each call inside real eager steps, averaged; rank0 and max over ranks",
@@ -606,7 +606,14 @@ def main():
                 "max_over_ranks": {"alltoall_fwd_us": us(in_step_max, "alltoall_fwd"), "alltoall_bwd_us": us(in_step_max, "alltoall_bwd"), "allreduce_us": us(in_step_max, "allreduce"),
                                    "embedding_branch_wait_us": us(in_step_max, "join_wait"), "gather_plus_alltoall_fwd_us": us(in_step_max, "gather"),
                                    "alltoall_bwd_plus_table_update_us": us(in_step_max, "table_update")},
-                "exposed_on_the_compute_stream_us": round((in_step_max["allreduce"] + in_step_max["join_wait"]) * 1e3, 1)}
+                # the MLP gradients' all-reduce goes out in buckets from inside backward() on a communication stream (round 5): each
+                # bucket's own interval there, their sum, and what the compute stream stood waiting for them in front of the optimizer
+                # (`allreduce_exposed_us`; `allreduce_us` above is what is left for update(): nothing, or the data-parallel tables)
+                "allreduce_buckets_us": {"rank0": [us(in_step, f"bucket{i}") for i in range(8) if in_step.get(f"bucket{i}", 0) > 0],
+                                         "max_over_ranks": [us(in_step_max, f"bucket{i}") for i in range(8) if in_step_max.get(f"bucket{i}", 0) > 0]},
+                "allreduce_buckets_sum_us": round(sum(in_step_max.get(f"bucket{i}", 0) for i in range(8)) * 1e3, 1),
+                "allreduce_exposed_us": us(in_step_max, "allreduce_wait"),
+                "exposed_on_the_compute_stream_us": round((in_step_max["allreduce"] + in_step_max["allreduce_wait"] + in_step_max["join_wait"]) * 1e3, 1)}
     if args.force_exchange:
         out["config"]["parallelism"] = f"1 rank, exchange path forced: {layout} + all-reduce; {collectives}"
     out["kernels"] = {}

@@ -213,7 +213,9 @@ class RcclComm:
     `boot` is a TorchComm over an initialised NCCL process group: it broadcasts the unique id and keeps the barrier.
     Raises RuntimeError on every rank if any rank cannot set it up (use `boot` then)."""
 
-    def __init__(self, boot: TorchComm):
+    def __init__(self, boot: TorchComm, own_bucket_channel: bool = False):
+        """own_bucket_channel: a second communicator (ncclCommSplit) for the MLP-gradient buckets, so that RCCL does not order them
+        against the all-to-alls (opt-in: `--allreduce-own-channel` of bench.py / run_dlrm.py)."""
         from . import ffmodel
         assert boot.on_gpu
         self.boot = boot
@@ -245,6 +247,10 @@ class RcclComm:
         # all-reduce, reduce-scatter, all-gather); every rank must pass or all fall back to the torch callbacks together
         self._base = {"alltoall": 0, "allreduce": 0, "reduce_scatter": 0, "allgather": 0}
         ok = self._self_test()
+        self.own_bucket_channel = False
+        if ok and own_bucket_channel:
+            L.flexflow_rccl_comm_enable_bucket_channel.restype = C.c_int
+            self.own_bucket_channel = L.flexflow_rccl_comm_enable_bucket_channel(C.byref(self.struct)) == 0      # collective; a failure keeps the shared channel
         self._base = self.calls                    # `calls` counts the model's collectives only
         flag.fill_(1 if ok else 0)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=boot.group)

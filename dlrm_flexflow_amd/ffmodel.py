@@ -46,7 +46,7 @@ class FFComm(C.Structure):
     """struct ffcomm (host/ffcomm.h)"""
     _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("user", C.c_void_p),
                 ("alltoall_f32", ALLTOALL_FN), ("allreduce_sum_f32", ALLREDUCE_FN), ("barrier", BARRIER_FN), ("nonblocking", C.c_int),
-                ("reduce_scatter_sum_f32", REDUCE_SCATTER_FN), ("allgather_f32", ALLGATHER_FN)]
+                ("reduce_scatter_sum_f32", REDUCE_SCATTER_FN), ("allgather_f32", ALLGATHER_FN), ("allreduce_bucket_sum_f32", ALLREDUCE_FN)]
 
 
 _lib = None
@@ -348,7 +348,7 @@ class DLRM:
     def run_epochs(self) -> float: return lib().flexflow_dlrm_run_epochs(self.h)
     def time_kernel(self, which, iters) -> float: return lib().flexflow_dlrm_time_kernel(self.h, which, iters)
 
-    PROBE_PAIRS = ("gather", "table_update", "alltoall_fwd", "alltoall_bwd", "allreduce", "join_wait")
+    PROBE_PAIRS = ("gather", "table_update", "alltoall_fwd", "alltoall_bwd", "allreduce", "join_wait", "allreduce_wait") + tuple(f"bucket{i}" for i in range(8))
 
     def probe_step(self, iters) -> dict:
         """In-step event intervals (milliseconds, averaged over `iters` real eager steps): the side-stream gather (+ forward exchange)

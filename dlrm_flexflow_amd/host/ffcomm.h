@@ -7,7 +7,7 @@
  * Here each process owns one GPU (one rank) and the launcher (bench.py / run_dlrm.py: torch.distributed
  * with the "nccl" backend = RCCL over xGMI; "gloo" in the CPU tests) provides:
  *   alltoall   uneven all-to-all of fp32 blocks  (embedding rows forward, their gradients backward)
- *   allreduce  in-place fp32 sum                 (one bucket = all MLP gradients)
+ *   allreduce  in-place fp32 sum                 (the MLP gradients: one bucket per wide layer, issued as the backward produces them)
  *   reduce_scatter / allgather   (row-wise sharded giant table only, --row-shard-rows: every rank's partial bag sums
  *              for the global batch are summed and each rank keeps its own samples; the gradients of those
  *              samples are gathered back to every rank).  May be NULL when no table is row-sharded.
@@ -38,6 +38,12 @@ typedef struct ffcomm {
   int (*reduce_scatter_sum_f32)(void* user, const float* send, float* recv, int64_t recv_count, void* stream);
   /* recv[r * send_count + i] = rank r's send[i]: send is [send_count], recv is [world_size * send_count] */
   int (*allgather_f32)(void* user, const float* send, float* recv, int64_t send_count, void* stream);
+  /* The same sum as allreduce_sum_f32 for ONE BUCKET of the MLP gradients, issued from inside backward() on the model's
+   * communication stream while the rest of the backward runs (the reference issues one ncclAllReduce per parameter from that
+   * parameter's own update task [ref: src/runtime/optimizer.cc:93-189, src/runtime/optimizer_kernel.cu:114-179]).  A transport that
+   * can run it concurrently with the all-to-alls serves it on a channel of its own (RcclComm: a second communicator from
+   * ncclCommSplit); NULL: the buckets go through allreduce_sum_f32. */
+  int (*allreduce_bucket_sum_f32)(void* user, float* buf, int64_t count, void* stream);
 } ffcomm;
 
 #ifdef __cplusplus

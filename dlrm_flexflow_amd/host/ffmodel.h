@@ -120,6 +120,13 @@ class FFConfig {
   bool dx_colsum;              // a layer's bias gradient from the epilogue of the data-gradient kernel of the layer above (A/B: --no-dx-colsum)
   bool dx_scatter;             // exchange mode: the layer above the feature Concat writes its dX into the send buffer itself (A/B: --no-dx-scatter)
   bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)
+  int  bucket_allreduce;       // the MLP gradients' all-reduce in buckets issued from inside backward() on a communication stream, one per wide layer, beside the
+                               // rest of the backward [ref: one ncclAllReduce per parameter from its own update task, src/runtime/optimizer.cc:93-189]:
+                               // 1 / 0 (--bucket-allreduce / --no-bucket-allreduce), -1 = where the transport only enqueues (ffcomm.nonblocking)
+  int64_t allreduce_bucket_floats;   // a bucket is closed once it holds this many gradients (--allreduce-bucket-floats N; default 1 Mi = 4 MB)
+  int64_t big_dw_min_weights;  // ... only a layer with at least this many weights is cut (--big-dw-min-weights N; default 2 Mi)
+  int  big_dw_chunks;          // with bucketed all-reduce: the biggest layer's weight-gradient GEMM as this many launches over row blocks of dW, a bucket behind each (its
+                               // gradients are two thirds of the bytes and the last to be complete: --big-dw-chunks N; 0 = by transport: 4 where collectives only enqueue, else 1)
   bool mlp_chain;              // a run of narrow Linear layers (every width <= 512) as one launch forward, two backward (ffh_mlp_chain_fwd / _bwd; A/B: --no-mlp-chain)
   int64_t mlp_chain_max_batch; // ... for at most this many samples per GPU (--mlp-chain-max-batch N)
   int64_t mlp_chain_fwd_min_batch;   // the forward chain from this many samples per GPU up (below, the per-layer kernels win: --mlp-chain-fwd-min-batch N)
@@ -299,6 +306,7 @@ class Linear : public Op {
   void forward(const FFModel&) override;
   void backward(const FFModel&) override;
   void backward_part(const FFModel&, int part);   // 0: all; 1: data gradient only; 2: weight / bias gradient only, on the weight-gradient stream
+  void backward_dw_rows(const FFModel&, int row0, int nrows);   // the weight (+ bias) gradient of output rows [row0, row0 + nrows) on the weight-gradient stream (dy final: premasked / no activation)
   int in_channels, out_channels;
   int in_padded;                // what the kernel library is told: in_channels, or that rounded up to 64 when the input tensor and the kernel were
                                 // given zero pad columns (FFModel::allocate step 4a: reduction depths the persistent GEMMs cannot take)
@@ -517,6 +525,23 @@ class FFModel {
   mutable bool dw1_used = false, dw2_used = false;   // which weight-gradient stream(s) this step's forks were offered (joined in update())
   mutable bool dw_stream_used_directly = false;   // a weight gradient was enqueued on dw_stream by this layer itself (deferred dW), not by the library's fork
   int defer_big_dw_layer() const;
+  // ---- bucketed all-reduce of the MLP gradients (allocate step 5b, backward(), update()) ----
+  struct GradBucket {
+    size_t off, count;          // floats in the dense gradient slab
+    int lowest_layer;           // complete once every layer >= this one has issued its backward
+    bool issued;
+    ffh_event ready, ready_dw, ready_dw2, done;
+    int chunk_layer, chunk_index;   // >= 0: the bucket of one row block of that layer's weight gradient (FFConfig::big_dw_chunks), issued by the layer's own backward
+    bool inline_issued;             // ran on the compute stream itself (capture): nothing to join
+  };
+  std::vector<GradBucket> grad_buckets;                 // in the order the backward completes them (top layers first)
+  std::vector<std::pair<size_t, size_t>> grad_rest;     // (offset, count) of what no bucket covers (data-parallel tables): reduced in update()
+  ffh_stream ar_stream = nullptr;                       // the buckets' stream
+  bool bucketed_now() const;                            // buckets are issued from backward() in this step
+  void issue_grad_buckets(int next_layer);              // every complete, not yet issued bucket (layers > next_layer have issued their backward)
+  void issue_one_bucket(size_t k, bool wait_main);      // wait_main: also behind what the compute stream holds now
+  int  big_dw_chunks_now() const;                       // row blocks the biggest layer's weight gradient is cut into this step (1: not cut)
+  mutable int64_t n_bucket_allreduces = 0;
   mutable int64_t n_chain_fwd_calls = 0, n_chain_bwd_calls = 0;   // successful ffh_mlp_chain_fwd / _bwd calls (tests: flexflow_model_get_counter)
   bool mlp_chain_usable(int64_t rows, bool fwd) const;      // the chain launches are allowed in this mode / at this batch
   int run_chain_fwd(const Linear* lowest) const;  // FFH_OK, or FFH_ERR_UNSUPPORTED with nothing launched
@@ -548,7 +573,7 @@ class FFModel {
   mutable bool probe_events_on = false;
   // pairs: 0/1 gather (+ forward exchange), 2/3 table update (+ backward exchange), 4/5 forward all-to-all, 6/7 backward all-to-all,
   // 8/9 gradient all-reduce (compute stream), 10/11 the compute stream's wait for the gather / exchange branch (its exposed part)
-  static constexpr int kProbeEvents = 12;
+  static constexpr int kProbeEvents = 30;     // pairs: gather, update, a2a fwd, a2a bwd, all-reduce (rest / single bucket), join wait, the compute stream's wait for the buckets, buckets 0..7
   mutable ffh_event probe_ev[kProbeEvents] = {};
   void probe_record(int which, ffh_stream s, ffh_ctx* cx) const;
   bool fused_embedding_update() const;        // the tables are updated on the sorted segments (plain SGD, or any optimizer with --sparse-embedding-optimizer)

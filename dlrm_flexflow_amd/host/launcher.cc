@@ -122,6 +122,10 @@ int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv)
     fprintf(stderr, "dlrm rank %d: ncclCommInitRank failed: %s\n", rank, flexflow_rccl_last_error());
     return 5;
   }
+  // --allreduce-own-channel: a second communicator for the MLP-gradient buckets (opt-in; collective: every rank passes the flag)
+  for (int i = 1; i < argc; i++)
+    if (!strcmp(argv[i], "--allreduce-own-channel") && flexflow_rccl_comm_enable_bucket_channel(&comm) != 0 && rank == 0)
+      fprintf(stderr, "dlrm: --allreduce-own-channel: %s (the buckets share the first communicator)\n", flexflow_rccl_last_error());
   g_bar.api = api; g_bar.ctx = ctx; g_bar.comm = &comm;
   void* p = nullptr;
   if (api->ffh_stream_create(ctx, &g_bar.stream) != FFH_OK || api->ffh_malloc(ctx, &p, 256) != FFH_OK) return 5;

@@ -133,6 +133,10 @@ FFConfig::FFConfig() {
   attach_events = true;
   fuse_pair = true;
   mlp_chain = true;
+  bucket_allreduce = -1;
+  allreduce_bucket_floats = 1 << 20;
+  big_dw_chunks = 0;
+  big_dw_min_weights = 2 << 20;
   mlp_chain_max_batch = 4096;
   // measured on whole steps (profiles/r05_ab_chain.txt) and alone (tools/chain_bench.py, profiles/r05_microbench_mlp_chain.txt): the
   // backward chain of the bottom MLPs beats the per-layer calls up to 4096 samples per GPU (alone 46 vs 86 us at 4096, 37 vs 74 at the
@@ -214,6 +218,11 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-attach-event")) { attach_events = false; continue; }
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-mlp-chain")) { mlp_chain = false; continue; }
+    if (is("--bucket-allreduce")) { bucket_allreduce = 1; continue; }
+    if (is("--no-bucket-allreduce")) { bucket_allreduce = 0; continue; }
+    if (is("--allreduce-bucket-floats")) { allreduce_bucket_floats = atoll(next()); continue; }
+    if (is("--big-dw-chunks")) { big_dw_chunks = atoi(next()); continue; }
+    if (is("--big-dw-min-weights")) { big_dw_min_weights = atoll(next()); continue; }
     if (is("--mlp-chain-max-batch")) { mlp_chain_max_batch = atoll(next()); continue; }
     if (is("--mlp-chain-fwd-min-batch")) { mlp_chain_fwd_min_batch = atoll(next()); continue; }
     if (is("--mlp-chain-max-weights")) { mlp_chain_max_weights = atoll(next()); continue; }
@@ -497,6 +506,7 @@ FFModel::FFModel(FFConfig& _config)
   check((config.stream_priorities && !exchange) ? api->ffh_stream_create_with_priority(ctx, &side_stream, -1) : api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream2), "stream create");
+  check(api->ffh_stream_create(ctx, &ar_stream), "stream create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw2_done), "event create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw_done), "event create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_z_free), "event create");
@@ -544,6 +554,8 @@ FFModel::~FFModel() {
   api->ffh_event_destroy(ctx, ev_z_free);
   for (ffh_event& e : probe_ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
   api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream); api->ffh_stream_destroy(ctx, dw_stream2);
+  for (GradBucket& b : grad_buckets) { api->ffh_event_destroy(ctx, b.ready); api->ffh_event_destroy(ctx, b.ready_dw); api->ffh_event_destroy(ctx, b.ready_dw2); api->ffh_event_destroy(ctx, b.done); }
+  if (ar_stream) api->ffh_stream_destroy(ctx, ar_stream);
   api->ffh_event_destroy(ctx, ev_dw2_done);
   api->ffh_ctx_destroy(ctx);
   for (Op* op : layers) delete op;
@@ -795,6 +807,26 @@ void Linear::backward_part(const FFModel& ff, int part) {
                                      flags, ff.stream, fork ? dws : nullptr), name);
   if (reserve > 0) ff.check(ff.api->ffh_ctx_set_dw_cu_reserve(ff.ctx, 0), "dw cu reserve");
   if (fork) { ff.dw_forked = true; (dws == ff.dw_stream ? ff.dw1_used : ff.dw2_used) = true; }
+}
+
+// One row block of this layer's weight gradient: dW[row0 .. row0 + nrows)[:] (and db of the same rows) as an ONLY_DW call of its own on
+// the weight-gradient stream, from the column slice of dy those outputs own.  For the bucketed all-reduce (FFModel::backward): the
+// biggest layer's gradients are two thirds of the slab and complete last; cut into row blocks, the sum of block c over the ranks runs
+// beside the GEMM of block c + 1.  The caller has issued the data gradient (part 1) and recorded layer_events[layer_index] behind it.
+void Linear::backward_dw_rows(const FFModel& ff, int row0, int nrows) {
+  const Tensor& x = inputs[0];
+  const Tensor& y = outputs[0];
+  const int64_t b = local_rows(y, &ff);
+  const float *xp = (const float*)x.impl->ptr, *yp = (const float*)y.impl->ptr + row0;
+  float *dyp = y.impl->grad + row0, *dwp = weights[0].impl->grad + (size_t)row0 * (size_t)weights[0].impl->ld;
+  const float* wp = (const float*)weights[0].impl->ptr + (size_t)row0 * (size_t)weights[0].impl->ld;
+  float* dbp = (use_bias && !db_from_upper) ? weights[1].impl->grad + row0 : nullptr;
+  const int flags = FFH_LINEAR_ONLY_DW | FFH_LINEAR_DY_PREMASKED;       // (dy final: the caller checked)
+  ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, x.impl->ld, nullptr, x.impl->grad_ld, yp, y.impl->ld, dyp, y.impl->grad_ld, wp, dwp, dbp, in_padded, nrows, b,
+                                     (int)activation, flags, ff.dw_stream, nullptr), name);
+  ff.dw_forked = true;
+  ff.dw1_used = true;
+  ff.dw_stream_used_directly = true;
 }
 
 // ---- chains of narrow Linear layers (ffh_mlp_chain_fwd / _bwd, ABI 12; built in FFModel::allocate step 4e) -------------------
@@ -1949,6 +1981,66 @@ void FFModel::allocate() {
   }
   // Op::weights[] are copies of the Parameters: same impl pointers, nothing to patch.
 
+  // ---- 5b. buckets of the MLP gradients' all-reduce ---------------------------------------------------------------------
+  // In the reference every parameter has its own update task with its own ncclAllReduce, ordered by region dependences only: a top
+  // layer's gradients are summed over the ranks while the layers below still run their backward [ref: src/runtime/optimizer.cc:93-189,
+  // src/runtime/model.cc:1471-1477].  Here: the Linear layers' slab ranges, walked in backward order and merged until a bucket holds
+  // allreduce_bucket_floats gradients; a bucket is issued on ar_stream as soon as the layers it covers have issued their backward
+  // (FFModel::issue_grad_buckets), the slab optimizer waits for all of them.  What no bucket covers (data-parallel tables in the slab)
+  // is reduced in update() as before.
+  for (GradBucket& b : grad_buckets) { api->ffh_event_destroy(ctx, b.ready); api->ffh_event_destroy(ctx, b.ready_dw); api->ffh_event_destroy(ctx, b.ready_dw2); api->ffh_event_destroy(ctx, b.done); }
+  grad_buckets.clear();
+  grad_rest.clear();
+  if (exchange && mlp_count) {
+    int chunks = config.big_dw_chunks > 0 ? config.big_dw_chunks : (config.comm.nonblocking ? 4 : 1);
+    Linear* big = big_dw_layer >= 0 ? static_cast<Linear*>(layers[big_dw_layer]) : nullptr;
+    // (cut only a layer worth cutting whose dy is final when its backward starts, into row blocks whose dy column slices stay 16-byte aligned)
+    if (!big || chunks < 2 || (int64_t)big->in_channels * big->out_channels < config.big_dw_min_weights || big->out_channels % (4 * chunks) != 0 ||
+        !(big->dy_premasked || big->activation == AC_MODE_NONE) || big->discard_input_grad || !config.parallel_dw)
+      chunks = 1;
+    auto build = [&](size_t threshold) {
+      std::vector<GradBucket> out;
+      GradBucket cur{0, 0, -1, false, nullptr, nullptr, nullptr, nullptr, -1, 0, false};
+      auto close = [&]() { if (cur.count) out.push_back(cur); cur = GradBucket{0, 0, -1, false, nullptr, nullptr, nullptr, nullptr, -1, 0, false}; };
+      for (int l = (int)layers.size() - 1; l >= 0; l--) {
+        Linear* li = layers[l]->op_type == OP_LINEAR ? static_cast<Linear*>(layers[l]) : nullptr;
+        if (!li) continue;
+        // the layer's range: kernel, then bias, adjacent in the slab (step 5)
+        const size_t lo = (size_t)(li->weights[0].impl->grad - mlp_grads);
+        size_t hi = lo + (li->weights[0].impl->bytes / 4 + 3) / 4 * 4;
+        if (li->use_bias) hi = (size_t)(li->weights[1].impl->grad - mlp_grads) + (li->weights[1].impl->bytes / 4 + 3) / 4 * 4;
+        if (li == big && chunks > 1) {      // its own buckets: row block c of the kernel; the last one takes the bias too
+          close();
+          const size_t per = (size_t)(big->out_channels / chunks) * (size_t)big->weights[0].impl->ld;
+          for (int c = 0; c < chunks; c++) {
+            GradBucket b{lo + c * per, c == chunks - 1 ? hi - (lo + c * per) : per, l, false, nullptr, nullptr, nullptr, nullptr, l, c, false};
+            out.push_back(b);
+          }
+          continue;
+        }
+        if (cur.count && hi != cur.off) close();          // not adjacent to the bucket being filled (tables in between)
+        if (!cur.count) { cur.off = lo; cur.count = hi - lo; }
+        else { cur.count += cur.off - lo; cur.off = lo; }
+        cur.lowest_layer = l;
+        if (cur.count >= threshold) close();
+      }
+      close();
+      return out;
+    };
+    size_t threshold = (size_t)std::max<int64_t>(config.allreduce_bucket_floats, 1);
+    grad_buckets = build(threshold);
+    while (grad_buckets.size() > 8 && threshold < mlp_count) { threshold *= 2; grad_buckets = build(threshold); }     // (the probes number eight)
+    std::vector<std::pair<size_t, size_t>> covered;
+    for (GradBucket& b : grad_buckets) {
+      for (ffh_event* e : {&b.ready, &b.ready_dw, &b.ready_dw2, &b.done}) check(api->ffh_event_create(ctx, e), "event create");
+      covered.push_back({b.off, b.count});
+    }
+    std::sort(covered.begin(), covered.end());
+    size_t at = 0;
+    for (auto& c : covered) { if (c.first > at) grad_rest.push_back({at, c.first - at}); at = c.first + c.second; }
+    if (at < mlp_count) grad_rest.push_back({at, mlp_count - at});
+  }
+
   // ---- 6. workspace + metrics -------------------------------------------------------------------
   workspace_bytes = 256;
   if (owned_shards && fused) {
@@ -2308,6 +2400,52 @@ void FFModel::embedding_dense_update() const {
 // =============================================================================================
 // the training step [ref: src/runtime/model.cc:1410-1477, examples/cpp/DLRM/dlrm.cc:166-182]
 // =============================================================================================
+// ---- bucketed all-reduce of the MLP gradients (allocate step 5b) ----------------------------------------------------------------
+bool FFModel::bucketed_now() const {
+  if (!exchange || grad_buckets.empty() || use_workers() || config.profiling) return false;
+  if (config.bucket_allreduce == 0) return false;
+  return config.bucket_allreduce == 1 || config.comm.nonblocking != 0;     // a transport whose calls block the host thread: opt-in only
+}
+int FFModel::big_dw_chunks_now() const {
+  if (!bucketed_now()) return 1;
+  int n = 0;
+  for (const GradBucket& b : grad_buckets) n += b.chunk_layer >= 0;
+  return n > 1 ? n : 1;
+}
+// Issues every bucket whose layers (indices > next_layer) have all issued their backward.  The bucket's stream waits for what the
+// compute stream and the weight-gradient streams hold at this point -- the layers' dW / db launches among it -- then runs the sum.
+// While a capture is open (--capture-exchange) the sum goes on the capturing stream itself: with RCCL work on a stream that joined
+// the capture through an event hipStreamEndCapture recurses (profiles/r04_capture_exchange_endcapture_backtrace.txt).
+void FFModel::issue_grad_buckets(int next_layer) {
+  for (size_t k = 0; k < grad_buckets.size(); k++) {
+    GradBucket& b = grad_buckets[k];
+    if (b.issued || b.lowest_layer <= next_layer) continue;
+    issue_one_bucket(k, true);
+  }
+}
+void FFModel::issue_one_bucket(size_t k, bool wait_main) {
+  GradBucket& b = grad_buckets[k];
+  const bool inline_now = capturing_trace >= 0 || config.capture_exchange;
+  ffh_stream s = inline_now ? stream : ar_stream;
+  if (dw_worker) dw_worker->drain();
+  if (!inline_now && wait_main) {
+    check(api->ffh_event_record(ctx, b.ready, stream), "bucket ready");
+    check(api->ffh_stream_wait_event(ctx, s, b.ready), "bucket ready");
+  }
+  // (the weight-gradient streams: joined where this step has used them so far -- a bucket whose layers kept everything on `stream`
+  //  waits for nothing extra; inline, `stream` itself takes the waits)
+  if (dw_forked && dw1_used) { check(api->ffh_event_record(ctx, b.ready_dw, dw_stream), "bucket ready"); check(api->ffh_stream_wait_event(ctx, s, b.ready_dw), "bucket ready"); }
+  if (dw_forked && dw2_used) { check(api->ffh_event_record(ctx, b.ready_dw2, dw_stream2), "bucket ready"); check(api->ffh_stream_wait_event(ctx, s, b.ready_dw2), "bucket ready"); }
+  if (k < 8) probe_record(14 + 2 * (int)k, s, ctx);
+  auto fn = config.comm.allreduce_bucket_sum_f32 ? config.comm.allreduce_bucket_sum_f32 : config.comm.allreduce_sum_f32;
+  if (fn(config.comm.user, mlp_grads + b.off, (int64_t)b.count, s) != 0) die("allreduce (bucket) failed");
+  if (k < 8) probe_record(15 + 2 * (int)k, s, ctx);
+  if (!inline_now) check(api->ffh_event_record(ctx, b.done, s), "bucket done");
+  b.issued = true;
+  b.inline_issued = inline_now;
+  n_bucket_allreduces++;
+}
+
 void FFModel::reset_metrics() {
   if (replaying_trace >= 0) return;
   check(api->ffh_zero(ctx, d_perf, sizeof(ffh_perf_metrics), stream), "reset_metrics");
@@ -2513,7 +2651,25 @@ void FFModel::backward(int _seq_length) {
   // 2.155 at 8192, 8.02 vs 7.87 at 32768, MLPerf shape 1.337 vs 1.273.
   const int defer_layer = defer_big_dw_layer();
   Linear* deferred = nullptr;
+  for (GradBucket& b : grad_buckets) b.issued = b.inline_issued = false;
+  const int dw_chunks = (defer_layer < 0 && !config.big_dw_mode) ? big_dw_chunks_now() : 1;
+  // the biggest layer with the bucketed all-reduce: data gradient, then its weight gradient in row blocks, a bucket behind each
+  auto chunked_big_backward = [&](Linear* up, int l) {
+    up->backward_part(*this, 1);
+    ffh_event ev = layer_events[l];
+    check(api->ffh_event_record(ctx, ev, stream), "event");
+    check(api->ffh_stream_wait_event(ctx, dw_stream, ev), "event");
+    const int per = up->out_channels / dw_chunks;
+    for (size_t k = 0; k < grad_buckets.size(); k++) {
+      GradBucket& b = grad_buckets[k];
+      if (b.chunk_layer != l) continue;
+      up->backward_dw_rows(*this, b.chunk_index * per, per);
+      issue_one_bucket(k, false);
+    }
+    up->db_from_upper = false;
+  };
   for (int l = first; l >= 0; l--) {
+    if (bucketed_now() && defer_layer < 0 && !config.big_dw_mode) issue_grad_buckets(l);     // the buckets every layer above l has completed
     if (l == grad_attach_layer) {
       check(api->ffh_event_record_with_next_linear_bwd(ctx, ev_grad_ready), "attach event");
       grad_ready_attached = true;
@@ -2523,6 +2679,7 @@ void FFModel::backward(int _seq_length) {
       const bool attach = l == scatter_attach_layer;
       check(api->ffh_linear_bwd_set_dx_scatter(ctx, up->dx_map, up->in_channels, attach ? ev_grad_ready : nullptr), "dx scatter");
       if (l == defer_layer) { up->backward_part(*this, 1); deferred = up; }
+      else if (dw_chunks > 1 && l == big_dw_layer) { chunked_big_backward(up, l); mark_z_free(l); }
       else { up->backward(*this); mark_z_free(l); }
       if (api->ffh_linear_dx_scatter_used(ctx)) {
         up->dx_map_concat->bwd_done = true;                    // its pack kernel is not needed this step
@@ -2573,6 +2730,7 @@ void FFModel::backward(int _seq_length) {
       mark_z_free(l);
       continue;
     }
+    if (up && dw_chunks > 1 && l == big_dw_layer) { chunked_big_backward(up, l); mark_z_free(l); continue; }
     layers[l]->backward(*this);
     mark_z_free(l);
   }
@@ -2580,6 +2738,7 @@ void FFModel::backward(int _seq_length) {
     deferred->backward_part(*this, 2);
     mark_z_free(deferred->layer_index);
   }
+  if (bucketed_now()) issue_grad_buckets(-1);
   if (emb_update_pending) {
     // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
     issue_embedding_update_on_side_stream();
@@ -2623,9 +2782,24 @@ void FFModel::update() {
   // data-parallel MLP gradients: ONE bucket [ref: one ncclAllReduce per tensor, src/runtime/optimizer_kernel.cu:170-171].
   // No 1/world_size: the loss already divides by the global batch.
   if (exchange && mlp_count) {
-    probe_record(8, stream, ctx);
-    if (config.comm.allreduce_sum_f32(config.comm.user, mlp_grads, (int64_t)mlp_count, stream) != 0) die("allreduce failed");
-    probe_record(9, stream, ctx);
+    bool any_issued = false;
+    for (const GradBucket& b : grad_buckets) any_issued = any_issued || b.issued;
+    if (any_issued) {
+      // the buckets went out from backward() on ar_stream: the optimizer waits for them here (what `stream` stands at these waits is
+      // the EXPOSED part of the all-reduce: probe pair 12 / 13), then what no bucket covers is reduced as before
+      for (const GradBucket& b : grad_buckets) if (!b.issued) die("update(): a gradient bucket was not issued");
+      probe_record(12, stream, ctx);
+      for (const GradBucket& b : grad_buckets) if (!b.inline_issued) check(api->ffh_stream_wait_event(ctx, stream, b.done), "join all-reduce bucket");
+      probe_record(13, stream, ctx);
+      probe_record(8, stream, ctx);
+      for (auto& r : grad_rest)
+        if (config.comm.allreduce_sum_f32(config.comm.user, mlp_grads + r.first, (int64_t)r.second, stream) != 0) die("allreduce failed");
+      probe_record(9, stream, ctx);
+    } else {
+      probe_record(8, stream, ctx);
+      if (config.comm.allreduce_sum_f32(config.comm.user, mlp_grads, (int64_t)mlp_count, stream) != 0) die("allreduce failed");
+      probe_record(9, stream, ctx);
+    }
   }
   // one launch over the whole MLP slab; it also clears the gradients it consumed, so the next zero_gradients()
   // has nothing to sweep [ref: one update task per parameter, src/runtime/optimizer.cc:93-189,256-330]

@@ -26,6 +26,7 @@ struct Api {
   int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_p, void*);
   int (*AllGather)(const void*, void*, size_t, int, ncclComm_p, void*);
   const char* (*GetErrorString)(int);
+  int (*CommSplit)(ncclComm_p, int, int, ncclComm_p*, void*);     // optional (NCCL >= 2.18 API)
 };
 
 std::string g_err;
@@ -48,6 +49,7 @@ bool load(const char* path) {
   SYM(AllReduce, "ncclAllReduce") SYM(ReduceScatter, "ncclReduceScatter") SYM(AllGather, "ncclAllGather")
   SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+  *(void**)(&g_api.CommSplit) = dlsym(h, "ncclCommSplit");
   g_api.lib = h;
   return true;
 }
@@ -56,6 +58,8 @@ struct Comm {
   ncclComm_p comm;
   int rank, world;
   int64_t n_alltoall, n_allreduce, n_reduce_scatter, n_allgather;
+  ncclComm_p comm2;        // the gradient buckets' own channel (ncclCommSplit of comm), or null: they share comm
+  int64_t n_bucket;
 };
 
 int fail(int rc, const char* what) {
@@ -88,6 +92,18 @@ int allreduce_sum_f32(void* user, float* buf, int64_t count, void* stream) {
     if (e != kNcclSuccess) return fail(e, "ncclAllReduce");
   }
   c->n_allreduce++;
+  return 0;
+}
+
+// one bucket of the MLP gradients, issued from inside the backward on the model's communication stream: on the second communicator
+// where there is one, so that RCCL does not order it against the all-to-alls of the first
+int allreduce_bucket_sum_f32(void* user, float* buf, int64_t count, void* stream) {
+  Comm* c = (Comm*)user;
+  if (count > 0) {
+    const int e = g_api.AllReduce(buf, buf, (size_t)count, kNcclFloat32, kNcclSum, c->comm2 ? c->comm2 : c->comm, stream);
+    if (e != kNcclSuccess) return fail(e, "ncclAllReduce (bucket)");
+  }
+  c->n_bucket++;
   return 0;
 }
 
@@ -135,9 +151,10 @@ int flexflow_rccl_comm_create(const unsigned char id[128], int rank, int world_s
   if (!load(lib_path)) return 1;
   ncclUniqueId_t u;
   memcpy(u.internal, id, 128);
-  Comm* c = new Comm{nullptr, rank, world_size, 0, 0, 0, 0};
+  Comm* c = new Comm{nullptr, rank, world_size, 0, 0, 0, 0, nullptr, 0};
   const int e = g_api.CommInitRank(&c->comm, world_size, u, rank);
   if (e != kNcclSuccess) { delete c; return fail(e, "ncclCommInitRank"); }
+
   memset(out, 0, sizeof *out);
   out->rank = rank;
   out->world_size = world_size;
@@ -148,12 +165,14 @@ int flexflow_rccl_comm_create(const unsigned char id[128], int rank, int world_s
   out->nonblocking = 1;
   out->reduce_scatter_sum_f32 = reduce_scatter_sum_f32;
   out->allgather_f32 = allgather_f32;
+  out->allreduce_bucket_sum_f32 = allreduce_bucket_sum_f32;
   return 0;
 }
 
 void flexflow_rccl_comm_destroy(ffcomm* comm) {
   if (!comm || !comm->user) return;
   Comm* c = (Comm*)comm->user;
+  if (c->comm2) g_api.CommDestroy(c->comm2);
   if (c->comm) g_api.CommDestroy(c->comm);
   delete c;
   comm->user = nullptr;
@@ -163,6 +182,26 @@ void flexflow_rccl_comm_calls(const ffcomm* comm, int64_t* a2a, int64_t* ar) {
   const Comm* c = comm ? (const Comm*)comm->user : nullptr;
   if (a2a) *a2a = c ? c->n_alltoall : 0;
   if (ar) *ar = c ? c->n_allreduce : 0;
+}
+
+// A second communicator over the same ranks for the gradient buckets, so that RCCL does not order them against the all-to-alls of the
+// first (it runs one communicator's collectives in issue order whatever streams they are on).  COLLECTIVE: every rank makes the call.
+// Opt-in (the launchers' --allreduce-own-channel): no multi-GPU box was available to measure it on.  Returns 0 when the channel
+// exists afterwards, 1 when the library has no ncclCommSplit or it failed (the buckets then share the first communicator).
+int flexflow_rccl_comm_enable_bucket_channel(ffcomm* comm) {
+  Comm* c = comm ? (Comm*)comm->user : nullptr;
+  if (!c) return 1;
+  if (c->comm2) return 0;
+  if (!g_api.CommSplit) { g_err = "librccl has no ncclCommSplit"; return 1; }
+  const int e = g_api.CommSplit(c->comm, 0, c->rank, &c->comm2, nullptr);
+  if (e != kNcclSuccess) { c->comm2 = nullptr; return fail(e, "ncclCommSplit"); }
+  return 0;
+}
+
+int64_t flexflow_rccl_comm_bucket_calls(const ffcomm* comm, int* own_channel) {
+  const Comm* c = comm ? (const Comm*)comm->user : nullptr;
+  if (own_channel) *own_channel = (c && c->comm2) ? 1 : 0;
+  return c ? c->n_bucket : 0;
 }
 
 void flexflow_rccl_comm_calls2(const ffcomm* comm, int64_t* rs, int64_t* ag) {

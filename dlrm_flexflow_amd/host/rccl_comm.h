@@ -21,6 +21,10 @@ const char* flexflow_rccl_last_error(void);
 /* number of all-to-all / all-reduce calls served so far (tests) */
 void flexflow_rccl_comm_calls(const ffcomm* comm, int64_t* alltoall, int64_t* allreduce);
 void flexflow_rccl_comm_calls2(const ffcomm* comm, int64_t* reduce_scatter, int64_t* allgather);
+/* gradient buckets (ffcomm.allreduce_bucket_sum_f32): calls served; *own_channel = 1 when they run on a second communicator */
+int64_t flexflow_rccl_comm_bucket_calls(const ffcomm* comm, int* own_channel);
+/* COLLECTIVE, opt-in: a second communicator (ncclCommSplit) for the gradient buckets; 0 = it exists, 1 = not available (they share the first) */
+int  flexflow_rccl_comm_enable_bucket_channel(ffcomm* comm);
 #ifdef __cplusplus
 }
 #endif
