@@ -295,7 +295,9 @@ class RcclComm:
         a, r, s, g = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self._L.flexflow_rccl_comm_calls(C.byref(self.struct), C.byref(a), C.byref(r))
         self._L.flexflow_rccl_comm_calls2(C.byref(self.struct), C.byref(s), C.byref(g))
-        return {"alltoall": a.value - self._base["alltoall"], "allreduce": r.value - self._base["allreduce"],
+        self._L.flexflow_rccl_comm_bucket_calls.restype = C.c_int64
+        nb = int(self._L.flexflow_rccl_comm_bucket_calls(C.byref(self.struct), None))       # the MLP-gradient buckets (issued from inside backward())
+        return {"alltoall": a.value - self._base["alltoall"], "allreduce": r.value - self._base["allreduce"], "allreduce_buckets": nb,
                 "reduce_scatter": s.value - self._base["reduce_scatter"], "allgather": g.value - self._base["allgather"]}
 
     def close(self):

@@ -126,7 +126,7 @@ class FFConfig {
   int64_t allreduce_bucket_floats;   // a bucket is closed once it holds this many gradients (--allreduce-bucket-floats N; default 1 Mi = 4 MB)
   int64_t big_dw_min_weights;  // ... only a layer with at least this many weights is cut (--big-dw-min-weights N; default 2 Mi)
   int  big_dw_chunks;          // with bucketed all-reduce: the biggest layer's weight-gradient GEMM as this many launches over row blocks of dW, a bucket behind each (its
-                               // gradients are two thirds of the bytes and the last to be complete: --big-dw-chunks N; 0 = by transport: 4 where collectives only enqueue, else 1)
+                               // gradients are two thirds of the bytes and the last to be complete: --big-dw-chunks N; 0 / 1 = not cut, the default: see allocate step 5b)
   bool mlp_chain;              // a run of narrow Linear layers (every width <= 512) as one launch forward, two backward (ffh_mlp_chain_fwd / _bwd; A/B: --no-mlp-chain)
   int64_t mlp_chain_max_batch; // ... for at most this many samples per GPU (--mlp-chain-max-batch N)
   int64_t mlp_chain_fwd_min_batch;   // the forward chain from this many samples per GPU up (below, the per-layer kernels win: --mlp-chain-fwd-min-batch N)

@@ -170,8 +170,11 @@ FFConfig::FFConfig() {
 
 void FFConfig::parse_args(char** argv, int argc) {
   for (int i = 1; i < argc; i++) {
-    auto is = [&](const char* a) { return !strcmp(argv[i], a); };
+    // "--flag value" as the reference's parser takes it, and "--flag=value" (one token: survives a launcher's word splitting)
+    const char* eq = strncmp(argv[i], "--", 2) == 0 ? strchr(argv[i], '=') : nullptr;
+    auto is = [&](const char* a) { return eq ? (strlen(a) == (size_t)(eq - argv[i]) && !strncmp(argv[i], a, (size_t)(eq - argv[i]))) : !strcmp(argv[i], a); };
     auto next = [&]() -> const char* {
+      if (eq) return eq + 1;
       if (i + 1 >= argc) die("flag %s needs a value", argv[i]);
       return argv[++i];
     };
@@ -506,7 +509,11 @@ FFModel::FFModel(FFConfig& _config)
   check((config.stream_priorities && !exchange) ? api->ffh_stream_create_with_priority(ctx, &side_stream, -1) : api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream2), "stream create");
-  check(api->ffh_stream_create(ctx, &ar_stream), "stream create");
+  // the gradient buckets' stream: the second weight-gradient stream where that is idle (the default) -- a FIFTH stream shares a hardware
+  // queue with one of the others (HIP maps streams onto four), and a bucket waiting there for a weight-gradient GEMM then holds back
+  // whatever that other stream has queued: measured, the biggest layer's data gradient started 90 us late behind such a wait
+  if (config.two_dw_streams) check(api->ffh_stream_create(ctx, &ar_stream), "stream create");
+  else ar_stream = dw_stream2;
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw2_done), "event create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw_done), "event create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_z_free), "event create");
@@ -555,7 +562,7 @@ FFModel::~FFModel() {
   for (ffh_event& e : probe_ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
   api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream); api->ffh_stream_destroy(ctx, dw_stream2);
   for (GradBucket& b : grad_buckets) { api->ffh_event_destroy(ctx, b.ready); api->ffh_event_destroy(ctx, b.ready_dw); api->ffh_event_destroy(ctx, b.ready_dw2); api->ffh_event_destroy(ctx, b.done); }
-  if (ar_stream) api->ffh_stream_destroy(ctx, ar_stream);
+  if (ar_stream && ar_stream != dw_stream2) api->ffh_stream_destroy(ctx, ar_stream);
   api->ffh_event_destroy(ctx, ev_dw2_done);
   api->ffh_ctx_destroy(ctx);
   for (Op* op : layers) delete op;
@@ -1992,7 +1999,10 @@ void FFModel::allocate() {
   grad_buckets.clear();
   grad_rest.clear();
   if (exchange && mlp_count) {
-    int chunks = config.big_dw_chunks > 0 ? config.big_dw_chunks : (config.comm.nonblocking ? 4 : 1);
+    // (row blocks of the biggest layer: measured on one GPU -- forced 1-rank RCCL exchange, 4096 samples -- every extra block costs the
+    //  step ~25 us (1.297 / 1.331 / 1.365 ms at 1 / 2 / 4 blocks: four GEMMs of a quarter of the rows take 268 us where one takes 207); what it
+    //  would hide of a 14 MB ring all-reduce could not be measured without a multi-GPU box: off unless asked for)
+    int chunks = config.big_dw_chunks > 0 ? config.big_dw_chunks : 1;
     Linear* big = big_dw_layer >= 0 ? static_cast<Linear*>(layers[big_dw_layer]) : nullptr;
     // (cut only a layer worth cutting whose dy is final when its backward starts, into row blocks whose dy column slices stay 16-byte aligned)
     if (!big || chunks < 2 || (int64_t)big->in_channels * big->out_channels < config.big_dw_min_weights || big->out_channels % (4 * chunks) != 0 ||
@@ -2025,6 +2035,13 @@ void FFModel::allocate() {
         if (cur.count >= threshold) close();
       }
       close();
+      // a small tail (the bottom MLP behind the biggest layer) joins the bucket before it where the two are adjacent: both wait for the
+      // last weight-gradient GEMM anyway, and one call fewer stands between it and the optimizer
+      if (out.size() >= 2) {
+        GradBucket& t = out.back();
+        GradBucket& p = out[out.size() - 2];
+        if (t.count < threshold / 4 && p.chunk_layer < 0 && t.off + t.count == p.off) { p.off = t.off; p.count += t.count; p.lowest_layer = t.lowest_layer; out.pop_back(); }
+      }
       return out;
     };
     size_t threshold = (size_t)std::max<int64_t>(config.allreduce_bucket_floats, 1);
@@ -2655,10 +2672,12 @@ void FFModel::backward(int _seq_length) {
   const int dw_chunks = (defer_layer < 0 && !config.big_dw_mode) ? big_dw_chunks_now() : 1;
   // the biggest layer with the bucketed all-reduce: data gradient, then its weight gradient in row blocks, a bucket behind each
   auto chunked_big_backward = [&](Linear* up, int l) {
-    up->backward_part(*this, 1);
+    // (dy is final here: the weight-gradient stream forks in FRONT of the data gradient, as the library's own fork does, and the GEMMs of
+    //  the row blocks run beside it)
     ffh_event ev = layer_events[l];
     check(api->ffh_event_record(ctx, ev, stream), "event");
     check(api->ffh_stream_wait_event(ctx, dw_stream, ev), "event");
+    up->backward_part(*this, 1);
     const int per = up->out_channels / dw_chunks;
     for (size_t k = 0; k < grad_buckets.size(); k++) {
       GradBucket& b = grad_buckets[k];

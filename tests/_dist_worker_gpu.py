@@ -54,6 +54,7 @@ def main():
                                                                      float(w[:64].astype(np.float64).sum())])
         out["alltoall_calls"] = np.array(comm.calls["alltoall"])
         out["allreduce_calls"] = np.array(comm.calls["allreduce"])
+        out["allreduce_bucket_calls"] = np.array(comm.calls.get("allreduce_buckets", 0))
         np.savez(os.path.join(outdir, f"rank{dist.get_rank()}.npz"), **out)
         app.close()
         dist.barrier()
@@ -72,6 +73,7 @@ def main():
             for k, v in rec.items():
                 out[f"s{step}/{k}"] = v
         out["allreduce_calls"] = np.array(comm.calls["allreduce"])
+        out["allreduce_bucket_calls"] = np.array(comm.calls.get("allreduce_buckets", 0))
         np.savez(os.path.join(outdir, f"rank{dist.get_rank()}.npz"), **out)
         m.close()
         dist.barrier()
@@ -90,6 +92,7 @@ def main():
             out[f"s{step}/{k}"] = v
     out["alltoall_calls"] = np.array(comm.calls["alltoall"])
     out["allreduce_calls"] = np.array(comm.calls["allreduce"])
+    out["allreduce_bucket_calls"] = np.array(comm.calls.get("allreduce_buckets", 0))
     out["reduce_scatter_calls"] = np.array(comm.calls["reduce_scatter"])
     out["allgather_calls"] = np.array(comm.calls["allgather"])
     np.savez(os.path.join(outdir, f"rank{dist.get_rank()}.npz"), **out)

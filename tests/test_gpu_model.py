@@ -183,7 +183,9 @@ def test_single_rank_nccl_exchange_path_on_gpu(hip, tmp_path, how):
     r = subprocess.run(["python", worker, str(tmp_path), how], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     z = np.load(os.path.join(tmp_path, "rank0.npz"))
-    assert int(z["alltoall_calls"]) == 4 and int(z["allreduce_calls"]) == 2
+    # 2 steps x (forward + backward all-to-all); the MLP gradients: with the torch callbacks (they block the host) one all-reduce per step in
+    # update(), with RCCL called from C++ one bucket per >= 4 MB of layers from inside backward() -- this small model is one bucket
+    assert int(z["alltoall_calls"]) == 4 and int(z["allreduce_calls"]) + int(z["allreduce_bucket_calls"]) == 2
     m, h = H.build_golden_dlrm(HIP, overlap=False)
     ref = H.run_steps(m, h, 2)
     m.close()

@@ -215,7 +215,7 @@ def test_exchange_path_in_the_bf16_pipe_math_modes(hip, tmp_path, flag):
     r = subprocess.run(["python", worker, str(tmp_path), "direct", "kaggle", flag], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     z = np.load(os.path.join(tmp_path, "rank0.npz"))
-    assert int(z["alltoall_calls"]) >= 2 * 4 and int(z["allreduce_calls"]) >= 4
+    assert int(z["alltoall_calls"]) >= 2 * 4 and int(z["allreduce_calls"]) + int(z["allreduce_bucket_calls"]) >= 4     # (round 5: the MLP gradients travel in buckets from inside backward())
     app = ffmodel.DLRM(H.KAGGLE_ARGS(2048, HIP) + [flag])
     app.warmup(); app.train_steps(3, trace=False); app.model.sync()
     m = app.model
