@@ -50,6 +50,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int SK_BM = 128, SK_BN = 128, SK_BK = 64;
 constexpr int SK_LDS_KC = 128 * 256 + 32 * 32;   // k-contiguous operand: row r at r*256 + (r>>2)*32
 constexpr int SK_LDS_KR = 64 * 512;              // rows-are-k operand: row k at k*512
+// 64-row tiles (TMW = 2: a wave owns 32 x 64 of a 64 x 128 tile; round 5): the forward / data-gradient forms of layers whose 128-row
+// tiles are fewer than the CUs -- 1024 -> 512 at 4096 samples is 128 tiles of 128 x 128 (stream-K with fix-up: 8 k-tiles per workgroup and a
+// round trip of partial tiles through memory, 95 TFLOP/s) but 256 tiles of 64 x 128, one per CU with the whole reduction.  The A image
+// pads 32 bytes every TMW rows (a wave's m-tile r holds rows TMW c + r: the fragment reads of lanes c = 0 .. 15 stay on sixteen bank groups).
+constexpr int sk_lds_kc_a(int TMW) { return 32 * TMW * 256 + 32 * 32; }     // BM = 32 TMW rows: BM * 256 + (BM / TMW) * 32
 
 enum { SK_EPI_FWD = 0, SK_EPI_DX_STORE = 1, SK_EPI_DX_ADD = 2, SK_EPI_DW_ATOMIC = 3, SK_EPI_DX_CMAP = 4 };
 
@@ -103,14 +108,18 @@ constexpr int SK_EP_WAVE = SK_EP_ROWS * SK_EP_LD * 4;     // bytes per wave
 // of the next tile) last, so the head usually is the last to arrive and its own part never leaves its registers.  Cross-workgroup
 // values travel as agent-scope relaxed atomics (sc1: written through / read behind the per-XCD L2s), ordered by completion (vmcnt
 // + barrier before the counter add; the loads behind the returned add + a barrier), as in embedding.hip's folds.
-template <bool AKR, bool BKR, int EPI, bool DB = false, bool SPLIT = false>
+template <bool AKR, bool BKR, int EPI, bool DB = false, bool SPLIT = false, int TMW = 4>
 __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
   static_assert(!DB || (EPI == SK_EPI_DW_ATOMIC && AKR), "the bias gradient rides on the weight-gradient form");
   static_assert(!SPLIT || EPI != SK_EPI_DW_ATOMIC, "the weight gradient meets by atomics");
+  static_assert(TMW == 4 || (TMW == 2 && !AKR && EPI != SK_EPI_DW_ATOMIC), "64-row tiles: forward and data gradient (A k-contiguous)");
   extern __shared__ __attribute__((aligned(16))) char sk_lds[];
   constexpr bool ATOMIC = EPI == SK_EPI_DW_ATOMIC;
   constexpr bool STREAMK = ATOMIC || SPLIT;
-  constexpr int LDS_A = AKR ? SK_LDS_KR : SK_LDS_KC;
+  constexpr int BM = 32 * TMW;                      // rows of the tile: 128 or 64
+  constexpr int NM = 64 * TMW;                      // MFMAs per k-tile and wave
+  constexpr int NPA = 2 * TMW, NP = NPA + 8;        // staging pieces (float4 per thread) of a k-tile: A, A + B
+  constexpr int LDS_A = AKR ? SK_LDS_KR : sk_lds_kc_a(TMW);
   char* const ldsA = sk_lds;
   char* const ldsB = sk_lds + LDS_A;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -119,16 +128,16 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
   const int c16 = lane & 15, q = lane >> 4;
 
   // fragment read addresses (bytes inside the operand's LDS image)
-  const int fra = AKR ? (q * 2048 + wy * 256 + c16 * 16) : ((64 * wy + 4 * c16) * 256 + (16 * wy + c16) * 32 + q * 16);
+  const int fra = AKR ? (q * 2048 + wy * 256 + c16 * 16) : ((16 * TMW * wy + TMW * c16) * 256 + (16 * wy + c16) * 32 + q * 16);
   const int frb = BKR ? (q * 2048 + wx * 256 + c16 * 16) : ((64 * wx + 4 * c16) * 256 + (16 * wx + c16) * 32 + q * 16);
   // staging roles: this thread's 8 + 8 float4 of a k-tile -- where they come from (per-lane byte offset in the matrix) and go to
   const int srowA = AKR ? (tid >> 5) : (tid >> 4), schA = AKR ? (tid & 31) : (tid & 15);
   const int srowB = BKR ? (tid >> 5) : (tid >> 4), schB = BKR ? (tid & 31) : (tid & 15);
   const unsigned voffA = (unsigned)((srowA * g.lda + schA * 4) * 4);
   const unsigned voffB = (unsigned)((srowB * g.ldb + schB * 4) * 4);
-  const int swA = AKR ? (srowA * 512 + schA * 16) : (srowA * 256 + (srowA >> 2) * 32 + schA * 16);
+  const int swA = AKR ? (srowA * 512 + schA * 16) : (srowA * 256 + (srowA / TMW) * 32 + schA * 16);
   const int swB = BKR ? (srowB * 512 + schB * 16) : (srowB * 256 + (srowB >> 2) * 32 + schB * 16);
-  constexpr int SW_STEP_A = AKR ? 4096 : 4224, SW_STEP_B = BKR ? 4096 : 4224;     // LDS bytes between a thread's consecutive pieces
+  constexpr int SW_STEP_A = AKR ? 4096 : (4096 + (16 / TMW) * 32), SW_STEP_B = BKR ? 4096 : 4224;     // LDS bytes between a thread's consecutive pieces
   const unsigned ioffA = (unsigned)((AKR ? 8 : 16) * g.lda * 4), ioffB = (unsigned)((BKR ? 8 : 16) * g.ldb * 4);   // global bytes between them
   const unsigned kadvA = AKR ? (unsigned)(SK_BK * g.lda * 4) : (unsigned)(SK_BK * 4), kadvB = BKR ? (unsigned)(SK_BK * g.ldb * 4) : (unsigned)(SK_BK * 4);
 
@@ -136,7 +145,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, g.b_bytes, 0x00020000);
 
   // ---- this workgroup's share of the (tile, k-tile) iteration space ----
-  const unsigned nbx = (unsigned)(g.N / SK_BN), nby = (unsigned)(g.M / SK_BM), ntiles = nbx * nby;
+  const unsigned nbx = (unsigned)(g.N / SK_BN), nby = (unsigned)(g.M / BM), ntiles = nbx * nby;
   const unsigned nk = (unsigned)(g.K / SK_BK);
   const unsigned G = gridDim.x, w = blockIdx.x;
   const unsigned total_it = ntiles * nk;                  // < 2^32 (the host checks)
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
     else lin = c.seq * G + wperm;
     if (lin >= ntiles) lin = ntiles - 1;                  // run-ahead loads past the end of the share: any valid tile
     const unsigned by = lin / nbx, bx = lin - by * nbx;
-    c.m0 = by * SK_BM; c.n0 = bx * SK_BN;
+    c.m0 = by * BM; c.n0 = bx * SK_BN;
     c.offA = (AKR ? c.m0 * 4u : (unsigned)(c.m0 * g.lda * 4)) + c.kt * kadvA;
     c.offB = (BKR ? c.n0 * 4u : (unsigned)(c.n0 * g.ldb * 4)) + c.kt * kadvB;
   };
@@ -173,37 +182,37 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
   Cursor ld{0, STREAMK ? it_b % nk : 0u, 0, 0, 0, 0}, cp = ld;
   place(ld); place(cp);
 
-  u32x4 P[16];
+  u32x4 P[NP];
   auto gload_one = [&](int i, const Cursor& c) {
-    if (i < 8) P[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, c.offA + (unsigned)i * ioffA, 0);
-    else P[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB, c.offB + (unsigned)(i - 8) * ioffB, 0);
+    if (i < NPA) P[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA, c.offA + (unsigned)i * ioffA, 0);
+    else P[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB, c.offB + (unsigned)(i - NPA) * ioffB, 0);
   };
   auto lwrite_one = [&](int i) {
-    if (i < 8) *reinterpret_cast<u32x4*>(ldsA + swA + i * SW_STEP_A) = P[i];
-    else *reinterpret_cast<u32x4*>(ldsB + swB + (i - 8) * SW_STEP_B) = P[i];
+    if (i < NPA) *reinterpret_cast<u32x4*>(ldsA + swA + i * SW_STEP_A) = P[i];
+    else *reinterpret_cast<u32x4*>(ldsB + swB + (i - NPA) * SW_STEP_B) = P[i];
   };
   f32x4 fa[4][4], fb[4][4];      // [j][r]: k-contiguous operand: r = 16-row tile, components = 4 k-steps; rows-are-k: r = k-step, components = 4 tiles
   auto fread = [&](int j, int r, bool isB) {
     if (!isB) fa[j][r] = *reinterpret_cast<const f32x4*>(ldsA + fra + (AKR ? (j * 8192 + r * 512) : (r * 256 + j * 64)));
     else fb[j][r] = *reinterpret_cast<const f32x4*>(ldsB + frb + (BKR ? (j * 8192 + r * 512) : (r * 256 + j * 64)));
   };
-  f32x4 acc[4][4];
+  f32x4 acc[TMW][4];
   f32x4 bsum = f32x4{0.f, 0.f, 0.f, 0.f};   // DB: column sums of A over this segment's k range, rows m0 + 64 wy + 4 c16 + {0..3}, this lane's k-steps
 
   // ---- prologue: k-tile 0 -> LDS, k-tile 1 -> registers, fragments j = 0 of k-tile 0 ----
 #pragma unroll
-  for (int i = 0; i < 16; i++) gload_one(i, ld);
+  for (int i = 0; i < NP; i++) gload_one(i, ld);
   advance(ld);
 #pragma unroll
-  for (int i = 0; i < 16; i++) lwrite_one(i);
+  for (int i = 0; i < NP; i++) lwrite_one(i);
 #pragma unroll
-  for (int i = 0; i < 16; i++) gload_one(i, ld);
+  for (int i = 0; i < NP; i++) gload_one(i, ld);
   advance(ld);
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __builtin_amdgcn_s_barrier();
   SK_PIN();
 #pragma unroll
-  for (int r = 0; r < 4; r++) { fread(0, r, false); fread(0, r, true); }
+  for (int r = 0; r < 4; r++) { if (r < TMW) fread(0, r, false); fread(0, r, true); }
   SK_PIN();
 
   // outer loop: the output tiles (stream-K: segments) of this workgroup; inner loop: their k-tiles.  The operand stream (cursor
@@ -211,14 +220,15 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
   for (unsigned it = 0; it < n_it;) {
     const unsigned seg = (nk - cp.kt) < (n_it - it) ? (nk - cp.kt) : (n_it - it);
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < TMW; i++)
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     asm volatile("s_nop 7" ::: "memory");
     for (unsigned kk = 0; kk < seg; kk++) {
-      sk_static_for<256>([&](auto sc) {
+      sk_static_for<NM>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        constexpr int j = s >> 6, e = (s >> 4) & 3, tm = (s >> 2) & 3, tn = s & 3;
+        // s -> (k-group j, k-step e, row tile tm, column tile tn): tn fastest, then tm, then e, then j
+        constexpr int tn = s & 3, tm = (s >> 2) % TMW, e = (s / (4 * TMW)) & 3, j = s / (16 * TMW);
         const float av = AKR ? fa[j][e][tm] : fa[j][tm][e];
         const float bv = BKR ? fb[j][e][tn] : fb[j][tn][e];
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[tm][tn]) : "v"(av), "v"(bv));
@@ -229,25 +239,33 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
                        : "+v"(bsum.x), "+v"(bsum.y), "+v"(bsum.z), "+v"(bsum.w)
                        : "v"(fa[j][e].x), "v"(fa[j][e].y), "v"(fa[j][e].z), "v"(fa[j][e].w));
         }
-        if constexpr (s < 24) {                    // fragments of k-groups 1..3
-          constexpr int jj = 1 + s / 8, r = (s % 8) >> 1;
-          fread(jj, r, (s & 1) != 0);
+        // the schedule in the MFMAs' shadows (128-row tiles: the constants of the header comment; 64-row tiles: the same order, scaled)
+        constexpr int RPG = TMW + 4;                        // fragment reads per k-group: TMW of A, 4 of B
+        constexpr int NRD = 3 * RPG;                        // ... of k-groups 1..3 of this k-tile: at s = 0 .. NRD - 1
+        constexpr int BAR1 = TMW == 4 ? 53 : 30;            // every wave has its fragments: the LDS buffer may be overwritten
+        constexpr int PSTEP = TMW == 4 ? 11 : 7;            // one (write the next k-tile's piece, load the one after it) pair every PSTEP MFMAs
+        constexpr int BAR2 = NM - 13;                       // the next k-tile is in LDS
+        if constexpr (s < NRD) {                   // fragments of k-groups 1..3
+          constexpr int jj = 1 + s / RPG, gi = s % RPG;
+          // order within a group: A0 B0 A1 B1 .. then the remaining B tiles
+          if constexpr (gi < 2 * TMW) fread(jj, gi >> 1, (gi & 1) != 0);
+          else fread(jj, gi - TMW, true);
         }
-        if constexpr (s == 53) {                   // every wave has its fragments: the LDS buffer may be overwritten
+        if constexpr (s == BAR1) {
           __builtin_amdgcn_s_waitcnt(0xC07F);
           __builtin_amdgcn_s_barrier();
         }
-        if constexpr (s >= 54 && s <= 219 && (s - 54) % 11 == 0) {
-          constexpr int i = (s - 54) / 11;
+        if constexpr (s > BAR1 && s <= BAR1 + 1 + (NP - 1) * PSTEP && (s - BAR1 - 1) % PSTEP == 0) {
+          constexpr int i = (s - BAR1 - 1) / PSTEP;
           lwrite_one(i);                           // next k-tile: registers -> LDS
           gload_one(i, ld);                        // the one after it -> the same registers
         }
-        if constexpr (s == 243) {
+        if constexpr (s == BAR2) {
           __builtin_amdgcn_s_waitcnt(0xC07F);
           __builtin_amdgcn_s_barrier();
         }
-        if constexpr (s >= 244 && s < 252) {       // first k-group of the next k-tile, in the order its MFMAs want them
-          constexpr int o = s - 244;               // A0 B0 B1 B2 B3 A1 A2 A3
+        if constexpr (s > BAR2 && s <= BAR2 + RPG) {       // first k-group of the next k-tile, in the order its MFMAs want them
+          constexpr int o = s - BAR2 - 1;          // A0 B0 B1 B2 B3 A1 [A2 A3]
           if constexpr (o == 0) fread(0, 0, false);
           else if constexpr (o <= 4) fread(0, o - 1, true);
           else fread(0, o - 4, false);
@@ -269,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
         // 1. this part's accumulators -> its slot
         u64* slot = reinterpret_cast<u64*>(g.sk_slots + (size_t)(head ? 2u * rng + 1u : 2u * rng) * (SK_BM * SK_BN));
 #pragma unroll
-        for (int tm = 0; tm < 4; tm++)
+        for (int tm = 0; tm < TMW; tm++)
 #pragma unroll
           for (int tn = 0; tn < 4; tn++) {
             const f32x4 v = acc[tm][tn];
@@ -294,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
           for (unsigned p = head ? 1u : 0u; p < nparts; p++) {
             const u64* sl = reinterpret_cast<const u64*>(g.sk_slots + (size_t)(p == 0 ? 2u * r0 + 1u : 2u * (r0 + p)) * (SK_BM * SK_BN));
 #pragma unroll
-            for (int tm = 0; tm < 4; tm++)
+            for (int tm = 0; tm < TMW; tm++)
 #pragma unroll
               for (int tn = 0; tn < 4; tn++) {
                 const u64* q2 = sl + ((tm * 4 + tn) * 256 + tid) * 2;
@@ -333,24 +351,24 @@ __global__ __launch_bounds__(256, 1) void gemm_sk_kernel(const SkArgs g) {
         cvec = cd3.base == cd0.base + 3 && cd3.ld == cd0.ld && ((((uintptr_t)cd0.base) | (uintptr_t)(cd0.ld * 4)) & 15) == 0;
         if (!cvec) { cd1 = g.colmap[nn + 1]; cd2 = g.colmap[nn + 2]; }
       }
-      f32x4 mk[4][4], cold[4][4];
+      f32x4 mk[TMW][4], cold[TMW][4];
       f32x4 csum = f32x4{0.f, 0.f, 0.f, 0.f};     // DX_STORE with g.colsum: this lane's four columns summed over its 16 rows
       (void)csum;
       if constexpr (EPI == SK_EPI_DX_STORE || EPI == SK_EPI_DX_ADD) {
 #pragma unroll
-        for (int tm = 0; tm < 4; tm++)
+        for (int tm = 0; tm < TMW; tm++)
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            const int mm = (int)cp.m0 + 64 * wy + 16 * q + 4 * i + tm;
+            const int mm = (int)cp.m0 + 16 * TMW * wy + TMW * (4 * q + i) + tm;
             if (g.mask_bytes) mk[tm][i] = *reinterpret_cast<const f32x4*>(g.mask + (int64_t)mm * g.ldmask + nn);      // uniform
             if constexpr (EPI == SK_EPI_DX_ADD) cold[tm][i] = *reinterpret_cast<const f32x4*>(g.C + (int64_t)mm * g.ldc + nn);
           }
       }
 #pragma unroll
-      for (int tm = 0; tm < 4; tm++)
+      for (int tm = 0; tm < TMW; tm++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const int mm = (int)cp.m0 + 64 * wy + 16 * q + 4 * i + tm;
+          const int mm = (int)cp.m0 + 16 * TMW * wy + TMW * (4 * q + i) + tm;
           f32x4 v = f32x4{acc[tm][0][i], acc[tm][1][i], acc[tm][2][i], acc[tm][3][i]};
           float* cptr = g.C + (int64_t)mm * g.ldc + nn;
           if constexpr (EPI == SK_EPI_DW_ATOMIC) {
@@ -439,7 +457,7 @@ inline bool sk_aligned(const void* p, int64_t ld) { return (((uintptr_t)p & 15) 
 namespace ffh_gemm {
 
 namespace {
-struct SkPlan { int64_t lda, ldb, a_bytes, b_bytes; int G; bool split; };
+struct SkPlan { int64_t lda, ldb, a_bytes, b_bytes; int G; bool split; int tmw; };
 bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
   static const int off = FFH_LAB_INT("FFH_GEMM_NO_SK", 0);   // A/B switch (tools/ab.sh)
   if (off) return false;
@@ -455,7 +473,7 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
     const int64_t nw = form == SK_FORM_DW ? (int64_t)g.M * g.N : (int64_t)g.N * g.K;
     if (nw < min_w || (form != SK_FORM_FWD && nw < min_wb)) return false;
   }
-  if (g.M % SK_BM || g.N % SK_BN || g.K % SK_BK || g.M <= 0 || g.N <= 0 || g.K <= 0) return false;
+  if (g.M % SK_BM || g.N % SK_BN || g.K % SK_BK || g.M <= 0 || g.N <= 0 || g.K <= 0) return false;      // (64-row tiles: M a multiple of 128 as well -- every other layer has it)
   const bool akr = form == SK_FORM_DW, bkr = form != SK_FORM_FWD;
   p.lda = akr ? g.sAk : g.sAm; p.ldb = bkr ? g.sBk : g.sBn;
   if ((akr ? g.sAm : g.sAk) != 1 || (bkr ? g.sBn : g.sBk) != 1) return false;
@@ -472,6 +490,7 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
   if (p.G < 8) return false;
   const int64_t ntiles = (int64_t)(g.M / SK_BM) * (g.N / SK_BN), nk = g.K / SK_BK;
   if (ntiles * nk >= (1LL << 31)) return false;
+  p.tmw = 4;
   if (form == SK_FORM_DW) {
     if (c->deterministic || g.epi != EPI_ATOMIC) return false;     // its partial tiles meet by atomics
     static const int dw_min_it = FFH_LAB_INT("FFH_SK_DW_MIN_IT", 8);       // A/B switch
@@ -484,6 +503,14 @@ bool sk_plan(const ffh_ctx* c, const GemmArgs& g, int form, SkPlan& p) {
     static const int no_split = FFH_LAB_INT("FFH_SK_NO_SPLIT", 0);     // A/B switch (tools/ab.sh)
     const int64_t rounds = (ntiles + p.G - 1) / p.G;
     const int64_t idle_it = (rounds * p.G - ntiles) * nk / p.G;      // k-tile iterations per workgroup the last round wastes
+    // less than one round of 128-row tiles, one (nearly) full round of 64-row tiles: those, whole, with the full reduction each
+    // (1024 -> 512 forward at 4096 samples: 128 tiles / 256)
+    static const int no_t64 = FFH_LAB_INT("FFH_SK_NO_T64", 0);        // A/B switch
+    p.tmw = 4;
+    if (!no_t64 && ntiles < p.G && g.M % 64 == 0 && (g.epi == EPI_STORE || g.epi == EPI_ADD) && nk >= 8) {
+      const int64_t nt64 = (int64_t)(g.M / 64) * (g.N / SK_BN);
+      if (nt64 <= p.G && nt64 * 100 >= (int64_t)p.G * 80) { p.tmw = 2; p.split = false; return true; }
+    }
     p.split = !no_split && idle_it >= 2 && ntiles * nk >= 8LL * p.G && g.epi == EPI_STORE;    // (four k-tiles per workgroup: 8192 x 512 -> 256 forward 33.3 us split, 27.8 on the LDS-DMA kernel)
     if (!p.split) {
       if (ntiles < p.G) return false;
@@ -538,7 +565,12 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
     hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(256), LDSB, as_stream(s), a);                               \
   }
   constexpr int BCW = 64;      // SPLIT: the arrival broadcast word behind the operand images
-  if (form == SK_FORM_FWD && p.split) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC + BCW, false, true)
+  constexpr int KC64 = sk_lds_kc_a(2);
+  if (form == SK_FORM_FWD && p.tmw == 2) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, KC64 + SK_LDS_KC, false, false, 2)
+  else if (form == SK_FORM_DX && p.tmw == 2 && g.colmap) FFH_SK_LAUNCH(false, true, SK_EPI_DX_CMAP, KC64 + SK_LDS_KR, false, false, 2)
+  else if (form == SK_FORM_DX && p.tmw == 2 && g.epi == EPI_STORE) FFH_SK_LAUNCH(false, true, SK_EPI_DX_STORE, KC64 + SK_LDS_KR, false, false, 2)
+  else if (form == SK_FORM_DX && p.tmw == 2) FFH_SK_LAUNCH(false, true, SK_EPI_DX_ADD, KC64 + SK_LDS_KR, false, false, 2)
+  else if (form == SK_FORM_FWD && p.split) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC + BCW, false, true)
   else if (form == SK_FORM_DX && p.split && g.colmap) FFH_SK_LAUNCH(false, true, SK_EPI_DX_CMAP, SK_LDS_KC + SK_LDS_KR + BCW, false, true)
   else if (form == SK_FORM_DX && p.split) FFH_SK_LAUNCH(false, true, SK_EPI_DX_STORE, SK_LDS_KC + SK_LDS_KR + BCW, false, true)
   else if (form == SK_FORM_FWD) FFH_SK_LAUNCH(false, false, SK_EPI_FWD, 2 * SK_LDS_KC)
@@ -555,7 +587,7 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
     if (e == hipErrorInvalidValue || e == hipErrorInvalidConfiguration || e == hipErrorLaunchOutOfResources || e == hipErrorSharedObjectInitFailed) return 0;
     if (e != hipSuccess) return ffh_fail_hip(c, e, name);
   }
-  { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_128x128x64%s%s%s|wgs=%d", name, g.colmap ? "|colmap" : "", p.split ? "|streamk" : "", a.colsum ? "|colsum" : "", G); ffh_route_add(c, tok); }
+  { char tok[96]; snprintf(tok, sizeof tok, "%s|sk_%dx128x64%s%s%s|wgs=%d", name, 32 * p.tmw, g.colmap ? "|colmap" : "", p.split ? "|streamk" : "", a.colsum ? "|colsum" : "", G); ffh_route_add(c, tok); }
   return 1;
 }
 

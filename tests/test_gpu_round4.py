@@ -451,11 +451,12 @@ def _close(got, exp, mass, what, tol=1e-5):
 @pytest.mark.timeout(1200)
 @pytest.mark.parametrize("B,IN,OUT,expect", [
     (4096, 3456, 1024, {"dx": "streamk"}),        # 864 data-gradient tiles on 256 workgroups: 3.4 rounds
-    (4096, 1024, 512, {"fwd": "streamk"}),        # 128 forward tiles: half a round
+    (4096, 1024, 512, {"fwd": "t64"}),            # 128 forward tiles of 128 rows = 256 of 64 rows, one per workgroup with the whole reduction (round 5; round 4: stream-K)
     (4096, 1024, 1024, {}),                       # 256 tiles: whole tiles, one per workgroup
-    (8192, 512, 256, {}),                         # MLPerf batch: 128 tiles of 8 k-tiles = 4 per workgroup: too few for the fix-up form, not split
-    (8192, 1024, 256, {"fwd": "streamk"}),        # 128 tiles of 16 k-tiles
-    (2560, 1280, 768, {"fwd": "streamk", "dx": "streamk"}),   # 120 / 200 tiles of 20 / 12 k-tiles: ranges that end mid-tile everywhere, a short last range
+    (8192, 512, 256, {"fwd": "t64"}),             # MLPerf batch: 128 tiles of 8 k-tiles -> 256 of 64 rows
+    (8192, 1024, 256, {"fwd": "t64"}),            # 128 tiles of 16 k-tiles -> 256 of 64 rows
+    (4096, 1024, 1280, {"fwd": "streamk"}),       # 320 forward tiles: 1.25 rounds -> stream-K with fix-up
+    (2560, 1280, 768, {"fwd": "t64", "dx": "streamk"}),   # forward: 120 tiles -> 240 of 64 rows; data gradient 200 tiles of 12 k-tiles: ranges that end mid-tile everywhere, a short last range
 ])
 def test_linear_layers_at_the_per_rank_batch_vs_oracle_with_routes(hip, oracle, B, IN, OUT, expect):
     """Forward, plain backward and the model's backward form (premasked dy, relu'-by-x mask, stored dX, forked dW) of the layers of
@@ -502,8 +503,10 @@ def test_linear_layers_at_the_per_rank_batch_vs_oracle_with_routes(hip, oracle, 
     _close(dx.cpu().numpy(), dx_e, m_dx, f"{IN}->{OUT} dx (plain)")
     print(f"routes {IN}->{OUT} @{B}:", routes)
     tok = lambda r, which: [t for t in r.split(";") if which in t.split("|")[0]]
-    if "fwd" in expect:
+    if expect.get("fwd") == "streamk":
         assert "streamk" in routes["fwd"] and "|sk_128x128x64" in routes["fwd"], routes
+    elif expect.get("fwd") == "t64":
+        assert "|sk_64x128x64" in routes["fwd"] and "streamk" not in routes["fwd"], routes
     else:
         assert "streamk" not in routes["fwd"], routes
     dx_tok = tok(routes["bwd_ex"], "dx")

@@ -182,15 +182,16 @@ def _mk_stream(hip):
 
 @pytest.mark.timeout(900)
 def test_stream_k_fixup_beside_other_persistent_kernels_is_bit_reproducible(hip, oracle):
-    """The SPLIT form of the persistent GEMM (forward of 1024 -> 512 and data gradient of 3456 -> 1024 at 4096 samples) launched on two
+    """The SPLIT form of the persistent GEMM (forward of 1024 -> 1280 -- 320 tiles, 1.25 rounds -- and data gradient of 3456 -> 1024 at 4096 samples) launched on two
     streams at once, beside a persistent weight-gradient GEMM on a third: no part of a tile waits for another (the part that arrives
     last adds them up), so nothing can hang whatever is resident; the parts are added in k order whoever is last, so every launch on
     every stream leaves the same bits -- also in deterministic mode, which now takes this form -- and they match the oracle."""
     B = 4096
     rng = np.random.default_rng(5)
     dev = lambda a: torch.from_numpy(a).to(DEV)
-    x1 = np.maximum(rng.uniform(-1, 1, (B, 1024)), 0).astype(np.float32); w1 = (rng.uniform(-1, 1, (512, 1024)) / 32).astype(np.float32)
-    b1 = rng.uniform(-1, 1, 512).astype(np.float32)
+    N1 = 1280
+    x1 = np.maximum(rng.uniform(-1, 1, (B, 1024)), 0).astype(np.float32); w1 = (rng.uniform(-1, 1, (N1, 1024)) / 32).astype(np.float32)
+    b1 = rng.uniform(-1, 1, N1).astype(np.float32)
     dy2 = (rng.uniform(-1, 1, (B, 1024)) / B).astype(np.float32); w2 = (rng.uniform(-1, 1, (1024, 3456)) / 59).astype(np.float32)
     y_e = oracle.linear_fwd(x1, w1, b1, RELU)
     m_y = np.abs(x1).astype(np.float64) @ np.abs(w1).astype(np.float64).T + np.abs(b1)
@@ -209,14 +210,14 @@ def test_stream_k_fixup_beside_other_persistent_kernels_is_bit_reproducible(hip,
         for det in (0, 1):
             hip.check(hip.lib.ffh_ctx_set_deterministic(hip.ctx, det), "deterministic")
             for rep in range(6):
-                ys = [torch.full((B, 512), 3.0, device=DEV) for _ in range(2)]
+                ys = [torch.full((B, N1), 3.0, device=DEV) for _ in range(2)]
                 dxs = [torch.full((B, 3456), 3.0, device=DEV) for _ in range(2)]
                 torch.cuda.synchronize()
                 if not det:
                     hip.call("ffh_linear_bwd_ex", xn, 1024, None, 1024, yn, 1024, dyn, 1024, wn, dwn, None, 1024, 1024, Bn, NONE,
                              capi.LINEAR_ONLY_DW | capi.LINEAR_DY_PREMASKED, s[2].value, None)
                 for k in range(2):
-                    hip.call("ffh_linear_fwd", x1d, 1024, ys[k], 512, w1d, b1d, 1024, 512, B, RELU, s[k].value)
+                    hip.call("ffh_linear_fwd", x1d, 1024, ys[k], N1, w1d, b1d, 1024, N1, B, RELU, s[k].value)
                     r_f = _route(hip)
                     hip.call("ffh_linear_bwd_ex", x2, 3456, dxs[k], 3456, y2, 1024, dy2d, 1024, w2d, dw2, None, 3456, 1024, B, NONE, flags_dx, s[k].value, None)
                     r_x = _route(hip)
@@ -226,7 +227,7 @@ def test_stream_k_fixup_beside_other_persistent_kernels_is_bit_reproducible(hip,
                 for k in range(2):
                     yk, dxk = ys[k].cpu().numpy(), dxs[k].cpu().numpy()
                     if not first:
-                        _close(yk, y_e, m_y, "1024->512 forward (stream-K)")
+                        _close(yk, y_e, m_y, "1024->1280 forward (stream-K)")
                         _close(dxk, dx_e, m_dx, "3456->1024 dX (stream-K)")
                         first["y"], first["dx"] = yk, dxk
                     assert yk.tobytes() == first["y"].tobytes(), f"forward differs (deterministic={det}, launch {rep}, stream {k})"
@@ -243,15 +244,51 @@ def test_scratch_is_reserved_explicitly_and_leaves_with_its_stream(hip):
     FFH_MAX_SCRATCH_STREAMS streams over its life."""
     import ctypes
     B = 4096
-    x = torch.rand(B, 1024, device=DEV); w = torch.rand(512, 1024, device=DEV); y = torch.zeros(B, 512, device=DEV)
+    x = torch.rand(B, 1024, device=DEV); w = torch.rand(1280, 1024, device=DEV); y = torch.zeros(B, 1280, device=DEV)
     for i in range(12):
         s = ctypes.c_void_p()
         hip.check(hip.lib.ffh_stream_create(hip.ctx, ctypes.byref(s)), "stream")
-        hip.call("ffh_linear_fwd", x, 1024, y, 512, w, None, 1024, 512, B, RELU, s.value)
+        hip.call("ffh_linear_fwd", x, 1024, y, 1280, w, None, 1024, 1280, B, RELU, s.value)
         assert "streamk" not in _route(hip), _route(hip)
         hip.check(hip.lib.ffh_ctx_reserve_scratch(hip.ctx, s), "scratch")
         hip.check(hip.lib.ffh_ctx_reserve_scratch(hip.ctx, s), "scratch (again)")
-        hip.call("ffh_linear_fwd", x, 1024, y, 512, w, None, 1024, 512, B, RELU, s.value)
+        hip.call("ffh_linear_fwd", x, 1024, y, 1280, w, None, 1024, 1280, B, RELU, s.value)
         assert "streamk" in _route(hip), _route(hip)
         hip.check(hip.lib.ffh_stream_sync(hip.ctx, s), "sync")
         hip.check(hip.lib.ffh_stream_destroy(hip.ctx, s), "destroy")
+
+
+@pytest.mark.parametrize("B,IN,OUT", [(4096, 1024, 512), (8192, 512, 256), (2560, 1280, 768)])
+def test_64_row_tiles_of_the_persistent_gemm_vs_oracle(hip, oracle, B, IN, OUT):
+    """Round 5: layers whose 128-row output tiles are fewer than the CUs run the persistent kernel on 64 x 128 tiles (one per CU, whole
+    reduction, no fix-up): forward (bias + ReLU) and the data-gradient forms (stored with the relu'-by-x mask / accumulated) against
+    the oracle at 1e-5 of the term mass, route asserted."""
+    rng = np.random.default_rng(IN + OUT + B)
+    x = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    xd, wd, bd = (torch.from_numpy(a).to(DEV) for a in (x, w, b))
+    y_e = oracle.linear_fwd(x, w, b, RELU)
+    y = torch.full((B, OUT), 3.0, device=DEV)
+    for rep in range(2):
+        hip.call("ffh_linear_fwd", xd, IN, y, OUT, wd, bd, IN, OUT, B, RELU, None)
+    assert "|sk_64x128x64" in _route(hip), _route(hip)
+    _close(y.cpu().numpy(), y_e, np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T + np.abs(b), f"{IN}->{OUT} forward on 64-row tiles")
+    # data gradient of the TRANSPOSED shape (dy [B][IN'] w [IN'][OUT'] -> dx [B][OUT']) so that dx has the few-tiles shape: the layer OUT -> IN
+    dy = (rng.uniform(-1, 1, (B, IN)) / B).astype(np.float32)            # gradient of a layer with in = OUT, out = IN
+    w2 = (rng.uniform(-1, 1, (IN, OUT)) / np.sqrt(IN)).astype(np.float32)
+    x2 = np.maximum(rng.uniform(-1, 1, (B, OUT)), 0).astype(np.float32)
+    y2 = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)
+    m_dx = np.abs(dy).astype(np.float64) @ np.abs(w2).astype(np.float64)
+    for flags, start in ((capi.LINEAR_ONLY_DX | capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DX_MASK_BY_X | capi.LINEAR_DY_PREMASKED, None),
+                         (capi.LINEAR_ONLY_DX | capi.LINEAR_DY_PREMASKED, rng.uniform(-1, 1, (B, OUT)).astype(np.float32))):
+        dx_e, _, _, _ = oracle.linear_bwd_ex(x2, y2, dy, w2, NONE, flags, dx0=start)
+        dx = torch.from_numpy(start).to(DEV) if start is not None else torch.full((B, OUT), 9.0, device=DEV)
+        dw = torch.zeros(IN, OUT, device=DEV)
+        hip.call("ffh_linear_bwd_ex", torch.from_numpy(x2).to(DEV), OUT, dx, OUT, torch.from_numpy(y2).to(DEV), IN, torch.from_numpy(dy).to(DEV), IN,
+                 torch.from_numpy(w2).to(DEV), dw, None, OUT, IN, B, NONE, flags, None, None)
+        r = _route(hip)
+        _close(dx.cpu().numpy(), dx_e, m_dx + (np.abs(start) if start is not None else 0), f"{IN}->{OUT} dX on 64-row tiles (flags {flags})")
+        print("route", r)
+        if OUT >= 256 or True:
+            assert "|sk_64x128x64" in r, r
