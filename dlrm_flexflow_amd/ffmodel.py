@@ -100,7 +100,7 @@ def lib() -> C.CDLL:
         "flexflow_model_get_label_tensor": (H, [H]), "flexflow_model_get_num_layers": (I, [H]),
         "flexflow_model_get_layer_name": (C.c_char_p, [H, I]), "flexflow_model_get_layer_num_weights": (I, [H, I]),
         "flexflow_model_get_parameter": (H, [H, I, I]), "flexflow_model_get_layer_output": (H, [H, I]),
-        "flexflow_model_get_stream": (P, [H]), "flexflow_model_uses_graph": (I, [H]),
+        "flexflow_model_get_stream": (P, [H]), "flexflow_model_uses_graph": (I, [H]), "flexflow_model_set_trace_mode": (None, [H, I]), "flexflow_model_trace_replays": (I, [H, I]),
         "flexflow_model_get_counter": (C.c_int64, [H, C.c_char_p]),
         "flexflow_tensor_get_num_dims": (I, [H]), "flexflow_tensor_get_dims": (None, [H, IP]),
         "flexflow_tensor_get_local_rows": (C.c_int64, [H]), "flexflow_tensor_is_local": (B, [H]),
@@ -317,6 +317,8 @@ class FFModel:
     def stream(self) -> int: return lib().flexflow_model_get_stream(self.h) or 0
     @property
     def uses_graph(self) -> bool: return bool(lib().flexflow_model_uses_graph(self.h))
+    def set_trace_mode(self, mode: int): lib().flexflow_model_set_trace_mode(self.h, int(mode))
+    def trace_replays(self, trace_id: int = 111) -> bool: return bool(lib().flexflow_model_trace_replays(self.h, trace_id))
     def counter(self, name: str) -> int: return int(lib().flexflow_model_get_counter(self.h, name.encode()))
 
     def perf_metrics(self) -> PerfMetrics:

@@ -384,6 +384,7 @@ void DLRMApp::train_steps(int n, bool trace) {
 
 double DLRMApp::run_epochs() {
   if (!warmed_up) warmup();
+  if (ff->config.trace_mode < 0) ff->config.trace_mode = 0;     // the driver's loop: a step is replayed only where the replay is not slower (FFConfig::trace_mode)
   const bool chatty = ff->rank == 0;
   ff->sync();   // issue_execution_fence + timing measurement
   if (ffconfig.comm.world_size > 1 && ffconfig.comm.barrier) ffconfig.comm.barrier(ffconfig.comm.user);

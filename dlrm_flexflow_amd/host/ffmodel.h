@@ -127,6 +127,11 @@ class FFConfig {
   int64_t big_dw_min_weights;  // ... only a layer with at least this many weights is cut (--big-dw-min-weights N; default 2 Mi)
   int  big_dw_chunks;          // with bucketed all-reduce: the biggest layer's weight-gradient GEMM as this many launches over row blocks of dW, a bucket behind each (its
                                // gradients are two thirds of the bytes and the last to be complete: --big-dw-chunks N; 0 / 1 = not cut, the default: see allocate step 5b)
+  int  trace_mode;             // begin_trace / end_trace: 1 = every traced step is replayed from its hipGraph, as the reference traces every iteration
+                               // [ref: examples/cpp/DLRM/dlrm.cc:174-181] (--always-replay); 0 = replayed only where that is not slower than launching it,
+                               // measured on the trace's first calls, one GPU (--adaptive-replay): on this runtime the replay of a two-stream step costs a
+                               // small model more than its launches (Kaggle shape: 210 vs 170 us).  -1 = not given: the FFModel API replays (1), the DLRM
+                               // driver's timed loop adapts (0)
   bool mlp_chain;              // a run of narrow Linear layers (every width <= 512) as one launch forward, two backward (ffh_mlp_chain_fwd / _bwd; A/B: --no-mlp-chain)
   int64_t mlp_chain_max_batch; // ... for at most this many samples per GPU (--mlp-chain-max-batch N)
   int64_t mlp_chain_fwd_min_batch;   // the forward chain from this many samples per GPU up (below, the per-layer kernels win: --mlp-chain-fwd-min-batch N)
@@ -625,6 +630,10 @@ class FFModel {
   // trace / graph
   std::map<int, ffh_graph> graphs;
   int capturing_trace, replaying_trace;
+  struct TraceTune { int calls = 0; int decided = 0; ffh_event ev[4] = {nullptr, nullptr, nullptr, nullptr}; float eager_ms = 0.f, graph_ms = 0.f; };   // decided: 0 not yet, 1 replay, 2 eager
+  std::map<int, TraceTune> trace_tune;
+  bool trace_adaptive() const { return config.trace_mode == 0 && !exchange; }      // (-1 counts as 1 here; DLRMApp::run_epochs turns -1 into 0)
+  bool trace_replays(int trace_id) const;      // this trace's steps are (or will be) replayed
   mutable bool inputs_dirty;    // an input tensor was written on `stream` since the last forward(): the side-stream gather must be ordered behind it
   mutable bool fork_recorded;   // this forward() recorded ev_fork
 

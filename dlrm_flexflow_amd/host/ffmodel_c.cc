@@ -118,6 +118,8 @@ flexflow_tensor_t flexflow_model_get_parameter(flexflow_model_t m, int l, int i)
 flexflow_tensor_t flexflow_model_get_layer_output(flexflow_model_t m, int l) { return wrap(M(m)->layers.at(l)->outputs[0]); }
 void* flexflow_model_get_stream(flexflow_model_t m) { return M(m)->stream; }
 int flexflow_model_uses_graph(flexflow_model_t m) { return M(m)->config.enable_graph ? 1 : 0; }
+void flexflow_model_set_trace_mode(flexflow_model_t m, int mode) { M(m)->config.trace_mode = mode; }
+int flexflow_model_trace_replays(flexflow_model_t m, int trace_id) { return M(m)->trace_replays(trace_id) ? 1 : 0; }
 int64_t flexflow_model_get_counter(flexflow_model_t m, const char* name) {
   const std::string n(name ? name : "");
   if (n == "mlp_chain_fwd_calls") return M(m)->n_chain_fwd_calls;

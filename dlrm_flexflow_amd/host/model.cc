@@ -133,6 +133,7 @@ FFConfig::FFConfig() {
   attach_events = true;
   fuse_pair = true;
   mlp_chain = true;
+  trace_mode = -1;
   bucket_allreduce = -1;
   allreduce_bucket_floats = 1 << 20;
   big_dw_chunks = 0;
@@ -221,6 +222,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-attach-event")) { attach_events = false; continue; }
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-mlp-chain")) { mlp_chain = false; continue; }
+    if (is("--always-replay")) { trace_mode = 1; continue; }
+    if (is("--adaptive-replay")) { trace_mode = 0; continue; }
     if (is("--bucket-allreduce")) { bucket_allreduce = 1; continue; }
     if (is("--no-bucket-allreduce")) { bucket_allreduce = 0; continue; }
     if (is("--allreduce-bucket-floats")) { allreduce_bucket_floats = atoll(next()); continue; }
@@ -2851,8 +2854,32 @@ void FFModel::update() {
   }
 }
 
+bool FFModel::trace_replays(int trace_id) const {
+  if (!config.enable_graph) return false;
+  auto it = trace_tune.find(trace_id);
+  return !(trace_adaptive() && it != trace_tune.end() && it->second.decided == 2);
+}
+
+// Adaptive replay (FFConfig::trace_mode 0, one GPU): calls 0-2 of a trace run eagerly with an event behind each, call 3 captures,
+// calls 4-6 replay with an event behind each; the seventh call compares the spacing of the events (steps 1-2 against replays 5-6:
+// what a step takes end to end, host gaps included) and keeps the faster form for good.
 void FFModel::begin_trace(int trace_id) {
   if (!config.enable_graph) return;
+  if (trace_adaptive()) {
+    TraceTune& t = trace_tune[trace_id];
+    if (t.decided == 2 || (t.decided == 0 && t.calls < 3)) return;      // an eager step
+    if (t.decided == 0 && t.calls == 7) {
+      check(api->ffh_event_sync(ctx, t.ev[3]), "trace timing");
+      check(api->ffh_event_elapsed_ms(ctx, t.ev[0], t.ev[1], &t.eager_ms), "trace timing");
+      check(api->ffh_event_elapsed_ms(ctx, t.ev[2], t.ev[3], &t.graph_ms), "trace timing");
+      t.decided = t.graph_ms <= 1.02f * t.eager_ms ? 1 : 2;
+      for (ffh_event& e : t.ev) { api->ffh_event_destroy(ctx, e); e = nullptr; }
+      if (config.profiling || getenv("FFM_TRACE_VERBOSE"))
+        fprintf(stderr, "[DLRM] trace %d: eager %.1f us / step, hipGraph replay %.1f us / step -> %s\n", trace_id, t.eager_ms * 500.f, t.graph_ms * 500.f,
+                t.decided == 1 ? "replay" : "eager");
+      if (t.decided == 2) return;
+    }
+  }
   refresh_weight_twin();                  // ahead of the capture / the replay, on `stream`
   auto it = graphs.find(trace_id);
   if (it != graphs.end()) { replaying_trace = trace_id; return; }
@@ -2866,6 +2893,36 @@ void FFModel::begin_trace(int trace_id) {
 
 void FFModel::end_trace(int trace_id) {
   if (!config.enable_graph) return;
+  TraceTune* tune = nullptr;
+  if (trace_adaptive()) {
+    TraceTune& t = trace_tune[trace_id];
+    if (t.decided == 2) return;
+    if (t.decided == 0) {
+      auto mark = [&](int k) {
+        if (!t.ev[k]) check(api->ffh_event_create(ctx, &t.ev[k]), "event create");
+        check(api->ffh_event_record(ctx, t.ev[k], stream), "trace timing");
+      };
+      if (t.calls < 3) {               // the eager steps: events behind the first and the third
+        if (t.calls == 0) mark(0);
+        if (t.calls == 2) mark(1);
+        t.calls++;
+        return;
+      }
+      tune = &t;
+    }
+  }
+  struct TuneMark {                    // behind the graph launch below (calls 4 and 6: two replays apart)
+    FFModel* ff; TraceTune* t;
+    ~TuneMark() {
+      if (!t) return;
+      const int k = t->calls == 4 ? 2 : (t->calls == 6 ? 3 : -1);
+      if (k >= 0) {
+        if (!t->ev[k]) ff->check(ff->api->ffh_event_create(ff->ctx, &t->ev[k]), "event create");
+        ff->check(ff->api->ffh_event_record(ff->ctx, t->ev[k], ff->stream), "trace timing");
+      }
+      t->calls++;
+    }
+  } tune_mark{this, tune};
   if (capturing_trace == trace_id) {
     ffh_graph g = nullptr;
     check(api->ffh_graph_end_capture(ctx, stream, &g), "end_trace");

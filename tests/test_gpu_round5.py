@@ -292,3 +292,34 @@ def test_64_row_tiles_of_the_persistent_gemm_vs_oracle(hip, oracle, B, IN, OUT):
         print("route", r)
         if OUT >= 256 or True:
             assert "|sk_64x128x64" in r, r
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def test_driver_replays_a_trace_only_where_the_replay_is_not_slower():
+    """The DLRM driver traces every iteration like the reference [ref: examples/cpp/DLRM/dlrm.cc:174-181]; on this runtime the replay of
+    a small two-stream step costs more than launching it (Kaggle shape, round 4: 231 vs 186 us).  Its timed loop therefore measures both
+    forms on the trace's first calls and keeps the faster one (FFConfig::trace_mode 0): the decision matches its own measurement, and
+    the throughput is not below the better of --always-replay / --no-trace by more than the noise of a short run."""
+    import os
+    import re
+    import subprocess
+    import dlrm_helpers as H
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "dlrm_flexflow_amd", "host", "dlrm")
+    args = ["-ll:gpu", "1"] + H.KAGGLE_ARGS(2048) + ["--data-size", str(2048 * 50), "--epochs", "6"]
+
+    def run(extra):
+        r = subprocess.run([exe] + args + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ, FFM_TRACE_VERBOSE="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        thr = float(re.search(r"THROUGHPUT = ([0-9.]+)", r.stdout).group(1))
+        return thr, r.stderr
+
+    thr_auto, err = run([])
+    m = re.search(r"trace 111: eager ([0-9.]+) us / step, hipGraph replay ([0-9.]+) us / step -> (\w+)", err)
+    assert m, err[-1500:]
+    eager_us, graph_us, pick = float(m.group(1)), float(m.group(2)), m.group(3)
+    assert pick == ("replay" if graph_us <= 1.02 * eager_us else "eager"), m.group(0)
+    thr_replay, _ = run(["--always-replay"])
+    thr_eager, _ = run(["--no-trace"])
+    print(f"adaptive {thr_auto:.0f} samples/s ({m.group(0)}); always replay {thr_replay:.0f}; eager {thr_eager:.0f}")
+    assert thr_auto >= 0.93 * max(thr_replay, thr_eager), (thr_auto, thr_replay, thr_eager)
