@@ -135,6 +135,7 @@ _SIGS = {
     "ffh_embedding_bwd_workspace_bytes": (SZ, [I, I, I, L]),
     "ffh_embedding_localize_rows": (I, [P, P, P, L, L, L, P]),
     "ffh_linear_fwd": (I, [P, P, L, P, L, P, P, I, I, L, I, P]),
+    "ffh_linear_fast_in_dim": (I, [I, I]),
     "ffh_linear_bwd": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, P]),
     "ffh_linear_bwd_ex": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, P]),
     "ffh_linear_bwd_mse": (I, [P, P, L, P, L, P, L, P, L, P, P, P, I, I, L, I, I, P, F, P, I, P]),

@@ -1594,6 +1594,13 @@ bool act_ok_fwd(int act) { return act_ok(act) || act == FFH_AC_MODE_GELU; }
 
 extern "C" {
 
+// the reduction depth a caller pads x / w to so that the layer meets the persistent kernels' contract (include/ff_hip.h)
+int ffh_linear_fast_in_dim(int in, int out) {
+  if (in <= 0 || out <= 0) return in;
+  if (in % 64 == 0 || in < 256 || out % 128 != 0) return in;
+  return (in + 63) / 64 * 64;
+}
+
 int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ldy, const float* w, const float* bias,
                    int in, int out, int64_t batch, int act, ffh_stream s) {
   FFH_REQUIRE(c, in > 0 && out > 0 && batch >= 0 && ldx >= in && ldy >= out, "linear_fwd: bad dims");

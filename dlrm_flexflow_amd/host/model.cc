@@ -1659,11 +1659,12 @@ void FFModel::allocate() {
     if (!li) continue;
     li->in_padded = li->in_channels;
     const Tensor& x = li->inputs[0];
-    if (!config.pad_linear_k || li->in_channels % 64 == 0 || li->in_channels < 256 || li->out_channels % 128 != 0) continue;
+    const int fast_in = api->ffh_linear_fast_in_dim(li->in_channels, li->out_channels);      // the library's own padding rule (fast-path contract, ff_hip.h)
+    if (!config.pad_linear_k || fast_in == li->in_channels) continue;
     if (!x.owner_op || consumers[x.impl] != 1 || alias_of.count(x.impl) || !x.impl->pieces.empty()) continue;
     if (x.owner_op->op_type != OP_DOT_INTERACTION && x.owner_op->op_type != OP_LINEAR) continue;
     if (x.numDim != 2) continue;
-    li->in_padded = (li->in_channels + 63) / 64 * 64;
+    li->in_padded = fast_in;
     padded_ld[x.impl] = li->in_padded;
   }
   auto cols_of = [&](const Tensor& o) -> int64_t { auto it = padded_ld.find(o.impl); return it == padded_ld.end() ? (int64_t)o.adim[0] : it->second; };

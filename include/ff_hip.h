@@ -354,6 +354,16 @@ int ffh_embedding_localize_rows(ffh_ctx* ctx, const int64_t* idx, int64_t* local
 int ffh_linear_fwd(ffh_ctx* ctx, const float* x, int64_t ldx, float* y, int64_t ldy,
                    const float* w, const float* bias,
                    int in_dim, int out_dim, int64_t batch, int activation, ffh_stream s);
+/* FAST-PATH CONTRACT of ffh_linear_fwd / ffh_linear_bwd* (every shape is served; this is what the persistent MFMA kernels of
+ * csrc/linear_sk.hip take -- 140-150 TFLOP/s against 75-100 on the general kernels): in_dim % 64 == 0, out_dim % 128 == 0, batch %
+ * 128 == 0, every operand row 16-byte aligned (pointers and leading dimensions multiples of 4 floats).  A layer whose in_dim breaks
+ * the first rule (MLPerf-DLRM's 479-wide first top layer: rows start at odd dwords, K is not whole k-tiles) reaches it by ZERO
+ * PADDING THE REDUCTION DEPTH in its caller's allocation: x [batch][ld = P] and w [out][ld = P] with P = ffh_linear_fast_in_dim(in_dim,
+ * out_dim), columns in_dim .. P - 1 zero, and in_dim = P in the calls.  Same values: the pads add exact zeros at the end of every k
+ * sum; dw's pad columns are dy^T * 0 = 0, so zero-initialised pads stay zero under SGD / momentum / weight decay / Adam; dx's pad columns
+ * are dy * 0 and nobody reads them.  The bundled shim does exactly this (FFModel::allocate step 4a; 8192 x 479 -> 1024: 99.6 / 74.9 / 75.2
+ * TFLOP/s unpadded, 123 / 130 / 111 padded).  Returns in_dim itself where padding does not pay (narrow layers, already a multiple). */
+int ffh_linear_fast_in_dim(int in_dim, int out_dim);
 /* Which kernel families the most recent ffh_linear_* call on this ctx launched: ';'-separated tokens "<gemm>:<family>[:detail]"
  * with <gemm> in {fwd, dx, dw, bwd} (e.g. "dx:f32_128x128x16;dw:glds_64x64:splitk=8").  Diagnostic (no reference
  * counterpart): lets a test assert that a shape really took the route it is meant to cover.  The oracle returns "oracle". */
@@ -635,7 +645,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) X(ffh_embedding_bwd_sort_multi) X(ffh_embedding_bwd_sgd_apply_multi) X(ffh_embedding_bwd_opt_fused_multi) X(ffh_embedding_bwd_opt_apply_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_mlp_chain_fwd) X(ffh_mlp_chain_bwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_linear_bwd_set_dx_colsum) X(ffh_linear_dx_colsum_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_fast_in_dim) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_mlp_chain_fwd) X(ffh_mlp_chain_bwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_linear_bwd_set_dx_colsum) X(ffh_linear_dx_colsum_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

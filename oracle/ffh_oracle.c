@@ -451,6 +451,13 @@ static float act_fwd(float v, int act) {
   return v;
 }
 
+/* the padding rule of the fast-path contract (include/ff_hip.h): the same answer as the product library */
+int ffh_linear_fast_in_dim(int in, int out) {
+  if (in <= 0 || out <= 0) return in;
+  if (in % 64 == 0 || in < 256 || out % 128 != 0) return in;
+  return (in + 63) / 64 * 64;
+}
+
 /* Linear::forward_kernel [ref: src/ops/linear.cu:436-453]:
  *   cublasSgemm(T,N, out,B,in): Y = W^T-view * X, beta 0      -> y[b][o] = sum_i x[b][i] w[o][i]
  *   cublasSgemm(T,N, out,B,1) with the ones vector, beta 1    -> y[b][o] += bias[o]

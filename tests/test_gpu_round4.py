@@ -289,21 +289,29 @@ def _weights(m):
     return out
 
 
-def _delta_check(name, dh, dc, tol_mass, tol_ulp, worst):
-    """|delta_hip - delta_cpu| <= 1e-5 of the update's term mass (+ the rounding of w itself) on at least 99.9 % of a tensor's
-    elements, and within 5e-2 of the mass everywhere.  The second tier is for the ReLU's discontinuity, not for the kernels: a
-    sample whose pre-activation lies within one rounding error of zero gets its relu' mask 1 from one backend and 0 from the other,
-    which adds or drops ONE whole term of that output's weight-gradient row (1/16,000 of the row's mass at this batch: 6e-5) and one
-    whole term of the 1024-term sums behind a table row's gradient (1e-3) -- a few samples per layer and step (density of
-    pre-activations at zero x 1e-7 x 8 M elements)."""
+def _delta_check(name, dh, dc, tol_mass, tol_ulp, worst, explained=None, extra_tol=0.0):
+    """|delta_hip - delta_cpu| <= 1e-5 of the update's term mass (+ the rounding of w itself).  An element beyond that bound must be
+    EXPLAINED by the ReLU's discontinuity, element by element (round 5; round 4 only bounded how many there were): a sample whose
+    pre-activation lies within one rounding error of zero gets its relu' mask 1 from one backend and 0 from the other, which adds or
+    drops ONE whole term of that unit's weight-gradient row (1/16,000 of the row's mass at this batch: 6e-5) and perturbs the gradient
+    that sample sends down to the tables (a row hit once carries it undiluted).  `explained` marks the elements such a flip -- derived
+    from the two runs' own activations, step by step -- can reach: the rows of the flipped units, the table rows the flipped samples
+    hit.  Nothing outside it may leave the 1e-5 bound; inside it the error stays within 5e-2 of the mass.  `extra_tol` widens the bound
+    of an MLP weight by what the samples with a flip ABOVE its layer contribute to it (4 x their own term mass): the flip changes the
+    gradient such a sample hands down by a whole term of a 128..1024-term sum, and where a weight's total mass is small that one sample
+    is more than 1e-5 of it (seen: 3 of 131,072 elements of the 512 -> 256 layer, off by 2x the plain bound)."""
     err = np.abs(dh - dc)
-    tol = tol_mass + tol_ulp
+    tol = tol_mass + tol_ulp + extra_tol
     bad = err > tol
-    worst[name] = (float(bad.mean()), float((err / tol).max()))
-    at = int((err / tol).argmax())
-    msg = (f"{name}: {int(bad.sum())} of {err.size} deltas beyond 1e-5 of the term mass; worst at flat index {at}: off by {err.flat[at]:.3e}, bound {tol.flat[at]:.3e} "
-           f"(delta hip {dh.flat[at]:.3e} cpu {dc.flat[at]:.3e})")
-    assert bad.mean() <= 1e-3, msg
+    if explained is None:
+        explained = np.zeros(err.shape, bool)
+    explained = np.broadcast_to(explained, err.shape)
+    unexplained = bad & ~explained
+    worst[name] = (int(bad.sum()), int(unexplained.sum()), float((err / tol).max()))
+    at = int(np.where(unexplained, err / tol, 0).argmax())
+    msg = (f"{name}: {int(unexplained.sum())} of {err.size} deltas beyond 1e-5 of the term mass that no relu' flip explains ({int(bad.sum())} beyond it in all); "
+           f"worst unexplained at flat index {at}: off by {err.flat[at]:.3e}, bound {tol.flat[at]:.3e} (delta hip {dh.flat[at]:.3e} cpu {dc.flat[at]:.3e})")
+    assert not unexplained.any(), msg
     assert np.all(err <= 5000 * tol_mass + tol_ulp), msg
 
 
@@ -313,7 +321,7 @@ def test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle(hip):
     batch 32768, eager launches on three streams, early sort: the next gather, the sort behind it and the update are all inside
     the window) on the HIP kernels against the same host code on the oracle, compared on the weight DELTAS: a weight is ~3e-2
     and one update ~1e-4, so round 3's rtol 2e-5 on the weights saw a gradient error only above ~0.5 % of the update.  Bound per
-    element (two tiers, see _delta_check: the relu' mask is a discontinuity): 1e-5 of the update's term mass -- lr * sum over the steps of sum_b |dy[b][o]| |x[b][i]| for an MLP weight (taken as
+    element (see _delta_check: the relu' mask is a discontinuity; every element beyond the bound must lie where a flip between the two runs -- derived from their own activations, step by step -- reaches): 1e-5 of the update's term mass -- lr * sum over the steps of sum_b |dy[b][o]| |x[b][i]| for an MLP weight (taken as
     steps x the last step's, computed in float64 from the oracle run's own activations and gradients), lr * sum_b |dy| for a bias, lr *
     the summed |dZ| mass of the hits for a table row -- plus two ulps of the weight per step for the rounding of w itself.  Row
     counts capped at 100,000 (the oracle's tables must fit the host; full-size tables: the next test)."""
@@ -325,10 +333,19 @@ def test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle(hip):
         app = ffmodel.DLRM(["--backend", backend] + TB_ARGS(rows))
         m = app.model
         w0 = _weights(m)                      # before the driver's warm-up iteration (a full training step): the common starting point
+        relu_layers = [li for li in range(m.num_layers) if m.layer_name(li).startswith("Dense")][:-1]        # every Dense but the click layer (sigmoid)
+        masks = []                            # per step: layer -> packed (y > 0) of the step's forward: where the backends' relu' masks differ
+
+        def snap():
+            m.sync()
+            masks.append({m.layer_name(li): np.packbits(m.layer_output(li).get() > 0) for li in relu_layers})
         app.warmup()
-        app.train_steps(steps - 1, trace=False)
+        snap()
+        for _ in range(steps - 1):
+            app.train_steps(1, trace=False)
+            snap()
         m.sync()
-        rec = {"w0": w0, "w1": _weights(m), "pred": m.layer_output(m.num_layers - 1).get()}
+        rec = {"w0": w0, "w1": _weights(m), "pred": m.layer_output(m.num_layers - 1).get(), "masks": masks}
         if name == "cpu":
             # activations and activation gradients of the LAST step: the operands of every weight gradient
             rec["x"], rec["dy"], rec["ids"] = {}, {}, {}
@@ -349,6 +366,22 @@ def test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle(hip):
     for k in h["w0"]:
         assert h["w0"][k].tobytes() == c["w0"][k].tobytes(), f"{k}: the two backends start from different weights"
     names = c["names"]
+    # the relu' flips between the two runs, from their own activations: (sample, unit) pairs whose y > 0 differs in any of the steps
+    Bn = 32768
+    flip_units, flip_samples, flip_rows = {}, np.zeros(Bn, bool), {}
+    nflips = {}
+    concat0 = [n for n in names if n.startswith("Concat")][0]
+    for nm in h["masks"][0]:
+        f = np.zeros(0, bool)
+        for mh, mc in zip(h["masks"], c["masks"]):
+            d = np.unpackbits(mh[nm] ^ mc[nm]).astype(bool)
+            f = d if f.size == 0 else (f | d)
+        f = f[:Bn * (f.size // Bn)].reshape(Bn, -1)
+        flip_units[nm] = f.any(0)
+        nflips[nm] = int(f.sum())
+        flip_rows[nm] = f.any(1)                                                      # samples with a flip in this layer
+        if names.index(nm) > names.index(concat0): flip_samples |= f.any(1)          # a top-MLP flip perturbs what that sample sends down to the tables
+    print("relu' flips between the backends over the steps, per layer:", nflips, "; samples with a top-MLP flip:", int(flip_samples.sum()))
     dd = lambda a: torch.from_numpy(np.abs(a)).to(DEV).double()
     # input of every Dense layer: the dense input, the layer before it, or (first top layer) the Concat output
     worst = {}
@@ -364,7 +397,20 @@ def test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle(hip):
             k = f"{nm}/{wi}"
             dh = h["w1"][k].astype(np.float64) - h["w0"][k].astype(np.float64)
             dc = c["w1"][k].astype(np.float64) - c["w0"][k].astype(np.float64)
-            _delta_check(k, dh, dc, 1e-5 * lr * steps * mass.reshape(dh.shape), steps * 2 * np.spacing(np.abs(c["w0"][k]).astype(np.float32)).astype(np.float64), worst)
+            fu = flip_units.get(nm, np.zeros(dh.shape[0], bool))                      # rows (kernel) / entries (bias) of the units that flipped
+            # samples with a flip in a layer whose gradient flows into this one: the Dense layers above it in its own MLP, and for the bottom
+            # MLP every top layer as well
+            above = np.zeros(Bn, bool)
+            for n2, fr in flip_rows.items():
+                i2 = names.index(n2)
+                if i2 > li: above |= fr
+            if above.any():
+                xs, dys = np.abs(x[above]).astype(np.float64), np.abs(dy[above]).astype(np.float64)
+                extra = 4.0 * lr * steps * (dys.T @ xs if wi == 0 else dys.sum(0))
+            else:
+                extra = 0.0
+            _delta_check(k, dh, dc, 1e-5 * lr * steps * mass.reshape(dh.shape), steps * 2 * np.spacing(np.abs(c["w0"][k]).astype(np.float32)).astype(np.float64), worst,
+                         explained=fu[:, None] if dh.ndim == 2 else fu, extra_tol=extra)
             assert np.abs(dc).max() > 0
     # tables: a row's update is lr * the sum of its hits' gradient rows = rows of dZ = dy1 W1[:, table's columns]
     dy1, w1 = c["dy"][first_top], c["w0"][f"{first_top}/0"]
@@ -379,12 +425,13 @@ def test_bench_workload_three_steps_at_b32768_weight_deltas_vs_oracle(hip):
         rowmass = torch.zeros(R, 128, dtype=torch.float64, device=DEV).index_add_(0, ids, dzmass[:, 128 * (t + 1):128 * (t + 2)]).cpu().numpy()
         dh = h["w1"][k].astype(np.float64) - h["w0"][k].astype(np.float64)
         dc = c["w1"][k].astype(np.float64) - c["w0"][k].astype(np.float64)
-        _delta_check(k, dh, dc, 1e-5 * lr * steps * rowmass, steps * 2 * np.spacing(np.abs(c["w0"][k]).astype(np.float32)).astype(np.float64), worst)
+        hit = np.zeros(R, bool); hit[c["ids"][nm].reshape(Bn, -1)[flip_samples].reshape(-1)] = True      # rows the flipped samples hit
+        _delta_check(k, dh, dc, 1e-5 * lr * steps * rowmass, steps * 2 * np.spacing(np.abs(c["w0"][k]).astype(np.float32)).astype(np.float64), worst, explained=hit[:, None])
         untouched = np.ones(R, bool); untouched[c["ids"][nm].reshape(-1)] = False
         assert not dh[untouched].any() and not dc[untouched].any()
         t += 1
     np.testing.assert_allclose(h["pred"], c["pred"], rtol=2e-5, atol=2e-6)
-    print("fraction beyond 1e-5 of the mass, worst error / bound per tensor:", {k: (round(v[0], 6), round(v[1], 2)) for k, v in sorted(worst.items(), key=lambda kv: -kv[1][1])[:10]})
+    print("per tensor: elements beyond 1e-5 of the mass, of those unexplained by a relu' flip, worst error / bound:", {k: (v[0], v[1], round(v[2], 2)) for k, v in sorted(worst.items(), key=lambda kv: -kv[1][2])[:10]})
 
 
 def _digest_of_touched_rows(hip, app, steps_ids=None):

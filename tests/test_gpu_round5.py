@@ -323,3 +323,38 @@ def test_driver_replays_a_trace_only_where_the_replay_is_not_slower():
     thr_eager, _ = run(["--no-trace"])
     print(f"adaptive {thr_auto:.0f} samples/s ({m.group(0)}); always replay {thr_replay:.0f}; eager {thr_eager:.0f}")
     assert thr_auto >= 0.93 * max(thr_replay, thr_eager), (thr_auto, thr_replay, thr_eager)
+
+
+def test_raw_c_abi_call_with_a_padded_reduction_depth_takes_the_fast_path(hip, oracle):
+    """an integrator who calls ffh_linear_* for MLPerf-DLRM's 479-wide layer as it stands gets the general kernels
+    (75-100 TFLOP/s).  The documented contract: allocate x / w with ld = ffh_linear_fast_in_dim(479, 1024) = 512 and zero pads, pass
+    in_dim = 512 -- the persistent kernels take the layer and the values are those of the 479-wide layer (oracle, unpadded)."""
+    B, IN, OUT = 8192, 479, 1024
+    P = hip.lib.ffh_linear_fast_in_dim(IN, OUT)
+    assert P == 512 and hip.lib.ffh_linear_fast_in_dim(13, 512) == 13
+    rng = np.random.default_rng(479)
+    x = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / 22).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    dy = (rng.uniform(-1, 1, (B, OUT)) / B).astype(np.float32)
+    xp = np.zeros((B, P), np.float32); xp[:, :IN] = x
+    wp = np.zeros((OUT, P), np.float32); wp[:, :IN] = w
+    y_e = oracle.linear_fwd(x, w, b, NONE)
+    dx_e, dw_e, db_e, _ = oracle.linear_bwd(x, y_e, dy, w, NONE)
+    dev = lambda a: torch.from_numpy(a).to(DEV)
+    xd, wd, bd, dyd = dev(xp), dev(wp), dev(b), dev(dy)
+    y = torch.zeros(B, OUT, device=DEV)
+    hip.call("ffh_linear_fwd", xd, P, y, OUT, wd, bd, P, OUT, B, NONE, None)
+    assert "|sk_" in _route(hip), _route(hip)
+    ax, aw = np.abs(x).astype(np.float64), np.abs(w).astype(np.float64)
+    _close(y.cpu().numpy(), y_e, ax @ aw.T + np.abs(b), "479 (padded to 512) -> 1024 forward")
+    dx = torch.zeros(B, P, device=DEV); dw = torch.zeros(OUT, P, device=DEV); db = torch.zeros(OUT, device=DEV)
+    hip.call("ffh_linear_bwd", xd, P, dx, P, y, OUT, dyd, OUT, wd, dw, db, P, OUT, B, NONE, None)
+    r = _route(hip)
+    torch.cuda.synchronize()
+    assert r.count("|sk_") >= 2, r
+    a = np.abs(dy).astype(np.float64)
+    dwn, dxn = dw.cpu().numpy(), dx.cpu().numpy()
+    _close(dwn[:, :IN], dw_e, a.T @ ax, "dw")
+    _close(dxn[:, :IN], dx_e, a @ aw, "dx")
+    assert not dwn[:, IN:].any() and not dxn[:, IN:].any()          # the pads stay exact zeros

@@ -167,3 +167,10 @@ def test_single_rank_forced_exchange_with_buckets_equals_plain_run():
     for sa, sb in zip(ra, rb):
         for k in sa:
             assert np.array_equal(sa[k], sb[k]), k
+
+
+def test_fast_path_padding_rule_is_the_same_in_both_libraries(oracle):
+    """ffh_linear_fast_in_dim (the contract of include/ff_hip.h: pad the reduction depth of a wide layer to whole 64-deep k-tiles)."""
+    o = oracle.lib().lib
+    for (i, n), exp in {(479, 1024): 512, (857, 1024): 896, (512, 1024): 512, (13, 512): 13, (479, 100): 479, (200, 1024): 200, (3456, 1024): 3456}.items():
+        assert o.ffh_linear_fast_in_dim(i, n) == exp, (i, n)
