@@ -458,7 +458,7 @@ def _digest_of_touched_rows(hip, app, steps_ids=None):
 
 
 @pytest.mark.timeout(3000)
-@pytest.mark.parametrize("full_size", [False, True])
+@pytest.mark.parametrize("full_size", [False, True, 4096])
 def test_benched_step_overlapped_equals_serial_bit_for_bit_under_deterministic(hip, full_size):
     """The composition the per-layer tests cannot see -- aliasing into the Concat buffer, premasked dy across layers, forked weight
     gradients, the early sort, the next gather beside the last weight-gradient GEMM -- at the size the driver times: three steps
@@ -467,10 +467,14 @@ def test_benched_step_overlapped_equals_serial_bit_for_bit_under_deterministic(h
     uncapped Terabyte row counts (96 GB of tables; the serial run is the reference), compared on the MLP, the predictions and
     every table row the batch touches."""
     _release_cached_device_memory()
-    rows = TERABYTE_ROWS if full_size else [min(r, 100000) for r in TERABYTE_ROWS]
+    # (round 5) 4096: the per-rank batch of the 8-GPU job, where the first top layer's data gradient runs as stream-K WITH FIX-UP -- the
+    # form deterministic mode now takes (its parts are added in k order whoever arrives last): the cross-workgroup slot / counter protocol
+    # runs beside the other streams' kernels here
+    batch = 4096 if full_size == 4096 else 32768
+    rows = TERABYTE_ROWS if full_size is True else [min(r, 100000) for r in TERABYTE_ROWS]
     runs = []
     for flags in ([], ["--no-overlap", "--no-early-sort", "--serial-dw"]):
-        app = ffmodel.DLRM(["--backend", HIP, "--deterministic"] + TB_ARGS(rows) + flags)
+        app = ffmodel.DLRM(["--backend", HIP, "--deterministic"] + TB_ARGS(rows, batch) + flags)
         app.warmup()
         app.train_steps(3, trace=False)
         app.model.sync()
