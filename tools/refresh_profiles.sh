@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the judged artefacts under profiles/ on one GPU box.  Outputs land in gpurun_out/refresh/ with their final
-# names (r04_*); copy them into profiles/ afterwards.   gpurun --timeout 3300 -- 'bash tools/refresh_profiles.sh'
+# names (r05_*); copy them into profiles/ afterwards.   gpurun --timeout 3300 -- 'bash tools/refresh_profiles.sh'
 R=$(pwd); O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $R
-P=${P:-r04}
+P=${P:-r05}
 line() { grep '^{' | tail -1; }
 
 # 0. HBM traffic of the embedding kernels first (two counter-only passes): the bench lines below quote it, and warn when the file on
@@ -46,6 +46,9 @@ for v in plain exchange; do
   find $O/prof_b4096_$v -name "*.csv" -size +10M -delete
 done
 
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_mlperf -- python3 bench.py --workload mlperf --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > /dev/null 2>&1
+T=$(find $O/prof_mlperf -name "*kernel_trace.csv" | head -1); python3 tools/trace_summary.py $T > $O/${P}_mlperf_step_timeline.txt; find $O/prof_mlperf -name "*.csv" -size +10M -delete
+
 # 5. hipGraph replay against eager launches, one step each
 for mode in graph eager; do
   F="--force-graph"; [ $mode = eager ] && F="--no-trace"
@@ -57,11 +60,13 @@ for mode in graph eager; do
 done
 
 # 6. GEMM microbenchmarks: fp32 kernels next to hipBLASLt (torch.mm) in one process; fp32 vs tensor-op (bf16) mode; the lab
-python3 tools/gemm_big.py -1 32768x3456x1024 32768x1024x1024 32768x1024x512 4096x3456x1024 4096x1024x1024 4096x1024x512 4096x512x256 8192x512x1024 8192x479x1024 8192x1024x1024 8192x1024x512 8192x512x256 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_vs_hipblaslt.txt
+python3 tools/gemm_big.py -1 32768x3456x1024 32768x1024x1024 32768x1024x512 4096x3456x1024 4096x1024x1024 4096x1024x512 4096x512x256 8192x512x1024 8192x479x1024 8192x1024x1024 8192x1024x512 8192x1024x256 8192x512x256 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_vs_hipblaslt.txt
 python3 tools/gemm_bf16_bench.py 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_gemm_bf16_mode.txt
 # the lab binary is built here from its source (never committed)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_big_lab.hip -lrocblas -o tools/lab/gemm_big_lab 2> $O/lab_build.err && timeout 300 tools/lab/gemm_big_lab 32768 1024 3456 > $O/${P}_lab_gemm_big.txt 2>&1
 python3 tools/microbench.py emb > $O/${P}_microbench_embedding.txt 2>&1
+# the chain launches of narrow Linear layers next to the per-layer calls (round 5), alone
+{ python3 tools/chain_bench.py 2048 4096 8192; python3 tools/chain_bench.py 4096 --single; } 2>&1 | grep "^B=" > $O/${P}_microbench_mlp_chain.txt
 # the stand-alone lab of the persistent fp32 GEMM (built here from its source), with its ablation modes
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_sk_lab.hip -o tools/lab/gemm_sk_lab 2>> $O/lab_build.err && { timeout 120 tools/lab/gemm_sk_lab 32768 1024 1024 1 256 1; timeout 120 tools/lab/gemm_sk_lab 32768 3456 1024 1 256 0; } > $O/${P}_lab_gemm_sk.txt 2>&1
 # tensor-op mode: one big layer with and without bf16 twins
