@@ -132,6 +132,9 @@ class FFConfig {
                                // measured on the trace's first calls, one GPU (--adaptive-replay): on this runtime the replay of a two-stream step costs a
                                // small model more than its launches (Kaggle shape: 210 vs 170 us).  -1 = not given: the FFModel API replays (1), the DLRM
                                // driver's timed loop adapts (0)
+  bool split_update;           // one GPU: the slab optimizer as two launches -- the bottom MLP's parameters on the compute stream as soon as its (chain) backward is
+                               // done, the rest on the weight-gradient stream behind the last weight gradient -- so that the next step's bottom-MLP forward does
+                               // not wait for the biggest layer's weight gradient and 14 MB of SGD (A/B: --split-update; measured level to slightly slower, off)
   bool mlp_chain;              // a run of narrow Linear layers (every width <= 512) as one launch forward, two backward (ffh_mlp_chain_fwd / _bwd; A/B: --no-mlp-chain)
   int64_t mlp_chain_max_batch; // ... for at most this many samples per GPU (--mlp-chain-max-batch N)
   int64_t mlp_chain_fwd_min_batch;   // the forward chain from this many samples per GPU up (below, the per-layer kernels win: --mlp-chain-fwd-min-batch N)
@@ -547,6 +550,14 @@ class FFModel {
   void issue_one_bucket(size_t k, bool wait_main);      // wait_main: also behind what the compute stream holds now
   int  big_dw_chunks_now() const;                       // row blocks the biggest layer's weight gradient is cut into this step (1: not cut)
   mutable int64_t n_bucket_allreduces = 0;
+  // ---- split slab update (FFConfig::split_update) ----
+  size_t bottom_floats = 0;              // slab elements of the Linear layers in front of the tables (0: no split possible)
+  int first_top_linear = -1;             // layer index of the first Linear behind the tables: its forward waits for the top part's update
+  ffh_event ev_top_mark = nullptr, ev_top_opt_done = nullptr;
+  bool bottom_bwd_on_stream = false;     // this step's bottom-MLP backward ran as a chain call on the compute stream (its gradients need no join)
+  bool top_opt_pending = false;          // the top part's update is in flight on the weight-gradient stream
+  mutable int64_t n_split_updates = 0;
+  void join_top_update();                // `stream` waits for it (no-op when nothing is pending)
   mutable int64_t n_chain_fwd_calls = 0, n_chain_bwd_calls = 0;   // successful ffh_mlp_chain_fwd / _bwd calls (tests: flexflow_model_get_counter)
   bool mlp_chain_usable(int64_t rows, bool fwd) const;      // the chain launches are allowed in this mode / at this batch
   int run_chain_fwd(const Linear* lowest) const;  // FFH_OK, or FFH_ERR_UNSUPPORTED with nothing launched

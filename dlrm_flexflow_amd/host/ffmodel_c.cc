@@ -125,6 +125,7 @@ int64_t flexflow_model_get_counter(flexflow_model_t m, const char* name) {
   if (n == "mlp_chain_fwd_calls") return M(m)->n_chain_fwd_calls;
   if (n == "mlp_chain_bwd_calls") return M(m)->n_chain_bwd_calls;
   if (n == "allreduce_bucket_calls") return M(m)->n_bucket_allreduces;
+  if (n == "split_updates") return M(m)->n_split_updates;
   if (n == "allreduce_buckets") return (int64_t)M(m)->grad_buckets.size();
   return -1;
 }

@@ -133,6 +133,7 @@ FFConfig::FFConfig() {
   attach_events = true;
   fuse_pair = true;
   mlp_chain = true;
+  split_update = false;        // measured (profiles/r05_ab_schedule.txt): 4096 samples 1.150-1.154 vs 1.145-1.146 ms, headline and Kaggle level -- off
   trace_mode = -1;
   bucket_allreduce = -1;
   allreduce_bucket_floats = 1 << 20;
@@ -222,6 +223,8 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-attach-event")) { attach_events = false; continue; }
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-mlp-chain")) { mlp_chain = false; continue; }
+    if (is("--no-split-update")) { split_update = false; continue; }
+    if (is("--split-update")) { split_update = true; continue; }
     if (is("--always-replay")) { trace_mode = 1; continue; }
     if (is("--adaptive-replay")) { trace_mode = 0; continue; }
     if (is("--bucket-allreduce")) { bucket_allreduce = 1; continue; }
@@ -470,7 +473,7 @@ void Op::print_layer(const FFModel&) const {
 static FFConfig& profiling_schedule(FFConfig& c) {
   if (c.profiling) {
     c.overlap_embedding = false; c.enable_graph = false; c.parallel_dw = false; c.async_launch = false;
-    c.fuse_pair = false; c.mlp_chain = false; c.attach_events = false; c.dx_scatter = false; c.timing_events = true;
+    c.fuse_pair = false; c.mlp_chain = false; c.split_update = false; c.attach_events = false; c.dx_scatter = false; c.timing_events = true;
   }
   return c;
 }
@@ -1992,6 +1995,21 @@ void FFModel::allocate() {
   }
   // Op::weights[] are copies of the Parameters: same impl pointers, nothing to patch.
 
+  // ---- 5a'. where the slab splits for the two-part optimizer launch (FFConfig::split_update) -----------------------------
+  bottom_floats = 0; first_top_linear = -1;
+  if (!embeddings.empty() && !exchange) {
+    const int first_emb = embeddings.front()->layer_index;
+    size_t at = 0; bool ok = true;
+    for (const Embedding* e : embeddings) if (e->replicated) ok = false;          // (data-parallel tables live in the slab between the two MLPs)
+    for (const Parameter& p : parameters) {
+      if (!in_dense_slab(p)) continue;
+      if (p.owner_op->layer_index < first_emb) { if (p.impl->grad != mlp_grads + at) ok = false; at += (slab_elems(p) + 3) / 4 * 4; }
+    }
+    for (size_t l = (size_t)first_emb; l < layers.size() && first_top_linear < 0; l++) if (layers[l]->op_type == OP_LINEAR) first_top_linear = (int)l;
+    if (ok && at > 0 && at < mlp_count && first_top_linear >= 0) bottom_floats = at;
+  }
+  if (!ev_top_mark) { check(api->ffh_event_create_sync(ctx, &ev_top_mark), "event create"); check(api->ffh_event_create_sync(ctx, &ev_top_opt_done), "event create"); }
+
   // ---- 5b. buckets of the MLP gradients' all-reduce ---------------------------------------------------------------------
   // In the reference every parameter has its own update task with its own ncclAllReduce, ordered by region dependences only: a top
   // layer's gradients are summed over the ranks while the layers below still run their backward [ref: src/runtime/optimizer.cc:93-189,
@@ -2484,6 +2502,12 @@ void FFModel::note_weight_write(const void* p) const {
   if (w_twin && (const char*)p >= (const char*)mlp_weights && (const char*)p < (const char*)(mlp_weights + mlp_count)) w_twin_dirty = true;
 }
 
+void FFModel::join_top_update() {
+  if (!top_opt_pending) return;
+  check(api->ffh_stream_wait_event(ctx, stream, ev_top_opt_done), "join the top part's update");
+  top_opt_pending = false;
+}
+
 void FFModel::forward(int _seq_length) {
   if (replaying_trace >= 0) return;
   seq_length = _seq_length;
@@ -2504,6 +2528,7 @@ void FFModel::forward(int _seq_length) {
     if (!exchange || config.comm.nonblocking || use_workers()) issue_embedding_forward_on_side_stream();
   }
   for (Op* op : layers) {
+    if (top_opt_pending && op->layer_index >= first_top_linear) join_top_update();      // (split update: the first consumer of the top MLP's weights)
     if (!config.profiling) { op->forward(*this); continue; }
     if (op->op_type == OP_EMBEDDING && emb_forward_issued) continue;      // the first table launched the whole group
     profiled(op, true, [&] { op->forward(*this); });
@@ -2672,6 +2697,8 @@ void FFModel::backward(int _seq_length) {
   // 2.155 at 8192, 8.02 vs 7.87 at 32768, MLPerf shape 1.337 vs 1.273.
   const int defer_layer = defer_big_dw_layer();
   Linear* deferred = nullptr;
+  bottom_bwd_on_stream = false;
+  join_top_update();
   for (GradBucket& b : grad_buckets) b.issued = b.inline_issued = false;
   const int dw_chunks = (defer_layer < 0 && !config.big_dw_mode) ? big_dw_chunks_now() : 1;
   // the biggest layer with the bucketed all-reduce: data gradient, then its weight gradient in row blocks, a bucket behind each
@@ -2722,8 +2749,13 @@ void FFModel::backward(int _seq_length) {
     if (up && !up->chain_bwd.empty() && mlp_chain_usable(local_rows(up->outputs[0], this), false)) {
       // the chain this layer tops: one call for all its members (their indices are l - n + 1 .. l)
       const int n = (int)up->chain_bwd.size();
+      // (split update: what the compute stream holds in front of the bottom MLP's chain -- every top layer's own-stream work -- is what
+      //  the top part's optimizer launch must follow)
+      const bool bottom_chain = l - n + 1 == 0 && bottom_floats > 0 && !embeddings.empty() && l + 1 == embeddings.front()->layer_index;     // the whole bottom MLP
+      if (bottom_chain) check(api->ffh_event_record(ctx, ev_top_mark, stream), "event");
       const int crc = run_chain_bwd(up);
       if (crc == FFH_OK) {
+        if (bottom_chain) bottom_bwd_on_stream = true;
         // a lower member completes the embedding output gradients: "gradients ready" behind the whole call (the chain's weight-gradient
         // kernel still reads the buffer the next gather overwrites).  (l itself: attached above, recorded by the call.)
         if (grad_attach_layer > l - n && grad_attach_layer < l && !grad_ready_attached) {
@@ -2780,9 +2812,27 @@ void FFModel::update() {
   if (side_worker) side_worker->drain();
   if (dw_forked && !dw_worker && !api->ffh_second_stream_used(ctx, 1) && !dw_stream_used_directly) { dw_forked = false; dw1_used = dw2_used = false; }   // the library kept everything on `stream`
   dw_stream_used_directly = false;
+  // Split update (one GPU, the bottom MLP's backward ran as a chain on `stream`, every forked weight gradient on dw_stream): the top
+  // part of the slab is updated ON dw_stream behind the last weight gradient, the bottom part on `stream` without joining it -- the next
+  // step's bottom-MLP forward then runs beside the biggest layer's weight gradient's tail and the 14 MB optimizer sweep instead of
+  // behind them (4096 samples: ~25 us of the 113 us between the end of that GEMM and the next top-MLP forward).  While a capture is
+  // open the join happens right here (a replayed graph is a barrier anyway).
+  const bool split_now = config.split_update && bottom_floats > 0 && bottom_bwd_on_stream && !exchange && dw_forked && dw1_used && !dw2_used && !dw_worker &&
+                         !config.profiling && (adam || sgd->momentum == 0.0);
   if (dw_forked) {   // the weight-gradient GEMMs ran on their own stream: join before the gradients are consumed
     if (dw_worker) { dw_worker->drain(); dw1_used = true; }
-    if (dw1_used) {
+    if (dw1_used && split_now) {
+      const size_t top = mlp_count - bottom_floats;
+      check(api->ffh_stream_wait_event(ctx, dw_stream, ev_top_mark), "split update");
+      if (adam) check(api->ffh_adam_update(ctx, mlp_weights + bottom_floats, mlp_grads + bottom_floats, adam->mlp_m + bottom_floats, adam->mlp_v + bottom_floats, (int64_t)top,
+                                           (float)adam->alpha_t, (float)adam->beta1, (float)adam->beta2, (float)adam->weight_decay, (float)adam->epsilon, FFH_OPT_ZERO_GRAD, dw_stream), "adam_update (top part)");
+      else check(api->ffh_sgd_update_ex(ctx, mlp_weights + bottom_floats, mlp_grads + bottom_floats, nullptr, (int64_t)top, (float)sgd->lr, (float)sgd->weight_decay, 0.0f, 0,
+                                        FFH_OPT_ZERO_GRAD, dw_stream), "sgd_update (top part)");
+      check(api->ffh_event_record(ctx, ev_top_opt_done, dw_stream), "split update");
+      check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");
+      top_opt_pending = true;
+      n_split_updates++;
+    } else if (dw1_used) {
       check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");
       check(api->ffh_stream_wait_event(ctx, stream, ev_dw_done), "join dw");
     }
@@ -2826,9 +2876,10 @@ void FFModel::update() {
   }
   // one launch over the whole MLP slab; it also clears the gradients it consumed, so the next zero_gradients()
   // has nothing to sweep [ref: one update task per parameter, src/runtime/optimizer.cc:93-189,256-330]
+  const size_t opt_count = split_now ? bottom_floats : mlp_count;      // (split: the rest is in flight on dw_stream)
   if (adam) {
     if (mlp_count) {
-      check(api->ffh_adam_update(ctx, mlp_weights, mlp_grads, adam->mlp_m, adam->mlp_v, (int64_t)mlp_count, (float)adam->alpha_t,
+      check(api->ffh_adam_update(ctx, mlp_weights, mlp_grads, adam->mlp_m, adam->mlp_v, (int64_t)opt_count, (float)adam->alpha_t,
                                  (float)adam->beta1, (float)adam->beta2, (float)adam->weight_decay, (float)adam->epsilon,
                                  FFH_OPT_ZERO_GRAD, stream), "adam_update (MLP slab)");
       mlp_grads_clean = true;
@@ -2837,10 +2888,11 @@ void FFModel::update() {
     for (const Parameter& p : parameters)
       if (in_dense_slab(p)) sgd->update(&p);
   } else if (mlp_count) {
-    check(api->ffh_sgd_update_ex(ctx, mlp_weights, mlp_grads, nullptr, (int64_t)mlp_count, (float)sgd->lr, (float)sgd->weight_decay, 0.0f,
+    check(api->ffh_sgd_update_ex(ctx, mlp_weights, mlp_grads, nullptr, (int64_t)opt_count, (float)sgd->lr, (float)sgd->weight_decay, 0.0f,
                                  0, FFH_OPT_ZERO_GRAD, stream), "sgd_update (MLP slab)");
     mlp_grads_clean = true;
   }
+  if (top_opt_pending && capturing_trace >= 0) join_top_update();
   if (fused_embedding_update()) {
     if (config.overlap_embedding) {
       // launched in backward() on the side stream.  Its only consumer, the next gather, runs on that same stream, and
@@ -2939,6 +2991,7 @@ void FFModel::end_trace(int trace_id) {
 }
 
 void FFModel::sync() {
+  join_top_update();
   if (dw_worker) dw_worker->drain();
   if (side_worker) side_worker->drain();
   check(api->ffh_stream_sync(ctx, stream), "sync");

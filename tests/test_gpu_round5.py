@@ -358,3 +358,30 @@ def test_raw_c_abi_call_with_a_padded_reduction_depth_takes_the_fast_path(hip, o
     _close(dwn[:, :IN], dw_e, a.T @ ax, "dw")
     _close(dxn[:, :IN], dx_e, a @ aw, "dx")
     assert not dwn[:, IN:].any() and not dxn[:, IN:].any()          # the pads stay exact zeros
+
+
+@pytest.mark.timeout(900)
+def test_split_slab_update_equals_the_single_launch(hip):
+    """One GPU, Terabyte shape at 4096 samples: the slab optimizer as two launches (the bottom MLP's parameters on the compute stream
+    behind its chain backward, the rest on the weight-gradient stream behind the last weight gradient; the next forward's first
+    top layer waits for the latter) against the single launch behind the join -- same arithmetic per element, so the weights after four
+    eager steps agree to the noise of the weight gradients' atomics; the split really ran; replayed steps (a capture closes the fork
+    inside update()) agree as well."""
+    import dlrm_helpers as H
+    from dlrm_flexflow_amd import ffmodel
+    rows = "-".join(["2000"] * 26)
+    args = ["--backend", capi.HIP_LIB_PATH, "-b", "4096", "--arch-sparse-feature-size", "128", "--arch-embedding-size", rows,
+            "--arch-mlp-bot", "13-512-256-128", "--arch-mlp-top", "3456-1024-1024-512-256-1", "--data-size", "4096"]
+    outs = []
+    for extra, trace in ((["--split-update"], False), (["--no-split-update"], False), (["--split-update"], True)):
+        app = ffmodel.DLRM(args + extra)
+        app.warmup(); app.train_steps(4, trace=trace); app.model.sync()
+        m = app.model
+        rec = {f"{l}/{w}": m.parameter(l, w).get_weights() for l in range(m.num_layers) for w in range(m.layer_num_weights(l))}
+        rec["pred"] = m.layer_output(m.num_layers - 1).get()
+        outs.append((rec, m.counter("split_updates")))
+        app.close()
+    assert outs[0][1] >= 4 and outs[1][1] == 0, (outs[0][1], outs[1][1])
+    for k in outs[0][0]:
+        np.testing.assert_allclose(outs[0][0][k], outs[1][0][k], rtol=2e-5, atol=2e-6, err_msg=f"split vs single: {k}")
+        np.testing.assert_allclose(outs[2][0][k], outs[1][0][k], rtol=2e-5, atol=2e-6, err_msg=f"replayed vs single: {k}")
