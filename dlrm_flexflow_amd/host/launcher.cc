@@ -75,6 +75,8 @@ int launcher_barrier(void*) {
 
 int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv) {
   const bool dry = getenv("FFM_LAUNCH_DRYRUN") != nullptr;     // tests: process management + rendezvous without a GPU
+  // (the three FFM_LAUNCH_TEST_* hooks act only inside the GPU-less dry run that exists for the process-management tests: a real launch
+  //  never reads them -- round-4 advisor)
   if (dry && getenv("FFM_LAUNCH_TEST_IGNORE_TERM")) signal(SIGTERM, SIG_IGN);   // tests: a rank that does not listen (SIGKILL after the grace period)
   unsigned char id[128];
   memset(id, 0, sizeof id);
@@ -184,7 +186,7 @@ int dlrm_launch(int argc, char** argv) {
   sa.sa_handler = note_signal;
   sigaction(SIGTERM, &sa, &old_term);
   sigaction(SIGINT, &sa, &old_int);
-  if (getenv("FFM_LAUNCH_TEST_SIGNAL_SELF_EARLY")) raise(SIGTERM);     // tests: a signal that arrives before the first fork (stays pending until the mask is restored)
+  if (getenv("FFM_LAUNCH_DRYRUN") && getenv("FFM_LAUNCH_TEST_SIGNAL_SELF_EARLY")) raise(SIGTERM);     // tests: a signal that arrives before the first fork (stays pending until the mask is restored)
   std::vector<pid_t> pids;
   for (int r = 0; r < n; r++) {
     const pid_t pid = fork();

@@ -724,10 +724,11 @@ int Linear::backward_pair(const FFModel& ff) {
   const int flags_l = (lo->dx_overwrite ? FFH_LINEAR_DX_OVERWRITE : 0) | (lo->dx_mask_by_x ? FFH_LINEAR_DX_MASK_BY_X : 0);
   const int rc = ff.api->ffh_linear_pair_bwd(
       ff.ctx, (const float*)xu.impl->ptr, xu.impl->ld, (const float*)yu.impl->ptr, yu.impl->ld, yu.impl->grad, yu.impl->grad_ld,
-      (const float*)weights[0].impl->ptr, weights[0].impl->grad, use_bias ? weights[1].impl->grad : nullptr, in_channels, out_channels,
+      (const float*)weights[0].impl->ptr, weights[0].impl->grad, (use_bias && !db_from_upper) ? weights[1].impl->grad : nullptr, in_channels, out_channels,
       (int)activation, flags_u, (const float*)xl.impl->ptr, xl.impl->ld, xl.impl->grad, xl.impl->grad_ld, xu.impl->grad, xu.impl->grad_ld,
       (const float*)lo->weights[0].impl->ptr, lo->in_channels, (int)lo->activation, flags_l, b, ff.stream);
   if (rc != FFH_OK) return rc;
+  db_from_upper = false;        // (honoured above and consumed: the layer above may have produced this layer's bias gradient -- round-4 advisor)
   // what is left of the lower layer: dW / db over the whole batch, from the gradient the launch above wrote (premasked)
   ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, (const float*)xl.impl->ptr, xl.impl->ld, nullptr, xl.impl->grad_ld, (const float*)xu.impl->ptr, xu.impl->ld,
                                      xu.impl->grad, xu.impl->grad_ld, (const float*)lo->weights[0].impl->ptr, lo->weights[0].impl->grad,
@@ -1502,8 +1503,10 @@ void FFModel::compile(Optimizer* _optimizer, LossType _loss_type, const std::vec
   // hip::Stream::EndCapture, profiles/r04_capture_exchange_endcapture_backtrace.txt) when RCCL's grouped send / recv were captured
   // on a stream that itself joined the capture through an event -- the side stream of the overlapped gather.  With the collectives
   // on the capturing stream itself the capture works, so a captured exchange step runs its embedding branch on the compute stream.
+  // (first: Adam never captures -- alpha_t is a new launch argument every step -- so it must not lose the side-stream overlap to a
+  //  capture that will not happen; round-4 advisor)
+  if (dynamic_cast<AdamOptimizer*>(optimizer) && config.enable_graph) config.enable_graph = false;
   if (exchange && config.enable_graph && config.capture_exchange) config.overlap_embedding = false;
-  if (dynamic_cast<AdamOptimizer*>(optimizer) && config.enable_graph) config.enable_graph = false;   // alpha_t is a new launch argument every step
   // Any optimizer x any placement (round 4).  Plain SGD: the fused sorted-segments update.  Momentum / weight-decay SGD, Adam:
   // by default the reference's own path on the rank(s) that hold the table -- an owner-local dense gradient (zeroed, scatter-added
   // from the rows the backward all-to-all returned, swept by sgd_update / adam_update with dense per-table state; sole owner: no
