@@ -107,15 +107,18 @@ constexpr int kDotD = 128;                               // floats per row in th
 constexpr int kDotImage = kMaxC * kDotD * 4;             // 16 KB per sample image
 constexpr int kDotLds = 4 * 2 * kDotImage;               // 4 waves x 2 buffers = 128 KB: one workgroup per CU
 
-template <int OV>
-__global__ __launch_bounds__(256) void dot_interaction_fwd_lds_kernel(const float* __restrict__ z, int64_t ldz, float* __restrict__ out, int64_t ldo,
+// NW = 4, NBUF = 2: one wave per SIMD, the next sample streaming into the wave's second image between this one's MFMAs (round 3).
+// NW = 8, NBUF = 1 (round 5): two waves per SIMD with ONE image each -- a wave issues its sample's pieces, waits, computes; what covers
+// its DMA issue stalls and its wait is the other wave's MFMAs instead of its own.
+template <int OV, int NW = 4, int NBUF = 2>
+__global__ __launch_bounds__(64 * NW) void dot_interaction_fwd_lds_kernel(const float* __restrict__ z, int64_t ldz, float* __restrict__ out, int64_t ldo,
                                                                       int64_t batch, int c) {
   ffh_kernel_prio();
   extern __shared__ __attribute__((aligned(16))) unsigned char dot_smem[];
   constexpr int d = kDotD;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  unsigned char* img = dot_smem + wave * 2 * kDotImage;
+  unsigned char* img = dot_smem + wave * NBUF * kDotImage;
   const unsigned lds_base = (unsigned)(size_t)(dot_lds_ptr_t)img;
   const int npieces = (c + 1) / 2;                       // DMA instructions per sample: two rows each (<= 16)
   // lane-linear piece i: LDS bytes [1024 i, 1024 i + 1024) = rows 2 i (lanes 0-31) and 2 i + 1 (lanes 32-63), position p = lane & 31
@@ -129,17 +132,21 @@ __global__ __launch_bounds__(256) void dot_interaction_fwd_lds_kernel(const floa
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
   };
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  int64_t b = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * NW;
+  int64_t b = (int64_t)blockIdx.x * NW + wave;
   int buf = 0;
-  if (b < batch) {
+  if (b < batch && NBUF == 2) {
     const float* zb = z + b * ldz;
     for (int i = 0; i < npieces; i++) issue_piece(zb, 0, i);
   }
-  for (; b < batch; b += nwaves, buf ^= 1) {
+  for (; b < batch; b += nwaves, buf ^= (NBUF - 1)) {
+    if (NBUF == 1) {                                         // single image: this sample's pieces now (the image's last reader -- the previous
+      const float* zb = z + b * ldz;                         // sample's stores of row 0 -- has its data in registers: wave barrier below)
+      for (int i = 0; i < npieces; i++) issue_piece(zb, 0, i);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this sample's image is complete (its pieces were issued between the previous sample's MFMAs)
     const int64_t bn = b + nwaves;
-    const bool more = bn < batch;
+    const bool more = NBUF == 2 && bn < batch;
     const float* zn = z + (more ? bn : b) * ldz;
     const unsigned char* im = img + buf * kDotImage + r * (d * 4);
     f32x16 acc;
@@ -387,6 +394,15 @@ int ffh_dot_interaction_fwd(ffh_ctx* c, const float* z, int64_t ldz, float* out,
     // one 4-wave workgroup per CU (128 KB of LDS), every wave walks its samples with the next one streaming in
     static const bool ok4 = hipFuncSetAttribute((const void*)dot_interaction_fwd_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kDotLds) == hipSuccess;
     static const bool ok1 = hipFuncSetAttribute((const void*)dot_interaction_fwd_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kDotLds) == hipSuccess;
+    static const bool ok8 = hipFuncSetAttribute((const void*)dot_interaction_fwd_lds_kernel<4, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kDotLds) == hipSuccess;
+    static const int w8 = FFH_LAB_INT("FFH_DOT_W8", 0);          // A/B switch: two single-image waves per SIMD
+    if (ok8 && w8 && o4) {
+      unsigned g2 = (unsigned)c->num_cus;
+      if ((int64_t)g2 * 8 > batch) g2 = (unsigned)((batch + 7) / 8);
+      hipLaunchKernelGGL((dot_interaction_fwd_lds_kernel<4, 8, 1>), dim3(g2), dim3(512), kDotLds, as_stream(s), z, ldz, out, ldo, batch, nrows);
+      FFH_LAUNCH_CHECK(c, "dot_interaction_fwd (lds, 8 waves)");
+      return FFH_OK;
+    }
     if (ok4 && ok1) {
       unsigned g2 = (unsigned)c->num_cus;
       if ((int64_t)g2 * 4 > batch) g2 = (unsigned)((batch + 3) / 4);
