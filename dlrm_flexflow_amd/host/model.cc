@@ -565,6 +565,8 @@ FFModel::~FFModel() {
   api->ffh_event_destroy(ctx, ev_grad_ready); api->ffh_event_destroy(ctx, ev_update_done);
   api->ffh_event_destroy(ctx, ev_dw_done);
   api->ffh_event_destroy(ctx, ev_z_free);
+  api->ffh_event_destroy(ctx, ev_top_mark); api->ffh_event_destroy(ctx, ev_top_opt_done);
+  for (auto& kv : trace_tune) for (ffh_event& e : kv.second.ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
   for (ffh_event& e : probe_ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
   api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream); api->ffh_stream_destroy(ctx, dw_stream2);
   for (GradBucket& b : grad_buckets) { api->ffh_event_destroy(ctx, b.ready); api->ffh_event_destroy(ctx, b.ready_dw); api->ffh_event_destroy(ctx, b.ready_dw2); api->ffh_event_destroy(ctx, b.done); }
