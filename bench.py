@@ -414,6 +414,7 @@ def main():
     ap.add_argument("--functional-test-backend", default="", help=argparse.SUPPRESS)   # tests only: walk this file's whole rank path on the
     #                      CPU (gloo + the given kernel library, i.e. the oracle); the line it prints is not a measurement
     args = ap.parse_args()
+    args.shim_flags = args.shim_flags.replace(",", " ")      # (a comma also separates flags: one shell word in scripted visits)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.cpu_baseline_leg:
         sys.exit(spawn_ranks(args.gpus))   # the parent: no torch import, no HIP call, nothing that initialises a GPU
     # stdout carries the ONE JSON line and nothing else: the C++ driver's printf banner ("[DLRM] ...", flushed by the C

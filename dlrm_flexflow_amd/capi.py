@@ -87,6 +87,7 @@ _SIGS = {
     "ffh_ctx_destroy": (I, [P]),
     "ffh_ctx_default": (I, [C.POINTER(P)]),
     "ffh_linear_last_route": (C.c_char_p, [P]),
+    "ffh_embedding_last_route": (C.c_char_p, [P]),
     "ffh_last_error_string": (C.c_char_p, [P]),
     "ffh_device_query": (I, [P, C.POINTER(DeviceInfo)]),
     "ffh_ctx_set_workspace": (I, [P, P, SZ]),

@@ -146,6 +146,10 @@ struct SortArgs {
   uint8_t   npass[FFH_MAX_TABLES];      // digits table t really has; later passes would be the identity and are skipped
   uint32_t* clear[2];                   // [nt][nclear[i]] dwords the pass-0 histogram kernel zeroes for the apply phase
   int       nclear[2];                  //   (level-1 meta slots, arrival counters)
+  // bucket form (one stable pass on every table's TOP digit, the rest of the order made inside the apply launch, see msd_window):
+  int       msd;                        // != 0: the digit of table t sits at shift_t[t] (0: its ids fit the digit -- the pass sorts it completely)
+  uint8_t   shift_t[FFH_MAX_TABLES];
+  uint32_t* bstart;                     // [nt][kMaxRadix + 1]: first sorted index of every bucket, [radix] = N (written by tile 0 of the scatter)
 };
 
 template <bool FIRST>
@@ -172,13 +176,14 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const SortArgs
   if (a.pass >= a.npass[t]) return;
   const int radix = 1 << a.bits;
   const uint32_t mask = radix - 1;
+  const int shift = (FIRST && a.msd) ? (int)a.shift_t[t] : a.shift;
   for (int d = threadIdx.x; d < radix; d += kSortThreads) s_hist[d] = 0;
   __syncthreads();
   const int64_t tile0 = (int64_t)blk * kSortTile;
 #pragma unroll
   for (int e = 0; e < kSortPerThread; e++) {
     const int64_t i = tile0 + e * kSortThreads + threadIdx.x;
-    if (i < a.N) atomicAdd(&s_hist[(sort_load_key<FIRST>(a, t, i) >> a.shift) & mask], 1u);
+    if (i < a.N) atomicAdd(&s_hist[(sort_load_key<FIRST>(a, t, i) >> shift) & mask], 1u);
   }
   __syncthreads();
   uint32_t* out = a.hist + ((int64_t)t * a.nblk + blk) * radix;
@@ -243,12 +248,16 @@ struct SortOutGlobal { uint2* kp; __device__ __forceinline__ void put(uint32_t d
 struct SortOutLds { uint32_t* k; uint32_t* p; __device__ __forceinline__ void put(uint32_t d, uint32_t key, uint32_t pos) const { k[d] = key; p[d] = pos; } };
 template <int E, class Out>
 __device__ __forceinline__ void sort_rank_and_scatter(const uint32_t (&key)[E], const uint32_t (&pos)[E], const bool (&valid)[E],
-                                                      int shift, int bits, uint32_t mask, uint32_t* wave_off, const Out out) {
+                                                      int shift, int bits, uint32_t mask, uint32_t* wave_off, const Out out, const int ne = E) {
   const int lane = threadIdx.x & 63;
-  volatile uint32_t* my_off = wave_off;
+  // (an LDS-typed pointer: as a generic one the volatile accesses below stayed flat instructions -- and, in the bucket form's window
+  //  sort, tripped a code-generation error of this compiler on the flat null check)
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  volatile lds_u32* my_off = (volatile lds_u32*)wave_off;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int e = 0; e < E; e++) {
+    if (e >= ne) break;                  // (uniform: rounds past the caller's live ones hold no entry)
     const uint32_t d = (key[e] >> shift) & mask;
     unsigned long long peers = __ballot(valid[e]);
     for (int bit = 0; bit < bits; bit++) {
@@ -285,6 +294,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
   const uint32_t mask = radix - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tile0 = (int64_t)blk * kSortTile;
+  const int shift = (FIRST && a.msd) ? (int)a.shift_t[t] : a.shift;
 
   for (int d = threadIdx.x; d < 4 * kMaxRadix; d += kSortThreads) (&s_off[0][0])[d] = 0;
   __syncthreads();
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
       const uint2 kp = valid[e] ? a.src[(int64_t)t * a.N + i] : make_uint2(0u, 0u);
       key[e] = kp.x; pos[e] = kp.y;
     }
-    if (valid[e]) atomicAdd(&s_off[wave][(key[e] >> a.shift) & mask], 1u);
+    if (valid[e]) atomicAdd(&s_off[wave][(key[e] >> shift) & mask], 1u);
   }
   __syncthreads();
 
@@ -332,7 +342,12 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const SortA
     }
   }
   sort_scan_offsets<4, 2>(all_d, before_d, radix, s_off, s_scan, s_wsum);
-  sort_rank_and_scatter<kSortPerThread>(key, pos, valid, a.shift, a.bits, mask, s_off[wave], SortOutGlobal{a.dst + (int64_t)t * a.N});
+  if (FIRST && a.msd && blk == 0) {      // tile 0 has nothing before it: its scan is the table's bucket starts
+    uint32_t* bs = a.bstart + (int64_t)t * (kMaxRadix + 1);
+    for (int d = threadIdx.x; d < radix; d += kSortThreads) bs[d] = s_scan[d];
+    if (threadIdx.x == 0) bs[radix] = (uint32_t)a.N;
+  }
+  sort_rank_and_scatter<kSortPerThread>(key, pos, valid, shift, a.bits, mask, s_off[wave], SortOutGlobal{a.dst + (int64_t)t * a.N});
 }
 
 // ---------------------------------------------------------------------------
@@ -429,6 +444,11 @@ struct RedArgs {
   OptP      op;             // the row rule's parameters (op.lr = the plain update's lr)
   float*    s0[FFH_MAX_TABLES];   // OPT 1: momentum buffer V; OPT 2: first moment M -- [num_entries][D] like the table, or null
   float*    s1[FFH_MAX_TABLES];   // OPT 2: second moment V
+  // bucket form (emb_sgd_reduce_kernel<.., MSD = true>): kp[parity] is ordered by the top digit only
+  uint8_t   shift_t[FFH_MAX_TABLES];   // the digit's position (0: the table is completely sorted)
+  const uint32_t* bstart;         // [nt][kMaxRadix + 1] bucket starts
+  uint32_t* nextkey;              // [nt][nchunks1]: the row id behind each 1024-block (written by the block's last tile, read by its fold)
+  int       radix;
 };
 
 template <int VEC>
@@ -505,7 +525,8 @@ struct RedShared {
 template <int VEC, bool AGENT, int OPT>
 __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const uint2* kp,
                                                  float* partial_t, uint2* meta_t, int64_t N, int nchunks, int tile, int tile_index,
-                                                 int L, int D_, bool avg_, const OptP& op, float* st0, float* st1, RedShared& sh, const int tid = threadIdx.x) {
+                                                 int L, int D_, bool avg_, const OptP& op, float* st0, float* st1, RedShared& sh, const int tid = threadIdx.x,
+                                                 const bool preloaded = false) {
   uint32_t* s_key = sh.key;
   uint32_t* s_pos = sh.pos;
   uint16_t* s_start = sh.start;
@@ -516,14 +537,16 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
   const int n = tile0 >= N ? 0 : (int)((N - tile0) < tile ? (N - tile0) : tile);   // a tile past the end still walks the barriers
   const int lane = tid & 63, wave = tid >> 6;
 
-  for (int i = tid; i < n; i += kRedThreads) {
-    const uint2 e = kp[tile0 + i];
-    s_key[1 + i] = e.x;
-    s_pos[i] = a.L == 1 ? e.y : e.y / (uint32_t)a.L;      // the sample (gradient row) of the entry
-  }
-  if (tid == 0) {
-    s_key[0] = (tile0 > 0 && tile0 < N) ? kp[tile0 - 1].x : 0xFFFFFFFFu;   // no valid key equals it when tile0 == 0 (checked below)
-    s_key[1 + n] = (tile0 + n < N) ? kp[tile0 + n].x : 0xFFFFFFFFu;
+  if (!preloaded) {       // (preloaded: the caller has filled s_key[0 .. n + 1] and s_pos[0 .. n) -- the bucket form, msd_window)
+    for (int i = tid; i < n; i += kRedThreads) {
+      const uint2 e = kp[tile0 + i];
+      s_key[1 + i] = e.x;
+      s_pos[i] = a.L == 1 ? e.y : e.y / (uint32_t)a.L;      // the sample (gradient row) of the entry
+    }
+    if (tid == 0) {
+      s_key[0] = (tile0 > 0 && tile0 < N) ? kp[tile0 - 1].x : 0xFFFFFFFFu;   // no valid key equals it when tile0 == 0 (checked below)
+      s_key[1 + n] = (tile0 + n < N) ? kp[tile0 + n].x : 0xFFFFFFFFu;
+    }
   }
   const int metas = 2 * (tile / FFH_EMB_CHUNK);
   if (tid < metas) s_meta[tid] = make_uint2(kMetaNone, 0);
@@ -635,11 +658,12 @@ template <int VEC, bool AGENT, int OPT>
 __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const float* part, const uint2* meta, float* pout_t, uint2* mout_t,
                                                 int nin, int ratio, int D, const OptP& op, float* st0, float* st1, int64_t slot_lo, int64_t slot_hi,
                                                 int64_t group0, int64_t ngroups, const uint2* keys = nullptr,
-                                                const uint2* staged = nullptr, int64_t staged_lo = 0, int staged_n = 0) {
+                                                const uint2* staged = nullptr, int64_t staged_lo = 0, int staged_n = 0,
+                                                const uint32_t* nextkey = nullptr) {
   // `staged`: an LDS copy of meta[staged_lo, staged_lo + staged_n) the caller fetched with one parallel load (the in-kernel folds:
   // a dependent memory round trip per slot and lane-group would otherwise be most of the fold)
   auto slot_meta = [&](int64_t sl) -> uint2 {
-    if (staged && sl >= staged_lo && sl < staged_lo + staged_n) return staged[sl - staged_lo];
+    if (sl >= staged_lo && sl < staged_lo + staged_n) return staged[sl - staged_lo];      // (staged_n = 0: nothing staged)
     return xwg_load2<AGENT>(meta + sl);
   };
   const int nvec = D / VEC;
@@ -678,7 +702,8 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
     if (b2 == bend && bend < nin) {
       // the run reached the end of the block: it continues iff the entry behind the block carries the same id (sorted list);
       // equivalently the next block's first slot is a continuation of this id
-      if (keys) cont_after = keys[bend * FFH_EMB_CHUNK].x == m.y;
+      if (nextkey) cont_after = __hip_atomic_load(nextkey + B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == m.y;    // (bucket form: the list in memory is not sorted)
+      else if (keys) cont_after = keys[bend * FFH_EMB_CHUNK].x == m.y;
       else { const uint2 m3 = slot_meta(2 * bend); cont_after = (m3.x == kMetaCont && m3.y == m.y); }
     }
     const bool head = m.x == kMetaFirst;
@@ -715,6 +740,351 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
   }
 }
 
+// ---------------------------------------------------------------------------
+// bucket form of the fused update (round 5; calls of <= 64 K lookups per table): ONE stable pass on the top digit of the row ids
+// (radix_hist_kernel + radix_scatter_kernel with msd set: the list ends up grouped by bucket, in position order inside a bucket),
+// and every tile of the apply launch makes the rest of the order for ITSELF in LDS -- three launches instead of seven at the
+// per-rank shape of the 8-GPU job, where the sort was six dependent launches of ~7 us with a few kilobytes of work each.
+//   * A tile needs the sorted entries [tile0 - 1, tile0 + n] (its own and the row id on either side).  An entry's sorted index
+//     is its bucket's start plus its rank inside the bucket, so the tile loads every bucket that overlaps that index range WHOLE
+//     (the window: ~tile + two average buckets), sorts the window by row id with the stable LDS radix passes of the small-batch
+//     kernel (ids relative to the window's first bucket: two or three passes), and reads its entries off the window at
+//     offset (tile0 - 1) - start(first bucket).  The canonical order (FFH_EMB_CHUNK cuts of the SORTED index) is untouched: what the
+//     tile adds and where its partial rows go is decided by exactly the same list as before, so the result is bit-identical.
+//   * A window larger than kWinMax entries (a hot row: thousands of hits in one bucket) is cut down to exactly the entries wanted:
+//     the row id and occurrence number of the entry at a given rank of a bucket are found by counting (msd_select: one pass over
+//     the bucket per nine id bits), and one more pass copies the entries between the two bounds in list order (msd_collect).  Cost
+//     ~ bucket size per overlapping tile; no fallback launch, no second code path on the host.
+//   * The fold of a 1024-block asks whether a run goes on behind the block: the last tile of every block leaves the row id behind
+//     it in `nextkey` (the list in memory is no longer sorted).
+// ---------------------------------------------------------------------------
+constexpr int kWinMax = 1536;                     // entries of a tile's window: tile (<= 1024) + 2 + the two edge buckets
+constexpr int kWinE = kWinMax / kRedThreads;      // ... per thread
+struct alignas(16) MsdShared {
+  uint32_t k[kWinMax], p[kWinMax];                // the window: row id relative to its first bucket, position
+  uint32_t off[4][kMaxRadix];
+  uint32_t scan[kMaxRadix];
+  uint32_t bs[kMaxRadix + 1];                     // the table's bucket starts
+  uint32_t wsum[4];
+  uint32_t w[3][4];
+  uint32_t misc[8];
+};
+
+// stable LSD radix sort of the window's `cnt` entries on the low `bitsw` bits of k[]
+__device__ __forceinline__ void msd_sort_window(MsdShared& ms, const uint32_t cnt, const int bitsw) {
+  if (bitsw <= 0 || cnt <= 1) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int np = (bitsw + kMaxRadixBits - 1) / kMaxRadixBits, rbw = (bitsw + np - 1) / np;
+  const int radixw = 1 << rbw;
+  const uint32_t mask = (uint32_t)radixw - 1u;
+  const int span = (((int)cnt + 3) / 4 + 63) / 64 * 64;       // consecutive entries per wave
+  const int ne = span / 64;                                   // <= kWinE
+  uint32_t key[kWinE], pos[kWinE];
+  bool valid[kWinE];
+  auto fetch = [&]() {
+#pragma unroll
+    for (int e = 0; e < kWinE; e++) {
+      const int i = wave * span + e * 64 + lane;
+      valid[e] = e < ne && i < (int)cnt;
+      key[e] = valid[e] ? ms.k[i] : 0u;
+      pos[e] = valid[e] ? ms.p[i] : 0u;
+    }
+  };
+  fetch();
+  __syncthreads();
+  for (int p = 0; p < np; p++) {
+    for (int w2 = 0; w2 < 4; w2++)
+      for (int d = threadIdx.x; d < radixw; d += kRedThreads) ms.off[w2][d] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < kWinE; e++)
+      if (valid[e]) atomicAdd(&ms.off[wave][(key[e] >> (p * rbw)) & mask], 1u);
+    __syncthreads();
+    uint32_t all_d[2] = {0, 0};
+    const uint32_t before_d[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int d = threadIdx.x + q * kRedThreads;
+      if (d < radixw) all_d[q] = ms.off[0][d] + ms.off[1][d] + ms.off[2][d] + ms.off[3][d];
+    }
+    sort_scan_offsets<4, 2>(all_d, before_d, radixw, ms.off, ms.scan, ms.wsum);
+    sort_rank_and_scatter<kWinE>(key, pos, valid, p * rbw, rbw, mask, ms.off[wave], SortOutLds{ms.k, ms.p}, ne);
+    __syncthreads();
+    if (p + 1 < np) { fetch(); __syncthreads(); }
+  }
+}
+
+// The usual window (whole buckets, a few dozen entries each) without a single workgroup barrier: buckets are independent sort
+// domains, so every wave takes a run of whole buckets (those that start in its quarter of the window), holds its <= 256 entries in
+// registers and runs the stable passes on its own 128-counter table -- seven-bit digits of the id relative to its first bucket, two
+// counters per lane for the scan, the ranking of sort_rank_and_scatter.  (A count-the-smaller-ones sort was tried first: n^2 / 256
+// 64-bit compares per thread cost more than the three radix passes it replaced.)  False: some wave's share is larger -- the caller
+// runs the workgroup-wide passes instead.
+constexpr int kWaveE = 4;
+struct SortOutLdsBase {
+  uint32_t* k; uint32_t* p; uint32_t kb;
+  __device__ __forceinline__ void put(uint32_t d, uint32_t key, uint32_t pos) const { k[d] = key + kb; p[d] = pos; }
+};
+__device__ __forceinline__ bool msd_sort_waves(MsdShared& ms, const uint32_t cnt, const int d_lo, const int d_hi, const int shift, const uint32_t ws) {
+  typedef __attribute__((address_space(3))) uint32_t lds_u32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t t_lo = (uint32_t)(((unsigned long long)wave * cnt) >> 2), t_hi = (uint32_t)(((unsigned long long)(wave + 1) * cnt) >> 2);
+  int n_lo = 0, n_hi = 0;                        // buckets from d_lo on that start below t_lo / t_hi
+  for (int b0 = d_lo; b0 <= d_hi; b0 += 64) {
+    const int b = b0 + lane;
+    const uint32_t st = b <= d_hi ? ms.bs[b] - ws : 0xFFFFFFFFu;
+    n_lo += __popcll(__ballot(st < t_lo));
+    n_hi += __popcll(__ballot(st < t_hi));
+  }
+  if (wave == 3) n_hi = d_hi - d_lo + 1;
+  const int fb = d_lo + n_lo, lb = d_lo + n_hi;  // this wave's buckets [fb, lb)
+  const uint32_t seg0 = ms.bs[fb] - ws, seg1 = ms.bs[lb] - ws;      // (bs[d_hi + 1] - ws = cnt)
+  const uint32_t m = seg1 - seg0;
+  if (lane == 0) ms.wsum[wave] = m;
+  __syncthreads();
+  const bool ok = ms.wsum[0] <= 64u * kWaveE && ms.wsum[1] <= 64u * kWaveE && ms.wsum[2] <= 64u * kWaveE && ms.wsum[3] <= 64u * kWaveE;
+  __syncthreads();
+  if (!ok) return false;
+  if (m > 1) {
+    int bitsw = shift;
+    for (uint32_t sp = (uint32_t)(lb - fb - 1); sp; sp >>= 1) bitsw++;
+    const int np = (bitsw + 6) / 7, rbw = (bitsw + np - 1) / np;
+    const uint32_t mask = (1u << rbw) - 1u;
+    const uint32_t kb = (uint32_t)(fb - d_lo) << shift;               // ms.k holds ids relative to bucket d_lo
+    const int ne = ((int)m + 63) / 64;
+    volatile lds_u32* const K = (volatile lds_u32*)(ms.k + seg0);
+    volatile lds_u32* const P = (volatile lds_u32*)(ms.p + seg0);
+    volatile lds_u32* const H = (volatile lds_u32*)ms.off[wave];
+    uint32_t key[kWaveE], pos[kWaveE];
+    bool valid[kWaveE];
+#pragma unroll
+    for (int e = 0; e < kWaveE; e++) {
+      const uint32_t i = (uint32_t)(e * 64 + lane);
+      valid[e] = e < ne && i < m;
+      key[e] = valid[e] ? K[i] - kb : 0u;
+      pos[e] = valid[e] ? P[i] : 0u;
+    }
+    for (int p = 0; p < np; p++) {
+      H[lane] = 0u; H[lane + 64] = 0u;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e = 0; e < kWaveE; e++)
+        if (valid[e]) __hip_atomic_fetch_add((lds_u32*)(H + ((key[e] >> (p * rbw)) & mask)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __builtin_amdgcn_wave_barrier();
+      const uint32_t c0 = H[2 * lane], c1 = H[2 * lane + 1], cs = c0 + c1;
+      uint32_t incl = cs;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t nb = __shfl_up(incl, o);
+        if (lane >= o) incl += nb;
+      }
+      __builtin_amdgcn_wave_barrier();
+      H[2 * lane] = incl - cs; H[2 * lane + 1] = incl - cs + c0;
+      __builtin_amdgcn_wave_barrier();
+      sort_rank_and_scatter<kWaveE>(key, pos, valid, p * rbw, rbw, mask, ms.off[wave], SortOutLdsBase{ms.k + seg0, ms.p + seg0, kb}, ne);
+      __builtin_amdgcn_wave_barrier();
+      if (p + 1 < np) {
+#pragma unroll
+        for (int e = 0; e < kWaveE; e++) {
+          const uint32_t i = (uint32_t)(e * 64 + lane);
+          if (valid[e]) { key[e] = K[i] - kb; pos[e] = P[i]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+  return true;
+}
+
+// the entry of rank r (by row id, then list order) of the bucket kp[s, e) (every id there has the top digit dbase >> shift): its row id
+// and how many entries with that id precede it.  r < e - s.
+__device__ __forceinline__ void msd_select(const uint2* __restrict__ kp, const int64_t s, const int64_t e, const uint32_t r, const int shift,
+                                           const uint32_t dbase, MsdShared& ms, uint32_t& row, uint32_t& app) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* h = ms.off[0];
+  uint32_t pv = 0, rr = r;
+  int pl = 0;
+  while (pl < shift) {
+    const int dg = (shift - pl) < kMaxRadixBits ? (shift - pl) : kMaxRadixBits;
+    const int up = shift - pl, sh2 = up - dg;
+    const uint32_t dmask = (1u << dg) - 1u;
+    for (int d = tid; d < kMaxRadix; d += kRedThreads) h[d] = 0;
+    __syncthreads();
+    for (int64_t base = s; base < e; base += kRedThreads * 8) {
+      uint32_t kk[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int64_t i = base + u * kRedThreads + tid;
+        kk[u] = i < e ? kp[i].x - dbase : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int64_t i = base + u * kRedThreads + tid;
+        if (i < e && (kk[u] >> up) == pv) atomicAdd(&h[(kk[u] >> sh2) & dmask], 1u);      // (up < 32; ids below the bucket's digit: kk < 2^shift)
+      }
+    }
+    __syncthreads();
+    // the digit whose candidates hold rank rr: thread t owns digits 2t, 2t + 1
+    const uint32_t c0 = h[2 * tid], c1 = h[2 * tid + 1], cc = c0 + c1;
+    uint32_t incl = cc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t nb = __shfl_up(incl, o);
+      if (lane >= o) incl += nb;
+    }
+    if (lane == 63) ms.wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w2 = 0; w2 < wave; w2++) woff += ms.wsum[w2];
+    const uint32_t excl = woff + incl - cc;
+    if (rr >= excl && rr < excl + cc) {
+      const bool second = rr >= excl + c0;
+      ms.misc[0] = 2u * tid + (second ? 1u : 0u);
+      ms.misc[1] = rr - excl - (second ? c0 : 0u);
+    }
+    __syncthreads();
+    pv = (pv << dg) | ms.misc[0];
+    rr = ms.misc[1];
+    pl += dg;
+    __syncthreads();
+  }
+  row = dbase + pv;
+  app = rr;
+}
+
+// appends, in list order, the entries of kp[s, e) from (row0, occurrence app0) on [has_lo] and before (row1, occurrence app1) [has_hi]
+// to the window; `count` (uniform) = entries in the window
+__device__ __forceinline__ void msd_collect(const uint2* __restrict__ kp, const int64_t s, const int64_t e, const bool has_lo, const uint32_t row0, const uint32_t app0,
+                                            const bool has_hi, const uint32_t row1, const uint32_t app1, const uint32_t kbase, MsdShared& ms, uint32_t& count) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t run0 = 0, run1 = 0;
+  for (int64_t base = s; base < e; base += 4 * kRedThreads) {
+    uint2 v[4];
+    bool val[4], m0[4], m1[4];
+    uint32_t i0[4], i1[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int64_t i = base + wave * 256 + r * 64 + lane;
+      val[r] = i < e;
+      v[r] = val[r] ? kp[i] : make_uint2(0u, 0u);
+    }
+    uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      m0[r] = val[r] && has_lo && v[r].x == row0;
+      m1[r] = val[r] && has_hi && v[r].x == row1;
+      const unsigned long long b0 = __ballot(m0[r]), b1 = __ballot(m1[r]);
+      i0[r] = w0 + __popcll(b0 & lt); i1[r] = w1 + __popcll(b1 & lt);
+      w0 += __popcll(b0); w1 += __popcll(b1);
+    }
+    if (lane == 0) { ms.w[0][wave] = w0; ms.w[1][wave] = w1; }
+    __syncthreads();
+    uint32_t o0 = run0, o1 = run1, t0 = 0, t1 = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+      const uint32_t q0 = ms.w[0][w2], q1 = ms.w[1][w2];
+      if (w2 < wave) { o0 += q0; o1 += q1; }
+      t0 += q0; t1 += q1;
+    }
+    bool take[4];
+    uint32_t tp[4], wt = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const bool ge = !has_lo || v[r].x > row0 || (m0[r] && o0 + i0[r] >= app0);
+      const bool ltb = !has_hi || v[r].x < row1 || (m1[r] && o1 + i1[r] < app1);
+      take[r] = val[r] && ge && ltb;
+      const unsigned long long bt = __ballot(take[r]);
+      tp[r] = wt + __popcll(bt & lt);
+      wt += __popcll(bt);
+    }
+    if (lane == 0) ms.w[2][wave] = wt;
+    __syncthreads();
+    uint32_t ot = count, tt = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; w2++) {
+      const uint32_t q = ms.w[2][w2];
+      if (w2 < wave) ot += q;
+      tt += q;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t dst = ot + tp[r];
+      if (take[r] && dst < (uint32_t)kWinMax) { ms.k[dst] = v[r].x - kbase; ms.p[dst] = v[r].y; }
+    }
+    run0 += t0; run1 += t1; count += tt;
+    __syncthreads();
+  }
+}
+
+// The sorted entries [tile0 - 1, tile0 + n] of table `kp` (grouped by top digit, bucket starts bs_g) for the reduce body: thread t
+// gets elements j = t + 256 r (r < 5) of the array { id before the tile, the tile's n ids, id behind it } in okey[r] and the
+// position of entry j - 1 in opos[r]; the caller copies them into RedShared (which shares its memory with ms) behind a barrier.
+__device__ __forceinline__ void msd_window(const uint2* __restrict__ kp, const uint32_t* __restrict__ bs_g, const int radix, const int shift,
+                                           const int64_t N, const int64_t tile0, const int n, MsdShared& ms, uint32_t (&okey)[5], uint32_t (&opos)[5]) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool have_before = tile0 > 0, have_after = tile0 + n < N;
+  const uint32_t a = (uint32_t)(have_before ? tile0 - 1 : tile0), b = (uint32_t)(tile0 + n + (have_after ? 1 : 0));      // sorted indices [a, b)
+  for (int d = tid; d <= radix; d += kRedThreads) ms.bs[d] = bs_g[d];
+  if (tid < 2) ms.misc[tid] = 0;
+  __syncthreads();
+  {
+    uint32_t ca = 0, cb = 0;
+    for (int d = tid; d < radix; d += kRedThreads) {
+      const uint32_t v = ms.bs[d];
+      ca += v <= a ? 1u : 0u;
+      cb += v <= b - 1u ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ca += __shfl_xor(ca, o); cb += __shfl_xor(cb, o); }
+    if (lane == 0) { atomicAdd(&ms.misc[0], ca); atomicAdd(&ms.misc[1], cb); }
+  }
+  __syncthreads();
+  const int d_lo = (int)ms.misc[0] - 1, d_hi = (int)ms.misc[1] - 1;           // the buckets holding index a and index b - 1
+  const uint32_t ws = ms.bs[d_lo], we = ms.bs[d_hi + 1];
+  const uint32_t kbase = (uint32_t)d_lo << shift;
+  uint32_t cnt, o;
+  __syncthreads();                                                            // (misc is reused below)
+  const bool whole_buckets = we - ws <= (uint32_t)kWinMax;
+  if (whole_buckets) {
+    cnt = we - ws; o = a - ws;
+    for (uint32_t i = tid; i < cnt; i += kRedThreads) {
+      const uint2 v = kp[ws + i];
+      ms.k[i] = v.x - kbase; ms.p[i] = v.y;
+    }
+  } else {
+    // cut the edge buckets down to the ranks wanted
+    cnt = 0; o = 0;
+    const uint32_t s_lo = ws, e_lo = ms.bs[d_lo + 1], s_hi = ms.bs[d_hi], e_hi = we;
+    uint32_t row0 = 0, app0 = 0, row1 = 0, app1 = 0;
+    const bool has_lo = a > s_lo, has_hi = b < e_hi;
+    if (has_lo) msd_select(kp, s_lo, e_lo, a - s_lo, shift, kbase, ms, row0, app0);
+    if (has_hi) msd_select(kp, s_hi, e_hi, b - s_hi, shift, (uint32_t)d_hi << shift, ms, row1, app1);
+    if (d_lo == d_hi) {
+      msd_collect(kp, s_lo, e_lo, has_lo, row0, app0, has_hi, row1, app1, kbase, ms, cnt);
+    } else {
+      msd_collect(kp, s_lo, e_lo, has_lo, row0, app0, false, 0u, 0u, kbase, ms, cnt);
+      if (s_hi > e_lo) msd_collect(kp, e_lo, s_hi, false, 0u, 0u, false, 0u, 0u, kbase, ms, cnt);
+      msd_collect(kp, s_hi, e_hi, false, 0u, 0u, has_hi, row1, app1, kbase, ms, cnt);
+    }
+  }
+  __syncthreads();
+  int bitsw = shift;
+  for (uint32_t span = (uint32_t)(d_hi - d_lo); span; span >>= 1) bitsw++;
+  if (!whole_buckets || !msd_sort_waves(ms, cnt, d_lo, d_hi, shift, ws)) msd_sort_window(ms, cnt, bitsw);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    const int j = tid + kRedThreads * r;
+    okey[r] = 0xFFFFFFFFu; opos[r] = 0u;
+    if (j <= n + 1) {
+      const bool real = (j > 0 || have_before) && (j <= n || have_after);
+      const uint32_t wi = o + (uint32_t)j - (have_before ? 0u : 1u);
+      if (real) { okey[r] = ms.k[wi] + kbase; opos[r] = ms.p[wi]; }
+    }
+  }
+}
+
 // step 2 + 3 in one launch.  The folds (step 3, above) used to be two more launches; now the LAST tile of a 1024-block to finish
 // folds that block's 32-block partials (the classic last-arriver reduction: an arrival counter per block, with write-through
 // stores / sc1 loads of the few cross-workgroup values in place of fences, see xwg_*), and the last 1024-block of a table to be
@@ -725,12 +1095,18 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
 // and the launch takes 336 instead of 230 us.
 // OPT != 0 (momentum / weight-decay SGD, Adam on the touched rows): the row rule holds up to three more rows' worth of registers;
 // those instantiations are compiled for 4 waves per SIMD instead of spilling.
-template <int VEC, int OPT>
-__global__ __launch_bounds__(kRedThreads, OPT == 0 ? 8 : 4) void emb_sgd_reduce_kernel(const RedArgs a) {
+// MSD: the bucket form above (the list is grouped by top digit only; six workgroups per CU: the window needs 25 KB of LDS).
+struct RedSmem { RedShared sh; uint2 fmeta[kFoldStage]; };
+union MsdSmem { RedSmem red; MsdShared ms; };          // the window is dead once the tile's entries sit in registers
+template <bool MSD> struct RedSmemOf { typedef RedSmem type; static __device__ __forceinline__ RedSmem& red(RedSmem& s) { return s; } };
+template <> struct RedSmemOf<true> { typedef MsdSmem type; static __device__ __forceinline__ RedSmem& red(MsdSmem& s) { return s.red; } };
+template <int VEC, int OPT, bool MSD = false>
+__global__ __launch_bounds__(kRedThreads, MSD ? (OPT == 0 ? 6 : 4) : (OPT == 0 ? 8 : 4)) void emb_sgd_reduce_kernel(const RedArgs a) {
   ffh_kernel_prio();
-  __shared__ RedShared sh;
+  __shared__ typename RedSmemOf<MSD>::type smem;
   __shared__ int s_last;
-  __shared__ uint2 s_fmeta[kFoldStage];
+  RedShared& sh = RedSmemOf<MSD>::red(smem).sh;
+  uint2* const s_fmeta = RedSmemOf<MSD>::red(smem).fmeta;
   const int tix = blockIdx.y;
   const ffh_emb_table& tb = a.t[tix];
   const uint2* keys = a.kp[a.parity[tix]] + (int64_t)tix * a.N;
@@ -738,8 +1114,28 @@ __global__ __launch_bounds__(kRedThreads, OPT == 0 ? 8 : 4) void emb_sgd_reduce_
   uint2* m0 = a.meta + (int64_t)tix * 2 * a.nchunks;
   float* const st0 = a.s0[tix];
   float* const st1 = a.s1[tix];
+  bool preloaded = false;
+  if constexpr (MSD) {
+    const int shift = a.shift_t[tix];
+    const int64_t tile0m = (int64_t)blockIdx.x * a.tile;
+    const int nm = tile0m >= a.N ? 0 : (int)((a.N - tile0m) < a.tile ? (a.N - tile0m) : a.tile);
+    if (shift > 0 && nm > 0) {         // (shift 0: the one pass sorted the table completely)
+      uint32_t okey[5], opos[5];
+      msd_window(keys, a.bstart + (int64_t)tix * (kMaxRadix + 1), a.radix, shift, a.N, tile0m, nm, smem.ms, okey, opos);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 5; r++) {
+        const int j = (int)threadIdx.x + kRedThreads * r;
+        if (j <= nm + 1) {
+          sh.key[j] = okey[r];
+          if (j >= 1 && j <= nm) sh.pos[j - 1] = a.L == 1 ? opos[r] : opos[r] / (uint32_t)a.L;
+        }
+      }
+      preloaded = true;
+    }
+  }
   reduce_tile_body<VEC, true, OPT>(tb, keys, p0, m0, a.N, a.nchunks, a.tile,
-                        (int)blockIdx.x, a.L, a.D, a.avg != 0, a.op, st0, st1, sh);
+                        (int)blockIdx.x, a.L, a.D, a.avg != 0, a.op, st0, st1, sh, threadIdx.x, preloaded);
 
   const int nvec = a.D / VEC;
   const int lpr = nvec < 64 ? nvec : 64;
@@ -757,6 +1153,12 @@ __global__ __launch_bounds__(kRedThreads, OPT == 0 ? 8 : 4) void emb_sgd_reduce_
   const int64_t B1 = tile0 / FFH_EMB_CHUNK1;
   const int64_t blk_end = (B1 + 1) * FFH_EMB_CHUNK1 < a.N ? (B1 + 1) * FFH_EMB_CHUNK1 : a.N;
   const uint32_t tiles_in_block = (uint32_t)((blk_end - B1 * FFH_EMB_CHUNK1 + a.tile - 1) / a.tile);
+  uint32_t* const nextkey = MSD ? a.nextkey + (int64_t)tix * a.nchunks1 : nullptr;
+  if constexpr (MSD) {
+    // the block's last tile: the row id behind the block, for whoever folds it
+    const int64_t tend = tile0 + a.tile < a.N ? tile0 + a.tile : a.N;
+    if (threadIdx.x == 0 && tend == blk_end) __hip_atomic_store(nextkey + B1, sh.key[1 + (int)(tend - tile0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   xwg_stores_done();
   __syncthreads();
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&arrive[B1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tiles_in_block - 1u;
@@ -779,7 +1181,7 @@ __global__ __launch_bounds__(kRedThreads, OPT == 0 ? 8 : 4) void emb_sgd_reduce_
     const int64_t lo = 2 * B1 * kRatio;
     const int64_t hi = lo + 2 * kRatio < 2 * (int64_t)a.nchunks ? lo + 2 * kRatio : 2 * (int64_t)a.nchunks;
     if (stage(m0, lo, hi))
-      fold_table_body<VEC, true, OPT>(tb, p0, m0, p1, m1, a.nchunks, kRatio, a.D, a.op, st0, st1, lo, hi, group0, ngroups, keys, s_fmeta, lo, (int)(hi - lo));
+      fold_table_body<VEC, true, OPT>(tb, p0, m0, p1, m1, a.nchunks, kRatio, a.D, a.op, st0, st1, lo, hi, group0, ngroups, MSD ? nullptr : keys, s_fmeta, lo, (int)(hi - lo), nextkey);
     xwg_stores_done();
     __syncthreads();
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(&arrive[a.nchunks1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)a.nchunks1 - 1u;
@@ -932,7 +1334,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct BwdLayout {
-  size_t kp_a, kp_b, hist, partial, meta, partial1, meta1, arrive, total;
+  size_t kp_a, kp_b, hist, partial, meta, partial1, meta1, arrive, bstart, total;
   int nblk, nchunks, nchunks1;
 };
 
@@ -969,6 +1371,7 @@ inline BwdLayout bwd_layout(int nt, int L, int D, int64_t batch) {
   l.partial1 = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks1 * (size_t)D * sizeof(float), 256);
   l.meta1 = o; o += align_up((size_t)nt * 2 * (size_t)l.nchunks1 * sizeof(uint2), 256);
   l.arrive = o; o += align_up((size_t)nt * ((size_t)l.nchunks1 + 1) * sizeof(uint32_t), 256);
+  l.bstart = o; o += align_up((size_t)nt * (kMaxRadix + 1) * sizeof(uint32_t), 256);      // (bucket form; its nextkey array lives in `hist`, free by then)
   l.total = o;
   return l;
 }
@@ -1129,6 +1532,7 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
 
   if (N <= kSmallMax) {
     // small-batch path: one launch, one workgroup per table (see emb_sgd_small_kernel): the sort lives inside it
+    snprintf(c->emb_route, sizeof c->emb_route, "small");
     if (!do_apply) return FFH_OK;
     int bits_s = 1;
     while (bits_s < 32 && ((maxR - 1) >> bits_s) != 0) bits_s++;
@@ -1162,8 +1566,17 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
   // radix plan: digits of <= 9 bits covering bit_length(maxR-1); a table only runs the passes its own ids need
   int bits = 1;
   while (bits < 32 && ((maxR - 1) >> bits) != 0) bits++;
-  const int passes = (bits + kMaxRadixBits - 1) / kMaxRadixBits;
-  const int rb = (bits + passes - 1) / passes;
+  // bucket form (msd_window): one pass on the top digit, the rest inside the apply launch.  Where the LSD form would need >= 2 passes
+  // and a bucket averages <= 128 entries (N <= 64 K at 512 buckets); the digit: ~32 entries per bucket, 4 .. 9 bits
+  static const int msd_env = FFH_LAB_INT("FFH_EMB_MSD", 1);          // A/B switch: 0 = never, 1 = by shape, 2 = wherever it is valid
+  static const int msd_max_tables = FFH_LAB_INT("FFH_EMB_MSD_MAX_TABLES", FFH_MAX_TABLES);      // (first rule: <= 8 tables; at 26 tables x 32768 lookups the form takes 196 instead of 238 us)
+  int mb = 4;
+  while (mb < kMaxRadixBits && (N >> (mb + 1)) >= 32) mb++;
+  const bool msd = msd_env != 0 && bits > kMaxRadixBits && N <= 65536 && (N >> mb) <= 128 && (msd_env == 2 || nt <= msd_max_tables) &&
+                   (size_t)lay.nblk * kMaxRadix >= (size_t)lay.nchunks1;
+  const int passes = msd ? 1 : (bits + kMaxRadixBits - 1) / kMaxRadixBits;
+  const int rb = msd ? mb : (bits + passes - 1) / passes;
+  if (msd) snprintf(c->emb_route, sizeof c->emb_route, "buckets:bits=%d", rb); else snprintf(c->emb_route, sizeof c->emb_route, "lsd:passes=%d", passes);
 
   SortArgs sa;
   memset(&sa, 0, sizeof sa);
@@ -1173,10 +1586,14 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
     sa.idx[i] = tables[i].idx;
     int tb = 1;
     while (tb < 32 && ((tables[i].num_entries - 1) >> tb) != 0) tb++;
-    const int np = (tb + rb - 1) / rb;
+    const int np = msd ? 1 : (tb + rb - 1) / rb;
     sa.npass[i] = (uint8_t)np;
     ra.parity[i] = (uint8_t)(np & 1);
+    sa.shift_t[i] = ra.shift_t[i] = (uint8_t)(msd && tb > rb ? tb - rb : 0);
   }
+  sa.msd = msd ? 1 : 0;
+  sa.bstart = (uint32_t*)(ws + lay.bstart);
+  ra.bstart = sa.bstart; ra.nextkey = (uint32_t*)(ws + lay.hist); ra.radix = 1 << rb;
   sa.hist = (uint32_t*)(ws + lay.hist);
   sa.N = N; sa.nblk = lay.nblk; sa.bits = rb;
   sa.clear[0] = (uint32_t*)(ws + lay.meta1); sa.nclear[0] = 4 * lay.nchunks1;     // uint2 slots, two per 1024-block
@@ -1206,6 +1623,10 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
   for (int i = 0; i < nt; i++) ra.t[i] = tables[i];
   ra.kp[0] = kbuf[0]; ra.kp[1] = kbuf[1];
   ra.tile = reduce_tile(nt, N);
+  {
+    static const int msd_tile = FFH_LAB_INT("FFH_EMB_MSD_TILE", 0);      // A/B switch: the bucket form's tile
+    if (msd && msd_tile >= 128 && msd_tile <= kRedTile && (msd_tile & (msd_tile - 1)) == 0) ra.tile = msd_tile;
+  }
   ra.partial = (float*)(ws + lay.partial);
   ra.meta = (uint2*)(ws + lay.meta);
   ra.N = N; ra.nchunks = lay.nchunks; ra.L = L; ra.D = D;
@@ -1217,10 +1638,11 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
   ra.arrive = (uint32_t*)(ws + lay.arrive);
   // segmented sums + both folds (32-block partials -> 1024-block partials -> row totals) + the SGD step: one launch
   dim3 rgrid((unsigned)((N + ra.tile - 1) / ra.tile), (unsigned)nt);
-#define FFH_RED(OPTV)                                                                                                 \
-  { if (v4) hipLaunchKernelGGL((emb_sgd_reduce_kernel<4, OPTV>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);        \
-    else hipLaunchKernelGGL((emb_sgd_reduce_kernel<1, OPTV>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra); }
-  if (kind == FFH_SPARSE_OPT_SGD) FFH_RED(0) else if (kind == FFH_SPARSE_OPT_SGD_MOMENTUM) FFH_RED(1) else FFH_RED(2)
+#define FFH_RED(OPTV, MSDV)                                                                                                 \
+  { if (v4) hipLaunchKernelGGL((emb_sgd_reduce_kernel<4, OPTV, MSDV>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);        \
+    else hipLaunchKernelGGL((emb_sgd_reduce_kernel<1, OPTV, MSDV>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra); }
+  if (msd) { if (kind == FFH_SPARSE_OPT_SGD) FFH_RED(0, true) else if (kind == FFH_SPARSE_OPT_SGD_MOMENTUM) FFH_RED(1, true) else FFH_RED(2, true) }
+  else { if (kind == FFH_SPARSE_OPT_SGD) FFH_RED(0, false) else if (kind == FFH_SPARSE_OPT_SGD_MOMENTUM) FFH_RED(1, false) else FFH_RED(2, false) }
 #undef FFH_RED
   FFH_LAUNCH_CHECK(c, "emb_sgd_reduce/fold");
   return FFH_OK;

@@ -41,6 +41,7 @@ struct ffh_ctx {
   const void* emb_sorted_ws;     // ffh_embedding_bwd_sort_multi left a sorted list (and cleared fold counters) in THIS workspace ...
   int64_t     emb_sorted_sig[4]; // ... for this (ntables, in_dim, out_dim, batch): ffh_embedding_bwd_sgd_apply_multi consumes it, once
   char        route[256]; // ffh_linear_last_route(): kernel families of the latest ffh_linear_* call
+  char        emb_route[64]; // ffh_embedding_last_route(): the form the latest fused table update took
   char        err[512];
 };
 

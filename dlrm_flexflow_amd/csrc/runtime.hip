@@ -101,6 +101,7 @@ int ffh_ctx_destroy(ffh_ctx* c) {
 
 const char* ffh_last_error_string(const ffh_ctx* c) { return c ? c->err : "null ctx"; }
 const char* ffh_linear_last_route(const ffh_ctx* c) { return c ? c->route : ""; }
+const char* ffh_embedding_last_route(const ffh_ctx* c) { return c ? c->emb_route : ""; }
 
 int ffh_device_query(ffh_ctx* c, ffh_device_info* info) {
   if (!c || !info) return FFH_ERR_BAD_ARG;

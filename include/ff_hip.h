@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 12   /* 12: ffh_mlp_chain_fwd / _bwd (a chain of narrow Linear layers as three launches), ffh_ctx_reserve_scratch; 11: ffh_stream_create_with_priority; 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 13   /* 13: ffh_embedding_last_route; 12: ffh_mlp_chain_fwd / _bwd (a chain of narrow Linear layers as three launches), ffh_ctx_reserve_scratch; 11: ffh_stream_create_with_priority; 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -302,6 +302,11 @@ int ffh_embedding_bwd_sort_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int 
                                  int in_dim, int out_dim, int64_t batch, ffh_stream s);
 int ffh_embedding_bwd_sgd_apply_multi(ffh_ctx* ctx, const ffh_emb_table* tables, int ntables,
                                       int in_dim, int out_dim, int64_t batch, int aggr, float lr, ffh_stream s);
+/* Which form the most recent fused table update on this ctx took (diagnostic, like ffh_linear_last_route; the result is the same
+ * bits in every form): "small" (one launch, <= 2048 lookups per table), "lsd:passes=P" (P stable LSD passes + the apply launch), or
+ * "buckets:bits=M" (one stable pass on the top M id bits, the rest of the order made per tile inside the apply launch: three launches;
+ * calls of <= 64 K lookups per table whose ids need more than one pass).  The oracle returns "oracle". */
+const char* ffh_embedding_last_route(const ffh_ctx* ctx);
 
 /* Any optimizer on the sorted segments (ABI 8; SURVEY 8f-4 "needs per-row state for the sparse variant").  The reference runs
  * sgd_update / adam_update over EVERY element of a parameter [ref: src/runtime/optimizer_kernel.cu:23-41,206-226] -- for an embedding
@@ -645,7 +650,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_fwd) X(ffh_embedding_fwd_multi) X(ffh_embedding_bwd_dense) \
   X(ffh_embedding_bwd_sgd_fused) X(ffh_embedding_bwd_sgd_fused_multi) X(ffh_embedding_bwd_sort_multi) X(ffh_embedding_bwd_sgd_apply_multi) X(ffh_embedding_bwd_opt_fused_multi) X(ffh_embedding_bwd_opt_apply_multi) \
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
-  X(ffh_linear_fwd) X(ffh_linear_fast_in_dim) X(ffh_linear_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_mlp_chain_fwd) X(ffh_mlp_chain_bwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_linear_bwd_set_dx_colsum) X(ffh_linear_dx_colsum_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
+  X(ffh_linear_fwd) X(ffh_linear_fast_in_dim) X(ffh_linear_last_route) X(ffh_embedding_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_mlp_chain_fwd) X(ffh_mlp_chain_bwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_linear_bwd_set_dx_colsum) X(ffh_linear_dx_colsum_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
   X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
 

@@ -82,6 +82,7 @@ int ffh_ctx_destroy(ffh_ctx* c) { free(c); return FFH_OK; }
  * the point of use): registrations are accepted and ignored; the explicit conversion is the rounding itself */
 int ffh_ctx_bf16_mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* twin) { (void)twin; return (c && base && bytes) ? FFH_OK : FFH_ERR_BAD_ARG; }
 const char* ffh_linear_last_route(const ffh_ctx* c) { (void)c; return "oracle"; }
+const char* ffh_embedding_last_route(const ffh_ctx* c) { (void)c; return "oracle"; }
 const char* ffh_last_error_string(const ffh_ctx* c) { return c ? c->err : "null ctx"; }
 int ffh_device_query(ffh_ctx* c, ffh_device_info* info) {
   if (!c || !info) return FFH_ERR_BAD_ARG;

@@ -385,3 +385,132 @@ def test_split_slab_update_equals_the_single_launch(hip):
     for k in outs[0][0]:
         np.testing.assert_allclose(outs[0][0][k], outs[1][0][k], rtol=2e-5, atol=2e-6, err_msg=f"split vs single: {k}")
         np.testing.assert_allclose(outs[2][0][k], outs[1][0][k], rtol=2e-5, atol=2e-6, err_msg=f"replayed vs single: {k}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the bucket form of the fused table update (ABI 13 shows the route): one stable pass on the top id bits, the rest of the order
+# made per tile inside the apply launch -- the same canonical order, so bit for bit the oracle's restatement of zero_grad +
+# embed_backward + sgd_update [ref: src/runtime/model.cc:466-490, src/ops/embedding.cu:192-217, src/runtime/optimizer_kernel.cu:23-41]
+# ---------------------------------------------------------------------------------------------------------------------------
+def _emb_route(hip):
+    return hip.lib.ffh_embedding_last_route(hip.ctx).decode()
+
+
+def _bucket_ids(rng, kind, B, L, rows):
+    n = B * L
+    if kind == "uniform":
+        ids = rng.integers(0, rows, n)
+    elif kind == "hot":            # one row takes half of the lookups, another (in a different bucket) a quarter: windows far beyond the LDS window
+        ids = rng.integers(0, rows, n)
+        ids[rng.random(n) < 0.5] = rows // 3
+        ids[rng.random(n) < 0.25] = rows - 7
+    elif kind == "hot-neighbours":  # three neighbouring rows of one bucket share most lookups: the tile bounds fall inside their runs
+        ids = rng.integers(0, rows, n)
+        m = rng.random(n) < 0.8
+        ids[m] = rows // 2 + rng.integers(0, 3, int(m.sum()))
+    elif kind == "warm":           # two neighbouring rows with ~600 hits each: a window between the counting sort's limit and the LDS window's
+        ids = rng.integers(0, rows, n)
+        h = min(600, n // 4)
+        ids[rng.permutation(n)[:2 * h]] = np.repeat([rows // 2, rows // 2 + 1], h)
+    elif kind == "one-row":        # every lookup on one row: a single run through every tile, block and bucket bound
+        ids = np.full(n, rows - 1)
+    elif kind == "zipf":
+        ids = np.minimum(rng.zipf(1.2, n) - 1, rows - 1)
+    elif kind == "low-half":       # only the first buckets are populated
+        ids = rng.integers(0, max(rows // 300, 2), n)
+    else:
+        raise ValueError(kind)
+    return ids.reshape(B, L).astype(np.int64)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "hot", "hot-neighbours", "warm", "one-row", "zipf", "low-half"])
+@pytest.mark.parametrize("B,L,D,rows", [
+    (4096, 1, 128, (4000000, 3000)),           # 512-byte rows, 22 id bits, a second table of 12
+    (8192, 2, 16, (1 << 20, 977, 513)),        # bags of two (16384 lookups), a table the one pass sorts completely
+    (2049, 1, 4, (70000,)),                    # just past the one-launch limit
+    (65536, 1, 8, (40000000,)),                # the largest call the form takes, 26 id bits
+    (5000, 3, 32, (123457, 99991)),            # 15000 lookups: a ragged last tile
+])
+def test_fused_update_bucket_form_equals_oracle(hip, oracle, kind, B, L, D, rows):
+    rng = np.random.default_rng(B * 7 + D + len(kind))
+    T = len(rows)
+    ws = torch.empty(hip.lib.ffh_embedding_bwd_workspace_bytes(T, L, D, B) + 256, dtype=torch.uint8, device=DEV)
+    hip.set_workspace(ws, ws.numel())
+    touched = [None] * T
+    In = [_bucket_ids(rng, kind, B, L, r) for r in rows]
+    # tables of millions of rows: keep only the rows the batch touches on the host (the untouched ones are checked through a checksum)
+    Wd = [torch.rand((r, D), device=DEV, dtype=torch.float32) * 2 - 1 for r in rows]
+    W0 = [w.clone() for w in Wd]
+    Gn = [rng.uniform(-1, 1, (B, D)).astype(np.float32) for _ in rows]
+    I = [torch.from_numpy(i).to(DEV) for i in In]
+    G = [torch.from_numpy(g).to(DEV) for g in Gn]
+    for aggr in (capi.AGGR_MODE_SUM, capi.AGGR_MODE_AVG):
+        for w, w0 in zip(Wd, W0):
+            w.copy_(w0)
+        arr = hip.emb_tables([(I[t], Wd[t], G[t], rows[t], D) for t in range(T)])
+        hip.check(hip.lib.ffh_embedding_bwd_sgd_fused_multi(hip.ctx, arr, T, L, D, B, aggr, 0.05, None), "fused")
+        torch.cuda.synchronize()
+        assert _emb_route(hip).startswith("buckets:bits="), _emb_route(hip)
+        for t in range(T):
+            u, inv = np.unique(In[t], return_inverse=True)
+            sub = W0[t][torch.from_numpy(u).to(DEV)].cpu().numpy()
+            exp = oracle.embedding_bwd_sgd_fused(inv.reshape(B, L).astype(np.int64), Gn[t], sub, 0.05, aggr=aggr)
+            got = Wd[t][torch.from_numpy(u).to(DEV)].cpu().numpy()
+            assert got.tobytes() == exp.tobytes(), f"{kind}, table {t}, aggr {aggr}: touched rows differ from the oracle"
+            mask = torch.ones(rows[t], dtype=torch.bool, device=DEV)
+            mask[torch.from_numpy(u).to(DEV)] = False
+            assert torch.equal(Wd[t][mask], W0[t][mask]), f"{kind}, table {t}: an untouched row changed"
+
+
+def test_fused_update_bucket_form_two_calls_and_optimizers(hip, oracle):
+    """sort + apply as two calls, and momentum-SGD / Adam on the touched rows, through the bucket form: the oracle's bits (weights and
+    both optimizer states)."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    B, L, D, rows = 6000, 2, 16, (300000, 70000)
+    T = len(rows)
+    In = [_bucket_ids(rng, "zipf" if t else "hot", B, L, r) for t, r in enumerate(rows)]
+    Gn = [rng.uniform(-1, 1, (B, D)).astype(np.float32) for _ in rows]
+    Wn = [rng.uniform(-1, 1, (r, D)).astype(np.float32) for r in rows]
+    I = [torch.from_numpy(i).to(DEV) for i in In]
+    G = [torch.from_numpy(g).to(DEV) for g in Gn]
+    ws = torch.empty(hip.lib.ffh_embedding_bwd_workspace_bytes(T, L, D, B) + 256, dtype=torch.uint8, device=DEV)
+    hip.set_workspace(ws, ws.numel())
+    for kind in (capi.SPARSE_OPT_SGD_MOMENTUM, capi.SPARSE_OPT_ADAM):
+        opt = capi.SparseOpt(kind=kind, lr=0.01, weight_decay=1e-4, momentum=0.9, nesterov=1, beta1=0.9, beta2=0.999, epsilon=1e-8)
+        exp = [oracle.embedding_bwd_opt(In[t], Gn[t], Wn[t], opt, np.zeros_like(Wn[t]), np.zeros_like(Wn[t])) for t in range(T)]
+        for two_calls in (False, True):
+            W = [torch.from_numpy(w).to(DEV) for w in Wn]
+            S0 = [torch.zeros_like(w) for w in W]
+            S1 = [torch.zeros_like(w) for w in W]
+            arr = hip.emb_tables([(I[t], W[t], G[t], rows[t], D) for t in range(T)])
+            sta = hip.emb_states([(S0[t], S1[t]) for t in range(T)])
+            if two_calls:
+                hip.check(hip.lib.ffh_embedding_bwd_sort_multi(hip.ctx, arr, T, L, D, B, None), "sort")
+                hip.check(hip.lib.ffh_embedding_bwd_opt_apply_multi(hip.ctx, arr, sta, T, L, D, B, capi.AGGR_MODE_SUM, C.byref(opt), None), "apply")
+            else:
+                hip.check(hip.lib.ffh_embedding_bwd_opt_fused_multi(hip.ctx, arr, sta, T, L, D, B, capi.AGGR_MODE_SUM, C.byref(opt), None), "fused")
+            torch.cuda.synchronize()
+            assert _emb_route(hip).startswith("buckets"), _emb_route(hip)
+            for t in range(T):
+                for name, got, want in (("w", W[t], exp[t][0]), ("s0", S0[t], exp[t][1]), ("s1", S1[t], exp[t][2])):
+                    if kind == capi.SPARSE_OPT_SGD_MOMENTUM and name == "s1":
+                        continue
+                    assert got.cpu().numpy().tobytes() == want.tobytes(), f"optimizer {kind}, two_calls {two_calls}, table {t}: {name} differs from the oracle"
+
+
+def test_fused_update_routes(hip):
+    """Which form a call takes (ffh_embedding_last_route): one launch up to 2048 lookups per table, the bucket form up to 64 K where the
+    ids need more than one pass, the LSD passes beyond."""
+    D = 4
+    for B, rows, want in ((2048, 100000, "small"), (2049, 100000, "buckets:bits=6"), (32768, 40000000, "buckets:bits=9"), (65536, 1 << 20, "buckets:bits=9"),
+                          (65537, 1 << 20, "lsd:passes=3"), (4096, 300, "lsd:passes=1")):
+        ws = torch.empty(hip.lib.ffh_embedding_bwd_workspace_bytes(1, 1, D, B) + 256, dtype=torch.uint8, device=DEV)
+        hip.set_workspace(ws, ws.numel())
+        W = torch.zeros((rows, D), device=DEV)
+        I = torch.randint(0, rows, (B, 1), device=DEV)
+        G = torch.zeros((B, D), device=DEV)
+        arr = hip.emb_tables([(I, W, G, rows, D)])
+        hip.check(hip.lib.ffh_embedding_bwd_sgd_fused_multi(hip.ctx, arr, 1, 1, D, B, capi.AGGR_MODE_SUM, 0.1, None), "fused")
+        torch.cuda.synchronize()
+        assert _emb_route(hip) == want, (B, rows, _emb_route(hip), want)
