@@ -137,6 +137,7 @@ class FFConfig {
                                // not wait for the biggest layer's weight gradient and 14 MB of SGD (A/B: --split-update; measured level to slightly slower, off)
   bool mlp_chain;              // a run of narrow Linear layers (every width <= 512) as one launch forward, two backward (ffh_mlp_chain_fwd / _bwd; A/B: --no-mlp-chain)
   int64_t mlp_chain_max_batch; // ... for at most this many samples per GPU (--mlp-chain-max-batch N)
+  int64_t mlp_chain_fwd_max_batch;   // ... and up to this many (--mlp-chain-fwd-max-batch N)
   int64_t mlp_chain_fwd_min_batch;   // the forward chain from this many samples per GPU up (below, the per-layer kernels win: --mlp-chain-fwd-min-batch N)
   int64_t mlp_chain_max_weights;     // chains of at most this many weights in all (every CU streams all of them from L2: --mlp-chain-max-weights N)
   bool attach_events;          // hang ev_grad_ready on the producing kernel's completion instead of a record packet (A/B: --no-attach-event)

@@ -139,13 +139,15 @@ FFConfig::FFConfig() {
   allreduce_bucket_floats = 1 << 20;
   big_dw_chunks = 0;
   big_dw_min_weights = 2 << 20;
-  mlp_chain_max_batch = 4096;
+  mlp_chain_max_batch = 8192;
+  mlp_chain_fwd_max_batch = 4096;
   // measured on whole steps (profiles/r05_ab_chain.txt) and alone (tools/chain_bench.py, profiles/r05_microbench_mlp_chain.txt): the
   // backward chain of the bottom MLPs beats the per-layer calls up to 4096 samples per GPU (alone 46 vs 86 us at 4096, 37 vs 74 at the
-  // Kaggle shape; steps 1.163 vs 1.188 ms and 0.170 vs 0.187); at 8192 it is faster alone (72 vs 116) but the step is slower (MLPerf
-  // shape 1.225 vs 1.200 ms: the per-layer weight gradients ran beside the data gradients on their own stream).  The forward chain
-  // is level with the per-layer kernels from 4096 samples (28 vs 31 us alone, the step unchanged) and slower below (28 vs 24 at
-  // 2048); a chain beyond ~200 K weights (the Kaggle top MLP: 352 K) loses below 4096 samples -- every CU streams every weight from
+  // Kaggle shape; steps 1.163 vs 1.188 ms and 0.170 vs 0.187); at 8192 it is faster alone (72 vs 116) and -- since the table update takes
+  // three launches at that size (the bucket form: the update no longer sits beside the whole bottom backward) -- on the step as well:
+  // MLPerf shape 1.162-1.173 vs 1.177-1.179 ms, Terabyte shape at 8192 samples 2.077 vs 2.099 (before: 1.225 vs 1.200).  The forward chain
+  // is level with the per-layer kernels at 4096 samples (28 vs 31 us alone, the step unchanged), slower below (28 vs 24 at
+  // 2048) and above (8192: 2.085 vs 2.077 ms with it); a chain beyond ~200 K weights (the Kaggle top MLP: 352 K) loses below 4096 samples -- every CU streams every weight from
   // L2 for its 16 rows, which bounds these kernels
   mlp_chain_fwd_min_batch = 4096;
   mlp_chain_max_weights = 200000;
@@ -234,6 +236,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--big-dw-min-weights")) { big_dw_min_weights = atoll(next()); continue; }
     if (is("--mlp-chain-max-batch")) { mlp_chain_max_batch = atoll(next()); continue; }
     if (is("--mlp-chain-fwd-min-batch")) { mlp_chain_fwd_min_batch = atoll(next()); continue; }
+    if (is("--mlp-chain-fwd-max-batch")) { mlp_chain_fwd_max_batch = atoll(next()); continue; }
     if (is("--mlp-chain-max-weights")) { mlp_chain_max_weights = atoll(next()); continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
     if (is("--no-dx-colsum")) { dx_colsum = false; continue; }
@@ -848,7 +851,7 @@ void Linear::backward_dw_rows(const FFModel& ff, int row0, int nrows) {
 // ---- chains of narrow Linear layers (ffh_mlp_chain_fwd / _bwd, ABI 12; built in FFModel::allocate step 4e) -------------------
 bool FFModel::mlp_chain_usable(int64_t rows, bool fwd) const {
   return config.mlp_chain && !config.profiling && !use_workers() && !config.deterministic && !config.allow_tensor_op_math_conversion &&
-         !config.fp32_split_bf16x3 && rows <= config.mlp_chain_max_batch && (!fwd || rows >= config.mlp_chain_fwd_min_batch);
+         !config.fp32_split_bf16x3 && rows <= config.mlp_chain_max_batch && (!fwd || (rows >= config.mlp_chain_fwd_min_batch && rows <= config.mlp_chain_fwd_max_batch));
 }
 static void fill_chain(const std::vector<Linear*>& ch, ffh_chain_layer* out) {
   for (size_t i = 0; i < ch.size(); i++) {
