@@ -628,8 +628,9 @@ def main():
         out["roofline"]["bytes_per_sample"] = fwd_bytes // B
         out["roofline"]["tables_in_launch"] = owned
         out["kernels"]["embedding_bwd_sgd_fused"] = hbm_block(
-            "radix_hist/radix_scatter (LDS-histogram LSD radix sort of the ids) + emb_sgd_reduce (segmented sums, both folds by the last tile "
-            "to arrive, W -= lr*sum); batch x bag <= 2048 per table: emb_sgd_small_kernel, one launch", bwd_bytes, t_bwd,
+            "radix_hist/radix_scatter (LDS-histogram stable radix passes on the ids) + emb_sgd_reduce (segmented sums, both folds by the last tile "
+            "to arrive, W -= lr*sum); <= 64 K lookups per table: ONE pass on the top digit, the rest of the order per tile inside emb_sgd_reduce "
+            "(3 launches); <= 2048: emb_sgd_small_kernel, one launch", bwd_bytes, t_bwd,
             pmc.get("update_bytes_per_call"), src, in_step_sec=t_bwd_in)
         sf = args.shim_flags.split()
         if "--early-sort" in sf or ("--no-early-sort" not in sf and (world > 1 or args.force_exchange or B // world < 8192)):
