@@ -15,6 +15,9 @@
 //     in registers by the lane-group that owns the run, and each touched row is
 //     read-modified-written exactly once.
 #include "ffh_common.h"
+#ifdef FFH_MSD_TIMING
+#include <vector>
+#endif
 
 #include <type_traits>
 
@@ -260,10 +263,15 @@ __device__ __forceinline__ void sort_rank_and_scatter(const uint32_t (&key)[E], 
     if (e >= ne) break;                  // (uniform: rounds past the caller's live ones hold no entry)
     const uint32_t d = (key[e] >> shift) & mask;
     unsigned long long peers = __ballot(valid[e]);
-    for (int bit = 0; bit < bits; bit++) {
-      const bool one = (d >> bit) & 1u;
-      const unsigned long long bal = __ballot(one);
-      peers &= one ? bal : ~bal;
+    // (unrolled over the largest digit with a uniform exit: as a loop with a run-time trip count the compiler kept `peers` under an
+    //  exec-mask loop, ~13 instructions per bit; straight-line it is a compare, two selects and two ands)
+#pragma unroll
+    for (int bit = 0; bit < kMaxRadixBits; bit++) {
+      if (bit < bits) {
+        const bool one = (d >> bit) & 1u;
+        const unsigned long long bal = __ballot(one);
+        peers &= one ? bal : ~bal;
+      }
     }
     if (valid[e]) {
       const uint32_t base = my_off[d];
@@ -446,6 +454,9 @@ struct RedArgs {
   float*    s1[FFH_MAX_TABLES];   // OPT 2: second moment V
   // bucket form (emb_sgd_reduce_kernel<.., MSD = true>): kp[parity] is ordered by the top digit only
   uint8_t   shift_t[FFH_MAX_TABLES];   // the digit's position (0: the table is completely sorted)
+#ifdef FFH_MSD_TIMING
+  unsigned long long* dbg;        // lab: [workgroup][8] s_memrealtime stamps
+#endif
   const uint32_t* bstart;         // [nt][kMaxRadix + 1] bucket starts
   uint32_t* nextkey;              // [nt][nchunks1]: the row id behind each 1024-block (written by the block's last tile, read by its fold)
   int       radix;
@@ -1115,6 +1126,13 @@ __global__ __launch_bounds__(kRedThreads, MSD ? (OPT == 0 ? 6 : 4) : (OPT == 0 ?
   float* const st0 = a.s0[tix];
   float* const st1 = a.s1[tix];
   bool preloaded = false;
+#ifdef FFH_MSD_TIMING
+  unsigned long long* dbg = a.dbg + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+  if (threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memrealtime();
+#define MSD_STAMP(i) if (threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define MSD_STAMP(i)
+#endif
   if constexpr (MSD) {
     const int shift = a.shift_t[tix];
     const int64_t tile0m = (int64_t)blockIdx.x * a.tile;
@@ -1134,8 +1152,10 @@ __global__ __launch_bounds__(kRedThreads, MSD ? (OPT == 0 ? 6 : 4) : (OPT == 0 ?
       preloaded = true;
     }
   }
+  MSD_STAMP(1);
   reduce_tile_body<VEC, true, OPT>(tb, keys, p0, m0, a.N, a.nchunks, a.tile,
                         (int)blockIdx.x, a.L, a.D, a.avg != 0, a.op, st0, st1, sh, threadIdx.x, preloaded);
+  MSD_STAMP(2);
 
   const int nvec = a.D / VEC;
   const int lpr = nvec < 64 ? nvec : 64;
@@ -1641,10 +1661,31 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
 #define FFH_RED(OPTV, MSDV)                                                                                                 \
   { if (v4) hipLaunchKernelGGL((emb_sgd_reduce_kernel<4, OPTV, MSDV>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra);        \
     else hipLaunchKernelGGL((emb_sgd_reduce_kernel<1, OPTV, MSDV>), rgrid, dim3(kRedThreads), 0, as_stream(s), ra); }
+#ifdef FFH_MSD_TIMING
+  static unsigned long long* dbg_buf = nullptr;
+  if (!dbg_buf) hipMalloc(&dbg_buf, 8 * 8 * 65536);
+  ra.dbg = dbg_buf;
+#endif
   if (msd) { if (kind == FFH_SPARSE_OPT_SGD) FFH_RED(0, true) else if (kind == FFH_SPARSE_OPT_SGD_MOMENTUM) FFH_RED(1, true) else FFH_RED(2, true) }
   else { if (kind == FFH_SPARSE_OPT_SGD) FFH_RED(0, false) else if (kind == FFH_SPARSE_OPT_SGD_MOMENTUM) FFH_RED(1, false) else FFH_RED(2, false) }
 #undef FFH_RED
   FFH_LAUNCH_CHECK(c, "emb_sgd_reduce/fold");
+#ifdef FFH_MSD_TIMING
+  {
+    static int calls = 0;
+    if (++calls % 23 == 0) {
+      hipDeviceSynchronize();
+      const int nwg = (int)(rgrid.x * rgrid.y);
+      std::vector<unsigned long long> h((size_t)nwg * 8);
+      hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost);
+      unsigned long long t0 = ~0ull, t2max = 0; double s1 = 0, s2 = 0, start = 0;
+      for (int i = 0; i < nwg; i++) { t0 = h[i * 8] < t0 ? h[i * 8] : t0; }
+      for (int i = 0; i < nwg; i++) { s1 += (double)(h[i * 8 + 1] - h[i * 8]); s2 += (double)(h[i * 8 + 2] - h[i * 8 + 1]); start += (double)(h[i * 8] - t0); t2max = h[i * 8 + 2] > t2max ? h[i * 8 + 2] : t2max; }
+      fprintf(stderr, "[msd timing] %d workgroups (msd %d): start after first %.2f us avg, window %.2f us avg, reduce %.2f us avg, last reduce end %.2f us after first start (100 MHz ticks)\n",
+              nwg, (int)msd, start / nwg / 100.0, s1 / nwg / 100.0, s2 / nwg / 100.0, (double)(t2max - t0) / 100.0);
+    }
+  }
+#endif
   return FFH_OK;
 }
 
