@@ -399,7 +399,10 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
   int splitk = 1;
   if (form == BF16_FORM_DW) {
     if (g.epi != EPI_ATOMIC || c->deterministic) return 0;       // the k-slices of a tile meet by atomics
-    if (tiles < 8) return 0;                                     // tiny outputs: the atomic traffic of ~256 / tiles slices outweighs the tile
+    // (round 5: from two tiles on -- 512 x 256 as 2 tiles x 64 slices takes 48.8 us where the 128 x 128 kernel took 93.8 and the fp32
+    //  kernel takes 79.7: with eight as the limit this was the one layer of the step that tensor-op mode made slower)
+    static const int min_tiles = FFH_LAB_INT("FFH_BF16_DMA_DW_MIN_TILES", 2);     // A/B switch
+    if (tiles < min_tiles) return 0;                             // a single tile: at most 64 slices, a quarter of the chip
     // the split with the least estimated time: rounds of one workgroup per CU x k-tiles per slice (~1 us each at the main
     // loop's rate) + the slices' atomic traffic at the memory-side adders' ~1.3 TB/s (every slice adds a whole tile).  At batch
     // 32768: 3456 x 1024 -> 4 slices (224 workgroups, one round), 1024 x 1024 -> 16, 1024 x 512 -> 16
