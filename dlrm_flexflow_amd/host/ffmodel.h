@@ -109,6 +109,7 @@ class FFConfig {
   int  big_dw_mode;                  // A/B: 0 the biggest layer's dW beside its dX (default), 1 forked behind its dX, 2 before its dX on the compute stream
   bool two_dw_streams;               // (A/B: --two-dw-streams, off) the biggest layer's weight-gradient GEMM on a stream of its own
   int  defer_big_dw;                 // --defer-big-dw (A/B, default 0): the biggest layer's weight gradient is issued last instead of beside its data gradient
+  bool bf16_convert_twins;               // tensor-op mode: a twin by conversion behind an fp32-kernel Linear that feeds a bf16-pipe one (--no-bf16-convert-twins)
   bool bf16_twins, force_async_launch;   // --no-bf16-twins / --force-async-launch (A/B and test switches; they used to be environment variables)
   bool capture_exchange;             // --capture-exchange: world_size > 1 with collectives enqueued from C++ (RcclComm): the step is captured / replayed as a hipGraph
   bool pad_linear_k;                 // (A/B: --no-pad-linear-k) zero-pad the input / kernel of a wide Linear whose in_dim is not a multiple of 64
@@ -336,6 +337,7 @@ class Linear : public Op {
   std::vector<Linear*> chain_fwd;  // non-empty on the LOWEST layer of a chain of narrow layers: its members bottom -> top; forward() of that layer
                                    // launches all of them (ffh_mlp_chain_fwd, ABI 12)
   mutable bool fwd_done_by_chain;  // set by the chain's lowest layer for this forward()
+  void* out_twin = nullptr;        // tensor-op mode: where forward() leaves the bf16 rounding of its output (allocate() step 7), or null
   std::vector<Linear*> chain_bwd;  // non-empty on the TOP layer of the chain FFModel::backward runs as one call (ffh_mlp_chain_bwd): members bottom -> top
   Initializer *kernel_initializer, *bias_initializer;
 };

@@ -158,6 +158,7 @@ FFConfig::FFConfig() {
   pad_linear_k = true;
   capture_exchange = false;
   bf16_twins = true;
+  bf16_convert_twins = true;
   force_async_launch = false;
   defer_big_dw = 0;
   two_dw_streams = false;      // measured in round 4: no gain (1.183-1.189 vs 1.184-1.188 ms at 4096 samples; MLPerf shape 1.29 vs 1.27: worse)
@@ -247,6 +248,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--sort-at-backward-start")) { early_sort = 2; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
     if (is("--capture-exchange")) { capture_exchange = true; continue; }
+    if (is("--no-bf16-convert-twins")) { bf16_convert_twins = false; continue; }    // A/B: no twin by conversion behind an fp32-kernel layer
     if (is("--no-bf16-twins")) { bf16_twins = false; continue; }               // A/B and tests: tensor-op mode rounding its operands inside the kernels
     if (is("--force-async-launch")) { force_async_launch = true; continue; }   // tests: the launch-worker threads on a synchronous backend
     if (is("--defer-big-dw")) { defer_big_dw = 1; continue; }
@@ -720,6 +722,9 @@ void Linear::forward(const FFModel& ff) {
   ff.check(ff.api->ffh_linear_fwd(ff.ctx, (const float*)x.impl->ptr, x.impl->ld, (float*)y.impl->ptr, y.impl->ld,
                                   (const float*)weights[0].impl->ptr, use_bias ? (const float*)weights[1].impl->ptr : nullptr,
                                   in_padded, out_channels, b, (int)activation, ff.stream), name);
+  // tensor-op mode: this layer runs on the fp32 kernels (in_dim or out_dim below FFH_BF16_MIN_DIM) but feeds one on the bf16 pipe: its
+  // output's twin by an explicit conversion (allocate(), step 7), so that the consumer reads both operands at two bytes per element
+  if (out_twin) ff.check(ff.api->ffh_convert_f32_to_bf16(ff.ctx, out_twin, (const float*)y.impl->ptr, b * (int64_t)y.impl->ld, ff.stream), name);
 }
 int Linear::backward_pair(const FFModel& ff) {
   Linear* lo = pair_lower;
@@ -2158,12 +2163,22 @@ void FFModel::allocate() {
           else act_ok = twin_linear(in.owner_op);
         }
       }
-      if (act_ok) reg(im->ptr, im->bytes, (char*)act_twin + ((const char*)im->ptr - act_slab) / 2);
-      // the gradient of this tensor: one consumer, a twin-writing Linear that stores its data gradient
       const Linear* only = nullptr; int ncons = 0;
       for (Op* q : layers)
         for (int i = 0; i < q->numInputs; i++)
           if (q->inputs[i].impl == im) { ncons++; only = q->op_type == OP_LINEAR ? static_cast<const Linear*>(q) : nullptr; }
+      // (round 5) a Linear the bf16 pipe does not take (13 -> 512 under the bottom MLP) whose only reader is one it does take: the twin by an
+      // explicit conversion behind its forward call -- 100 MB of traffic at 32768 samples, for which the reader's forward and weight
+      // gradient take both operands from twins (the LDS-DMA kernels instead of the converting 128 x 128 one)
+      if (!act_ok && config.bf16_convert_twins && op->op_type == OP_LINEAR && ncons == 1 && only && twin_linear(only) && !use_workers() && im->ld % 8 == 0) {
+        Linear* li = static_cast<Linear*>(op);
+        if (!li->pair_upper && !li->pair_lower) {      // (the chain launches stand back in tensor-op mode: mlp_chain_usable)
+          li->out_twin = (char*)act_twin + ((const char*)im->ptr - act_slab) / 2;
+          act_ok = true;
+        }
+      }
+      if (act_ok) reg(im->ptr, im->bytes, (char*)act_twin + ((const char*)im->ptr - act_slab) / 2);
+      // the gradient of this tensor: one consumer, a twin-writing Linear that stores its data gradient
       // (... or the one-launch backward of a layer with <= 4 outputs, which writes the twin of its data gradient too: the
       //  256 -> 1 layer on top of the Terabyte MLP, whose input gradient is the 512 -> 256 layer's dy)
       auto skinny_twin = [&](const Linear* l) {
