@@ -246,6 +246,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-early-sort")) { early_sort = 0; continue; }
     if (is("--early-sort")) { early_sort = 1; continue; }
     if (is("--sort-at-backward-start")) { early_sort = 2; continue; }
+    if (is("--sort-at-interaction-backward")) { early_sort = 3; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
     if (is("--capture-exchange")) { capture_exchange = true; continue; }
     if (is("--no-bf16-convert-twins")) { bf16_convert_twins = false; continue; }    // A/B: no twin by conversion behind an fp32-kernel layer
@@ -2752,6 +2753,14 @@ void FFModel::backward(int _seq_length) {
       grad_ready_attached = true;
     }
     Linear* up = layers[l]->op_type == OP_LINEAR ? static_cast<Linear*>(layers[l]) : nullptr;
+    if (layers[l]->op_type == OP_DOT_INTERACTION && !emb_sorted_early && early_sort_possible(3)) {
+      // the index-only sort beside the interaction's backward -- an HBM-bound kernel, the one stretch of the backward in which no
+      // persistent GEMM holds the SIMDs' issue slots (an index-heavy kernel runs ~8x slower beside one)
+      check(api->ffh_event_record(ctx, layer_events[l], stream), "event");
+      check(api->ffh_stream_wait_event(ctx, side_stream, layer_events[l]), "event");
+      launch_shard_groups(this, kSortOnly, side_stream, ctx);
+      emb_sorted_early = true;
+    }
     if (up && up->dx_map && !use_workers()) {
       const bool attach = l == scatter_attach_layer;
       check(api->ffh_linear_bwd_set_dx_scatter(ctx, up->dx_map, up->in_channels, attach ? ev_grad_ready : nullptr), "dx scatter");
