@@ -514,3 +514,23 @@ def test_fused_update_routes(hip):
         hip.check(hip.lib.ffh_embedding_bwd_sgd_fused_multi(hip.ctx, arr, 1, 1, D, B, capi.AGGR_MODE_SUM, 0.1, None), "fused")
         torch.cuda.synchronize()
         assert _emb_route(hip) == want, (B, rows, _emb_route(hip), want)
+
+
+def test_sort_placement_at_the_interaction_backward_same_bits_on_gpu():
+    """--sort-at-interaction-backward on the HIP library (the bucket form's sort phase issued beside the dot interaction's backward on the
+    side stream, the apply phase later): the default placement's bits, eager and replayed."""
+    from dlrm_flexflow_amd import ffmodel
+    base = ["--backend", capi.HIP_LIB_PATH, "-b", "4096", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "3000-700000-11-40000",
+            "--arch-mlp-bot", "13-64-16", "--arch-mlp-top", "26-32-1", "--data-size", "4096", "--arch-interaction-op", "dot-tril", "--deterministic"]
+    out = []
+    for extra, trace in (([], False), (["--sort-at-interaction-backward"], False), (["--sort-at-interaction-backward"], True)):
+        app = ffmodel.DLRM(base + extra)
+        app.warmup(); app.train_steps(3, trace=trace); app.model.sync()
+        m = app.model
+        o = {f"{l}/{i}": m.parameter(l, i).get_weights() for l in range(m.num_layers) for i in range(m.layer_num_weights(l))}
+        o["pred"] = m.layer_output(m.num_layers - 1).get()
+        out.append(o)
+        app.close()
+    for other in out[1:]:
+        for k in out[0]:
+            assert np.array_equal(out[0][k], other[k]), k

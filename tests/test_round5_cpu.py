@@ -174,3 +174,26 @@ def test_fast_path_padding_rule_is_the_same_in_both_libraries(oracle):
     o = oracle.lib().lib
     for (i, n), exp in {(479, 1024): 512, (857, 1024): 896, (512, 1024): 512, (13, 512): 13, (479, 100): 479, (200, 1024): 200, (3456, 1024): 3456}.items():
         assert o.ffh_linear_fast_in_dim(i, n) == exp, (i, n)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# placements and switches added late in round 5: same bits whatever the order of issue
+def test_sort_placements_and_conversion_twins_do_not_change_the_bits():
+    """--sort-at-interaction-backward (the index-only sort of the table update issued beside the dot interaction's backward) against the
+    default placement and the other two; tensor-op mode with and without the twin-by-conversion behind an fp32-kernel layer.  The host
+    logic runs on the oracle backend: what is checked is the order / bookkeeping of the calls (a sort consumed twice or not at all
+    fails loudly in the library: the one-shot contract of ffh_embedding_bwd_sort_multi)."""
+    base = ["--backend", H.oracle_backend(), "-b", "2304", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "3000-70000-11",
+            "--arch-mlp-bot", "13-64-16", "--arch-mlp-top", "22-32-1", "--data-size", "2304", "--arch-interaction-op", "dot-tril"]
+    ref, _ = _run(base, 2)
+    for extra in (["--sort-at-interaction-backward"], ["--early-sort"], ["--sort-at-backward-start"], ["--no-early-sort"]):
+        got, _ = _run(base + extra, 2)
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), (extra, k)
+    top = ["--backend", H.oracle_backend(), "-b", "64", "--arch-sparse-feature-size", "128", "--arch-embedding-size", "300-70",
+           "--arch-mlp-bot", "13-256-128", "--arch-mlp-top", "384-256-1", "--data-size", "64", "--allow-tensor-op-math-conversion"]
+    a, _ = _run(top, 2)
+    b, _ = _run(top + ["--no-bf16-convert-twins"], 2)
+    c, _ = _run(top + ["--no-bf16-twins"], 2)
+    for k in a:
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k]), k
