@@ -2755,7 +2755,7 @@ void FFModel::backward(int _seq_length) {
     Linear* up = layers[l]->op_type == OP_LINEAR ? static_cast<Linear*>(layers[l]) : nullptr;
     if (layers[l]->op_type == OP_DOT_INTERACTION && !emb_sorted_early && early_sort_possible(3)) {
       // the index-only sort beside the interaction's backward -- an HBM-bound kernel, the one stretch of the backward in which no
-      // persistent GEMM holds the SIMDs' issue slots (an index-heavy kernel runs ~8x slower beside one)
+      // persistent GEMM is meant to be on the chip (an index-heavy kernel runs ~8x slower beside one)
       check(api->ffh_event_record(ctx, layer_events[l], stream), "event");
       check(api->ffh_stream_wait_event(ctx, side_stream, layer_events[l]), "event");
       launch_shard_groups(this, kSortOnly, side_stream, ctx);
