@@ -1038,92 +1038,6 @@ __global__ __launch_bounds__(512) void linear_thin_fwd_kernel(const float* __res
   }
 }
 
-// Weight (and bias) gradient of the same layer: dw[o][i] += sum_b dy[b][o] x[b][i] with in <= 16 is a read of dy -- 67 MB at 32768 samples --
-// and 2 x in multiply-adds per element read.  As a GEMM (32 x 32 tiles, the batch split 16 ways, dy read in 128-byte pieces) it took 98 us
-// in the 32768-sample step and sat in front of the slab optimizer; here a workgroup streams whole rows of dy (thread t the OC consecutive
-// columns OC t ..: one 2-KiB row per instruction at 512 outputs), the matching rows of x come through LDS as broadcasts, the thread's
-// OC x 16 sums stay in registers, and the workgroup's partial dW -- contiguous in memory, ld = in -- leaves through LDS as whole-line
-// atomics.  dy arrives final (no activation, or premasked by the layer above).  Sums per element: ascending rows inside a workgroup's
-// range, ranges by atomics (the weight-gradient contract: 1e-5 of the term mass).
-constexpr int kThinDwChunk = 64;            // rows of x staged per step
-template <int OC>
-__global__ __launch_bounds__(256) void linear_thin_dw_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t lddy,
-                                                             float* __restrict__ dw, float* __restrict__ db, int in, int out, int64_t batch, int rows_per_wg) {
-  ffh_kernel_prio();
-  extern __shared__ __attribute__((aligned(16))) float td_lds[];
-  float (*s_x)[16] = reinterpret_cast<float (*)[16]>(td_lds);                 // [kThinDwChunk][16], zero padded
-  float* s_part = td_lds + kThinDwChunk * 16;                                  // [out][in] (+ [out] for db)
-  const int tid = threadIdx.x;
-  const int o0 = OC * tid;
-  const bool live = o0 < out;                    // (out % OC == 0: the host checks)
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-  const int64_t r1 = r0 + rows_per_wg < batch ? r0 + rows_per_wg : batch;
-  float acc[OC][16], accb[OC];
-#pragma unroll
-  for (int c = 0; c < OC; c++) {
-    accb[c] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; i++) acc[c][i] = 0.f;
-  }
-  typedef float vecf __attribute__((ext_vector_type(OC)));
-  for (int64_t base = r0; base < r1; base += kThinDwChunk) {
-    const int nr = (int)(r1 - base < kThinDwChunk ? r1 - base : kThinDwChunk);
-    __syncthreads();                             // the previous chunk's x is no longer read
-    for (int e = tid; e < kThinDwChunk * 16; e += 256) {
-      const int r = e >> 4, i = e & 15;
-      s_x[r][i] = (r < nr && i < in) ? x[(base + r) * ldx + i] : 0.f;
-    }
-    __syncthreads();
-    if (live) {
-      const float* dp = dy + base * lddy + o0;
-      for (int r = 0; r < nr; r += 8) {
-        float dv[8][OC];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {            // eight rows of dy in flight
-          if (r + u < nr) {
-            if constexpr (OC == 1) dv[u][0] = dp[(int64_t)(r + u) * lddy];
-            else {
-              const vecf v = *reinterpret_cast<const vecf*>(dp + (int64_t)(r + u) * lddy);
-#pragma unroll
-              for (int c = 0; c < OC; c++) dv[u][c] = v[c];
-            }
-          } else {
-#pragma unroll
-            for (int c = 0; c < OC; c++) dv[u][c] = 0.f;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const float4* xr = reinterpret_cast<const float4*>(s_x[(r + u) < kThinDwChunk ? (r + u) : 0]);      // (rows past nr: dv = 0)
-          const float4 x0 = xr[0], x1 = xr[1], x2 = xr[2], x3 = xr[3];
-          const float xv[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
-#pragma unroll
-          for (int c = 0; c < OC; c++) {
-            accb[c] += dv[u][c];
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[c][i] = __fmaf_rn(dv[u][c], xv[i], acc[c][i]);
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (live) {
-#pragma unroll
-    for (int c = 0; c < OC; c++) {
-#pragma unroll
-      for (int i = 0; i < 16; i++)
-        if (i < in) s_part[(o0 + c) * in + i] = acc[c][i];
-      s_part[out * in + o0 + c] = accb[c];
-    }
-  }
-  __syncthreads();
-  const int n = out * in;
-  for (int e = tid; e < n; e += 256) atomicAdd(dw + e, s_part[e]);             // consecutive lanes, consecutive floats: whole lines per instruction
-  if (db)
-    for (int e = tid; e < out; e += 256) atomicAdd(db + e, s_part[n + e]);
-}
-
 // The same layer as an HBM-write-bound stream (the 13 -> 512 layer at 32768 samples writes 67 MB and reads 1.7 MB): a wave owns
 // a ROW and 256 consecutive columns -- lane l the four columns 4l .. 4l+3, so a row segment leaves as ONE 1-KiB store
 // instruction; the <= 16 inputs of the row are wave-uniform (staged through LDS, below), the lane's 4 x in weights stay in registers for
@@ -2018,29 +1932,9 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     FFH_HIP_TRY(c, hipStreamWaitEvent(as_stream(sw), c->ev_fork, 0));
   }
   const bool relu = act == FFH_AC_MODE_RELU;
-  // 2a. a handful of inputs (13 -> 512 under DLRM's bottom MLP) with a final dy: the weight gradient as a stream over dy (linear_thin_dw_kernel)
-  bool dw_done = false;
-  {
-    static const int no_thin_dw = FFH_LAB_INT("FFH_NO_THIN_DW", 0);      // A/B switch (tools/ab.sh)
-    static const int64_t thin_dw_min = FFH_LAB_I64("FFH_THIN_DW_MIN_BATCH", 2048);
-    const int oc = out <= 256 ? 1 : (out <= 512 ? 2 : 4);
-    if (do_dw && !no_thin_dw && in <= 16 && out >= 64 && out <= 1024 && out % oc == 0 && act == FFH_AC_MODE_NONE && !separate && !c->deterministic &&
-        batch >= thin_dw_min && lddy % oc == 0 && (((uintptr_t)dy) & (4 * oc - 1)) == 0 && (kThinDwChunk * 16 + out * in + out) * 4 <= 65536) {
-      int64_t rows = (batch + c->num_cus - 1) / c->num_cus;
-      rows = (rows + kThinDwChunk - 1) / kThinDwChunk * kThinDwChunk;
-      const unsigned grid = (unsigned)((batch + rows - 1) / rows);
-      const int lds = (kThinDwChunk * 16 + out * in + out) * 4;
-      if (oc == 1) hipLaunchKernelGGL((linear_thin_dw_kernel<1>), dim3(grid), dim3(256), lds, as_stream(sw), x, ldx, dy, lddy, dw, db, in, out, batch, (int)rows);
-      else if (oc == 2) hipLaunchKernelGGL((linear_thin_dw_kernel<2>), dim3(grid), dim3(256), lds, as_stream(sw), x, ldx, dy, lddy, dw, db, in, out, batch, (int)rows);
-      else hipLaunchKernelGGL((linear_thin_dw_kernel<4>), dim3(grid), dim3(256), lds, as_stream(sw), x, ldx, dy, lddy, dw, db, in, out, batch, (int)rows);
-      FFH_LAUNCH_CHECK(c, "linear_thin_dw_kernel");
-      ffh_route_add(c, "linear_bwd dw|thin_rows");
-      dw_done = true;
-    }
-  }
   // 2. dw[o][i] += sum_b dy[b][o] x[b][i]   (split-K over the batch, fp32 atomics); relu' mask applied on load and
   //    written back to dy in place, db = column sums of the same tiles
-  if (do_dw && !dw_done) {
+  if (do_dw) {
     GemmArgs g{};
     g.A = dy; g.sAm = 1; g.sAk = lddy;
     g.B = x; g.sBn = 1; g.sBk = ldx;

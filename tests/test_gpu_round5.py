@@ -534,39 +534,3 @@ def test_sort_placement_at_the_interaction_backward_same_bits_on_gpu():
     for other in out[1:]:
         for k in out[0]:
             assert np.array_equal(out[0][k], other[k]), k
-
-
-@pytest.mark.parametrize("B,IN,OUT,act,flags,bias", [
-    (32768, 13, 512, capi.AC_MODE_RELU, capi.LINEAR_DY_PREMASKED | capi.LINEAR_ONLY_DW, True),     # DLRM's first bottom layer at the headline batch
-    (4099, 13, 512, capi.AC_MODE_NONE, 0, True),                                                   # ragged batch; the data gradient of the same call through its own kernel
-    (5000, 16, 64, capi.AC_MODE_RELU, capi.LINEAR_DY_PREMASKED, False),                            # one column per thread, no bias gradient
-    (2048, 3, 1024, capi.AC_MODE_NONE, capi.LINEAR_ONLY_DW, True),                                 # four columns per thread
-    (40000, 13, 256, capi.AC_MODE_NONE, capi.LINEAR_ONLY_DW, True),
-])
-def test_weight_gradient_of_a_layer_with_a_handful_of_inputs(hip, oracle, B, IN, OUT, act, flags, bias):
-    """linear_thin_dw_kernel (in_dim <= 16, dy final): dw / db against the oracle's restatement of Linear::backward_kernel
-    [ref: src/ops/linear.cu:624-659] at 1e-5 of the term mass, the route recorded, dy untouched, accumulation into a non-zero dw."""
-    rng = np.random.default_rng(B + OUT)
-    x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
-    w = rng.uniform(-1, 1, (OUT, IN)).astype(np.float32)
-    y = np.maximum(rng.uniform(-1, 1, (B, OUT)), 0).astype(np.float32)
-    dy = rng.uniform(-1, 1, (B, OUT)).astype(np.float32)
-    dw0 = rng.uniform(-1, 1, (OUT, IN)).astype(np.float32)
-    tx, tw, ty, tdy = (torch.from_numpy(a).to(DEV) for a in (x, w, y, dy))
-    tdw = torch.from_numpy(dw0).to(DEV)
-    tdb = torch.zeros(OUT, device=DEV) if bias else None
-    tdx = torch.zeros((B, IN), device=DEV)
-    hip.call("ffh_linear_bwd_ex", tx, IN, tdx, IN, ty, OUT, tdy, OUT, tw, tdw, tdb, IN, OUT, B, act, flags | capi.LINEAR_DX_OVERWRITE, None, None)
-    torch.cuda.synchronize()
-    route = hip.lib.ffh_linear_last_route(hip.ctx).decode()
-    assert "dw|thin_rows" in route, route
-    dx_e, dw_e, db_e, dy_e = oracle.linear_bwd_ex(x, y, dy, w, act, flags | capi.LINEAR_DX_OVERWRITE, use_bias=bias)
-    assert np.array_equal(tdy.cpu().numpy(), dy_e)
-    mass = np.abs(dy).astype(np.float64).T @ np.abs(x).astype(np.float64)
-    got = tdw.cpu().numpy().astype(np.float64) - dw0
-    assert np.all(np.abs(got - dw_e) <= 1e-5 * mass + 1e-5), float(np.abs(got - dw_e).max())
-    if bias:
-        assert np.all(np.abs(tdb.cpu().numpy().astype(np.float64) - db_e) <= 1e-5 * np.abs(dy).astype(np.float64).sum(0) + 1e-6)
-    if not (flags & capi.LINEAR_ONLY_DW):
-        mx = np.abs(dy).astype(np.float64) @ np.abs(w).astype(np.float64)
-        assert np.all(np.abs(tdx.cpu().numpy().astype(np.float64) - dx_e) <= 1e-5 * mx + 1e-6)
