@@ -421,7 +421,12 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
   } else {
     if (g.epi != EPI_STORE && g.epi != EPI_ADD) return 0;
     if (form == BF16_FORM_FWD && g.epi != EPI_STORE) return 0;
-    if (tiles < c->num_cus) return 0;                            // fewer tiles than CUs: linear_bf16.hip's 128 x 128 tiles fill the chip better
+    // From half as many tiles as CUs on (round 5; before: as many).  Alone the 128 x 128 kernel is the faster one on such a shape (32768 x 512 ->
+    // 256 forward 27 vs 34 us, 8192 x 1024 -> 1024 36 vs 43), in the step it is the slower: its workgroups put MFMA-dense waves on every CU and
+    // the gather on the side stream stands still beside them, 128 tiles of this kernel leave it half the chip -- tensor-op
+    // step 2.002-2.012 -> 1.973-1.984 ms at 32768 samples, 1.309 -> 1.219 at 16384, 0.959 -> 0.917 at 8192.
+    static const int min_pct = FFH_LAB_INT("FFH_BF16_DMA_MIN_TILES_PCT", 50);      // A/B switch: least number of tiles, in per cent of the CUs
+    if (tiles * 100 < (int64_t)c->num_cus * min_pct) return 0;   // fewer: linear_bf16.hip's 128 x 128 tiles
   }
   if (tiles * splitk >= (1LL << 31)) return 0;
   DmaArgs a{};
