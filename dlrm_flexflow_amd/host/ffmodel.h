@@ -106,6 +106,7 @@ class FFConfig {
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
   int  dw_cu_reserve;                // --dw-cu-reserve N: CUs the biggest layer's persistent weight-gradient GEMM leaves free (-1: by per-GPU batch)
+  int bottom_dw_cu_reserve;    // A/B: the same for the bottom MLP's weight-gradient GEMMs (--bottom-dw-cu-reserve N; measured, off)
   int  big_dw_mode;                  // A/B: 0 the biggest layer's dW beside its dX (default), 1 forked behind its dX, 2 before its dX on the compute stream
   bool two_dw_streams;               // (A/B: --two-dw-streams, off) the biggest layer's weight-gradient GEMM on a stream of its own
   int  defer_big_dw;                 // --defer-big-dw (A/B, default 0): the biggest layer's weight gradient is issued last instead of beside its data gradient

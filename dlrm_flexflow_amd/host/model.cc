@@ -164,6 +164,7 @@ FFConfig::FFConfig() {
   two_dw_streams = false;      // measured in round 4: no gain (1.183-1.189 vs 1.184-1.188 ms at 4096 samples; MLPerf shape 1.29 vs 1.27: worse)
   big_dw_mode = 0;
   dw_cu_reserve = -1;
+  bottom_dw_cu_reserve = 0;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
@@ -257,6 +258,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--two-dw-streams")) { two_dw_streams = true; continue; }
     if (is("--big-dw-mode")) { big_dw_mode = atoi(next()); continue; }
     if (is("--dw-cu-reserve")) { dw_cu_reserve = atoi(next()); continue; }
+    if (is("--bottom-dw-cu-reserve")) { bottom_dw_cu_reserve = atoi(next()); continue; }
     if (is("--no-defer-big-dw")) { defer_big_dw = 0; continue; }
     if (is("--sparse-embedding-optimizer")) { sparse_embedding_optimizer = true; continue; }
   }
@@ -826,7 +828,10 @@ void Linear::backward_part(const FFModel& ff, int part) {
   // The biggest layer's weight-gradient GEMM leaves a few CUs without one of its persistent workgroups when the small dependent
   // kernels that run beside it (the bottom MLP's backward chain, the table update, the next gather) are a large share of the step --
   // small per-GPU batches; see ffh_ctx_set_dw_cu_reserve and FFConfig::dw_cu_reserve.
-  const int reserve = (fork && layer_index == ff.big_dw_layer) ? ff.dw_cu_reserve_for(b) : 0;
+  int reserve = (fork && layer_index == ff.big_dw_layer) ? ff.dw_cu_reserve_for(b) : 0;
+  // (--bottom-dw-cu-reserve N, A/B: the bottom MLP's persistent weight-gradient GEMMs -- which run beside the table update and the next gather --
+  //  leave N CUs without a workgroup)
+  if (ff.config.bottom_dw_cu_reserve > 0 && !ff.embeddings.empty() && layer_index < ff.embeddings.front()->layer_index) reserve = ff.config.bottom_dw_cu_reserve;
   if (reserve > 0) ff.check(ff.api->ffh_ctx_set_dw_cu_reserve(ff.ctx, reserve), "dw cu reserve");
   ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                      flags, ff.stream, fork ? dws : nullptr), name);
