@@ -1775,9 +1775,21 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
   if (label) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: not a one-launch layer (out_dim <= 4, in_dim <= 1024, aligned)");
   if (use_bf16(c, in, out)) {
     // tensor-op math mode: the activation gradient (and db) as its own fp32 pass over dy, then the two GEMMs on bf16 operands
-    const bool relu_ = act == FFH_AC_MODE_RELU;
+    bool relu_ = act == FFH_AC_MODE_RELU;
     auto act_pass = [&](ffh_stream st, int a) -> int { return launch_act_bwd_bias(c, dy, lddy, y, ldy, db, out, batch, a, st); };
     if (separate && do_dx) { const int rc = act_pass(s, act); if (rc) return rc; }       // sigmoid: in place, with db, before any fork
+    // A live relu' with both gradients wanted (round 5): the pass over dy FIRST, on s, in front of the fork -- 12 us at 32768 x 128 -- and then the
+    // two GEMMs as for a final dy.  Before, the pass ran on the weight-gradient stream while the data-gradient GEMM read dy through
+    // relu'(y) (the masking 128 x 128 kernel: y as a third operand, the mask applied in registers); that kernel heads the mode's critical
+    // chain in the DLRM step (the bottom MLP's last layer: 301 us beside the table update).  Same values, same kernels' arithmetic.
+    // Measured: the call alone 134 -> 114 us at 32768 x 256 -> 128; the step level (1.95-2.01 ms either way: that stretch is bound by what runs beside it).
+    static const int relu_first = FFH_LAB_INT("FFH_BF16_RELU_FIRST", 1);          // A/B switch
+    bool relu_done = false;
+    if (relu_first && relu_ && !separate && do_dw && do_dx && dx) {
+      const int rc = act_pass(s, act);
+      if (rc) return rc;
+      relu_ = false; relu_done = true;
+    }
     const bool forked_ = do_dw && do_dx && s_dw != nullptr && s_dw != s;
     ffh_stream sw_ = forked_ ? s_dw : s;
     if (forked_) {
@@ -1789,8 +1801,8 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     if (do_dw) {
       // no activation gradient to apply (premasked dy / no activation): the pass would only sum db -- the LDS-DMA weight-gradient
       // kernel does that itself from the fp32 dy where it serves the layer
-      const bool db_only = !separate && act == FFH_AC_MODE_NONE && db != nullptr;
-      if (!separate && !db_only) { const int rc = act_pass(sw_, act); if (rc) return rc; }          // relu: mask written back in place (idempotent); db
+      const bool db_only = !separate && !relu_done && act == FFH_AC_MODE_NONE && db != nullptr;
+      if (!separate && !db_only && !relu_done) { const int rc = act_pass(sw_, act); if (rc) return rc; }          // relu: mask written back in place (idempotent); db
       GemmArgs gw{};
       gw.A = dy; gw.sAm = 1; gw.sAk = lddy;
       gw.B = x; gw.sBn = 1; gw.sBk = ldx;
