@@ -558,6 +558,7 @@ class FFModel {
   size_t bottom_floats = 0;              // slab elements of the Linear layers in front of the tables (0: no split possible)
   int first_top_linear = -1;             // layer index of the first Linear behind the tables: its forward waits for the top part's update
   ffh_event ev_top_mark = nullptr, ev_top_opt_done = nullptr;
+  mutable ffh_event ev_sort_done = nullptr;   // --sort-before-bottom-backward: the sort phase on the compute stream, the apply phase on the side stream behind it
   bool bottom_bwd_on_stream = false;     // this step's bottom-MLP backward ran as a chain call on the compute stream (its gradients need no join)
   bool top_opt_pending = false;          // the top part's update is in flight on the weight-gradient stream
   mutable int64_t n_split_updates = 0;
@@ -607,7 +608,8 @@ class FFModel {
   void profiled(const Op* op, bool fwd, const std::function<void()>& fn) const;   // --profiling: one op between two events
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
   static constexpr int early_sort_big_batch_mode = 0;   // one GPU, >= 8192 samples: 0 = the sort stays in front of the apply phase (see early_sort_possible)
-  bool early_sort_possible(int where) const;      // one launch group, nothing else on the workspace between a step's gather and its update
+  bool early_sort_possible(int where) const;
+  void sort_embedding_indices_on(ffh_stream s) const;      // one launch group, nothing else on the workspace between a step's gather and its update
   mutable bool emb_sorted_early;         // this step's sort was issued behind the gather: the update is the apply phase only
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
   std::vector<Initializer*> owned_initializers;

@@ -248,6 +248,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--early-sort")) { early_sort = 1; continue; }
     if (is("--sort-at-backward-start")) { early_sort = 2; continue; }
     if (is("--sort-at-interaction-backward")) { early_sort = 3; continue; }
+    if (is("--sort-before-bottom-backward")) { early_sort = 4; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
     if (is("--capture-exchange")) { capture_exchange = true; continue; }
     if (is("--no-bf16-convert-twins")) { bf16_convert_twins = false; continue; }    // A/B: no twin by conversion behind an fp32-kernel layer
@@ -574,6 +575,7 @@ FFModel::~FFModel() {
   api->ffh_event_destroy(ctx, ev_dw_done);
   api->ffh_event_destroy(ctx, ev_z_free);
   api->ffh_event_destroy(ctx, ev_top_mark); api->ffh_event_destroy(ctx, ev_top_opt_done);
+  api->ffh_event_destroy(ctx, ev_sort_done);
   for (auto& kv : trace_tune) for (ffh_event& e : kv.second.ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
   for (ffh_event& e : probe_ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
   api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream); api->ffh_stream_destroy(ctx, dw_stream2);
@@ -996,6 +998,16 @@ void Embedding::backward(const FFModel& ff) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
       // backward(), after the host has enqueued the bottom-MLP backward it overlaps with
       if (!ff.grad_ready_attached) ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
+      if (!ff.emb_sorted_early && ff.early_sort_possible(4)) {
+        // (--sort-before-bottom-backward) the index-only sort ON the compute stream, in front of the bottom MLP's backward: 13 us alone at the
+        // MLPerf shape, where beside the chain kernels of that backward (MFMA-dense) its two launches took 83.  The apply phase -- issued
+        // below, on the side stream -- follows it
+        if (!ff.ev_sort_done) ff.check(ff.api->ffh_event_create_sync(ff.ctx, &ff.ev_sort_done), "event create");
+        ff.sort_embedding_indices_on(ff.stream);
+        ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_sort_done, ff.stream), "event");
+        ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.side_stream, ff.ev_sort_done), "event");
+        ff.emb_sorted_early = true;
+      }
       if (ff.exchange && !ff.config.comm.nonblocking && !ff.use_workers()) {
         ff.emb_update_pending = true;      // host-side collectives on this thread: issue after the bottom-MLP backward is enqueued
       } else {
@@ -2267,6 +2279,8 @@ static void launch_shard_groups(const FFModel* ff, ShardLaunch what, ffh_stream 
     }
   }
 }
+// the index-only sort phase of the fused table update on stream s (Embedding::backward, --sort-before-bottom-backward)
+void FFModel::sort_embedding_indices_on(ffh_stream s) const { launch_shard_groups(this, kSortOnly, s, ctx); }
 
 // the batched gather (fwd) or fused update kernels of this rank's shards alone, no exchange: what bench.py times as the
 // roofline kernels of a multi-rank job

@@ -523,7 +523,8 @@ def test_sort_placement_at_the_interaction_backward_same_bits_on_gpu():
     base = ["--backend", capi.HIP_LIB_PATH, "-b", "4096", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "3000-700000-11-40000",
             "--arch-mlp-bot", "13-64-16", "--arch-mlp-top", "26-32-1", "--data-size", "4096", "--arch-interaction-op", "dot-tril", "--deterministic"]
     out = []
-    for extra, trace in (([], False), (["--sort-at-interaction-backward"], False), (["--sort-at-interaction-backward"], True)):
+    for extra, trace in (([], False), (["--sort-at-interaction-backward"], False), (["--sort-at-interaction-backward"], True),
+                         (["--sort-before-bottom-backward"], False), (["--sort-before-bottom-backward"], True)):
         app = ffmodel.DLRM(base + extra)
         app.warmup(); app.train_steps(3, trace=trace); app.model.sync()
         m = app.model

@@ -186,7 +186,7 @@ def test_sort_placements_and_conversion_twins_do_not_change_the_bits():
     base = ["--backend", H.oracle_backend(), "-b", "2304", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "3000-70000-11",
             "--arch-mlp-bot", "13-64-16", "--arch-mlp-top", "22-32-1", "--data-size", "2304", "--arch-interaction-op", "dot-tril"]
     ref, _ = _run(base, 2)
-    for extra in (["--sort-at-interaction-backward"], ["--early-sort"], ["--sort-at-backward-start"], ["--no-early-sort"]):
+    for extra in (["--sort-at-interaction-backward"], ["--sort-before-bottom-backward"], ["--early-sort"], ["--sort-at-backward-start"], ["--no-early-sort"]):
         got, _ = _run(base + extra, 2)
         for k in ref:
             assert np.array_equal(ref[k], got[k]), (extra, k)
