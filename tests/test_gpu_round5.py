@@ -535,3 +535,41 @@ def test_sort_placement_at_the_interaction_backward_same_bits_on_gpu():
     for other in out[1:]:
         for k in out[0]:
             assert np.array_equal(out[0][k], other[k]), k
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_update_bucket_form_random_sweep(hip, oracle, seed):
+    """Random calls through the bucket form (table count, batch, bag size, row width, row counts from 600 to 30 M, a mix of id distributions
+    per call, SUM or AVG): touched rows bit for bit the oracle's, untouched rows untouched."""
+    rng = np.random.default_rng(1000 + seed)
+    T = int(rng.integers(1, 7))
+    L = int(rng.choice([1, 1, 2, 3]))
+    B = int(rng.integers(2049 // L + 1, 60000 // L))
+    D = int(rng.choice([4, 8, 16, 32, 64]))
+    rows = [int(rng.choice([600, 5000, 70000, 1 << 20, 30000000])) for _ in range(T)]
+    if max(rows) <= 512:
+        rows[0] = 70000
+    kinds = [str(rng.choice(["uniform", "hot", "hot-neighbours", "warm", "zipf", "low-half", "one-row"])) for _ in range(T)]
+    aggr = int(rng.choice([capi.AGGR_MODE_SUM, capi.AGGR_MODE_AVG]))
+    ws = torch.empty(hip.lib.ffh_embedding_bwd_workspace_bytes(T, L, D, B) + 256, dtype=torch.uint8, device=DEV)
+    hip.set_workspace(ws, ws.numel())
+    In = [_bucket_ids(rng, kinds[t], B, L, rows[t]) for t in range(T)]
+    Wd = [torch.rand((r, D), device=DEV, dtype=torch.float32) * 2 - 1 for r in rows]
+    W0 = [w.clone() for w in Wd]
+    Gn = [rng.uniform(-1, 1, (B, D)).astype(np.float32) for _ in rows]
+    I = [torch.from_numpy(i).to(DEV) for i in In]
+    G = [torch.from_numpy(g).to(DEV) for g in Gn]
+    arr = hip.emb_tables([(I[t], Wd[t], G[t], rows[t], D) for t in range(T)])
+    hip.check(hip.lib.ffh_embedding_bwd_sgd_fused_multi(hip.ctx, arr, T, L, D, B, aggr, 0.03, None), "fused")
+    torch.cuda.synchronize()
+    desc = (T, B, L, D, rows, kinds, aggr)
+    if max(rows) > 512:
+        assert _emb_route(hip).startswith("buckets:bits="), (_emb_route(hip), desc)
+    for t in range(T):
+        u, inv = np.unique(In[t], return_inverse=True)
+        ut = torch.from_numpy(u).to(DEV)
+        exp = oracle.embedding_bwd_sgd_fused(inv.reshape(B, L).astype(np.int64), Gn[t], W0[t][ut].cpu().numpy(), 0.03, aggr=aggr)
+        assert Wd[t][ut].cpu().numpy().tobytes() == exp.tobytes(), (t, desc)
+        mask = torch.ones(rows[t], dtype=torch.bool, device=DEV)
+        mask[ut] = False
+        assert torch.equal(Wd[t][mask], W0[t][mask]), (t, desc)
