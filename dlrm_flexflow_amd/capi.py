@@ -96,6 +96,8 @@ _SIGS = {
     "ffh_ctx_set_dw_cu_reserve": (I, [P, I]),
     "ffh_ctx_reserve_scratch": (I, [P, P]),
     "ffh_ctx_bf16_mirror_set": (I, [P, P, SZ, P]),
+    "ffh_ctx_bf16x3_mirror_set": (I, [P, P, SZ, P]),
+    "ffh_convert_f32_to_bf16x3": (I, [P, P, L, L, L, P]),
     "ffh_convert_f32_to_bf16": (I, [P, P, P, L, P]),
     "ffh_malloc": (I, [P, C.POINTER(P), SZ]),
     "ffh_free": (I, [P, P]),

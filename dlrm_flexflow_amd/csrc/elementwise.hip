@@ -466,6 +466,7 @@ int ffh_sgd_update_ex(ffh_ctx* c, float* w, float* g, float* v, int64_t n, float
   else hipLaunchKernelGGL((sgd_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov, zg);
   FFH_LAUNCH_CHECK(c, "sgd_kernel");
   if (unsigned short* tw = ffh_mirror_of(c, w, (size_t)n * 4)) return ffh_convert_f32_to_bf16(c, tw, w, n, s);   // tensor-op mode: the weights' bf16 twin
+  { int col0; if (ffh_planes_of(c, w, (size_t)n * 4, &col0)) return ffh_convert_f32_to_bf16x3(c, w, 1, n, n, s); }      // split mode: their three-plane image
   return FFH_OK;
 }
 
@@ -484,6 +485,7 @@ int ffh_adam_update(ffh_ctx* c, float* w, float* g, float* m, float* v, int64_t 
   else hipLaunchKernelGGL((adam_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, m, v, n, alpha_t, b1, b2, wd, eps, zg);
   FFH_LAUNCH_CHECK(c, "adam_kernel");
   if (unsigned short* tw = ffh_mirror_of(c, w, (size_t)n * 4)) return ffh_convert_f32_to_bf16(c, tw, w, n, s);
+  { int col0; if (ffh_planes_of(c, w, (size_t)n * 4, &col0)) return ffh_convert_f32_to_bf16x3(c, w, 1, n, n, s); }
   return FFH_OK;
 }
 

@@ -28,6 +28,8 @@ constexpr int kMaxChunks = 4;   // row chunks per lane: D <= 4*64*4 = 1024 (vect
 struct EmbArgs {
   ffh_emb_table t[FFH_MAX_TABLES];
   unsigned short* out16[FFH_MAX_TABLES];   // forward, tensor-op mode: bf16 twin of t[i].io (same leading dimension) or null
+  char* out3[FFH_MAX_TABLES];              // forward, split mode: the I32 image group that holds t[i].io[0] (ffh_ctx_bf16x3_mirror_set) or null ...
+  int   out3c[FFH_MAX_TABLES];             // ... and that element's position in its group
   int64_t batch;
   int     ntables;
   int     L;
@@ -45,6 +47,8 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(const EmbArgs a) {
   using vec_t = typename std::conditional<VEC == 4, float4, float>::type;
   const ffh_emb_table tb = a.t[blockIdx.y];
   unsigned short* const o16 = a.out16[blockIdx.y];
+  char* const o3 = a.out3[blockIdx.y];
+  const int o3c = a.out3c[blockIdx.y];
   const int D = a.D, L = a.L;
   const int nvec = D / VEC;                       // vectors per row
   const int lpr = nvec < 64 ? nvec : 64;          // lanes per row
@@ -98,6 +102,12 @@ __global__ __launch_bounds__(256) void emb_fwd_kernel(const EmbArgs a) {
             typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
             const bf2 lo = {(__bf16)f[0], (__bf16)f[1]}, hi = {(__bf16)f[2], (__bf16)f[3]};
             reinterpret_cast<uint2*>(o16 + b * tb.ld)[c] = make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+          }
+          if (VEC == 4 && o3) {       // split mode: the three-plane image of the row piece (ffh_ctx_bf16x3_mirror_set; ld a multiple of 32)
+            uint2 p1, p2, p3;
+            ffh_split_bf16x3(make_float4(f[0], f[1], f[2], f[3]), p1, p2, p3);
+            char* d = o3 + b * tb.ld * 6 + ffh_i32_off(o3c + 4 * c);
+            *reinterpret_cast<uint2*>(d) = p1; *reinterpret_cast<uint2*>(d + 64) = p2; *reinterpret_cast<uint2*>(d + 128) = p3;
           }
         }
       }
@@ -1442,6 +1452,11 @@ int ffh_embedding_fwd_multi(ffh_ctx* c, const ffh_emb_table* tables, int nt, int
     a.t[i] = tables[i];
     // tensor-op mode with a registered twin of the destination: the gather writes the bf16 roundings beside the fp32 rows
     a.out16[i] = (v4 && tables[i].ld % 4 == 0) ? ffh_mirror_of(c, tables[i].io, (size_t)((batch - 1) * tables[i].ld + D) * 4) : nullptr;
+    // split mode with a registered image of the destination (rows a whole number of 32-element groups apart): the three terms beside the fp32 rows
+    int col0 = 0;
+    a.out3[i] = (v4 && tables[i].ld % 32 == 0) ? ffh_planes_of(c, tables[i].io, (size_t)((batch - 1) * tables[i].ld + D) * 4, &col0) : nullptr;
+    a.out3c[i] = col0;
+    if (a.out3[i] && (col0 & 3)) a.out3[i] = nullptr;
   }
   a.batch = batch; a.ntables = nt; a.L = L; a.D = D; a.aggr = aggr;
   const int lpr = nvec < 64 ? nvec : 64;

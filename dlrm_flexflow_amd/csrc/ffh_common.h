@@ -10,7 +10,7 @@
 #include "../../include/ff_hip.h"
 #include "../../include/ffh_rng.h"
 
-struct ffh_mirror_region { const char* base; size_t bytes; char* twin; };   // ffh_ctx_bf16_mirror_set
+struct ffh_mirror_region { const char* base; size_t bytes; char* twin; int planes; };   // ffh_ctx_bf16_mirror_set (planes 1: bf16 twin), ffh_ctx_bf16x3_mirror_set (planes 3: I32 image)
 
 struct ffh_ctx {
   int         device;
@@ -29,7 +29,7 @@ struct ffh_ctx {
   int         dw_cu_reserve;   // ffh_ctx_set_dw_cu_reserve(): CUs the persistent weight-gradient GEMMs leave free
   int         math_mode; // ffh_ctx_set_math_mode(): FFH_MATH_DEFAULT | FFH_MATH_TENSOR_OP_BF16
   float*      zeros;     // 256 zero bytes in device memory: source of out-of-range LDS-DMA chunks (linear.hip)
-  ffh_mirror_region mirrors[32];   // bf16 twins of fp32 buffers (tensor-op mode)
+  ffh_mirror_region mirrors[64];   // bf16 twins (tensor-op mode) and three-plane images (split mode) of fp32 buffers
   int         nmirrors;
   // ctx-owned scratch per stream, reserved by ffh_ctx_reserve_scratch(ctx, stream) and released by ffh_stream_destroy / ffh_ctx_destroy;
   // no compute entry point allocates:
@@ -107,10 +107,29 @@ static inline unsigned short* ffh_mirror_of(const ffh_ctx* c, const void* p, siz
   const char* q = (const char*)p;
   for (int i = 0; i < c->nmirrors; i++) {
     const ffh_mirror_region& r = c->mirrors[i];
-    if (q >= r.base && q + span_bytes <= r.base + r.bytes) return (unsigned short*)(r.twin + (q - r.base) / 2);
+    if (r.planes == 1 && q >= r.base && q + span_bytes <= r.base + r.bytes) return (unsigned short*)(r.twin + (q - r.base) / 2);
   }
   return nullptr;
 }
+
+// The three-plane image (ff_hip.h, "I32") of the fp32 element at p: the address of the 192-byte group that holds it, when [p, p + span_bytes)
+// lies inside a region registered with ffh_ctx_bf16x3_mirror_set and (any_mode or the split mode is on).  *col0 receives the element's
+// position inside its group (0..31); with col0 == nullptr the element must start a group.
+constexpr int kMirrorRegions = 64;
+static inline char* ffh_planes_of(const ffh_ctx* c, const void* p, size_t span_bytes, int* col0 = nullptr, bool any_mode = false) {
+  if (!c || !p || (!any_mode && c->math_mode != FFH_MATH_FP32_SPLIT_BF16X3)) return nullptr;
+  const char* q = (const char*)p;
+  for (int i = 0; i < c->nmirrors; i++) {
+    const ffh_mirror_region& r = c->mirrors[i];
+    if (r.planes != 3 || q < r.base || q + span_bytes > r.base + r.bytes) continue;
+    const size_t e = (size_t)(q - r.base) / 4;
+    if (col0) *col0 = (int)(e & 31); else if (e & 31) return nullptr;
+    return r.twin + (e >> 5) * 192;
+  }
+  return nullptr;
+}
+// byte offset of term 0 of column c (counted from a group's first element) inside a row of the image
+__host__ __device__ static inline int64_t ffh_i32_off(int64_t c) { return (c >> 5) * 192 + (c & 31) * 2; }
 
 // grid sizing for memory-bound grid-stride kernels: enough workgroups to fill
 // 256 CUs x 8 blocks, capped (cdna guide, Guideline 11)
@@ -150,6 +169,28 @@ __device__ __forceinline__ float4 ld4u(const float* p) {
 __device__ __forceinline__ void st4u(float* p, const float4 v) {
   float4u u; u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
   *reinterpret_cast<float4u*>(p) = u;
+}
+
+// x -> (x1, x2, x3), three bfloat16 terms of an fp32 value (FFH_MATH_FP32_SPLIT_BF16X3, ff_hip.h): x1 = bf16(x) nearest-even, x2 = bf16(x - x1),
+// x3 = bf16(x - x1 - x2); both differences are exact in fp32.  Four elements at a time, 22 VALU instructions.  The unpack and the subtraction
+// are spelled as instructions: left to itself hipcc re-converts the low element (v_cvt_pk_bf16_f32 + shift instead of a shift of the packed
+// word) and packs the subtractions into v_pk_add_f32, which costs four times a v_sub_f32 beside an MFMA.  (An infinite x gives x - x1 = NaN.)
+typedef __bf16 ffh_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 ffh_pack_bf16x4(const float4 v) {
+  const ffh_bf16x2 lo = {(__bf16)v.x, (__bf16)v.y}, hi = {(__bf16)v.z, (__bf16)v.w};
+  return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+}
+__device__ __forceinline__ float ffh_bf16_lo_as_f32(const unsigned p) { unsigned r; asm("v_lshlrev_b32 %0, 16, %1" : "=v"(r) : "v"(p)); return __uint_as_float(r); }
+__device__ __forceinline__ float ffh_bf16_hi_as_f32(const unsigned p) { unsigned r; asm("v_and_b32 %0, 0xffff0000, %1" : "=v"(r) : "v"(p)); return __uint_as_float(r); }
+__device__ __forceinline__ float ffh_sub_f32(const float a, const float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float4 ffh_residual_f32x4(const float4 v, const uint2 p) {
+  return make_float4(ffh_sub_f32(v.x, ffh_bf16_lo_as_f32(p.x)), ffh_sub_f32(v.y, ffh_bf16_hi_as_f32(p.x)), ffh_sub_f32(v.z, ffh_bf16_lo_as_f32(p.y)), ffh_sub_f32(v.w, ffh_bf16_hi_as_f32(p.y)));
+}
+__device__ __forceinline__ void ffh_split_bf16x3(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
+  p1 = ffh_pack_bf16x4(v);
+  const float4 r = ffh_residual_f32x4(v, p1);
+  p2 = ffh_pack_bf16x4(r);
+  p3 = ffh_pack_bf16x4(ffh_residual_f32x4(r, p2));
 }
 
 #endif

@@ -1770,6 +1770,10 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
 #undef FFH_SKINNY
     FFH_LAUNCH_CHECK(c, "linear_skinny_bwd_kernel");
     ffh_route_add(c, "linear_bwd|skinny");
+    if (a.do_dx) {      // split mode: the three-plane image of dx (the dy of the layer below), by a pass over what the launch stored
+      int col0 = 0;
+      if (ffh_planes_of(c, dx, (size_t)((batch - 1) * lddx + in) * 4, &col0)) return ffh_convert_f32_to_bf16x3(c, dx, batch, in, lddx, s);
+    }
     return FFH_OK;
   }
   if (label) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: not a one-launch layer (out_dim <= 4, in_dim <= 1024, aligned)");

@@ -558,6 +558,21 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     gz = g.splitk;
   }
   if (gy > 65535 || gz > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm (bf16): grid too large");
+  // split mode: the image of C (ffh_ctx_bf16x3_mirror_set) after a launch of the split-in-kernel form, by a pass over C
+  auto x3_image_of_c = [&]() -> int {
+    if (g.epi == EPI_ATOMIC) return FFH_OK;
+    int col0 = 0;
+    if (!ffh_planes_of(c, g.C, (size_t)((int64_t)(g.M - 1) * g.ldc + g.N) * 4, &col0)) return FFH_OK;
+    return ffh_convert_f32_to_bf16x3(c, g.C, g.M, g.N, g.ldc, s);
+  };
+  if constexpr (!MASK_A) {
+    if (x3) {      // both operands with images: the LDS-DMA form (linear_x3_dma.hip)
+      const int rc = launch_gemm_x3_dma(c, g, AKC && BKC ? BF16_FORM_FWD : (AKC ? BF16_FORM_DX : BF16_FORM_DW), s, name);
+      if (rc < 0) return rc;
+      if (rc > 0) { if (g.db && !AKC && !BKC) g.db_done = 1; return FFH_OK; }
+    }
+  }
+  if (x3) { char tok[96]; snprintf(tok, sizeof tok, "%s|bf16x3_%s|splitk=%d", name, big ? "256x256" : "128x128", g.splitk); ffh_route_add(c, tok); }
   if (x3 && big) {
     auto kern3b = gemm_bf16x3_kernel<AKC, BKC, MASK_A, 256, 256, 128>;
     constexpr int lds3b = 3 * (256 + 256) * kX3BK * 2;          // 96 KB: one 8-wave workgroup per CU
@@ -566,7 +581,7 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     hipLaunchKernelGGL(kern3b, dim3(gx, gy, gz), dim3(512), lds3b, as_stream(s), g);
     hipError_t e3b = hipGetLastError();
     if (e3b != hipSuccess) return ffh_fail_hip(c, e3b, name);
-    return FFH_OK;
+    return x3_image_of_c();
   }
   if (x3) {
     auto kern3 = gemm_bf16x3_kernel<AKC, BKC, MASK_A>;
@@ -575,7 +590,7 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
     hipLaunchKernelGGL(kern3, dim3(gx, gy, gz), dim3(256), kX3Lds, as_stream(s), g);
     hipError_t e3 = hipGetLastError();
     if (e3 != hipSuccess) return ffh_fail_hip(c, e3, name);
-    return FFH_OK;
+    return x3_image_of_c();
   }
   // bf16 twins (ffh_ctx_bf16_mirror_set): the output's twin is written whenever one is registered; the operands come from
   // their twins when both have one and the problem is whole tiles of this launch

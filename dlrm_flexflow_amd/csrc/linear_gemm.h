@@ -92,6 +92,9 @@ int launch_gemm_bf16_form(ffh_ctx* c, GemmArgs& g, int form, ffh_stream s, const
 // Tensor-op mode, operands with bf16 twins, outputs of at least one 256 x 256 tile per CU (linear_bf16_dma.hip): LDS-DMA operand
 // path, two wave groups alternating on the matrix pipe.  g.A16 / g.B16 / g.C16 as launch_gemm_bf16_form found them.
 int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name);     // 1 launched, 0 not served, < 0 error
+// Split mode, both operands with three-plane images (ffh_ctx_bf16x3_mirror_set) that start a 32-element group, leading dimensions and
+// reduction depth multiples of 32 (linear_x3_dma.hip): the LDS-DMA form of the fp32-accurate GEMM; writes the image of C beside C.
+int launch_gemm_x3_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name);       // 1 launched, 0 not served, < 0 error
 
 // The persistent one-workgroup-per-CU fp32 kernels for the big aligned layers (linear_sk.hip): forward (bias + activation),
 // data gradient (store / add, optional relu'-of-the-layer-below mask), weight gradient (stream-K, atomics).

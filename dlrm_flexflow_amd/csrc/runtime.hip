@@ -137,21 +137,23 @@ int ffh_ctx_set_dw_cu_reserve(ffh_ctx* c, int ncus) {
   return FFH_OK;
 }
 
-int ffh_ctx_bf16_mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* twin) {
-  if (!c || !base || bytes == 0 || ((uintptr_t)base & 15) || ((uintptr_t)twin & 15)) return FFH_ERR_BAD_ARG;
+static int mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* twin, int planes, unsigned align) {
+  if (!c || !base || bytes == 0 || ((uintptr_t)base & (align - 1)) || ((uintptr_t)twin & (align - 1))) return FFH_ERR_BAD_ARG;
   int at = -1;
-  for (int i = 0; i < c->nmirrors; i++) if (c->mirrors[i].base == (const char*)base) at = i;
+  for (int i = 0; i < c->nmirrors; i++) if (c->mirrors[i].base == (const char*)base && c->mirrors[i].planes == planes) at = i;
   if (!twin) {
     if (at >= 0) { c->mirrors[at] = c->mirrors[c->nmirrors - 1]; c->nmirrors--; }
     return FFH_OK;
   }
   if (at < 0) {
-    if (c->nmirrors >= 32) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "bf16_mirror_set: more than 32 regions");
+    if (c->nmirrors >= kMirrorRegions) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mirror_set: more than 64 regions");
     at = c->nmirrors++;
   }
-  c->mirrors[at].base = (const char*)base; c->mirrors[at].bytes = bytes; c->mirrors[at].twin = (char*)twin;
+  c->mirrors[at].base = (const char*)base; c->mirrors[at].bytes = bytes; c->mirrors[at].twin = (char*)twin; c->mirrors[at].planes = planes;
   return FFH_OK;
 }
+int ffh_ctx_bf16_mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* twin) { return mirror_set(c, base, bytes, twin, 1, 16); }
+int ffh_ctx_bf16x3_mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* planes) { return mirror_set(c, base, bytes, planes, 3, 128); }
 
 __global__ __launch_bounds__(256) void convert_bf16_kernel(unsigned short* __restrict__ dst, const float* __restrict__ src, int64_t n) {
   ffh_kernel_prio();
@@ -173,6 +175,52 @@ int ffh_convert_f32_to_bf16(ffh_ctx* c, void* dst, const float* src, int64_t n, 
   if (n == 0) return FFH_OK;
   hipLaunchKernelGGL(convert_bf16_kernel, dim3(ffh_grid((n + 3) / 4, 256)), dim3(256), 0, as_stream(s), (unsigned short*)dst, src, n);
   FFH_LAUNCH_CHECK(c, "convert_bf16_kernel");
+  return FFH_OK;
+}
+
+// fp32 -> three bf16 terms, into the I32 image (ff_hip.h).  `img` is the image of the region, e0 the index of src[0] in it; element (r, c) of
+// the sub-matrix is region element e0 + r * ld + c.  Four elements per lane where the pieces are 16-byte aligned on both sides.
+__global__ __launch_bounds__(256) void convert_bf16x3_kernel(char* __restrict__ img, const float* __restrict__ src, int64_t e0, int64_t rows, int64_t cols, int64_t ld, int vec) {
+  ffh_kernel_prio();
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  if (vec) {
+    const int64_t per_row = cols / 4, total = rows * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+      const int64_t r = i / per_row, cc = (i - r * per_row) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(src + r * ld + cc);
+      uint2 p1, p2, p3;
+      ffh_split_bf16x3(v, p1, p2, p3);
+      const int64_t e = e0 + r * ld + cc;
+      char* d = img + (e >> 5) * 192 + (e & 31) * 2;
+      *reinterpret_cast<uint2*>(d) = p1; *reinterpret_cast<uint2*>(d + 64) = p2; *reinterpret_cast<uint2*>(d + 128) = p3;
+    }
+  } else {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+      const int64_t r = i / cols, cc = i - r * cols;
+      const float x = src[r * ld + cc];
+      const __bf16 b1 = (__bf16)x; const float r1 = x - (float)b1;
+      const __bf16 b2 = (__bf16)r1; const float r2 = r1 - (float)b2;
+      const __bf16 b3 = (__bf16)r2;
+      const int64_t e = e0 + r * ld + cc;
+      unsigned short* d = reinterpret_cast<unsigned short*>(img + (e >> 5) * 192 + (e & 31) * 2);
+      d[0] = __builtin_bit_cast(unsigned short, b1); d[32] = __builtin_bit_cast(unsigned short, b2); d[64] = __builtin_bit_cast(unsigned short, b3);
+    }
+  }
+}
+
+int ffh_convert_f32_to_bf16x3(ffh_ctx* c, const float* src, int64_t rows, int64_t cols, int64_t ld, ffh_stream s) {
+  FFH_REQUIRE(c, rows >= 0 && cols >= 0 && (rows <= 1 || ld >= cols), "convert_f32_to_bf16x3: bad dims");
+  if (rows == 0 || cols == 0) return FFH_OK;
+  FFH_REQUIRE(c, src != nullptr, "convert_f32_to_bf16x3: null pointer");
+  int col0 = 0;
+  char* grp = ffh_planes_of(c, src, (size_t)((rows - 1) * ld + cols) * 4, &col0, true);
+  if (!grp) return ffh_fail(c, FFH_ERR_BAD_ARG, "convert_f32_to_bf16x3: not inside a region registered with ffh_ctx_bf16x3_mirror_set");
+  // (the kernel takes the group's address as the image origin and col0 as e0: the same addresses as from the region's base)
+  const int vec = (col0 % 4 == 0) && (cols % 4 == 0) && (rows == 1 || ld % 4 == 0) && (((uintptr_t)src & 15) == 0);
+  const int64_t work = vec ? rows * (cols / 4) : rows * cols;
+  hipLaunchKernelGGL(convert_bf16x3_kernel, dim3(ffh_grid(work, 256)), dim3(256), 0, as_stream(s), grp, src, (int64_t)col0, rows, cols, ld, vec);
+  FFH_LAUNCH_CHECK(c, "convert_bf16x3_kernel");
   return FFH_OK;
 }
 

@@ -339,6 +339,7 @@ class Linear : public Op {
                                    // launches all of them (ffh_mlp_chain_fwd, ABI 12)
   mutable bool fwd_done_by_chain;  // set by the chain's lowest layer for this forward()
   void* out_twin = nullptr;        // tensor-op mode: where forward() leaves the bf16 rounding of its output (allocate() step 7), or null
+  bool out_twin_x3 = false;        // ... split mode: out_twin is the output's three-plane image (ffh_convert_f32_to_bf16x3 finds it by the registration)
   std::vector<Linear*> chain_bwd;  // non-empty on the TOP layer of the chain FFModel::backward runs as one call (ffh_mlp_chain_bwd): members bottom -> top
   Initializer *kernel_initializer, *bias_initializer;
 };

@@ -729,7 +729,8 @@ void Linear::forward(const FFModel& ff) {
                                   in_padded, out_channels, b, (int)activation, ff.stream), name);
   // tensor-op mode: this layer runs on the fp32 kernels (in_dim or out_dim below FFH_BF16_MIN_DIM) but feeds one on the bf16 pipe: its
   // output's twin by an explicit conversion (allocate(), step 7), so that the consumer reads both operands at two bytes per element
-  if (out_twin) ff.check(ff.api->ffh_convert_f32_to_bf16(ff.ctx, out_twin, (const float*)y.impl->ptr, b * (int64_t)y.impl->ld, ff.stream), name);
+  if (out_twin && out_twin_x3) ff.check(ff.api->ffh_convert_f32_to_bf16x3(ff.ctx, (const float*)y.impl->ptr, b, out_channels, y.impl->ld, ff.stream), name);
+  else if (out_twin) ff.check(ff.api->ffh_convert_f32_to_bf16(ff.ctx, out_twin, (const float*)y.impl->ptr, b * (int64_t)y.impl->ld, ff.stream), name);
 }
 int Linear::backward_pair(const FFModel& ff) {
   Linear* lo = pair_lower;
@@ -1991,9 +1992,12 @@ void FFModel::allocate() {
     if (p.owner_op->op_type == OP_LINEAR && p.numDim == 2) return (size_t)p.adim[1] * (size_t)static_cast<const Linear*>(p.owner_op)->in_padded;
     return p.get_volume();
   };
+  // (a tensor's range is a whole number of 32 floats: every tensor starts a 128-byte line and a group of the split mode's plane image,
+  //  include/ff_hip.h ffh_ctx_bf16x3_mirror_set; the pad floats are zeros that every slab-wise kernel keeps zero)
+  auto slab_span = [&](const Parameter& p) -> size_t { return (slab_elems(p) + 31) / 32 * 32; };
   mlp_count = 0;
   for (Parameter& p : parameters)
-    if (in_dense_slab(p)) mlp_count += (slab_elems(p) + 3) / 4 * 4;
+    if (in_dense_slab(p)) mlp_count += slab_span(p);
   mlp_weights = (float*)dmalloc(std::max<size_t>(mlp_count, 64) * 4);
   mlp_grads = (float*)dmalloc(std::max<size_t>(mlp_count, 64) * 4);
   check(api->ffh_zero(ctx, mlp_weights, std::max<size_t>(mlp_count, 64) * 4, stream), "zero");
@@ -2011,7 +2015,7 @@ void FFModel::allocate() {
       im->grad_ld = im->ld;
       im->alias = true;
       im->bytes = slab_elems(p) * 4;
-      off_p += (slab_elems(p) + 3) / 4 * 4;
+      off_p += slab_span(p);
     } else {
       Embedding* e = static_cast<Embedding*>(p.owner_op);
       if (!e->held_here(rank)) continue;   // sole owner (or one column / row block per rank): never replicated, never all-reduced
@@ -2034,7 +2038,7 @@ void FFModel::allocate() {
     for (const Embedding* e : embeddings) if (e->replicated) ok = false;          // (data-parallel tables live in the slab between the two MLPs)
     for (const Parameter& p : parameters) {
       if (!in_dense_slab(p)) continue;
-      if (p.owner_op->layer_index < first_emb) { if (p.impl->grad != mlp_grads + at) ok = false; at += (slab_elems(p) + 3) / 4 * 4; }
+      if (p.owner_op->layer_index < first_emb) { if (p.impl->grad != mlp_grads + at) ok = false; at += slab_span(p); }
     }
     for (size_t l = (size_t)first_emb; l < layers.size() && first_top_linear < 0; l++) if (layers[l]->op_type == OP_LINEAR) first_top_linear = (int)l;
     if (ok && at > 0 && at < mlp_count && first_top_linear >= 0) bottom_floats = at;
@@ -2070,8 +2074,8 @@ void FFModel::allocate() {
         if (!li) continue;
         // the layer's range: kernel, then bias, adjacent in the slab (step 5)
         const size_t lo = (size_t)(li->weights[0].impl->grad - mlp_grads);
-        size_t hi = lo + (li->weights[0].impl->bytes / 4 + 3) / 4 * 4;
-        if (li->use_bias) hi = (size_t)(li->weights[1].impl->grad - mlp_grads) + (li->weights[1].impl->bytes / 4 + 3) / 4 * 4;
+        size_t hi = lo + (li->weights[0].impl->bytes / 4 + 31) / 32 * 32;
+        if (li->use_bias) hi = (size_t)(li->weights[1].impl->grad - mlp_grads) + (li->weights[1].impl->bytes / 4 + 31) / 32 * 32;
         if (li == big && chunks > 1) {      // its own buckets: row block c of the kernel; the last one takes the bias too
           close();
           const size_t per = (size_t)(big->out_channels / chunks) * (size_t)big->weights[0].impl->ld;
@@ -2146,17 +2150,28 @@ void FFModel::allocate() {
   //   * the output of such a Linear with storage of its own; a Concat output all of whose inputs are written in place by
   //     tables and such Linears;
   //   * the gradient buffer of a tensor whose single consumer is such a Linear storing (not accumulating) its data gradient.
+  // The split mode (--fp32-split-bf16x3) keeps, for the same buffers and by the same rules, the THREE-PLANE IMAGE of ffh_ctx_bf16x3_mirror_set
+  // (6 bytes per element; FFH_BF16X3_IMAGE_BYTES): its GEMMs then stream the operands' bf16 terms by LDS-DMA instead of splitting fp32 tiles in
+  // registers (csrc/linear_x3_dma.hip).  twin_at() below is the one place the two layouts differ for this layer.
   n_twin_regions = 0;
-  if (config.allow_tensor_op_math_conversion && config.bf16_twins && mlp_count > 0) {
+  const bool x3_images = config.fp32_split_bf16x3 && !config.allow_tensor_op_math_conversion;
+  if ((config.allow_tensor_op_math_conversion || x3_images) && config.bf16_twins && mlp_count > 0) {
     const size_t ab = std::max<size_t>(act_bytes, 256);
-    act_twin = dmalloc(ab / 2 + 256); grad_twin = dmalloc(ab / 2 + 256); w_twin = dmalloc((size_t)mlp_count * 2 + 256);
-    check(api->ffh_zero(ctx, act_twin, ab / 2 + 256, stream), "zero"); check(api->ffh_zero(ctx, grad_twin, ab / 2 + 256, stream), "zero");
-    check(api->ffh_zero(ctx, w_twin, (size_t)mlp_count * 2 + 256, stream), "zero");
+    const size_t act_tb = x3_images ? FFH_BF16X3_IMAGE_BYTES(ab) : ab / 2, w_tb = x3_images ? FFH_BF16X3_IMAGE_BYTES((size_t)mlp_count * 4) : (size_t)mlp_count * 2;
+    act_twin = dmalloc(act_tb + 256); grad_twin = dmalloc(act_tb + 256); w_twin = dmalloc(w_tb + 256);
+    check(api->ffh_zero(ctx, act_twin, act_tb + 256, stream), "zero"); check(api->ffh_zero(ctx, grad_twin, act_tb + 256, stream), "zero");
+    check(api->ffh_zero(ctx, w_twin, w_tb + 256, stream), "zero");
+    // the twin / image address of the fp32 byte offset `off` of a slab (the image: whole 128-byte groups only)
+    auto twin_at = [&](void* twin_base, size_t off) -> void* {
+      if (!x3_images) return (char*)twin_base + off / 2;
+      return off % 128 ? nullptr : (char*)twin_base + off / 128 * 192;
+    };
     auto reg = [&](const void* base, size_t bytes, void* twin) {
-      if (bytes == 0 || n_twin_regions >= 30) return;
-      check(api->ffh_ctx_bf16_mirror_set(ctx, base, bytes, twin), "bf16 twin");
-      if (dw_worker) check(api->ffh_ctx_bf16_mirror_set(dw_worker->ctx(), base, bytes, twin), "bf16 twin");
-      if (side_worker) check(api->ffh_ctx_bf16_mirror_set(side_worker->ctx(), base, bytes, twin), "bf16 twin");
+      if (bytes == 0 || !twin || n_twin_regions >= 30) return;
+      auto set = x3_images ? api->ffh_ctx_bf16x3_mirror_set : api->ffh_ctx_bf16_mirror_set;
+      check(set(ctx, base, bytes, twin), "bf16 twin");
+      if (dw_worker) check(set(dw_worker->ctx(), base, bytes, twin), "bf16 twin");
+      if (side_worker) check(set(side_worker->ctx(), base, bytes, twin), "bf16 twin");
       n_twin_regions++;
     };
     reg(mlp_weights, (size_t)mlp_count * 4, w_twin);
@@ -2172,7 +2187,7 @@ void FFModel::allocate() {
       bool act_ok = false;
       if (twin_linear(op)) act_ok = true;
       else if (Concat* c = dynamic_cast<Concat*>(op)) {
-        act_ok = !exchange && c->numInputs > 0;
+        act_ok = !exchange && c->numInputs > 0 && (!x3_images || im->ld % 32 == 0);      // (the gather writes the image of rows that are whole 32-element groups apart)
         for (int i = 0; i < c->numInputs && act_ok; i++) {
           const Tensor& in = c->inputs[i];
           auto it = alias_of.find(in.impl);
@@ -2191,11 +2206,12 @@ void FFModel::allocate() {
       if (!act_ok && config.bf16_convert_twins && op->op_type == OP_LINEAR && ncons == 1 && only && twin_linear(only) && !use_workers() && im->ld % 8 == 0) {
         Linear* li = static_cast<Linear*>(op);
         if (!li->pair_upper && !li->pair_lower) {      // (the chain launches stand back in tensor-op mode: mlp_chain_usable)
-          li->out_twin = (char*)act_twin + ((const char*)im->ptr - act_slab) / 2;
-          act_ok = true;
+          li->out_twin = twin_at(act_twin, (size_t)((const char*)im->ptr - act_slab));
+          li->out_twin_x3 = x3_images;
+          act_ok = li->out_twin != nullptr;
         }
       }
-      if (act_ok) reg(im->ptr, im->bytes, (char*)act_twin + ((const char*)im->ptr - act_slab) / 2);
+      if (act_ok) reg(im->ptr, im->bytes, twin_at(act_twin, (size_t)((const char*)im->ptr - act_slab)));
       // the gradient of this tensor: one consumer, a twin-writing Linear that stores its data gradient
       // (... or the one-launch backward of a layer with <= 4 outputs, which writes the twin of its data gradient too: the
       //  256 -> 1 layer on top of the Terabyte MLP, whose input gradient is the 512 -> 256 layer's dy)
@@ -2208,7 +2224,7 @@ void FFModel::allocate() {
       const Linear* prod = op->op_type == OP_LINEAR ? static_cast<const Linear*>(op) : nullptr;
       const bool twin_read = prod && twin_linear(prod) && (prod->dy_premasked || prod->activation == AC_MODE_NONE);
       if (ncons == 1 && twin_read && only && (twin_linear(only) || skinny_twin(only)) && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange)
-        reg(im->grad, im->bytes, (char*)grad_twin + ((const char*)im->grad - act_grad_slab) / 2);
+        reg(im->grad, im->bytes, twin_at(grad_twin, (size_t)((const char*)im->grad - act_grad_slab)));
     }
   }
   check(api->ffh_stream_sync(ctx, stream), "allocate sync");
@@ -2542,7 +2558,8 @@ void FFModel::reset_metrics() {
 // every replay) and from forward() for eager steps: the captured GEMMs of a replayed step never read a stale twin.
 void FFModel::refresh_weight_twin() const {
   if (!w_twin || !w_twin_dirty) return;
-  check(api->ffh_convert_f32_to_bf16(ctx, w_twin, mlp_weights, (int64_t)mlp_count, stream), "weight twin");
+  if (config.fp32_split_bf16x3 && !config.allow_tensor_op_math_conversion) check(api->ffh_convert_f32_to_bf16x3(ctx, mlp_weights, 1, (int64_t)mlp_count, (int64_t)mlp_count, stream), "weight image");
+  else check(api->ffh_convert_f32_to_bf16(ctx, w_twin, mlp_weights, (int64_t)mlp_count, stream), "weight twin");
   w_twin_dirty = false;
 }
 void FFModel::note_weight_write(const void* p) const {

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 13   /* 13: ffh_embedding_last_route; 12: ffh_mlp_chain_fwd / _bwd (a chain of narrow Linear layers as three launches), ffh_ctx_reserve_scratch; 11: ffh_stream_create_with_priority; 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 14   /* 14: ffh_ctx_bf16x3_mirror_set, ffh_convert_f32_to_bf16x3 (three-plane images for the fp32-accurate split mode); 13: ffh_embedding_last_route; 12: ffh_mlp_chain_fwd / _bwd (a chain of narrow Linear layers as three launches), ffh_ctx_reserve_scratch; 11: ffh_stream_create_with_priority; 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -172,6 +172,33 @@ int         ffh_ctx_set_math_mode(ffh_ctx* ctx, int mode);
  * applies a live activation derivative to dy in place (RELU / SIGMOID without FFH_LINEAR_DY_PREMASKED) does not read dy's twin. */
 int         ffh_ctx_bf16_mirror_set(ffh_ctx* ctx, const void* fp32_base, size_t fp32_bytes, void* bf16_base);
 int         ffh_convert_f32_to_bf16(ffh_ctx* ctx, void* dst_bf16, const float* src, int64_t count, ffh_stream s);
+/* THREE-PLANE IMAGES for the fp32-accurate split mode (ABI 14; no reference counterpart).  In FFH_MATH_FP32_SPLIT_BF16X3 every GEMM operand
+ * element is used as three bfloat16 terms x1 + x2 + x3; a kernel that splits fp32 operands as it stages them spends 3 vector instructions
+ * per matrix instruction and moves every fp32 tile through registers (the split-in-kernel form, still the fall-back).  A caller may instead
+ * give an fp32 buffer a PLANE IMAGE that its producers keep current, and the GEMMs then bring the terms on chip by LDS-DMA with no vector
+ * work on the operand path (csrc/linear_x3_dma.hip):
+ *   ffh_ctx_bf16x3_mirror_set(ctx, fp32_base, fp32_bytes, planes)   registers the region (planes NULL: removes it); fp32_base and planes
+ *                                                                   128-byte aligned, planes holds FFH_BF16X3_IMAGE_BYTES(fp32_bytes)
+ * Layout of the image ("I32"): 32 consecutive fp32 elements (128 bytes, counted from fp32_base) <-> 192 bytes
+ *   [ x1 of the 32 | x2 of the 32 | x3 of the 32 ]   (64 bytes each; x1 = bf16(x) nearest-even, x2 = bf16(x - x1), x3 = bf16(x - x1 - x2),
+ *                                                      both differences exact in fp32)
+ * so element e (index from fp32_base) has its term p at byte (e / 32) * 192 + p * 64 + (e % 32) * 2.  A k-tile of 32 of a row is 192
+ * contiguous bytes, 128 columns of a row 768: both operand orientations of the GEMMs stream whole runs.
+ * From then on, in FFH_MATH_FP32_SPLIT_BF16X3 only,
+ *   the producers listed for the bf16 twins above (ffh_linear_fwd: y; ffh_linear_bwd / _ex / _mse: dx; ffh_embedding_fwd / _multi: out, for
+ *   leading dimensions that are multiples of 32; ffh_sgd_update / _ex, ffh_adam_update: w; ffh_convert_f32_to_bf16x3: explicit) keep the image of
+ *   what they write into a registered region current;
+ *   a wide Linear GEMM takes BOTH operands from their images when both lie in registered regions, start a 32-element group and have leading
+ *   dimensions that are multiples of 32 (reduction depth a multiple of 32); otherwise it splits in the kernel as before.
+ * Same arithmetic either way (the six products per 32-deep k-step in the same order, fp32 accumulation): a forward / data-gradient result is
+ * BIT-identical with and without images; weight gradients differ in the order of their split-K atomics only.  Validity is the caller's
+ * contract, exactly as for the bf16 twins. */
+#define FFH_BF16X3_IMAGE_BYTES(fp32_bytes) ((((size_t)(fp32_bytes) + 127) / 128) * 192)
+int         ffh_ctx_bf16x3_mirror_set(ffh_ctx* ctx, const void* fp32_base, size_t fp32_bytes, void* planes);
+/* recomputes the image of the rows x cols sub-matrix at src (leading dimension ld elements; rows == 1: a flat range) of a registered region;
+ * any math mode.  FFH_ERR_BAD_ARG when [src, src + ((rows - 1) * ld + cols) * 4) is not inside a region registered with
+ * ffh_ctx_bf16x3_mirror_set. */
+int         ffh_convert_f32_to_bf16x3(ffh_ctx* ctx, const float* src, int64_t rows, int64_t cols, int64_t ld, ffh_stream s);
 /* on != 0: every weight / bias gradient is produced WITHOUT floating-point atomics -- no split-K over workgroups (one
  * workgroup owns an output element and adds its k-ordered sum once), no per-workgroup partials meeting in one address;
  * the one-launch skinny / pair / dX+dW forms that rely on such atomics report FFH_ERR_UNSUPPORTED or are bypassed.  Results
@@ -639,7 +666,7 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
  * FFModel shim and by tests/test_abi_symbols.py). */
 #define FFH_API_LIST(X) \
   X(ffh_abi_version) X(ffh_backend_name) X(ffh_ctx_create) X(ffh_ctx_destroy) X(ffh_ctx_default) \
-  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) X(ffh_ctx_set_dw_cu_reserve) X(ffh_ctx_reserve_scratch) X(ffh_ctx_bf16_mirror_set) X(ffh_convert_f32_to_bf16) \
+  X(ffh_last_error_string) X(ffh_device_query) X(ffh_ctx_set_workspace) X(ffh_ctx_set_math_mode) X(ffh_ctx_set_deterministic) X(ffh_ctx_set_dw_cu_reserve) X(ffh_ctx_reserve_scratch) X(ffh_ctx_bf16_mirror_set) X(ffh_convert_f32_to_bf16) X(ffh_ctx_bf16x3_mirror_set) X(ffh_convert_f32_to_bf16x3) \
   X(ffh_malloc) X(ffh_free) X(ffh_memcpy_h2d) X(ffh_memcpy_d2h) X(ffh_memcpy_d2d) \
   X(ffh_stream_create) X(ffh_stream_create_with_priority) X(ffh_stream_destroy) X(ffh_stream_sync) X(ffh_device_sync) \
   X(ffh_event_create) X(ffh_event_create_sync) X(ffh_event_destroy) X(ffh_event_record) X(ffh_event_sync) \

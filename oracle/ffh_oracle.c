@@ -49,6 +49,8 @@ struct ffh_ctx {
   float* colsum_dst; int colsum_ncols, colsum_used;   /* ffh_linear_bwd_set_dx_colsum: pending for the next ffh_linear_bwd / _ex */
   int    scatter_ncols, scatter_used;
   int    math_mode;                  /* ffh_ctx_set_math_mode */
+  struct { const char* base; size_t bytes; char* img; } x3[64];   /* ffh_ctx_bf16x3_mirror_set */
+  int    nx3;
 };
 
 static int fail(ffh_ctx* c, int code, const char* msg) {
@@ -124,6 +126,43 @@ int ffh_convert_f32_to_bf16(ffh_ctx* c, void* dst, const float* src, int64_t n, 
   uint16_t* d = (uint16_t*)dst;
   for (int64_t i = 0; i < n; i++) { const float r = bf16_round(src[i]); uint32_t u; memcpy(&u, &r, 4); d[i] = (uint16_t)(u >> 16); }
   return FFH_OK;
+}
+/* Three-plane images of the split mode (ff_hip.h, "I32": 32 fp32 elements <-> 192 bytes [x1 | x2 | x3], x1 = bf16(x), x2 = bf16(x - x1),
+ * x3 = bf16(x - x1 - x2)).  The oracle's GEMMs never read them (its split mode is the fp32 arithmetic the mode is held to); registrations are
+ * kept so that ffh_convert_f32_to_bf16x3 can restate the image on the host -- the tests compare the HIP producers' images with it bit for bit. */
+int ffh_ctx_bf16x3_mirror_set(ffh_ctx* c, const void* base, size_t bytes, void* img) {
+  if (!c || !base || bytes == 0 || ((uintptr_t)base & 127) || ((uintptr_t)img & 127)) return FFH_ERR_BAD_ARG;
+  int at = -1;
+  for (int i = 0; i < c->nx3; i++) if (c->x3[i].base == (const char*)base) at = i;
+  if (!img) { if (at >= 0) c->x3[at] = c->x3[--c->nx3]; return FFH_OK; }
+  if (at < 0) { if (c->nx3 >= 64) return fail(c, FFH_ERR_UNSUPPORTED, "bf16x3_mirror_set: more than 64 regions"); at = c->nx3++; }
+  c->x3[at].base = (const char*)base; c->x3[at].bytes = bytes; c->x3[at].img = (char*)img;
+  return FFH_OK;
+}
+int ffh_convert_f32_to_bf16x3(ffh_ctx* c, const float* src, int64_t rows, int64_t cols, int64_t ld, ffh_stream s) {
+  (void)s;
+  if (!c || rows < 0 || cols < 0 || (rows > 1 && ld < cols)) return FFH_ERR_BAD_ARG;
+  if (rows == 0 || cols == 0) return FFH_OK;
+  if (!src) return FFH_ERR_BAD_ARG;
+  const char* q = (const char*)src;
+  const size_t span = (size_t)((rows - 1) * ld + cols) * 4;
+  for (int i = 0; i < c->nx3; i++) {
+    if (q < c->x3[i].base || q + span > c->x3[i].base + c->x3[i].bytes) continue;
+    const int64_t e0 = (int64_t)(q - c->x3[i].base) / 4;
+    for (int64_t r = 0; r < rows; r++)
+      for (int64_t k = 0; k < cols; k++) {
+        const float x = src[r * ld + k];
+        const float x1 = bf16_round(x), r1 = x - x1, x2 = bf16_round(r1), r2 = r1 - x2, x3 = bf16_round(r2);
+        const int64_t e = e0 + r * ld + k;
+        uint16_t* d = (uint16_t*)(c->x3[i].img + (e >> 5) * 192 + (e & 31) * 2);
+        uint32_t u;
+        memcpy(&u, &x1, 4); d[0] = (uint16_t)(u >> 16);
+        memcpy(&u, &x2, 4); d[32] = (uint16_t)(u >> 16);
+        memcpy(&u, &x3, 4); d[64] = (uint16_t)(u >> 16);
+      }
+    return FFH_OK;
+  }
+  return fail(c, FFH_ERR_BAD_ARG, "convert_f32_to_bf16x3: not inside a region registered with ffh_ctx_bf16x3_mirror_set");
 }
 static inline int use_bf16(const ffh_ctx* c, int in, int out) {
   return c && c->math_mode == FFH_MATH_TENSOR_OP_BF16 && in >= FFH_BF16_MIN_DIM && out >= FFH_BF16_MIN_DIM;
