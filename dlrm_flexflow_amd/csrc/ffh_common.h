@@ -101,6 +101,8 @@ static inline hipStream_t as_stream(ffh_stream s) { return (hipStream_t)s; }
 #define FFH_LAB_F64(name, dflt) (dflt)
 #endif
 
+static inline bool ffh_split_mode(const ffh_ctx* c) { return c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3 || c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3_ALL; }
+
 // the bf16 twin of the fp32 element at p when [p, p + span_bytes) lies inside a registered region and the tensor-op mode is on
 static inline unsigned short* ffh_mirror_of(const ffh_ctx* c, const void* p, size_t span_bytes) {
   if (!c || !p || c->math_mode != FFH_MATH_TENSOR_OP_BF16) return nullptr;
@@ -117,7 +119,7 @@ static inline unsigned short* ffh_mirror_of(const ffh_ctx* c, const void* p, siz
 // position inside its group (0..31); with col0 == nullptr the element must start a group.
 constexpr int kMirrorRegions = 64;
 static inline char* ffh_planes_of(const ffh_ctx* c, const void* p, size_t span_bytes, int* col0 = nullptr, bool any_mode = false) {
-  if (!c || !p || (!any_mode && c->math_mode != FFH_MATH_FP32_SPLIT_BF16X3)) return nullptr;
+  if (!c || !p || (!any_mode && !ffh_split_mode(c))) return nullptr;
   const char* q = (const char*)p;
   for (int i = 0; i < c->nmirrors; i++) {
     const ffh_mirror_region& r = c->mirrors[i];

@@ -1644,7 +1644,7 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   g.C = y; g.ldc = ldy; g.bias = bias;
   g.M = (int)batch; g.N = out; g.K = in;
   g.epi = EPI_STORE; g.act = act;
-  if (use_bf16(c, in, out)) return launch_gemm_bf16_form(c, g, BF16_FORM_FWD, s, "linear_fwd gemm (bf16)");
+  if (use_bf16(c, in, out, batch)) return launch_gemm_bf16_form(c, g, BF16_FORM_FWD, s, "linear_fwd gemm (bf16)");
   {
     // big aligned layers: the persistent one-workgroup-per-CU kernel (linear_sk.hip)
     const int rc = launch_gemm_sk(c, g, SK_FORM_FWD, s, "linear_fwd gemm");
@@ -1777,7 +1777,7 @@ int linear_bwd_impl(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_t 
     return FFH_OK;
   }
   if (label) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "linear_bwd_mse: not a one-launch layer (out_dim <= 4, in_dim <= 1024, aligned)");
-  if (use_bf16(c, in, out)) {
+  if (use_bf16(c, in, out, batch)) {
     // tensor-op math mode: the activation gradient (and db) as its own fp32 pass over dy, then the two GEMMs on bf16 operands
     bool relu_ = act == FFH_AC_MODE_RELU;
     auto act_pass = [&](ffh_stream st, int a) -> int { return launch_act_bwd_bias(c, dy, lddy, y, ldy, db, out, batch, a, st); };

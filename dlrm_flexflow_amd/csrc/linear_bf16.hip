@@ -507,7 +507,7 @@ __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16x3_kernel(const GemmArg
 template <bool AKC, bool BKC, bool MASK_A = false>
 int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0) return FFH_OK;
-  const bool x3 = c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3;      // three bf16 planes per operand: fp32-accurate
+  const bool x3 = ffh_split_mode(c);      // three bf16 planes per operand: fp32-accurate
   // 256 x 256 tiles (one 8-wave workgroup per CU, 128 x 64 per wave) where the output still fills the chip with them: half
   // the operand traffic per flop.  Measured at batch 32768: forward 3456 -> 1024 492 -> 353 us, 1024 -> 1024 162 -> 143;
   // dX +3...6 % from a reduction depth of 1024 up, slower below; the split-K weight-gradient form: see below.

@@ -79,8 +79,13 @@ bool glds_set_lds(K kern, int bytes) {
   return true;
 }
 
-inline bool use_bf16(const ffh_ctx* c, int in, int out) {     // either bf16-pipe mode: same layers, same launch paths
-  return (c->math_mode == FFH_MATH_TENSOR_OP_BF16 || c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3) && in >= FFH_BF16_MIN_DIM && out >= FFH_BF16_MIN_DIM;
+inline bool use_bf16(const ffh_ctx* c, int in, int out, int64_t batch) {     // either bf16-pipe mode: same launch paths
+  if (in < FFH_BF16_MIN_DIM || out < FFH_BF16_MIN_DIM) return false;
+  if (c->math_mode == FFH_MATH_TENSOR_OP_BF16) return true;
+  // the split mode only where it is the faster exact-to-fp32 form -- GEMMs of at least FFH_BF16X3_MIN_FLOP: at 32768 samples 512 -> 256 (8.6 GFLOP)
+  // forward takes 88-111 us on the split kernels against 66-73 us on the fp32 ones, 256 -> 128 70 against 22, 1024 -> 512 (34 GFLOP) 153 against 243;
+  // at 4096 samples 1024 -> 512 (4.3 GFLOP) 65 against 48, 1024 -> 1024 (8.6) 65 against 78, 3456 -> 1024 (29) 192 against 232
+  return c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3_ALL || (c->math_mode == FFH_MATH_FP32_SPLIT_BF16X3 && 2.0 * (double)batch * (double)in * (double)out >= FFH_BF16X3_MIN_FLOP);
 }
 
 // The GEMM forms of a Linear layer on the bf16 matrix pipe (tensor-op and fp32-accurate split modes; linear_bf16.hip)

@@ -409,7 +409,7 @@ namespace ffh_gemm {
 // 1: launched; 0: not this kernel's problem (nothing launched); < 0: error.  g.C3 (the image of C, or null) is set by the caller.
 int launch_gemm_x3_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name) {
   static const int off = FFH_LAB_INT("FFH_X3_NO_DMA", 0);     // A/B switch (tools/ab.sh)
-  if (off || c->math_mode != FFH_MATH_FP32_SPLIT_BF16X3 || g.a_not_twinned) return 0;
+  if (off || !ffh_split_mode(c) || g.a_not_twinned) return 0;
   if (form != BF16_FORM_FWD && form != BF16_FORM_DX && form != BF16_FORM_DW) return 0;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.K % X_BK || g.N % 8) return 0;
   if (g.colmap || g.act_y || g.fuse) return 0;

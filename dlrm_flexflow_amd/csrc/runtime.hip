@@ -126,7 +126,7 @@ int ffh_ctx_set_workspace(ffh_ctx* c, void* ws, size_t bytes) {
 }
 
 int ffh_ctx_set_math_mode(ffh_ctx* c, int mode) {
-  if (!c || (mode != FFH_MATH_DEFAULT && mode != FFH_MATH_TENSOR_OP_BF16 && mode != FFH_MATH_FP32_SPLIT_BF16X3)) return FFH_ERR_BAD_ARG;
+  if (!c || (mode != FFH_MATH_DEFAULT && mode != FFH_MATH_TENSOR_OP_BF16 && mode != FFH_MATH_FP32_SPLIT_BF16X3 && mode != FFH_MATH_FP32_SPLIT_BF16X3_ALL)) return FFH_ERR_BAD_ARG;
   c->math_mode = mode;
   return FFH_OK;
 }

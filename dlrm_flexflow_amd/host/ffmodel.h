@@ -339,6 +339,7 @@ class Linear : public Op {
                                    // launches all of them (ffh_mlp_chain_fwd, ABI 12)
   mutable bool fwd_done_by_chain;  // set by the chain's lowest layer for this forward()
   void* out_twin = nullptr;        // tensor-op mode: where forward() leaves the bf16 rounding of its output (allocate() step 7), or null
+  bool dx_image = false;           // split mode: backward() leaves the three-plane image of the data gradient it stores (allocate() step 7)
   bool out_twin_x3 = false;        // ... split mode: out_twin is the output's three-plane image (ffh_convert_f32_to_bf16x3 finds it by the registration)
   std::vector<Linear*> chain_bwd;  // non-empty on the TOP layer of the chain FFModel::backward runs as one call (ffh_mlp_chain_bwd): members bottom -> top
   Initializer *kernel_initializer, *bias_initializer;
@@ -387,6 +388,7 @@ class Concat : public Op {
   mutable bool bwd_done;        // the consumer stored its data gradient straight into this Concat's inputs (ffh_linear_bwd_set_dx_scatter)
   int axis;                     // Legion axis (user axis flipped, [ref: src/ops/concat.cu:29-49,109-112])
   bool bwd_overwrite;           // every input has this Concat as its only consumer: slices are stored, not accumulated
+  std::vector<int> image_inputs;   // split mode: inputs written in place by layers that keep no image (fp32-kernel Linears): forward() converts their slices
 };
 
 class BatchMatmul : public Op {

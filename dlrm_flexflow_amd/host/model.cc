@@ -782,9 +782,12 @@ void Linear::backward_part(const FFModel& ff, int part) {
     }
     ~ColsumScope() { if (lo) lo->db_from_upper = ff.api->ffh_linear_dx_colsum_used(ff.ctx) != 0; }
   } colsum_scope(ff, colsum_lower, dx != nullptr && (part == 0 || part == 1) && !ff.use_workers() && !ff.config.profiling);
+  // split mode, this layer on the fp32 kernels under one that streams images: the image of the data gradient just stored (allocate(), step 7)
+  auto image_dx = [&] { if (dx_image && dx) ff.check(ff.api->ffh_convert_f32_to_bf16x3(ff.ctx, dx, b, in_channels, lddx, ff.stream), name); };
   if (part == 1) {
     ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                        flags | FFH_LINEAR_ONLY_DX, ff.stream, nullptr), name);
+    image_dx();
     return;
   }
   if (part == 3) {      // the weight / bias gradient on the compute stream itself (A/B: --big-dw-mode 2)
@@ -839,6 +842,7 @@ void Linear::backward_part(const FFModel& ff, int part) {
   ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                      flags, ff.stream, fork ? dws : nullptr), name);
   if (reserve > 0) ff.check(ff.api->ffh_ctx_set_dw_cu_reserve(ff.ctx, 0), "dw cu reserve");
+  image_dx();
   if (fork) { ff.dw_forked = true; (dws == ff.dw_stream ? ff.dw1_used : ff.dw2_used) = true; }
 }
 
@@ -1093,6 +1097,12 @@ void concat_parts(const Concat* c, const std::vector<int64_t>& ib, bool grads, s
 
 void Concat::forward(const FFModel& ff) {
   if (ff.emb_forward_issued && !ff.emb_forward_joined) ff.join_embedding_forward();   // before the first consumer
+  // split mode: the slices that layers without an image of their own wrote in place (the bottom MLP's last layer, on the fp32 kernels) get
+  // theirs here, whatever launch produced them (allocate(), step 7)
+  for (int i : image_inputs) {
+    const TensorImpl* im = inputs[i].impl;
+    ff.check(ff.api->ffh_convert_f32_to_bf16x3(ff.ctx, (const float*)im->ptr, local_rows(outputs[0], &ff), inputs[i].adim[0], im->ld, ff.stream), name);
+  }
   int64_t nb, ob;
   std::vector<int64_t> ib, blks, lds;
   std::vector<float*> ptrs;
@@ -2154,6 +2164,7 @@ void FFModel::allocate() {
   // (6 bytes per element; FFH_BF16X3_IMAGE_BYTES): its GEMMs then stream the operands' bf16 terms by LDS-DMA instead of splitting fp32 tiles in
   // registers (csrc/linear_x3_dma.hip).  twin_at() below is the one place the two layouts differ for this layer.
   n_twin_regions = 0;
+  for (Op* op : layers) if (op->op_type == OP_LINEAR) static_cast<Linear*>(op)->dx_image = false;
   const bool x3_images = config.fp32_split_bf16x3 && !config.allow_tensor_op_math_conversion;
   if ((config.allow_tensor_op_math_conversion || x3_images) && config.bf16_twins && mlp_count > 0) {
     const size_t ab = std::max<size_t>(act_bytes, 256);
@@ -2178,7 +2189,8 @@ void FFModel::allocate() {
     w_twin_dirty = true;
     auto twin_linear = [&](const Op* op) {
       const Linear* l = op && op->op_type == OP_LINEAR ? static_cast<const Linear*>(op) : nullptr;
-      return l && l->in_channels >= FFH_BF16_MIN_DIM && l->out_channels >= FFH_BF16_MIN_DIM;
+      return l && l->in_channels >= FFH_BF16_MIN_DIM && l->out_channels >= FFH_BF16_MIN_DIM &&
+             (!x3_images || 2.0 * (double)local_rows(l->outputs[0], this) * (double)l->in_padded * (double)l->out_channels >= FFH_BF16X3_MIN_FLOP);      // (the layers the mode takes: include/ff_hip.h)
     };
     auto in_slab = [&](const void* q) { return (const char*)q >= act_slab && (const char*)q < act_slab + act_bytes; };
     for (Op* op : layers) {
@@ -2188,13 +2200,17 @@ void FFModel::allocate() {
       if (twin_linear(op)) act_ok = true;
       else if (Concat* c = dynamic_cast<Concat*>(op)) {
         act_ok = !exchange && c->numInputs > 0 && (!x3_images || im->ld % 32 == 0);      // (the gather writes the image of rows that are whole 32-element groups apart)
+        std::vector<int> x3_convert;
+        c->image_inputs.clear();
         for (int i = 0; i < c->numInputs && act_ok; i++) {
           const Tensor& in = c->inputs[i];
           auto it = alias_of.find(in.impl);
           if (it == alias_of.end() || it->second.first != c || !in.owner_op) { act_ok = false; break; }
           if (in.owner_op->op_type == OP_EMBEDDING) act_ok = static_cast<const Embedding*>(in.owner_op)->out_channels % 4 == 0 && !static_cast<const Embedding*>(in.owner_op)->replicated;
+          else if (x3_images && in.owner_op->op_type == OP_LINEAR && !twin_linear(in.owner_op) && !use_workers()) x3_convert.push_back(i);   // its slice's image in Concat::forward
           else act_ok = twin_linear(in.owner_op);
         }
+        if (act_ok) c->image_inputs = x3_convert;
       }
       const Linear* only = nullptr; int ncons = 0;
       for (Op* q : layers)
@@ -2225,6 +2241,14 @@ void FFModel::allocate() {
       const bool twin_read = prod && twin_linear(prod) && (prod->dy_premasked || prod->activation == AC_MODE_NONE);
       if (ncons == 1 && twin_read && only && (twin_linear(only) || skinny_twin(only)) && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange)
         reg(im->grad, im->bytes, twin_at(grad_twin, (size_t)((const char*)im->grad - act_grad_slab)));
+      // split mode: the consumer is a Linear on the fp32 kernels (below FFH_BF16X3_MIN_WEIGHTS: 512 -> 256 on top of the Terabyte MLP) -- the image of
+      // the data gradient it stores by a pass behind its backward call (Linear::backward_part), so that the layer this gradient is the dy of
+      // (1024 -> 512) streams it: 60 us of conversion for 170 us of split-in-kernel GEMM at 32768 samples
+      else if (x3_images && ncons == 1 && twin_read && only && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange && !use_workers() &&
+               !only->pair_upper && !only->pair_lower && twin_at(grad_twin, (size_t)((const char*)im->grad - act_grad_slab))) {
+        reg(im->grad, im->bytes, twin_at(grad_twin, (size_t)((const char*)im->grad - act_grad_slab)));
+        const_cast<Linear*>(only)->dx_image = true;
+      }
     }
   }
   check(api->ffh_stream_sync(ctx, stream), "allocate sync");

@@ -153,7 +153,11 @@ int         ffh_ctx_set_workspace(ffh_ctx* ctx, void* ws, size_t bytes);
  *                             gives NaN outputs where fp32 arithmetic gives an infinity (x - x1 = inf - inf), and so does a
  *                             finite one above the largest bfloat16 (3.39e38); NaN stays NaN.  Opt-in. */
 #define FFH_MATH_FP32_SPLIT_BF16X3 2
+/*   FFH_MATH_FP32_SPLIT_BF16X3_ALL the split mode on EVERY Linear layer with both dims >= FFH_BF16_MIN_DIM, whatever its size (the layer rule of the mode as
+ *                             round 5 shipped it): for tests and A/B runs -- small layers are slower here than on the fp32 kernels */
+#define FFH_MATH_FP32_SPLIT_BF16X3_ALL 3
 #define FFH_BF16_MIN_DIM 128
+#define FFH_BF16X3_MIN_FLOP 1.0e10   /* FFH_MATH_FP32_SPLIT_BF16X3 takes the Linear layers with 2 * batch * in_dim * out_dim >= this (and both dims >= FFH_BF16_MIN_DIM): below, the exact-fp32 kernels are the faster fp32-accurate form */
 int         ffh_ctx_set_math_mode(ffh_ctx* ctx, int mode);
 /* bf16 MIRRORS for the tensor-op mode (no reference counterpart; the reference reaches its tensor cores through cuBLAS, which
  * converts internally).  In FFH_MATH_TENSOR_OP_BF16 the GEMM operands are rounded to bfloat16 anyway; with fp32 operands in HBM

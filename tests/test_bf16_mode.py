@@ -264,7 +264,7 @@ def test_dlrm_step_bf16_mode_hip_vs_oracle_backend(hip, oracle, trace):
 # FFH_MATH_FP32_SPLIT_BF16X3: fp32-accurate GEMMs on the bf16 pipe (three bf16 terms per operand, six products).  Held to the
 # SAME bound as the exact-fp32 kernels against the fp32 oracle, and its error against float64 must be of the same size.
 # ---------------------------------------------------------------------------------------------------------------------
-MATH_X3 = 2
+MATH_X3 = 3        # FFH_MATH_FP32_SPLIT_BF16X3_ALL: every wide layer on the split kernels, whatever its size (the mode proper, 2, leaves small GEMMs to the fp32 kernels)
 
 
 @pytest.fixture()

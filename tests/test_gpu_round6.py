@@ -12,7 +12,7 @@ import pytest
 
 from dlrm_flexflow_amd import capi
 
-MATH_X3 = 2
+MATH_X3 = 3        # FFH_MATH_FP32_SPLIT_BF16X3_ALL: every wide layer on the split kernels, whatever its size (the mode proper, 2, leaves small GEMMs to the fp32 kernels)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -144,7 +144,7 @@ def test_explicit_conversion_writes_the_image_bit_for_bit(hip):
     assert hip.lib.ffh_convert_f32_to_bf16x3(hip.ctx, t.data_ptr(), 1, 32, 32, None) != 0
 
 
-LAYERS = [(8192, 1024, 1024), (8224, 1024, 1056), (32768, 512, 256), (8192, 1088, 1344)]
+LAYERS = [(8192, 1024, 1024), (8224, 1024, 1056), (32768, 1024, 512), (8192, 1088, 1344)]
 
 
 @pytest.mark.gpu
@@ -216,7 +216,7 @@ def test_x3_dma_declines_what_it_cannot_serve_and_the_fallback_keeps_the_image(h
     stored (written by a pass over y)."""
     import torch
     hip, dev = hip_x3, "cuda:0"
-    for B, IN, OUT, xoff in ((512, 1024, 256, 0), (8192, 1000, 1024, 0), (8192, 1024, 1024, 8)):
+    for B, IN, OUT, xoff in ((512, 1024, 512, 0), (8192, 1000, 1024, 0), (8192, 1024, 1024, 8)):
         rng = np.random.default_rng(B + IN)
         x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
         w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
@@ -317,3 +317,24 @@ def test_dlrm_step_split_mode_images_on_equals_images_off_and_the_fp32_oracle(hi
     for k in out["images"]:
         np.testing.assert_allclose(out["images"][k], out["in_kernel"][k], rtol=2e-5, atol=2e-6, err_msg=k)
         np.testing.assert_allclose(out["images"][k], out["oracle"][k], rtol=2e-5, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_split_mode_proper_leaves_small_gemms_to_the_fp32_kernels(hip):
+    """FFH_MATH_FP32_SPLIT_BF16X3 (2) takes a Linear layer only where its GEMMs are at least FFH_BF16X3_MIN_FLOP (2 * batch * in * out >= 1e10):
+    below that the exact-fp32 kernels are the faster fp32-accurate form; ..._ALL (3) takes every wide layer.  Told by the route."""
+    import torch
+    dev = "cuda:0"
+    route = lambda: hip.lib.ffh_linear_last_route(hip.ctx).decode()
+    for B, IN, OUT, want in ((4096, 512, 256, False), (4096, 1024, 1024, False), (8192, 1024, 1024, True), (4096, 3456, 1024, True)):
+        x = torch.rand(B, IN, device=dev); w = torch.rand(OUT, IN, device=dev) / IN; y = torch.zeros(B, OUT, device=dev)
+        try:
+            assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, 2) == 0
+            hip.call("ffh_linear_fwd", x, IN, y, OUT, w, None, IN, OUT, B, capi.AC_MODE_NONE, None)
+            assert ("bf16x3" in route() or "x3_dma" in route()) == want, (B, IN, OUT, route())
+            assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, 3) == 0
+            hip.call("ffh_linear_fwd", x, IN, y, OUT, w, None, IN, OUT, B, capi.AC_MODE_NONE, None)
+            assert "bf16x3" in route() or "x3_dma" in route(), route()
+        finally:
+            assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, 0) == 0
+        torch.cuda.synchronize()
