@@ -102,6 +102,7 @@ def lib() -> C.CDLL:
         "flexflow_model_get_parameter": (H, [H, I, I]), "flexflow_model_get_layer_output": (H, [H, I]),
         "flexflow_model_get_stream": (P, [H]), "flexflow_model_uses_graph": (I, [H]), "flexflow_model_set_trace_mode": (None, [H, I]), "flexflow_model_trace_replays": (I, [H, I]),
         "flexflow_model_get_counter": (C.c_int64, [H, C.c_char_p]),
+        "flexflow_model_get_backend_name": (C.c_char_p, [H]), "flexflow_model_get_backend_path": (C.c_char_p, [H]),
         "flexflow_tensor_get_num_dims": (I, [H]), "flexflow_tensor_get_dims": (None, [H, IP]),
         "flexflow_tensor_get_local_rows": (C.c_int64, [H]), "flexflow_tensor_is_local": (B, [H]),
         "flexflow_tensor_get_device_ptr": (P, [H]), "flexflow_tensor_get_ld": (C.c_int64, [H]),
@@ -320,6 +321,10 @@ class FFModel:
     def set_trace_mode(self, mode: int): lib().flexflow_model_set_trace_mode(self.h, int(mode))
     def trace_replays(self, trace_id: int = 111) -> bool: return bool(lib().flexflow_model_trace_replays(self.h, trace_id))
     def counter(self, name: str) -> int: return int(lib().flexflow_model_get_counter(self.h, name.encode()))
+    @property
+    def backend(self) -> dict:
+        """the kernel library this model loaded: {'name': ffh_backend_name(), 'path': file}"""
+        return {"name": lib().flexflow_model_get_backend_name(self.h).decode(), "path": lib().flexflow_model_get_backend_path(self.h).decode()}
 
     def perf_metrics(self) -> PerfMetrics:
         p = PerfMetrics()

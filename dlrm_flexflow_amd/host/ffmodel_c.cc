@@ -101,6 +101,8 @@ void flexflow_model_update(flexflow_model_t m) { M(m)->update(); }
 void flexflow_model_begin_trace(flexflow_model_t m, int id) { M(m)->begin_trace(id); }
 void flexflow_model_end_trace(flexflow_model_t m, int id) { M(m)->end_trace(id); }
 void flexflow_model_sync(flexflow_model_t m) { M(m)->sync(); }
+const char* flexflow_model_get_backend_name(flexflow_model_t m) { return M(m)->api->ffh_backend_name(); }
+const char* flexflow_model_get_backend_path(flexflow_model_t m) { return M(m)->api->path.c_str(); }
 void flexflow_model_get_perf_metrics(flexflow_model_t m, flexflow_perf_metrics_t* out) {
   PerfMetrics p = M(m)->get_perf_metrics();
   out->train_all = p.train_all; out->train_correct = p.train_correct; out->cce_loss = p.cce_loss;

@@ -84,6 +84,8 @@ flexflow_tensor_t flexflow_model_get_parameter(flexflow_model_t, int layer, int 
 flexflow_tensor_t flexflow_model_get_layer_output(flexflow_model_t, int layer);
 void* flexflow_model_get_stream(flexflow_model_t);
 int  flexflow_model_uses_graph(flexflow_model_t);
+const char* flexflow_model_get_backend_name(flexflow_model_t);   /* ffh_backend_name() of the kernel library the model loaded: "hip-gfx950" | "oracle-cpu" */
+const char* flexflow_model_get_backend_path(flexflow_model_t);   /* ... and the file it was loaded from */
 void flexflow_model_set_trace_mode(flexflow_model_t, int mode);   /* 0: replay a trace only where that is not slower than launching it (decided on its first calls); 1: always replay */
 int  flexflow_model_trace_replays(flexflow_model_t, int trace_id);   /* 0 once the adaptive mode has settled on eager launches for this trace */
 int64_t flexflow_model_get_counter(flexflow_model_t, const char* name);   /* diagnostics for tests: "mlp_chain_fwd_calls", "mlp_chain_bwd_calls"; -1: unknown */
