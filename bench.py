@@ -423,7 +423,9 @@ def main():
     ap.add_argument("--leg-budget", type=float, default=7.0, help=argparse.SUPPRESS)
     ap.add_argument("--replicate-embedding-rows", type=int, default=0, help="N > 1: tables with at most this many rows are data-parallel (a copy on every "
                     "rank, dense gradient in the MLP's all-reduce bucket) instead of table-wise in the all-to-all; 0 (default): every table table-wise")
-    ap.add_argument("--allreduce-own-channel", action="store_true", help="a second RCCL communicator (ncclCommSplit) for the MLP-gradient buckets (N > 1; unmeasured: no multi-GPU box)")
+    ap.add_argument("--allreduce-shared-channel", action="store_true", help="N > 1: the MLP-gradient buckets on the SAME RCCL communicator as the all-to-alls (A/B; by default "
+                    "they get a second one from ncclCommSplit where every rank has it -- one communicator runs its collectives in issue order)")
+    ap.add_argument("--allreduce-own-channel", action="store_true", help=argparse.SUPPRESS)     # (the default since round 6: accepted, no effect)
     ap.add_argument("--shim-flags", default="", help="extra FFConfig flags for A/B runs, e.g. '--serial-dw --no-overlap'")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # tests: ranks rendezvous over gloo and report, no GPU
     ap.add_argument("--functional-test-backend", default="", help=argparse.SUPPRESS)   # tests only: walk this file's whole rank path on the
@@ -487,7 +489,7 @@ def main():
         collectives = "torch.distributed (RCCL) callbacks" if not ftest else "torch.distributed (gloo) callbacks: FUNCTIONAL TEST, not a measurement"
         if not ftest and not args.torch_collectives and not os.environ.get("FFM_NO_DIRECT_RCCL"):
             try:
-                comm = RcclComm(comm, own_bucket_channel=args.allreduce_own_channel)       # the same callbacks served by RCCL from the C++ host layer, no Python per collective
+                comm = RcclComm(comm, own_bucket_channel=not args.allreduce_shared_channel)       # the same callbacks served by RCCL from the C++ host layer, no Python per collective
                 collectives = "RCCL called from the C++ host layer"
             except Exception as e:  # noqa: BLE001  every rank raises together (comm.py): fall back to the torch callbacks
                 if rank == 0:
@@ -570,6 +572,12 @@ def main():
     t_lin_bwd = app.time_kernel(7, 20 if B > 4096 else 100) * 1e-3 if solo else None
     uses_graph = app.model.uses_graph and trace
     backend = app.model.backend       # the kernel library the timed steps ran on (host/backend.cc honours --backend / $FFH_BACKEND_LIB)
+    nbk = max(app.model.counter("allreduce_buckets"), 0)
+    bucket_mb = [round(app.model.counter(f"allreduce_bucket_floats_{k}") * 4 / 1e6, 2) for k in range(nbk)]
+    bucketed = app.model.counter("allreduce_bucket_calls") > 0
+    grads = (f"gradients all-reduced in {nbk} buckets issued from inside backward() ({' + '.join(str(v) for v in bucket_mb)} MB, "
+             f"{'a communicator of their own (ncclCommSplit)' if app.model.counter('allreduce_bucket_channel_own') == 1 else 'the all-to-alls communicator: held until the backward all-to-all is enqueued'})"
+             if bucketed else "1 all-reduce of the gradient slab")
     app.close()
     if world > 1:
         barrier()                                  # the probes above are rank 0's: nobody tears the group down under them
@@ -595,7 +603,7 @@ def main():
                                f"{'dot (strict lower triangle)' if 'dot-tril' in wx else 'dot (all pairs)' if 'dot' in wx else 'cat'} interaction, SGD lr 0.01, MSE loss",
                    "global_batch": w["B"], "per_gpu_batch": w["B"] // world,
                    "parallelism": ("single GPU, hipGraph-replayed step" if uses_graph else "single GPU, eager launches on 3 HIP streams") if world == 1 else
-                                  f"{layout} over {world} ranks, MLPs data-parallel (1 all-reduce of the gradient slab); {collectives}",
+                                  f"{layout} over {world} ranks, MLPs data-parallel ({grads}); {collectives}",
                    "kernel_library": backend, "step_graph": bool(uses_graph), "step_us_graph_vs_eager": {k: round(v, 1) for k, v in step_us.items()}},
         "mse_over_timed_steps": round(2.0 * pm.mse_loss / max(pm.train_all, 1), 6),   # train_all is double-counted (1 class + accuracy), as in the reference
     }

@@ -213,9 +213,9 @@ class RcclComm:
     `boot` is a TorchComm over an initialised NCCL process group: it broadcasts the unique id and keeps the barrier.
     Raises RuntimeError on every rank if any rank cannot set it up (use `boot` then)."""
 
-    def __init__(self, boot: TorchComm, own_bucket_channel: bool = False):
-        """own_bucket_channel: a second communicator (ncclCommSplit) for the MLP-gradient buckets, so that RCCL does not order them
-        against the all-to-alls (opt-in: `--allreduce-own-channel` of bench.py / run_dlrm.py)."""
+    def __init__(self, boot: TorchComm, own_bucket_channel: bool = True):
+        """own_bucket_channel (default): a second communicator (ncclCommSplit) for the MLP-gradient buckets, so that RCCL does not order them
+        against the all-to-alls; taken only when EVERY rank can make it (`--allreduce-shared-channel` of bench.py / run_dlrm.py turns it off)."""
         from . import ffmodel
         assert boot.on_gpu
         self.boot = boot
@@ -247,16 +247,30 @@ class RcclComm:
         # all-reduce, reduce-scatter, all-gather); every rank must pass or all fall back to the torch callbacks together
         self._base = {"alltoall": 0, "allreduce": 0, "reduce_scatter": 0, "allgather": 0}
         ok = self._self_test()
-        self.own_bucket_channel = False
-        if ok and own_bucket_channel:
-            L.flexflow_rccl_comm_enable_bucket_channel.restype = C.c_int
-            self.own_bucket_channel = L.flexflow_rccl_comm_enable_bucket_channel(C.byref(self.struct)) == 0      # collective; a failure keeps the shared channel
-        self._base = self.calls                    # `calls` counts the model's collectives only
         flag.fill_(1 if ok else 0)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=boot.group)
         if int(flag.item()) == 0:
             self.close()
             raise RuntimeError("direct RCCL communicator failed its self-test on some rank")
+        # The buckets' own channel.  ncclCommSplit is COLLECTIVE: the ranks agree (MIN) that every one of them has the symbol BEFORE any of them
+        # makes the call, and agree again on its outcome -- a rank that failed alone would leave its peers inside the call, or send its buckets on
+        # a communicator they do not use (round-5 advisor).  Only after the self-test's own agreement above: every rank is still here.
+        self.own_bucket_channel = False
+        if own_bucket_channel:
+            L.flexflow_rccl_comm_enable_bucket_channel.restype = C.c_int
+            L.flexflow_rccl_has_comm_split.restype = C.c_int
+            L.flexflow_rccl_has_comm_split.argtypes = [C.c_char_p]
+            flag.fill_(1 if L.flexflow_rccl_has_comm_split(path) == 0 else 0)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=boot.group)
+            if int(flag.item()) == 1:
+                mine = L.flexflow_rccl_comm_enable_bucket_channel(C.byref(self.struct)) == 0
+                flag.fill_(1 if mine else 0)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=boot.group)
+                if int(flag.item()) == 1:
+                    self.own_bucket_channel = True
+                else:
+                    L.flexflow_rccl_comm_disable_bucket_channel(C.byref(self.struct))        # every rank: back to the shared channel together
+        self._base = self.calls                    # `calls` counts the model's collectives only
 
     def _self_test(self) -> bool:
         W, r = self.world, self.rank

@@ -75,6 +75,8 @@ struct ChainDwArgs {
   int64_t batch;
   int n, nitems, S;
   int64_t rows_per_split;  // multiple of 32
+  float* slots;            // deterministic mode: workgroup (item, split) leaves its 64 x 64 block (+ 64 bias sums) in slot item * S + split of
+                           // kSkinnyWsRow floats instead of adding it to dW; mlp_chain_dw_reduce_kernel adds the splits in order.  Null: atomics
   DwLayer L[CH_MAXL];
 };
 
@@ -486,7 +488,7 @@ __device__ __forceinline__ f32x4 dw_load(const __amdgpu_buffer_rsrc_t rs, const 
 
 template <bool AVEC, bool BVEC>
 __device__ __forceinline__ void ch_dw_block(const DwLayer& L, const int m0, const int n0, const int64_t r0, const int64_t r1, float* lds,
-                                            const int tid, const int wave, const int c16, const int q) {
+                                            const int tid, const int wave, const int c16, const int q, float* slot) {
   constexpr int D = 8;
   const int64_t nrows = r1 - r0;
   const int steps = (int)((nrows + 3) >> 2);              // 4-row k-steps of the split; wave w takes w, w + 8, ...
@@ -563,13 +565,15 @@ __device__ __forceinline__ void ch_dw_block(const DwLayer& L, const int m0, cons
 #pragma unroll
     for (int w = 0; w < 8; w++) v += lds[w * 4096 + e];
     const int m = m0 + (e >> 6), n = n0 + (e & 63);
-    if (m < L.M && n < L.N) atomicAdd(L.dw + (int64_t)m * L.ldw + n, v);
+    if (slot) slot[e] = v;                                   // deterministic mode: the block as it is (the sums above run in a fixed order)
+    else if (m < L.M && n < L.N) atomicAdd(L.dw + (int64_t)m * L.ldw + n, v);
   }
   if (want_db && tid < 64) {
     float v = 0.0f;
 #pragma unroll
     for (int w = 0; w < 8; w++) v += dbl[w * 64 + tid];
-    if (m0 + tid < L.M) atomicAdd(L.db + m0 + tid, v);
+    if (slot) slot[4096 + tid] = v;
+    else if (m0 + tid < L.M) atomicAdd(L.db + m0 + tid, v);
   }
 }
 
@@ -589,12 +593,44 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_dw_kernel(const ChainDwA
   int64_t r1 = r0 + a.rows_per_split;
   if (r1 > a.batch) r1 = a.batch;
   if (r0 >= r1) return;
+  float* slot = a.slots ? a.slots + (size_t)blockIdx.x * kSkinnyWsRow : nullptr;
   if (L.a_vec) {
-    if (L.b_vec) ch_dw_block<true, true>(L, m0, n0, r0, r1, ch_lds, tid, wave, c16, q);
-    else ch_dw_block<true, false>(L, m0, n0, r0, r1, ch_lds, tid, wave, c16, q);
+    if (L.b_vec) ch_dw_block<true, true>(L, m0, n0, r0, r1, ch_lds, tid, wave, c16, q, slot);
+    else ch_dw_block<true, false>(L, m0, n0, r0, r1, ch_lds, tid, wave, c16, q, slot);
   } else {
-    if (L.b_vec) ch_dw_block<false, true>(L, m0, n0, r0, r1, ch_lds, tid, wave, c16, q);
-    else ch_dw_block<false, false>(L, m0, n0, r0, r1, ch_lds, tid, wave, c16, q);
+    if (L.b_vec) ch_dw_block<false, true>(L, m0, n0, r0, r1, ch_lds, tid, wave, c16, q, slot);
+    else ch_dw_block<false, false>(L, m0, n0, r0, r1, ch_lds, tid, wave, c16, q, slot);
+  }
+}
+
+// Deterministic mode (ffh_ctx_set_deterministic): one workgroup per 64 x 64 block of some layer's dW adds the block's batch splits in split
+// order -- the one writer of those elements of dW / db, so the result does not depend on which workgroup finished first (the SPLIT /
+// skinny pattern, as its own launch: no arrival protocol).  Splits beyond the batch wrote nothing and are skipped, as the dW kernel skipped them.
+__global__ __launch_bounds__(CH_THREADS) void mlp_chain_dw_reduce_kernel(const ChainDwArgs a) {
+  ffh_kernel_prio();
+  const int tid = threadIdx.x, item = (int)blockIdx.x;
+  int l = 0;
+  while (l + 1 < a.n && item >= a.L[l + 1].first_item) l++;
+  const DwLayer& L = a.L[l];
+  const int li = item - L.first_item;
+  const int m0 = (li / L.nbn) * 64, n0 = (li % L.nbn) * 64;
+  int S = 0;
+  while (S < a.S && (int64_t)S * a.rows_per_split < a.batch) S++;
+  const float* slots = a.slots + (size_t)item * a.S * kSkinnyWsRow;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int e = tid + CH_THREADS * j;
+    const int m = m0 + (e >> 6), n = n0 + (e & 63);
+    if (m >= L.M || n >= L.N) continue;
+    float v = 0.0f;
+    for (int sp = 0; sp < S; sp++) v += slots[(size_t)sp * kSkinnyWsRow + e];
+    float* d = L.dw + (int64_t)m * L.ldw + n;
+    *d = *d + v;
+  }
+  if (L.db && n0 == 0 && tid < 64 && m0 + tid < L.M) {
+    float v = 0.0f;
+    for (int sp = 0; sp < S; sp++) v += slots[(size_t)sp * kSkinnyWsRow + 4096 + tid];
+    L.db[m0 + tid] += v;
   }
 }
 
@@ -688,7 +724,6 @@ int ffh_mlp_chain_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
     FFH_REQUIRE(c, layers[l].dy && layers[l].dw && layers[l].lddy >= layers[l].out_dim, "mlp_chain_bwd: null pointer / leading dimension");
   }
   if (c->math_mode != FFH_MATH_DEFAULT) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: fp32 math mode only");
-  if (c->deterministic) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: the weight gradients meet by atomics (not in deterministic mode)");
   const ffh_chain_layer& top = layers[nlayers - 1];
   const bool premasked = (flags & FFH_LINEAR_DY_PREMASKED) != 0;
   if (top.activation != FFH_AC_MODE_NONE && top.activation != FFH_AC_MODE_RELU && top.activation != FFH_AC_MODE_SIGMOID)
@@ -708,6 +743,44 @@ int ffh_mlp_chain_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   if (dx && (flags & FFH_LINEAR_DX_MASK_BY_X) && (!al16(x) || (ldx & 3))) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: x rows not 16-byte aligned");
   ffh_route_clear(c);
   if (batch == 0) return FFH_OK;
+
+  // ---- 0. everything that can still say "not served" -- BEFORE the first launch: the data-gradient kernel masks dy in place and stores or
+  //         accumulates dx, so a later FFH_ERR_UNSUPPORTED would have the caller's per-layer calls do that a second time (round-5 advisor) ----
+  ChainDwArgs w{};
+  w.batch = batch; w.n = nlayers;
+  int items = 0;
+  for (int l = 0; l < nlayers; l++) {
+    const ffh_chain_layer& L = layers[l];
+    DwLayer& d = w.L[l];
+    d.dy = L.dy; d.lddy = L.lddy;
+    d.x = l == 0 ? x : layers[l - 1].y; d.ldx = l == 0 ? ldx : layers[l - 1].ldy;
+    d.dw = L.dw; d.db = L.db; d.ldw = L.ldw; d.M = L.out_dim; d.N = L.in_dim;
+    d.nbn = (L.in_dim + 63) / 64;
+    d.first_item = items;
+    items += ((L.out_dim + 63) / 64) * d.nbn;
+    d.a_vec = (al16(d.dy) && (d.lddy & 3) == 0 && (d.M & 3) == 0) ? 1 : 0;
+    d.b_vec = (al16(d.x) && (d.ldx & 3) == 0 && (d.N & 3) == 0) ? 1 : 0;
+  }
+  w.nitems = items;
+  int S = c->num_cus / items;
+  if (S < 1) S = 1;
+  const int64_t max_s = (batch + 63) / 64;                 // at least two 4-row steps per wave
+  if (S > max_s) S = (int)max_s;
+  int64_t rps = (batch + S - 1) / S;
+  rps = (rps + 31) / 32 * 32;
+  S = (int)((batch + rps - 1) / rps);
+  w.S = S; w.rows_per_split = rps;
+  if (c->deterministic) {
+    // the splits' blocks meet in the stream's scratch (ffh_ctx_reserve_scratch: the narrow-layer backward's partial rows, one row per
+    // workgroup here) and a second launch adds them in split order
+    for (int i = 0; i < c->nscratch; i++)
+      if (c->scratch[i].stream == (void*)as_stream(s) && c->scratch[i].skinny_ws) w.slots = c->scratch[i].skinny_ws;
+    if (!w.slots || (int64_t)items * S > kSkinnyWsBlocks)
+      return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: deterministic mode needs the stream's scratch (ffh_ctx_reserve_scratch)");
+  }
+  const int lds_dw = (8 * 4096 + 8 * 64) * 4;
+  static signed char okw[64];
+  if (!ch_set_lds(c, mlp_chain_dw_kernel, lds_dw, okw)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: LDS attribute");
 
   // ---- 1. the data-gradient chain (nothing to do for a single layer whose input gradient is discarded and whose dy is final) ----
   const bool top_live = !premasked && top.activation != FFH_AC_MODE_NONE;
@@ -753,36 +826,13 @@ int ffh_mlp_chain_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   }
 
   // ---- 2. every layer's weight / bias gradient ----
-  ChainDwArgs w{};
-  w.batch = batch; w.n = nlayers;
-  int items = 0;
-  for (int l = 0; l < nlayers; l++) {
-    const ffh_chain_layer& L = layers[l];
-    DwLayer& d = w.L[l];
-    d.dy = L.dy; d.lddy = L.lddy;
-    d.x = l == 0 ? x : layers[l - 1].y; d.ldx = l == 0 ? ldx : layers[l - 1].ldy;
-    d.dw = L.dw; d.db = L.db; d.ldw = L.ldw; d.M = L.out_dim; d.N = L.in_dim;
-    d.nbn = (L.in_dim + 63) / 64;
-    d.first_item = items;
-    items += ((L.out_dim + 63) / 64) * d.nbn;
-    d.a_vec = (al16(d.dy) && (d.lddy & 3) == 0 && (d.M & 3) == 0) ? 1 : 0;
-    d.b_vec = (al16(d.x) && (d.ldx & 3) == 0 && (d.N & 3) == 0) ? 1 : 0;
-  }
-  w.nitems = items;
-  int S = c->num_cus / items;
-  if (S < 1) S = 1;
-  const int64_t max_s = (batch + 63) / 64;                 // at least two 4-row steps per wave
-  if (S > max_s) S = (int)max_s;
-  int64_t rps = (batch + S - 1) / S;
-  rps = (rps + 31) / 32 * 32;
-  S = (int)((batch + rps - 1) / rps);
-  w.S = S; w.rows_per_split = rps;
-  const int lds_dw = (8 * 4096 + 8 * 64) * 4;
-  static signed char okw[64];
-  if (!ch_set_lds(c, mlp_chain_dw_kernel, lds_dw, okw)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: LDS attribute");
   hipLaunchKernelGGL(mlp_chain_dw_kernel, dim3((unsigned)(items * S)), dim3(CH_THREADS), lds_dw, as_stream(s), w);
   FFH_LAUNCH_CHECK(c, "mlp_chain_dw_kernel");
-  { char tok[64]; snprintf(tok, sizeof tok, "mlp_chain_dw|blocks=%d|splits=%d", items, S); ffh_route_add(c, tok); }
+  if (w.slots) {
+    hipLaunchKernelGGL(mlp_chain_dw_reduce_kernel, dim3((unsigned)items), dim3(CH_THREADS), 0, as_stream(s), w);
+    FFH_LAUNCH_CHECK(c, "mlp_chain_dw_reduce_kernel");
+  }
+  { char tok[80]; snprintf(tok, sizeof tok, "mlp_chain_dw|blocks=%d|splits=%d%s", items, S, w.slots ? "|ordered" : ""); ffh_route_add(c, tok); }
   return FFH_OK;
 }
 

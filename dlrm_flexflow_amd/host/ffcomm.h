@@ -44,6 +44,12 @@ typedef struct ffcomm {
    * can run it concurrently with the all-to-alls serves it on a channel of its own (RcclComm: a second communicator from
    * ncclCommSplit); NULL: the buckets go through allreduce_sum_f32. */
   int (*allreduce_bucket_sum_f32)(void* user, float* buf, int64_t count, void* stream);
+  /* 1: allreduce_bucket_sum_f32 runs on a channel of its own -- the transport does NOT order a bucket against the all-to-alls, so the model issues
+   * every bucket as soon as its layers have issued their backward.  0 (a shared channel: one RCCL communicator runs its collectives in issue
+   * order whatever streams they are on): the model holds the buckets until the step's backward all-to-all has been enqueued, so that the
+   * exchange of the embedding gradients -- and the table update and the next gather behind it -- never waits for a weight-gradient GEMM and
+   * its all-reduce (FFModel::issue_grad_buckets). */
+  int bucket_channel_own;
 } ffcomm;
 
 #ifdef __cplusplus

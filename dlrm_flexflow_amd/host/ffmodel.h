@@ -105,11 +105,6 @@ class FFConfig {
   bool deterministic;          // --deterministic: weight / bias gradients without fp atomics (ffh_ctx_set_deterministic): bit-identical runs
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
-  int  dw_cu_reserve;                // --dw-cu-reserve N: CUs the biggest layer's persistent weight-gradient GEMM leaves free (-1: by per-GPU batch)
-  int bottom_dw_cu_reserve;    // A/B: the same for the bottom MLP's weight-gradient GEMMs (--bottom-dw-cu-reserve N; measured, off)
-  int  big_dw_mode;                  // A/B: 0 the biggest layer's dW beside its dX (default), 1 forked behind its dX, 2 before its dX on the compute stream
-  bool two_dw_streams;               // (A/B: --two-dw-streams, off) the biggest layer's weight-gradient GEMM on a stream of its own
-  int  defer_big_dw;                 // --defer-big-dw (A/B, default 0): the biggest layer's weight gradient is issued last instead of beside its data gradient
   bool bf16_convert_twins;               // tensor-op mode: a twin by conversion behind an fp32-kernel Linear that feeds a bf16-pipe one (--no-bf16-convert-twins)
   bool bf16_twins, force_async_launch;   // --no-bf16-twins / --force-async-launch (A/B and test switches; they used to be environment variables)
   bool capture_exchange;             // --capture-exchange: world_size > 1 with collectives enqueued from C++ (RcclComm): the step is captured / replayed as a hipGraph
@@ -118,7 +113,6 @@ class FFConfig {
                                // sorted segments of the fused update (ffh_sparse_opt: lazy semantics, a stated divergence) instead of the reference's dense sweep
   int early_sort;              // the index-only sort of the fused table update runs behind the gather (ffh_embedding_bwd_sort_multi), off the backward's critical path:
                                // 1 / 0 (--early-sort / --no-early-sort), -1 = by shape (FFModel::early_sort_possible)
-  bool stream_priorities;      // the embedding stream is created at a higher HIP priority (A/B: --stream-priorities; off; ignored with the exchange)
   bool dx_colsum;              // a layer's bias gradient from the epilogue of the data-gradient kernel of the layer above (A/B: --no-dx-colsum)
   bool dx_scatter;             // exchange mode: the layer above the feature Concat writes its dX into the send buffer itself (A/B: --no-dx-scatter)
   bool fuse_pair;              // two narrow layers' backward as one launch + the lower dW GEMM (A/B: --no-fused-pair)
@@ -134,9 +128,6 @@ class FFConfig {
                                // measured on the trace's first calls, one GPU (--adaptive-replay): on this runtime the replay of a two-stream step costs a
                                // small model more than its launches (Kaggle shape: 210 vs 170 us).  -1 = not given: the FFModel API replays (1), the DLRM
                                // driver's timed loop adapts (0)
-  bool split_update;           // one GPU: the slab optimizer as two launches -- the bottom MLP's parameters on the compute stream as soon as its (chain) backward is
-                               // done, the rest on the weight-gradient stream behind the last weight gradient -- so that the next step's bottom-MLP forward does
-                               // not wait for the biggest layer's weight gradient and 14 MB of SGD (A/B: --split-update; measured level to slightly slower, off)
   bool mlp_chain;              // a run of narrow Linear layers (every width <= 512) as one launch forward, two backward (ffh_mlp_chain_fwd / _bwd; A/B: --no-mlp-chain)
   int64_t mlp_chain_max_batch; // ... for at most this many samples per GPU (--mlp-chain-max-batch N)
   int64_t mlp_chain_fwd_max_batch;   // ... and up to this many (--mlp-chain-fwd-max-batch N)
@@ -316,7 +307,7 @@ class Linear : public Op {
   void create_output_and_partition(FFModel& model) override;
   void forward(const FFModel&) override;
   void backward(const FFModel&) override;
-  void backward_part(const FFModel&, int part);   // 0: all; 1: data gradient only; 2: weight / bias gradient only, on the weight-gradient stream
+  void backward_part(const FFModel&, int part);   // 0: all; 1: data gradient only
   void backward_dw_rows(const FFModel&, int row0, int nrows);   // the weight (+ bias) gradient of output rows [row0, row0 + nrows) on the weight-gradient stream (dy final: premasked / no activation)
   int in_channels, out_channels;
   int in_padded;                // what the kernel library is told: in_channels, or that rounded up to 64 when the input tensor and the kernel were
@@ -531,21 +522,18 @@ class FFModel {
   ffh_stream stream;           // main compute stream
   ffh_stream side_stream;      // embedding gather / exchange / sparse update
   ffh_stream dw_stream;        // weight-gradient GEMMs (parallel_dw): the biggest layer's ...
-  ffh_stream dw_stream2;       // ... and everybody else's (A/B: --one-dw-stream)
-  ffh_event ev_dw_done, ev_dw2_done;
+  ffh_event ev_dw_done;
   int big_dw_layer;            // the Linear with the most multiply-adds
   bool need_zero_gsend;        // some gradient in the exchange send buffer is accumulated rather than stored
   bool need_zero_act_grads;    // some activation gradient is accumulated by more than one producer
   mutable bool dw_forked;
-  mutable bool dw1_used = false, dw2_used = false;   // which weight-gradient stream(s) this step's forks were offered (joined in update())
+  mutable bool dw1_used = false;   // this step's forks were offered the weight-gradient stream (joined in update())
   mutable bool dw_stream_used_directly = false;   // a weight gradient was enqueued on dw_stream by this layer itself (deferred dW), not by the library's fork
-  int defer_big_dw_layer() const;
-  // ---- bucketed all-reduce of the MLP gradients (allocate step 5b, backward(), update()) ----
   struct GradBucket {
     size_t off, count;          // floats in the dense gradient slab
     int lowest_layer;           // complete once every layer >= this one has issued its backward
     bool issued;
-    ffh_event ready, ready_dw, ready_dw2, done;
+    ffh_event ready, ready_dw, done;
     int chunk_layer, chunk_index;   // >= 0: the bucket of one row block of that layer's weight gradient (FFConfig::big_dw_chunks), issued by the layer's own backward
     bool inline_issued;             // ran on the compute stream itself (capture): nothing to join
   };
@@ -553,24 +541,15 @@ class FFModel {
   std::vector<std::pair<size_t, size_t>> grad_rest;     // (offset, count) of what no bucket covers (data-parallel tables): reduced in update()
   ffh_stream ar_stream = nullptr;                       // the buckets' stream
   bool bucketed_now() const;                            // buckets are issued from backward() in this step
+  bool buckets_held() const;          // a shared channel and this step's backward all-to-all not enqueued yet
   void issue_grad_buckets(int next_layer);              // every complete, not yet issued bucket (layers > next_layer have issued their backward)
   void issue_one_bucket(size_t k, bool wait_main);      // wait_main: also behind what the compute stream holds now
   int  big_dw_chunks_now() const;                       // row blocks the biggest layer's weight gradient is cut into this step (1: not cut)
   mutable int64_t n_bucket_allreduces = 0;
-  // ---- split slab update (FFConfig::split_update) ----
-  size_t bottom_floats = 0;              // slab elements of the Linear layers in front of the tables (0: no split possible)
-  int first_top_linear = -1;             // layer index of the first Linear behind the tables: its forward waits for the top part's update
-  ffh_event ev_top_mark = nullptr, ev_top_opt_done = nullptr;
-  mutable ffh_event ev_sort_done = nullptr;   // --sort-before-bottom-backward: the sort phase on the compute stream, the apply phase on the side stream behind it
-  bool bottom_bwd_on_stream = false;     // this step's bottom-MLP backward ran as a chain call on the compute stream (its gradients need no join)
-  bool top_opt_pending = false;          // the top part's update is in flight on the weight-gradient stream
-  mutable int64_t n_split_updates = 0;
-  void join_top_update();                // `stream` waits for it (no-op when nothing is pending)
   mutable int64_t n_chain_fwd_calls = 0, n_chain_bwd_calls = 0;   // successful ffh_mlp_chain_fwd / _bwd calls (tests: flexflow_model_get_counter)
   bool mlp_chain_usable(int64_t rows, bool fwd) const;      // the chain launches are allowed in this mode / at this batch
   int run_chain_fwd(const Linear* lowest) const;  // FFH_OK, or FFH_ERR_UNSUPPORTED with nothing launched
   int run_chain_bwd(Linear* top);
-  int dw_cu_reserve_for(int64_t batch) const;
   mutable bool mlp_grads_clean;   // the optimizer kernel cleared the MLP gradient slab (FFH_OPT_ZERO_GRAD): zero_gradients() skips it
   LaunchWorker *dw_worker, *side_worker;   // NULL: launches are issued inline by the calling thread
   std::vector<ffh_event> layer_events;     // one per layer: "dY of this layer is ready"
@@ -612,7 +591,6 @@ class FFModel {
   mutable bool emb_forward_issued, emb_forward_joined, emb_update_pending;
   static constexpr int early_sort_big_batch_mode = 0;   // one GPU, >= 8192 samples: 0 = the sort stays in front of the apply phase (see early_sort_possible)
   bool early_sort_possible(int where) const;
-  void sort_embedding_indices_on(ffh_stream s) const;      // one launch group, nothing else on the workspace between a step's gather and its update
   mutable bool emb_sorted_early;         // this step's sort was issued behind the gather: the update is the apply phase only
   int scatter_attach_layer;     // exchange mode: the Linear whose scattered dX completes the embedding output gradients (-1: none)
   std::vector<Initializer*> owned_initializers;
@@ -623,6 +601,7 @@ class FFModel {
   mutable bool w_twin_dirty = false;      // a host write / initializer touched the weights: reconvert before the next step
   void refresh_weight_twin() const;
   void note_weight_write(const void* p) const;
+  mutable bool bwd_alltoall_issued = false;   // this step's backward all-to-all has been enqueued (FFModel::issue_grad_buckets: a shared channel holds the buckets until then)
   int n_twin_regions = 0;
   int z_reader_layer;           // the lowest-index Linear that reads a Concat output the tables are gathered into (-1: unknown): behind ITS
                                 // backward no forked weight-gradient GEMM reads that buffer any more, so the next gather may overwrite it

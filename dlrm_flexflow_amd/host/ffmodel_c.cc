@@ -127,8 +127,12 @@ int64_t flexflow_model_get_counter(flexflow_model_t m, const char* name) {
   if (n == "mlp_chain_fwd_calls") return M(m)->n_chain_fwd_calls;
   if (n == "mlp_chain_bwd_calls") return M(m)->n_chain_bwd_calls;
   if (n == "allreduce_bucket_calls") return M(m)->n_bucket_allreduces;
-  if (n == "split_updates") return M(m)->n_split_updates;
   if (n == "allreduce_buckets") return (int64_t)M(m)->grad_buckets.size();
+  if (n.rfind("allreduce_bucket_floats_", 0) == 0) {      // floats of bucket k, in issue order
+    const size_t k = (size_t)atoi(n.c_str() + 24);
+    return k < M(m)->grad_buckets.size() ? (int64_t)M(m)->grad_buckets[k].count : -1;
+  }
+  if (n == "allreduce_bucket_channel_own") return M(m)->config.comm.bucket_channel_own;
   return -1;
 }
 
@@ -272,7 +276,7 @@ float flexflow_dlrm_time_kernel(flexflow_dlrm_t h, int which, int iters) {
     ff->check(ff->api->ffh_event_record(ff->ctx, ff->ev_dw_done, ff->dw_stream), "join dw");
     ff->check(ff->api->ffh_stream_wait_event(ff->ctx, ff->stream, ff->ev_dw_done), "join dw");
     ff->dw_forked = false;
-    ff->dw1_used = ff->dw2_used = false;
+    ff->dw1_used = false;
   }
   ff->check(ff->api->ffh_event_record(ff->ctx, e1, ff->stream), "event");
   ff->check(ff->api->ffh_event_sync(ff->ctx, e1), "event");

@@ -124,16 +124,32 @@ int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv)
     fprintf(stderr, "dlrm rank %d: ncclCommInitRank failed: %s\n", rank, flexflow_rccl_last_error());
     return 5;
   }
-  // --allreduce-own-channel: a second communicator for the MLP-gradient buckets (opt-in; collective: every rank passes the flag)
-  for (int i = 1; i < argc; i++)
-    if (!strcmp(argv[i], "--allreduce-own-channel") && flexflow_rccl_comm_enable_bucket_channel(&comm) != 0 && rank == 0)
-      fprintf(stderr, "dlrm: --allreduce-own-channel: %s (the buckets share the first communicator)\n", flexflow_rccl_last_error());
   g_bar.api = api; g_bar.ctx = ctx; g_bar.comm = &comm;
   void* p = nullptr;
   if (api->ffh_stream_create(ctx, &g_bar.stream) != FFH_OK || api->ffh_malloc(ctx, &p, 256) != FFH_OK) return 5;
   g_bar.buf = (float*)p;
   api->ffh_zero(ctx, p, 256, g_bar.stream);
   comm.barrier = launcher_barrier;
+  // A second communicator for the MLP-gradient buckets (ncclCommSplit), unless --allreduce-shared-channel: the ranks first AGREE that every
+  // one of them can make the collective call, make it, and agree again on its outcome -- a rank that failed alone would otherwise leave the
+  // others inside ncclCommSplit, or send its buckets on a communicator its peers do not use (round-5 advisor).
+  bool want_own = true;
+  for (int i = 1; i < argc; i++) if (!strcmp(argv[i], "--allreduce-shared-channel")) want_own = false;
+  auto all_ranks = [&](bool ok) -> bool {      // true when `ok` holds on every rank: sum of the failure flags over the first communicator
+    const float mine = ok ? 0.0f : 1.0f;
+    float sum = 1.0f;
+    if (api->ffh_memcpy_h2d(ctx, g_bar.buf, &mine, 4, g_bar.stream) != FFH_OK || comm.allreduce_sum_f32(comm.user, g_bar.buf, 1, g_bar.stream) != 0 ||
+        api->ffh_memcpy_d2h(ctx, &sum, g_bar.buf, 4, g_bar.stream) != FFH_OK || api->ffh_stream_sync(ctx, g_bar.stream) != FFH_OK) return false;
+    return sum == 0.0f;
+  };
+  if (want_own && all_ranks(flexflow_rccl_has_comm_split(rccl) == 0)) {
+    const bool mine = flexflow_rccl_comm_enable_bucket_channel(&comm) == 0;
+    if (!all_ranks(mine)) {
+      flexflow_rccl_comm_disable_bucket_channel(&comm);
+      if (rank == 0) fprintf(stderr, "dlrm: ncclCommSplit failed on some rank (%s): the gradient buckets share the first communicator\n", flexflow_rccl_last_error());
+    }
+  }
+  api->ffh_zero(ctx, p, 256, g_bar.stream);
   // the rank's own argv: the same flags + its device
   std::vector<char*> av(argv, argv + argc);
   std::string dev = std::to_string(rank);

@@ -133,7 +133,6 @@ FFConfig::FFConfig() {
   attach_events = true;
   fuse_pair = true;
   mlp_chain = true;
-  split_update = false;        // measured (profiles/r05_ab_schedule.txt): 4096 samples 1.150-1.154 vs 1.145-1.146 ms, headline and Kaggle level -- off
   trace_mode = -1;
   bucket_allreduce = -1;
   allreduce_bucket_floats = 1 << 20;
@@ -153,18 +152,12 @@ FFConfig::FFConfig() {
   mlp_chain_max_weights = 200000;
   dx_scatter = true;
   dx_colsum = true;
-  stream_priorities = false;
   early_sort = -1;
   pad_linear_k = true;
   capture_exchange = false;
   bf16_twins = true;
   bf16_convert_twins = true;
   force_async_launch = false;
-  defer_big_dw = 0;
-  two_dw_streams = false;      // measured in round 4: no gain (1.183-1.189 vs 1.184-1.188 ms at 4096 samples; MLPerf shape 1.29 vs 1.27: worse)
-  big_dw_mode = 0;
-  dw_cu_reserve = -1;
-  bottom_dw_cu_reserve = 0;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
   fp32_split_bf16x3 = false;
@@ -227,8 +220,6 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--no-attach-event")) { attach_events = false; continue; }
     if (is("--no-fused-pair")) { fuse_pair = false; continue; }
     if (is("--no-mlp-chain")) { mlp_chain = false; continue; }
-    if (is("--no-split-update")) { split_update = false; continue; }
-    if (is("--split-update")) { split_update = true; continue; }
     if (is("--always-replay")) { trace_mode = 1; continue; }
     if (is("--adaptive-replay")) { trace_mode = 0; continue; }
     if (is("--bucket-allreduce")) { bucket_allreduce = 1; continue; }
@@ -242,25 +233,13 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--mlp-chain-max-weights")) { mlp_chain_max_weights = atoll(next()); continue; }
     if (is("--no-dx-scatter")) { dx_scatter = false; continue; }
     if (is("--no-dx-colsum")) { dx_colsum = false; continue; }
-    if (is("--stream-priorities")) { stream_priorities = true; continue; }
-    if (is("--no-stream-priorities")) { stream_priorities = false; continue; }
     if (is("--no-early-sort")) { early_sort = 0; continue; }
     if (is("--early-sort")) { early_sort = 1; continue; }
-    if (is("--sort-at-backward-start")) { early_sort = 2; continue; }
-    if (is("--sort-at-interaction-backward")) { early_sort = 3; continue; }
-    if (is("--sort-before-bottom-backward")) { early_sort = 4; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
     if (is("--capture-exchange")) { capture_exchange = true; continue; }
     if (is("--no-bf16-convert-twins")) { bf16_convert_twins = false; continue; }    // A/B: no twin by conversion behind an fp32-kernel layer
     if (is("--no-bf16-twins")) { bf16_twins = false; continue; }               // A/B and tests: tensor-op mode rounding its operands inside the kernels
     if (is("--force-async-launch")) { force_async_launch = true; continue; }   // tests: the launch-worker threads on a synchronous backend
-    if (is("--defer-big-dw")) { defer_big_dw = 1; continue; }
-    if (is("--one-dw-stream")) { two_dw_streams = false; continue; }
-    if (is("--two-dw-streams")) { two_dw_streams = true; continue; }
-    if (is("--big-dw-mode")) { big_dw_mode = atoi(next()); continue; }
-    if (is("--dw-cu-reserve")) { dw_cu_reserve = atoi(next()); continue; }
-    if (is("--bottom-dw-cu-reserve")) { bottom_dw_cu_reserve = atoi(next()); continue; }
-    if (is("--no-defer-big-dw")) { defer_big_dw = 0; continue; }
     if (is("--sparse-embedding-optimizer")) { sparse_embedding_optimizer = true; continue; }
   }
 }
@@ -304,7 +283,7 @@ bool Tensor::set_tensor(const FFModel* model, const std::vector<int>& dims, cons
   if (model->side_worker) model->side_worker->drain();
   model->check(model->api->ffh_stream_sync(model->ctx, model->side_stream), "set_tensor sync");
   model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream), "set_tensor sync");
-  model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream2), "set_tensor sync");
+  model->check(model->api->ffh_stream_sync(model->ctx, model->ar_stream), "set_tensor sync");
   if (impl->ld == cols_) {
     model->check(model->api->ffh_memcpy_h2d(model->ctx, impl->ptr, data, vol * sizeof(T), model->stream), "set_tensor");
   } else {
@@ -328,7 +307,7 @@ bool copy_out(const FFModel* model, const Tensor& t, const void* base, int64_t l
   model->check(model->api->ffh_stream_sync(model->ctx, model->stream), "get_tensor sync");
   model->check(model->api->ffh_stream_sync(model->ctx, model->side_stream), "get_tensor sync");
   model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream), "get_tensor sync");
-  model->check(model->api->ffh_stream_sync(model->ctx, model->dw_stream2), "get_tensor sync");
+  model->check(model->api->ffh_stream_sync(model->ctx, model->ar_stream), "get_tensor sync");
   if (ld == cols_) {
     model->check(model->api->ffh_memcpy_d2h(model->ctx, data, base, (size_t)nrows * cols_ * sizeof(T), model->stream), "get_tensor");
   } else {
@@ -482,7 +461,7 @@ void Op::print_layer(const FFModel&) const {
 static FFConfig& profiling_schedule(FFConfig& c) {
   if (c.profiling) {
     c.overlap_embedding = false; c.enable_graph = false; c.parallel_dw = false; c.async_launch = false;
-    c.fuse_pair = false; c.mlp_chain = false; c.split_update = false; c.attach_events = false; c.dx_scatter = false; c.timing_events = true;
+    c.fuse_pair = false; c.mlp_chain = false; c.attach_events = false; c.dx_scatter = false; c.timing_events = true;
   }
   return c;
 }
@@ -495,7 +474,7 @@ FFModel::FFModel(FFConfig& _config)
       act_slab(nullptr), act_grad_slab(nullptr), act_grad_bytes(0), workspace(nullptr), workspace_bytes(0), repl_workspace(nullptr), repl_workspace_bytes(0), d_perf(nullptr),
       xsend(nullptr), xrecv(nullptr), gsend(nullptr), grecv(nullptr), capturing_trace(-1), replaying_trace(-1), inputs_dirty(true), fork_recorded(false) {
   seed_counter = 0;
-  dw_stream = dw_stream2 = nullptr; ev_dw_done = ev_dw2_done = nullptr; big_dw_layer = -1; need_zero_act_grads = true; need_zero_gsend = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
+  dw_stream = nullptr; ev_dw_done = nullptr; big_dw_layer = -1; need_zero_act_grads = true; need_zero_gsend = true; dw_forked = false; mlp_grads_clean = false; dw_worker = side_worker = nullptr;
   rank = config.comm.world_size > 1 ? config.comm.rank : 0;
   world_size = config.comm.world_size > 1 ? config.comm.world_size : 1;
   if (world_size == 1 && config.workersPerNode > 1)
@@ -517,19 +496,10 @@ FFModel::FFModel(FFConfig& _config)
   // the compute stream runs the Linear layers: the library's scratch for their stream-K / last-arriver forms is reserved here, once,
   // outside any capture (ffh_ctx_reserve_scratch, ABI 12: compute entry points never allocate)
   check(api->ffh_ctx_reserve_scratch(ctx, stream), "reserve scratch");
-  // --stream-priorities (A/B, off): the embedding stream at a higher HIP priority (ABI 11).  Measured in round 4 (profiles/r04_ab_schedule.txt):
-  // level at 32768 samples (7.80-7.83 vs 7.82-7.84 ms), worse at 4096 (1.180-1.184 vs 1.173-1.178), 7 us better at the MLPerf shape --
-  // and never with the exchange on that stream: RCCL's send/recv kernels at the higher priority made the 1-rank exchange step
-  // 1.27 -> 1.99 ms (Terabyte shape, 4096 samples) and 0.195 -> 0.716 ms (Kaggle shape)
-  check((config.stream_priorities && !exchange) ? api->ffh_stream_create_with_priority(ctx, &side_stream, -1) : api->ffh_stream_create(ctx, &side_stream), "stream create");
+  check(api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
-  check(api->ffh_stream_create(ctx, &dw_stream2), "stream create");
-  // the gradient buckets' stream: the second weight-gradient stream where that is idle (the default) -- a FIFTH stream shares a hardware
-  // queue with one of the others (HIP maps streams onto four), and a bucket waiting there for a weight-gradient GEMM then holds back
-  // whatever that other stream has queued: measured, the biggest layer's data gradient started 90 us late behind such a wait
-  if (config.two_dw_streams) check(api->ffh_stream_create(ctx, &ar_stream), "stream create");
-  else ar_stream = dw_stream2;
-  check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw2_done), "event create");
+  // the gradient buckets' stream (a fifth stream would share a hardware queue with one of the others: HIP maps streams onto four)
+  check(api->ffh_stream_create(ctx, &ar_stream), "stream create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw_done), "event create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_z_free), "event create");
   z_reader_layer = -1; z_free_recorded = false;
@@ -574,14 +544,10 @@ FFModel::~FFModel() {
   api->ffh_event_destroy(ctx, ev_grad_ready); api->ffh_event_destroy(ctx, ev_update_done);
   api->ffh_event_destroy(ctx, ev_dw_done);
   api->ffh_event_destroy(ctx, ev_z_free);
-  api->ffh_event_destroy(ctx, ev_top_mark); api->ffh_event_destroy(ctx, ev_top_opt_done);
-  api->ffh_event_destroy(ctx, ev_sort_done);
   for (auto& kv : trace_tune) for (ffh_event& e : kv.second.ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
   for (ffh_event& e : probe_ev) if (e) { api->ffh_event_destroy(ctx, e); e = nullptr; }
-  api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream); api->ffh_stream_destroy(ctx, dw_stream2);
-  for (GradBucket& b : grad_buckets) { api->ffh_event_destroy(ctx, b.ready); api->ffh_event_destroy(ctx, b.ready_dw); api->ffh_event_destroy(ctx, b.ready_dw2); api->ffh_event_destroy(ctx, b.done); }
-  if (ar_stream && ar_stream != dw_stream2) api->ffh_stream_destroy(ctx, ar_stream);
-  api->ffh_event_destroy(ctx, ev_dw2_done);
+  api->ffh_stream_destroy(ctx, stream); api->ffh_stream_destroy(ctx, side_stream); api->ffh_stream_destroy(ctx, dw_stream); api->ffh_stream_destroy(ctx, ar_stream);
+  for (GradBucket& b : grad_buckets) { api->ffh_event_destroy(ctx, b.ready); api->ffh_event_destroy(ctx, b.ready_dw); api->ffh_event_destroy(ctx, b.done); }
   api->ffh_ctx_destroy(ctx);
   for (Op* op : layers) delete op;
   for (Initializer* i : owned_initializers) delete i;
@@ -754,9 +720,8 @@ int Linear::backward_pair(const FFModel& ff) {
 }
 void Linear::backward(const FFModel& ff) { backward_part(ff, 0); }
 
-// part 0: the whole backward; 1: the data gradient only (FFH_LINEAR_ONLY_DX on the compute stream); 2: the weight / bias gradient
-// only (FFH_LINEAR_ONLY_DW on the weight-gradient stream, behind everything the compute stream holds at this point).  The two
-// halves are for FFModel::backward's deferred weight gradient (--defer-big-dw).
+// part 0: the whole backward; 1: the data gradient only (FFH_LINEAR_ONLY_DX on the compute stream) -- for FFModel::backward's row-block
+// weight gradient of the biggest layer (backward_dw_rows), which follows it.
 void Linear::backward_part(const FFModel& ff, int part) {
   // [ref: src/ops/linear.cu:632-635: "only support relu and sigmoid for now" -- an assert there, a named error here]
   if (activation == AC_MODE_GELU) die("%s: GELU has no backward (forward / inference only, as in the reference)", name);
@@ -790,22 +755,6 @@ void Linear::backward_part(const FFModel& ff, int part) {
     image_dx();
     return;
   }
-  if (part == 3) {      // the weight / bias gradient on the compute stream itself (A/B: --big-dw-mode 2)
-    ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, nullptr, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
-                                       flags | FFH_LINEAR_ONLY_DW, ff.stream, nullptr), name);
-    return;
-  }
-  if (part == 2) {
-    ffh_event ev = ff.layer_events[layer_index];
-    ff.check(ff.api->ffh_event_record(ff.ctx, ev, ff.stream), "event");
-    ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.dw_stream, ev), "event");
-    ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, nullptr, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
-                                       flags | FFH_LINEAR_ONLY_DW, ff.dw_stream, nullptr), name);
-    ff.dw_forked = true;
-    ff.dw1_used = true;
-    ff.dw_stream_used_directly = true;
-    return;
-  }
   if (fork && ff.use_workers()) {
     // two host threads: this one keeps walking the dX chain, the dW GEMM is issued by the dw worker on its stream
     const KernelApi* api = ff.api;
@@ -825,25 +774,11 @@ void Linear::backward_part(const FFModel& ff, int part) {
     ff.dw_forked = true;
     return;
   }
-  // Two weight-gradient streams: the biggest layer's GEMM (the first top layer's: a persistent launch of hundreds of microseconds)
-  // has one to itself.  On a single stream the bottom MLP's weight gradients -- forked seconds of host time later, but needing only
-  // operands that exist long before the big GEMM ends -- queued BEHIND it and ran, with the optimizer and the next forward behind
-  // them, after it (4096 samples: ~80 of the 130 us between the end of that GEMM and the next top-MLP forward).
-  ffh_stream dws = layer_index == ff.big_dw_layer ? ff.dw_stream : ff.dw_stream2;
-  if (!ff.config.two_dw_streams) dws = ff.dw_stream;
-  // The biggest layer's weight-gradient GEMM leaves a few CUs without one of its persistent workgroups when the small dependent
-  // kernels that run beside it (the bottom MLP's backward chain, the table update, the next gather) are a large share of the step --
-  // small per-GPU batches; see ffh_ctx_set_dw_cu_reserve and FFConfig::dw_cu_reserve.
-  int reserve = (fork && layer_index == ff.big_dw_layer) ? ff.dw_cu_reserve_for(b) : 0;
-  // (--bottom-dw-cu-reserve N, A/B: the bottom MLP's persistent weight-gradient GEMMs -- which run beside the table update and the next gather --
-  //  leave N CUs without a workgroup)
-  if (ff.config.bottom_dw_cu_reserve > 0 && !ff.embeddings.empty() && layer_index < ff.embeddings.front()->layer_index) reserve = ff.config.bottom_dw_cu_reserve;
-  if (reserve > 0) ff.check(ff.api->ffh_ctx_set_dw_cu_reserve(ff.ctx, reserve), "dw cu reserve");
+  ffh_stream dws = ff.dw_stream;
   ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                      flags, ff.stream, fork ? dws : nullptr), name);
-  if (reserve > 0) ff.check(ff.api->ffh_ctx_set_dw_cu_reserve(ff.ctx, 0), "dw cu reserve");
   image_dx();
-  if (fork) { ff.dw_forked = true; (dws == ff.dw_stream ? ff.dw1_used : ff.dw2_used) = true; }
+  if (fork) { ff.dw_forked = true; ff.dw1_used = true; }
 }
 
 // One row block of this layer's weight gradient: dW[row0 .. row0 + nrows)[:] (and db of the same rows) as an ONLY_DW call of its own on
@@ -868,7 +803,7 @@ void Linear::backward_dw_rows(const FFModel& ff, int row0, int nrows) {
 
 // ---- chains of narrow Linear layers (ffh_mlp_chain_fwd / _bwd, ABI 12; built in FFModel::allocate step 4e) -------------------
 bool FFModel::mlp_chain_usable(int64_t rows, bool fwd) const {
-  return config.mlp_chain && !config.profiling && !use_workers() && !config.deterministic && !config.allow_tensor_op_math_conversion &&
+  return config.mlp_chain && !config.profiling && !use_workers() && !config.allow_tensor_op_math_conversion &&
          !config.fp32_split_bf16x3 && rows <= config.mlp_chain_max_batch && (!fwd || (rows >= config.mlp_chain_fwd_min_batch && rows <= config.mlp_chain_fwd_max_batch));
 }
 static void fill_chain(const std::vector<Linear*>& ch, ffh_chain_layer* out) {
@@ -1003,16 +938,6 @@ void Embedding::backward(const FFModel& ff) {
       // gradients of every table are complete here; the side-stream update itself is issued at the END of
       // backward(), after the host has enqueued the bottom-MLP backward it overlaps with
       if (!ff.grad_ready_attached) ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_grad_ready, ff.stream), "event");
-      if (!ff.emb_sorted_early && ff.early_sort_possible(4)) {
-        // (--sort-before-bottom-backward) the index-only sort ON the compute stream, in front of the bottom MLP's backward: 13 us alone at the
-        // MLPerf shape, where beside the chain kernels of that backward (MFMA-dense) its two launches took 83.  The apply phase -- issued
-        // below, on the side stream -- follows it
-        if (!ff.ev_sort_done) ff.check(ff.api->ffh_event_create_sync(ff.ctx, &ff.ev_sort_done), "event create");
-        ff.sort_embedding_indices_on(ff.stream);
-        ff.check(ff.api->ffh_event_record(ff.ctx, ff.ev_sort_done, ff.stream), "event");
-        ff.check(ff.api->ffh_stream_wait_event(ff.ctx, ff.side_stream, ff.ev_sort_done), "event");
-        ff.emb_sorted_early = true;
-      }
       if (ff.exchange && !ff.config.comm.nonblocking && !ff.use_workers()) {
         ff.emb_update_pending = true;      // host-side collectives on this thread: issue after the bottom-MLP backward is enqueued
       } else {
@@ -1957,7 +1882,7 @@ void FFModel::allocate() {
   // the exchange path's column map.
   for (Op* op : layers)
     if (Linear* li = dynamic_cast<Linear*>(op)) { li->chain_fwd.clear(); li->chain_bwd.clear(); li->fwd_done_by_chain = false; }
-  if (config.mlp_chain && !config.profiling && !config.async_launch && !config.deterministic && !config.allow_tensor_op_math_conversion && !config.fp32_split_bf16x3) {
+  if (config.mlp_chain && !config.profiling && !config.async_launch && !config.allow_tensor_op_math_conversion && !config.fp32_split_bf16x3) {
     auto member_ok = [&](const Linear* li) {
       return li->in_channels <= FFH_CHAIN_MAX_WIDTH && li->out_channels <= FFH_CHAIN_MAX_WIDTH && li->in_padded == li->in_channels &&
              li->inputs[0].impl->pieces.empty() && li->outputs[0].impl->pieces.empty() && li->inputs[0].impl->ptr && li->outputs[0].impl->ptr;
@@ -2040,21 +1965,6 @@ void FFModel::allocate() {
   }
   // Op::weights[] are copies of the Parameters: same impl pointers, nothing to patch.
 
-  // ---- 5a'. where the slab splits for the two-part optimizer launch (FFConfig::split_update) -----------------------------
-  bottom_floats = 0; first_top_linear = -1;
-  if (!embeddings.empty() && !exchange) {
-    const int first_emb = embeddings.front()->layer_index;
-    size_t at = 0; bool ok = true;
-    for (const Embedding* e : embeddings) if (e->replicated) ok = false;          // (data-parallel tables live in the slab between the two MLPs)
-    for (const Parameter& p : parameters) {
-      if (!in_dense_slab(p)) continue;
-      if (p.owner_op->layer_index < first_emb) { if (p.impl->grad != mlp_grads + at) ok = false; at += slab_span(p); }
-    }
-    for (size_t l = (size_t)first_emb; l < layers.size() && first_top_linear < 0; l++) if (layers[l]->op_type == OP_LINEAR) first_top_linear = (int)l;
-    if (ok && at > 0 && at < mlp_count && first_top_linear >= 0) bottom_floats = at;
-  }
-  if (!ev_top_mark) { check(api->ffh_event_create_sync(ctx, &ev_top_mark), "event create"); check(api->ffh_event_create_sync(ctx, &ev_top_opt_done), "event create"); }
-
   // ---- 5b. buckets of the MLP gradients' all-reduce ---------------------------------------------------------------------
   // In the reference every parameter has its own update task with its own ncclAllReduce, ordered by region dependences only: a top
   // layer's gradients are summed over the ranks while the layers below still run their backward [ref: src/runtime/optimizer.cc:93-189,
@@ -2062,7 +1972,7 @@ void FFModel::allocate() {
   // allreduce_bucket_floats gradients; a bucket is issued on ar_stream as soon as the layers it covers have issued their backward
   // (FFModel::issue_grad_buckets), the slab optimizer waits for all of them.  What no bucket covers (data-parallel tables in the slab)
   // is reduced in update() as before.
-  for (GradBucket& b : grad_buckets) { api->ffh_event_destroy(ctx, b.ready); api->ffh_event_destroy(ctx, b.ready_dw); api->ffh_event_destroy(ctx, b.ready_dw2); api->ffh_event_destroy(ctx, b.done); }
+  for (GradBucket& b : grad_buckets) { api->ffh_event_destroy(ctx, b.ready); api->ffh_event_destroy(ctx, b.ready_dw); api->ffh_event_destroy(ctx, b.done); }
   grad_buckets.clear();
   grad_rest.clear();
   if (exchange && mlp_count) {
@@ -2077,8 +1987,8 @@ void FFModel::allocate() {
       chunks = 1;
     auto build = [&](size_t threshold) {
       std::vector<GradBucket> out;
-      GradBucket cur{0, 0, -1, false, nullptr, nullptr, nullptr, nullptr, -1, 0, false};
-      auto close = [&]() { if (cur.count) out.push_back(cur); cur = GradBucket{0, 0, -1, false, nullptr, nullptr, nullptr, nullptr, -1, 0, false}; };
+      GradBucket cur{0, 0, -1, false, nullptr, nullptr, nullptr, -1, 0, false};
+      auto close = [&]() { if (cur.count) out.push_back(cur); cur = GradBucket{0, 0, -1, false, nullptr, nullptr, nullptr, -1, 0, false}; };
       for (int l = (int)layers.size() - 1; l >= 0; l--) {
         Linear* li = layers[l]->op_type == OP_LINEAR ? static_cast<Linear*>(layers[l]) : nullptr;
         if (!li) continue;
@@ -2090,7 +2000,7 @@ void FFModel::allocate() {
           close();
           const size_t per = (size_t)(big->out_channels / chunks) * (size_t)big->weights[0].impl->ld;
           for (int c = 0; c < chunks; c++) {
-            GradBucket b{lo + c * per, c == chunks - 1 ? hi - (lo + c * per) : per, l, false, nullptr, nullptr, nullptr, nullptr, l, c, false};
+            GradBucket b{lo + c * per, c == chunks - 1 ? hi - (lo + c * per) : per, l, false, nullptr, nullptr, nullptr, l, c, false};
             out.push_back(b);
           }
           continue;
@@ -2116,7 +2026,7 @@ void FFModel::allocate() {
     while (grad_buckets.size() > 8 && threshold < mlp_count) { threshold *= 2; grad_buckets = build(threshold); }     // (the probes number eight)
     std::vector<std::pair<size_t, size_t>> covered;
     for (GradBucket& b : grad_buckets) {
-      for (ffh_event* e : {&b.ready, &b.ready_dw, &b.ready_dw2, &b.done}) check(api->ffh_event_create(ctx, e), "event create");
+      for (ffh_event* e : {&b.ready, &b.ready_dw, &b.done}) check(api->ffh_event_create(ctx, e), "event create");
       covered.push_back({b.off, b.count});
     }
     std::sort(covered.begin(), covered.end());
@@ -2319,9 +2229,6 @@ static void launch_shard_groups(const FFModel* ff, ShardLaunch what, ffh_stream 
     }
   }
 }
-// the index-only sort phase of the fused table update on stream s (Embedding::backward, --sort-before-bottom-backward)
-void FFModel::sort_embedding_indices_on(ffh_stream s) const { launch_shard_groups(this, kSortOnly, s, ctx); }
-
 // the batched gather (fwd) or fused update kernels of this rank's shards alone, no exchange: what bench.py times as the
 // roofline kernels of a multi-rank job
 void FFModel::embedding_kernels_only(bool fwd, ffh_stream s, const std::vector<const int64_t*>* idx_override) const {
@@ -2353,27 +2260,6 @@ bool FFModel::early_sort_possible(int where) const {
   for (const Embedding* e : embeddings)
     if (e->row_sharded) return false;
   return n > 0 && n <= FFH_MAX_TABLES;
-}
-
-// the layer whose weight gradient is issued last under --defer-big-dw (-1: none): the Linear with the most multiply-adds
-int FFModel::defer_big_dw_layer() const {
-  if (config.defer_big_dw <= 0 || !config.parallel_dw || config.profiling || use_workers() || config.deterministic) return -1;
-  int best = -1; double best_macs = 0.0;
-  for (size_t l = 0; l < layers.size(); l++) {
-    const Linear* li = layers[l]->op_type == OP_LINEAR ? static_cast<const Linear*>(layers[l]) : nullptr;
-    if (!li || li->discard_input_grad || li->activation == AC_MODE_SIGMOID || (li->activation == AC_MODE_RELU && !li->dy_premasked)) continue;
-    const double m = (double)li->in_channels * li->out_channels * (double)local_batch;
-    if (m > best_macs) { best_macs = m; best = (int)l; }
-  }
-  if (best < 0 || best == (int)layers.size() - 1) return -1;
-  return best;
-}
-
-// Measured in round 4 (profiles/r04_ab_schedule.txt): every CU taken from the GEMM costs more than the kernels beside it gain -- plain
-// step at 4096 samples 1.186 / 1.199 / 1.210 / 1.226 / 1.239 ms for 0 / 16 / 32 / 48 / 64 CUs, 32768 samples 7.87 / 8.00 / 8.08; only the
-// exchange-forced step (RCCL's copy kernels run beside that GEMM) gains 1 % at 32.  Default: none.
-int FFModel::dw_cu_reserve_for(int64_t) const {
-  return config.dw_cu_reserve > 0 ? config.dw_cu_reserve : 0;
 }
 
 void FFModel::probe_record(int which, ffh_stream s, ffh_ctx* cx) const {
@@ -2464,6 +2350,7 @@ void FFModel::embedding_group_update(ffh_stream s, ffh_ctx* on_ctx) const {
     if (!shards.empty() && config.comm.alltoall_f32(config.comm.user, gsend, fwd_recv_counts.data(), grecv, fwd_send_counts.data(), s) != 0)
       die("alltoall (embedding backward) failed");
     probe_record(7, s, on_ctx ? on_ctx : ctx);
+    bwd_alltoall_issued = true;
   }
   launch_shard_groups(this, emb_sorted_early ? kApplyOnly : kFusedUpdate, s, on_ctx ? on_ctx : ctx);
   emb_sorted_early = false;
@@ -2542,7 +2429,15 @@ int FFModel::big_dw_chunks_now() const {
 // compute stream and the weight-gradient streams hold at this point -- the layers' dW / db launches among it -- then runs the sum.
 // While a capture is open (--capture-exchange) the sum goes on the capturing stream itself: with RCCL work on a stream that joined
 // the capture through an event hipStreamEndCapture recurses (profiles/r04_capture_exchange_endcapture_backtrace.txt).
+bool FFModel::buckets_held() const {
+  return !config.comm.bucket_channel_own && !shards.empty() && !embeddings.empty() && fused_embedding_update() && !bwd_alltoall_issued;
+}
 void FFModel::issue_grad_buckets(int next_layer) {
+  // A transport that serves the buckets on the SAME channel as the all-to-alls (ffcomm.bucket_channel_own == 0: one RCCL communicator runs its
+  // collectives in issue order, whatever streams they are on): nothing goes out before this step's backward all-to-all has been enqueued --
+  // otherwise the exchange of the embedding gradients, the table update and the next gather behind it would wait for the biggest layer's
+  // weight-gradient GEMM and its all-reduce (round-5 advisor).  The held buckets follow at the next layer boundary.
+  if (buckets_held()) return;
   for (size_t k = 0; k < grad_buckets.size(); k++) {
     GradBucket& b = grad_buckets[k];
     if (b.issued || b.lowest_layer <= next_layer) continue;
@@ -2561,7 +2456,6 @@ void FFModel::issue_one_bucket(size_t k, bool wait_main) {
   // (the weight-gradient streams: joined where this step has used them so far -- a bucket whose layers kept everything on `stream`
   //  waits for nothing extra; inline, `stream` itself takes the waits)
   if (dw_forked && dw1_used) { check(api->ffh_event_record(ctx, b.ready_dw, dw_stream), "bucket ready"); check(api->ffh_stream_wait_event(ctx, s, b.ready_dw), "bucket ready"); }
-  if (dw_forked && dw2_used) { check(api->ffh_event_record(ctx, b.ready_dw2, dw_stream2), "bucket ready"); check(api->ffh_stream_wait_event(ctx, s, b.ready_dw2), "bucket ready"); }
   if (k < 8) probe_record(14 + 2 * (int)k, s, ctx);
   auto fn = config.comm.allreduce_bucket_sum_f32 ? config.comm.allreduce_bucket_sum_f32 : config.comm.allreduce_sum_f32;
   if (fn(config.comm.user, mlp_grads + b.off, (int64_t)b.count, s) != 0) die("allreduce (bucket) failed");
@@ -2590,12 +2484,6 @@ void FFModel::note_weight_write(const void* p) const {
   if (w_twin && (const char*)p >= (const char*)mlp_weights && (const char*)p < (const char*)(mlp_weights + mlp_count)) w_twin_dirty = true;
 }
 
-void FFModel::join_top_update() {
-  if (!top_opt_pending) return;
-  check(api->ffh_stream_wait_event(ctx, stream, ev_top_opt_done), "join the top part's update");
-  top_opt_pending = false;
-}
-
 void FFModel::forward(int _seq_length) {
   if (replaying_trace >= 0) return;
   seq_length = _seq_length;
@@ -2616,7 +2504,6 @@ void FFModel::forward(int _seq_length) {
     if (!exchange || config.comm.nonblocking || use_workers()) issue_embedding_forward_on_side_stream();
   }
   for (Op* op : layers) {
-    if (top_opt_pending && op->layer_index >= first_top_linear) join_top_update();      // (split update: the first consumer of the top MLP's weights)
     if (!config.profiling) { op->forward(*this); continue; }
     if (op->op_type == OP_EMBEDDING && emb_forward_issued) continue;      // the first table launched the whole group
     profiled(op, true, [&] { op->forward(*this); });
@@ -2768,27 +2655,15 @@ void FFModel::backward(int _seq_length) {
                                    local_rows(fin, this), fin.adim[0], scale, metrics_flags, stream), "metrics + loss backward");
   grad_ready_attached = false;
   z_free_recorded = false;
-  if (!emb_sorted_early && early_sort_possible(2)) {      // (--sort-at-backward-start) the index-only sort beside the first backward GEMMs
-    launch_shard_groups(this, kSortOnly, side_stream, ctx);
-    emb_sorted_early = true;
-  }
   auto mark_z_free = [&](int l) {     // behind the last reader of the gather's destination among the forked weight-gradient GEMMs
     if (l == z_reader_layer && dw_forked && !dw_worker && capturing_trace < 0) {
-      check(api->ffh_event_record(ctx, ev_z_free, (l == big_dw_layer || !config.two_dw_streams) ? dw_stream : dw_stream2), "z free");   // the stream that layer's dW is on
+      check(api->ffh_event_record(ctx, ev_z_free, dw_stream), "z free");
       z_free_recorded = true;
     }
   };
-  // --defer-big-dw (A/B switch, off): the biggest layer's weight-gradient GEMM (a persistent one-workgroup-per-CU launch of 200+ us
-  // that needs nothing the rest of the backward produces) issued LAST, so that the bottom MLP's backward chain and the table update --
-  // which run 5-10x slower beside it than alone -- finish before it takes the chip.  Measured in round 4 and kept off: the layer's
-  // data- and weight-gradient GEMMs overlap each other better than they run apart -- 1.228 vs 1.190 ms at 4096 samples, 2.224 vs
-  // 2.155 at 8192, 8.02 vs 7.87 at 32768, MLPerf shape 1.337 vs 1.273.
-  const int defer_layer = defer_big_dw_layer();
-  Linear* deferred = nullptr;
-  bottom_bwd_on_stream = false;
-  join_top_update();
+  bwd_alltoall_issued = false;
   for (GradBucket& b : grad_buckets) b.issued = b.inline_issued = false;
-  const int dw_chunks = (defer_layer < 0 && !config.big_dw_mode) ? big_dw_chunks_now() : 1;
+  const int dw_chunks = big_dw_chunks_now();
   // the biggest layer with the bucketed all-reduce: data gradient, then its weight gradient in row blocks, a bucket behind each
   auto chunked_big_backward = [&](Linear* up, int l) {
     // (dy is final here: the weight-gradient stream forks in FRONT of the data gradient, as the library's own fork does, and the GEMMs of
@@ -2802,30 +2677,21 @@ void FFModel::backward(int _seq_length) {
       GradBucket& b = grad_buckets[k];
       if (b.chunk_layer != l) continue;
       up->backward_dw_rows(*this, b.chunk_index * per, per);
-      issue_one_bucket(k, false);
+      if (!buckets_held()) issue_one_bucket(k, false);      // (held: issue_grad_buckets sends it once the backward all-to-all is enqueued)
     }
     up->db_from_upper = false;
   };
   for (int l = first; l >= 0; l--) {
-    if (bucketed_now() && defer_layer < 0 && !config.big_dw_mode) issue_grad_buckets(l);     // the buckets every layer above l has completed
+    if (bucketed_now()) issue_grad_buckets(l);     // the buckets every layer above l has completed
     if (l == grad_attach_layer) {
       check(api->ffh_event_record_with_next_linear_bwd(ctx, ev_grad_ready), "attach event");
       grad_ready_attached = true;
     }
     Linear* up = layers[l]->op_type == OP_LINEAR ? static_cast<Linear*>(layers[l]) : nullptr;
-    if (layers[l]->op_type == OP_DOT_INTERACTION && !emb_sorted_early && early_sort_possible(3)) {
-      // the index-only sort beside the interaction's backward -- an HBM-bound kernel, the one stretch of the backward in which no
-      // persistent GEMM is meant to be on the chip (an index-heavy kernel runs ~8x slower beside one)
-      check(api->ffh_event_record(ctx, layer_events[l], stream), "event");
-      check(api->ffh_stream_wait_event(ctx, side_stream, layer_events[l]), "event");
-      launch_shard_groups(this, kSortOnly, side_stream, ctx);
-      emb_sorted_early = true;
-    }
     if (up && up->dx_map && !use_workers()) {
       const bool attach = l == scatter_attach_layer;
       check(api->ffh_linear_bwd_set_dx_scatter(ctx, up->dx_map, up->in_channels, attach ? ev_grad_ready : nullptr), "dx scatter");
-      if (l == defer_layer) { up->backward_part(*this, 1); deferred = up; }
-      else if (dw_chunks > 1 && l == big_dw_layer) { chunked_big_backward(up, l); mark_z_free(l); }
+      if (dw_chunks > 1 && l == big_dw_layer) { chunked_big_backward(up, l); mark_z_free(l); }
       else { up->backward(*this); mark_z_free(l); }
       if (api->ffh_linear_dx_scatter_used(ctx)) {
         up->dx_map_concat->bwd_done = true;                    // its pack kernel is not needed this step
@@ -2845,13 +2711,8 @@ void FFModel::backward(int _seq_length) {
     if (up && !up->chain_bwd.empty() && mlp_chain_usable(local_rows(up->outputs[0], this), false)) {
       // the chain this layer tops: one call for all its members (their indices are l - n + 1 .. l)
       const int n = (int)up->chain_bwd.size();
-      // (split update: what the compute stream holds in front of the bottom MLP's chain -- every top layer's own-stream work -- is what
-      //  the top part's optimizer launch must follow)
-      const bool bottom_chain = l - n + 1 == 0 && bottom_floats > 0 && !embeddings.empty() && l + 1 == embeddings.front()->layer_index;     // the whole bottom MLP
-      if (bottom_chain) check(api->ffh_event_record(ctx, ev_top_mark, stream), "event");
       const int crc = run_chain_bwd(up);
       if (crc == FFH_OK) {
-        if (bottom_chain) bottom_bwd_on_stream = true;
         // a lower member completes the embedding output gradients: "gradients ready" behind the whole call (the chain's weight-gradient
         // kernel still reads the buffer the next gather overwrites).  (l itself: attached above, recorded by the call.)
         if (grad_attach_layer > l - n && grad_attach_layer < l && !grad_ready_attached) {
@@ -2871,30 +2732,18 @@ void FFModel::backward(int _seq_length) {
       if (prc != FFH_ERR_UNSUPPORTED) check(prc, up->name);
       up->pair_lower = nullptr;                                // not a shape the pair launch serves: the ordinary calls from now on
     }
-    if (l == defer_layer && up) { up->backward_part(*this, 1); deferred = up; continue; }
-    if (up && config.big_dw_mode && l == big_dw_layer && defer_layer < 0 && !up->discard_input_grad && !(up->activation == AC_MODE_RELU && !up->dy_premasked) &&
-        up->activation != AC_MODE_SIGMOID && !config.profiling && !use_workers() && !config.deterministic) {
-      // A/B (--big-dw-mode): 1 = the biggest layer's dW forked BEHIND its dX (the two persistent GEMMs do not share the chip);
-      //                      2 = dW first, then dX, both on the compute stream
-      if (config.big_dw_mode == 1) { up->backward_part(*this, 1); up->backward_part(*this, 2); }
-      else { up->backward_part(*this, 3); up->backward_part(*this, 1); }
-      mark_z_free(l);
-      continue;
-    }
     if (up && dw_chunks > 1 && l == big_dw_layer) { chunked_big_backward(up, l); mark_z_free(l); continue; }
     layers[l]->backward(*this);
     mark_z_free(l);
   }
-  if (deferred) {
-    deferred->backward_part(*this, 2);
-    mark_z_free(deferred->layer_index);
-  }
-  if (bucketed_now()) issue_grad_buckets(-1);
   if (emb_update_pending) {
     // exchange of the row gradients + fused sparse update on the side stream, beside the bottom-MLP backward
     issue_embedding_update_on_side_stream();
     emb_update_pending = false;
   }
+  // what is left (a shared channel: the buckets held until the exchange above was enqueued; a model whose backward all-to-all runs in update():
+  // released here all the same -- update() waits for every bucket)
+  if (bucketed_now()) { bwd_alltoall_issued = true; issue_grad_buckets(-1); }
 }
 
 void FFModel::update() {
@@ -2906,35 +2755,13 @@ void FFModel::update() {
   if (!sgd && !adam) die("update(): unknown optimizer");
   // every rank must issue its collectives in the same order: the side thread's all-to-all (backward) first
   if (side_worker) side_worker->drain();
-  if (dw_forked && !dw_worker && !api->ffh_second_stream_used(ctx, 1) && !dw_stream_used_directly) { dw_forked = false; dw1_used = dw2_used = false; }   // the library kept everything on `stream`
+  if (dw_forked && !dw_worker && !api->ffh_second_stream_used(ctx, 1) && !dw_stream_used_directly) { dw_forked = false; dw1_used = false; }   // the library kept everything on `stream`
   dw_stream_used_directly = false;
-  // Split update (one GPU, the bottom MLP's backward ran as a chain on `stream`, every forked weight gradient on dw_stream): the top
-  // part of the slab is updated ON dw_stream behind the last weight gradient, the bottom part on `stream` without joining it -- the next
-  // step's bottom-MLP forward then runs beside the biggest layer's weight gradient's tail and the 14 MB optimizer sweep instead of
-  // behind them (4096 samples: ~25 us of the 113 us between the end of that GEMM and the next top-MLP forward).  While a capture is
-  // open the join happens right here (a replayed graph is a barrier anyway).
-  const bool split_now = config.split_update && bottom_floats > 0 && bottom_bwd_on_stream && !exchange && dw_forked && dw1_used && !dw2_used && !dw_worker &&
-                         !config.profiling && (adam || sgd->momentum == 0.0);
   if (dw_forked) {   // the weight-gradient GEMMs ran on their own stream: join before the gradients are consumed
     if (dw_worker) { dw_worker->drain(); dw1_used = true; }
-    if (dw1_used && split_now) {
-      const size_t top = mlp_count - bottom_floats;
-      check(api->ffh_stream_wait_event(ctx, dw_stream, ev_top_mark), "split update");
-      if (adam) check(api->ffh_adam_update(ctx, mlp_weights + bottom_floats, mlp_grads + bottom_floats, adam->mlp_m + bottom_floats, adam->mlp_v + bottom_floats, (int64_t)top,
-                                           (float)adam->alpha_t, (float)adam->beta1, (float)adam->beta2, (float)adam->weight_decay, (float)adam->epsilon, FFH_OPT_ZERO_GRAD, dw_stream), "adam_update (top part)");
-      else check(api->ffh_sgd_update_ex(ctx, mlp_weights + bottom_floats, mlp_grads + bottom_floats, nullptr, (int64_t)top, (float)sgd->lr, (float)sgd->weight_decay, 0.0f, 0,
-                                        FFH_OPT_ZERO_GRAD, dw_stream), "sgd_update (top part)");
-      check(api->ffh_event_record(ctx, ev_top_opt_done, dw_stream), "split update");
-      check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");
-      top_opt_pending = true;
-      n_split_updates++;
-    } else if (dw1_used) {
+    if (dw1_used) {
       check(api->ffh_event_record(ctx, ev_dw_done, dw_stream), "join dw");
       check(api->ffh_stream_wait_event(ctx, stream, ev_dw_done), "join dw");
-    }
-    if (dw2_used) {
-      check(api->ffh_event_record(ctx, ev_dw2_done, dw_stream2), "join dw");
-      check(api->ffh_stream_wait_event(ctx, stream, ev_dw2_done), "join dw");
     }
     // the next gather (side stream) overwrites embedding outputs that alias the Concat output -- the x operand of the first
     // top-MLP layer, which a forked dW GEMM may still be reading: write-after-read across streams
@@ -2942,10 +2769,9 @@ void FFModel::update() {
       if (z_free_recorded) check(api->ffh_stream_wait_event(ctx, side_stream, ev_z_free), "join dw (embedding stream)");
       else {
         if (dw1_used) check(api->ffh_stream_wait_event(ctx, side_stream, ev_dw_done), "join dw (embedding stream)");
-        if (dw2_used) check(api->ffh_stream_wait_event(ctx, side_stream, ev_dw2_done), "join dw (embedding stream)");
       }
     }
-    dw1_used = dw2_used = false;
+    dw1_used = false;
     dw_forked = false;
   }
   // data-parallel MLP gradients: ONE bucket [ref: one ncclAllReduce per tensor, src/runtime/optimizer_kernel.cu:170-171].
@@ -2972,7 +2798,7 @@ void FFModel::update() {
   }
   // one launch over the whole MLP slab; it also clears the gradients it consumed, so the next zero_gradients()
   // has nothing to sweep [ref: one update task per parameter, src/runtime/optimizer.cc:93-189,256-330]
-  const size_t opt_count = split_now ? bottom_floats : mlp_count;      // (split: the rest is in flight on dw_stream)
+  const size_t opt_count = mlp_count;
   if (adam) {
     if (mlp_count) {
       check(api->ffh_adam_update(ctx, mlp_weights, mlp_grads, adam->mlp_m, adam->mlp_v, (int64_t)opt_count, (float)adam->alpha_t,
@@ -2988,7 +2814,6 @@ void FFModel::update() {
                                  0, FFH_OPT_ZERO_GRAD, stream), "sgd_update (MLP slab)");
     mlp_grads_clean = true;
   }
-  if (top_opt_pending && capturing_trace >= 0) join_top_update();
   if (fused_embedding_update()) {
     if (config.overlap_embedding) {
       // launched in backward() on the side stream.  Its only consumer, the next gather, runs on that same stream, and
@@ -3087,13 +2912,12 @@ void FFModel::end_trace(int trace_id) {
 }
 
 void FFModel::sync() {
-  join_top_update();
   if (dw_worker) dw_worker->drain();
   if (side_worker) side_worker->drain();
   check(api->ffh_stream_sync(ctx, stream), "sync");
   check(api->ffh_stream_sync(ctx, side_stream), "sync");
   check(api->ffh_stream_sync(ctx, dw_stream), "sync");
-  check(api->ffh_stream_sync(ctx, dw_stream2), "sync");
+  check(api->ffh_stream_sync(ctx, ar_stream), "sync");
 }
 
 PerfMetrics FFModel::get_perf_metrics() {

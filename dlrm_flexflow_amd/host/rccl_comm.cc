@@ -186,7 +186,8 @@ void flexflow_rccl_comm_calls(const ffcomm* comm, int64_t* a2a, int64_t* ar) {
 
 // A second communicator over the same ranks for the gradient buckets, so that RCCL does not order them against the all-to-alls of the
 // first (it runs one communicator's collectives in issue order whatever streams they are on).  COLLECTIVE: every rank makes the call.
-// Opt-in (the launchers' --allreduce-own-channel): no multi-GPU box was available to measure it on.  Returns 0 when the channel
+// The launchers' default where every rank's RCCL has ncclCommSplit (see flexflow_rccl_has_comm_split): the order problem it removes is structural,
+// not a tuning question; --allreduce-shared-channel turns it off for A/B runs.  Returns 0 when the channel
 // exists afterwards, 1 when the library has no ncclCommSplit or it failed (the buckets then share the first communicator).
 int flexflow_rccl_comm_enable_bucket_channel(ffcomm* comm) {
   Comm* c = comm ? (Comm*)comm->user : nullptr;
@@ -195,7 +196,19 @@ int flexflow_rccl_comm_enable_bucket_channel(ffcomm* comm) {
   if (!g_api.CommSplit) { g_err = "librccl has no ncclCommSplit"; return 1; }
   const int e = g_api.CommSplit(c->comm, 0, c->rank, &c->comm2, nullptr);
   if (e != kNcclSuccess) { c->comm2 = nullptr; return fail(e, "ncclCommSplit"); }
+  comm->bucket_channel_own = 1;
   return 0;
+}
+// 0 when this process's RCCL has ncclCommSplit.  LOCAL: the launchers agree on it over all ranks BEFORE any of them makes the collective
+// call above (a rank without the symbol would return at once and leave the others inside ncclCommSplit).
+int flexflow_rccl_has_comm_split(const char* lib_path) { return (load(lib_path) && g_api.CommSplit) ? 0 : 1; }
+// Back to the shared channel (local; every rank calls it when the ranks did not ALL get their second communicator: a rank with comm2 and
+// a rank without would issue the same bucket on different communicators and hang).
+void flexflow_rccl_comm_disable_bucket_channel(ffcomm* comm) {
+  Comm* c = comm ? (Comm*)comm->user : nullptr;
+  if (!c) return;
+  if (c->comm2) { g_api.CommDestroy(c->comm2); c->comm2 = nullptr; }
+  comm->bucket_channel_own = 0;
 }
 
 int64_t flexflow_rccl_comm_bucket_calls(const ffcomm* comm, int* own_channel) {

@@ -23,8 +23,11 @@ void flexflow_rccl_comm_calls(const ffcomm* comm, int64_t* alltoall, int64_t* al
 void flexflow_rccl_comm_calls2(const ffcomm* comm, int64_t* reduce_scatter, int64_t* allgather);
 /* gradient buckets (ffcomm.allreduce_bucket_sum_f32): calls served; *own_channel = 1 when they run on a second communicator */
 int64_t flexflow_rccl_comm_bucket_calls(const ffcomm* comm, int* own_channel);
-/* COLLECTIVE, opt-in: a second communicator (ncclCommSplit) for the gradient buckets; 0 = it exists, 1 = not available (they share the first) */
+/* COLLECTIVE: a second communicator (ncclCommSplit) for the gradient buckets; 0 = it exists, 1 = not available (they share the first) */
 int  flexflow_rccl_comm_enable_bucket_channel(ffcomm* comm);
+/* LOCAL: 0 = this process's RCCL has ncclCommSplit (agree over the ranks before the collective call above); undo after a partial failure */
+int  flexflow_rccl_has_comm_split(const char* lib_path);
+void flexflow_rccl_comm_disable_bucket_channel(ffcomm* comm);
 #ifdef __cplusplus
 }
 #endif

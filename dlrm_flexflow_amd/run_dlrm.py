@@ -91,7 +91,7 @@ def rank_main(argv) -> int:
             comm = TorchComm(on_gpu=True)
             if not torch_coll:
                 try:
-                    comm = RcclComm(comm, own_bucket_channel="--allreduce-own-channel" in sys.argv)
+                    comm = RcclComm(comm, own_bucket_channel="--allreduce-shared-channel" not in sys.argv)
                 except Exception as e:  # noqa: BLE001  every rank raises together: all keep the torch callbacks
                     if rank == 0:
                         print("run_dlrm: direct RCCL not used:", e, file=sys.stderr, flush=True)

@@ -458,7 +458,7 @@ def _digest_of_touched_rows(hip, app, steps_ids=None):
 
 
 @pytest.mark.timeout(3000)
-@pytest.mark.parametrize("full_size", [False, True, 4096])
+@pytest.mark.parametrize("full_size", [False, True, 4096, "8192-mlperf"])
 def test_benched_step_overlapped_equals_serial_bit_for_bit_under_deterministic(hip, full_size):
     """The composition the per-layer tests cannot see -- aliasing into the Concat buffer, premasked dy across layers, forked weight
     gradients, the early sort, the next gather beside the last weight-gradient GEMM -- at the size the driver times: three steps
@@ -470,15 +470,25 @@ def test_benched_step_overlapped_equals_serial_bit_for_bit_under_deterministic(h
     # (round 5) 4096: the per-rank batch of the 8-GPU job, where the first top layer's data gradient runs as stream-K WITH FIX-UP -- the
     # form deterministic mode now takes (its parts are added in k order whoever arrives last): the cross-workgroup slot / counter protocol
     # runs beside the other streams' kernels here
-    batch = 4096 if full_size == 4096 else 32768
+    # (round 6) 4096 and the MLPerf shape at 8192 samples (BASELINE configs[3] per GPU): the bottom MLP's backward runs as the CHAIN launches there
+    # (mlp_chain_dx_kernel / mlp_chain_dw_kernel beside the biggest weight-gradient GEMM and the table update) -- deterministic mode now takes
+    # them (the splits of a weight-gradient block are added in split order by a second launch), and the test asserts that it did
+    mlperf = full_size == "8192-mlperf"
+    batch = 4096 if full_size == 4096 else (8192 if mlperf else 32768)
     rows = TERABYTE_ROWS if full_size is True else [min(r, 100000) for r in TERABYTE_ROWS]
+    args = TB_ARGS(rows, batch)
+    if mlperf:
+        args = ["-b", str(batch), "--arch-sparse-feature-size", "128", "--arch-embedding-size", "-".join(str(r) for r in rows), "--arch-mlp-bot", "13-512-256-128",
+                "--arch-mlp-top", "479-1024-1024-512-256-1", "--arch-interaction-op", "dot-tril", "--data-size", str(batch)]
     runs = []
     for flags in ([], ["--no-overlap", "--no-early-sort", "--serial-dw"]):
-        app = ffmodel.DLRM(["--backend", HIP, "--deterministic"] + TB_ARGS(rows, batch) + flags)
+        app = ffmodel.DLRM(["--backend", HIP, "--deterministic"] + args + flags)
         app.warmup()
         app.train_steps(3, trace=False)
         app.model.sync()
         m = app.model
+        if batch <= 8192:
+            assert m.counter("mlp_chain_bwd_calls") >= 3, "the chain launches did not run under --deterministic"
         rec = {f"{m.layer_name(li)}/{wi}": m.parameter(li, wi).get_weights() for li in range(m.num_layers) if m.layer_name(li).startswith("Dense")
                for wi in range(m.layer_num_weights(li))}
         rec["pred"] = m.layer_output(m.num_layers - 1).get()

@@ -155,7 +155,8 @@ def test_mlp_chain_backward_vs_oracle_per_layer(hip, oracle, widths, acts, B, pr
 
 def test_mlp_chain_refuses_what_it_does_not_serve(hip):
     """Nothing launched, FFH_ERR_UNSUPPORTED / BAD_ARG: widths beyond 512, widths that do not chain, an inner sigmoid in the backward,
-    deterministic mode (the weight gradients meet by atomics)."""
+    deterministic mode on a stream without scratch (round 6: with the stream's scratch the weight-gradient blocks meet there and are added
+    in split order -- tests/test_gpu_round6.py)."""
     B = 64
     t = lambda *s: torch.zeros(*s, device=DEV)
     mk = lambda i, o, act=RELU: dict(w=t(o, i), y=t(B, o), dy=t(B, o), dw=t(o, i), db=t(o), in_dim=i, out_dim=o, activation=act)
@@ -163,11 +164,17 @@ def test_mlp_chain_refuses_what_it_does_not_serve(hip):
     assert hip.lib.ffh_mlp_chain_fwd(hip.ctx, capi.ptr(x), 1024, hip.chain_layers([mk(1024, 64), mk(64, 16)]), 2, B, None) == capi.FFH_ERR_BAD_ARG
     assert hip.lib.ffh_mlp_chain_fwd(hip.ctx, capi.ptr(x), 64, hip.chain_layers([mk(64, 32), mk(48, 16)]), 2, B, None) == capi.FFH_ERR_BAD_ARG
     assert hip.lib.ffh_mlp_chain_bwd(hip.ctx, capi.ptr(x), 64, None, 64, hip.chain_layers([mk(64, 32, SIG), mk(32, 16)]), 2, B, 0, None) == capi.FFH_ERR_UNSUPPORTED
+    import ctypes
+    bare = ctypes.c_void_p()
+    hip.check(hip.lib.ffh_stream_create(hip.ctx, ctypes.byref(bare)), "stream")          # no ffh_ctx_reserve_scratch for this one
     hip.check(hip.lib.ffh_ctx_set_deterministic(hip.ctx, 1), "deterministic")
     try:
-        assert hip.lib.ffh_mlp_chain_bwd(hip.ctx, capi.ptr(x), 64, None, 64, hip.chain_layers([mk(64, 32), mk(32, 16)]), 2, B, 0, None) == capi.FFH_ERR_UNSUPPORTED
+        assert hip.lib.ffh_mlp_chain_bwd(hip.ctx, capi.ptr(x), 64, None, 64, hip.chain_layers([mk(64, 32), mk(32, 16)]), 2, B, 0, bare) == capi.FFH_ERR_UNSUPPORTED
+        assert hip.lib.ffh_mlp_chain_bwd(hip.ctx, capi.ptr(x), 64, None, 64, hip.chain_layers([mk(64, 32), mk(32, 16)]), 2, B, 0, None) == 0
     finally:
         hip.check(hip.lib.ffh_ctx_set_deterministic(hip.ctx, 0), "deterministic")
+        torch.cuda.synchronize()
+        hip.check(hip.lib.ffh_stream_destroy(hip.ctx, bare), "stream destroy")
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -360,33 +367,6 @@ def test_raw_c_abi_call_with_a_padded_reduction_depth_takes_the_fast_path(hip, o
     assert not dwn[:, IN:].any() and not dxn[:, IN:].any()          # the pads stay exact zeros
 
 
-@pytest.mark.timeout(900)
-def test_split_slab_update_equals_the_single_launch(hip):
-    """One GPU, Terabyte shape at 4096 samples: the slab optimizer as two launches (the bottom MLP's parameters on the compute stream
-    behind its chain backward, the rest on the weight-gradient stream behind the last weight gradient; the next forward's first
-    top layer waits for the latter) against the single launch behind the join -- same arithmetic per element, so the weights after four
-    eager steps agree to the noise of the weight gradients' atomics; the split really ran; replayed steps (a capture closes the fork
-    inside update()) agree as well."""
-    import dlrm_helpers as H
-    from dlrm_flexflow_amd import ffmodel
-    rows = "-".join(["2000"] * 26)
-    args = ["--backend", capi.HIP_LIB_PATH, "-b", "4096", "--arch-sparse-feature-size", "128", "--arch-embedding-size", rows,
-            "--arch-mlp-bot", "13-512-256-128", "--arch-mlp-top", "3456-1024-1024-512-256-1", "--data-size", "4096"]
-    outs = []
-    for extra, trace in ((["--split-update"], False), (["--no-split-update"], False), (["--split-update"], True)):
-        app = ffmodel.DLRM(args + extra)
-        app.warmup(); app.train_steps(4, trace=trace); app.model.sync()
-        m = app.model
-        rec = {f"{l}/{w}": m.parameter(l, w).get_weights() for l in range(m.num_layers) for w in range(m.layer_num_weights(l))}
-        rec["pred"] = m.layer_output(m.num_layers - 1).get()
-        outs.append((rec, m.counter("split_updates")))
-        app.close()
-    assert outs[0][1] >= 4 and outs[1][1] == 0, (outs[0][1], outs[1][1])
-    for k in outs[0][0]:
-        np.testing.assert_allclose(outs[0][0][k], outs[1][0][k], rtol=2e-5, atol=2e-6, err_msg=f"split vs single: {k}")
-        np.testing.assert_allclose(outs[2][0][k], outs[1][0][k], rtol=2e-5, atol=2e-6, err_msg=f"replayed vs single: {k}")
-
-
 # ---------------------------------------------------------------------------------------------------------------------------
 # the bucket form of the fused table update (ABI 13 shows the route): one stable pass on the top id bits, the rest of the order
 # made per tile inside the apply launch -- the same canonical order, so bit for bit the oracle's restatement of zero_grad +
@@ -514,27 +494,6 @@ def test_fused_update_routes(hip):
         hip.check(hip.lib.ffh_embedding_bwd_sgd_fused_multi(hip.ctx, arr, 1, 1, D, B, capi.AGGR_MODE_SUM, 0.1, None), "fused")
         torch.cuda.synchronize()
         assert _emb_route(hip) == want, (B, rows, _emb_route(hip), want)
-
-
-def test_sort_placement_at_the_interaction_backward_same_bits_on_gpu():
-    """--sort-at-interaction-backward on the HIP library (the bucket form's sort phase issued beside the dot interaction's backward on the
-    side stream, the apply phase later): the default placement's bits, eager and replayed."""
-    from dlrm_flexflow_amd import ffmodel
-    base = ["--backend", capi.HIP_LIB_PATH, "-b", "4096", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "3000-700000-11-40000",
-            "--arch-mlp-bot", "13-64-16", "--arch-mlp-top", "26-32-1", "--data-size", "4096", "--arch-interaction-op", "dot-tril", "--deterministic"]
-    out = []
-    for extra, trace in (([], False), (["--sort-at-interaction-backward"], False), (["--sort-at-interaction-backward"], True),
-                         (["--sort-before-bottom-backward"], False), (["--sort-before-bottom-backward"], True)):
-        app = ffmodel.DLRM(base + extra)
-        app.warmup(); app.train_steps(3, trace=trace); app.model.sync()
-        m = app.model
-        o = {f"{l}/{i}": m.parameter(l, i).get_weights() for l in range(m.num_layers) for i in range(m.layer_num_weights(l))}
-        o["pred"] = m.layer_output(m.num_layers - 1).get()
-        out.append(o)
-        app.close()
-    for other in out[1:]:
-        for k in out[0]:
-            assert np.array_equal(out[0][k], other[k]), k
 
 
 @pytest.mark.parametrize("seed", range(12))

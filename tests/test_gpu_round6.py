@@ -338,3 +338,64 @@ def test_split_mode_proper_leaves_small_gemms_to_the_fp32_kernels(hip):
         finally:
             assert hip.lib.ffh_ctx_set_math_mode(hip.ctx, 0) == 0
         torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("widths,B", [((13, 512, 256, 128), 4096), ((13, 512, 256, 128), 8192), ((432, 512, 256), 2048), ((64, 512, 256, 64, 16), 2048), ((16, 48, 20), 77)])
+def test_mlp_chain_backward_in_deterministic_mode_is_bit_reproducible(hip, oracle, widths, B):
+    """ffh_mlp_chain_bwd under ffh_ctx_set_deterministic (round 6: the batch splits of a 64 x 64 weight-gradient block meet in the stream's
+    scratch and a second launch adds them in split order -- no floating-point atomics [ref: the per-layer path it replaces,
+    src/ops/linear.cu:610-660]): six launches on the same inputs give the same bits in every dW / db / dy / dx, the route says "ordered", and
+    the values agree with the atomic form of the same kernels to 1e-5 of the term mass."""
+    import torch
+    dev = "cuda:0"
+    RELU = capi.AC_MODE_RELU
+    rng = np.random.default_rng(sum(widths) + B)
+    n = len(widths) - 1
+    ws = [(rng.uniform(-1, 1, (widths[l + 1], widths[l])) / np.sqrt(widths[l])).astype(np.float32) for l in range(n)]
+    bs = [rng.uniform(-0.5, 0.5, widths[l + 1]).astype(np.float32) for l in range(n)]
+    x = np.maximum(rng.uniform(-1, 1, (B, widths[0])), 0).astype(np.float32)
+    ys, cur = [], x
+    for l in range(n):
+        cur = oracle.linear_fwd(cur, ws[l], bs[l], RELU)
+        ys.append(cur)
+    g_top = (rng.uniform(-1, 1, (B, widths[-1])) / B).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    xd, wd, yd = t(x), [t(w) for w in ws], [t(y) for y in ys]
+
+    def launch():
+        dyd = [torch.full((B, widths[l + 1]), 5.0, device=dev) for l in range(n)]
+        dyd[-1] = t(g_top)
+        dwd = [torch.zeros(widths[l + 1], widths[l], device=dev) for l in range(n)]
+        dbd = [torch.zeros(widths[l + 1], device=dev) for l in range(n)]
+        dxd = torch.zeros(B, widths[0], device=dev) if widths[0] % 4 == 0 else None
+        layers = hip.chain_layers([dict(w=wd[l], y=yd[l], dy=dyd[l], dw=dwd[l], db=dbd[l], in_dim=widths[l], out_dim=widths[l + 1], activation=RELU) for l in range(n)])
+        flags = capi.LINEAR_DX_OVERWRITE if dxd is not None else 0
+        hip.check(hip.lib.ffh_mlp_chain_bwd(hip.ctx, capi.ptr(xd), widths[0], capi.ptr(dxd), widths[0], layers, n, B, flags, None), "chain bwd")
+        route = hip.lib.ffh_linear_last_route(hip.ctx).decode()
+        torch.cuda.synchronize()
+        out = {f"dw{l}": dwd[l].cpu().numpy() for l in range(n)}
+        out.update({f"db{l}": dbd[l].cpu().numpy() for l in range(n)})
+        out.update({f"dy{l}": dyd[l].cpu().numpy() for l in range(n)})
+        if dxd is not None:
+            out["dx"] = dxd.cpu().numpy()
+        return out, route
+
+    ref, r0 = launch()
+    assert "ordered" not in r0 and "mlp_chain_dw" in r0, r0
+    hip.check(hip.lib.ffh_ctx_set_deterministic(hip.ctx, 1), "deterministic")
+    try:
+        runs = [launch() for _ in range(6)]
+    finally:
+        hip.check(hip.lib.ffh_ctx_set_deterministic(hip.ctx, 0), "deterministic")
+    for out, route in runs:
+        assert "mlp_chain_dw" in route and "|ordered" in route and "mlp_chain_dx" in route, route
+        for k in out:
+            assert out[k].tobytes() == runs[0][0][k].tobytes(), f"{k}: two deterministic launches differ"
+    det = runs[0][0]
+    for l in range(n):
+        a = np.abs(det[f"dy{l}"]).astype(np.float64)
+        xin = np.abs(x if l == 0 else ys[l - 1]).astype(np.float64)
+        assert np.array_equal(det[f"dy{l}"], ref[f"dy{l}"])                            # the data-gradient chain has no atomics in either mode
+        assert np.all(np.abs(det[f"dw{l}"].astype(np.float64) - ref[f"dw{l}"]) <= 1e-5 * (a.T @ xin) + 1e-6), f"dw{l}"
+        assert np.all(np.abs(det[f"db{l}"].astype(np.float64) - ref[f"db{l}"]) <= 1e-5 * a.sum(0) + 1e-6), f"db{l}"

@@ -222,20 +222,6 @@ def test_padded_reduction_depth_is_invisible(opt):
             assert outs[0][k].shape == outs[1][k].shape and outs[0][k].tobytes() == outs[1][k].tobytes(), k
 
 
-def test_deferred_big_weight_gradient_is_only_a_schedule():
-    """--defer-big-dw (the biggest layer's weight-gradient GEMM issued after the rest of the backward; default by per-GPU batch):
-    same arithmetic, another launch order -- on the sequential oracle backend the three-step trajectory keeps its bits, also
-    behind the exchange (one gloo-less rank, --force-exchange is covered by the GPU twin)."""
-    outs = []
-    for flags in (["--no-defer-big-dw"], ["--defer-big-dw"]):
-        m, h = H.build_golden_dlrm(H.oracle_backend(), overlap=True, extra_argv=flags)
-        outs.append(H.run_steps(m, h, 3))
-        m.close()
-    for step in range(3):
-        for k in outs[0][step]:
-            assert outs[0][step][k].tobytes() == outs[1][step][k].tobytes(), (step, k)
-
-
 @pytest.mark.parametrize("opt", ["sgd", "adam"])
 def test_bias_gradient_from_the_upper_layers_data_gradient_is_only_a_placement(opt):
     adam = H.ADAM_HP if opt == "adam" else None

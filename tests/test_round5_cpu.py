@@ -179,14 +179,14 @@ def test_fast_path_padding_rule_is_the_same_in_both_libraries(oracle):
 # ---------------------------------------------------------------------------------------------------------------------------
 # placements and switches added late in round 5: same bits whatever the order of issue
 def test_sort_placements_and_conversion_twins_do_not_change_the_bits():
-    """--sort-at-interaction-backward (the index-only sort of the table update issued beside the dot interaction's backward) against the
-    default placement and the other two; tensor-op mode with and without the twin-by-conversion behind an fp32-kernel layer.  The host
+    """--early-sort / --no-early-sort (the index-only sort of the table update issued behind the gather, or in front of the apply phase) against the
+    default placement by shape; tensor-op mode with and without the twin-by-conversion behind an fp32-kernel layer.  The host
     logic runs on the oracle backend: what is checked is the order / bookkeeping of the calls (a sort consumed twice or not at all
     fails loudly in the library: the one-shot contract of ffh_embedding_bwd_sort_multi)."""
     base = ["--backend", H.oracle_backend(), "-b", "2304", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "3000-70000-11",
             "--arch-mlp-bot", "13-64-16", "--arch-mlp-top", "22-32-1", "--data-size", "2304", "--arch-interaction-op", "dot-tril"]
     ref, _ = _run(base, 2)
-    for extra in (["--sort-at-interaction-backward"], ["--sort-before-bottom-backward"], ["--early-sort"], ["--sort-at-backward-start"], ["--no-early-sort"]):
+    for extra in (["--early-sort"], ["--no-early-sort"]):
         got, _ = _run(base + extra, 2)
         for k in ref:
             assert np.array_equal(ref[k], got[k]), (extra, k)

@@ -1,0 +1,95 @@
+"""Round 6, host logic on the CPU (oracle kernels, gloo): the order in which a step issues its collectives, by the kind of channel the
+transport gives the MLP-gradient buckets [ref: the reference issues one ncclAllReduce per parameter from that parameter's own update task,
+ordered by region dependences only: src/runtime/optimizer.cc:93-189, src/runtime/optimizer_kernel.cu:114-179].
+
+One RCCL communicator runs its collectives in ISSUE order whatever streams they are on.  With the buckets on the all-to-alls' communicator
+(ffcomm.bucket_channel_own == 0) a bucket issued before the step's backward all-to-all would put the exchange of the embedding gradients --
+and the table update and the next gather behind it -- behind a weight-gradient GEMM and its all-reduce; the model therefore holds the
+buckets until that all-to-all has been enqueued.  With a channel of their own (the launchers' default: ncclCommSplit, agreed by all ranks)
+every bucket goes out as soon as its layers have issued their backward.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import dlrm_helpers as H
+
+
+def _recording_comm(nonblocking, own):
+    import torch.distributed as dist
+    from dlrm_flexflow_amd.comm import TorchComm
+    from dlrm_flexflow_amd.ffmodel import ALLREDUCE_FN
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{32300 + os.getpid() % 1000}", rank=0, world_size=1)
+
+    class Recording(TorchComm):
+        def __init__(self):
+            super().__init__(on_gpu=False)
+            self.log = []
+            self._bk = ALLREDUCE_FN(self._bucket)
+            self.struct.allreduce_bucket_sum_f32 = self._bk
+            self.struct.nonblocking = nonblocking
+            self.struct.bucket_channel_own = own
+
+        def _alltoall(self, *a):
+            self.log.append("alltoall")
+            return super()._alltoall(*a)
+
+        def _allreduce(self, *a):
+            self.log.append("allreduce")
+            return super()._allreduce(*a)
+
+        def _bucket(self, user, buf, count, stream):
+            self.log.append("bucket")
+            return TorchComm._allreduce(self, user, buf, count, stream)
+
+    return Recording()
+
+
+@pytest.mark.parametrize("nonblocking", [0, 1])
+def test_buckets_wait_for_the_backward_alltoall_on_a_shared_channel_and_not_on_their_own(nonblocking):
+    """One gloo rank, exchange path forced, buckets forced on (tiny buckets, the biggest layer's weight gradient in two row blocks), a transport
+    that records its calls.  Per step [forward all-to-all ... backward all-to-all]: on a SHARED channel no bucket lies between the two and every
+    bucket follows the second; on a channel of their OWN at least one bucket (the top MLP's) precedes the backward all-to-all.  Same bits
+    either way and as without buckets."""
+    res = {}
+    for own in (0, 1):
+        comm = _recording_comm(nonblocking, own)
+        extra = ["--bucket-allreduce", "--allreduce-bucket-floats", "64", "--big-dw-chunks", "2", "--big-dw-min-weights", "1"]
+        m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True, extra_argv=extra)
+        nb = m.counter("allreduce_buckets")
+        assert nb >= 3 and m.counter("allreduce_bucket_channel_own") == own
+        comm.log.clear()
+        recs = H.run_steps(m, h, 3)
+        log = list(comm.log)
+        m.close()
+        res[own] = recs
+        # cut the log into steps at every forward all-to-all (the 1st, 3rd, 5th "alltoall")
+        a2a = [i for i, c in enumerate(log) if c == "alltoall"]
+        assert len(a2a) == 6, log
+        for s in range(3):
+            fwd, bwd = a2a[2 * s], a2a[2 * s + 1]
+            end = a2a[2 * s + 2] if s < 2 else len(log)
+            between, after = log[fwd + 1:bwd], log[bwd + 1:end]
+            assert between.count("bucket") + after.count("bucket") == nb, (own, s, log)
+            if own == 0:
+                assert "bucket" not in between, (s, log)                 # held until the exchange of the embedding gradients is enqueued
+            else:
+                assert "bucket" in between, (s, log)                     # the top MLP's buckets go out while its backward still runs
+    for sa, sb in zip(res[0], res[1]):
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), k
+
+
+def test_ffcomm_struct_layout_matches_the_header():
+    """ffmodel.FFComm (ctypes) against host/ffcomm.h: same fields in the same order (the field appended in round 6 included)."""
+    import re
+    from dlrm_flexflow_amd import ffmodel
+    src = open(os.path.join(H.ROOT if hasattr(H, "ROOT") else os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dlrm_flexflow_amd", "host", "ffcomm.h")).read()
+    body = src[src.index("typedef struct ffcomm {"):src.index("} ffcomm;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\(\*(\w+)\)\(|(?:int|void\*)\s+(\w+);", body)
+    header = [a or b for a, b in names]
+    assert header == [f[0] for f in ffmodel.FFComm._fields_], (header, [f[0] for f in ffmodel.FFComm._fields_])
