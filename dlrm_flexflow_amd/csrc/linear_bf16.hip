@@ -503,6 +503,192 @@ __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16x3_kernel(const GemmArg
     }
 }
 
+// =============================================================================================
+// The split-in-kernel form of the forward and data-gradient GEMMs with the ARITHMETIC of the LDS-DMA kernel (linear_x3_dma.hip): the same
+// instruction (v_mfma_f32_16x16x32_bf16: one instruction per 32-deep k-step and product), the same k-slot assignment (lane group q of a
+// fragment holds k = 8q .. 8q + 7 of the step), the same six products in the same order into the same accumulator, k-steps in ascending
+// order from a zero accumulator, the same epilogue operations -- so a layer gives the SAME BITS whether its operands come from producer-kept
+// images or are split here (tests/test_gpu_round6.py).  Same tiles, staging and LDS images as gemm_bf16x3_kernel above (A is k-contiguous
+// in both forms; B k-contiguous forward, rows-are-k in dX); the k-contiguous image's swizzle is the one that makes the 16-row fragments'
+// ds_read_b128 conflict-free.  The weight gradient keeps the kernel above: its k-slices meet by atomics, whose order is free anyway.
+// =============================================================================================
+__device__ __forceinline__ unsigned x3v_off_kc(int row, int chunk) { return (unsigned)(row * 64 + ((chunk ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3)) << 4)); }
+
+template <bool BKC, bool MASK_A = false, int BM = 128, int BN = 128, int WM = 64>
+__global__ __launch_bounds__(BM / WM * BN) void gemm_bf16x3_v2_kernel(const GemmArgs g) {
+  ffh_kernel_prio();
+  constexpr int BK = kX3BK, NT = BM / WM * BN;                  // one wave per WM x 64 of the tile
+  constexpr int NA = BM * 8 / NT, NB = BN * 8 / NT;             // float4 per thread per k-tile
+  constexpr int TM = WM / 16;
+  constexpr int PLANE_A = BM * BK * 2, PLANE_B = BN * BK * 2;   // bytes of one bf16 plane of an operand image
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bx, by;
+  {
+    const unsigned nbx = gridDim.x, nby = gridDim.y;
+    const unsigned total = nbx * nby;
+    const unsigned lin = blockIdx.y * nbx + blockIdx.x;
+    const unsigned xcd = lin & 7u, loc = lin >> 3;
+    const unsigned q = total >> 3, rem = total & 7u;
+    const unsigned nlin = xcd * q + (xcd < rem ? xcd : rem) + loc;
+    bx = (int)(nlin % nbx);
+    by = (int)(nlin / nbx);
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int ke = g.K;
+  const int nk = (ke + BK - 1) / BK;
+  const float* A = g.A;
+  const float* B = g.B;
+
+  float4 ra0[NA], rb0[NB];
+  const bool a_in = m0 + BM <= g.M, b_in = n0 + BN <= g.N;
+  auto load_tile = [&](int kt, auto fast_tag, float4 (&ra)[NA], float4 (&rb)[NB]) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+      const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i;
+      const int m = m0 + row, k = k0 + 4 * k4;
+      if (FAST) ra[i] = ld4u(A + (int64_t)m * g.sAm + k);
+      else ra[i] = load4_guard(A + (int64_t)m * g.sAm + k, m < g.M, k, ke, true);
+      if (MASK_A) {
+        float4 yv;
+        if (FAST) yv = ld4u(g.act_y + (int64_t)m * g.ld_act_y + k);
+        else yv = load4_guard(g.act_y + (int64_t)m * g.ld_act_y + k, m < g.M, k, ke, true);
+        ra[i].x = yv.x > 0.0f ? ra[i].x : 0.0f; ra[i].y = yv.y > 0.0f ? ra[i].y : 0.0f;
+        ra[i].z = yv.z > 0.0f ? ra[i].z : 0.0f; ra[i].w = yv.w > 0.0f ? ra[i].w : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      if (BKC) {
+        const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i;
+        const int n = n0 + row, k = k0 + 4 * k4;
+        if (FAST) rb[i] = ld4u(B + (int64_t)n * g.sBn + k);
+        else rb[i] = load4_guard(B + (int64_t)n * g.sBn + k, n < g.N, k, ke, true);
+      } else {
+        const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;
+        const int n = n0 + 4 * n4, k = k0 + kr;
+        if (FAST) rb[i] = ld4u(B + (int64_t)k * g.sBk + n);
+        else rb[i] = load4_guard(B + (int64_t)k * g.sBk + n, k < ke, n, g.N, true);
+      }
+    }
+  };
+  auto split_store = [&](const float4 (&ra)[NA], const float4 (&rb)[NB]) {
+    unsigned char* as = x3_smem;
+    unsigned char* bs = x3_smem + 3 * PLANE_A;
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+      uint2 p1, p2, p3;
+      split_bf16x3(ra[i], p1, p2, p3);
+      const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i;
+      const unsigned o = x3v_off_kc(row, k4 >> 1) + 8 * (k4 & 1);
+      *reinterpret_cast<uint2*>(as + o) = p1;
+      *reinterpret_cast<uint2*>(as + PLANE_A + o) = p2;
+      *reinterpret_cast<uint2*>(as + 2 * PLANE_A + o) = p3;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      uint2 p1, p2, p3;
+      split_bf16x3(rb[i], p1, p2, p3);
+      unsigned o;
+      if (BKC) { const int k4 = tid & 7, row = (tid >> 3) + (NT / 8) * i; o = x3v_off_kc(row, k4 >> 1) + 8 * (k4 & 1); }
+      else     { const int n4 = tid % (BN / 4), kr = tid / (BN / 4) + (4 * NT / BN) * i;  o = bf_off_kr<BN>(kr, n4 >> 1) + 8 * (n4 & 1); }
+      *reinterpret_cast<uint2*>(bs + o) = p1;
+      *reinterpret_cast<uint2*>(bs + PLANE_B + o) = p2;
+      *reinterpret_cast<uint2*>(bs + 2 * PLANE_B + o) = p3;
+    }
+  };
+
+  f32x4_t acc[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int wm0 = (wave / (BN / 64)) * WM, wn0 = (wave % (BN / 64)) * 64;
+  const int c = lane & 15, q = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  typedef s16x4_t __attribute__((address_space(3))) * lds_s16x4_p;
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  // fragment of the 16 rows (columns) starting at `o`: lane (c, q) gets k = 8q .. 8q + 7 of the 32-deep step for row (column) o + c
+  auto frag_kc = [&](const unsigned char* img, int o) -> bf16x8_t { return *reinterpret_cast<const bf16x8_t*>(img + x3v_off_kc(o + c, q)); };
+  auto frag_kr = [&](const unsigned char* img, int o) -> bf16x8_t {
+    const int ch = (o >> 3) + (tp >> 1), r1 = 8 * q + tq;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<BN>(r1, ch) + 8 * (tp & 1)));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(img + bf_off_kr<BN>(r1 + 4, ch) + 8 * (tp & 1)));
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto compute_tile = [&]() {
+    const unsigned char* as = x3_smem;
+    const unsigned char* bs = x3_smem + 3 * PLANE_A;
+    bf16x8_t b[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int p = 0; p < 3; p++) b[j][p] = BKC ? frag_kc(bs + p * PLANE_B, wn0 + 16 * j) : frag_kr(bs + p * PLANE_B, wn0 + 16 * j);
+#pragma unroll
+    for (int ih = 0; ih < TM; ih += 4) {                  // four row blocks at a time: 12 + 12 fragments live
+      bf16x8_t a[4][3];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) a[i][p] = frag_kc(as + p * PLANE_A, wm0 + 16 * (ih + i));
+      // the six products with i + j <= 4, small terms first -- per accumulator the order of linear_x3_dma.hip
+#pragma unroll
+      for (int pr = 0; pr < 6; pr++) {
+        const int pa = pr == 0 ? 2 : (pr == 1 || pr >= 4 ? 0 : 1), pb = pr == 1 ? 2 : (pr == 2 || pr == 4 ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)      // operands swapped: a lane then holds 4 consecutive columns of one row
+            acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][pb], a[i][pa], acc[ih + i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  const int nfull = (a_in && b_in) ? ke / BK : 0;
+  auto load_any = [&](int kt, float4 (&ra)[NA], float4 (&rb)[NB]) {
+    if (kt >= nk) return;
+    if (kt < nfull) load_tile(kt, std::true_type{}, ra, rb); else load_tile(kt, std::false_type{}, ra, rb);
+  };
+  load_any(0, ra0, rb0);
+  split_store(ra0, rb0);
+  __syncthreads();
+  for (int t = 0; t < nk; t++) {
+    load_any(t + 1, ra0, rb0);
+    compute_tile();
+    __syncthreads();
+    if (t + 1 < nk) { split_store(ra0, rb0); __syncthreads(); }
+  }
+
+  // lane (c, q) holds C[wm0 + 16 i + c][wn0 + 16 j + 4 q + {0..3}]
+  float* C = g.C;
+  const bool vec = (g.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (!g.mask || ((g.ldmask & 3) == 0 && (((uintptr_t)g.mask) & 15) == 0));
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    const int m = m0 + wm0 + 16 * i + c;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int n = n0 + wn0 + 16 * j + 4 * q;
+      if (n >= g.N) continue;
+      float* cp = C + (int64_t)m * g.ldc + n;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const bool whole = vec && n + 3 < g.N;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (n + e >= g.N) continue;
+        if (g.epi == EPI_STORE) v[e] = act_apply(v[e] + (g.bias ? g.bias[n + e] : 0.0f), g.act);
+        if (g.mask && !(g.mask[(int64_t)m * g.ldmask + n + e] > 0.0f)) v[e] = 0.0f;
+        if (g.epi == EPI_ADD) v[e] = v[e] + cp[e];
+        if (!whole) cp[e] = v[e];
+      }
+      if (whole) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
 // bf16-operand form of launch_gemm (tensor-op math mode): 128 x 128 tiles; EPI_ATOMIC splits K over workgroups
 template <bool AKC, bool BKC, bool MASK_A = false>
 int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
@@ -572,7 +758,21 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
       if (rc > 0) { if (g.db && !AKC && !BKC) g.db_done = 1; return FFH_OK; }
     }
   }
-  if (x3) { char tok[96]; snprintf(tok, sizeof tok, "%s|bf16x3_%s|splitk=%d", name, big ? "256x256" : "128x128", g.splitk); ffh_route_add(c, tok); }
+  if (x3) { char tok[96]; snprintf(tok, sizeof tok, "%s|bf16x3_%s|splitk=%d", name, (big && g.epi == EPI_ATOMIC) ? "256x256" : "128x128", g.splitk); ffh_route_add(c, tok); }
+  if constexpr (AKC) {
+    if (x3 && g.epi != EPI_ATOMIC) {      // forward / data gradient: the arithmetic of the LDS-DMA form, bit for bit (gemm_bf16x3_v2_kernel)
+      // (128 x 128 tiles only: with 128 x 64 per wave the 16 x 16 accumulators, two operands' fragments and the staging registers do not fit 256 VGPRs)
+      const int vx = (g.N + kBfBN - 1) / kBfBN, vy = (g.M + kBfBM - 1) / kBfBM;
+      if (vy > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm (bf16x3): grid too large");
+      auto kv = gemm_bf16x3_v2_kernel<BKC, MASK_A>;
+      static const bool okv = glds_set_lds(kv, kX3Lds);
+      if (!okv) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16x3): cannot reserve 48 KB of LDS");
+      hipLaunchKernelGGL(kv, dim3(vx, vy, 1), dim3(256), kX3Lds, as_stream(s), g);
+      hipError_t ev = hipGetLastError();
+      if (ev != hipSuccess) return ffh_fail_hip(c, ev, name);
+      return x3_image_of_c();
+    }
+  }
   if (x3 && big) {
     auto kern3b = gemm_bf16x3_kernel<AKC, BKC, MASK_A, 256, 256, 128>;
     constexpr int lds3b = 3 * (256 + 256) * kX3BK * 2;          // 96 KB: one 8-wave workgroup per CU

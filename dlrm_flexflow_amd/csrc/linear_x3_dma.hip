@@ -451,8 +451,10 @@ int launch_gemm_x3_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, co
   } else {
     if (g.epi != EPI_STORE && g.epi != EPI_ADD) return 0;
     if (form == BF16_FORM_FWD && g.epi != EPI_STORE) return 0;
-    static const int min_pct = FFH_LAB_INT("FFH_X3_DMA_MIN_TILES_PCT", 50);      // A/B switch: least number of tiles, in per cent of the CUs
-    if (tiles * 100 < (int64_t)c->num_cus * min_pct) return 0;   // fewer: linear_bf16.hip's 128 x 128 tiles fill the chip better
+    // at least one tile per CU: with 128 tiles (8192 x 3456 -> 1024 forward) this kernel takes 307-322 us where the split-in-kernel 128 x 128 form,
+    // whose 512 tiles fill the chip, takes 280; 8192 x 1024 -> 1024: 108-121 against 93 (profiles/r06_microbench_x3_images.txt)
+    static const int min_pct = FFH_LAB_INT("FFH_X3_DMA_MIN_TILES_PCT", 100);      // A/B switch: least number of tiles, in per cent of the CUs
+    if (tiles * 100 < (int64_t)c->num_cus * min_pct) return 0;
   }
   if (tiles * splitk >= (1LL << 31)) return 0;
   X3Args a{};

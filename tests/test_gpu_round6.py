@@ -144,7 +144,7 @@ def test_explicit_conversion_writes_the_image_bit_for_bit(hip):
     assert hip.lib.ffh_convert_f32_to_bf16x3(hip.ctx, t.data_ptr(), 1, 32, 32, None) != 0
 
 
-LAYERS = [(8192, 1024, 1024), (8224, 1024, 1056), (32768, 1024, 512), (8192, 1088, 1344)]
+LAYERS = [(16384, 1024, 1024), (16416, 1024, 1056), (32768, 1024, 512), (16384, 1088, 1344)]
 
 
 @pytest.mark.gpu
@@ -207,6 +207,10 @@ def test_x3_dma_gemms_from_images_meet_the_fp32_bound_and_write_images(hip_x3, B
         assert "x3_dma" not in rf0 + rb0 and "bf16x3" in rf0, (rf0, rb0)
         for k in exact:
             assert np.all(np.abs(got[k].astype(np.float64) - off[k]) <= 1e-5 * masses[k] + 1e-6), k
+        # forward and data gradient: the split-in-kernel form sums the same products in the same order (gemm_bf16x3_v2_kernel): the same BITS;
+        # the weight gradient's k-slices meet by atomics in both forms
+        assert got["y"].tobytes() == off["y"].tobytes(), "y: images on and off differ in bits"
+        assert got["dx"].tobytes() == off["dx"].tobytes(), "dx: images on and off differ in bits"
 
 
 @pytest.mark.gpu
@@ -216,7 +220,7 @@ def test_x3_dma_declines_what_it_cannot_serve_and_the_fallback_keeps_the_image(h
     stored (written by a pass over y)."""
     import torch
     hip, dev = hip_x3, "cuda:0"
-    for B, IN, OUT, xoff in ((512, 1024, 512, 0), (8192, 1000, 1024, 0), (8192, 1024, 1024, 8)):
+    for B, IN, OUT, xoff in ((512, 1024, 512, 0), (16384, 1000, 1024, 0), (16384, 1024, 1024, 8)):
         rng = np.random.default_rng(B + IN)
         x = rng.uniform(-1, 1, (B, IN)).astype(np.float32)
         w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
@@ -295,15 +299,15 @@ def test_gather_optimizers_and_the_narrow_backward_keep_their_images(hip_x3, ora
 @pytest.mark.timeout(1200)
 def test_dlrm_step_split_mode_images_on_equals_images_off_and_the_fp32_oracle(hip, oracle):
     """Whole model in split mode at the Terabyte widths (top 3456-1024-1024-512-256-1: every big layer reads images, the gather writes the image
-    of the Concat output, the optimizer the weights' image), batch 8192, rows capped: three steps with the images against the same run with
+    of the Concat output, the optimizer the weights' image), batch 16384, rows capped: three steps with the images against the same run with
     --no-bf16-twins (operands split inside the kernels) and against the oracle backend in its DEFAULT fp32 mode, at the tolerance of the fp32
     driver tests."""
     import dlrm_helpers as H  # noqa: F401
     from dlrm_flexflow_amd import ffmodel
     rows = "-".join(str(min(r, 20000)) for r in [39884406, 39043, 17289, 7420, 20263, 3, 7120, 1543, 63, 38532951, 2953546, 403346, 10, 2208, 11938, 155, 4, 976, 14,
                                                  39979771, 25641295, 39664984, 585935, 12972, 108, 36])
-    base = ["-b", "8192", "--arch-sparse-feature-size", "128", "--arch-embedding-size", rows, "--arch-mlp-bot", "13-512-256-128",
-            "--arch-mlp-top", "3456-1024-1024-512-256-1", "--data-size", "8192"]
+    base = ["-b", "16384", "--arch-sparse-feature-size", "128", "--arch-embedding-size", rows, "--arch-mlp-bot", "13-512-256-128",
+            "--arch-mlp-top", "3456-1024-1024-512-256-1", "--data-size", "16384"]
     out = {}
     for name, args in (("images", ["--backend", capi.HIP_LIB_PATH, "--fp32-split-bf16x3"]), ("in_kernel", ["--backend", capi.HIP_LIB_PATH, "--fp32-split-bf16x3", "--no-bf16-twins"]),
                        ("oracle", ["--backend", oracle.ORACLE_LIB])):
