@@ -578,6 +578,8 @@ def main():
     grads = (f"gradients all-reduced in {nbk} buckets issued from inside backward() ({' + '.join(str(v) for v in bucket_mb)} MB, "
              f"{'a communicator of their own (ncclCommSplit)' if app.model.counter('allreduce_bucket_channel_own') == 1 else 'the all-to-alls communicator: held until the backward all-to-all is enqueued'})"
              if bucketed else "1 all-reduce of the gradient slab")
+    grads += ("; each sum DIRECT: all-to-all of 1/N slices + local sum in rank order + all-gather (--direct-allreduce)" if app.model.counter("direct_allreduces") > 0
+              else "; each sum by the transport's all-reduce (ring)")
     app.close()
     if world > 1:
         barrier()                                  # the probes above are rank 0's: nobody tears the group down under them

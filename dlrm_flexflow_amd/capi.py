@@ -170,6 +170,7 @@ _SIGS = {
     "ffh_sgd_update_ex": (I, [P, P, P, P, L, F, F, F, I, I, P]),
     "ffh_adam_update": (I, [P, P, P, P, P, L, F, F, F, F, F, I, P]),
     "ffh_add_scaled": (I, [P, P, P, L, F, P]),
+    "ffh_sum_slices_f32": (I, [P, P, P, I, L, L, P]),
 }
 
 

@@ -357,6 +357,28 @@ __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ d, 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) d[i] = __fmaf_rn(src[i], scale, d[i]);
 }
 
+// dst[i] = sum over the slices, in slice order: one fixed fp32 chain per element (ffh_sum_slices_f32)
+__global__ __launch_bounds__(256) void sum_slices_kernel(float* __restrict__ d, const float* __restrict__ src, int nslices, int64_t n, int64_t stride, int vec) {
+  ffh_kernel_prio();
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += step * 4) {
+      float4 v = *reinterpret_cast<const float4*>(src + i);
+      for (int q = 1; q < nslices; q++) {
+        const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)q * stride + i);
+        v.x = v.x + t.x; v.y = v.y + t.y; v.z = v.z + t.z; v.w = v.w + t.w;
+      }
+      *reinterpret_cast<float4*>(d + i) = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+      float v = src[i];
+      for (int q = 1; q < nslices; q++) v = v + src[(int64_t)q * stride + i];
+      d[i] = v;
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -494,6 +516,15 @@ int ffh_add_scaled(ffh_ctx* c, float* d, const float* src, int64_t n, float scal
   if (n == 0) return FFH_OK;
   hipLaunchKernelGGL(add_scaled_kernel, dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), d, src, n, scale);
   FFH_LAUNCH_CHECK(c, "add_scaled_kernel");
+  return FFH_OK;
+}
+
+int ffh_sum_slices_f32(ffh_ctx* c, float* d, const float* src, int nslices, int64_t n, int64_t stride, ffh_stream s) {
+  FFH_REQUIRE(c, n >= 0 && nslices >= 1 && (nslices == 1 || stride >= n) && ((d && src) || n == 0), "sum_slices_f32: bad args");
+  if (n == 0) return FFH_OK;
+  const int vec = (n % 4 == 0) && (stride % 4 == 0) && al16(d) && al16(src);
+  hipLaunchKernelGGL(sum_slices_kernel, dim3(ffh_grid(vec ? n / 4 : n, 256)), dim3(256), 0, as_stream(s), d, src, nslices, n, stride, vec);
+  FFH_LAUNCH_CHECK(c, "sum_slices_kernel");
   return FFH_OK;
 }
 

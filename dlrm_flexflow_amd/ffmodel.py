@@ -46,7 +46,8 @@ class FFComm(C.Structure):
     """struct ffcomm (host/ffcomm.h)"""
     _fields_ = [("rank", C.c_int), ("world_size", C.c_int), ("user", C.c_void_p),
                 ("alltoall_f32", ALLTOALL_FN), ("allreduce_sum_f32", ALLREDUCE_FN), ("barrier", BARRIER_FN), ("nonblocking", C.c_int),
-                ("reduce_scatter_sum_f32", REDUCE_SCATTER_FN), ("allgather_f32", ALLGATHER_FN), ("allreduce_bucket_sum_f32", ALLREDUCE_FN), ("bucket_channel_own", C.c_int)]
+                ("reduce_scatter_sum_f32", REDUCE_SCATTER_FN), ("allgather_f32", ALLGATHER_FN), ("allreduce_bucket_sum_f32", ALLREDUCE_FN), ("bucket_channel_own", C.c_int),
+                ("alltoall_bucket_f32", ALLTOALL_FN), ("allgather_bucket_f32", ALLGATHER_FN)]
 
 
 _lib = None

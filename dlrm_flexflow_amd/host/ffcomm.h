@@ -50,6 +50,11 @@ typedef struct ffcomm {
    * exchange of the embedding gradients -- and the table update and the next gather behind it -- never waits for a weight-gradient GEMM and
    * its all-reduce (FFModel::issue_grad_buckets). */
   int bucket_channel_own;
+  /* The two collectives of the DIRECT all-reduce of a bucket (--direct-allreduce: all-to-all of 1 / world_size slices, local sum in rank
+   * order, all-gather of the sums -- every link of the fully connected node carries 1 / world_size of the bucket, where a ring is bound by one
+   * link), on the buckets' channel.  Same contracts as alltoall_f32 / allgather_f32.  NULL: the model uses those two. */
+  int (*alltoall_bucket_f32)(void* user, const float* send, const int64_t* send_counts, float* recv, const int64_t* recv_counts, void* stream);
+  int (*allgather_bucket_f32)(void* user, const float* send, float* recv, int64_t send_count, void* stream);
 } ffcomm;
 
 #ifdef __cplusplus

@@ -119,6 +119,8 @@ class FFConfig {
   int  bucket_allreduce;       // the MLP gradients' all-reduce in buckets issued from inside backward() on a communication stream, one per wide layer, beside the
                                // rest of the backward [ref: one ncclAllReduce per parameter from its own update task, src/runtime/optimizer.cc:93-189]:
                                // 1 / 0 (--bucket-allreduce / --no-bucket-allreduce), -1 = where the transport only enqueues (ffcomm.nonblocking)
+  bool direct_allreduce;             // --direct-allreduce: a bucket's sum as all-to-all of 1 / N slices + local sum in rank order + all-gather (every xGMI link
+                                     // carries 1 / N of it) instead of ncclAllReduce, whose ring one link bounds
   int64_t allreduce_bucket_floats;   // a bucket is closed once it holds this many gradients (--allreduce-bucket-floats N; default 1 Mi = 4 MB)
   int64_t big_dw_min_weights;  // ... only a layer with at least this many weights is cut (--big-dw-min-weights N; default 2 Mi)
   int  big_dw_chunks;          // with bucketed all-reduce: the biggest layer's weight-gradient GEMM as this many launches over row blocks of dW, a bucket behind each (its
@@ -541,6 +543,11 @@ class FFModel {
   std::vector<std::pair<size_t, size_t>> grad_rest;     // (offset, count) of what no bucket covers (data-parallel tables): reduced in update()
   ffh_stream ar_stream = nullptr;                       // the buckets' stream
   bool bucketed_now() const;                            // buckets are issued from backward() in this step
+  int  allreduce_grads(float* buf, int64_t count, ffh_stream s, bool bucket) const;   // ring (the transport's all-reduce) or direct; 0 = ok
+  float* ar_scratch = nullptr;          // direct all-reduce: the received slices + the gathered sums (2 x the largest bucket, padded)
+  size_t ar_scratch_floats = 0;
+  mutable int64_t n_direct_allreduces = 0;
+  mutable std::map<int64_t, std::vector<int64_t>> direct_plans;   // count -> [send counts | receive counts] of its all-to-all (stable addresses)
   bool buckets_held() const;          // a shared channel and this step's backward all-to-all not enqueued yet
   void issue_grad_buckets(int next_layer);              // every complete, not yet issued bucket (layers > next_layer have issued their backward)
   void issue_one_bucket(size_t k, bool wait_main);      // wait_main: also behind what the compute stream holds now

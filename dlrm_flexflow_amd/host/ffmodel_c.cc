@@ -133,6 +133,7 @@ int64_t flexflow_model_get_counter(flexflow_model_t m, const char* name) {
     return k < M(m)->grad_buckets.size() ? (int64_t)M(m)->grad_buckets[k].count : -1;
   }
   if (n == "allreduce_bucket_channel_own") return M(m)->config.comm.bucket_channel_own;
+  if (n == "direct_allreduces") return M(m)->n_direct_allreduces;
   return -1;
 }
 

@@ -136,6 +136,7 @@ FFConfig::FFConfig() {
   trace_mode = -1;
   bucket_allreduce = -1;
   allreduce_bucket_floats = 1 << 20;
+  direct_allreduce = false;
   big_dw_chunks = 0;
   big_dw_min_weights = 2 << 20;
   mlp_chain_max_batch = 8192;
@@ -225,6 +226,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--bucket-allreduce")) { bucket_allreduce = 1; continue; }
     if (is("--no-bucket-allreduce")) { bucket_allreduce = 0; continue; }
     if (is("--allreduce-bucket-floats")) { allreduce_bucket_floats = atoll(next()); continue; }
+    if (is("--direct-allreduce")) { direct_allreduce = true; continue; }
     if (is("--big-dw-chunks")) { big_dw_chunks = atoi(next()); continue; }
     if (is("--big-dw-min-weights")) { big_dw_min_weights = atoll(next()); continue; }
     if (is("--mlp-chain-max-batch")) { mlp_chain_max_batch = atoll(next()); continue; }
@@ -531,7 +533,7 @@ FFModel::~FFModel() {
     if (t->ptr && !t->alias && t->bytes) api->ffh_free(ctx, t->ptr);
     delete t;
   }
-  for (void* p : {w_twin, act_twin, grad_twin}) if (p) api->ffh_free(ctx, p);
+  for (void* p : {w_twin, act_twin, grad_twin, (void*)ar_scratch}) if (p) api->ffh_free(ctx, p);
   for (void* p : {(void*)mlp_weights, (void*)mlp_grads, (void*)act_slab, (void*)act_grad_slab, workspace, repl_workspace, (void*)d_perf, (void*)xsend,
                   (void*)xrecv, (void*)gsend, (void*)grecv})
     if (p) api->ffh_free(ctx, p);
@@ -1965,6 +1967,14 @@ void FFModel::allocate() {
   }
   // Op::weights[] are copies of the Parameters: same impl pointers, nothing to patch.
 
+  // ---- 5a'. scratch of the direct all-reduce (--direct-allreduce): the received slices + the gathered sums of the largest range ----
+  if (ar_scratch) { api->ffh_free(ctx, ar_scratch); ar_scratch = nullptr; ar_scratch_floats = 0; }
+  if (config.direct_allreduce && exchange && mlp_count) {
+    const int64_t slice = ((((int64_t)mlp_count + world_size - 1) / world_size) + 3) / 4 * 4;
+    ar_scratch_floats = (size_t)(2 * slice * world_size);
+    ar_scratch = (float*)dmalloc(ar_scratch_floats * 4);
+  }
+
   // ---- 5b. buckets of the MLP gradients' all-reduce ---------------------------------------------------------------------
   // In the reference every parameter has its own update task with its own ncclAllReduce, ordered by region dependences only: a top
   // layer's gradients are summed over the ranks while the layers below still run their backward [ref: src/runtime/optimizer.cc:93-189,
@@ -2410,6 +2420,45 @@ void FFModel::embedding_dense_update() const {
 // the training step [ref: src/runtime/model.cc:1410-1477, examples/cpp/DLRM/dlrm.cc:166-182]
 // =============================================================================================
 // ---- bucketed all-reduce of the MLP gradients (allocate step 5b) ----------------------------------------------------------------
+// The sum of a gradient range over the ranks.  Ring: the transport's all-reduce (ncclAllReduce: 2 (N - 1) / N of the bytes over ONE link per
+// hop).  Direct (--direct-allreduce; SURVEY section 5: "prefer direct (fully-connected) algorithms"): xGMI connects every pair of GPUs, so
+//   1. all-to-all: rank r receives slice r of the range from every rank (every link carries 1 / N of the range, all at once),
+//   2. ffh_sum_slices_f32: the N copies added in RANK order -- the same fp32 chain on whichever rank owns the slice: every rank ends up with
+//      the same bits, and a run gives the same bits as the next,
+//   3. all-gather of the sums (again 1 / N per link), copied back into the range.
+// Both collectives go to the buckets' channel where the transport has one.  [ref: one ncclAllReduce per parameter,
+// src/runtime/optimizer_kernel.cu:170-171]
+int FFModel::allreduce_grads(float* buf, int64_t count, ffh_stream s, bool bucket) const {
+  const int G = world_size;
+  auto ring = [&]() -> int {
+    auto fn = (bucket && config.comm.allreduce_bucket_sum_f32) ? config.comm.allreduce_bucket_sum_f32 : config.comm.allreduce_sum_f32;
+    return fn(config.comm.user, buf, count, s);
+  };
+  auto a2a = config.comm.alltoall_bucket_f32 ? config.comm.alltoall_bucket_f32 : config.comm.alltoall_f32;
+  auto gather = config.comm.allgather_bucket_f32 ? config.comm.allgather_bucket_f32 : config.comm.allgather_f32;
+  if (!config.direct_allreduce || G < 2 || !gather || !a2a || count <= 0) return ring();
+  const int64_t slice = (((count + G - 1) / G) + 3) / 4 * 4;
+  if ((size_t)(2 * slice * G) > ar_scratch_floats) return ring();
+  // (the count arrays live as long as the model: a transport may key its own bookkeeping on their addresses, as TorchComm does)
+  auto& plan = direct_plans[count];
+  if (plan.empty()) {
+    plan.resize(2 * (size_t)G);
+    for (int p = 0; p < G; p++) plan[p] = std::max<int64_t>(0, std::min<int64_t>(slice, count - (int64_t)p * slice));
+    for (int q = 0; q < G; q++) plan[G + q] = plan[rank];
+  }
+  const int64_t* sc = plan.data();
+  const int64_t* rc = plan.data() + G;
+  const int64_t mine = sc[rank];
+  float* r1 = ar_scratch;                    // [G][mine]: slice `rank` as every rank holds it
+  float* r2 = ar_scratch + (size_t)slice * G;   // [G][slice]: the sums
+  if (a2a(config.comm.user, buf, sc, r1, rc, s) != 0) return 1;
+  if (api->ffh_sum_slices_f32(ctx, r1, r1, G, mine, mine, s) != FFH_OK) return 1;
+  if (gather(config.comm.user, r1, r2, slice, s) != 0) return 1;
+  if (api->ffh_memcpy_d2d(ctx, buf, r2, (size_t)count * 4, s) != FFH_OK) return 1;
+  n_direct_allreduces++;
+  return 0;
+}
+
 bool FFModel::bucketed_now() const {
   if (!exchange || grad_buckets.empty() || use_workers() || config.profiling) return false;
   if (config.bucket_allreduce == 0) return false;
@@ -2457,8 +2506,7 @@ void FFModel::issue_one_bucket(size_t k, bool wait_main) {
   //  waits for nothing extra; inline, `stream` itself takes the waits)
   if (dw_forked && dw1_used) { check(api->ffh_event_record(ctx, b.ready_dw, dw_stream), "bucket ready"); check(api->ffh_stream_wait_event(ctx, s, b.ready_dw), "bucket ready"); }
   if (k < 8) probe_record(14 + 2 * (int)k, s, ctx);
-  auto fn = config.comm.allreduce_bucket_sum_f32 ? config.comm.allreduce_bucket_sum_f32 : config.comm.allreduce_sum_f32;
-  if (fn(config.comm.user, mlp_grads + b.off, (int64_t)b.count, s) != 0) die("allreduce (bucket) failed");
+  if (allreduce_grads(mlp_grads + b.off, (int64_t)b.count, s, true) != 0) die("allreduce (bucket) failed");
   if (k < 8) probe_record(15 + 2 * (int)k, s, ctx);
   if (!inline_now) check(api->ffh_event_record(ctx, b.done, s), "bucket done");
   b.issued = true;
@@ -2788,11 +2836,11 @@ void FFModel::update() {
       probe_record(13, stream, ctx);
       probe_record(8, stream, ctx);
       for (auto& r : grad_rest)
-        if (config.comm.allreduce_sum_f32(config.comm.user, mlp_grads + r.first, (int64_t)r.second, stream) != 0) die("allreduce failed");
+        if (allreduce_grads(mlp_grads + r.first, (int64_t)r.second, stream, false) != 0) die("allreduce failed");
       probe_record(9, stream, ctx);
     } else {
       probe_record(8, stream, ctx);
-      if (config.comm.allreduce_sum_f32(config.comm.user, mlp_grads, (int64_t)mlp_count, stream) != 0) die("allreduce failed");
+      if (allreduce_grads(mlp_grads, (int64_t)mlp_count, stream, false) != 0) die("allreduce failed");
       probe_record(9, stream, ctx);
     }
   }

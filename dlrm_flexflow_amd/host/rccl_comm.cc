@@ -69,19 +69,36 @@ int fail(int rc, const char* what) {
 }
 
 // uneven all-to-all: one grouped send/recv pair per peer, blocks contiguous in rank order (counts in floats)
-int alltoall_f32(void* user, const float* send, const int64_t* sc, float* recv, const int64_t* rc, void* stream) {
-  Comm* c = (Comm*)user;
+int alltoall_on(Comm* c, ncclComm_p comm, const float* send, const int64_t* sc, float* recv, const int64_t* rc, void* stream) {
   int e = g_api.GroupStart();
   if (e != kNcclSuccess) return fail(e, "ncclGroupStart");
   int64_t so = 0, ro = 0;
   for (int p = 0; p < c->world; p++) {
-    if (sc[p] > 0) { e = g_api.Send(send + so, (size_t)sc[p], kNcclFloat32, p, c->comm, stream); if (e != kNcclSuccess) { g_api.GroupEnd(); return fail(e, "ncclSend"); } }
-    if (rc[p] > 0) { e = g_api.Recv(recv + ro, (size_t)rc[p], kNcclFloat32, p, c->comm, stream); if (e != kNcclSuccess) { g_api.GroupEnd(); return fail(e, "ncclRecv"); } }
+    if (sc[p] > 0) { e = g_api.Send(send + so, (size_t)sc[p], kNcclFloat32, p, comm, stream); if (e != kNcclSuccess) { g_api.GroupEnd(); return fail(e, "ncclSend"); } }
+    if (rc[p] > 0) { e = g_api.Recv(recv + ro, (size_t)rc[p], kNcclFloat32, p, comm, stream); if (e != kNcclSuccess) { g_api.GroupEnd(); return fail(e, "ncclRecv"); } }
     so += sc[p]; ro += rc[p];
   }
   e = g_api.GroupEnd();
   if (e != kNcclSuccess) return fail(e, "ncclGroupEnd");
+  return 0;
+}
+int alltoall_f32(void* user, const float* send, const int64_t* sc, float* recv, const int64_t* rc, void* stream) {
+  Comm* c = (Comm*)user;
+  if (alltoall_on(c, c->comm, send, sc, recv, rc, stream) != 0) return 1;
   c->n_alltoall++;
+  return 0;
+}
+// the direct all-reduce's two collectives on the buckets' channel (the second communicator where there is one)
+int alltoall_bucket_f32(void* user, const float* send, const int64_t* sc, float* recv, const int64_t* rc, void* stream) {
+  Comm* c = (Comm*)user;
+  return alltoall_on(c, c->comm2 ? c->comm2 : c->comm, send, sc, recv, rc, stream);
+}
+int allgather_bucket_f32(void* user, const float* send, float* recv, int64_t send_count, void* stream) {
+  Comm* c = (Comm*)user;
+  if (send_count > 0) {
+    const int e = g_api.AllGather(send, recv, (size_t)send_count, kNcclFloat32, c->comm2 ? c->comm2 : c->comm, stream);
+    if (e != kNcclSuccess) return fail(e, "ncclAllGather (bucket)");
+  }
   return 0;
 }
 
@@ -166,6 +183,8 @@ int flexflow_rccl_comm_create(const unsigned char id[128], int rank, int world_s
   out->reduce_scatter_sum_f32 = reduce_scatter_sum_f32;
   out->allgather_f32 = allgather_f32;
   out->allreduce_bucket_sum_f32 = allreduce_bucket_sum_f32;
+  out->alltoall_bucket_f32 = alltoall_bucket_f32;
+  out->allgather_bucket_f32 = allgather_bucket_f32;
   return 0;
 }
 

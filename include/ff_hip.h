@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define FFH_ABI_VERSION 14   /* 14: ffh_ctx_bf16x3_mirror_set, ffh_convert_f32_to_bf16x3 (three-plane images for the fp32-accurate split mode); 13: ffh_embedding_last_route; 12: ffh_mlp_chain_fwd / _bwd (a chain of narrow Linear layers as three launches), ffh_ctx_reserve_scratch; 11: ffh_stream_create_with_priority; 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
+#define FFH_ABI_VERSION 14   /* 14: ffh_ctx_bf16x3_mirror_set, ffh_convert_f32_to_bf16x3 (three-plane images for the fp32-accurate split mode), ffh_sum_slices_f32 (direct all-reduce); 13: ffh_embedding_last_route; 12: ffh_mlp_chain_fwd / _bwd (a chain of narrow Linear layers as three launches), ffh_ctx_reserve_scratch; 11: ffh_stream_create_with_priority; 10: ffh_linear_bwd_set_dx_colsum, ffh_linear_dx_colsum_used; 9: ffh_ctx_set_dw_cu_reserve; 8: ffh_embedding_bwd_opt_fused_multi / _apply_multi (sparse momentum-SGD / Adam on the sorted segments); 7: ffh_embedding_bwd_sort_multi, ffh_embedding_bwd_sgd_apply_multi; 6: ffh_ctx_bf16_mirror_set, ffh_convert_f32_to_bf16; 5: ffh_ctx_default, ffh_linear_last_route; 4: ffh_ctx_set_math_mode, ffh_ctx_set_deterministic; 2: optimizer / linear / concat *_ex entry points, ffh_adam_update, ffh_second_stream_used; 3: ffh_embedding_localize_rows, ffh_tril_*, ffh_dot_interaction_*, ffh_linear_bwd_mse, ffh_linear_pair_fwd / _bwd, ffh_linear_bwd_set_dx_scatter */
 
 /* status codes */
 #define FFH_OK               0
@@ -661,6 +661,11 @@ int ffh_adam_update(ffh_ctx* ctx, float* w, float* w_grad, float* m, float* v, i
                     float alpha_t, float beta1, float beta2, float weight_decay, float epsilon, int flags, ffh_stream s);
 /* apply_add_with_scale [ref: src/runtime/cuda_helper.cu:99-108] : dst += src*scale */
 int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, float scale, ffh_stream s);
+/* dst[i] = src[i] + src[stride + i] + ... + src[(nslices - 1) * stride + i], i < count, added in that order (fp32; dst may be src's slice 0).
+ * The local step of the DIRECT all-reduce of the MLP gradients (host: --direct-allreduce): every rank receives one slice of the bucket from
+ * every rank over all links at once (all-to-all), sums them in RANK order with this kernel -- every rank computes the same bits -- and the sums
+ * are gathered back.  Replaces ncclAllReduce's ring, which one xGMI link bounds [ref: src/runtime/optimizer_kernel.cu:170-171]. */
+int ffh_sum_slices_f32(ffh_ctx* ctx, float* dst, const float* src, int nslices, int64_t count, int64_t stride, ffh_stream s);
 
 #ifdef __cplusplus
 }
@@ -683,6 +688,6 @@ int ffh_add_scaled(ffh_ctx* ctx, float* dst, const float* src, int64_t count, fl
   X(ffh_embedding_bwd_workspace_bytes) X(ffh_embedding_localize_rows) \
   X(ffh_linear_fwd) X(ffh_linear_fast_in_dim) X(ffh_linear_last_route) X(ffh_embedding_last_route) X(ffh_linear_bwd) X(ffh_linear_bwd_ex) X(ffh_linear_bwd_mse) X(ffh_linear_pair_bwd) X(ffh_linear_pair_fwd) X(ffh_mlp_chain_fwd) X(ffh_mlp_chain_bwd) X(ffh_second_stream_used) X(ffh_event_record_with_next_linear_bwd) X(ffh_linear_bwd_set_dx_scatter) X(ffh_linear_dx_scatter_used) X(ffh_linear_bwd_set_dx_colsum) X(ffh_linear_dx_colsum_used) X(ffh_concat_fwd) X(ffh_concat_bwd) X(ffh_concat_bwd_ex) \
   X(ffh_bmm_fwd) X(ffh_bmm_bwd) X(ffh_transpose_fwd) X(ffh_transpose_bwd) X(ffh_tril_fwd) X(ffh_tril_bwd) X(ffh_dot_interaction_fwd) X(ffh_dot_interaction_bwd) X(ffh_mse_bwd) X(ffh_mse_bwd_metrics) X(ffh_metrics_update) \
-  X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled)
+  X(ffh_sgd_update) X(ffh_sgd_update_ex) X(ffh_adam_update) X(ffh_add_scaled) X(ffh_sum_slices_f32)
 
 #endif /* FF_HIP_H_ */

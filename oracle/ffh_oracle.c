@@ -1117,6 +1117,17 @@ int ffh_adam_update(ffh_ctx* c, float* w, float* g, float* m, float* v, int64_t 
 }
 
 /* apply_add_with_scale [ref: src/runtime/cuda_helper.cu:99-108] */
+/* dst[i] = the slices' i-th elements added in slice order (ffh_sum_slices_f32: the local step of the direct all-reduce) */
+int ffh_sum_slices_f32(ffh_ctx* c, float* d, const float* src, int nslices, int64_t n, int64_t stride, ffh_stream s) {
+  (void)s;
+  if (!c || n < 0 || nslices < 1 || (nslices > 1 && stride < n) || ((!d || !src) && n)) return FFH_ERR_BAD_ARG;
+  for (int64_t i = 0; i < n; i++) {
+    float v = src[i];
+    for (int q = 1; q < nslices; q++) v = v + src[(int64_t)q * stride + i];
+    d[i] = v;
+  }
+  return FFH_OK;
+}
 int ffh_add_scaled(ffh_ctx* c, float* d, const float* src, int64_t n, float scale, ffh_stream s) {
   (void)c; (void)s;
 #pragma omp parallel for schedule(static)

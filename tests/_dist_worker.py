@@ -42,13 +42,16 @@ def main():
         # the default keeps one bucket), tiny buckets, the biggest layer's weight gradient in two row blocks; "buckets-mixed": with
         # data-parallel tables in the dense slab (the part no bucket covers)
         extra = ["--bucket-allreduce", "--allreduce-bucket-floats", "64", "--big-dw-chunks", "2", "--big-dw-min-weights", "1"]
+        if mode.endswith("-direct"):        # round 6: every bucket (and what no bucket covers) through the direct all-reduce
+            extra.append("--direct-allreduce")
         m, h = H.build_golden_dlrm(H.oracle_backend(), comm=comm.struct, overlap=True, force_exchange=True, extra_argv=extra,
-                                   replicate_rows=39 if mode == "buckets-mixed" else 0)
+                                   replicate_rows=39 if mode.startswith("buckets-mixed") else 0)
         recs = H.run_steps(m, h, 2)
         for step, rec in enumerate(recs):
             for k, v in rec.items():
                 out[f"s{step}/{k}"] = v
         out["bucket_calls"] = np.array(m.counter("allreduce_bucket_calls"))
+        out["direct_allreduces"] = np.array(m.counter("direct_allreduces"))
         m.close()
     elif mode in ("golden", "column", "strategy", "row", "replicated", "replicated_all", "replicated_adam"):
         extra = ["--import", os.path.join(outdir, "strategy.txt"), "--export", os.path.join(outdir, "export.txt")] if mode == "strategy" else []

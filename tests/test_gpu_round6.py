@@ -403,3 +403,26 @@ def test_mlp_chain_backward_in_deterministic_mode_is_bit_reproducible(hip, oracl
         assert np.array_equal(det[f"dy{l}"], ref[f"dy{l}"])                            # the data-gradient chain has no atomics in either mode
         assert np.all(np.abs(det[f"dw{l}"].astype(np.float64) - ref[f"dw{l}"]) <= 1e-5 * (a.T @ xin) + 1e-6), f"dw{l}"
         assert np.all(np.abs(det[f"db{l}"].astype(np.float64) - ref[f"db{l}"]) <= 1e-5 * a.sum(0) + 1e-6), f"db{l}"
+
+
+@pytest.mark.gpu
+def test_sum_slices_is_the_ordered_chain(hip, oracle):
+    """ffh_sum_slices_f32 (the local step of the direct all-reduce): dst[i] = ((s0[i] + s1[i]) + s2[i]) + ... in slice order, bit for bit the numpy
+    chain and the oracle's, vector and scalar paths, in place on slice 0."""
+    import torch
+    rng = np.random.default_rng(23)
+    for n, stride, G in ((4096, 4096, 8), (1001, 1003, 5), (12, 16, 2), (7, 7, 1)):
+        src = (rng.uniform(-1, 1, (G, stride)) * 2.0 ** rng.integers(-8, 8, (G, stride))).astype(np.float32)
+        exp = src[0, :n].copy()
+        for q in range(1, G):
+            exp = exp + src[q, :n]
+        t = torch.from_numpy(src).to("cuda:0")
+        hip.call("ffh_sum_slices_f32", t, t, G, n, stride, None)
+        torch.cuda.synchronize()
+        got = t.cpu().numpy()
+        assert got[0, :n].tobytes() == exp.tobytes(), (n, stride, G)
+        assert np.array_equal(got[1:], src[1:]) and np.array_equal(got[0, n:], src[0, n:])
+        o = src.copy()
+        lib = oracle.lib()
+        assert lib.lib.ffh_sum_slices_f32(lib.ctx, o.ctypes.data, o.ctypes.data, G, n, stride, None) == 0
+        assert o[0, :n].tobytes() == exp.tobytes()

@@ -93,3 +93,46 @@ def test_ffcomm_struct_layout_matches_the_header():
     names = re.findall(r"\(\*(\w+)\)\(|(?:int|void\*)\s+(\w+);", body)
     header = [a or b for a, b in names]
     assert header == [f[0] for f in ffmodel.FFComm._fields_], (header, [f[0] for f in ffmodel.FFComm._fields_])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the direct all-reduce of the gradient buckets (--direct-allreduce): all-to-all of 1 / N slices, local sum in rank order, all-gather
+import subprocess
+import sys
+
+WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dist_worker.py")
+
+
+def _run_ranks(world, outdir, mode, port_salt):
+    os.makedirs(outdir, exist_ok=True)
+    port = 33500 + (os.getpid() % 2000) + port_salt
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, WORKER, mode, str(outdir)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+@pytest.mark.parametrize("world,mode", [(2, "buckets"), (4, "buckets"), (2, "buckets-mixed")])
+def test_direct_allreduce_equals_the_ring_and_is_identical_on_every_rank(tmp_path, world, mode):
+    """2 / 4 gloo ranks on the oracle kernels, two steps, buckets forced on: --direct-allreduce (all-to-all of slices, ffh_sum_slices_f32 in
+    rank order, all-gather; the slices are multiples of 4 floats, so the last rank's is shorter -- or empty -- for most bucket sizes) against the transport's all-reduce -- the same sums to
+    1e-6 (the order of the adds differs: rank order here, gloo's ring order there), the direct path really ran, and every rank holds the SAME
+    BITS in every data-parallel parameter after each step (the sum of a slice is computed once, by its owner, and gathered)."""
+    a_dir, b_dir = os.path.join(tmp_path, "ring"), os.path.join(tmp_path, "direct")
+    _run_ranks(world, a_dir, mode, 3)
+    _run_ranks(world, b_dir, mode + "-direct", 11)
+    recs = [np.load(os.path.join(b_dir, f"rank{r}.npz")) for r in range(world)]
+    for r in range(world):
+        za, zb = np.load(os.path.join(a_dir, f"rank{r}.npz")), recs[r]
+        assert int(za["direct_allreduces"]) == 0 and int(zb["direct_allreduces"]) >= 2 * 3, (int(za["direct_allreduces"]), int(zb["direct_allreduces"]))
+        keys = [k for k in za.files if k.startswith("s")]
+        assert keys and set(keys) == {k for k in zb.files if k.startswith("s")}
+        for k in keys:
+            np.testing.assert_allclose(za[k], zb[k], rtol=1e-6, atol=1e-7, err_msg=k)
+    for k in recs[0].files:
+        if k.startswith("s") and ("top" in k or "bot" in k) and all(k in z.files for z in recs):      # the MLPs' parameters: data-parallel, one copy per rank
+            for r in range(1, world):
+                assert recs[0][k].tobytes() == recs[r][k].tobytes(), f"{k}: ranks 0 and {r} differ"
