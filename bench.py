@@ -469,6 +469,8 @@ def main():
     from dlrm_flexflow_amd import ffmodel
 
     ftest = args.functional_test_backend           # tests only (see the flag): everything below runs, nothing is measured
+    if ftest and os.environ.get("FFM_TESTING") != "1":
+        sys.exit("bench.py: --functional-test-backend is test scaffolding (tests/test_launchers.py sets FFM_TESTING=1); it measures nothing")
     if not ftest and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the product path has no CPU fallback)")
     if not ftest:

@@ -537,8 +537,10 @@ int launch_gemm_sk(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const 
   if (!sk_plan(c, g, form, p)) return 0;
   float* slots = nullptr; unsigned* flags = nullptr;
   if (p.split && !sk_slots_for(c, as_stream(s), &slots, &flags)) {
-    // no scratch reserved for this stream (ffh_ctx_reserve_scratch): the whole-tile form where it serves, else not this kernel's launch
+    // no scratch reserved for this stream (ffh_ctx_reserve_scratch): the whole-tile form where it serves, else not this kernel's launch --
+    // said in the route, so that a caller who launches on a stream of its own sees why a slower form ran
     p.split = false;
+    { char tok[96]; snprintf(tok, sizeof tok, "%s|no_scratch_on_this_stream", name); ffh_route_add(c, tok); }
     const int64_t ntiles = (int64_t)(g.M / SK_BM) * (g.N / SK_BN), rounds = (ntiles + p.G - 1) / p.G;
     if (ntiles < p.G || ntiles * 100 < rounds * p.G * 80) return 0;
   }

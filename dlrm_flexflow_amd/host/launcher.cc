@@ -26,6 +26,15 @@
 #include "dlrm.h"
 #include "rccl_comm.h"
 
+// Test hooks (a GPU-less dry run of the process management, a rank that hangs / ignores SIGTERM, a signal before the first fork, the launcher
+// forced for one rank) exist only in the -DFFM_TESTING build of this file: host/Makefile links it into `dlrm_testing`, the binary
+// tests/test_launchers.py drives.  The product library and `dlrm` are compiled without it: the hooks are not there to be switched on.
+#ifdef FFM_TESTING
+#define FFM_TEST_ENV(name) getenv(name)
+#else
+#define FFM_TEST_ENV(name) ((const char*)nullptr)
+#endif
+
 namespace {
 
 int gpus_requested(int argc, char** argv) {
@@ -74,10 +83,10 @@ int launcher_barrier(void*) {
 }
 
 int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv) {
-  const bool dry = getenv("FFM_LAUNCH_DRYRUN") != nullptr;     // tests: process management + rendezvous without a GPU
+  const bool dry = FFM_TEST_ENV("FFM_LAUNCH_DRYRUN") != nullptr;     // tests: process management + rendezvous without a GPU
   // (the three FFM_LAUNCH_TEST_* hooks act only inside the GPU-less dry run that exists for the process-management tests: a real launch
   //  never reads them -- round-4 advisor)
-  if (dry && getenv("FFM_LAUNCH_TEST_IGNORE_TERM")) signal(SIGTERM, SIG_IGN);   // tests: a rank that does not listen (SIGKILL after the grace period)
+  if (dry && FFM_TEST_ENV("FFM_LAUNCH_TEST_IGNORE_TERM")) signal(SIGTERM, SIG_IGN);   // tests: a rank that does not listen (SIGKILL after the grace period)
   unsigned char id[128];
   memset(id, 0, sizeof id);
   const char* rccl = getenv("FFM_RCCL_LIB");
@@ -114,7 +123,7 @@ int run_rank(int argc, char** argv, int rank, int world, const std::string& rdv)
     for (int i = 0; i < 128; i++) sum += id[i];
     printf("[launcher] rank %d of %d: rendezvous ok (id checksum %u)\n", rank, world, sum);
     fflush(stdout);
-    if (getenv("FFM_LAUNCH_TEST_HANG")) {                      // tests: a rank that never ends by itself (the parent must end it)
+    if (FFM_TEST_ENV("FFM_LAUNCH_TEST_HANG")) {                      // tests: a rank that never ends by itself (the parent must end it)
       for (;;) pause();
     }
     return 0;
@@ -179,7 +188,7 @@ int dlrm_launch(int argc, char** argv) {
     return run_rank(argc, argv, rank, world, rdv);
   }
   int n = gpus_requested(argc, argv);
-  const bool force = getenv("FFM_FORCE_LAUNCHER") != nullptr;                 // tests: walk the launcher with one rank
+  const bool force = FFM_TEST_ENV("FFM_FORCE_LAUNCHER") != nullptr;                 // tests: walk the launcher with one rank
   if (n <= 1 && !force) return dlrm_main(argc, argv, nullptr);                // -ll:gpu 0 / 1: this process is the one rank
   if (n < 1) n = 1;
 
@@ -202,7 +211,7 @@ int dlrm_launch(int argc, char** argv) {
   sa.sa_handler = note_signal;
   sigaction(SIGTERM, &sa, &old_term);
   sigaction(SIGINT, &sa, &old_int);
-  if (getenv("FFM_LAUNCH_DRYRUN") && getenv("FFM_LAUNCH_TEST_SIGNAL_SELF_EARLY")) raise(SIGTERM);     // tests: a signal that arrives before the first fork (stays pending until the mask is restored)
+  if (FFM_TEST_ENV("FFM_LAUNCH_DRYRUN") && FFM_TEST_ENV("FFM_LAUNCH_TEST_SIGNAL_SELF_EARLY")) raise(SIGTERM);     // tests: a signal that arrives before the first fork (stays pending until the mask is restored)
   std::vector<pid_t> pids;
   for (int r = 0; r < n; r++) {
     const pid_t pid = fork();

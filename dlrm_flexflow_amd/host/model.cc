@@ -500,6 +500,8 @@ FFModel::FFModel(FFConfig& _config)
   check(api->ffh_ctx_reserve_scratch(ctx, stream), "reserve scratch");
   check(api->ffh_stream_create(ctx, &side_stream), "stream create");
   check(api->ffh_stream_create(ctx, &dw_stream), "stream create");
+  // (the row-block weight gradients of the biggest layer launch on dw_stream as their primary stream: its scratch too -- round-5 advisor)
+  check(api->ffh_ctx_reserve_scratch(ctx, dw_stream), "reserve scratch");
   // the gradient buckets' stream (a fifth stream would share a hardware queue with one of the others: HIP maps streams onto four)
   check(api->ffh_stream_create(ctx, &ar_stream), "stream create");
   check((config.timing_events ? api->ffh_event_create : api->ffh_event_create_sync)(ctx, &ev_dw_done), "event create");
@@ -2882,15 +2884,16 @@ bool FFModel::trace_replays(int trace_id) const {
   return !(trace_adaptive() && it != trace_tune.end() && it->second.decided == 2);
 }
 
-// Adaptive replay (FFConfig::trace_mode 0, one GPU): calls 0-2 of a trace run eagerly with an event behind each, call 3 captures,
-// calls 4-6 replay with an event behind each; the seventh call compares the spacing of the events (steps 1-2 against replays 5-6:
-// what a step takes end to end, host gaps included) and keeps the faster form for good.
+// Adaptive replay (FFConfig::trace_mode 0, one GPU): calls 0-4 of a trace run eagerly -- the first two unmeasured (one-off costs of a first
+// launch: code-object loads, hipFuncSetAttribute, a fall-back path taken once; a cold sample biased the choice towards the replay: round-5
+// advisor), events behind calls 2 and 4 --, call 5 captures, calls 6-8 replay with events behind 6 and 8; the tenth call compares the spacing
+// of the events (eager steps 3-4 against replays 7-8: what a step takes end to end, host gaps included) and keeps the faster form for good.
 void FFModel::begin_trace(int trace_id) {
   if (!config.enable_graph) return;
   if (trace_adaptive()) {
     TraceTune& t = trace_tune[trace_id];
-    if (t.decided == 2 || (t.decided == 0 && t.calls < 3)) return;      // an eager step
-    if (t.decided == 0 && t.calls == 7) {
+    if (t.decided == 2 || (t.decided == 0 && t.calls < 5)) return;      // an eager step
+    if (t.decided == 0 && t.calls == 9) {
       check(api->ffh_event_sync(ctx, t.ev[3]), "trace timing");
       check(api->ffh_event_elapsed_ms(ctx, t.ev[0], t.ev[1], &t.eager_ms), "trace timing");
       check(api->ffh_event_elapsed_ms(ctx, t.ev[2], t.ev[3], &t.graph_ms), "trace timing");
@@ -2924,20 +2927,20 @@ void FFModel::end_trace(int trace_id) {
         if (!t.ev[k]) check(api->ffh_event_create(ctx, &t.ev[k]), "event create");
         check(api->ffh_event_record(ctx, t.ev[k], stream), "trace timing");
       };
-      if (t.calls < 3) {               // the eager steps: events behind the first and the third
-        if (t.calls == 0) mark(0);
-        if (t.calls == 2) mark(1);
+      if (t.calls < 5) {               // the eager steps: events behind the third and the fifth
+        if (t.calls == 2) mark(0);
+        if (t.calls == 4) mark(1);
         t.calls++;
         return;
       }
       tune = &t;
     }
   }
-  struct TuneMark {                    // behind the graph launch below (calls 4 and 6: two replays apart)
+  struct TuneMark {                    // behind the graph launch below (calls 6 and 8: two replays apart)
     FFModel* ff; TraceTune* t;
     ~TuneMark() {
       if (!t) return;
-      const int k = t->calls == 4 ? 2 : (t->calls == 6 ? 3 : -1);
+      const int k = t->calls == 6 ? 2 : (t->calls == 8 ? 3 : -1);
       if (k >= 0) {
         if (!t->ev[k]) ff->check(ff->api->ffh_event_create(ff->ctx, &t->ev[k]), "event create");
         ff->check(ff->api->ffh_event_record(ff->ctx, t->ev[k], ff->stream), "trace timing");

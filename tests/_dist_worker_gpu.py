@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from dlrm_flexflow_amd import capi  # noqa: E402
-from dlrm_flexflow_amd.comm import HostStagedComm, RcclComm, TorchComm  # noqa: E402
+from dlrm_flexflow_amd.comm import RcclComm, TorchComm  # noqa: E402
+from host_staged_comm import HostStagedComm  # noqa: E402
 import dlrm_helpers as H  # noqa: E402
 
 

@@ -208,7 +208,7 @@ def _run_two_ranks_on_one_gpu(tmp_path, *mode, world=2):
 
 def test_two_ranks_on_one_gpu_equal_single_rank(hip, tmp_path):
     """world_size 2 on the HIP kernels: both ranks share this box's one GPU, the collectives go through the host-staged
-    test transport (comm.HostStagedComm over gloo; RCCL refuses two ranks on one device).  Table-wise shards, exchange
+    test transport (tests/host_staged_comm.py over gloo; RCCL refuses two ranks on one device).  Table-wise shards, exchange
     buffers, Concat unpack / pack, global-batch fused update and the gradient all-reduce must reproduce the
     single-rank run: tables within 1e-6 (same canonical order), MLP within 1e-5."""
     z = _run_two_ranks_on_one_gpu(tmp_path)

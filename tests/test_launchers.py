@@ -15,7 +15,7 @@ import pytest
 from conftest import ROOT
 from dlrm_flexflow_amd import build
 
-EXE = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm")
+EXE = os.path.join(ROOT, "dlrm_flexflow_amd", "host", "dlrm_testing")      # the -DFFM_TESTING build of the launcher: the hooks below are compiled out of `dlrm`
 RUN_DLRM = os.path.join(ROOT, "dlrm_flexflow_amd", "run_dlrm.py")
 BENCH = os.path.join(ROOT, "bench.py")
 SMALL = ["-b", "64", "--arch-sparse-feature-size", "8", "--arch-embedding-size", "100-200-50", "--arch-mlp-bot", "13-16-8",
@@ -193,7 +193,9 @@ def test_bench_one_rank_exchange_line_on_gpu(hip):
 # roofline probes on rank 0, barriers, MAX-reduced time, the single JSON line) runs and reports what it saw.
 # ---------------------------------------------------------------------------------------------------------------------
 def _bench_env():
-    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FFM_TESTING"] = "1"          # bench.py honours --functional-test-backend only with it
+    return env
 
 
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
