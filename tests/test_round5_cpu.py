@@ -92,9 +92,11 @@ def test_host_layer_runs_narrow_mlps_as_chains_same_bits_as_per_layer(bot, top, 
 def test_chains_stand_back_where_they_are_not_served():
     base = ["--backend", H.oracle_backend(), "-b", "48", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "30-11",
             "--arch-mlp-bot", "13-96-64-16", "--arch-mlp-top", "48-24-1", "--data-size", "48", "--mlp-chain-fwd-min-batch", "1"]
-    for extra in (["--deterministic"], ["--profiling"], ["--mlp-chain-max-batch", "32"], ["--allow-tensor-op-math-conversion"], ["--mlp-chain-max-weights", "100"]):
+    for extra in (["--profiling"], ["--mlp-chain-max-batch", "32"], ["--allow-tensor-op-math-conversion"], ["--mlp-chain-max-weights", "100"]):
         _, c = _run(base + extra, 1)
         assert c == (0, 0), (extra, c)
+    _, c = _run(base + ["--deterministic"], 1)      # round 6: deterministic mode takes the chains (the weight-gradient blocks are added in split order)
+    assert c[0] > 0 and c[1] > 0, c
     _, c = _run(base, 2, trace=True)          # under begin_trace / end_trace as well (the oracle backend runs traces eagerly)
     assert c[0] > 0 and c[1] > 0
     _, c = _run(base[:-2], 1)                 # the forward chain waits for 4096 samples per GPU by default; the backward chain does not

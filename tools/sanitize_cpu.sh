@@ -26,5 +26,5 @@ run $EXE --backend $LIB $SMALL --no-trace --profiling
 run $EXE --backend $LIB $SMALL --allow-tensor-op-math-conversion --deterministic
 run $EXE --backend $LIB $SMALL --export $S/strategy.txt
 run $EXE --backend $LIB $SMALL --import $S/strategy.txt
-FFM_LAUNCH_DRYRUN=1 run $EXE -ll:gpu 3 $SMALL
+FFM_LAUNCH_DRYRUN=1 run $S/dlrm_flexflow_amd/host/dlrm_testing -ll:gpu 3 $SMALL      # (the -DFFM_TESTING build of the launcher: the dry run is compiled out of dlrm)
 echo "sanitizer run clean"
