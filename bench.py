@@ -129,7 +129,8 @@ def mlp_flops_per_sample(w):
 # CPU baseline (host only; the oracle is the kernel library of the same C++ application)
 # ------------------------------------------------------------------------------------------------------------------
 CPU_ROW_CAP = 1_000_000     # rows per table in the CPU sample: initialising 24 G table elements on the host would take minutes
-CPU_BATCH = 512             # samples per CPU step (a 32768-sample step is ~1 TFLOP: minutes on one thread)
+CPU_BATCH = 2048            # samples per CPU step (a 32768-sample step is ~1 TFLOP: minutes on one thread): 256 blocks of 8 samples for the oracle's
+                            # OpenMP loops, so that the all-threads leg of a 256-thread host has one block per thread
 
 
 def cpu_sample_workload(name):
@@ -221,10 +222,10 @@ def cpu_baseline(args, budget_s=24.0):
             "host_cpus": ncpu,
             "by_threads": {str(t): legs[t]["value"] for t in sorted(legs)},
             "scaling_note": "the port is the test oracle: clarity over speed.  Its GEMMs run one fp32 FMA chain per output element (the order the parity tests "
-                            "pin), OpenMP over the batch for forward / dX and over the output rows for dW, with no cache blocking -- every sample re-streams the "
-                            "layer's whole weight matrix (14 MB for 3456 x 1024), so beyond a few dozen threads the legs are bound by shared memory bandwidth and "
-                            "the all-threads leg can be SLOWER than the quarter leg; `value` is the fastest leg, `cores` its thread count.  The reference's own "
-                            "CPU arithmetic for this path is `reference_lookup` (one thread, as the reference runs it).",
+                            "pin), OpenMP over blocks of 8 samples (forward / dX: a weight row is used for the whole block while it is cached) and of 8 output rows "
+                            "(dW: a sample's x row likewise) -- round 6: before, every sample re-streamed the layer's whole weight matrix and the all-threads leg was "
+                            "slower than the quarter leg; `value` is the fastest leg, `cores` its thread count.  The reference's own CPU arithmetic for this "
+                            "path is `reference_lookup` (one thread, as the reference runs it).",
             "reference_lookup": reference_lookup()}
 
 

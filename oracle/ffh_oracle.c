@@ -514,18 +514,27 @@ int ffh_linear_fwd(ffh_ctx* c, const float* x, int64_t ldx, float* y, int64_t ld
   if (!wt) return fail(c, FFH_ERR_NOMEM, "oom");
   const int bf = use_bf16(c, in, out);      /* tensor-op mode: both operands rounded to bfloat16, fp32 products and sums */
   for (int o = 0; o < out; o++) for (int i = 0; i < in; i++) wt[(size_t)i * out + o] = bf ? bf16_round(w[(size_t)o * in + i]) : w[(size_t)o * in + i];
+  /* blocks of LIN_BB samples share each weight row while it is in the cache (the weight matrix is streamed once per block, not once per
+   * sample); an output element is still ONE i-ascending fma chain from 0: the same bits as the sample-by-sample loop */
+  enum { LIN_BB = 8 };
 #pragma omp parallel for schedule(static)
-  for (int64_t b = 0; b < B; b++) {
-    float* yr = y + b * ldy;
-    const float* xr = x + b * ldx;
-    for (int o = 0; o < out; o++) yr[o] = 0.0f;
+  for (int64_t b0 = 0; b0 < B; b0 += LIN_BB) {
+    const int nb = (int)((B - b0) < LIN_BB ? (B - b0) : LIN_BB);
+    for (int r = 0; r < nb; r++) { float* yr = y + (b0 + r) * ldy; for (int o = 0; o < out; o++) yr[o] = 0.0f; }
     for (int i = 0; i < in; i++) {
-      const float xi = bf ? bf16_round(xr[i]) : xr[i];
       const float* wr = wt + (size_t)i * out;
-      for (int o = 0; o < out; o++) yr[o] = fmaf(xi, wr[o], yr[o]);
+      for (int r = 0; r < nb; r++) {
+        float* yr = y + (b0 + r) * ldy;
+        const float xv = x[(b0 + r) * ldx + i];
+        const float xi = bf ? bf16_round(xv) : xv;
+        for (int o = 0; o < out; o++) yr[o] = fmaf(xi, wr[o], yr[o]);
+      }
     }
-    if (bias) for (int o = 0; o < out; o++) yr[o] = yr[o] + bias[o];
-    if (act != FFH_AC_MODE_NONE) for (int o = 0; o < out; o++) yr[o] = act_fwd(yr[o], act);
+    for (int r = 0; r < nb; r++) {
+      float* yr = y + (b0 + r) * ldy;
+      if (bias) for (int o = 0; o < out; o++) yr[o] = yr[o] + bias[o];
+      if (act != FFH_AC_MODE_NONE) for (int o = 0; o < out; o++) yr[o] = act_fwd(yr[o], act);
+    }
   }
   free(wt);
   return FFH_OK;
@@ -562,19 +571,26 @@ static int linear_bwd_parts(ffh_ctx* c, const float* x, int64_t ldx, float* dx, 
   const int m = mask_on_load ? act : FFH_AC_MODE_NONE;
   const int bf = use_bf16(c, in, out);      /* tensor-op mode: GEMM operands rounded to bfloat16 (db stays an fp32 sum of fp32 values) */
   if (do_dw) {
+    /* blocks of LIN_OB output rows share each sample's x row while it is in the cache (x is streamed once per block of rows, not once per
+     * row); an element of dW is still ONE b-ascending fma chain from 0, then one add */
+    enum { LIN_OB = 8 };
 #pragma omp parallel
     {
-      float* tmp = (float*)malloc(sizeof(float) * (size_t)in);
+      float* tmp = (float*)malloc(sizeof(float) * (size_t)in * LIN_OB);
 #pragma omp for schedule(static)
-      for (int o = 0; o < out; o++) {
-        for (int i = 0; i < in; i++) tmp[i] = 0.0f;
+      for (int o0 = 0; o0 < out; o0 += LIN_OB) {
+        const int no = (out - o0) < LIN_OB ? (out - o0) : LIN_OB;
+        for (int i = 0; i < in * no; i++) tmp[i] = 0.0f;
         for (int64_t b = 0; b < B; b++) {
-          float d = act_grad(dy[b * lddy + o], y[b * ldy + o], m);
           const float* xr = x + b * ldx;
-          if (bf) { d = bf16_round(d); for (int i = 0; i < in; i++) tmp[i] = fmaf(d, bf16_round(xr[i]), tmp[i]); }
-          else for (int i = 0; i < in; i++) tmp[i] = fmaf(d, xr[i], tmp[i]);
+          for (int r = 0; r < no; r++) {
+            float d = act_grad(dy[b * lddy + o0 + r], y[b * ldy + o0 + r], m);
+            float* t = tmp + (size_t)r * in;
+            if (bf) { d = bf16_round(d); for (int i = 0; i < in; i++) t[i] = fmaf(d, bf16_round(xr[i]), t[i]); }
+            else for (int i = 0; i < in; i++) t[i] = fmaf(d, xr[i], t[i]);
+          }
         }
-        for (int i = 0; i < in; i++) dw[(size_t)o * in + i] += tmp[i];
+        for (int r = 0; r < no; r++) for (int i = 0; i < in; i++) dw[(size_t)(o0 + r) * in + i] += tmp[(size_t)r * in + i];
       }
       free(tmp);
     }
@@ -587,20 +603,30 @@ static int linear_bwd_parts(ffh_ctx* c, const float* x, int64_t ldx, float* dx, 
     }
   }
   if (do_dx && dx) {
+    /* blocks of LIN_XB samples share each weight row (as the forward); an element of dX is still ONE o-ascending fma chain from 0, then one add */
+    enum { LIN_XB = 8 };
 #pragma omp parallel
     {
-      float* tmp = (float*)malloc(sizeof(float) * (size_t)in);
+      float* tmp = (float*)malloc(sizeof(float) * (size_t)in * LIN_XB);
 #pragma omp for schedule(static)
-      for (int64_t b = 0; b < B; b++) {
-        for (int i = 0; i < in; i++) tmp[i] = 0.0f;
+      for (int64_t b0 = 0; b0 < B; b0 += LIN_XB) {
+        const int nb = (int)((B - b0) < LIN_XB ? (B - b0) : LIN_XB);
+        for (int i = 0; i < in * nb; i++) tmp[i] = 0.0f;
         for (int o = 0; o < out; o++) {
-          float d = act_grad(dy[b * lddy + o], y[b * ldy + o], m);
           const float* wr = w + (size_t)o * in;
-          if (bf) { d = bf16_round(d); for (int i = 0; i < in; i++) tmp[i] = fmaf(d, bf16_round(wr[i]), tmp[i]); }
-          else for (int i = 0; i < in; i++) tmp[i] = fmaf(d, wr[i], tmp[i]);
+          for (int r = 0; r < nb; r++) {
+            const int64_t b = b0 + r;
+            float d = act_grad(dy[b * lddy + o], y[b * ldy + o], m);
+            float* t = tmp + (size_t)r * in;
+            if (bf) { d = bf16_round(d); for (int i = 0; i < in; i++) t[i] = fmaf(d, bf16_round(wr[i]), t[i]); }
+            else for (int i = 0; i < in; i++) t[i] = fmaf(d, wr[i], t[i]);
+          }
         }
         /* DX_MASK_BY_X: reluBackward of the layer below, applied to what this layer hands down */
-        for (int i = 0; i < in; i++) dx[b * lddx + i] += (mask_by_x && !(x[b * ldx + i] > 0.0f)) ? 0.0f : tmp[i];
+        for (int r = 0; r < nb; r++) {
+          const int64_t b = b0 + r;
+          for (int i = 0; i < in; i++) dx[b * lddx + i] += (mask_by_x && !(x[b * ldx + i] > 0.0f)) ? 0.0f : tmp[(size_t)r * in + i];
+        }
       }
       free(tmp);
     }
