@@ -212,6 +212,9 @@ def test_weight_twin_is_fresh_under_a_replayed_step_after_a_host_write(hip):
     assert d < 1e-4, d          # a stale twin (weights 4x larger in the GEMMs) moves the sigmoid outputs by ~1e-1
 
 
+from conftest import exact_routes
+
+
 def _route(hip):
     return hip.lib.ffh_linear_last_route(hip.ctx).decode()
 
@@ -249,7 +252,7 @@ def test_exchange_mode_first_top_layer_backward_takes_the_persistent_kernels(hip
     route = _route(hip)
     torch.cuda.synchronize()
     assert int(hip.lib.ffh_linear_dx_scatter_used(hip.ctx)) == 1
-    assert route.count("|sk_128x128x64") == 2 and "colmap" in route, route
+    assert not exact_routes(hip) or (route.count("|sk_128x128x64") == 2 and "colmap" in route), route
     got = torch.cat([bot, send, odd[1:].reshape(B, 128)], 1).cpu().numpy()
     exp = dy.astype(np.float64) @ w.astype(np.float64)
     mass = np.abs(dy).astype(np.float64) @ np.abs(w).astype(np.float64)
@@ -563,6 +566,8 @@ def test_linear_layers_at_the_per_rank_batch_vs_oracle_with_routes(hip, oracle, 
     _close(dw.cpu().numpy(), dw_e, m_dw, f"{IN}->{OUT} dw (plain)")
     _close(dx.cpu().numpy(), dx_e, m_dx, f"{IN}->{OUT} dx (plain)")
     print(f"routes {IN}->{OUT} @{B}:", routes)
+    if not exact_routes(hip):
+        return                                    # the split-mode run (conftest.SPLIT_MODE_TESTS): the numbers above, other kernels
     tok = lambda r, which: [t for t in r.split(";") if which in t.split("|")[0]]
     if expect.get("fwd") == "streamk":
         assert "streamk" in routes["fwd"] and "|sk_128x128x64" in routes["fwd"], routes

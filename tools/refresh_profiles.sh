@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the judged artefacts under profiles/ on one GPU box.  Outputs land in gpurun_out/refresh/ with their final
-# names (r05_*); copy them into profiles/ afterwards.   gpurun --timeout 3300 -- 'bash tools/refresh_profiles.sh'
+# names (r06_*); copy them into profiles/ afterwards.   gpurun --timeout 3300 -- 'bash tools/refresh_profiles.sh'
 R=$(pwd); O=$R/gpurun_out/refresh; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $R
-P=${P:-r05}
+P=${P:-r06}
 line() { grep '^{' | tail -1; }
 
 # 0. HBM traffic of the embedding kernels first (two counter-only passes): the bench lines below quote it, and warn when the file on
@@ -73,6 +73,12 @@ python3 tools/microbench.py emb > $O/${P}_microbench_embedding.txt 2>&1
 { python3 tools/bf16_twin_probe.py 32768x3456x1024; python3 tools/bf16_twin_probe.py 32768x1024x1024; } 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_bf16_twins.txt
 # SQ counters of the split-bf16x3 forward GEMM alone (MFMA busy cycles against GRBM_GUI_ACTIVE: what bounds that kernel)
 bash tools/pmc_x3.sh 2 > $O/pmc_x3.log 2>&1; cp gpurun_out/pmc_x3/summary.json $O/${P}_pmc_split_bf16x3_gemm.json
+# round 6: the split mode from three-plane images -- one layer through the C-ABI with and without images, the stand-alone lab, step timelines
+python3 tools/x3_image_probe.py 32768x3456x1024 32768x1024x1024 32768x1024x512 8192x3456x1024 4096x3456x1024 2>&1 | grep -v "DLRM\|amdgpu.ids" > $O/${P}_microbench_x3_images.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lab/gemm_x3_lab.hip -o tools/lab/gemm_x3_lab 2>> $O/lab_build.err && { timeout 300 tools/lab/gemm_x3_lab 32768 3456 1024 1; timeout 300 tools/lab/gemm_x3_lab 32768 1024 1024; } 2>&1 | grep -v "split3" > $O/${P}_lab_gemm_x3.txt
+tools/step_timeline.sh ${P}_terabyte_split --fp32-split-bf16x3 > /dev/null 2>&1; cp gpurun_out/${P}_terabyte_split_step_timeline.txt $O/
+tools/step_timeline.sh ${P}_terabyte_bf16 --allow-tensor-op-math-conversion > /dev/null 2>&1; cp gpurun_out/${P}_terabyte_bf16_step_timeline.txt $O/
+tools/step_timeline.sh ${P}_terabyte_b4096_split --fp32-split-bf16x3 --per-gpu-batch 4096 > /dev/null 2>&1; cp gpurun_out/${P}_terabyte_b4096_split_step_timeline.txt $O/
 
 for f in $O/${P}_bench_*.json; do echo "$(basename $f): $(python3 -c "import json,sys; d=json.load(open('$f')); print(d['value'], d['ms_per_step'], d.get('roofline',{}).get('frac'))" 2>&1 | tail -1)"; done
 cat $O/${P}_bench_terabyte_probe_averages.txt
