@@ -615,6 +615,7 @@ def main():
     if world > 1 or args.force_exchange:
         out["config"]["ranks_observed"] = dist.get_world_size()
         out["config"]["collective_calls_rank0"] = calls
+        out["config"]["gradient_allreduce"] = grads          # buckets, their communicator, ring or direct: what this run did (also part of `parallelism` at N > 1)
         # what one step moves over xGMI from / to rank 0 (payload, not counting RCCL's own protocol)
         def mlp_params(spec, first_in=None):
             dims = [int(v) for v in spec.split("-")]

@@ -167,6 +167,23 @@ def test_dlrm_binary_launcher_one_rccl_rank_on_gpu(hip):
 
 
 @pytest.mark.gpu
+def test_bench_one_rccl_rank_direct_allreduce_on_gpu(hip):
+    """--direct-allreduce through RCCL on one rank (round 6): the gradient sum as all-to-all of slices + ffh_sum_slices_f32 + all-gather on
+    the buckets' own communicator -- functional (the calls are enqueued on the HIP streams and the step completes), the line says which
+    algorithm ran, and with one rank the sum is the slice itself: the same throughput-independent facts as the ring run (collective counts)."""
+    lines = {}
+    for tag, extra in (("ring", []), ("direct", ["--shim-flags=--direct-allreduce"])):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--force-exchange", "--per-gpu-batch", "4096", "--steps", "4", "--warmup", "2",
+                            "--no-cpu-baseline", "--no-secondary", *extra], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    par = {k: v["config"]["gradient_allreduce"] for k, v in lines.items()}
+    assert "DIRECT" in par["direct"] and "DIRECT" not in par["ring"], par
+    assert "a communicator of their own" in par["direct"], par          # the launchers' default where ncclCommSplit exists
+    assert lines["direct"]["config"]["collective_calls_rank0"]["alltoall"] == lines["ring"]["config"]["collective_calls_rank0"]["alltoall"]
+
+
+@pytest.mark.gpu
 def test_run_dlrm_one_rank_on_gpu(hip):
     r = subprocess.run([sys.executable, RUN_DLRM, "-ll:gpu", "1", *SMALL], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
