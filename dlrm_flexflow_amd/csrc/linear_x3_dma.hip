@@ -451,9 +451,11 @@ int launch_gemm_x3_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, co
   } else {
     if (g.epi != EPI_STORE && g.epi != EPI_ADD) return 0;
     if (form == BF16_FORM_FWD && g.epi != EPI_STORE) return 0;
-    // at least one tile per CU: with 128 tiles (8192 x 3456 -> 1024 forward) this kernel takes 307-322 us where the split-in-kernel 128 x 128 form,
-    // whose 512 tiles fill the chip, takes 280; 8192 x 1024 -> 1024: 108-121 against 93 (profiles/r06_microbench_x3_images.txt)
-    static const int min_pct = FFH_LAB_INT("FFH_X3_DMA_MIN_TILES_PCT", 100);      // A/B switch: least number of tiles, in per cent of the CUs
+    // at least three tiles per four CUs: with 128 tiles (8192 x 3456 -> 1024 forward) this kernel takes 307-322 us where the split-in-kernel
+    // 128 x 128 form, whose 512 tiles fill the chip, takes 280; 8192 x 1024 -> 1024: 108-121 against 93; with 224 tiles (4096 x 3456 -> 1024 data
+    // gradient) it takes 123-145 us against 196-219 (profiles/r06_microbench_x3_images.txt): a tile runs at 1/256 of this kernel's ~290 TF, the
+    // 128 x 128 form reaches 150-210 on the whole chip
+    static const int min_pct = FFH_LAB_INT("FFH_X3_DMA_MIN_TILES_PCT", 75);       // A/B switch: least number of tiles, in per cent of the CUs
     if (tiles * 100 < (int64_t)c->num_cus * min_pct) return 0;
   }
   if (tiles * splitk >= (1LL << 31)) return 0;

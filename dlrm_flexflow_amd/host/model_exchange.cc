@@ -250,7 +250,7 @@ int FFModel::allreduce_grads(float* buf, int64_t count, ffh_stream s, bool bucke
   };
   auto a2a = config.comm.alltoall_bucket_f32 ? config.comm.alltoall_bucket_f32 : config.comm.alltoall_f32;
   auto gather = config.comm.allgather_bucket_f32 ? config.comm.allgather_bucket_f32 : config.comm.allgather_f32;
-  if (!config.direct_allreduce || G < 2 || !gather || !a2a || count <= 0) return ring();
+  if (!config.direct_allreduce || !gather || !a2a || count <= 0) return ring();      // (one forced rank: the same three calls on one slice -- the functional run)
   const int64_t slice = (((count + G - 1) / G) + 3) / 4 * 4;
   if ((size_t)(2 * slice * G) > ar_scratch_floats) return ring();
   // (the count arrays live as long as the model: a transport may key its own bookkeeping on their addresses, as TorchComm does)
