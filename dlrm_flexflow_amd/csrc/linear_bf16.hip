@@ -627,11 +627,12 @@ __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16x3_v2_kernel(const Gemm
     for (int j = 0; j < 4; j++)
 #pragma unroll
       for (int p = 0; p < 3; p++) b[j][p] = BKC ? frag_kc(bs + p * PLANE_B, wn0 + 16 * j) : frag_kr(bs + p * PLANE_B, wn0 + 16 * j);
+    constexpr int IB = TM < 4 ? TM : 4;
 #pragma unroll
-    for (int ih = 0; ih < TM; ih += 4) {                  // four row blocks at a time: 12 + 12 fragments live
-      bf16x8_t a[4][3];
+    for (int ih = 0; ih < TM; ih += IB) {                 // (up to) four row blocks at a time: 12 + 12 fragments live
+      bf16x8_t a[IB][3];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < IB; i++)
 #pragma unroll
         for (int p = 0; p < 3; p++) a[i][p] = frag_kc(as + p * PLANE_A, wm0 + 16 * (ih + i));
       // the six products with i + j <= 4, small terms first -- per accumulator the order of linear_x3_dma.hip
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(BM / WM * BN) void gemm_bf16x3_v2_kernel(const Gemm
       for (int pr = 0; pr < 6; pr++) {
         const int pa = pr == 0 ? 2 : (pr == 1 || pr >= 4 ? 0 : 1), pb = pr == 1 ? 2 : (pr == 2 || pr == 4 ? 1 : 0);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < IB; i++)
 #pragma unroll
           for (int j = 0; j < 4; j++)      // operands swapped: a lane then holds 4 consecutive columns of one row
             acc[ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][pb], a[i][pa], acc[ih + i][j], 0, 0, 0);
@@ -764,10 +765,21 @@ int launch_gemm_bf16(ffh_ctx* c, GemmArgs& g, ffh_stream s, const char* name) {
       // (128 x 128 tiles only: with 128 x 64 per wave the 16 x 16 accumulators, two operands' fragments and the staging registers do not fit 256 VGPRs)
       const int vx = (g.N + kBfBN - 1) / kBfBN, vy = (g.M + kBfBM - 1) / kBfBM;
       if (vy > 65535) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "gemm (bf16x3): grid too large");
+      // few tiles (at most ~one per CU: 4096 x 3456 -> 1024 forward has 256): the same tile on EIGHT waves of 32 x 64 instead of four of 64 x 64 --
+      // a CU that holds one workgroup then has two waves per SIMD, one's loads and LDS passes under the other's MFMAs (same sums per
+      // accumulator, same bits)
+      static const int w8_pct = FFH_LAB_INT("FFH_X3V_W8_PCT", 150);      // A/B switch: eight waves up to this many tiles, in per cent of the CUs
+      if ((int64_t)vx * vy * 100 <= (int64_t)c->num_cus * w8_pct) {
+        auto kv8 = gemm_bf16x3_v2_kernel<BKC, MASK_A, 128, 128, 32>;
+        static const bool okv8 = glds_set_lds(kv8, kX3Lds);
+        if (!okv8) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16x3): cannot reserve 48 KB of LDS");
+        hipLaunchKernelGGL(kv8, dim3(vx, vy, 1), dim3(512), kX3Lds, as_stream(s), g);
+      } else {
       auto kv = gemm_bf16x3_v2_kernel<BKC, MASK_A>;
       static const bool okv = glds_set_lds(kv, kX3Lds);
       if (!okv) return ffh_fail(c, FFH_ERR_HIP, "gemm (bf16x3): cannot reserve 48 KB of LDS");
       hipLaunchKernelGGL(kv, dim3(vx, vy, 1), dim3(256), kX3Lds, as_stream(s), g);
+      }
       hipError_t ev = hipGetLastError();
       if (ev != hipSuccess) return ffh_fail_hip(c, ev, name);
       return x3_image_of_c();

@@ -214,6 +214,42 @@ def test_x3_dma_gemms_from_images_meet_the_fp32_bound_and_write_images(hip_x3, B
 
 
 @pytest.mark.gpu
+def test_split_mode_bits_of_a_row_do_not_depend_on_the_kernel_that_computed_it(hip_x3):
+    """Three kernels serve the split mode's forward, by tile count: the LDS-DMA kernel from images (16384 samples of 1024 -> 1024: 256 tiles of
+    256 x 256), the split-in-kernel form on four waves of 64 x 64 (8192 samples: 512 tiles of 128 x 128) and on eight waves of 32 x 64 (4096
+    samples: 256 tiles, one workgroup per CU).  All three add the same six products per k-step in the same order, and a row of y depends on
+    its own row of x only: the first 4096 / 8192 rows of the big call are the small calls' results BIT FOR BIT (and so are the data gradients)."""
+    import torch
+    hip, dev = hip_x3, "cuda:0"
+    IN = OUT = 1024
+    rng = np.random.default_rng(77)
+    x = np.maximum(rng.uniform(-1, 1, (16384, IN)), 0).astype(np.float32)
+    w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+    b = rng.uniform(-1, 1, OUT).astype(np.float32)
+    dy = (rng.uniform(-1, 1, (16384, OUT)) / 16384).astype(np.float32)
+    wd, bd = torch.from_numpy(w).to(dev), torch.from_numpy(b).to(dev)
+    res, routes = {}, {}
+    for B in (16384, 8192, 4096):
+        xd = torch.from_numpy(x[:B]).to(dev); dyd = torch.from_numpy(dy[:B]).to(dev)
+        y = torch.full((B, OUT), 3.0, device=dev); dx = torch.full((B, IN), 9.0, device=dev)
+        with Images(hip, x=xd, w=wd, y=y, dy=dyd, dx=dx) as im:
+            im.convert("x", "w", "dy")
+            hip.call("ffh_linear_fwd", xd, IN, y, OUT, wd, bd, IN, OUT, B, capi.AC_MODE_RELU, None)
+            r_f = hip.lib.ffh_linear_last_route(hip.ctx).decode()
+            flags = capi.LINEAR_ONLY_DX | capi.LINEAR_DX_OVERWRITE | capi.LINEAR_DY_PREMASKED | capi.LINEAR_DX_MASK_BY_X
+            hip.call("ffh_linear_bwd_ex", xd, IN, dx, IN, y, OUT, dyd, OUT, wd, torch.zeros(OUT, IN, device=dev), None, IN, OUT, B, capi.AC_MODE_RELU, flags, None, None)
+            r_b = hip.lib.ffh_linear_last_route(hip.ctx).decode()
+            torch.cuda.synchronize()
+            res[B] = (y.cpu().numpy(), dx.cpu().numpy()); routes[B] = (r_f, r_b)
+    print(routes)
+    assert "x3_dma_256x256" in routes[16384][0] and "x3_dma_256x256" in routes[16384][1], routes
+    assert "bf16x3_128x128" in routes[8192][0] and "bf16x3_128x128" in routes[4096][0], routes
+    for B in (8192, 4096):
+        assert res[16384][0][:B].tobytes() == res[B][0].tobytes(), f"y: the first {B} rows differ from the {B}-sample call"
+        assert res[16384][1][:B].tobytes() == res[B][1].tobytes(), f"dx: the first {B} rows differ from the {B}-sample call"
+
+
+@pytest.mark.gpu
 def test_x3_dma_declines_what_it_cannot_serve_and_the_fallback_keeps_the_image(hip_x3, oracle):
     """Shapes the LDS-DMA form does not take (too few tiles, a reduction depth that is not a multiple of 32, an operand that does not start a
     group): the split-in-kernel form runs, the result meets the same bound, and the registered image of y is still the image of what was
