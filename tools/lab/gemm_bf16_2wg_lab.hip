@@ -1,5 +1,8 @@
 // gemm_bf16_2wg_lab.hip -- stand-alone lab for the tensor-op (bf16 operands, fp32 accumulate) GEMM with TWO independent workgroups per CU
-// (not part of the product; the kernel moves to csrc/linear_bf16_dma2.hip once it measures).
+// (not part of the product).  OUTCOME (round 6): correct, and not taken -- with the DMA removed from its loop this kernel runs at 1.5 PFLOP/s, with the
+// MFMAs removed it takes as long as with them: it is bound by the rate LDS-DMA fills LDS (~11 TB/s chip-wide on either tile shape), and a 128 x 256
+// tile needs 1.5x the operand bytes per flop of the 256 x 256 one.  Wired into the library for the forward of layers up to 1024 deep it was level
+// alone (32768 x 1024 -> 1024: 101 vs 96 us through the C-ABI) and slower in the step (120 vs 99 us).  profiles/r06_lab_gemm_bf16_2wg.txt.
 //
 // Why: csrc/linear_bf16_dma.hip runs one workgroup of 8 waves per CU on a 256 x 256 tile with all 160 KB of LDS.  Its main loop reaches
 // ~1.4 PFLOP/s, but every workgroup of a round reaches its epilogue at the same time: 256 tiles x 256 x 256 x 6 bytes (fp32 + bf16 twin) leave
