@@ -106,6 +106,7 @@ class FFConfig {
   bool fp32_split_bf16x3;      // --fp32-split-bf16x3: wide Linear GEMMs fp32-accurate on the bf16 pipe (FFH_MATH_FP32_SPLIT_BF16X3)
   bool allow_tensor_op_math_conversion;   // --allow-tensor-op-math-conversion: bf16-operand MFMA GEMMs for the wide Linear layers (ffh_ctx_set_math_mode)
   bool bf16_convert_twins;               // tensor-op mode: a twin by conversion behind an fp32-kernel Linear that feeds a bf16-pipe one (--no-bf16-convert-twins)
+  bool bf16_exact_small_backward;        // tensor-op mode: the backward of a small layer with a live activation derivative in exact mode (--no-bf16-exact-small-backward)
   bool bf16_twins, force_async_launch;   // --no-bf16-twins / --force-async-launch (A/B and test switches; they used to be environment variables)
   bool capture_exchange;             // --capture-exchange: world_size > 1 with collectives enqueued from C++ (RcclComm): the step is captured / replayed as a hipGraph
   bool pad_linear_k;                 // (A/B: --no-pad-linear-k) zero-pad the input / kernel of a wide Linear whose in_dim is not a multiple of 64
@@ -332,6 +333,9 @@ class Linear : public Op {
                                    // launches all of them (ffh_mlp_chain_fwd, ABI 12)
   mutable bool fwd_done_by_chain;  // set by the chain's lowest layer for this forward()
   void* out_twin = nullptr;        // tensor-op mode: where forward() leaves the bf16 rounding of its output (allocate() step 7), or null
+  bool bwd_exact = false;          // tensor-op mode: backward() runs this layer's two GEMMs in exact mode (allocate() step 7: a small layer whose dy arrives with a live activation derivative)
+  void* dx_twin = nullptr;         // ... and then refreshes the bf16 twin of the data gradient it stored, where that buffer has one
+  bool dx_twin_registered = false;
   bool dx_image = false;           // split mode: backward() leaves the three-plane image of the data gradient it stores (allocate() step 7)
   bool out_twin_x3 = false;        // ... split mode: out_twin is the output's three-plane image (ffh_convert_f32_to_bf16x3 finds it by the registration)
   std::vector<Linear*> chain_bwd;  // non-empty on the TOP layer of the chain FFModel::backward runs as one call (ffh_mlp_chain_bwd): members bottom -> top

@@ -134,6 +134,11 @@ int64_t flexflow_model_get_counter(flexflow_model_t m, const char* name) {
   }
   if (n == "allreduce_bucket_channel_own") return M(m)->config.comm.bucket_channel_own;
   if (n == "direct_allreduces") return M(m)->n_direct_allreduces;
+  if (n == "tensor_op_exact_backward_layers") {      // Linear layers whose backward runs in exact mode under --allow-tensor-op-math-conversion (allocate() step 7)
+    int64_t k = 0;
+    for (Op* op : M(m)->layers) if (op->op_type == OP_LINEAR && static_cast<Linear*>(op)->bwd_exact) k++;
+    return k;
+  }
   return -1;
 }
 

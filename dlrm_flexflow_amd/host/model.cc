@@ -560,7 +560,16 @@ void Linear::backward_part(const FFModel& ff, int part) {
     ~ColsumScope() { if (lo) lo->db_from_upper = ff.api->ffh_linear_dx_colsum_used(ff.ctx) != 0; }
   } colsum_scope(ff, colsum_lower, dx != nullptr && (part == 0 || part == 1) && !ff.use_workers() && !ff.config.profiling);
   // split mode, this layer on the fp32 kernels under one that streams images: the image of the data gradient just stored (allocate(), step 7)
-  auto image_dx = [&] { if (dx_image && dx) ff.check(ff.api->ffh_convert_f32_to_bf16x3(ff.ctx, dx, b, in_channels, lddx, ff.stream), name); };
+  // tensor-op mode, bwd_exact: the twin of the data gradient the exact kernels stored
+  auto image_dx = [&] {
+    if (dx_image && dx) ff.check(ff.api->ffh_convert_f32_to_bf16x3(ff.ctx, dx, b, in_channels, lddx, ff.stream), name);
+    if (bwd_exact && dx && dx_twin) ff.check(ff.api->ffh_convert_f32_to_bf16(ff.ctx, dx_twin, dx, b * (int64_t)in_channels, ff.stream), name);
+  };
+  struct ExactScope {      // (allocate() step 7: bwd_exact)
+    const FFModel& ff; bool on;
+    ExactScope(const FFModel& f, bool o) : ff(f), on(o) { if (on) ff.check(ff.api->ffh_ctx_set_math_mode(ff.ctx, FFH_MATH_DEFAULT), "math mode"); }
+    ~ExactScope() { if (on) ff.check(ff.api->ffh_ctx_set_math_mode(ff.ctx, FFH_MATH_TENSOR_OP_BF16), "math mode"); }
+  } exact_scope(ff, bwd_exact && !ff.use_workers());
   if (part == 1) {
     ff.check(ff.api->ffh_linear_bwd_ex(ff.ctx, xp, ldx, dx, lddx, yp, ldy, dyp, lddy, wp, dwp, dbp, in_padded, out_channels, b, (int)activation,
                                        flags | FFH_LINEAR_ONLY_DX, ff.stream, nullptr), name);

@@ -779,7 +779,7 @@ void FFModel::allocate() {
   // (6 bytes per element; FFH_BF16X3_IMAGE_BYTES): its GEMMs then stream the operands' bf16 terms by LDS-DMA instead of splitting fp32 tiles in
   // registers (csrc/linear_x3_dma.hip).  twin_at() below is the one place the two layouts differ for this layer.
   n_twin_regions = 0;
-  for (Op* op : layers) if (op->op_type == OP_LINEAR) static_cast<Linear*>(op)->dx_image = false;
+  for (Op* op : layers) if (op->op_type == OP_LINEAR) { Linear* li = static_cast<Linear*>(op); li->dx_image = false; li->bwd_exact = false; li->dx_twin = nullptr; li->dx_twin_registered = false; }
   const bool x3_images = config.fp32_split_bf16x3 && !config.allow_tensor_op_math_conversion;
   if ((config.allow_tensor_op_math_conversion || x3_images) && config.bf16_twins && mlp_count > 0) {
     const size_t ab = std::max<size_t>(act_bytes, 256);
@@ -854,8 +854,14 @@ void FFModel::allocate() {
       // shape, of which the bottom MLP reads 128 through a live relu') has no such reader: 226 MB per step not written
       const Linear* prod = op->op_type == OP_LINEAR ? static_cast<const Linear*>(op) : nullptr;
       const bool twin_read = prod && twin_linear(prod) && (prod->dy_premasked || prod->activation == AC_MODE_NONE);
-      if (ncons == 1 && twin_read && only && (twin_linear(only) || skinny_twin(only)) && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange)
+      if (ncons == 1 && twin_read && only && (twin_linear(only) || skinny_twin(only)) && only->dx_overwrite && !only->discard_input_grad && im->grad && !exchange) {
         reg(im->grad, im->bytes, twin_at(grad_twin, (size_t)((const char*)im->grad - act_grad_slab)));
+        if (!x3_images) {      // (bwd_exact below)
+          Linear* o = const_cast<Linear*>(only);
+          o->dx_twin_registered = true;
+          if (im->grad_ld == op->outputs[0].adim[0]) o->dx_twin = twin_at(grad_twin, (size_t)((const char*)im->grad - act_grad_slab));
+        }
+      }
       // split mode: the consumer is a Linear on the fp32 kernels (below FFH_BF16X3_MIN_WEIGHTS: 512 -> 256 on top of the Terabyte MLP) -- the image of
       // the data gradient it stores by a pass behind its backward call (Linear::backward_part), so that the layer this gradient is the dy of
       // (1024 -> 512) streams it: 60 us of conversion for 170 us of split-in-kernel GEMM at 32768 samples
@@ -866,6 +872,21 @@ void FFModel::allocate() {
       }
     }
   }
+  // tensor-op mode: a SMALL layer whose dy arrives with a live activation derivative (the bottom MLP's last layer under the Concat: relu' cannot be
+  // folded into the producer of dy) runs its backward in EXACT mode.  On the bf16 pipe that backward is a pass over dy (relu', bias gradient) and
+  // two GEMMs on the converting 128 x 128 kernel, because dy, changed in place, has no valid twin: 256 -> 128 at 32768 samples 114 us alone against
+  // 98 on the fp32 kernels (which fuse the mask), and 420 us of kernel time in the step's tail beside the table update.  The mode is per-ctx
+  // state: backward() switches it around that one call, for whichever kernel library is loaded (the oracle follows the same host code).
+  if (config.allow_tensor_op_math_conversion && !x3_images && config.bf16_exact_small_backward && !use_workers())
+    for (Op* op : layers) {
+      if (op->op_type != OP_LINEAR) continue;
+      Linear* li = static_cast<Linear*>(op);
+      const double flop = 2.0 * (double)local_rows(li->outputs[0], this) * (double)li->in_padded * (double)li->out_channels;
+      if (li->in_channels < FFH_BF16_MIN_DIM || li->out_channels < FFH_BF16_MIN_DIM || flop >= 4.0e9) continue;
+      if (li->dy_premasked || (li->activation != AC_MODE_RELU && li->activation != AC_MODE_SIGMOID)) continue;
+      if (li->pair_upper || li->pair_lower || (li->dx_twin_registered && !li->dx_twin)) continue;
+      li->bwd_exact = true;
+    }
   check(api->ffh_stream_sync(ctx, stream), "allocate sync");
 }
 

@@ -60,6 +60,7 @@ FFConfig::FFConfig() {
   capture_exchange = false;
   bf16_twins = true;
   bf16_convert_twins = true;
+  bf16_exact_small_backward = true;
   force_async_launch = false;
   sparse_embedding_optimizer = false;
   allow_tensor_op_math_conversion = false;
@@ -141,6 +142,7 @@ void FFConfig::parse_args(char** argv, int argc) {
     if (is("--early-sort")) { early_sort = 1; continue; }
     if (is("--no-pad-linear-k")) { pad_linear_k = false; continue; }
     if (is("--capture-exchange")) { capture_exchange = true; continue; }
+    if (is("--no-bf16-exact-small-backward")) { bf16_exact_small_backward = false; continue; }      // A/B: every wide layer's backward on the bf16 pipe
     if (is("--no-bf16-convert-twins")) { bf16_convert_twins = false; continue; }    // A/B: no twin by conversion behind an fp32-kernel layer
     if (is("--no-bf16-twins")) { bf16_twins = false; continue; }               // A/B and tests: tensor-op mode rounding its operands inside the kernels
     if (is("--force-async-launch")) { force_async_launch = true; continue; }   // tests: the launch-worker threads on a synchronous backend

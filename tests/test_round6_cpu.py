@@ -136,3 +136,41 @@ def test_direct_allreduce_equals_the_ring_and_is_identical_on_every_rank(tmp_pat
         if k.startswith("s") and ("top" in k or "bot" in k) and all(k in z.files for z in recs):      # the MLPs' parameters: data-parallel, one copy per rank
             for r in range(1, world):
                 assert recs[0][k].tobytes() == recs[r][k].tobytes(), f"{k}: ranks 0 and {r} differ"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# tensor-op mode: the backward of a small layer with a live activation derivative in exact mode (FFModel::allocate step 7, bwd_exact)
+def test_tensor_op_mode_runs_the_small_live_relu_backward_in_exact_mode():
+    """Host logic on the oracle kernels: bottom MLP 13-256-128 under a Concat, top 384-256-1.  With --allow-tensor-op-math-conversion the
+    bottom MLP's last layer (256 -> 128: wide enough for the bf16 pipe, its dy arrives from the Concat with relu' still to apply) is the one
+    layer whose backward the shim switches to exact mode; --no-bf16-exact-small-backward keeps it on the bf16 pipe.  Both are the same
+    mathematics to bf16 accuracy and not the same bits; the first is closer to the all-exact run in that layer's weight gradient."""
+    from dlrm_flexflow_amd import ffmodel
+
+    def run(extra):
+        args = ["--backend", H.oracle_backend(), "-b", "64", "--arch-sparse-feature-size", "128", "--arch-embedding-size", "300-70",
+                "--arch-mlp-bot", "13-256-128", "--arch-mlp-top", "384-256-1", "--data-size", "64"] + extra
+        app = ffmodel.DLRM(args)
+        w0 = {l: app.model.parameter(l, 0).get_weights() for l in range(app.model.num_layers) if app.model.layer_num_weights(l)}
+        app.warmup()
+        app.train_steps(1)
+        m = app.model
+        m.sync()
+        res = {l: m.parameter(l, 0).get_weights() - w0[l] for l in w0}
+        n = m.counter("tensor_op_exact_backward_layers")
+        app.close()
+        return res, n
+
+    exact, n0 = run([])
+    on, n1 = run(["--allow-tensor-op-math-conversion"])
+    off, n2 = run(["--allow-tensor-op-math-conversion", "--no-bf16-exact-small-backward"])
+    assert (n0, n1, n2) == (0, 1, 0), (n0, n1, n2)
+    layer = 1                                     # layers: 0 = 13 -> 256, 1 = 256 -> 128, then the tables, the Concat, the top MLP
+    assert exact[layer].shape == (128, 256)
+    assert not np.array_equal(on[layer], off[layer])
+    scale = np.abs(exact[layer]).max()
+    e_on, e_off = np.abs(on[layer] - exact[layer]).max() / scale, np.abs(off[layer] - exact[layer]).max() / scale
+    assert e_on < 0.06 and e_off < 0.06, (e_on, e_off)          # both: the mode's accuracy on a one-step weight delta (dy itself comes through bf16 layers above)
+    # the mean error of the layer's weight update: without the rounding of dy and x in this layer's own GEMM it is the smaller one
+    m_on, m_off = np.abs(on[layer] - exact[layer]).mean(), np.abs(off[layer] - exact[layer]).mean()
+    assert m_on < m_off, (m_on, m_off)
