@@ -75,7 +75,10 @@ bool FFModel::early_sort_possible(int where) const {
   // the next gather, so the sort leaves that chain; on one GPU it pays at small per-GPU batches (4096 samples: 1.178 vs 1.191 ms)
   // and costs at large ones, where it runs beside the top MLP's first forward GEMM (32768: 7.76-7.79 vs 7.71-7.73; 8192, MLPerf
   // shape: 1.236-1.239 vs 1.227-1.233)
-  const int mode = config.early_sort > 0 ? config.early_sort : ((!exchange && local_batch >= 8192) ? early_sort_big_batch_mode : 1);
+  // (round 6) in the two bf16-pipe math modes the GEMMs the update used to hide under are 1.5-4x shorter and the sort sits on the step's
+  // critical chain [sort -> apply -> gather] at every batch: early there (32768 samples: split mode 5.21-5.27 vs 5.28-5.31 ms, tensor-op 1.949-1.960 vs 1.969-1.972)
+  const bool exact_gemms = !config.allow_tensor_op_math_conversion && !config.fp32_split_bf16x3;
+  const int mode = config.early_sort > 0 ? config.early_sort : ((!exchange && local_batch >= 8192 && exact_gemms) ? early_sort_big_batch_mode : 1);
   if (mode != where) return false;
   int n = 0, cols = -1;
   for (const EmbShard& sh : shards) {
