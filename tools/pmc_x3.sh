@@ -6,7 +6,7 @@ M=${1:-2}
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/a -- python3 tools/x3_probe.py $M > $O/a.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d $O/b -- python3 tools/x3_probe.py $M > $O/b.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_MISC --output-format csv -d $O/c -- python3 tools/x3_probe.py $M > $O/c.log 2>&1
-tail -1 $O/a.log $O/b.log $O/c.log
+for f in $O/a.log $O/b.log $O/c.log; do tail -n 1 $f; done
 python3 tools/pmc_summary.py --all $(find $O -name "*counter_collection.csv") > $O/summary.json
 python3 - <<PY
 import json
