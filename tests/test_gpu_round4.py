@@ -461,7 +461,7 @@ def _digest_of_touched_rows(hip, app, steps_ids=None):
 
 
 @pytest.mark.timeout(3000)
-@pytest.mark.parametrize("full_size", [False, True, 4096, "8192-mlperf"])
+@pytest.mark.parametrize("full_size", [False, True, 4096, "8192-mlperf", "split", "tensor-op"])
 def test_benched_step_overlapped_equals_serial_bit_for_bit_under_deterministic(hip, full_size):
     """The composition the per-layer tests cannot see -- aliasing into the Concat buffer, premasked dy across layers, forked weight
     gradients, the early sort, the next gather beside the last weight-gradient GEMM -- at the size the driver times: three steps
@@ -476,6 +476,10 @@ def test_benched_step_overlapped_equals_serial_bit_for_bit_under_deterministic(h
     # (round 6) 4096 and the MLPerf shape at 8192 samples (BASELINE configs[3] per GPU): the bottom MLP's backward runs as the CHAIN launches there
     # (mlp_chain_dx_kernel / mlp_chain_dw_kernel beside the biggest weight-gradient GEMM and the table update) -- deterministic mode now takes
     # them (the splits of a weight-gradient block are added in split order by a second launch), and the test asserts that it did
+    # (round 6) "split" / "tensor-op": the benched shape in the two bf16-pipe math modes -- the three-plane images / bf16 twins add writers and
+    # readers on three streams (the gather's image on the side stream, the optimizer's refresh of the weights' image, conversions behind fp32-kernel
+    # layers, the early sort at every batch): a stale or half-written image is exactly the kind of bug only the composition shows
+    mode_flags = {"split": ["--fp32-split-bf16x3"], "tensor-op": ["--allow-tensor-op-math-conversion"]}.get(full_size, [])
     mlperf = full_size == "8192-mlperf"
     batch = 4096 if full_size == 4096 else (8192 if mlperf else 32768)
     rows = TERABYTE_ROWS if full_size is True else [min(r, 100000) for r in TERABYTE_ROWS]
@@ -485,7 +489,7 @@ def test_benched_step_overlapped_equals_serial_bit_for_bit_under_deterministic(h
                 "--arch-mlp-top", "479-1024-1024-512-256-1", "--arch-interaction-op", "dot-tril", "--data-size", str(batch)]
     runs = []
     for flags in ([], ["--no-overlap", "--no-early-sort", "--serial-dw"]):
-        app = ffmodel.DLRM(["--backend", HIP, "--deterministic"] + args + flags)
+        app = ffmodel.DLRM(["--backend", HIP, "--deterministic"] + mode_flags + args + flags)
         app.warmup()
         app.train_steps(3, trace=False)
         app.model.sync()
