@@ -186,12 +186,18 @@ def test_ranks_on_one_gpu_any_optimizer_equals_one_rank(hip, tmp_path, world, mo
     assert seen == set(range(len(rows)))
 
 
-def test_weight_twin_is_fresh_under_a_replayed_step_after_a_host_write(hip):
+@pytest.mark.parametrize("mode", ["tensor-op", "split"])
+def test_weight_twin_is_fresh_under_a_replayed_step_after_a_host_write(hip, mode):
     """Round-3 advisor (medium): tensor-op mode + hipGraph replay -- forward() returns at once when replaying, so the bf16 twin of
     the weights was reconverted only AFTER the replayed step had used the stale one.  Kaggle widths (432->512, 512->256 read twins):
     two traced steps, then every MLP weight is overwritten from the host, then one more replayed step -- against the same
-    sequence with eager launches."""
-    args = H.KAGGLE_ARGS(2048) + ["--allow-tensor-op-math-conversion"]
+    sequence with eager launches.  (round 6) "split": the same for the three-plane image of the weights, on a model whose layers are
+    big enough for the mode to take them (16384 samples, 384 -> 1024 -> 512 -> 1: 1.3e10 / 1.7e10 flop per GEMM)."""
+    if mode == "tensor-op":
+        args = H.KAGGLE_ARGS(2048) + ["--allow-tensor-op-math-conversion"]
+    else:
+        args = ["-b", "16384", "--arch-sparse-feature-size", "128", "--arch-embedding-size", "3000-700", "--arch-mlp-bot", "13-256-128",
+                "--arch-mlp-top", "384-1024-512-1", "--data-size", "16384", "--fp32-split-bf16x3"]
     outs = []
     for trace in (True, False):
         app = ffmodel.DLRM(["--backend", HIP] + args + ([] if trace else ["--no-trace"]))
