@@ -191,7 +191,9 @@ int         ffh_convert_f32_to_bf16(ffh_ctx* ctx, void* dst_bf16, const float* s
  * From then on, in FFH_MATH_FP32_SPLIT_BF16X3 only,
  *   the producers listed for the bf16 twins above (ffh_linear_fwd: y; ffh_linear_bwd / _ex / _mse: dx; ffh_embedding_fwd / _multi: out, for
  *   leading dimensions that are multiples of 32; ffh_sgd_update / _ex, ffh_adam_update: w; ffh_convert_f32_to_bf16x3: explicit) keep the image of
- *   what they write into a registered region current;
+ *   what they write into a registered region current -- the Linear entries under the same condition as for the twins: when the call runs on the
+ *   mode's kernels (both dims >= FFH_BF16_MIN_DIM and, in FFH_MATH_FP32_SPLIT_BF16X3 proper, the FFH_BF16X3_MIN_FLOP rule; ffh_linear_last_route then
+ *   names "bf16x3" or "x3_dma" for that GEMM).  A layer the mode leaves to the fp32 kernels writes fp32 only: refresh with ffh_convert_f32_to_bf16x3;
  *   a wide Linear GEMM takes BOTH operands from their images when both lie in registered regions, start a 32-element group and have leading
  *   dimensions that are multiples of 32 (reduction depth a multiple of 32); otherwise it splits in the kernel as before.
  * Same arithmetic either way (the six products per 32-deep k-step in the same order, fp32 accumulation): a forward / data-gradient result is
