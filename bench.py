@@ -364,7 +364,8 @@ def bf16_mode_block(ffmodel, w, local_rank, B, split=False):
                 "algorithmic_flop_per_launch": 2.0 * B * int(i_o.split("->")[0]) * int(i_o.split("->")[1]),
                 "note": "achieved = fp32-equivalent flops (2 * batch * in * out) over the launch time (HIP events on the model's stream, back to back, settled clocks); "
                         "peak = dense bf16 MFMA peak / 6: six bf16 products make one fp32-accurate product; counters: profiles/r06_pmc_split_bf16x3_gemm.json "
-                        "(matrix pipe busy 86 % of the launch, 0.26 other vector instructions per MFMA)"}
+                        "(matrix pipe busy 86 % of the launch, 0.26 other vector instructions per MFMA); bare MFMAs of this shape sustain 0.81-0.82 of `peak` on this part "
+                        "(338-342 TFLOP/s in these units: profiles/r06_lab_mfma_power_probe.txt)"}
         return {"flag": "--fp32-split-bf16x3 (ffh_ctx_set_math_mode(FFH_MATH_FP32_SPLIT_BF16X3)); opt-in: `value` above stays the exact-fp32-MFMA route",
                 "metric": "dlrm_training_samples_per_sec", "value": round(B / dt, 1), "unit": "samples/s", "ms_per_step": round(dt * 1e3, 4), "steps": n, "dtype": "f32",
                 "parity": "the SAME bound as the exact-fp32 kernels: |error| <= 1e-5 of the term mass (sum_k |a_k b_k|) + 1e-6 against float64 / the fp32 oracle, every GEMM form "
