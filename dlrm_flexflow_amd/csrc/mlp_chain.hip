@@ -668,6 +668,17 @@ void fill_layer(ChLayer& d, const ffh_chain_layer& s) {
 
 }  // namespace
 
+// The chains run on the exact-fp32 kernels.  FFH_MATH_FP32_SPLIT_BF16X3 proper leaves a layer to those kernels where its GEMMs are below
+// FFH_BF16X3_MIN_FLOP (round 6: a chain of narrow layers always is, up to ~19000 samples at 512 x 512) -- then a chain is the per-layer calls of
+// that mode exactly; a chain with a layer the mode would take, the tensor-op mode and the every-shape test mode refuse the chain as before.
+static bool chain_math_mode_ok(const ffh_ctx* c, const ffh_chain_layer* layers, int nlayers, int64_t batch) {
+  if (c->math_mode == FFH_MATH_DEFAULT) return true;
+  if (c->math_mode != FFH_MATH_FP32_SPLIT_BF16X3) return false;
+  for (int l = 0; l < nlayers; l++)
+    if (ffh_gemm::use_bf16(c, layers[l].in_dim, layers[l].out_dim, batch)) return false;
+  return true;
+}
+
 extern "C" {
 
 int ffh_mlp_chain_fwd(ffh_ctx* c, const float* x, int64_t ldx, const ffh_chain_layer* layers, int nlayers, int64_t batch, ffh_stream s) {
@@ -680,7 +691,7 @@ int ffh_mlp_chain_fwd(ffh_ctx* c, const float* x, int64_t ldx, const ffh_chain_l
     if (act != FFH_AC_MODE_NONE && act != FFH_AC_MODE_RELU && act != FFH_AC_MODE_SIGMOID && act != FFH_AC_MODE_GELU)
       return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_fwd: activation not supported (NONE, RELU, SIGMOID, GELU)");
   }
-  if (c->math_mode != FFH_MATH_DEFAULT) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_fwd: fp32 math mode only");
+  if (!chain_math_mode_ok(c, layers, nlayers, batch)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_fwd: layers of the exact-fp32 kernels only (math mode)");
   ffh_route_clear(c);
   if (batch == 0) return FFH_OK;
   ChainFwdArgs a{};
@@ -723,7 +734,7 @@ int ffh_mlp_chain_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   for (int l = 0; l < nlayers; l++) {
     FFH_REQUIRE(c, layers[l].dy && layers[l].dw && layers[l].lddy >= layers[l].out_dim, "mlp_chain_bwd: null pointer / leading dimension");
   }
-  if (c->math_mode != FFH_MATH_DEFAULT) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: fp32 math mode only");
+  if (!chain_math_mode_ok(c, layers, nlayers, batch)) return ffh_fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: layers of the exact-fp32 kernels only (math mode)");
   const ffh_chain_layer& top = layers[nlayers - 1];
   const bool premasked = (flags & FFH_LINEAR_DY_PREMASKED) != 0;
   if (top.activation != FFH_AC_MODE_NONE && top.activation != FFH_AC_MODE_RELU && top.activation != FFH_AC_MODE_SIGMOID)

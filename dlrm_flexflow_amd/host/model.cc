@@ -624,8 +624,9 @@ void Linear::backward_dw_rows(const FFModel& ff, int row0, int nrows) {
 
 // ---- chains of narrow Linear layers (ffh_mlp_chain_fwd / _bwd, ABI 12; built in FFModel::allocate step 4e) -------------------
 bool FFModel::mlp_chain_usable(int64_t rows, bool fwd) const {
-  return config.mlp_chain && !config.profiling && !use_workers() && !config.allow_tensor_op_math_conversion &&
-         !config.fp32_split_bf16x3 && rows <= config.mlp_chain_max_batch && (!fwd || (rows >= config.mlp_chain_fwd_min_batch && rows <= config.mlp_chain_fwd_max_batch));
+  // (the split mode leaves the narrow layers of a chain to the exact kernels: the library takes the chain there, allocate() step 7 drops a chain
+  //  with a member that keeps an image by conversion)
+  return config.mlp_chain && !config.profiling && !use_workers() && !config.allow_tensor_op_math_conversion && rows <= config.mlp_chain_max_batch && (!fwd || (rows >= config.mlp_chain_fwd_min_batch && rows <= config.mlp_chain_fwd_max_batch));
 }
 static void fill_chain(const std::vector<Linear*>& ch, ffh_chain_layer* out) {
   for (size_t i = 0; i < ch.size(); i++) {

@@ -579,7 +579,7 @@ void FFModel::allocate() {
   // the exchange path's column map.
   for (Op* op : layers)
     if (Linear* li = dynamic_cast<Linear*>(op)) { li->chain_fwd.clear(); li->chain_bwd.clear(); li->fwd_done_by_chain = false; }
-  if (config.mlp_chain && !config.profiling && !config.async_launch && !config.allow_tensor_op_math_conversion && !config.fp32_split_bf16x3) {
+  if (config.mlp_chain && !config.profiling && !config.async_launch && !config.allow_tensor_op_math_conversion) {      // (split mode: see the end of step 7)
     auto member_ok = [&](const Linear* li) {
       return li->in_channels <= FFH_CHAIN_MAX_WIDTH && li->out_channels <= FFH_CHAIN_MAX_WIDTH && li->in_padded == li->in_channels &&
              li->inputs[0].impl->pieces.empty() && li->outputs[0].impl->pieces.empty() && li->inputs[0].impl->ptr && li->outputs[0].impl->ptr;
@@ -886,6 +886,17 @@ void FFModel::allocate() {
       if (li->dy_premasked || (li->activation != AC_MODE_RELU && li->activation != AC_MODE_SIGMOID)) continue;
       if (li->pair_upper || li->pair_lower || (li->dx_twin_registered && !li->dx_twin)) continue;
       li->bwd_exact = true;
+    }
+  // split mode: a chain of narrow layers (step 4e) runs as the chain launches only when none of its members keeps an image by a conversion of
+  // its own behind its per-layer call (out_twin: forward(); dx_image: backward_part()) -- the chain launches would skip that pass.  (The library
+  // refuses a chain with a member the mode's kernels would take: mlp_chain.hip, chain_math_mode_ok.)
+  if (x3_images)
+    for (Op* op : layers) {
+      if (op->op_type != OP_LINEAR) continue;
+      Linear* li = static_cast<Linear*>(op);
+      auto converts = [](const std::vector<Linear*>& ch) { for (const Linear* m : ch) if (m->out_twin || m->dx_image) return true; return false; };
+      if (converts(li->chain_fwd)) li->chain_fwd.clear();
+      if (converts(li->chain_bwd)) li->chain_bwd.clear();
     }
   check(api->ffh_stream_sync(ctx, stream), "allocate sync");
 }

@@ -585,7 +585,8 @@ int ffh_linear_pair_fwd(ffh_ctx* ctx, const float* x_l, int64_t ldx_l, const flo
  *                          FFH_LINEAR_DX_MASK_BY_X to dx.  dw / db accumulate into buffers the caller zeroed (atomics: not in
  *                          deterministic mode).  An event attached with ffh_event_record_with_next_linear_bwd is recorded behind the
  *                          data-gradient chain, in front of the weight gradients (dx and every dy are final there).
- * Served: fp32 math mode; inner activations NONE / RELU (top layer also SIGMOID; forward also GELU); backward: rows of y, dy, dx and
+ * Served: fp32 math mode -- and FFH_MATH_FP32_SPLIT_BF16X3 (proper, not _ALL) when every layer of the chain is one that mode leaves to the exact
+ * kernels (2 * batch * in * out < FFH_BF16X3_MIN_FLOP or a dim < FFH_BF16_MIN_DIM): the chain is then that mode's per-layer calls; inner activations NONE / RELU (top layer also SIGMOID; forward also GELU); backward: rows of y, dy, dx and
  * w 16-byte aligned and in_dim % 4 == 0 for every layer whose data gradient is produced.  Anything else returns FFH_ERR_UNSUPPORTED
  * with nothing launched and the caller makes the per-layer calls. */
 #define FFH_CHAIN_MAX_LAYERS 8

@@ -775,10 +775,18 @@ static float* chain_compact(const float* w, int out, int in, int ldw) {
   if (t) for (int o = 0; o < out; o++) memcpy(t + (size_t)o * in, w + (size_t)o * ldw, sizeof(float) * (size_t)in);
   return t;
 }
+/* the chain entries' math-mode rule (csrc/mlp_chain.hip, chain_math_mode_ok): exact mode, or the split mode proper with every layer below its flop rule */
+static int chain_math_mode_ok(const ffh_ctx* c, const ffh_chain_layer* ls, int n, int64_t B) {
+  if (!c || c->math_mode == FFH_MATH_DEFAULT) return 1;
+  if (c->math_mode != FFH_MATH_FP32_SPLIT_BF16X3) return 0;
+  for (int l = 0; l < n; l++)
+    if (ls[l].in_dim >= FFH_BF16_MIN_DIM && ls[l].out_dim >= FFH_BF16_MIN_DIM && 2.0 * (double)B * (double)ls[l].in_dim * (double)ls[l].out_dim >= FFH_BF16X3_MIN_FLOP) return 0;
+  return 1;
+}
 int ffh_mlp_chain_fwd(ffh_ctx* c, const float* x, int64_t ldx, const ffh_chain_layer* ls, int n, int64_t B, ffh_stream s) {
   int rc = chain_check(c, ls, n, B, "fwd");
   if (rc != FFH_OK) return rc;
-  if (c && c->math_mode != FFH_MATH_DEFAULT) return fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_fwd: fp32 math mode only");
+  if (!chain_math_mode_ok(c, ls, n, B)) return fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_fwd: layers of the exact-fp32 kernels only (math mode)");
   for (int l = 0; l < n && rc == FFH_OK; l++) {
     const ffh_chain_layer* L = &ls[l];
     const float* xin = l == 0 ? x : ls[l - 1].y;
@@ -797,7 +805,7 @@ int ffh_mlp_chain_bwd(ffh_ctx* c, const float* x, int64_t ldx, float* dx, int64_
   if (flags & ~(FFH_LINEAR_DX_OVERWRITE | FFH_LINEAR_DX_MASK_BY_X | FFH_LINEAR_DY_PREMASKED)) return fail(c, FFH_ERR_BAD_ARG, "mlp_chain_bwd: flags");
   for (int l = 0; l < n; l++)
     if (!ls[l].dy || !ls[l].dw || ls[l].lddy < ls[l].out_dim) return fail(c, FFH_ERR_BAD_ARG, "mlp_chain_bwd: null pointer / leading dimension");
-  if (c && c->math_mode != FFH_MATH_DEFAULT) return fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: fp32 math mode only");
+  if (!chain_math_mode_ok(c, ls, n, B)) return fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: layers of the exact-fp32 kernels only (math mode)");
   for (int l = 0; l + 1 < n; l++)
     if (ls[l].activation != FFH_AC_MODE_NONE && ls[l].activation != FFH_AC_MODE_RELU) return fail(c, FFH_ERR_UNSUPPORTED, "mlp_chain_bwd: inner layers NONE or RELU");
   for (int l = n - 1; l >= 0 && rc == FFH_OK; l--) {

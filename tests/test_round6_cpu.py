@@ -174,3 +174,31 @@ def test_tensor_op_mode_runs_the_small_live_relu_backward_in_exact_mode():
     # the mean error of the layer's weight update: without the rounding of dy and x in this layer's own GEMM it is the smaller one
     m_on, m_off = np.abs(on[layer] - exact[layer]).mean(), np.abs(off[layer] - exact[layer]).mean()
     assert m_on < m_off, (m_on, m_off)
+
+
+def test_split_mode_runs_the_narrow_chains_of_the_exact_kernels():
+    """--fp32-split-bf16x3 leaves narrow layers to the exact kernels (FFH_BF16X3_MIN_FLOP), so the chain launches of round 5 serve them in that mode too
+    (round 6: mlp_chain.hip chain_math_mode_ok, restated by the oracle).  Host logic on the oracle kernels: the chains run (counters), and the
+    result is the per-layer calls' bit for bit; the tensor-op mode still runs none."""
+    from dlrm_flexflow_amd import ffmodel
+
+    def run(extra):
+        args = ["--backend", H.oracle_backend(), "-b", "48", "--arch-sparse-feature-size", "16", "--arch-embedding-size", "30-11",
+                "--arch-mlp-bot", "13-96-64-16", "--arch-mlp-top", "48-24-1", "--data-size", "48", "--mlp-chain-fwd-min-batch", "1"] + extra
+        app = ffmodel.DLRM(args)
+        app.warmup()
+        app.train_steps(2)
+        m = app.model
+        m.sync()
+        res = {l: m.parameter(l, 0).get_weights() for l in range(m.num_layers) if m.layer_num_weights(l)}
+        res["pred"] = m.layer_output(m.num_layers - 1).get()
+        cnt = (m.counter("mlp_chain_fwd_calls"), m.counter("mlp_chain_bwd_calls"))
+        app.close()
+        return res, cnt
+
+    a, ca = run(["--fp32-split-bf16x3"])
+    b, cb = run(["--fp32-split-bf16x3", "--no-mlp-chain"])
+    c, cc = run(["--allow-tensor-op-math-conversion"])
+    assert ca[0] > 0 and ca[1] > 0 and cb == (0, 0) and cc == (0, 0), (ca, cb, cc)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
