@@ -812,7 +812,15 @@ void FFModel::allocate() {
       TensorImpl* im = op->outputs[0].impl;
       if (!im || !im->ptr || alias_of.count(im) || !in_slab(im->ptr) || !im->pieces.empty()) continue;
       bool act_ok = false;
-      if (twin_linear(op)) act_ok = true;
+      if (twin_linear(op)) {
+        act_ok = true;
+        if (x3_images) {      // 6 bytes per element in the epilogue: only where a layer the mode takes reads the image (its forward's x, its weight gradient's x)
+          act_ok = false;
+          for (Op* q : layers)
+            for (int i = 0; i < q->numInputs; i++)
+              if (q->inputs[i].impl == im && twin_linear(q)) act_ok = true;
+        }
+      }
       else if (Concat* c = dynamic_cast<Concat*>(op)) {
         act_ok = !exchange && c->numInputs > 0 && (!x3_images || im->ld % 32 == 0);      // (the gather writes the image of rows that are whole 32-element groups apart)
         std::vector<int> x3_convert;
