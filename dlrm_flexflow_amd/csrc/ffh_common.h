@@ -36,7 +36,8 @@ struct ffh_ctx {
   //   sk_slots / sk_cnt    stream-K partial tiles of the persistent fp32 GEMMs (linear_sk.hip): 2 x num_cus slots of 128 x 128 floats + one
   //                        arrival counter per range
   //   skinny_ws / _cnt     one-launch narrow-layer backward (linear_skinny_bwd_kernel): the workgroups' partial dW / db rows + an arrival counter
-  struct { void* stream; float* sk_slots; unsigned* sk_cnt; float* skinny_ws; unsigned* skinny_cnt; } scratch[FFH_MAX_SCRATCH_STREAMS];
+  //   x3_slots             split mode, weight gradient from images (linear_x3_dma.hip): kX3DwSlots partial tiles of 256 x 256 floats, one per (tile, k-slice)
+  struct { void* stream; float* sk_slots; unsigned* sk_cnt; float* skinny_ws; unsigned* skinny_cnt; float* x3_slots; } scratch[FFH_MAX_SCRATCH_STREAMS];
   int         nscratch;
   const void* emb_sorted_ws;     // ffh_embedding_bwd_sort_multi left a sorted list (and cleared fold counters) in THIS workspace ...
   int64_t     emb_sorted_sig[4]; // ... for this (ntables, in_dim, out_dim, batch): ffh_embedding_bwd_sgd_apply_multi consumes it, once
@@ -85,6 +86,8 @@ static inline int ffh_fail_hip(ffh_ctx* c, hipError_t e, const char* what) {
 constexpr int kSkinnyWsBlocks = 512;                       // workgroups the narrow-layer backward's scratch holds
 constexpr int kSkinnyWsRow = 4160;                          // floats per partial row: out * in + out for out <= 4, in <= 1024 (4100) and out <= 16, in <= 256 (4112)
 constexpr int kSkTileFloats = 128 * 128;                    // one stream-K slot (linear_sk.hip's tile)
+constexpr int kX3DwSlots = 512;                             // 134 MB: 3456 x 1024 at 32768 samples is 56 tiles x 9 k-slices
+constexpr int kX3TileFloats = 256 * 256;
 static inline hipStream_t as_stream(ffh_stream s) { return (hipStream_t)s; }
 
 // A/B switches of the development builds.  The release library reads NO environment variable ("no global state" behind the

@@ -65,6 +65,7 @@ struct DmaArgs {
   const float* mask;           // DX: C = mask[m][n] > 0 ? v : 0 (relu' of the layer below) or null
   const unsigned short* mask16;   // ... the bf16 twin of mask, read instead where there is one (half the bytes; same sign as the
                                //     fp32 value except 0 < x < 2^-134, which rounds to +0: stated in ff_hip.h)
+  float* slots;                // DW: null = every k-slice adds its tile to C by atomics; else it stores it to slots[(tile * splitk + ks)][256][256] (dw_tile_slots, linear_gemm.h)
   const float* Af32;           // DW with db: the fp32 matrix behind A (same strides)
   float*       db;             // DW: db[m] += sum_k A(k, m) over this workgroup's share of its k-slice, from the fp32 values
                                //     [ref: src/ops/linear.cu:644-651], or null
@@ -329,6 +330,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_dma_kernel(const DmaArgs g) 
       }
     // the wave's own block: no barrier, LDS operations of one wave execute in order
     if constexpr (EPI == DM_EPI_DW) {
+      if (g.slots) {        // plain stores of whole 128-byte runs into the slice's own slot; the ordered pass follows the launch
+        float* sl = g.slots + ((size_t)tile * (size_t)g.splitk + ks) * (size_t)(DM_BM * DM_BN) + (size_t)(half * 128 + grp * 64) * DM_BN + wc * 32;
+        const int rr8 = lane >> 3, rc8 = lane & 7;
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+            *reinterpret_cast<f32x4*>(sl + (size_t)(p * 8 + rr8) * DM_BN + h * 128 + rc8 * 4) = *reinterpret_cast<const f32x4*>(blk + (p * 8 + rr8) * EP_LD + (h * 32 + rc8 * 4) * 4);
+        continue;
+      }
       const int rr = lane >> 5, rc = lane & 31;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
@@ -433,6 +444,7 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
   a.A = g.A16; a.B = g.B16; a.C = g.C; a.C16 = form == BF16_FORM_DW ? nullptr : g.C16;
   a.bias = form == BF16_FORM_FWD ? g.bias : nullptr; a.mask = form == BF16_FORM_DX ? g.mask : nullptr;
   a.Af32 = g.A; a.db = form == BF16_FORM_DW ? g.db : nullptr;
+  if (form == BF16_FORM_DW) a.slots = dw_tile_slots(c, s, tiles, splitk, g.ldc);
   static const int mask_fp32 = FFH_LAB_INT("FFH_BF16_MASK_FP32", 0);      // A/B switch
   a.mask16 = (a.mask && !mask_fp32) ? ffh_mirror_of(c, g.mask, (size_t)((int64_t)(g.M - 1) * g.ldmask + g.N) * 4) : nullptr;
   if (a.mask16 && ((uintptr_t)a.mask16 & 7)) a.mask16 = nullptr;
@@ -451,9 +463,10 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
   else if (form == BF16_FORM_DX) FFH_DMA_LAUNCH(false, true, DM_EPI_DX)
   else FFH_DMA_LAUNCH(true, true, DM_EPI_DW)
 #undef FFH_DMA_LAUNCH
+  if (a.slots) launch_dw_tile_reduce(a.slots, g.C, g.ldc, g.M, g.N, tiles, splitk, s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, name);
-  { char tok[96]; snprintf(tok, sizeof tok, "%s|bf16_dma_256x256_twins|splitk=%d", name, splitk); ffh_route_add(c, tok); }
+  { char tok[96]; snprintf(tok, sizeof tok, "%s|bf16_dma_256x256_twins|splitk=%d%s", name, splitk, a.slots ? "|slots" : ""); ffh_route_add(c, tok); }
   return 1;
 }
 

@@ -100,6 +100,10 @@ int launch_gemm_bf16_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, 
 // Split mode, both operands with three-plane images (ffh_ctx_bf16x3_mirror_set) that start a 32-element group, leading dimensions and
 // reduction depth multiples of 32 (linear_x3_dma.hip): the LDS-DMA form of the fp32-accurate GEMM; writes the image of C beside C.
 int launch_gemm_x3_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name);       // 1 launched, 0 not served, < 0 error
+// The k-slices of a weight gradient on 256 x 256 tiles meeting through the stream's reserved slots + an ordered pass instead of float atomics
+// (both LDS-DMA kernels; linear_x3_dma.hip): slice ks of tile t stores its tile at slots + (t * splitk + ks) * 65536, then C[tile] += sum over ks in order
+float* dw_tile_slots(const ffh_ctx* c, ffh_stream s, int64_t tiles, int splitk, int64_t ldc);          // null: use atomics
+void launch_dw_tile_reduce(const float* slots, float* C, int64_t ldc, int M, int N, int64_t tiles, int splitk, ffh_stream s);
 
 // The persistent one-workgroup-per-CU fp32 kernels for the big aligned layers (linear_sk.hip): forward (bias + activation),
 // data gradient (store / add, optional relu'-of-the-layer-below mask), weight gradient (stream-K, atomics).

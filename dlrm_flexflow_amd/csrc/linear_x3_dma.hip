@@ -67,6 +67,8 @@ struct X3Args {
   const float* mask;                 // DX: C = mask[m][n] > 0 ? v : 0 (relu' of the layer below) or null
   const char* mask3;                 // ... the image of mask, whose first term is read instead where there is one (half the bytes; same sign as
                                      //     the fp32 value except 0 < x < 2^-134, which rounds to +0: stated in ff_hip.h)
+  float* slots;                      // DW: null = every k-slice adds its tile to C by atomics; else slice ks of tile t stores it to slots[(t * splitk + ks)][256][256]
+                                     //     (x3_dw_reduce_kernel then adds the slices in order: no atomics on C, the same bits every run)
   const float* Af32; float* db;      // DW: db[m] += sum_k A(k, m) over this workgroup's share of its k-slice, from the fp32 values
                                      //     [ref: src/ops/linear.cu:644-651], or null
   int64_t lda, ldb, ldc, ldmask;     // elements
@@ -344,6 +346,14 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_dma_kernel(const X3Args g) {
       }
     // the wave's own block: no barrier, LDS operations of one wave execute in order
     if constexpr (EPI == X_EPI_DW) {
+      if (g.slots) {        // whole 256-byte runs of the slice's own slot: plain stores (ctx scratch, reserved per stream)
+        float* sl = g.slots + ((size_t)tile * (size_t)g.splitk + ks) * (size_t)(X_BM * X_BN) + (size_t)(half * 128 + grp * 64) * X_BN + 64 * wc;
+        const int rr4 = lane >> 4, rc4 = lane & 15;
+#pragma unroll
+        for (int p = 0; p < 16; p++)
+          *reinterpret_cast<f32x4*>(sl + (size_t)(p * 4 + rr4) * X_BN + rc4 * 4) = *reinterpret_cast<const f32x4*>(blk + (p * 4 + rr4) * EP_LD + rc4 * 16);
+        continue;
+      }
       const int rr = lane >> 5, rc = lane & 31;
 #pragma unroll
       for (int h = 0; h < 2; h++) {
@@ -402,9 +412,38 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_dma_kernel(const X3Args g) {
   }
 }
 
+// C[tile] += slot(tile, 0) + slot(tile, 1) + ... in slice order: one thread per four columns of one row of a tile
+__global__ __launch_bounds__(256) void x3_dw_reduce_kernel(const float* __restrict__ slots, float* __restrict__ C, int64_t ldc, int M, int N, int nbx, int splitk) {
+  const unsigned tile = blockIdx.x >> 6, part = blockIdx.x & 63u;                  // 64 workgroups of 256 threads x 4 floats per tile
+  const unsigned e4 = part * 256u + threadIdx.x, r = e4 >> 6, c4 = (e4 & 63u) * 4u;
+  const int by = (int)(tile / (unsigned)nbx), bx = (int)(tile - (unsigned)by * (unsigned)nbx);
+  const int row = by * X_BM + (int)r, col = bx * X_BN + (int)c4;
+  if (row >= M || col >= N) return;
+  const float* sp = slots + (size_t)tile * (size_t)splitk * (size_t)(X_BM * X_BN) + (size_t)r * X_BN + c4;
+  f32x4 s = *reinterpret_cast<const f32x4*>(sp);
+  for (int k = 1; k < splitk; k++) s += *reinterpret_cast<const f32x4*>(sp + (size_t)k * (size_t)(X_BM * X_BN));
+  float* cp = C + (int64_t)row * ldc + col;
+  if (col + 3 < N) { *reinterpret_cast<f32x4*>(cp) = *reinterpret_cast<const f32x4*>(cp) + s; }
+  else { for (int e = 0; e < 4 && col + e < N; e++) cp[e] += s[e]; }
+}
+
 }  // namespace
 
 namespace ffh_gemm {
+
+// the stream's slots for the k-slices of a weight gradient on 256 x 256 tiles (ffh_ctx_reserve_scratch), or null: no scratch on this stream / too many slices /
+// more than one round of workgroups (with two rounds the first one's atomics run under the second one's MFMAs: 3456 x 1024 at 32768 samples 893 vs 906 us)
+float* dw_tile_slots(const ffh_ctx* c, ffh_stream s, int64_t tiles, int splitk, int64_t ldc) {
+  static const int no_slots = FFH_LAB_INT("FFH_X3_DW_NO_SLOTS", 0);      // A/B switches
+  static const int slots_rounds = FFH_LAB_INT("FFH_X3_DW_SLOTS_MAX_ROUNDS", 1);
+  if (no_slots || splitk <= 1 || tiles * splitk > kX3DwSlots || tiles * splitk > (int64_t)slots_rounds * c->num_cus || ldc % 4) return nullptr;
+  for (int i = 0; i < c->nscratch; i++)
+    if (c->scratch[i].stream == (void*)as_stream(s) && c->scratch[i].x3_slots) return c->scratch[i].x3_slots;
+  return nullptr;
+}
+void launch_dw_tile_reduce(const float* slots, float* C, int64_t ldc, int M, int N, int64_t tiles, int splitk, ffh_stream s) {
+  hipLaunchKernelGGL(x3_dw_reduce_kernel, dim3((unsigned)tiles * 64u), dim3(256), 0, as_stream(s), slots, C, ldc, M, N, (int)((N + X_BN - 1) / X_BN), splitk);
+}
 
 // 1: launched; 0: not this kernel's problem (nothing launched); < 0: error.  g.C3 (the image of C, or null) is set by the caller.
 int launch_gemm_x3_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, const char* name) {
@@ -465,6 +504,9 @@ int launch_gemm_x3_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, co
   a.bias = form == BF16_FORM_FWD ? g.bias : nullptr; a.mask = form == BF16_FORM_DX ? g.mask : nullptr;
   a.mask3 = (a.mask && g.ldmask % 32 == 0) ? ffh_planes_of(c, g.mask, (size_t)((int64_t)(g.M - 1) * g.ldmask + g.N) * 4) : nullptr;
   a.Af32 = g.A; a.db = form == BF16_FORM_DW ? g.db : nullptr;
+  // the weight gradient's k-slices through the stream's slots instead of atomics: 129 MB of float atomics (3456 x 1024, 9 slices) take ~100 us
+  // at the memory-side adders, plain stores + an ordered pass over them a third of that -- and the result no longer depends on arrival order
+  if (form == BF16_FORM_DW) a.slots = dw_tile_slots(c, s, tiles, splitk, g.ldc);
   a.lda = lda; a.ldb = ldb; a.ldc = g.ldc; a.ldmask = g.ldmask;
   a.M = g.M; a.N = g.N; a.K = g.K; a.act = g.act; a.add = g.epi == EPI_ADD; a.splitk = splitk;
   a.a_bytes = (uint32_t)a_bytes; a.b_bytes = (uint32_t)b_bytes;
@@ -480,9 +522,10 @@ int launch_gemm_x3_dma(ffh_ctx* c, const GemmArgs& g, int form, ffh_stream s, co
   else if (form == BF16_FORM_DX) FFH_X3_LAUNCH(false, true, X_EPI_DX)
   else FFH_X3_LAUNCH(true, true, X_EPI_DW)
 #undef FFH_X3_LAUNCH
+  if (a.slots) launch_dw_tile_reduce(a.slots, g.C, g.ldc, g.M, g.N, tiles, splitk, s);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ffh_fail_hip(c, e, name);
-  { char tok[112]; snprintf(tok, sizeof tok, "%s|x3_dma_256x256_planes%s|splitk=%d", name, a.C3 ? "+image" : "", splitk); ffh_route_add(c, tok); }
+  { char tok[112]; snprintf(tok, sizeof tok, "%s|x3_dma_256x256_planes%s|splitk=%d%s", name, a.C3 ? "+image" : "", splitk, a.slots ? "|slots" : ""); ffh_route_add(c, tok); }
   // the image of C where it has one the kernel could not write in place (C not at a group start, ldc not a multiple of 32)
   if (form != BF16_FORM_DW && !a.C3) {
     int col0 = 0;

@@ -55,6 +55,7 @@ static void ffh_scratch_free(ffh_ctx* c, int i) {
   if (t.sk_cnt) (void)hipFree(t.sk_cnt);
   if (t.skinny_ws) (void)hipFree(t.skinny_ws);
   if (t.skinny_cnt) (void)hipFree(t.skinny_cnt);
+  if (t.x3_slots) (void)hipFree(t.x3_slots);
   t = {};
 }
 
@@ -78,7 +79,8 @@ int ffh_ctx_reserve_scratch(ffh_ctx* c, ffh_stream st) {
   bool ok = hipMalloc((void**)&t.sk_slots, 2 * G * kSkTileFloats * sizeof(float)) == hipSuccess &&
             hipMalloc((void**)&t.sk_cnt, (G + 16) * sizeof(unsigned)) == hipSuccess &&
             hipMalloc((void**)&t.skinny_ws, (size_t)kSkinnyWsBlocks * kSkinnyWsRow * sizeof(float)) == hipSuccess &&
-            hipMalloc((void**)&t.skinny_cnt, 64) == hipSuccess;
+            hipMalloc((void**)&t.skinny_cnt, 64) == hipSuccess &&
+            hipMalloc((void**)&t.x3_slots, (size_t)kX3DwSlots * kX3TileFloats * sizeof(float)) == hipSuccess;
   // (counters cleared ON the stream the launches go to: a null-stream hipMemset is not ordered against a non-blocking stream, and a
   //  launch that finds a counter mid-way never sees its last arriver)
   ok = ok && hipMemsetAsync(t.sk_cnt, 0, (G + 16) * sizeof(unsigned), s) == hipSuccess && hipMemsetAsync(t.skinny_cnt, 0, 64, s) == hipSuccess;

@@ -250,6 +250,39 @@ def test_split_mode_bits_of_a_row_do_not_depend_on_the_kernel_that_computed_it(h
 
 
 @pytest.mark.gpu
+def test_x3_weight_gradient_through_slots_is_bit_reproducible(hip_x3):
+    """Where the k-slices of the LDS-DMA weight gradient fit one round of workgroups they meet through the stream's reserved slots and an
+    ordered pass (route token "|slots") instead of float atomics: dW of 16384 x 1024 -> 1024 and of a ragged 12320 x 1056 -> 800, four launches
+    each from a dW that already holds values -- the same bits every time, and the float64 sums at the usual bound."""
+    import torch
+    hip, dev = hip_x3, "cuda:0"
+    for B, IN, OUT in ((16384, 1024, 1024), (12320, 1056, 800)):
+        rng = np.random.default_rng(B + OUT)
+        x = np.maximum(rng.uniform(-1, 1, (B, IN)), 0).astype(np.float32)
+        dy = (rng.uniform(-1, 1, (B, OUT)) / B).astype(np.float32)
+        w = (rng.uniform(-1, 1, (OUT, IN)) / np.sqrt(IN)).astype(np.float32)
+        dw0 = rng.uniform(-1, 1, (OUT, IN)).astype(np.float32)
+        xd, dyd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(dy).to(dev), torch.from_numpy(w).to(dev)
+        y = torch.zeros(B, OUT, device=dev)
+        outs = []
+        with Images(hip, x=xd, dy=dyd) as im:
+            im.convert("x", "dy")
+            for rep in range(4):
+                dw = torch.from_numpy(dw0).to(dev)
+                flags = capi.LINEAR_ONLY_DW | capi.LINEAR_DY_PREMASKED
+                hip.call("ffh_linear_bwd_ex", xd, IN, None, IN, y, OUT, dyd, OUT, wd, dw, None, IN, OUT, B, capi.AC_MODE_RELU, flags, None, None)
+                route = hip.lib.ffh_linear_last_route(hip.ctx).decode()
+                assert "x3_dma_256x256" in route and "|slots" in route, route
+                torch.cuda.synchronize()
+                outs.append(dw.cpu().numpy())
+        for o in outs[1:]:
+            assert o.tobytes() == outs[0].tobytes(), f"{B}x{IN}->{OUT}: two launches of the slots form differ"
+        exact = dw0.astype(np.float64) + dy.astype(np.float64).T @ x.astype(np.float64)
+        mass = np.abs(dw0).astype(np.float64) + np.abs(dy).astype(np.float64).T @ np.abs(x).astype(np.float64)
+        assert np.all(np.abs(outs[0] - exact) <= 1e-5 * mass + 1e-6)
+
+
+@pytest.mark.gpu
 def test_x3_dma_declines_what_it_cannot_serve_and_the_fallback_keeps_the_image(hip_x3, oracle):
     """Shapes the LDS-DMA form does not take (too few tiles, a reduction depth that is not a multiple of 32, an operand that does not start a
     group): the split-in-kernel form runs, the result meets the same bound, and the registered image of y is still the image of what was
