@@ -197,7 +197,8 @@ int         ffh_convert_f32_to_bf16(ffh_ctx* ctx, void* dst_bf16, const float* s
  *   a wide Linear GEMM takes BOTH operands from their images when both lie in registered regions, start a 32-element group and have leading
  *   dimensions that are multiples of 32 (reduction depth a multiple of 32); otherwise it splits in the kernel as before.
  * Same arithmetic either way (the six products per 32-deep k-step in the same order, fp32 accumulation): a forward / data-gradient result is
- * BIT-identical with and without images; weight gradients differ in the order of their split-K atomics only.  Validity is the caller's
+ * BIT-identical with and without images; weight gradients differ in the order of their split-K atomics only (and not even that
+ * where the k-slices fit one round of workgroups on a stream with reserved scratch: they then meet through slots in slice order).  Validity is the caller's
  * contract, exactly as for the bf16 twins. */
 #define FFH_BF16X3_IMAGE_BYTES(fp32_bytes) ((((size_t)(fp32_bytes) + 127) / 128) * 192)
 int         ffh_ctx_bf16x3_mirror_set(ffh_ctx* ctx, const void* fp32_base, size_t fp32_bytes, void* planes);
@@ -220,7 +221,8 @@ int         ffh_ctx_set_deterministic(ffh_ctx* ctx, int on);
  * summation-order bound).  Returns FFH_ERR_BAD_ARG for ncus < 0 or >= the device's CU count. */
 int         ffh_ctx_set_dw_cu_reserve(ffh_ctx* ctx, int ncus);
 /* Scratch the library owns for launches on stream `s` (ABI 12): the partial-tile slots + arrival counters of the stream-K forms with
- * fix-up (csrc/linear_sk.hip) and the partial rows of the narrow-layer backward (csrc/linear.hip) -- ~36 MB.  THE one place they are
+ * fix-up (csrc/linear_sk.hip), the partial rows of the narrow-layer backward (csrc/linear.hip) and (round 6) 512 slots of 256 x 256 floats for the
+ * k-slices of the bf16-pipe weight gradients (csrc/linear_x3_dma.hip, linear_bf16_dma.hip) -- ~170 MB.  THE one place they are
  * allocated: compute entry points never allocate (top of this file); a launch on a stream without scratch runs the other forms of the
  * same layers (same results to the usual bound; ffh_linear_last_route shows it).  Call it once per stream that runs Linear layers,
  * outside any capture; idempotent.  Released by ffh_stream_destroy(s) / ffh_ctx_destroy; at most FFH_MAX_SCRATCH_STREAMS streams hold
