@@ -265,9 +265,23 @@ int transpose_launch(ffh_ctx* c, float* dst, const float* src, int nd, const int
   return FFH_OK;
 }
 
+// the optimizers keep the mirrors of the weights they write (ffh_ctx_bf16_mirror_set / ffh_ctx_bf16x3_mirror_set) in the same pass, where the
+// launch is the four-elements-per-lane form: the bf16 twin of elements 4 i .. 4 i + 3, or their three-plane image (element e0 + 4 i of the region).
+// The same roundings as ffh_convert_f32_to_bf16 / _bf16x3 (same device helpers): the same bits as a conversion pass behind the update.
+__device__ __forceinline__ void store_mirrors(const float4 v, unsigned short* twin, char* planes, int64_t e0, int64_t i) {
+  if (twin) *reinterpret_cast<uint2*>(twin + 4 * i) = ffh_pack_bf16x4(v);
+  if (planes) {
+    uint2 p1, p2, p3;
+    ffh_split_bf16x3(v, p1, p2, p3);
+    char* d = planes + ffh_i32_off(e0 + 4 * i);
+    *reinterpret_cast<uint2*>(d) = p1; *reinterpret_cast<uint2*>(d + 64) = p2; *reinterpret_cast<uint2*>(d + 128) = p3;
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ v,
-                                                  int64_t n, float lr, float wd, float mom, int nesterov, int zero_grad) {
+                                                  int64_t n, float lr, float wd, float mom, int nesterov, int zero_grad,
+                                                  unsigned short* __restrict__ twin, char* __restrict__ planes, int64_t e0) {
   ffh_kernel_prio();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t nv = n / VEC;
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* 
     }
     if (VEC == 4) {
       reinterpret_cast<float4*>(w)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      store_mirrors(make_float4(wv[0], wv[1], wv[2], wv[3]), twin, planes, e0, i);
       if (mom > 0.f) reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
       if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
@@ -306,7 +321,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* 
 // adam_update [ref: src/runtime/optimizer_kernel.cu:206-226]; canonical rounding as stated in ff_hip.h
 template <int VEC>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   int64_t n, float alpha_t, float b1, float b2, float wd, float eps, int zero_grad) {
+                                                   int64_t n, float alpha_t, float b1, float b2, float wd, float eps, int zero_grad,
+                                                   unsigned short* __restrict__ twin, char* __restrict__ planes, int64_t e0) {
   ffh_kernel_prio();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t nv = n / VEC;
@@ -341,6 +357,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float*
     }
     if (VEC == 4) {
       reinterpret_cast<float4*>(w)[i] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      store_mirrors(make_float4(wv[0], wv[1], wv[2], wv[3]), twin, planes, e0, i);
       reinterpret_cast<float4*>(m)[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
       reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
       if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -484,11 +501,17 @@ int ffh_sgd_update_ex(ffh_ctx* c, float* w, float* g, float* v, int64_t n, float
   if (n == 0) return FFH_OK;
   const int zg = (flags & FFH_OPT_ZERO_GRAD) ? 1 : 0;
   const bool vec = al16(w) && al16(g) && (!(mom > 0.f) || al16(v)) && (n % 4 == 0);
-  if (vec) hipLaunchKernelGGL((sgd_kernel<4>), dim3(ffh_grid(n / 4, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov, zg);
-  else hipLaunchKernelGGL((sgd_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov, zg);
+  // the weights' mirrors: the bf16 twin (tensor-op mode) / the three-plane image (split mode) -- in the same pass where the launch is the vector form
+  // (round 6: as a conversion launch behind the update it ran beside the next gather: 99 us in the split-mode step for 10 us of work), else by conversion
+  unsigned short* tw = ffh_mirror_of(c, w, (size_t)n * 4);
+  int col0 = 0;
+  char* pl = const_cast<char*>(ffh_planes_of(c, w, (size_t)n * 4, &col0));
+  const bool fused = vec && (!tw || ((uintptr_t)tw & 7) == 0) && (!pl || col0 % 4 == 0);
+  if (vec) hipLaunchKernelGGL((sgd_kernel<4>), dim3(ffh_grid(n / 4, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov, zg, fused ? tw : nullptr, fused ? pl : nullptr, (int64_t)col0);
+  else hipLaunchKernelGGL((sgd_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, v, n, lr, wd, mom, nesterov, zg, (unsigned short*)nullptr, (char*)nullptr, (int64_t)0);
   FFH_LAUNCH_CHECK(c, "sgd_kernel");
-  if (unsigned short* tw = ffh_mirror_of(c, w, (size_t)n * 4)) return ffh_convert_f32_to_bf16(c, tw, w, n, s);   // tensor-op mode: the weights' bf16 twin
-  { int col0; if (ffh_planes_of(c, w, (size_t)n * 4, &col0)) return ffh_convert_f32_to_bf16x3(c, w, 1, n, n, s); }      // split mode: their three-plane image
+  if (!fused && tw) return ffh_convert_f32_to_bf16(c, tw, w, n, s);
+  if (!fused && pl) return ffh_convert_f32_to_bf16x3(c, w, 1, n, n, s);
   return FFH_OK;
 }
 
@@ -503,11 +526,15 @@ int ffh_adam_update(ffh_ctx* c, float* w, float* g, float* m, float* v, int64_t 
   if (n == 0) return FFH_OK;
   const int zg = (flags & FFH_OPT_ZERO_GRAD) ? 1 : 0;
   const bool vec = al16(w) && al16(g) && al16(m) && al16(v) && (n % 4 == 0);
-  if (vec) hipLaunchKernelGGL((adam_kernel<4>), dim3(ffh_grid(n / 4, 256)), dim3(256), 0, as_stream(s), w, g, m, v, n, alpha_t, b1, b2, wd, eps, zg);
-  else hipLaunchKernelGGL((adam_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, m, v, n, alpha_t, b1, b2, wd, eps, zg);
+  unsigned short* tw = ffh_mirror_of(c, w, (size_t)n * 4);      // (the mirrors: as in ffh_sgd_update_ex)
+  int col0 = 0;
+  char* pl = const_cast<char*>(ffh_planes_of(c, w, (size_t)n * 4, &col0));
+  const bool fused = vec && (!tw || ((uintptr_t)tw & 7) == 0) && (!pl || col0 % 4 == 0);
+  if (vec) hipLaunchKernelGGL((adam_kernel<4>), dim3(ffh_grid(n / 4, 256)), dim3(256), 0, as_stream(s), w, g, m, v, n, alpha_t, b1, b2, wd, eps, zg, fused ? tw : nullptr, fused ? pl : nullptr, (int64_t)col0);
+  else hipLaunchKernelGGL((adam_kernel<1>), dim3(ffh_grid(n, 256)), dim3(256), 0, as_stream(s), w, g, m, v, n, alpha_t, b1, b2, wd, eps, zg, (unsigned short*)nullptr, (char*)nullptr, (int64_t)0);
   FFH_LAUNCH_CHECK(c, "adam_kernel");
-  if (unsigned short* tw = ffh_mirror_of(c, w, (size_t)n * 4)) return ffh_convert_f32_to_bf16(c, tw, w, n, s);
-  { int col0; if (ffh_planes_of(c, w, (size_t)n * 4, &col0)) return ffh_convert_f32_to_bf16x3(c, w, 1, n, n, s); }
+  if (!fused && tw) return ffh_convert_f32_to_bf16(c, tw, w, n, s);
+  if (!fused && pl) return ffh_convert_f32_to_bf16x3(c, w, 1, n, n, s);
   return FFH_OK;
 }
 
