@@ -389,12 +389,18 @@ enum : uint32_t { kMetaNone = 0, kMetaFirst = 1, kMetaCont = 2 };
 // of the kernels: 0 = plain SGD (the fused update of SURVEY 8a-4, unchanged instructions), 1 = sgd_update with weight decay /
 // momentum / nesterov, 2 = adam_update -- the element arithmetic of sgd_kernel / adam_kernel (elementwise.hip), statement by
 // statement, so a row hit by one gradient row ends up with the bits the dense optimizer gives that row.
-struct OptP { float lr, wd, mom, b1, b2, eps, omb1, omb2; int nesterov; };
+struct OptP { float lr, wd, mom, b1, b2, eps, omb1, omb2; int nesterov; int64_t nt_rows; };   // nt_rows: tables of more rows have their rows read and written nontemporal (lab)
 
 template <int VEC, int OPT>
-__device__ __forceinline__ void apply_row(const OptP& o, float* wrow, float* s0row, float* s1row, int c, const float (&acc)[VEC]) {
+__device__ __forceinline__ void apply_row(const OptP& o, float* wrow, float* s0row, float* s1row, int c, const float (&acc)[VEC], const bool nt = false) {
   if (OPT == 0) {
-    if (VEC == 4) {
+    if (VEC == 4 && nt) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4 w = __builtin_nontemporal_load(reinterpret_cast<const f4*>(wrow) + c);
+      w.x = __fmaf_rn(-o.lr, acc[0], w.x); w.y = __fmaf_rn(-o.lr, acc[1], w.y);
+      w.z = __fmaf_rn(-o.lr, acc[2], w.z); w.w = __fmaf_rn(-o.lr, acc[3], w.w);
+      __builtin_nontemporal_store(w, reinterpret_cast<f4*>(wrow) + c);
+    } else if (VEC == 4) {
       float4 w = reinterpret_cast<float4*>(wrow)[c];
       w.x = __fmaf_rn(-o.lr, acc[0], w.x); w.y = __fmaf_rn(-o.lr, acc[1], w.y);
       w.z = __fmaf_rn(-o.lr, acc[2], w.z); w.w = __fmaf_rn(-o.lr, acc[3], w.w);
@@ -658,7 +664,7 @@ __device__ __forceinline__ void reduce_tile_body(const ffh_emb_table& tb, const 
           for (int v = 0; v < VEC; v++) acc[v] = acc[v] + v0[v];
         }
         if (single) {
-          apply_row<VEC, OPT>(op, wrow, OPT ? st0 + (int64_t)key * D : nullptr, OPT == 2 ? st1 + (int64_t)key * D : nullptr, c, acc);
+          apply_row<VEC, OPT>(op, wrow, OPT ? st0 + (int64_t)key * D : nullptr, OPT == 2 ? st1 + (int64_t)key * D : nullptr, c, acc, tb.num_entries > op.nt_rows);
         } else {
           xwg_store_row<VEC, AGENT>(prow, c, acc);
         }
@@ -760,7 +766,7 @@ __device__ __forceinline__ void fold_table_body(const ffh_emb_table& tb, const f
         for (int v = 0; v < VEC; v++) acc[v] = acc[v] + v0[v];
       }
       if (complete) {
-        apply_row<VEC, OPT>(op, wrow, OPT ? st0 + (int64_t)m.y * D : nullptr, OPT == 2 ? st1 + (int64_t)m.y * D : nullptr, c, acc);
+        apply_row<VEC, OPT>(op, wrow, OPT ? st0 + (int64_t)m.y * D : nullptr, OPT == 2 ? st1 + (int64_t)m.y * D : nullptr, c, acc, tb.num_entries > op.nt_rows);
       } else {
         xwg_store_row<VEC, AGENT>(orow, c, acc);
       }
@@ -1531,6 +1537,7 @@ static int emb_bwd_phases(ffh_ctx* c, const ffh_emb_table* tables, int nt, int L
   if (rc) return rc;
   OptP op{};
   op.lr = lr;
+  op.nt_rows = FFH_LAB_INT("FFH_EMB_APPLY_NT_MB", 1 << 30) * (int64_t)(1 << 20) / ((int64_t)D * 4);      // lab A/B: default off
   int kind = FFH_SPARSE_OPT_SGD;
   if (opt && do_apply) {
     kind = opt->kind;
